@@ -1,0 +1,190 @@
+/*
+ * t2v.h -- C ABI of libt2v_hip.so: the MI355X (gfx950) frame-synthesis hot path of Text2Video.
+ *
+ * This is the drop-in boundary "B2" of SURVEY.md section 8(b).  The reference reaches its device
+ * kernels through torch-0.4.1's THCUNN C ABI; each entry point below names the reference
+ * interface it replaces ($SP = /root/reference/venv_vid2vid/lib/python3.7/site-packages).
+ *
+ * Conventions
+ *   - plain C: pointers + sizes, no torch types.  All tensor pointers are DEVICE pointers to
+ *     fp32 NHWC data (channels innermost) unless stated otherwise.  "cs" arguments are the
+ *     channel *storage* stride (a multiple of 4 >= the logical channel count; extra channels
+ *     must hold finite values and are ignored / written as zero).
+ *   - ownership: the caller allocates every device buffer (tensors, packed weights, workspace)
+ *     and keeps it alive until the stream has drained.  The library allocates nothing after
+ *     t2v_create() (which owns one 4 KiB zero page).
+ *   - asynchronous: work is enqueued on the hipStream_t passed as `void* stream`
+ *     (torch.cuda.current_stream().cuda_stream on the Python side); nothing synchronises.
+ *   - errors: every call returns T2V_OK (0) or a negative t2v_status; t2v_last_error() returns a
+ *     thread-local message.  Nothing throws across the ABI.  (THCUNN raised THError -> Python
+ *     RuntimeError; the Python binding re-raises RuntimeError from the status code.)
+ *   - threading: a t2v_ctx is bound to one device; use one ctx per host thread.
+ */
+#ifndef T2V_H_
+#define T2V_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define T2V_ABI_VERSION 1
+
+typedef enum {
+    T2V_OK = 0,
+    T2V_ERR_INVALID = -1,   /* bad argument / unsupported shape */
+    T2V_ERR_HIP = -2,       /* a HIP runtime call failed */
+    T2V_ERR_WORKSPACE = -3  /* workspace too small */
+} t2v_status;
+
+enum { T2V_PAD_ZERO = 0, T2V_PAD_REFLECT = 1 };
+/* epilogue activations fused into the conv (Tanh_updateOutput THCUNN.h:1177,
+ * Sigmoid_updateOutput :1098, flow x20 [SURVEY App. A.1]) */
+enum { T2V_ACT_NONE = 0, T2V_ACT_TANH = 1, T2V_ACT_FLOW_W = 2 /* ch0,1: x*20 ; ch2: sigmoid */ };
+
+typedef struct t2v_ctx t2v_ctx;
+
+int t2v_abi_version(void);
+const char* t2v_last_error(void);
+int t2v_create(t2v_ctx** out, int device);
+int t2v_destroy(t2v_ctx* ctx);
+
+/* ------------------------------------------------------------------------------------------
+ * Convolution.  Replaces SpatialReflectionPadding_updateOutput (THCUNN.h:952) +
+ * SpatialConvolutionMM_updateOutput (THCUNN.h:664) [Conv2d.forward $SP/torch/nn/modules/conv.py:
+ * 299-300] and SpatialFullDilatedConvolution_updateOutput (THCUNN.h:794) [ConvTranspose2d.forward
+ * conv.py:687-691].  Reflection padding is resolved inside the kernel's tile loader.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int H, W;        /* input spatial size */
+    int Cin, Cout;   /* logical channels */
+    int kH, kW;      /* kernel */
+    int stride;      /* 1 or 2 */
+    int pad;         /* padding on each side (reflect: the ReflectionPad2d amount) */
+    int pad_mode;    /* T2V_PAD_ZERO | T2V_PAD_REFLECT */
+    int transposed;  /* 1: ConvTranspose2d(k=3, stride=2, padding=1, output_padding=1) */
+    int act;         /* T2V_ACT_* applied after bias */
+    float act_scale; /* T2V_ACT_FLOW_W: multiplier of the two flow channels (20 * 2^scale) */
+} t2v_conv_desc;
+
+/* output spatial size */
+int t2v_conv_out_dims(const t2v_conv_desc* d, int* Hout, int* Wout);
+/* number of floats of the packed weight buffer (includes all zero padding) */
+size_t t2v_conv_packed_weight_floats(const t2v_conv_desc* d, int x_cs);
+/* repack a torch-layout weight ([Cout,Cin,kH,kW], or [Cin,Cout,3,3] when transposed -- conv.py:
+ * 28-33) that already lives on the device into the kernel's K-contiguous layout. */
+int t2v_conv_pack_weight(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, int x_cs,
+                         const float* w_torch_dev, float* packed_dev);
+/* number of floats of the per-tile instance-norm partial-statistics buffer for this conv */
+size_t t2v_conv_stats_floats(const t2v_conv_desc* d);
+/* y = act(conv(x) + bias).  If stats_partial != NULL the epilogue also emits per-(tile,channel)
+ * (mean, M2) partials over the block's pixels for the fused instance norm. */
+int t2v_conv2d_forward(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, const float* x, int x_cs,
+                       const float* w_packed, const float* bias, float* y, int y_cs,
+                       float* stats_partial);
+
+/* ------------------------------------------------------------------------------------------
+ * Instance norm (+affine) + ReLU + residual.  Replaces BatchNormalization_updateOutput(train)
+ * (THCUNN.h:33) as reached from F.instance_norm ($SP/torch/nn/functional.py:1258-1301) and
+ * Threshold_updateOutput (THCUNN.h:1328).  Biased variance, eps inside the sqrt.
+ *   finalize: combines the conv epilogue's partials (Chan et al.) -> mean_rstd[C][2]
+ *   apply:    y = [relu]((x-mean)*rstd*gamma+beta) + res1 + res2   (gamma/beta/res* nullable,
+ *             y may alias x)
+ * ------------------------------------------------------------------------------------------ */
+int t2v_instance_norm_finalize(t2v_ctx* ctx, void* stream, const t2v_conv_desc* producer,
+                               const float* stats_partial, float eps, float* mean_rstd);
+int t2v_instance_norm_apply(t2v_ctx* ctx, void* stream, const float* x, const float* mean_rstd,
+                            const float* gamma, const float* beta, const float* res1,
+                            const float* res2, float* y, long npix, int C, int relu);
+
+/* ------------------------------------------------------------------------------------------
+ * Flow-warp compositor.  Replaces SpatialGridSamplerBilinear_updateOutput (THCUNN.h:1048; F.
+ * grid_sample functional.py:2046-2093, corner aligned, border padding) plus the blend
+ * out = raw*w + warp(prev, flow)*(1-w) [SURVEY App. A.1].  fw = [H,W,3] (flow_x, flow_y in
+ * pixels, weight).  prev: NHWC with storage stride prev_cs, the 3 channels starting at prev_c0.
+ * warp_out (nullable) receives the warped image.
+ * ------------------------------------------------------------------------------------------ */
+int t2v_flow_warp_composite(t2v_ctx* ctx, void* stream, const float* raw, const float* fw,
+                            const float* prev, int prev_cs, int prev_c0, float* out, float* warp_out,
+                            int H, int W);
+
+/* AvgPool2d(3, stride 2, padding 1, count_include_pad=False) -- SpatialAveragePooling_
+ * updateOutput (THCUNN.h:579; pooling.py:536-543).  NHWC, C % 4 == 0 not required. */
+int t2v_avgpool3x3s2(t2v_ctx* ctx, void* stream, const float* x, float* y, int H, int W, int C);
+
+/* layout / dtype plumbing on the device */
+int t2v_nchw_to_nhwc(t2v_ctx* ctx, void* stream, const float* src, float* dst, int C, int H, int W, int dst_cs);
+int t2v_nhwc_to_nchw(t2v_ctx* ctx, void* stream, const float* src, float* dst, int C, int H, int W, int src_cs);
+/* ToTensor + Normalize(.5,.5) ($SP/torchvision/transforms/functional.py:38-60,206-208) of a
+ * uint8 HWC(3) pose map into channels [c0,c0+3) of an NHWC fp32 buffer */
+int t2v_pose_u8_to_f32(t2v_ctx* ctx, void* stream, const uint8_t* src_hwc3, float* dst, long npix, int dst_cs, int c0);
+/* util.tensor2im [SURVEY 3.2]: uint8((x+1)/2*255 clipped), same layout */
+int t2v_tensor2im_u8(t2v_ctx* ctx, void* stream, const float* x, uint8_t* y, long n);
+int t2v_copy_channels(t2v_ctx* ctx, void* stream, const float* src, int src_cs, int src_c0, float* dst,
+                      int dst_cs, int dst_c0, int nc, long npix);
+
+/* ------------------------------------------------------------------------------------------
+ * Whole-frame generator.  Replaces CompositeGenerator.forward / CompositeLocalGenerator.forward
+ * [SURVEY App. A.1/A.2] as called by Vid2VidModelG.generate_frame_infer.
+ *
+ * Layer order of `layers` (conv layers only; gamma/beta are the affine params of the norm that
+ * follows the conv, NULL for InstanceNorm(affine=False) and for the heads):
+ *   global (is_local=0):
+ *     down_seg: c7, d x n_downsample, RB x (n_blocks - n_blocks/2) [2 convs each]
+ *     down_img: same
+ *     res_img : RB x (n_blocks/2)        up_img: u x n_downsample       final_img: c7
+ *     if !no_flow: res_flow RB x (n_blocks/2), up_flow u x n_downsample,
+ *                  final_flow_w: ONE c7 with 3 outputs = cat(model_final_flow, model_final_w)
+ *   local (is_local=1, ngf = ngf of this scale):
+ *     down_seg: c7, d      down_img: c7, d
+ *     up_img: RB x n_blocks, u         final_img: c7
+ *     if !no_flow: up_flow: RB x n_blocks, u ; final_flow_w
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int H, W;           /* multiples of 2^n_downsample */
+    int input_nc;       /* pose channels x n_frames_G (9)   -> storage round_up4 (12) */
+    int prev_nc;        /* (n_frames_G-1) x output_nc (6)   -> storage round_up4 (8)  */
+    int output_nc;      /* 3 */
+    int ngf;
+    int n_downsample;
+    int n_blocks;
+    int no_flow;
+    int norm_affine;    /* 1: BatchNorm2d(affine) in train mode, N=1  ==  IN + gamma/beta */
+    int is_local;       /* 0: CompositeGenerator, 1: CompositeLocalGenerator */
+    float flow_multiplier; /* 20 * 2^scale */
+    float eps;          /* 1e-5 */
+} t2v_gen_desc;
+
+typedef struct {
+    const float* w;      /* packed by t2v_conv_pack_weight */
+    const float* bias;   /* [Cout] */
+    const float* gamma;  /* [Cout] or NULL */
+    const float* beta;   /* [Cout] or NULL */
+} t2v_layer;
+
+typedef struct {
+    const float* pose;              /* [H,W,round_up4(input_nc)] */
+    const float* prev;              /* [H,W,round_up4(prev_nc)]  */
+    const float* coarse_img_feat;   /* local only: [H/2,W/2,2*ngf] */
+    const float* coarse_flow_feat;  /* local only, !no_flow */
+    int use_raw_only;
+    float* out;        /* [H,W,4] final frame, channels 0..2 (channel 3 = 0) */
+    float* raw;        /* nullable [H,W,4] img_raw */
+    float* flow_w;     /* nullable [H,W,4] flow_x, flow_y, weight */
+    float* img_feat;   /* nullable [H,W,ngf] */
+    float* flow_feat;  /* nullable [H,W,ngf] */
+} t2v_gen_io;
+
+int t2v_generator_num_layers(const t2v_gen_desc* d);
+/* conv descriptor of layer i (what to pack weights with) and its input storage stride */
+int t2v_generator_layer_desc(const t2v_gen_desc* d, int i, t2v_conv_desc* out, int* x_cs);
+size_t t2v_generator_workspace_bytes(const t2v_gen_desc* d);
+int t2v_generator_forward(t2v_ctx* ctx, void* stream, const t2v_gen_desc* d, const t2v_layer* layers,
+                          int n_layers, const t2v_gen_io* io, void* workspace, size_t ws_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* T2V_H_ */

@@ -1,0 +1,218 @@
+"""GPU parity tests, operator level: every HIP kernel behind the C ABI vs a plain torch fp32 CPU
+reference of the same op (the semantics pinned in oracle/generator_ref.py's header).
+Tolerances: fp32 MFMA is an exact fp32 fma chain, only the summation order differs from the
+CPU reference => |delta| <= 1e-4 absolute on O(1) activations (north_star: 1e-3 end to end)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU test without a GPU"
+    return torch.device("cuda:0")
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    rng = np.random.default_rng(seed)
+    return torch.from_numpy((rng.standard_normal(shape) * scale).astype(np.float32))
+
+
+def _to_nhwc(x_chw, cs=None):
+    from text2video_amd import ops
+    return ops.nchw_to_nhwc(x_chw.to(_dev()).contiguous(), cs)
+
+
+def _from_nhwc(y_hwc, C):
+    return y_hwc[..., :C].permute(2, 0, 1).cpu()
+
+
+def _ref_conv(x, w, b, k, stride, pad, pad_mode, transposed):
+    x = x.unsqueeze(0)
+    if transposed:
+        return F.conv_transpose2d(x, w, b, stride=2, padding=1, output_padding=1)[0]
+    if pad_mode == 1 and pad > 0:
+        x = F.pad(x, (pad, pad, pad, pad), mode="reflect")
+        pad = 0
+    return F.conv2d(x, w, b, stride=stride, padding=pad)[0]
+
+
+CONV_CASES = [
+    # name, H, W, Cin, Cout, k, stride, pad, pad_mode(1=reflect), transposed
+    ("rb3x3_fast", 16, 16, 64, 128, 3, 1, 1, 1, False),
+    ("rb3x3_ragged_M", 20, 12, 32, 128, 3, 1, 1, 1, False),
+    ("rb3x3_Ntail160", 8, 8, 32, 160, 3, 1, 1, 1, False),
+    ("rb3x3_Cout8", 8, 8, 32, 8, 3, 1, 1, 1, False),
+    ("stem7x7_cin9", 24, 24, 9, 128, 7, 1, 3, 1, False),
+    ("stem7x7_cin6", 16, 20, 6, 16, 7, 1, 3, 1, False),
+    ("down3x3_s2", 32, 32, 32, 64, 3, 2, 1, 0, False),
+    ("down3x3_s2_narrow", 16, 24, 8, 16, 3, 2, 1, 0, False),
+    ("convT_fast", 8, 8, 64, 32, 3, 2, 1, 0, True),
+    ("convT_narrow", 8, 12, 16, 8, 3, 2, 1, 0, True),
+    ("convT_ragged", 10, 6, 32, 32, 3, 2, 1, 0, True),
+    ("disc4x4_s2_p2", 16, 16, 8, 64, 4, 2, 2, 0, False),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv_with_norm_stats(case):
+    from text2video_amd import ops
+    name, H, W, Cin, Cout, k, stride, pad, pad_mode, transposed = case
+    x = _rand(Cin, H, W, seed=1)
+    w = _rand(*((Cin, Cout, k, k) if transposed else (Cout, Cin, k, k)), seed=2, scale=0.1)
+    b = _rand(Cout, seed=3, scale=0.1)
+    ref = _ref_conv(x, w, b, k, stride, pad, pad_mode, transposed)
+    desc = ops.conv_desc(H, W, Cin, Cout, k, stride, pad, pad_mode, transposed)
+    xs = _to_nhwc(x)
+    pw = ops.pack_conv_weight(w.to(_dev()), desc, xs.shape[-1])
+    bd = b.to(_dev())
+    # plain conv
+    y = ops.conv2d(xs, pw, bd, desc)
+    got = _from_nhwc(y, Cout)
+    assert got.shape == ref.shape
+    assert (got - ref).abs().max().item() <= TOL * max(1.0, ref.abs().max().item())
+    if y.shape[-1] > Cout:  # padded output channels are written as zeros
+        assert y[..., Cout:].abs().max().item() == 0.0
+    if Cout % 4 == 0 and Cout > 16:
+        # conv + fused instance-norm statistics + apply(ReLU)
+        ref_n = F.relu(F.instance_norm(ref.unsqueeze(0), eps=1e-5))[0]
+        yn = ops.conv_norm_act(xs, pw, bd, desc, relu=True)
+        assert (_from_nhwc(yn, Cout) - ref_n).abs().max().item() <= 2e-4
+
+
+@pytest.mark.parametrize("act", ["tanh", "flow_w"])
+def test_head_conv_small_cout(act):
+    from text2video_amd import ops
+    H, W, Cin = 24, 20, 32
+    x = _rand(Cin, H, W, seed=4)
+    w = _rand(3, Cin, 7, 7, seed=5, scale=0.05)
+    b = _rand(3, seed=6, scale=0.1)
+    ref = _ref_conv(x, w, b, 7, 1, 3, 1, False)
+    if act == "tanh":
+        ref = torch.tanh(ref)
+        desc = ops.conv_desc(H, W, Cin, 3, 7, 1, 3, ops.PAD_REFLECT, False, ops.ACT_TANH)
+    else:
+        ref = torch.cat([ref[:2] * 40.0, torch.sigmoid(ref[2:3])], 0)
+        desc = ops.conv_desc(H, W, Cin, 3, 7, 1, 3, ops.PAD_REFLECT, False, ops.ACT_FLOW_W, 40.0)
+    xs = _to_nhwc(x)
+    pw = ops.pack_conv_weight(w.to(_dev()), desc, Cin)
+    y = ops.conv2d(xs, pw, b.to(_dev()), desc, y_cs=4)
+    assert (_from_nhwc(y, 3) - ref).abs().max().item() <= TOL * max(1.0, ref.abs().max().item())
+    assert y[..., 3].abs().max().item() == 0.0
+
+
+def test_instance_norm_affine_residual_matches_trainmode_batchnorm():
+    """BN(train, N=1) == IN + affine; apply adds two residuals after the ReLU-less norm."""
+    from text2video_amd import ops
+    H, W, Cin, C = 12, 12, 32, 64
+    x = _rand(Cin, H, W, seed=7)
+    w = _rand(C, Cin, 3, 3, seed=8, scale=0.1)
+    b = _rand(C, seed=9)
+    g = 1.0 + _rand(C, seed=10, scale=0.1)
+    bt = _rand(C, seed=11, scale=0.1)
+    r1 = _rand(C, H, W, seed=12)
+    r2 = _rand(C, H, W, seed=13)
+    conv = _ref_conv(x, w, b, 3, 1, 1, 1, False)
+    bn = torch.nn.BatchNorm2d(C, affine=True)
+    bn.train()
+    with torch.no_grad():
+        bn.weight.copy_(g)
+        bn.bias.copy_(bt)
+        ref = bn(conv.unsqueeze(0))[0] + r1 + r2
+    desc = ops.conv_desc(H, W, Cin, C, 3, 1, 1, ops.PAD_REFLECT)
+    xs = _to_nhwc(x)
+    pw = ops.pack_conv_weight(w.to(_dev()), desc, Cin)
+    y = ops.conv_norm_act(xs, pw, b.to(_dev()), desc, gamma=g.to(_dev()), beta=bt.to(_dev()), relu=False,
+                          res1=_to_nhwc(r1), res2=_to_nhwc(r2))
+    assert (_from_nhwc(y, C) - ref).abs().max().item() <= 2e-4
+
+
+def test_instance_norm_large_mean_is_stable():
+    """Chan-merged two-pass statistics: a large per-channel offset must not destroy the variance."""
+    from text2video_amd import ops
+    H, W, Cin, C = 32, 32, 32, 64
+    x = _rand(Cin, H, W, seed=14)
+    w = _rand(C, Cin, 3, 3, seed=15, scale=0.05)
+    b = torch.full((C,), 300.0)
+    conv = _ref_conv(x.double(), w.double(), b.double(), 3, 1, 1, 1, False)
+    ref = F.instance_norm(conv.unsqueeze(0), eps=1e-5)[0].float()
+    desc = ops.conv_desc(H, W, Cin, C, 3, 1, 1, ops.PAD_REFLECT)
+    xs = _to_nhwc(x)
+    pw = ops.pack_conv_weight(w.to(_dev()), desc, Cin)
+    y = ops.conv_norm_act(xs, pw, b.to(_dev()), desc, relu=False)
+    assert (_from_nhwc(y, C) - ref).abs().max().item() <= 2e-3  # fp32 conv output at |x|~300 carries ~3e-5 abs error
+
+
+def test_flow_warp_composite_vs_grid_sample():
+    from oracle.generator_ref import resample
+    from text2video_amd import ops
+    H, W = 40, 56
+    prev = _rand(6, H, W, seed=16).clamp(-1, 1)
+    raw = torch.tanh(_rand(3, H, W, seed=17))
+    flow = _rand(2, H, W, seed=18, scale=6.0)   # large flows exercise the border clamp
+    wgt = torch.sigmoid(_rand(1, H, W, seed=19))
+    warp_ref = resample(prev[None, -3:], flow[None])[0]
+    ref = raw * wgt + warp_ref * (1 - wgt)
+    fw = _to_nhwc(torch.cat([flow, wgt], 0))
+    out, warp = ops.flow_warp_composite(_to_nhwc(raw), fw, _to_nhwc(prev), 3, want_warp=True)
+    assert (_from_nhwc(warp, 3) - warp_ref).abs().max().item() <= 1e-4
+    assert (_from_nhwc(out, 3) - ref).abs().max().item() <= 1e-4
+
+
+def test_flow_warp_identity_returns_input():
+    """Sanity anchor derivable from the reference: zero flow, corner aligned => warp(x) == x."""
+    from text2video_amd import ops
+    H, W = 17, 33
+    prev = _rand(6, H, W, seed=20)
+    z = torch.zeros(3, H, W)
+    out, warp = ops.flow_warp_composite(_to_nhwc(z), _to_nhwc(z), _to_nhwc(prev), 3, want_warp=True)
+    assert (_from_nhwc(warp, 3) - prev[-3:]).abs().max().item() <= 2e-5
+
+
+def test_avgpool_count_include_pad_false():
+    from text2video_amd import ops
+    for (H, W, C) in [(16, 16, 12), (18, 14, 8), (7, 9, 3)]:
+        x = _rand(C, H, W, seed=21)
+        ref = F.avg_pool2d(x[None], 3, 2, 1, count_include_pad=False)[0]
+        y = ops.avgpool3x3s2(x.permute(1, 2, 0).contiguous().to(_dev()))
+        assert (y.permute(2, 0, 1).cpu() - ref).abs().max().item() <= 1e-6
+
+
+def test_pose_u8_and_tensor2im_roundtrip():
+    from text2video_amd import ops
+    rng = np.random.default_rng(22)
+    img = torch.from_numpy(rng.integers(0, 256, size=(20, 24, 3), dtype=np.uint8))
+    dst = torch.zeros(20, 24, 12, device=_dev())
+    ops.pose_u8_to_f32(img.to(_dev()), dst, 3)
+    ref = (img.float() / 255.0 - 0.5) / 0.5
+    assert (dst[..., 3:6].cpu() - ref).abs().max().item() == 0.0
+    assert dst[..., :3].abs().max().item() == 0.0 and dst[..., 6:].abs().max().item() == 0.0
+    u8 = ops.tensor2im_u8(dst[..., 3:6].contiguous()).cpu()
+    ref_u8 = ((ref + 1) / 2.0 * 255.0).clamp(0, 255).to(torch.uint8)
+    assert (u8.int() - ref_u8.int()).abs().max().item() == 0
+
+
+def test_fullsize_resblock_conv_1024():
+    """The kernel that is 84 % of the FLOPs at its real size: 1024->1024 3x3 reflect @64x64."""
+    from text2video_amd import ops
+    H = W = 64
+    C = 1024
+    x = _rand(C, H, W, seed=23)
+    w = _rand(C, C, 3, 3, seed=24, scale=0.02)
+    b = _rand(C, seed=25, scale=0.1)
+    torch.set_num_threads(max(1, torch.get_num_threads()))
+    ref = _ref_conv(x, w, b, 3, 1, 1, 1, False)
+    desc = ops.conv_desc(H, W, C, C, 3, 1, 1, ops.PAD_REFLECT)
+    xs = _to_nhwc(x)
+    pw = ops.pack_conv_weight(w.to(_dev()), desc, C)
+    y = ops.conv2d(xs, pw, b.to(_dev()), desc)
+    err = (_from_nhwc(y, C) - ref).abs().max().item()
+    assert err <= 1e-4 * max(1.0, ref.abs().max().item()), err
+    # linearity (size-independent property): conv(2x) - bias == 2*(conv(x) - bias)
+    y2 = ops.conv2d(xs * 2, pw, b.to(_dev()), desc)
+    lin = ((y2 - b.to(_dev())) - 2 * (y - b.to(_dev()))).abs().max().item()
+    assert lin <= 1e-4

@@ -1,0 +1,128 @@
+"""ctypes binding of libt2v_hip.so (C ABI declared in include/t2v.h).
+
+The product path has NO fallback: if the shared library is missing or does not export the
+expected symbols, importing/using it raises.  Build it with `python __graft_entry__.py` or
+`make -C text2video_amd/csrc`.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_long, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libt2v_hip.so")
+
+T2V_OK = 0
+PAD_ZERO, PAD_REFLECT = 0, 1
+ACT_NONE, ACT_TANH, ACT_FLOW_W = 0, 1, 2
+ABI_VERSION = 1
+
+
+class ConvDesc(Structure):
+    """t2v_conv_desc (include/t2v.h)."""
+    _fields_ = [("H", c_int), ("W", c_int), ("Cin", c_int), ("Cout", c_int), ("kH", c_int), ("kW", c_int),
+                ("stride", c_int), ("pad", c_int), ("pad_mode", c_int), ("transposed", c_int), ("act", c_int),
+                ("act_scale", c_float)]
+
+
+class GenDesc(Structure):
+    """t2v_gen_desc (include/t2v.h)."""
+    _fields_ = [("H", c_int), ("W", c_int), ("input_nc", c_int), ("prev_nc", c_int), ("output_nc", c_int),
+                ("ngf", c_int), ("n_downsample", c_int), ("n_blocks", c_int), ("no_flow", c_int),
+                ("norm_affine", c_int), ("is_local", c_int), ("flow_multiplier", c_float), ("eps", c_float)]
+
+
+class Layer(Structure):
+    """t2v_layer."""
+    _fields_ = [("w", c_void_p), ("bias", c_void_p), ("gamma", c_void_p), ("beta", c_void_p)]
+
+
+class GenIO(Structure):
+    """t2v_gen_io."""
+    _fields_ = [("pose", c_void_p), ("prev", c_void_p), ("coarse_img_feat", c_void_p),
+                ("coarse_flow_feat", c_void_p), ("use_raw_only", c_int), ("out", c_void_p), ("raw", c_void_p),
+                ("flow_w", c_void_p), ("img_feat", c_void_p), ("flow_feat", c_void_p)]
+
+
+# name -> (restype, argtypes); every symbol include/t2v.h declares
+SIGNATURES = {
+    "t2v_abi_version": (c_int, []),
+    "t2v_last_error": (c_char_p, []),
+    "t2v_create": (c_int, [POINTER(c_void_p), c_int]),
+    "t2v_destroy": (c_int, [c_void_p]),
+    "t2v_conv_out_dims": (c_int, [POINTER(ConvDesc), POINTER(c_int), POINTER(c_int)]),
+    "t2v_conv_packed_weight_floats": (c_size_t, [POINTER(ConvDesc), c_int]),
+    "t2v_conv_pack_weight": (c_int, [c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_void_p, c_void_p]),
+    "t2v_conv_stats_floats": (c_size_t, [POINTER(ConvDesc)]),
+    "t2v_conv2d_forward": (c_int, [c_void_p, c_void_p, POINTER(ConvDesc), c_void_p, c_int, c_void_p, c_void_p,
+                                   c_void_p, c_int, c_void_p]),
+    "t2v_instance_norm_finalize": (c_int, [c_void_p, c_void_p, POINTER(ConvDesc), c_void_p, c_float, c_void_p]),
+    "t2v_instance_norm_apply": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_void_p, c_void_p, c_long, c_int, c_int]),
+    "t2v_flow_warp_composite": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
+                                        c_void_p, c_int, c_int]),
+    "t2v_avgpool3x3s2": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int]),
+    "t2v_nchw_to_nhwc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int]),
+    "t2v_nhwc_to_nchw": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int]),
+    "t2v_pose_u8_to_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_int]),
+    "t2v_tensor2im_u8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long]),
+    "t2v_copy_channels": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int,
+                                  c_long]),
+    "t2v_generator_num_layers": (c_int, [POINTER(GenDesc)]),
+    "t2v_generator_layer_desc": (c_int, [POINTER(GenDesc), c_int, POINTER(ConvDesc), POINTER(c_int)]),
+    "t2v_generator_workspace_bytes": (c_size_t, [POINTER(GenDesc)]),
+    "t2v_generator_forward": (c_int, [c_void_p, c_void_p, POINTER(GenDesc), POINTER(Layer), c_int, POINTER(GenIO),
+                                      c_void_p, c_size_t]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libt2v_hip.so and bind every declared symbol.  Raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "libt2v_hip.so not found at %s: the HIP extension is required (no CPU fallback). "
+            "Build it with `python __graft_entry__.py` or `make -C text2video_amd/csrc`." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.t2v_abi_version() != ABI_VERSION:
+        raise RuntimeError("libt2v_hip.so ABI %d != binding ABI %d" % (lib.t2v_abi_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(status, what=""):
+    if status != T2V_OK:
+        msg = load().t2v_last_error()
+        raise RuntimeError("t2v %s failed (status %d): %s" % (what, status, msg.decode() if msg else "?"))
+
+
+class Context:
+    """Owns a t2v_ctx bound to one device."""
+
+    def __init__(self, device=0):
+        self.lib = load()
+        self._h = c_void_p()
+        check(self.lib.t2v_create(ctypes.byref(self._h), int(device)), "t2v_create")
+        self.device = int(device)
+
+    @property
+    def handle(self):
+        return self._h
+
+    def close(self):
+        if self._h:
+            self.lib.t2v_destroy(self._h)
+            self._h = c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,263 @@
+// capi.hip -- extern "C" surface of libt2v_hip.so (declared in include/t2v.h) and the conv planner.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "conv_plan.h"
+
+namespace t2v {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+int build_conv_plan(const t2v_conv_desc* d, int x_cs, bool need_stats, ConvPlan* out) {
+    T2V_REQUIRE(d && out, "null conv descriptor");
+    T2V_REQUIRE(d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0, "conv: bad dims H=%d W=%d Cin=%d Cout=%d", d->H,
+                d->W, d->Cin, d->Cout);
+    T2V_REQUIRE(x_cs % 4 == 0 && x_cs >= d->Cin, "conv: input channel storage %d must be a multiple of 4 >= Cin=%d",
+                x_cs, d->Cin);
+    ConvPlan& pl = *out;
+    memset(&pl, 0, sizeof(pl));
+    ConvKParams& k = pl.kp;
+    // the small-Cout tile has no statistics epilogue; weights are always packed to the 128-row
+    // granule so either tile can read them
+    pl.tile = need_stats ? kTileL : conv_tile_for(d->Cout);
+    conv_tile_dims(pl.tile, &pl.BM, &pl.BN);
+    k.Hin = d->H;
+    k.Win = d->W;
+    k.Cin_s = x_cs;
+    k.Cout = d->Cout;
+    k.act = d->act;
+    k.act_scale = d->act_scale;
+    k.ntiles = (d->Cout + pl.BN - 1) / pl.BN;
+    pl.Cout_p = round_up(d->Cout, 128);
+    int Hm, Wm;
+    if (!d->transposed) {
+        T2V_REQUIRE(d->kH * d->kW <= kMaxTaps, "conv: kernel %dx%d too large", d->kH, d->kW);
+        T2V_REQUIRE(d->stride >= 1 && d->pad >= 0, "conv: bad stride/pad");
+        pl.Hout = (d->H + 2 * d->pad - d->kH) / d->stride + 1;
+        pl.Wout = (d->W + 2 * d->pad - d->kW) / d->stride + 1;
+        T2V_REQUIRE(pl.Hout > 0 && pl.Wout > 0, "conv: empty output");
+        if (d->pad_mode == T2V_PAD_REFLECT)
+            T2V_REQUIRE(d->pad < d->H && d->pad < d->W, "reflection pad %d needs H,W > pad (H=%d W=%d)", d->pad, d->H,
+                        d->W);
+        Hm = pl.Hout;
+        Wm = pl.Wout;
+        k.stride = d->stride;
+        k.ostride = 1;
+        k.pad_mode = d->pad_mode;
+        k.nphases = 1;
+        k.KW = d->kW;
+        k.pad = d->pad;
+        ConvPhase& ph = k.ph[0];
+        ph.ntaps = d->kH * d->kW;
+        ph.tap0 = 0;
+        ph.Kp = round_up(ph.ntaps * x_cs, kBK);
+        ph.nk = ph.Kp / kBK;
+        ph.w_off = 0;
+        ph.oy0 = ph.ox0 = 0;
+        for (int kh = 0; kh < d->kH; ++kh)
+            for (int kw = 0; kw < d->kW; ++kw) {
+                k.tdy[kh * d->kW + kw] = kh - d->pad;
+                k.tdx[kh * d->kW + kw] = kw - d->pad;
+            }
+        pl.wfloats = (size_t)pl.Cout_p * ph.Kp;
+    } else {
+        T2V_REQUIRE(d->kH == 3 && d->kW == 3 && d->stride == 2 && d->pad == 1,
+                    "transposed conv: only k=3, stride=2, padding=1, output_padding=1 is on the path");
+        pl.Hout = 2 * d->H;
+        pl.Wout = 2 * d->W;
+        Hm = d->H;
+        Wm = d->W;
+        k.stride = 1;
+        k.ostride = 2;
+        k.pad_mode = T2V_PAD_ZERO;
+        k.nphases = 4;
+        k.KW = 3;
+        k.pad = 0;
+        int tap0 = 0;
+        long woff = 0;
+        for (int p = 0; p < 4; ++p) {
+            int nt, kh[4], kw[4], dy[4], dx[4], a, b;
+            convT_phase_taps_host(p, &nt, kh, kw, dy, dx, &a, &b);
+            ConvPhase& ph = k.ph[p];
+            ph.ntaps = nt;
+            ph.tap0 = tap0;
+            ph.Kp = round_up(nt * x_cs, kBK);
+            ph.nk = ph.Kp / kBK;
+            ph.w_off = woff;
+            ph.oy0 = a;
+            ph.ox0 = b;
+            for (int t = 0; t < nt; ++t) {
+                k.tdy[tap0 + t] = dy[t];
+                k.tdx[tap0 + t] = dx[t];
+            }
+            tap0 += nt;
+            woff += (long)pl.Cout_p * ph.Kp;
+        }
+        pl.wfloats = (size_t)woff;
+    }
+    k.Wm = Wm;
+    k.M = Hm * Wm;
+    k.Wout = pl.Wout;
+    k.mtiles = (k.M + pl.BM - 1) / pl.BM;
+    pl.nparts = k.nphases * k.mtiles;
+    T2V_REQUIRE((long)k.mtiles * k.ntiles * k.nphases < (1L << 31), "conv: grid too large");
+    return T2V_OK;
+}
+
+int run_conv(t2v_ctx* ctx, hipStream_t s, const ConvPlan& pl, const float* x, const float* w, const float* bias,
+             float* y, int y_cs, float* stats) {
+    T2V_REQUIRE(ctx && x && w && y, "conv: null pointer");
+    T2V_REQUIRE(y_cs >= pl.kp.Cout && y_cs <= pl.Cout_p, "conv: output channel storage %d out of range [%d,%d]", y_cs,
+                pl.kp.Cout, pl.Cout_p);
+    ConvKParams k = pl.kp;
+    k.x = x;
+    k.w = w;
+    k.bias = bias;
+    k.y = y;
+    k.Cout_s = y_cs;
+    k.stats = stats;
+    k.zero = ctx->zero_page;
+    return launch_conv_igemm(s, k, pl.tile);
+}
+
+}  // namespace t2v
+
+using namespace t2v;
+
+extern "C" {
+
+int t2v_abi_version(void) { return T2V_ABI_VERSION; }
+const char* t2v_last_error(void) { return g_err; }
+
+int t2v_create(t2v_ctx** out, int device) {
+    T2V_REQUIRE(out, "t2v_create: null out");
+    int n = 0;
+    T2V_HIP_CHECK(hipGetDeviceCount(&n));
+    T2V_REQUIRE(device >= 0 && device < n, "t2v_create: device %d out of range (%d visible)", device, n);
+    T2V_HIP_CHECK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    T2V_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+    T2V_REQUIRE(strncmp(prop.gcnArchName, "gfx950", 6) == 0,
+                "libt2v_hip is built for gfx950 (MI355X) only; device %d is %s", device, prop.gcnArchName);
+    t2v_ctx* c = new t2v_ctx();
+    c->device = device;
+    c->zero_page = nullptr;
+    hipError_t e = hipMalloc(&c->zero_page, 4096);
+    if (e == hipSuccess) e = hipMemset(c->zero_page, 0, 4096);
+    if (e != hipSuccess) {
+        set_error("t2v_create: zero page: %s", hipGetErrorString(e));
+        delete c;
+        return T2V_ERR_HIP;
+    }
+    *out = c;
+    return T2V_OK;
+}
+
+int t2v_destroy(t2v_ctx* ctx) {
+    if (!ctx) return T2V_OK;
+    if (ctx->zero_page) (void)hipFree(ctx->zero_page);
+    delete ctx;
+    return T2V_OK;
+}
+
+int t2v_conv_out_dims(const t2v_conv_desc* d, int* Hout, int* Wout) {
+    ConvPlan pl;
+    T2V_TRY(build_conv_plan(d, round_up(d ? d->Cin : 0, 4), false, &pl));
+    if (Hout) *Hout = pl.Hout;
+    if (Wout) *Wout = pl.Wout;
+    return T2V_OK;
+}
+
+size_t t2v_conv_packed_weight_floats(const t2v_conv_desc* d, int x_cs) {
+    ConvPlan pl;
+    if (build_conv_plan(d, x_cs, false, &pl) != T2V_OK) return 0;
+    return pl.wfloats;
+}
+
+int t2v_conv_pack_weight(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, int x_cs, const float* w_torch_dev,
+                         float* packed_dev) {
+    T2V_REQUIRE(ctx && w_torch_dev && packed_dev, "pack_weight: null pointer");
+    ConvPlan pl;
+    T2V_TRY(build_conv_plan(d, x_cs, false, &pl));
+    hipStream_t s = (hipStream_t)stream;
+    if (!d->transposed)
+        return launch_pack_conv_weight(s, w_torch_dev, packed_dev, d->Cout, d->Cin, d->kH, d->kW, x_cs, pl.kp.ph[0].Kp,
+                                       pl.Cout_p);
+    return launch_pack_convT_weight(s, w_torch_dev, packed_dev, d->Cin, d->Cout, x_cs, pl.Cout_p);
+}
+
+size_t t2v_conv_stats_floats(const t2v_conv_desc* d) {
+    ConvPlan pl;
+    if (!d || build_conv_plan(d, round_up(d->Cin, 4), true, &pl) != T2V_OK) return 0;
+    return (size_t)pl.nparts * d->Cout * 2;
+}
+
+int t2v_conv2d_forward(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, const float* x, int x_cs,
+                       const float* w_packed, const float* bias, float* y, int y_cs, float* stats_partial) {
+    ConvPlan pl;
+    T2V_TRY(build_conv_plan(d, x_cs, stats_partial != nullptr, &pl));
+    return run_conv(ctx, (hipStream_t)stream, pl, x, w_packed, bias, y, y_cs, stats_partial);
+}
+
+int t2v_instance_norm_finalize(t2v_ctx* ctx, void* stream, const t2v_conv_desc* producer, const float* stats_partial,
+                               float eps, float* mean_rstd) {
+    T2V_REQUIRE(ctx && stats_partial && mean_rstd, "inorm_finalize: null pointer");
+    ConvPlan pl;
+    T2V_TRY(build_conv_plan(producer, round_up(producer ? producer->Cin : 0, 4), true, &pl));
+    return launch_inorm_finalize((hipStream_t)stream, stats_partial, pl.nparts, pl.kp.mtiles, pl.BM, pl.kp.M,
+                                 producer->Cout, eps, mean_rstd);
+}
+
+int t2v_instance_norm_apply(t2v_ctx* ctx, void* stream, const float* x, const float* mean_rstd, const float* gamma,
+                            const float* beta, const float* res1, const float* res2, float* y, long npix, int C,
+                            int relu) {
+    T2V_REQUIRE(ctx && x && mean_rstd && y, "inorm_apply: null pointer");
+    T2V_REQUIRE((gamma == nullptr) == (beta == nullptr), "inorm_apply: gamma and beta must both be given or both NULL");
+    return launch_inorm_apply((hipStream_t)stream, x, mean_rstd, gamma, beta, res1, res2, y, npix, C, relu);
+}
+
+int t2v_flow_warp_composite(t2v_ctx* ctx, void* stream, const float* raw, const float* fw, const float* prev,
+                            int prev_cs, int prev_c0, float* out, float* warp_out, int H, int W) {
+    T2V_REQUIRE(ctx && raw && fw && prev && out, "flow_warp_composite: null pointer");
+    T2V_REQUIRE(H > 1 && W > 1, "flow_warp_composite: H,W must be > 1");
+    return launch_warp_composite((hipStream_t)stream, raw, fw, prev, prev_cs, prev_c0, out, warp_out, H, W);
+}
+
+int t2v_avgpool3x3s2(t2v_ctx* ctx, void* stream, const float* x, float* y, int H, int W, int C) {
+    T2V_REQUIRE(ctx && x && y, "avgpool: null pointer");
+    return launch_avgpool3s2((hipStream_t)stream, x, y, H, W, C);
+}
+
+int t2v_nchw_to_nhwc(t2v_ctx* ctx, void* stream, const float* src, float* dst, int C, int H, int W, int dst_cs) {
+    T2V_REQUIRE(ctx && src && dst && dst_cs >= C, "nchw_to_nhwc: bad arguments");
+    return launch_nchw_to_nhwc((hipStream_t)stream, src, dst, C, H, W, dst_cs);
+}
+int t2v_nhwc_to_nchw(t2v_ctx* ctx, void* stream, const float* src, float* dst, int C, int H, int W, int src_cs) {
+    T2V_REQUIRE(ctx && src && dst && src_cs >= C, "nhwc_to_nchw: bad arguments");
+    return launch_nhwc_to_nchw((hipStream_t)stream, src, dst, C, H, W, src_cs);
+}
+int t2v_pose_u8_to_f32(t2v_ctx* ctx, void* stream, const uint8_t* src_hwc3, float* dst, long npix, int dst_cs,
+                       int c0) {
+    T2V_REQUIRE(ctx && src_hwc3 && dst && c0 + 3 <= dst_cs, "pose_u8_to_f32: bad arguments");
+    return launch_u8_pose_to_f32((hipStream_t)stream, src_hwc3, dst, npix, dst_cs, c0);
+}
+int t2v_tensor2im_u8(t2v_ctx* ctx, void* stream, const float* x, uint8_t* y, long n) {
+    T2V_REQUIRE(ctx && x && y, "tensor2im: null pointer");
+    return launch_to_u8((hipStream_t)stream, x, y, n);
+}
+int t2v_copy_channels(t2v_ctx* ctx, void* stream, const float* src, int src_cs, int src_c0, float* dst, int dst_cs,
+                      int dst_c0, int nc, long npix) {
+    T2V_REQUIRE(ctx && src && dst && src_c0 + nc <= src_cs && dst_c0 + nc <= dst_cs, "copy_channels: bad arguments");
+    return launch_copy_channels((hipStream_t)stream, src, src_cs, src_c0, dst, dst_cs, dst_c0, nc, npix);
+}
+
+}  // extern "C"

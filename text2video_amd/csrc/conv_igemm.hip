@@ -1,0 +1,375 @@
+// conv_igemm.hip -- fp32 implicit-GEMM convolution for gfx950 (MI355X), hand-written for CDNA4.
+//
+// Replaces, for the vid2vid generator:
+//   SpatialReflectionPadding_updateOutput + SpatialConvolutionMM_updateOutput  (THCUNN.h:952,664)
+//   SpatialFullDilatedConvolution_updateOutput                                  (THCUNN.h:794)
+//
+// Design (MI355X-first, not a port of im2col+SGEMM):
+//   * NHWC activations: the GEMM K index is tap*Cin + c, so an A-row segment of one LDS stage
+//     (32 floats = 128 B) is one contiguous, coalesced 128-byte run of the input.
+//   * Operands go HBM/L2 -> LDS with the gfx950 LDS-DMA (global_load_lds_dwordx4): no VGPR
+//     round trip, no ds_write pass.  Reflection / zero padding and ragged edges are resolved in
+//     the per-lane SOURCE address (out-of-range -> a zero page); the im2col matrix never exists.
+//   * LDS image is lane-linear (DMA constraint); the 16-byte slot a lane fetches is XOR-swizzled
+//     on the source side, (row>>1)&7, and un-swizzled on the ds_read_b128 side, so fragment reads
+//     are bank-conflict free (cdna_hip_programming.md rule 21 / T2).
+//   * Exact fp32 on the matrix cores: v_mfma_f32_32x32x2_f32 (big layers) / 16x16x4 (3-channel
+//     heads).  One ds_read_b128 feeds 4 MFMAs: the k-order inside a stage is permuted
+//     identically for A and B, which only reorders the fp32 summation.
+//   * 128x128 block tile, 4 waves (one per SIMD) each 64x64 => 64 accumulator VGPRs, 2-stage LDS
+//     ring, one barrier per 32-deep K stage (4096 MFMA cycles per stage per wave).
+//   * Epilogue fuses bias, the head activations (tanh | flow*20 + sigmoid) and the instance-norm
+//     partial statistics (per block: mean and M2 over its pixels, two-pass in registers) so the
+//     norm never re-reads the activation to compute statistics.
+//   * blockIdx -> tile mapping is XCD-aware: each XCD's L2 sees a contiguous band of tiles that
+//     share A rows / all B columns.
+#include "t2v_internal.h"
+
+namespace t2v {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int MF> struct Mfma;
+template <> struct Mfma<32> {
+    using acc_t = f32x16;
+    static constexpr int NREG = 16;
+    static __device__ __forceinline__ acc_t run(float a, float b, acc_t c) {
+        return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+    }
+    // C/D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    static __device__ __forceinline__ int row(int reg, int g) { return (reg & 3) + 8 * (reg >> 2) + 4 * g; }
+};
+template <> struct Mfma<16> {
+    using acc_t = f32x4;
+    static constexpr int NREG = 4;
+    static __device__ __forceinline__ acc_t run(float a, float b, acc_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    }
+    // C/D layout: col = lane&15, row = 4*(lane>>4) + reg
+    static __device__ __forceinline__ int row(int reg, int g) { return 4 * g + reg; }
+};
+
+// MF: MFMA tile edge; WAVES_M x WAVES_N waves; each wave TM x TN MFMA tiles.
+template <int MF_, int WAVES_M_, int WAVES_N_, int TM_, int TN_>
+struct TileCfg {
+    static constexpr int MF = MF_, WAVES_M = WAVES_M_, WAVES_N = WAVES_N_, TM = TM_, TN = TN_;
+    static constexpr int BM = WAVES_M * TM * MF;
+    static constexpr int BN = WAVES_N * TN * MF;
+    static constexpr int NG = 64 / MF;           // lane groups along k inside one MFMA (2 or 4)
+    static constexpr int RQ = 8 / NG;            // ds_read_b128 per fragment per stage (4 or 2)
+    static constexpr int STAGE_BYTES = (BM + BN) * 128;
+    static constexpr int LDS_BYTES = 2 * STAGE_BYTES;
+    static_assert(WAVES_M * WAVES_N == 4, "256-thread blocks");
+    static_assert(BM % 32 == 0, "A loader: 8 rows per wave instruction, 4 waves");
+};
+using CfgL = TileCfg<32, 2, 2, 2, 2>;  // 128 x 128
+using CfgS = TileCfg<16, 4, 1, 4, 1>;  // 256 x 16 (3-channel heads)
+
+__device__ __forceinline__ void glds16(const float* src, char* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+__device__ __forceinline__ int reflect_idx(int i, int n) {
+    i = i < 0 ? -i : i;
+    return i >= n ? 2 * n - 2 - i : i;
+}
+
+// MODE 0: Cin_s % 32 == 0 (a stage lies inside one tap; tap offsets read with scalar loads)
+// MODE 1: any Cin_s % 4 == 0, regular conv (tap -> (kh,kw) by arithmetic): the 7x7 stems
+// MODE 2: any Cin_s % 4 == 0, tap table looked up per lane: transposed convs of narrow test nets
+template <class Cfg, int MODE, bool STATS>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using MM = Mfma<Cfg::MF>;
+    using acc_t = typename MM::acc_t;
+    constexpr int BM = Cfg::BM, BN = Cfg::BN, MF = Cfg::MF;
+    constexpr int A_ITERS = BM / 32;                      // wave-instructions per wave for A
+    constexpr int B_INSTR = BN / 8;                       // wave-instructions for B in total
+    constexpr int B_ITERS = (B_INSTR + 3) / 4;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // ---- XCD-aware tile id: block b runs on XCD b%8; give every XCD a contiguous tile band ----
+    int t;
+    {
+        const int nb = gridDim.x, b = blockIdx.x;
+        const int xcd = b & 7, idx = b >> 3;
+        const int q = nb >> 3, r = nb & 7;
+        t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tiles_per_phase = p.mtiles * p.ntiles;
+    const int phase = t / tiles_per_phase;
+    const int rem = t - phase * tiles_per_phase;
+    const int mt = rem / p.ntiles;
+    const int nt = rem - mt * p.ntiles;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const ConvPhase ph = p.ph[phase];
+    const float* __restrict__ wbase = p.w + ph.w_off;
+
+    // ---- loader lane geometry: a wave instruction moves 8 rows x 128 B; lane -> (row, slot) ----
+    const int lrow = lane >> 3;   // 0..7
+    const int lslot = lane & 7;   // physical 16-B slot in the row
+    int a_by[A_ITERS], a_bx[A_ITERS];
+    bool a_ok[A_ITERS];
+    int a_chunk[A_ITERS];  // data chunk (of 8) this lane fetches = slot ^ swizzle(row)
+#pragma unroll
+    for (int i = 0; i < A_ITERS; ++i) {
+        const int r = wid * (BM / 4) + i * 8 + lrow;
+        const int m = m0 + r;
+        a_ok[i] = m < p.M;
+        const int my = m / p.Wm, mx = m - my * p.Wm;
+        a_by[i] = my * p.stride;
+        a_bx[i] = mx * p.stride;
+        a_chunk[i] = lslot ^ ((r >> 1) & 7);
+    }
+
+    auto stage = [&](int kt, int buf) {
+        char* sA = smem + buf * Cfg::STAGE_BYTES;
+        char* sB = sA + BM * 128;
+        if constexpr (MODE == 0) {
+            // whole 32-deep stage lies inside one tap: tap index and channel base are scalar
+            const int cpt = p.Cin_s >> 5;
+            const int tap = kt / cpt;
+            const int c0 = (kt - tap * cpt) << 5;
+            const int dy = p.tdy[ph.tap0 + tap], dx = p.tdx[ph.tap0 + tap];
+#pragma unroll
+            for (int i = 0; i < A_ITERS; ++i) {
+                int iy = a_by[i] + dy, ix = a_bx[i] + dx;
+                bool ok = a_ok[i];
+                if (p.pad_mode == T2V_PAD_REFLECT) {
+                    iy = reflect_idx(iy, p.Hin);
+                    ix = reflect_idx(ix, p.Win);
+                } else {
+                    ok = ok && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
+                }
+                const float* src = ok ? p.x + ((size_t)(iy * p.Win + ix) * p.Cin_s + c0 + a_chunk[i] * 4) : p.zero;
+                glds16(src, sA + (wid * (BM / 4) + i * 8) * 128);
+            }
+        } else {
+            // general path (stem convs, Cin_s = 8 / 12): every 16-B chunk resolves its own tap
+            const int K = ph.ntaps * p.Cin_s;
+#pragma unroll
+            for (int i = 0; i < A_ITERS; ++i) {
+                const int k = kt * kBK + a_chunk[i] * 4;
+                const bool kin = k < K;
+                const int tap = kin ? k / p.Cin_s : 0;
+                const int c = k - tap * p.Cin_s;
+                int dy, dx;
+                if constexpr (MODE == 1) {
+                    const int kh = tap / p.KW;
+                    dy = kh - p.pad;
+                    dx = tap - kh * p.KW - p.pad;
+                } else {
+                    dy = p.tdy[ph.tap0 + tap];
+                    dx = p.tdx[ph.tap0 + tap];
+                }
+                int iy = a_by[i] + dy, ix = a_bx[i] + dx;
+                bool ok = a_ok[i] && kin;
+                if (p.pad_mode == T2V_PAD_REFLECT) {
+                    iy = reflect_idx(iy, p.Hin);
+                    ix = reflect_idx(ix, p.Win);
+                    // k >= K lanes may compute wild coordinates: they take the zero page
+                } else {
+                    ok = ok && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
+                }
+                const float* src = ok ? p.x + ((size_t)(iy * p.Win + ix) * p.Cin_s + c) : p.zero;
+                glds16(src, sA + (wid * (BM / 4) + i * 8) * 128);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < B_ITERS; ++i) {
+            const int instr = (B_INSTR >= 4) ? wid * B_ITERS + i : wid;
+            if (B_INSTR >= 4 || wid < B_INSTR) {
+                const int r = instr * 8 + lrow;
+                const int chunk = lslot ^ ((r >> 1) & 7);
+                const float* src = wbase + (size_t)(n0 + r) * ph.Kp + kt * kBK + chunk * 4;
+                glds16(src, sB + instr * 8 * 128);
+            }
+        }
+    };
+
+    // ---- MFMA fragment geometry ----
+    const int wm = wid / Cfg::WAVES_N, wn = wid - wm * Cfg::WAVES_N;
+    const int fr = lane & (MF - 1);  // row (A) / col (B) inside the MFMA tile
+    const int g = lane / MF;         // k group
+    const int fsw = (fr >> 1) & 7;   // tile bases are multiples of 16 rows, so swizzle(row) = swizzle(fr)
+    const int a_row0 = wm * (Cfg::TM * MF) + fr;
+    const int b_row0 = wn * (Cfg::TN * MF) + fr;
+
+    acc_t acc[Cfg::TM][Cfg::TN];
+#pragma unroll
+    for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < Cfg::TN; ++j)
+#pragma unroll
+            for (int r = 0; r < MM::NREG; ++r) acc[i][j][r] = 0.f;
+
+    auto compute = [&](int buf) {
+        const char* sA = smem + buf * Cfg::STAGE_BYTES;
+        const char* sB = sA + BM * 128;
+#pragma unroll
+        for (int q = 0; q < Cfg::RQ; ++q) {
+            const int slot = ((q * Cfg::NG + g) ^ fsw) * 16;
+            f32x4 af[Cfg::TM], bf[Cfg::TN];
+#pragma unroll
+            for (int i = 0; i < Cfg::TM; ++i)
+                af[i] = *reinterpret_cast<const f32x4*>(sA + (a_row0 + i * MF) * 128 + slot);
+#pragma unroll
+            for (int j = 0; j < Cfg::TN; ++j)
+                bf[j] = *reinterpret_cast<const f32x4*>(sB + (b_row0 + j * MF) * 128 + slot);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < Cfg::TN; ++j) acc[i][j] = MM::run(af[i][e], bf[j][e], acc[i][j]);
+        }
+    };
+
+    // ---- main loop: 2-stage LDS ring, DMA of stage kt+1 in flight under the MFMAs of stage kt ----
+    const int nk = ph.nk;
+    stage(0, 0);
+    __syncthreads();
+    int buf = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
+        compute(buf);
+        __syncthreads();
+        buf ^= 1;
+    }
+
+    // ---- epilogue ----
+    float bias_v[Cfg::TN];
+    int col[Cfg::TN];
+#pragma unroll
+    for (int j = 0; j < Cfg::TN; ++j) {
+        col[j] = n0 + wn * (Cfg::TN * MF) + j * MF + fr;
+        bias_v[j] = (col[j] < p.Cout && p.bias) ? p.bias[col[j]] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < Cfg::TN; ++j)
+#pragma unroll
+            for (int r = 0; r < MM::NREG; ++r) acc[i][j][r] += bias_v[j];
+
+    if constexpr (STATS) {
+        // per-block, per-channel mean and M2 over the block's valid pixels (two passes over the
+        // accumulators held in registers); combined across blocks by inorm_finalize (Chan).
+        static_assert(!STATS || Cfg::WAVES_M == 2, "stats reduction written for 2 waves along M");
+        float* red = reinterpret_cast<float*>(smem);  // [2][BN]; main loop ended with a barrier
+        const int cnt = min(BM, p.M - m0);
+        const float inv_cnt = 1.f / (float)cnt;
+        float mean_b[Cfg::TN];
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+            for (int j = 0; j < Cfg::TN; ++j) {
+                float s = 0.f;
+#pragma unroll
+                for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+                    for (int r = 0; r < MM::NREG; ++r) {
+                        const int row = wm * (Cfg::TM * MF) + i * MF + MM::row(r, g);
+                        float v = acc[i][j][r];
+                        if (pass == 1) {
+                            v -= mean_b[j];
+                            v *= v;
+                        }
+                        s += (row < cnt) ? v : 0.f;
+                    }
+                s += __shfl_xor(s, 32);
+                if (g == 0) red[wm * BN + wn * (Cfg::TN * MF) + j * MF + fr] = s;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < Cfg::TN; ++j) {
+                const int c = wn * (Cfg::TN * MF) + j * MF + fr;
+                const float tot = red[c] + red[BN + c];
+                if (pass == 0) {
+                    mean_b[j] = tot * inv_cnt;
+                } else if (wm == 0 && g == 0 && col[j] < p.Cout) {
+                    const size_t part = (size_t)phase * p.mtiles + mt;
+                    float2* dst = reinterpret_cast<float2*>(p.stats) + part * p.Cout + col[j];
+                    *dst = make_float2(mean_b[j], tot);
+                }
+            }
+            __syncthreads();
+        }
+    }
+
+#pragma unroll
+    for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+        for (int r = 0; r < MM::NREG; ++r) {
+            const int row = wm * (Cfg::TM * MF) + i * MF + MM::row(r, g);
+            const int m = m0 + row;
+            if (m < p.M) {
+                const int my = m / p.Wm, mx = m - my * p.Wm;
+                const int oy = my * p.ostride + ph.oy0, ox = mx * p.ostride + ph.ox0;
+                float* yrow = p.y + (size_t)(oy * p.Wout + ox) * p.Cout_s;
+#pragma unroll
+                for (int j = 0; j < Cfg::TN; ++j) {
+                    if (col[j] < p.Cout_s) {
+                        float v = acc[i][j][r];
+                        if (p.act == T2V_ACT_TANH) {
+                            v = tanhf(v);
+                        } else if (p.act == T2V_ACT_FLOW_W) {
+                            v = col[j] < 2 ? v * p.act_scale : 1.f / (1.f + expf(-v));
+                        }
+                        yrow[col[j]] = col[j] < p.Cout ? v : 0.f;
+                    }
+                }
+            }
+        }
+}
+
+int conv_tile_for(int Cout) { return Cout <= 16 ? kTileS : kTileL; }
+void conv_tile_dims(int tile, int* BM, int* BN) {
+    if (tile == kTileS) {
+        *BM = CfgS::BM;
+        *BN = CfgS::BN;
+    } else {
+        *BM = CfgL::BM;
+        *BN = CfgL::BN;
+    }
+}
+
+template <class Cfg, int MODE, bool STATS>
+static int launch_one(hipStream_t s, const ConvKParams& p) {
+    auto kern = conv_igemm_kernel<Cfg, MODE, STATS>;
+    static bool attr_done = false;  // per instantiation
+    if (!attr_done) {
+        T2V_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
+        attr_done = true;
+    }
+    const int nblocks = p.mtiles * p.ntiles * p.nphases;
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), Cfg::LDS_BYTES, s, p);
+    T2V_HIP_CHECK(hipGetLastError());
+    return T2V_OK;
+}
+
+int launch_conv_igemm(hipStream_t s, const ConvKParams& p, int tile) {
+    const int mode = (p.Cin_s % kBK) == 0 ? 0 : (p.nphases == 1 ? 1 : 2);
+    const bool stats = p.stats != nullptr;
+    if (tile == kTileL) {
+        switch (mode) {
+            case 0: return stats ? launch_one<CfgL, 0, true>(s, p) : launch_one<CfgL, 0, false>(s, p);
+            case 1: return stats ? launch_one<CfgL, 1, true>(s, p) : launch_one<CfgL, 1, false>(s, p);
+            default: return stats ? launch_one<CfgL, 2, true>(s, p) : launch_one<CfgL, 2, false>(s, p);
+        }
+    }
+    T2V_REQUIRE(!stats, "small-Cout tile has no instance-norm statistics epilogue");
+    switch (mode) {
+        case 0: return launch_one<CfgS, 0, false>(s, p);
+        case 1: return launch_one<CfgS, 1, false>(s, p);
+        default: return launch_one<CfgS, 2, false>(s, p);
+    }
+}
+
+}  // namespace t2v

@@ -1,0 +1,407 @@
+// elementwise.hip -- the HBM-bound kernels of the frame-synthesis path (gfx950).
+//   instance-norm finalize/apply(+ReLU+residual), flow-warp compositor, 3x3/s2 average pool,
+//   weight repacking and NCHW<->NHWC / uint8 plumbing.  All NHWC, 16-byte accesses where the
+//   layout allows, grid-stride with <= 2048 blocks (cdna_hip_programming.md Guideline 11/13).
+#include "t2v_internal.h"
+
+namespace t2v {
+
+static inline int grid_for(long n, int block) {
+    long g = (n + block - 1) / block;
+    if (g > 2048) g = 2048;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Instance norm.  Semantics: F.instance_norm -> batch_norm(training=True) on [1,B*C,H,W]
+// ($SP/torch/nn/functional.py:1258-1301): biased variance, y=(x-mean)/sqrt(var+eps)*gamma+beta.
+// Statistics arrive as per-tile (mean_b, M2_b) partials from the conv epilogue; they are merged
+// with Chan's parallel update (numerically a two-pass variance, no E[x^2]-E[x]^2 cancellation).
+// ---------------------------------------------------------------------------------------------
+struct Moments {
+    float n, mean, m2;
+};
+__device__ __forceinline__ void chan_merge(Moments& a, float nb, float mb, float m2b) {
+    if (nb <= 0.f) return;
+    const float n = a.n + nb;
+    const float delta = mb - a.mean;
+    const float f = nb / n;
+    a.mean += delta * f;
+    a.m2 += m2b + delta * delta * a.n * f;
+    a.n = n;
+}
+
+// block = 16 slices x 16 channels; grid = ceil(C/16)
+__global__ __launch_bounds__(256) void inorm_finalize_kernel(const float2* __restrict__ stats, int nparts, int mtiles,
+                                                             int BM, int M, int C, float eps,
+                                                             float2* __restrict__ mean_rstd) {
+    __shared__ float sh[3][16][17];
+    const int cc = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cc;
+    Moments a{0.f, 0.f, 0.f};
+    if (c < C) {
+        for (int part = sl; part < nparts; part += 16) {
+            const int mt = part % mtiles;
+            const int nb = min(BM, M - mt * BM);
+            const float2 v = stats[(size_t)part * C + c];
+            chan_merge(a, (float)nb, v.x, v.y);
+        }
+    }
+    sh[0][sl][cc] = a.n;
+    sh[1][sl][cc] = a.mean;
+    sh[2][sl][cc] = a.m2;
+    __syncthreads();
+    if (sl == 0 && c < C) {
+        for (int s = 1; s < 16; ++s) chan_merge(a, sh[0][s][cc], sh[1][s][cc], sh[2][s][cc]);
+        const float var = a.m2 / a.n;
+        mean_rstd[c] = make_float2(a.mean, 1.0f / sqrtf(var + eps));
+    }
+}
+
+int launch_inorm_finalize(hipStream_t s, const float* stats, int nparts, int mtiles, int BM, int M, int C,
+                          float eps, float* mean_rstd) {
+    hipLaunchKernelGGL(inorm_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, s,
+                       reinterpret_cast<const float2*>(stats), nparts, mtiles, BM, M, C, eps,
+                       reinterpret_cast<float2*>(mean_rstd));
+    T2V_HIP_CHECK(hipGetLastError());
+    return T2V_OK;
+}
+
+// y = [relu]((x-mean)*rstd*gamma+beta) + res1 + res2 ; float4 over NHWC, C % 4 == 0
+__global__ __launch_bounds__(256) void inorm_apply_kernel(const float4* __restrict__ x,
+                                                          const float4* __restrict__ mean_rstd,
+                                                          const float4* __restrict__ gamma,
+                                                          const float4* __restrict__ beta,
+                                                          const float4* __restrict__ res1,
+                                                          const float4* __restrict__ res2, float4* __restrict__ y,
+                                                          long n4, int C4, int relu) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const int c4 = (int)(i % C4);
+        const float4 a = mean_rstd[2 * c4], b = mean_rstd[2 * c4 + 1];  // (m0,r0,m1,r1) (m2,r2,m3,r3)
+        float4 v = x[i];
+        v.x = (v.x - a.x) * a.y;
+        v.y = (v.y - a.z) * a.w;
+        v.z = (v.z - b.x) * b.y;
+        v.w = (v.w - b.z) * b.w;
+        if (gamma) {
+            const float4 gm = gamma[c4], bt = beta[c4];
+            v.x = v.x * gm.x + bt.x;
+            v.y = v.y * gm.y + bt.y;
+            v.z = v.z * gm.z + bt.z;
+            v.w = v.w * gm.w + bt.w;
+        }
+        if (relu) {
+            v.x = fmaxf(v.x, 0.f);
+            v.y = fmaxf(v.y, 0.f);
+            v.z = fmaxf(v.z, 0.f);
+            v.w = fmaxf(v.w, 0.f);
+        }
+        if (res1) {
+            const float4 r = res1[i];
+            v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+        }
+        if (res2) {
+            const float4 r = res2[i];
+            v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+        }
+        y[i] = v;
+    }
+}
+
+int launch_inorm_apply(hipStream_t s, const float* x, const float* mean_rstd, const float* gamma,
+                       const float* beta, const float* res1, const float* res2, float* y, long npix, int C,
+                       int relu) {
+    T2V_REQUIRE(C % 4 == 0, "inorm_apply: C=%d must be a multiple of 4", C);
+    const long n4 = npix * (C / 4);
+    hipLaunchKernelGGL(inorm_apply_kernel, dim3(grid_for(n4, 256)), dim3(256), 0, s,
+                       reinterpret_cast<const float4*>(x), reinterpret_cast<const float4*>(mean_rstd),
+                       reinterpret_cast<const float4*>(gamma), reinterpret_cast<const float4*>(beta),
+                       reinterpret_cast<const float4*>(res1), reinterpret_cast<const float4*>(res2),
+                       reinterpret_cast<float4*>(y), n4, C / 4, relu);
+    T2V_HIP_CHECK(hipGetLastError());
+    return T2V_OK;
+}
+
+__global__ void add_kernel(const float4* __restrict__ a, const float4* __restrict__ b, float4* __restrict__ y,
+                           long n4) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 u = a[i];
+        const float4 v = b[i];
+        u.x += v.x; u.y += v.y; u.z += v.z; u.w += v.w;
+        y[i] = u;
+    }
+}
+int launch_add(hipStream_t s, const float* a, const float* b, float* y, long n) {
+    T2V_REQUIRE(n % 4 == 0, "add: n must be a multiple of 4");
+    hipLaunchKernelGGL(add_kernel, dim3(grid_for(n / 4, 256)), dim3(256), 0, s,
+                       reinterpret_cast<const float4*>(a), reinterpret_cast<const float4*>(b),
+                       reinterpret_cast<float4*>(y), n / 4);
+    T2V_HIP_CHECK(hipGetLastError());
+    return T2V_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight repacking: torch layouts ($SP/torch/nn/modules/conv.py:28-33) -> [Cout_p][Kp], K =
+// tap*Cin_s + c, zero padded.  One-time, at checkpoint load.
+// ---------------------------------------------------------------------------------------------
+__global__ void pack_conv_weight_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin,
+                                        int KH, int KW, int Cin_s, int Kp, long total) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int n = (int)(i / Kp), k = (int)(i - (long)n * Kp);
+        const int tap = k / Cin_s, c = k - tap * Cin_s;
+        float v = 0.f;
+        if (n < Cout && tap < KH * KW && c < Cin) {
+            const int kh = tap / KW, kw = tap - kh * KW;
+            v = w[(((size_t)n * Cin + c) * KH + kh) * KW + kw];
+        }
+        out[i] = v;
+    }
+}
+int launch_pack_conv_weight(hipStream_t s, const float* w, float* packed, int Cout, int Cin, int KH, int KW,
+                            int Cin_s, int Kp, int Cout_p) {
+    const long total = (long)Cout_p * Kp;
+    hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, w, packed, Cout, Cin,
+                       KH, KW, Cin_s, Kp, total);
+    T2V_HIP_CHECK(hipGetLastError());
+    return T2V_OK;
+}
+
+// ConvTranspose2d(k3,s2,p1,op1), weight [Cin][Cout][3][3]:  out[2i+a][2j+b] = sum over the taps
+// of phase (a,b).  y = 2i - 1 + kh  =>  a=0: kh=1 (dy 0) ; a=1: kh=2 (dy 0), kh=0 (dy +1).
+// Phase order (heaviest first): (1,1) 4 taps, (1,0) 2, (0,1) 2, (0,0) 1 -- must match
+// the launcher, which shares convT_phase_taps().
+__device__ __host__ inline void convT_phase_taps(int phase, int* ntaps, int kh[4], int kw[4], int dy[4], int dx[4],
+                                                 int* a, int* b) {
+    const int pa[4] = {1, 1, 0, 0}, pb[4] = {1, 0, 1, 0};
+    *a = pa[phase];
+    *b = pb[phase];
+    int ykh[2], ydy[2], ny, xkw[2], xdx[2], nx;
+    if (*a == 0) { ny = 1; ykh[0] = 1; ydy[0] = 0; } else { ny = 2; ykh[0] = 2; ydy[0] = 0; ykh[1] = 0; ydy[1] = 1; }
+    if (*b == 0) { nx = 1; xkw[0] = 1; xdx[0] = 0; } else { nx = 2; xkw[0] = 2; xdx[0] = 0; xkw[1] = 0; xdx[1] = 1; }
+    int n = 0;
+    for (int iy = 0; iy < ny; ++iy)
+        for (int ix = 0; ix < nx; ++ix) {
+            kh[n] = ykh[iy]; dy[n] = ydy[iy];
+            kw[n] = xkw[ix]; dx[n] = xdx[ix];
+            ++n;
+        }
+    *ntaps = n;
+}
+
+__global__ void pack_convT_weight_kernel(const float* __restrict__ w, float* __restrict__ out, int Cin, int Cout,
+                                         int Cout_p, int Cin_s) {
+    // one launch per phase via blockIdx.y
+    const int phase = blockIdx.y;
+    int ntaps, kh[4], kw[4], dy[4], dx[4], a, b;
+    convT_phase_taps(phase, &ntaps, kh, kw, dy, dx, &a, &b);
+    long off = 0;
+    for (int q = 0; q < phase; ++q) {
+        int nt, t1[4], t2[4], t3[4], t4[4], aa, bb;
+        convT_phase_taps(q, &nt, t1, t2, t3, t4, &aa, &bb);
+        const int Kq = (nt * Cin_s + kBK - 1) / kBK * kBK;
+        off += (long)Cout_p * Kq;
+    }
+    const int Kp = (ntaps * Cin_s + kBK - 1) / kBK * kBK;
+    const long total = (long)Cout_p * Kp;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int n = (int)(i / Kp), k = (int)(i - (long)n * Kp);
+        const int tap = k / Cin_s, c = k - tap * Cin_s;
+        float v = 0.f;
+        if (n < Cout && tap < ntaps && c < Cin) v = w[(((size_t)c * Cout + n) * 3 + kh[tap]) * 3 + kw[tap]];
+        out[off + i] = v;
+    }
+}
+void convT_phase_taps_host(int phase, int* ntaps, int kh[4], int kw[4], int dy[4], int dx[4], int* a, int* b) {
+    convT_phase_taps(phase, ntaps, kh, kw, dy, dx, a, b);
+}
+int launch_pack_convT_weight(hipStream_t s, const float* w, float* packed, int Cin, int Cout, int Cin_s,
+                             int Cout_p) {
+    const long total = (long)Cout_p * 4 * Cin_s;
+    hipLaunchKernelGGL(pack_convT_weight_kernel, dim3(grid_for(total, 256), 4), dim3(256), 0, s, w, packed, Cin,
+                       Cout, Cout_p, Cin_s);
+    T2V_HIP_CHECK(hipGetLastError());
+    return T2V_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// layout plumbing
+// ---------------------------------------------------------------------------------------------
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, long HW, int Cs) {
+    const long total = HW * Cs;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const long pix = i / Cs;
+        const int c = (int)(i - pix * Cs);
+        dst[i] = c < C ? src[(long)c * HW + pix] : 0.f;
+    }
+}
+int launch_nchw_to_nhwc(hipStream_t s, const float* src, float* dst, int C, int H, int W, int Cs) {
+    const long HW = (long)H * W;
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for(HW * Cs, 256)), dim3(256), 0, s, src, dst, C, HW, Cs);
+    T2V_HIP_CHECK(hipGetLastError());
+    return T2V_OK;
+}
+__global__ void nhwc_to_nchw_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, long HW, int Cs) {
+    const long total = HW * C;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int c = (int)(i / HW);
+        const long pix = i - (long)c * HW;
+        dst[i] = src[pix * Cs + c];
+    }
+}
+int launch_nhwc_to_nchw(hipStream_t s, const float* src, float* dst, int C, int H, int W, int Cs) {
+    const long HW = (long)H * W;
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for(HW * C, 256)), dim3(256), 0, s, src, dst, C, HW, Cs);
+    T2V_HIP_CHECK(hipGetLastError());
+    return T2V_OK;
+}
+
+__global__ void copy_channels_kernel(const float* __restrict__ src, int src_cs, int src_c0, float* __restrict__ dst,
+                                     int dst_cs, int dst_c0, int nc, long npix) {
+    const long total = npix * nc;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const long pix = i / nc;
+        const int c = (int)(i - pix * nc);
+        dst[pix * dst_cs + dst_c0 + c] = src[pix * src_cs + src_c0 + c];
+    }
+}
+int launch_copy_channels(hipStream_t s, const float* src, int src_cs, int src_c0, float* dst, int dst_cs,
+                         int dst_c0, int nc, long npix) {
+    hipLaunchKernelGGL(copy_channels_kernel, dim3(grid_for(npix * nc, 256)), dim3(256), 0, s, src, src_cs, src_c0,
+                       dst, dst_cs, dst_c0, nc, npix);
+    T2V_HIP_CHECK(hipGetLastError());
+    return T2V_OK;
+}
+
+// ToTensor (u8/255) + Normalize(0.5,0.5): (v/255 - 0.5)/0.5, same operation order as
+// $SP/torchvision/transforms/functional.py:38-60,206-208
+__global__ void u8_pose_to_f32_kernel(const uint8_t* __restrict__ src, float* __restrict__ dst, long npix, int Cs,
+                                      int c0) {
+    const long total = npix * 3;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const long pix = i / 3;
+        const int c = (int)(i - pix * 3);
+        const float v = (float)src[i] / 255.0f;
+        dst[pix * Cs + c0 + c] = (v - 0.5f) / 0.5f;
+    }
+}
+int launch_u8_pose_to_f32(hipStream_t s, const uint8_t* src, float* dst, long npix, int Cs, int c0) {
+    hipLaunchKernelGGL(u8_pose_to_f32_kernel, dim3(grid_for(npix * 3, 256)), dim3(256), 0, s, src, dst, npix, Cs, c0);
+    T2V_HIP_CHECK(hipGetLastError());
+    return T2V_OK;
+}
+
+// util.tensor2im: (x+1)/2*255, clip to [0,255], astype(uint8) (truncation)
+__global__ void to_u8_kernel(const float* __restrict__ x, uint8_t* __restrict__ y, long n) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float v = (x[i] + 1.0f) / 2.0f * 255.0f;
+        v = fminf(fmaxf(v, 0.f), 255.f);
+        y[i] = (uint8_t)v;
+    }
+}
+int launch_to_u8(hipStream_t s, const float* x, uint8_t* y, long n) {
+    hipLaunchKernelGGL(to_u8_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, x, y, n);
+    T2V_HIP_CHECK(hipGetLastError());
+    return T2V_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Flow-warp compositor: grid_sample(prev, base_grid + flow/((W-1)/2,(H-1)/2), bilinear, border,
+// corner-aligned) fused with out = raw*w + warp*(1-w).  Same operation order as the reference
+// formulation (normalised grid, then un-normalise) so fp32 rounding tracks the oracle.
+// raw/out: [H,W,4]; fw: [H,W,4] = (flow_x, flow_y, weight, 0).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void warp_composite_kernel(const float4* __restrict__ raw,
+                                                             const float4* __restrict__ fw,
+                                                             const float* __restrict__ prev, int prev_cs,
+                                                             int prev_c0, float4* __restrict__ out,
+                                                             float4* __restrict__ warp_out, int H, int W) {
+    const long npix = (long)H * W;
+    const long stride = (long)gridDim.x * blockDim.x;
+    const float sx = (float)(W - 1) / 2.0f, sy = (float)(H - 1) / 2.0f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += stride) {
+        const int y = (int)(i / W), x = (int)(i - (long)y * W);
+        const float4 f = fw[i];
+        // torch.linspace(-1,1,n): start + i*step for the lower half, end - (n-1-i)*step above
+        const float stepx = 2.0f / (float)(W - 1), stepy = 2.0f / (float)(H - 1);
+        const float gx0 = x < W / 2 ? -1.0f + stepx * (float)x : 1.0f - stepx * (float)(W - 1 - x);
+        const float gy0 = y < H / 2 ? -1.0f + stepy * (float)y : 1.0f - stepy * (float)(H - 1 - y);
+        const float gx = gx0 + f.x / sx, gy = gy0 + f.y / sy;
+        float px = ((gx + 1.0f) / 2.0f) * (float)(W - 1);
+        float py = ((gy + 1.0f) / 2.0f) * (float)(H - 1);
+        px = fminf(fmaxf(px, 0.f), (float)(W - 1));  // padding_mode='border'
+        py = fminf(fmaxf(py, 0.f), (float)(H - 1));
+        const float fx0 = floorf(px), fy0 = floorf(py);
+        const int x0 = (int)fx0, y0 = (int)fy0;
+        const int x1 = x0 + 1, y1 = y0 + 1;
+        const float wx1 = px - fx0, wy1 = py - fy0, wx0 = 1.0f - wx1, wy0 = 1.0f - wy1;
+        const float w00 = wx0 * wy0, w10 = wx1 * wy0, w01 = wx0 * wy1, w11 = wx1 * wy1;
+        const bool okx = x1 < W, oky = y1 < H;
+        float wv[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float* pc = prev + prev_c0 + c;
+            float v = pc[((long)y0 * W + x0) * prev_cs] * w00;
+            if (okx) v += pc[((long)y0 * W + x1) * prev_cs] * w10;
+            if (oky) v += pc[((long)y1 * W + x0) * prev_cs] * w01;
+            if (okx && oky) v += pc[((long)y1 * W + x1) * prev_cs] * w11;
+            wv[c] = v;
+        }
+        const float4 r = raw[i];
+        const float wt = f.z;
+        out[i] = make_float4(r.x * wt + wv[0] * (1.0f - wt), r.y * wt + wv[1] * (1.0f - wt),
+                             r.z * wt + wv[2] * (1.0f - wt), 0.f);
+        if (warp_out) warp_out[i] = make_float4(wv[0], wv[1], wv[2], 0.f);
+    }
+}
+int launch_warp_composite(hipStream_t s, const float* raw, const float* fw, const float* prev, int prev_cs,
+                          int prev_c0, float* out, float* warp_out, int H, int W) {
+    hipLaunchKernelGGL(warp_composite_kernel, dim3(grid_for((long)H * W, 256)), dim3(256), 0, s,
+                       reinterpret_cast<const float4*>(raw), reinterpret_cast<const float4*>(fw), prev, prev_cs,
+                       prev_c0, reinterpret_cast<float4*>(out), reinterpret_cast<float4*>(warp_out), H, W);
+    T2V_HIP_CHECK(hipGetLastError());
+    return T2V_OK;
+}
+
+// AvgPool2d(3, stride 2, padding 1, count_include_pad=False): divisor = taps inside the image
+__global__ void avgpool3s2_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int C, int Ho,
+                                  int Wo) {
+    const long total = (long)Ho * Wo * C;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int c = (int)(i % C);
+        const long pix = i / C;
+        const int ox = (int)(pix % Wo), oy = (int)(pix / Wo);
+        float s = 0.f;
+        int n = 0;
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = oy * 2 - 1 + ky;
+            if ((unsigned)iy >= (unsigned)H) continue;
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = ox * 2 - 1 + kx;
+                if ((unsigned)ix >= (unsigned)W) continue;
+                s += x[((long)iy * W + ix) * C + c];
+                ++n;
+            }
+        }
+        y[i] = s / (float)n;
+    }
+}
+int launch_avgpool3s2(hipStream_t s, const float* x, float* y, int H, int W, int C) {
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    hipLaunchKernelGGL(avgpool3s2_kernel, dim3(grid_for((long)Ho * Wo * C, 256)), dim3(256), 0, s, x, y, H, W, C,
+                       Ho, Wo);
+    T2V_HIP_CHECK(hipGetLastError());
+    return T2V_OK;
+}
+
+}  // namespace t2v

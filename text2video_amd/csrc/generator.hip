@@ -1,0 +1,346 @@
+// generator.hip -- whole-frame orchestration of the vid2vid generators on one HIP stream.
+//
+// Replaces CompositeGenerator.forward / CompositeLocalGenerator.forward (SURVEY.md App. A.1/A.2;
+// section 8a rows a4, a13).  Pure launch sequencing: every tensor lives in the caller's
+// workspace (bump-allocated here, identically by t2v_generator_workspace_bytes), nothing
+// synchronises, so a frame is ~150 back-to-back launches on the caller's stream.
+#include <vector>
+
+#include "conv_plan.h"
+
+namespace t2v {
+namespace {
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+struct Arena {
+    char* base;
+    size_t cap;
+    size_t off = 0;
+    bool overflow = false;
+    float* alloc(size_t floats) {
+        const size_t bytes = (floats * sizeof(float) + 255) / 256 * 256;
+        float* p = reinterpret_cast<float*>(base + off);
+        off += bytes;
+        if (base && off > cap) overflow = true;
+        return p;
+    }
+};
+
+t2v_conv_desc mk_conv(int H, int W, int Cin, int Cout, int k, int stride, int pad, int pad_mode, int transposed,
+                      int act = T2V_ACT_NONE, float act_scale = 1.f) {
+    t2v_conv_desc d;
+    d.H = H; d.W = W; d.Cin = Cin; d.Cout = Cout; d.kH = k; d.kW = k; d.stride = stride; d.pad = pad;
+    d.pad_mode = pad_mode; d.transposed = transposed; d.act = act; d.act_scale = act_scale;
+    return d;
+}
+
+struct LayerSpec {
+    t2v_conv_desc cd;
+    int x_cs;
+    bool has_norm;
+};
+
+// canonical layer list (the order documented in t2v.h)
+void enumerate_layers(const t2v_gen_desc& g, std::vector<LayerSpec>& out) {
+    const int G = g.ngf, n = g.is_local ? 1 : g.n_downsample;
+    const int H = g.H, W = g.W;
+    auto enc = [&](int in_nc) {
+        out.push_back({mk_conv(H, W, in_nc, G, 7, 1, 3, T2V_PAD_REFLECT, 0), round_up(in_nc, 4), true});
+        for (int i = 0; i < n; ++i)
+            out.push_back({mk_conv(H >> i, W >> i, G << i, G << (i + 1), 3, 2, 1, T2V_PAD_ZERO, 0), G << i, true});
+    };
+    auto rbs = [&](int count) {
+        const int C = G << n;
+        for (int i = 0; i < 2 * count; ++i)
+            out.push_back({mk_conv(H >> n, W >> n, C, C, 3, 1, 1, T2V_PAD_REFLECT, 0), C, true});
+    };
+    auto ups = [&]() {
+        for (int i = 0; i < n; ++i) {
+            const int l = n - i;
+            out.push_back({mk_conv(H >> l, W >> l, G << l, G << (l - 1), 3, 2, 1, T2V_PAD_ZERO, 1), G << l, true});
+        }
+    };
+    const int nb_enc = g.is_local ? 0 : g.n_blocks - g.n_blocks / 2;
+    const int nb_res = g.is_local ? g.n_blocks : g.n_blocks / 2;
+    enc(g.input_nc); rbs(nb_enc);
+    enc(g.prev_nc);  rbs(nb_enc);
+    rbs(nb_res); ups();
+    out.push_back({mk_conv(H, W, G, g.output_nc, 7, 1, 3, T2V_PAD_REFLECT, 0, T2V_ACT_TANH), G, false});
+    if (!g.no_flow) {
+        rbs(nb_res); ups();
+        out.push_back({mk_conv(H, W, G, 3, 7, 1, 3, T2V_PAD_REFLECT, 0, T2V_ACT_FLOW_W, g.flow_multiplier), G, false});
+    }
+}
+
+int check_desc(const t2v_gen_desc* g) {
+    T2V_REQUIRE(g, "null generator descriptor");
+    const int n = g->is_local ? 1 : g->n_downsample;
+    T2V_REQUIRE(g->ngf > 0 && g->ngf % 4 == 0, "ngf=%d must be a positive multiple of 4", g->ngf);
+    T2V_REQUIRE(n >= 1 && n <= 6, "n_downsample=%d out of range", n);
+    T2V_REQUIRE(g->H > 0 && g->W > 0 && g->H % (1 << n) == 0 && g->W % (1 << n) == 0,
+                "H=%d W=%d must be positive multiples of %d", g->H, g->W, 1 << n);
+    T2V_REQUIRE((g->H >> n) >= 2 && (g->W >> n) >= 2, "bottleneck %dx%d too small for reflection pad 1", g->H >> n,
+                g->W >> n);
+    T2V_REQUIRE(g->output_nc == 3, "output_nc=%d: only RGB output is on the path", g->output_nc);
+    T2V_REQUIRE(g->input_nc > 0 && g->prev_nc >= 3, "bad input_nc/prev_nc");
+    T2V_REQUIRE(g->n_blocks >= 0, "bad n_blocks");
+    return T2V_OK;
+}
+
+struct Buffers {
+    float *encA[8], *encB[8];  // encoder activations per level (A: pose/seg, B: prev-image)
+    float* bt[4];              // bottleneck temporaries (resnet chains)
+    float* d;                  // encoder sum
+    float *dimg, *dflow;       // local generator: d + coarse features
+    float *decI[8], *decF[8];  // decoder activations per level
+    float *raw, *fw;
+    float* stats;
+    float* mean_rstd;
+};
+
+void plan_buffers(const t2v_gen_desc& g, const std::vector<LayerSpec>& layers, Arena& a, Buffers& b) {
+    const int G = g.ngf, n = g.is_local ? 1 : g.n_downsample;
+    auto lvl = [&](int l) { return (size_t)(g.H >> l) * (g.W >> l) * (G << l); };
+    for (int l = 0; l <= n; ++l) {
+        b.encA[l] = a.alloc(lvl(l));
+        b.encB[l] = a.alloc(lvl(l));
+    }
+    for (int i = 0; i < 4; ++i) b.bt[i] = a.alloc(lvl(n));
+    b.d = a.alloc(lvl(n));
+    b.dimg = a.alloc(lvl(n));
+    b.dflow = a.alloc(lvl(n));
+    for (int l = 0; l < n; ++l) {
+        b.decI[l] = a.alloc(lvl(l));
+        b.decF[l] = g.no_flow ? nullptr : a.alloc(lvl(l));
+    }
+    b.raw = a.alloc((size_t)g.H * g.W * 4);
+    b.fw = a.alloc((size_t)g.H * g.W * 4);
+    size_t max_stats = 0;
+    int max_c = 4;
+    for (const LayerSpec& L : layers) {
+        ConvPlan pl;
+        if (L.has_norm && build_conv_plan(&L.cd, L.x_cs, true, &pl) == T2V_OK) {
+            const size_t s = (size_t)pl.nparts * L.cd.Cout * 2;
+            if (s > max_stats) max_stats = s;
+        }
+        if (L.cd.Cout > max_c) max_c = L.cd.Cout;
+    }
+    b.stats = a.alloc(max_stats);
+    b.mean_rstd = a.alloc((size_t)max_c * 2);
+}
+
+struct Runner {
+    t2v_ctx* ctx;
+    hipStream_t s;
+    const t2v_gen_desc& g;
+    const std::vector<LayerSpec>& specs;
+    const t2v_layer* layers;
+    Buffers& b;
+    int li = 0;
+
+    // conv (+ fused stats) -> finalize -> apply.  y receives the conv output and is normalised in
+    // place: y = [relu](norm(conv(x))) + res1 + res2
+    int conv_norm(const float* x, float* y, int relu, const float* res1, const float* res2) {
+        const LayerSpec& L = specs[li];
+        const t2v_layer& w = layers[li];
+        ++li;
+        ConvPlan pl;
+        T2V_TRY(build_conv_plan(&L.cd, L.x_cs, true, &pl));
+        const int Cout = L.cd.Cout;
+        T2V_TRY(run_conv(ctx, s, pl, x, w.w, w.bias, y, Cout, b.stats));
+        T2V_TRY(launch_inorm_finalize(s, b.stats, pl.nparts, pl.kp.mtiles, pl.BM, pl.kp.M, Cout, g.eps, b.mean_rstd));
+        const float* gamma = g.norm_affine ? w.gamma : nullptr;
+        const float* beta = g.norm_affine ? w.beta : nullptr;
+        if (g.norm_affine) T2V_REQUIRE(gamma && beta, "layer %d: norm_affine=1 but gamma/beta missing", li - 1);
+        return launch_inorm_apply(s, y, b.mean_rstd, gamma, beta, res1, res2, y, (long)pl.Hout * pl.Wout, Cout, relu);
+    }
+
+    int head(const float* x, float* y) {
+        const LayerSpec& L = specs[li];
+        const t2v_layer& w = layers[li];
+        ++li;
+        ConvPlan pl;
+        T2V_TRY(build_conv_plan(&L.cd, L.x_cs, false, &pl));
+        return run_conv(ctx, s, pl, x, w.w, w.bias, y, 4, nullptr);
+    }
+
+    // x + [pad1,conv3,N,ReLU,pad1,conv3,N](x) (+ extra)
+    int resblock(const float* x, float* t, float* y, const float* extra) {
+        T2V_TRY(conv_norm(x, t, 1, nullptr, nullptr));
+        return conv_norm(t, y, 0, x, extra);
+    }
+
+    // chain of `count` resblocks starting from x (never written); result pointer in *out.
+    // `extra` is added to the output of the LAST block.  tmp: 3 distinct buffers != x.
+    int res_chain(const float* x, int count, float* tmp[3], const float* extra, const float** out) {
+        const float* cur = x;
+        for (int i = 0; i < count; ++i) {
+            float* t = tmp[0];
+            float* y = (cur == tmp[1]) ? tmp[2] : tmp[1];
+            T2V_TRY(resblock(cur, t, y, i == count - 1 ? extra : nullptr));
+            cur = y;
+        }
+        *out = cur;
+        return T2V_OK;
+    }
+
+    // c7,N,R, (d,N,R) x n, RB x nb ; `extra` added to the final output
+    int encoder(const float* x, float** act, int nb, float* tmp[3], const float* extra, const float** out) {
+        const int n = g.is_local ? 1 : g.n_downsample;
+        T2V_TRY(conv_norm(x, act[0], 1, nullptr, nullptr));
+        for (int i = 0; i < n; ++i) {
+            const bool last = (i == n - 1) && nb == 0;
+            T2V_TRY(conv_norm(act[i], act[i + 1], 1, last ? extra : nullptr, nullptr));
+        }
+        if (nb == 0) {
+            *out = act[n];
+            return T2V_OK;
+        }
+        return res_chain(act[n], nb, tmp, extra, out);
+    }
+
+    int decoder(const float* x, float** dec, const float** out) {
+        const int n = g.is_local ? 1 : g.n_downsample;
+        const float* cur = x;
+        for (int i = 0; i < n; ++i) {
+            float* y = dec[n - 1 - i];
+            T2V_TRY(conv_norm(cur, y, 1, nullptr, nullptr));
+            cur = y;
+        }
+        *out = cur;
+        return T2V_OK;
+    }
+};
+
+}  // namespace
+}  // namespace t2v
+
+using namespace t2v;
+
+extern "C" {
+
+int t2v_generator_num_layers(const t2v_gen_desc* d) {
+    if (check_desc(d) != T2V_OK) return -1;
+    std::vector<LayerSpec> L;
+    enumerate_layers(*d, L);
+    return (int)L.size();
+}
+
+int t2v_generator_layer_desc(const t2v_gen_desc* d, int i, t2v_conv_desc* out, int* x_cs) {
+    T2V_TRY(check_desc(d));
+    std::vector<LayerSpec> L;
+    enumerate_layers(*d, L);
+    T2V_REQUIRE(i >= 0 && i < (int)L.size() && out, "layer index %d out of range", i);
+    *out = L[i].cd;
+    if (x_cs) *x_cs = L[i].x_cs;
+    return T2V_OK;
+}
+
+size_t t2v_generator_workspace_bytes(const t2v_gen_desc* d) {
+    if (check_desc(d) != T2V_OK) return 0;
+    std::vector<LayerSpec> L;
+    enumerate_layers(*d, L);
+    Arena a{nullptr, 0};
+    Buffers b;
+    plan_buffers(*d, L, a, b);
+    return a.off;
+}
+
+int t2v_generator_forward(t2v_ctx* ctx, void* stream, const t2v_gen_desc* d, const t2v_layer* layers, int n_layers,
+                          const t2v_gen_io* io, void* workspace, size_t ws_bytes) {
+    T2V_REQUIRE(ctx && layers && io && workspace, "generator_forward: null pointer");
+    T2V_TRY(check_desc(d));
+    std::vector<LayerSpec> specs;
+    enumerate_layers(*d, specs);
+    T2V_REQUIRE(n_layers == (int)specs.size(), "generator_forward: expected %d layers, got %d", (int)specs.size(),
+                n_layers);
+    T2V_REQUIRE(io->pose && io->prev && io->out, "generator_forward: pose/prev/out must be set");
+    T2V_REQUIRE(((uintptr_t)workspace & 255) == 0, "workspace must be 256-byte aligned");
+    if (d->is_local) {
+        T2V_REQUIRE(io->coarse_img_feat, "local generator needs coarse_img_feat");
+        T2V_REQUIRE(d->no_flow || io->coarse_flow_feat, "local generator with flow needs coarse_flow_feat");
+    }
+    for (int i = 0; i < n_layers; ++i)
+        T2V_REQUIRE(layers[i].w && layers[i].bias, "layer %d: weight/bias pointer missing", i);
+    Arena a{reinterpret_cast<char*>(workspace), ws_bytes};
+    Buffers b;
+    plan_buffers(*d, specs, a, b);
+    if (a.overflow) {
+        set_error("generator_forward: workspace %zu bytes < required %zu", ws_bytes, a.off);
+        return T2V_ERR_WORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    Runner r{ctx, s, *d, specs, layers, b};
+    const int n = d->is_local ? 1 : d->n_downsample;
+    const int G = d->ngf;
+    const size_t bott = (size_t)(d->H >> n) * (d->W >> n) * (G << n);
+    const int nb_enc = d->is_local ? 0 : d->n_blocks - d->n_blocks / 2;
+    const int nb_res = d->is_local ? d->n_blocks : d->n_blocks / 2;
+    float* tmp[3] = {b.bt[0], b.bt[1], b.bt[2]};
+
+    // d = model_down_seg(x) + model_down_img(prev): the sum is fused into the last apply of the
+    // second encoder (residual input), so `d` is never a separate pass.
+    const float* segout;
+    T2V_TRY(r.encoder(io->pose, b.encA, nb_enc, tmp, nullptr, &segout));
+    // keep segout alive: the second encoder must not use its buffer as a temporary
+    float* tmp2[3];
+    {
+        float* cand[5] = {b.bt[0], b.bt[1], b.bt[2], b.bt[3], b.d};
+        int k = 0;
+        for (int i = 0; i < 5 && k < 3; ++i)
+            if (cand[i] != segout) tmp2[k++] = cand[i];
+    }
+    const float* dsum;
+    T2V_TRY(r.encoder(io->prev, b.encB, nb_enc, tmp2, segout, &dsum));
+
+    const float* img_in = dsum;
+    const float* flow_in = dsum;
+    if (d->is_local) {
+        T2V_TRY(launch_add(s, dsum, io->coarse_img_feat, b.dimg, (long)bott));
+        img_in = b.dimg;
+        if (!d->no_flow) {
+            T2V_TRY(launch_add(s, dsum, io->coarse_flow_feat, b.dflow, (long)bott));
+            flow_in = b.dflow;
+        }
+    }
+    // temporaries for the residual trunks: anything that is not dsum / img_in / flow_in
+    float* tmp3[3];
+    {
+        float* cand[7] = {b.bt[0], b.bt[1], b.bt[2], b.bt[3], b.d, b.encA[n], b.encB[n]};
+        int k = 0;
+        for (int i = 0; i < 7 && k < 3; ++i)
+            if (cand[i] != dsum && cand[i] != img_in && cand[i] != flow_in) tmp3[k++] = cand[i];
+    }
+    const float *res_img, *img_feat;
+    T2V_TRY(r.res_chain(img_in, nb_res, tmp3, nullptr, &res_img));
+    T2V_TRY(r.decoder(res_img, b.decI, &img_feat));
+    const bool blend = !(d->no_flow || io->use_raw_only);
+    float* raw = io->raw ? io->raw : (blend ? b.raw : io->out);
+    T2V_TRY(r.head(img_feat, raw));
+    if (io->img_feat)
+        T2V_HIP_CHECK(hipMemcpyAsync(io->img_feat, img_feat, (size_t)d->H * d->W * G * sizeof(float),
+                                     hipMemcpyDeviceToDevice, s));
+    if (!d->no_flow) {
+        const float *res_flow, *flow_feat;
+        T2V_TRY(r.res_chain(flow_in, nb_res, tmp3, nullptr, &res_flow));
+        T2V_TRY(r.decoder(res_flow, b.decF, &flow_feat));
+        float* fw = io->flow_w ? io->flow_w : b.fw;
+        T2V_TRY(r.head(flow_feat, fw));
+        if (io->flow_feat)
+            T2V_HIP_CHECK(hipMemcpyAsync(io->flow_feat, flow_feat, (size_t)d->H * d->W * G * sizeof(float),
+                                         hipMemcpyDeviceToDevice, s));
+        if (blend) {
+            const int prev_cs = round_up(d->prev_nc, 4);
+            T2V_TRY(launch_warp_composite(s, raw, fw, io->prev, prev_cs, d->prev_nc - 3, io->out, nullptr, d->H,
+                                          d->W));
+        }
+    }
+    if (!blend && raw != io->out)
+        T2V_HIP_CHECK(hipMemcpyAsync(io->out, raw, (size_t)d->H * d->W * 4 * sizeof(float), hipMemcpyDeviceToDevice,
+                                     s));
+    T2V_REQUIRE(r.li == n_layers, "internal: consumed %d of %d layers", r.li, n_layers);
+    return T2V_OK;
+}
+
+}  // extern "C"

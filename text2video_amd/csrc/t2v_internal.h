@@ -1,0 +1,114 @@
+// Internal declarations shared by the HIP translation units of libt2v_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+#include "../../include/t2v.h"
+
+namespace t2v {
+
+// ---------------------------------------------------------------------------------------------
+// error plumbing: nothing throws across the C ABI; every entry point returns t2v_status and
+// leaves a thread-local message for t2v_last_error().
+// ---------------------------------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+#define T2V_HIP_CHECK(expr)                                                            \
+    do {                                                                               \
+        hipError_t _e = (expr);                                                        \
+        if (_e != hipSuccess) {                                                        \
+            ::t2v::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr,             \
+                             hipGetErrorString(_e));                                   \
+            return T2V_ERR_HIP;                                                        \
+        }                                                                              \
+    } while (0)
+#define T2V_REQUIRE(cond, ...)                                                         \
+    do {                                                                               \
+        if (!(cond)) {                                                                 \
+            ::t2v::set_error(__VA_ARGS__);                                             \
+            return T2V_ERR_INVALID;                                                    \
+        }                                                                              \
+    } while (0)
+#define T2V_TRY(expr)                                                                  \
+    do {                                                                               \
+        int _s = (expr);                                                               \
+        if (_s != T2V_OK) return _s;                                                   \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// implicit-GEMM convolution kernel parameters (conv_igemm.hip)
+//   GEMM view:  D[m][n] = sum_k A[m][k] * B[n][k]
+//     m = pixel of the "GEMM pixel grid" (Hm x Wm), n = output channel,
+//     k = tap * Cin_s + c   (tap-major, channel-minor; NHWC makes c contiguous)
+//   A is gathered on the fly from the NHWC input (reflect / zero padding resolved in the
+//   loader's address computation -- SpatialReflectionPadding is never materialised),
+//   B is the pre-packed weight [Cout_p][Kp] (K contiguous, zero padded).
+//   A transposed convolution (k3 s2 p1 op1) is 4 sub-pixel "phases", each a small-tap conv on
+//   the input grid whose output is scattered with stride 2 (no zero insertion).
+// ---------------------------------------------------------------------------------------------
+constexpr int kMaxTaps = 52;
+constexpr int kMaxPhases = 4;
+constexpr int kBK = 32;  // K-depth of one LDS stage (floats): 128-byte rows
+
+struct ConvPhase {
+    int ntaps;     // taps of this phase
+    int tap0;      // first entry in tdy/tdx
+    int nk;        // number of BK stages (= Kp / 32)
+    int Kp;        // padded K of this phase
+    long w_off;    // float offset of this phase's packed weights
+    int oy0, ox0;  // output offset (sub-pixel phase)
+};
+
+struct ConvKParams {
+    const float* x;
+    const float* w;
+    const float* bias;
+    float* y;
+    float* stats;  // [nparts][Cout][2] (mean_b, M2_b) or nullptr
+    const float* zero;  // >= 16 bytes of zeros in device memory
+    int Hin, Win, Cin_s;
+    int Wm, M;
+    int Cout, Cout_s, Wout;
+    int stride, ostride;
+    int pad_mode, act;
+    float act_scale;  // flow multiplier of T2V_ACT_FLOW_W
+    int mtiles, ntiles, nphases;
+    int KW, pad;  // MODE 1 (Cin_s % 32 != 0, regular conv): tap -> (kh,kw) by arithmetic
+    ConvPhase ph[kMaxPhases];
+    int tdy[kMaxTaps];  // ints: read with scalar loads (uniform index), never a vector load
+    int tdx[kMaxTaps];
+};
+
+enum ConvTile { kTileL = 0 /*128x128, 32x32x2 MFMA*/, kTileS = 1 /*256x16, 16x16x4 MFMA*/ };
+int conv_tile_for(int Cout);
+void conv_tile_dims(int tile, int* BM, int* BN);
+int launch_conv_igemm(hipStream_t s, const ConvKParams& p, int tile);
+
+// elementwise.hip
+int launch_inorm_finalize(hipStream_t s, const float* stats, int nparts, int mtiles, int BM, int M, int C,
+                          float eps, float* mean_rstd);
+int launch_inorm_apply(hipStream_t s, const float* x, const float* mean_rstd, const float* gamma,
+                       const float* beta, const float* res1, const float* res2, float* y, long npix, int C,
+                       int relu);
+int launch_pack_conv_weight(hipStream_t s, const float* w, float* packed, int Cout, int Cin, int KH, int KW,
+                            int Cin_s, int Kp, int Cout_p);
+int launch_pack_convT_weight(hipStream_t s, const float* w, float* packed, int Cin, int Cout, int Cin_s,
+                             int Cout_p);
+// taps of sub-pixel phase `phase` of ConvTranspose2d(k3,s2,p1,op1); shared by packer and launcher
+void convT_phase_taps_host(int phase, int* ntaps, int kh[4], int kw[4], int dy[4], int dx[4], int* a, int* b);
+int launch_nchw_to_nhwc(hipStream_t s, const float* src, float* dst, int C, int H, int W, int Cs);
+int launch_nhwc_to_nchw(hipStream_t s, const float* src, float* dst, int C, int H, int W, int Cs);
+int launch_add(hipStream_t s, const float* a, const float* b, float* y, long n);
+int launch_warp_composite(hipStream_t s, const float* raw, const float* fw, const float* prev, int prev_cs,
+                          int prev_c0, float* out, float* warp_out, int H, int W);
+int launch_avgpool3s2(hipStream_t s, const float* x, float* y, int H, int W, int C);
+int launch_to_u8(hipStream_t s, const float* x, uint8_t* y, long n);
+int launch_u8_pose_to_f32(hipStream_t s, const uint8_t* src, float* dst, long npix, int Cs, int c0);
+int launch_copy_channels(hipStream_t s, const float* src, int src_cs, int src_c0, float* dst, int dst_cs,
+                         int dst_c0, int nc, long npix);
+
+}  // namespace t2v
+
+struct t2v_ctx {
+    int device;
+    float* zero_page;  // 4 KiB of zeros (owned)
+};

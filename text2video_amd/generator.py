@@ -1,0 +1,293 @@
+"""Host side of the vid2vid generators on MI355X: checkpoint -> packed weights -> HIP forward.
+
+Mirrors the reference-side objects for the hot path:
+  * `HipGenerator`   ~ networks.CompositeGenerator / CompositeLocalGenerator (netG0 / netG1)
+  * `Vid2VidModelG`  ~ models/vid2vid_model_G.py: `inference(A, B, inst)` with the 2-deep FIFO of
+                       generated frames, `--no_first_img` first-frame rule and the spatial pyramid.
+State-dict key names are upstream's (nn.Sequential indices), so a real
+checkpoints/<name>/latest_net_G0.pth loads unchanged (SURVEY section 5 "Checkpoint / resume").
+All device math goes through libt2v_hip.so; torch only owns memory and the stream.
+"""
+import ctypes
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+from ._lib import GenDesc, GenIO, Layer, check
+
+
+@dataclass
+class GeneratorSpec:
+    input_nc: int = 9          # opt.input_nc(3) * n_frames_G(3)
+    prev_nc: int = 6           # (n_frames_G-1) * output_nc
+    output_nc: int = 3
+    ngf: int = 128
+    n_downsample: int = 3      # --n_downsample_G
+    n_blocks: int = 9          # --n_blocks (global) / --n_blocks_local (local)
+    no_flow: bool = False      # --no_flow, implied by --openpose_only
+    norm: str = "batch"        # --norm {batch: BatchNorm2d(affine) in train mode == IN+affine | instance}
+    is_local: bool = False
+    scale: int = 0             # spatial scale index s; flow multiplier 20*2^s
+
+    @property
+    def n_down(self):
+        return 1 if self.is_local else self.n_downsample
+
+
+def layer_keys(spec):
+    """Canonical layer order of t2v_generator_forward -> [(conv_key, norm_key|None, kind)], kind in
+    {'conv','convT','head','flow_w'}.  Key names per SURVEY App. A.1 (last paragraph) / A.2."""
+    out = []
+    n = spec.n_down
+
+    def enc(prefix):
+        out.append((prefix + ".1", prefix + ".2", "conv"))
+        for i in range(n):
+            out.append((prefix + ".%d" % (4 + 3 * i), prefix + ".%d" % (5 + 3 * i), "conv"))
+
+    def rbs(prefix, first, count):
+        for j in range(count):
+            base = prefix + ".%d.conv_block" % (first + j)
+            out.append((base + ".1", base + ".2", "conv"))
+            out.append((base + ".5", base + ".6", "conv"))
+
+    def ups(prefix, first):
+        for i in range(n):
+            out.append((prefix + ".%d" % (first + 3 * i), prefix + ".%d" % (first + 3 * i + 1), "convT"))
+
+    if not spec.is_local:
+        nb_enc = spec.n_blocks - spec.n_blocks // 2
+        nb_res = spec.n_blocks // 2
+        enc("model_down_seg"); rbs("model_down_seg", 4 + 3 * n, nb_enc)
+        enc("model_down_img"); rbs("model_down_img", 4 + 3 * n, nb_enc)
+        rbs("model_res_img", 0, nb_res); ups("model_up_img", 0)
+        out.append(("model_final_img.1", None, "head"))
+        if not spec.no_flow:
+            rbs("model_res_flow", 0, nb_res); ups("model_up_flow", 0)
+            out.append((("model_final_flow.1", "model_final_w.1"), None, "flow_w"))
+    else:
+        enc("model_down_seg")
+        enc("model_down_img")
+        rbs("model_up_img", 0, spec.n_blocks); ups("model_up_img", spec.n_blocks)
+        out.append(("model_final_img.1", None, "head"))
+        if not spec.no_flow:
+            rbs("model_up_flow", 0, spec.n_blocks); ups("model_up_flow", spec.n_blocks)
+            out.append((("model_final_flow.1", "model_final_w.1"), None, "flow_w"))
+    return out
+
+
+def _gen_desc(spec, H, W):
+    return GenDesc(H, W, spec.input_nc, spec.prev_nc, spec.output_nc, spec.ngf, spec.n_downsample, spec.n_blocks,
+                   int(spec.no_flow), int(spec.norm == "batch"), int(spec.is_local), 20.0 * (2 ** spec.scale), 1e-5)
+
+
+def layer_shapes(spec):
+    """[(state-dict key, torch-layout shape, role)] for this generator; role in
+    {'conv_w','conv_b','norm_w','norm_b'}.  Shapes do not depend on H, W."""
+    lib = _lib.load()
+    gd = _gen_desc(spec, 64, 64)
+    keys = layer_keys(spec)
+    if lib.t2v_generator_num_layers(ctypes.byref(gd)) != len(keys):
+        raise RuntimeError("layer list mismatch between generator.py and libt2v_hip.so: %s"
+                           % lib.t2v_last_error().decode())
+    out = []
+    for i, (ck, nk, kind) in enumerate(keys):
+        cd, xcs = _lib.ConvDesc(), ctypes.c_int()
+        check(lib.t2v_generator_layer_desc(ctypes.byref(gd), i, ctypes.byref(cd), ctypes.byref(xcs)), "layer_desc")
+        if kind == "flow_w":
+            out += [(ck[0] + ".weight", (2, cd.Cin, cd.kH, cd.kW), "conv_w"), (ck[0] + ".bias", (2,), "conv_b"),
+                    (ck[1] + ".weight", (1, cd.Cin, cd.kH, cd.kW), "conv_w"), (ck[1] + ".bias", (1,), "conv_b")]
+        else:
+            wshape = (cd.Cin, cd.Cout, 3, 3) if kind == "convT" else (cd.Cout, cd.Cin, cd.kH, cd.kW)
+            out += [(ck + ".weight", wshape, "conv_w"), (ck + ".bias", (cd.Cout,), "conv_b")]
+        if nk is not None and spec.norm == "batch":
+            out += [(nk + ".weight", (cd.Cout,), "norm_w"), (nk + ".bias", (cd.Cout,), "norm_b")]
+    return out
+
+
+def synthetic_state_dict(spec, seed=1, init="uniform_fan_in"):
+    """Deterministic random-init weights (numpy RNG, platform independent) in upstream key names.
+
+    init='uniform_fan_in': U(-1/sqrt(fan_in), +) for conv weight AND bias = torch-0.4.1 default
+        ($SP/torch/nn/modules/conv.py:40-47; fan_in = weight.size(1)*kH*kW) -- the BASELINE.md /
+        SURVEY 8(d) config-2 weights.
+    init='vid2vid': vid2vid's weights_init, N(0,0.02) conv weights [RECALL].
+    Norm affine params (norm='batch'): gamma ~ N(1,0.02) (weights_init), beta ~ N(0,0.1) so the
+    affine path is exercised.
+    """
+    rng = np.random.default_rng(seed)
+    sd = {}
+    bound = 1.0
+    for key, shape, role in layer_shapes(spec):
+        if role == "conv_w":
+            bound = 1.0 / np.sqrt(shape[1] * shape[2] * shape[3])
+            a = rng.normal(0.0, 0.02, size=shape) if init == "vid2vid" else rng.uniform(-bound, bound, size=shape)
+        elif role == "conv_b":
+            a = rng.uniform(-bound, bound, size=shape)
+        elif role == "norm_w":
+            a = rng.normal(1.0, 0.02, size=shape)
+        else:
+            a = rng.normal(0.0, 0.1, size=shape)
+        sd[key] = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+    return sd
+
+
+class HipGenerator:
+    """One generator scale resident on the GPU: packed weights + workspace + forward()."""
+
+    def __init__(self, spec, device="cuda"):
+        self.spec = spec
+        self.device = torch.device(device)
+        self.ctx = ops.context(self.device)
+        self.lib = self.ctx.lib
+        self.keys = layer_keys(spec)
+        self._params = []      # keeps device tensors alive
+        self._layers = None
+        self._ws = None
+        self._ws_hw = None
+
+    # -- weights ---------------------------------------------------------------------------------
+    def load_state_dict(self, sd):
+        """sd: upstream-named tensors (CPU or GPU).  Repacks every conv weight on the device."""
+        spec = self.spec
+        gd = _gen_desc(spec, 64, 64)
+        n = len(self.keys)
+        arr = (Layer * n)()
+        self._params = []
+
+        def dev(t):
+            t = t.detach().to(self.device, torch.float32).contiguous()
+            self._params.append(t)
+            return t
+
+        for i, (ck, nk, kind) in enumerate(self.keys):
+            cd, xcs = _lib.ConvDesc(), ctypes.c_int()
+            check(self.lib.t2v_generator_layer_desc(ctypes.byref(gd), i, ctypes.byref(cd), ctypes.byref(xcs)),
+                  "layer_desc")
+            if kind == "flow_w":
+                w = torch.cat([sd[ck[0] + ".weight"], sd[ck[1] + ".weight"]], 0)
+                b = torch.cat([sd[ck[0] + ".bias"], sd[ck[1] + ".bias"]], 0)
+            else:
+                w, b = sd[ck + ".weight"], sd[ck + ".bias"]
+            # raw torch-layout weight is transient: the pack kernel runs on the current stream and the
+            # caching allocator recycles the buffer in stream order
+            packed = ops.pack_conv_weight(w.detach().to(self.device, torch.float32).contiguous(), cd, xcs.value)
+            self._params.append(packed)
+            arr[i].w = packed.data_ptr()
+            arr[i].bias = dev(b).data_ptr()
+            if nk is not None and spec.norm == "batch":
+                arr[i].gamma = dev(sd[nk + ".weight"]).data_ptr()
+                arr[i].beta = dev(sd[nk + ".bias"]).data_ptr()
+        torch.cuda.current_stream().synchronize()
+        self._layers = arr
+        return self
+
+    # -- forward ---------------------------------------------------------------------------------
+    def _workspace(self, H, W):
+        if self._ws_hw != (H, W):
+            gd = _gen_desc(self.spec, H, W)
+            nbytes = self.lib.t2v_generator_workspace_bytes(ctypes.byref(gd))
+            if nbytes == 0:
+                raise RuntimeError("generator: %s" % self.lib.t2v_last_error().decode())
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            self._ws_hw = (H, W)
+            self._gd = gd
+        return self._ws
+
+    def forward(self, pose, prev, use_raw_only=False, coarse_img_feat=None, coarse_flow_feat=None,
+                want=("out",)):
+        """pose [H,W,round_up4(input_nc)], prev [H,W,round_up4(prev_nc)] NHWC fp32 on the device.
+        Returns dict of NHWC tensors for the names in `want` ⊆ {out, raw, flow_w, img_feat, flow_feat}."""
+        if self._layers is None:
+            raise RuntimeError("HipGenerator.forward before load_state_dict")
+        H, W = pose.shape[0], pose.shape[1]
+        ws = self._workspace(H, W)
+        res = {}
+
+        def buf(name, c):
+            if name in want:
+                res[name] = torch.empty(H, W, c, dtype=torch.float32, device=self.device)
+                return res[name].data_ptr()
+            return None
+
+        io = GenIO()
+        io.pose, io.prev = pose.data_ptr(), prev.data_ptr()
+        io.coarse_img_feat = coarse_img_feat.data_ptr() if coarse_img_feat is not None else None
+        io.coarse_flow_feat = coarse_flow_feat.data_ptr() if coarse_flow_feat is not None else None
+        io.use_raw_only = int(use_raw_only)
+        res["out"] = torch.empty(H, W, 4, dtype=torch.float32, device=self.device)
+        io.out = res["out"].data_ptr()
+        io.raw = buf("raw", 4)
+        io.flow_w = buf("flow_w", 4) if not self.spec.no_flow else None
+        io.img_feat = buf("img_feat", self.spec.ngf)
+        io.flow_feat = buf("flow_feat", self.spec.ngf) if not self.spec.no_flow else None
+        check(self.lib.t2v_generator_forward(self.ctx.handle, ops._stream(), ctypes.byref(self._gd), self._layers,
+                                             len(self.keys), ctypes.byref(io), ctypes.c_void_p(ws.data_ptr()),
+                                             ws.numel()), "generator_forward")
+        return res
+
+
+class Vid2VidModelG:
+    """`Vid2VidModelG.inference` on the HIP path.
+
+    nets: [HipGenerator scale 0 (coarsest, global), scale 1 (local), ...]
+    """
+
+    def __init__(self, nets, n_frames_G=3, output_nc=3, no_first_img=True):
+        self.nets = nets
+        self.n_scales = len(nets)
+        self.tG = n_frames_G
+        self.output_nc = output_nc
+        self.no_first_img = no_first_img
+        self.device = nets[0].device
+        self.prev = None  # per scale: NHWC [H,W,8] FIFO of the tG-1 previous outputs
+
+    def reset(self):
+        """`model.fake_B_prev = None` on data['change_seq']."""
+        self.prev = None
+
+    @torch.no_grad()
+    def inference_nhwc(self, pose):
+        """pose: [H,W,round_up4(3*tG)] fp32 NHWC window (oldest frame first).  Returns [H,W,4] (RGB0)."""
+        first = self.prev is None
+        if first and not self.no_first_img:
+            raise NotImplementedError("first-frame generator: the reference always passes --no_first_img")
+        # spatial pyramid: index 0 = finest
+        poses = [pose]
+        for _ in range(1, self.n_scales):
+            poses.append(ops.avgpool3x3s2(poses[-1]))
+        pcs = ops.round_up(self.nets[0].spec.prev_nc, 4)
+        if first:
+            self.prev = [torch.zeros(p.shape[0], p.shape[1], pcs, dtype=torch.float32, device=self.device)
+                         for p in poses]
+        use_raw_only = self.no_first_img and first
+        img_feat = flow_feat = None
+        out = None
+        for s in range(self.n_scales):
+            si = self.n_scales - 1 - s
+            net = self.nets[s]
+            want = ("out",) if s == self.n_scales - 1 else \
+                (("out", "img_feat") if net.spec.no_flow else ("out", "img_feat", "flow_feat"))
+            r = net.forward(poses[si], self.prev[si], use_raw_only, img_feat, flow_feat, want)
+            out = r["out"]
+            img_feat, flow_feat = r.get("img_feat"), r.get("flow_feat")
+            # fake_B_prev = cat(fake_B_prev[1:], fake_B): shift the FIFO (ping-pong buffer)
+            nc = self.output_nc
+            newp = torch.zeros_like(self.prev[si])
+            for f in range(self.tG - 2):
+                ops.copy_channels(self.prev[si], (f + 1) * nc, newp, f * nc, nc)
+            ops.copy_channels(out, 0, newp, (self.tG - 2) * nc, nc)
+            self.prev[si] = newp
+        return out
+
+    @torch.no_grad()
+    def inference(self, A, B=None, inst=None):
+        """Reference signature.  A: [1, tG, 3, H, W] fp32 device tensor in [-1,1].
+        Returns (fake_B [1,3,H,W], real_A last frame [3,H,W]) like upstream."""
+        _, tG, nc, H, W = A.shape
+        pose = ops.nchw_to_nhwc(A.reshape(tG * nc, H, W).contiguous())
+        out = self.inference_nhwc(pose)
+        fake_B = ops.nhwc_to_nchw(out, self.output_nc).unsqueeze(0)
+        return fake_B, A[0, -1]

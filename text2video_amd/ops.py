@@ -1,0 +1,186 @@
+"""Operator-level Python surface over libt2v_hip.so.
+
+Mirrors the reference's operator interface for the hot path -- the torch.nn.functional calls the
+vid2vid generator makes on torch 0.4.1 ($SP/torch/nn/functional.py: conv2d, conv_transpose2d,
+instance_norm:1258, grid_sample:2046, pad(reflect):2169, avg_pool2d) -- but on NHWC fp32 device
+tensors and with the fusions the HIP kernels implement.  PyTorch is used only as the device
+allocator / stream provider; every computation below is a call through the C ABI.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import ACT_FLOW_W, ACT_NONE, ACT_TANH, PAD_REFLECT, PAD_ZERO, ConvDesc, check  # noqa: F401
+
+_contexts = {}
+
+
+def context(device=None):
+    """Per-device t2v context (created lazily; requires a visible gfx950 GPU)."""
+    if not torch.cuda.is_available():
+        raise RuntimeError("text2video_amd: no HIP device visible; the frame-synthesis path has no CPU fallback")
+    dev = torch.cuda.current_device() if device is None else torch.device(device).index or 0
+    c = _contexts.get(dev)
+    if c is None:
+        with torch.cuda.device(dev):
+            c = _lib.Context(dev)
+        _contexts[dev] = c
+    return c
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _chk(t, name):
+    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise ValueError("%s must be a contiguous fp32 device tensor" % name)
+
+
+def round_up(v, m):
+    return (v + m - 1) // m * m
+
+
+def conv_desc(H, W, Cin, Cout, k, stride=1, pad=0, pad_mode=PAD_ZERO, transposed=False, act=ACT_NONE,
+              act_scale=1.0):
+    return ConvDesc(H, W, Cin, Cout, k, k, stride, pad, pad_mode, int(transposed), act, act_scale)
+
+
+def conv_out_dims(desc):
+    h, w = ctypes.c_int(), ctypes.c_int()
+    check(_lib.load().t2v_conv_out_dims(ctypes.byref(desc), ctypes.byref(h), ctypes.byref(w)), "conv_out_dims")
+    return h.value, w.value
+
+
+def pack_conv_weight(weight, desc, x_cs=None):
+    """weight: torch layout ([Cout,Cin,kH,kW], or [Cin,Cout,3,3] if desc.transposed) on the device."""
+    c = context()
+    _chk(weight, "weight")
+    x_cs = round_up(desc.Cin, 4) if x_cs is None else x_cs
+    n = c.lib.t2v_conv_packed_weight_floats(ctypes.byref(desc), x_cs)
+    if n == 0:
+        raise RuntimeError("pack_conv_weight: %s" % c.lib.t2v_last_error().decode())
+    packed = torch.empty(n, dtype=torch.float32, device=weight.device)
+    check(c.lib.t2v_conv_pack_weight(c.handle, _stream(), ctypes.byref(desc), x_cs, _p(weight), _p(packed)),
+          "conv_pack_weight")
+    return packed
+
+
+def conv_stats_buffer(desc, device):
+    n = _lib.load().t2v_conv_stats_floats(ctypes.byref(desc))
+    return torch.empty(max(n, 1), dtype=torch.float32, device=device)
+
+
+def conv2d(x, packed_w, bias, desc, y_cs=None, stats=None, out=None):
+    """x: [H,W,x_cs] NHWC.  Returns y [Hout,Wout,y_cs].  Reflection padding, bias, the head
+    activation and (if `stats` is given) the instance-norm partial statistics are fused."""
+    c = context()
+    _chk(x, "x")
+    x_cs = x.shape[-1]
+    ho, wo = conv_out_dims(desc)
+    y_cs = round_up(desc.Cout, 4) if y_cs is None else y_cs
+    y = out if out is not None else torch.empty(ho, wo, y_cs, dtype=torch.float32, device=x.device)
+    check(c.lib.t2v_conv2d_forward(c.handle, _stream(), ctypes.byref(desc), _p(x), x_cs, _p(packed_w), _p(bias),
+                                   _p(y), y_cs, _p(stats)), "conv2d_forward")
+    return y
+
+
+def instance_norm_finalize(stats, desc, eps=1e-5, out=None):
+    c = context()
+    mr = out if out is not None else torch.empty(desc.Cout, 2, dtype=torch.float32, device=stats.device)
+    check(c.lib.t2v_instance_norm_finalize(c.handle, _stream(), ctypes.byref(desc), _p(stats), eps, _p(mr)),
+          "instance_norm_finalize")
+    return mr
+
+
+def instance_norm_apply(x, mean_rstd, gamma=None, beta=None, res1=None, res2=None, relu=False, out=None):
+    c = context()
+    _chk(x, "x")
+    C = x.shape[-1]
+    npix = x.numel() // C
+    y = out if out is not None else torch.empty_like(x)
+    check(c.lib.t2v_instance_norm_apply(c.handle, _stream(), _p(x), _p(mean_rstd), _p(gamma), _p(beta), _p(res1),
+                                        _p(res2), _p(y), npix, C, int(relu)), "instance_norm_apply")
+    return y
+
+
+def conv_norm_act(x, packed_w, bias, desc, gamma=None, beta=None, relu=True, res1=None, res2=None, eps=1e-5):
+    """[ReflPad,] Conv, InstanceNorm(+affine), [ReLU], [+res]: one conv launch + finalize + apply."""
+    stats = conv_stats_buffer(desc, x.device)
+    y = conv2d(x, packed_w, bias, desc, y_cs=desc.Cout, stats=stats)
+    mr = instance_norm_finalize(stats, desc, eps)
+    return instance_norm_apply(y, mr, gamma, beta, res1, res2, relu, out=y)
+
+
+def flow_warp_composite(raw, fw, prev, prev_c0, want_warp=False):
+    """raw,fw: [H,W,4]; prev: [H,W,prev_cs] (3 channels from prev_c0).  out = raw*w + warp*(1-w)."""
+    c = context()
+    H, W = raw.shape[0], raw.shape[1]
+    out = torch.empty_like(raw)
+    warp = torch.empty_like(raw) if want_warp else None
+    check(c.lib.t2v_flow_warp_composite(c.handle, _stream(), _p(raw), _p(fw), _p(prev), prev.shape[-1], prev_c0,
+                                        _p(out), _p(warp), H, W), "flow_warp_composite")
+    return (out, warp) if want_warp else out
+
+
+def avgpool3x3s2(x):
+    """AvgPool2d(3, 2, 1, count_include_pad=False) on [H,W,C]."""
+    c = context()
+    _chk(x, "x")
+    H, W, C = x.shape
+    y = torch.empty((H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1, C, dtype=torch.float32, device=x.device)
+    check(c.lib.t2v_avgpool3x3s2(c.handle, _stream(), _p(x), _p(y), H, W, C), "avgpool3x3s2")
+    return y
+
+
+def nchw_to_nhwc(x, cs=None, out=None):
+    """[C,H,W] -> [H,W,cs] (extra channels zero)."""
+    c = context()
+    _chk(x, "x")
+    C, H, W = x.shape
+    cs = round_up(C, 4) if cs is None else cs
+    y = out if out is not None else torch.empty(H, W, cs, dtype=torch.float32, device=x.device)
+    check(c.lib.t2v_nchw_to_nhwc(c.handle, _stream(), _p(x), _p(y), C, H, W, cs), "nchw_to_nhwc")
+    return y
+
+
+def nhwc_to_nchw(x, C=None):
+    """[H,W,cs] -> [C,H,W]."""
+    c = context()
+    _chk(x, "x")
+    H, W, cs = x.shape
+    C = cs if C is None else C
+    y = torch.empty(C, H, W, dtype=torch.float32, device=x.device)
+    check(c.lib.t2v_nhwc_to_nchw(c.handle, _stream(), _p(x), _p(y), C, H, W, cs), "nhwc_to_nchw")
+    return y
+
+
+def pose_u8_to_f32(src_u8, dst, c0):
+    """uint8 [H,W,3] pose map -> channels [c0,c0+3) of dst [H,W,cs] as (v/255-0.5)/0.5."""
+    c = context()
+    H, W, _ = src_u8.shape
+    check(c.lib.t2v_pose_u8_to_f32(c.handle, _stream(), _p(src_u8), _p(dst), H * W, dst.shape[-1], c0),
+          "pose_u8_to_f32")
+    return dst
+
+
+def tensor2im_u8(x):
+    """util.tensor2im on the device: uint8 of (x+1)/2*255, same layout."""
+    c = context()
+    _chk(x, "x")
+    y = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    check(c.lib.t2v_tensor2im_u8(c.handle, _stream(), _p(x), _p(y), x.numel()), "tensor2im_u8")
+    return y
+
+
+def copy_channels(src, src_c0, dst, dst_c0, nc):
+    c = context()
+    npix = src.numel() // src.shape[-1]
+    check(c.lib.t2v_copy_channels(c.handle, _stream(), _p(src), src.shape[-1], src_c0, _p(dst), dst.shape[-1],
+                                  dst_c0, nc, npix), "copy_channels")
+    return dst
