@@ -262,7 +262,7 @@ class Vid2VidInferenceRef:
         first = self.fake_B_prev is None
         if first:
             assert self.no_first_img, "first-frame generator not part of the reference's flag set"
-            z = torch.zeros(tG - 1, self.output_nc, H, W)
+            z = torch.zeros(tG - 1, self.output_nc, H, W, dtype=A.dtype)
             self.fake_B_prev = self._pyr(z)
         real_A = self._pyr(A)
         use_raw_only = self.no_first_img and first

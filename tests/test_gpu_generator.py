@@ -18,7 +18,7 @@ def _pose_seq(n, H, W, seed=0):
     return torch.from_numpy(a)
 
 
-def _build(spec_kw, scales=1, seed=1, init="vid2vid"):
+def _build(spec_kw, scales=1, seed=1, init="vid2vid", flow_gain=0.1):
     from oracle.generator_ref import CompositeGenerator, CompositeLocalGenerator, Vid2VidInferenceRef
     from text2video_amd.generator import GeneratorSpec, HipGenerator, Vid2VidModelG, synthetic_state_dict
     ref_nets, hip_nets = [], []
@@ -32,7 +32,7 @@ def _build(spec_kw, scales=1, seed=1, init="vid2vid"):
             kw.update(ngf=spec_kw["ngf"] // (2 ** s), n_blocks=2, is_local=True, scale=s)
             spec = GeneratorSpec(**kw)
             net = CompositeLocalGenerator(spec.input_nc, 3, spec.prev_nc, spec_kw["ngf"], 2, s, spec.no_flow, spec.norm)
-        sd = synthetic_state_dict(spec, seed + s, init)
+        sd = synthetic_state_dict(spec, seed + s, init, flow_gain)
         missing, unexpected = net.load_state_dict(sd, strict=False)
         assert not unexpected and all(("running" in k or "num_batches" in k) for k in missing), (missing, unexpected)
         ref_nets.append(net)
@@ -49,38 +49,93 @@ CASES = [
 ]
 
 
+TOL_FORCED = 2e-4  # same inputs in, fp32 summation-order differences only (observed ~1e-5)
+
+
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
-def test_sequence_matches_oracle(case):
+def test_sequence_teacher_forced(case):
+    """Every frame of a sequence with the oracle's own previous frames as the recurrent input:
+    isolates the kernels from the (chaotic, for random-init weights) frame recurrence."""
+    name, kw, scales, H, W = case
+    for flow_gain in ((0.1, 1.0) if not kw["no_flow"] else (1.0,)):
+        ref, hip = _build(kw, scales, flow_gain=flow_gain)
+        poses = _pose_seq(6, H, W, seed=5)
+        for t in range(2, 6):
+            A = poses[t - 2:t + 1].unsqueeze(0)
+            first = ref.fake_B_prev is None
+            if not first:
+                hip.load_prev(ref.fake_B_prev)
+            want = ref.inference(A)
+            got, _ = hip.inference(A.to("cuda:0"))
+            assert got.shape == want.shape
+            if first:
+                continue  # zero-image first frame: see test_first_frame_zero_prev
+            err = (got.cpu() - want).abs().max().item()
+            # full-gain random flow heads (+-40 px) multiply the conv rounding differences by the
+            # x20 flow multiplier times the image gradient: north_star tolerance there
+            tol = TOL_FORCED if (kw["no_flow"] or flow_gain < 1.0) else TOL
+            assert err <= tol, "%s gain %g frame %d: max|delta|=%g" % (name, flow_gain, t, err)
+
+
+@pytest.mark.parametrize("case", [c for c in CASES if c[1]["norm"] == "batch"],
+                         ids=[c[0] for c in CASES if c[1]["norm"] == "batch"])
+def test_first_frame_zero_prev(case):
+    """--no_first_img first frame: zero previous frames, raw output only.  The prev-image encoder
+    sees an all-zero image, i.e. norm layers over constant maps: with affine norm (upstream default
+    --norm batch) that is well defined and must match to the north_star tolerance.  (With
+    InstanceNorm(affine=False) it is 0/0 -- rounding noise renormalised to unit variance -- in the
+    reference algorithm itself, so no implementation can be compared there.)  Also checks that a
+    reset() (change_seq) reproduces the first frame bit for bit."""
     name, kw, scales, H, W = case
     ref, hip = _build(kw, scales)
-    poses = _pose_seq(6, H, W)
-    worst = 0.0
-    for t in range(2, 6):  # sliding window of tG=3 pose maps; first output frame uses raw only
+    A = _pose_seq(3, H, W, seed=6).unsqueeze(0)
+    want = ref.inference(A)
+    got, _ = hip.inference(A.to("cuda:0"))
+    assert (got.cpu() - want).abs().max().item() <= TOL
+    hip.inference(A.to("cuda:0"))
+    hip.reset()
+    again, _ = hip.inference(A.to("cuda:0"))
+    assert torch.equal(again, got)
+
+
+def test_free_running_sequence_vs_fp64_conditioning():
+    """Free-running recurrence (each path feeds on its OWN previous outputs).  A random-init
+    generator is an expanding map of its previous frames, so two fp32 evaluations drift apart; the
+    yardstick is an fp64 evaluation of the same network: the HIP path must stay as close to fp64
+    as the fp32 CPU oracle does (x10 slack + 1e-4), and within 1e-3 while the fp32 oracle itself is
+    within 1e-4 of fp64."""
+    import copy
+    name, kw, scales, H, W = CASES[0]
+    ref, hip = _build(kw, scales)
+    ref64 = copy.deepcopy(ref)
+    for n in ref64.nets:
+        n.double()
+    poses = _pose_seq(7, H, W, seed=7)
+    for t in range(2, 7):
         A = poses[t - 2:t + 1].unsqueeze(0)
-        want = ref.inference(A)
-        got, _ = hip.inference(A.to("cuda:0"))
-        err = (got.cpu() - want).abs().max().item()
-        worst = max(worst, err)
-        assert got.shape == want.shape
-        assert err <= TOL, "%s frame %d: max|delta|=%g" % (name, t, err)
-    # recurrence reset on change_seq reproduces the first frame
-    ref.reset(); hip.reset()
-    A = poses[0:3].unsqueeze(0)
-    assert (hip.inference(A.to("cuda:0"))[0].cpu() - ref.inference(A)).abs().max().item() <= TOL
-    print(name, "worst max|delta|", worst)
+        truth = ref64.inference(A.double())
+        e32 = (ref.inference(A).double() - truth).abs().max().item()
+        ehip = (hip.inference(A.to("cuda:0"))[0].cpu().double() - truth).abs().max().item()
+        print("frame %d: |oracle32-fp64|=%.2e |hip-fp64|=%.2e" % (t, e32, ehip))
+        assert ehip <= 10 * e32 + 1e-4
+        if e32 <= 1e-4:
+            assert ehip <= TOL
 
 
 def test_fullsize_frame_512_noflow_matches_oracle():
     """BASELINE config 2 geometry (ngf 128, 3 down, 9 blocks, 512x512, openpose_only => no flow):
-    two frames through the real-size network vs the CPU oracle."""
+    the first frame (zero prev) and a teacher-forced second frame through the real-size network."""
     kw = dict(ngf=128, n_downsample=3, n_blocks=9, no_flow=True, norm="batch")
     ref, hip = _build(kw, 1, init="uniform_fan_in")
     poses = _pose_seq(4, 512, 512, seed=3)
     for t in (2, 3):
         A = poses[t - 2:t + 1].unsqueeze(0)
+        if ref.fake_B_prev is not None:
+            hip.load_prev(ref.fake_B_prev)
         want = ref.inference(A)
         got, _ = hip.inference(A.to("cuda:0"))
         err = (got.cpu() - want).abs().max().item()
+        print("512x512 frame %d max|delta| = %.3g" % (t, err))
         assert err <= TOL, "frame %d: max|delta|=%g" % (t, err)
         assert want.abs().max().item() > 0.05  # the comparison is not vacuous
 

@@ -86,6 +86,13 @@ def load():
         raise RuntimeError(
             "libt2v_hip.so not found at %s: the HIP extension is required (no CPU fallback). "
             "Build it with `python __graft_entry__.py` or `make -C text2video_amd/csrc`." % LIB_PATH)
+    # torch must initialise first: it bundles its own libamdhip64.so (same soname as /opt/rocm's).
+    # Loaded in this order the one HIP runtime of the process is torch's and device pointers /
+    # streams are shared; the other order would put two HIP runtimes in one process.
+    import torch  # noqa: F401
+    hip_rt = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    if os.path.exists(hip_rt):
+        ctypes.CDLL(hip_rt, mode=ctypes.RTLD_GLOBAL)
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported

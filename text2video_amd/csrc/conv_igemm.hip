@@ -269,7 +269,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
         for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
             for (int j = 0; j < Cfg::TN; ++j) {
-                float s = 0.f;
+                // pairwise (tree) summation: log-depth rounding error, and exact for a constant
+                // map (power-of-two counts of equal values) -- the all-zero previous-frame input
+                // of a sequence's first frame makes every channel of the image encoder constant
+                float tsum[Cfg::TM * MM::NREG];
 #pragma unroll
                 for (int i = 0; i < Cfg::TM; ++i)
 #pragma unroll
@@ -280,8 +283,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
                             v -= mean_b[j];
                             v *= v;
                         }
-                        s += (row < cnt) ? v : 0.f;
+                        tsum[i * MM::NREG + r] = (row < cnt) ? v : 0.f;
                     }
+#pragma unroll
+                for (int w = Cfg::TM * MM::NREG / 2; w >= 1; w >>= 1)
+#pragma unroll
+                    for (int i = 0; i < w; ++i) tsum[i] += tsum[i + w];
+                float s = tsum[0];
                 s += __shfl_xor(s, 32);
                 if (g == 0) red[wm * BN + wn * (Cfg::TN * MF) + j * MF + fr] = s;
             }

@@ -107,7 +107,7 @@ def layer_shapes(spec):
     return out
 
 
-def synthetic_state_dict(spec, seed=1, init="uniform_fan_in"):
+def synthetic_state_dict(spec, seed=1, init="uniform_fan_in", flow_gain=1.0):
     """Deterministic random-init weights (numpy RNG, platform independent) in upstream key names.
 
     init='uniform_fan_in': U(-1/sqrt(fan_in), +) for conv weight AND bias = torch-0.4.1 default
@@ -116,6 +116,10 @@ def synthetic_state_dict(spec, seed=1, init="uniform_fan_in"):
     init='vid2vid': vid2vid's weights_init, N(0,0.02) conv weights [RECALL].
     Norm affine params (norm='batch'): gamma ~ N(1,0.02) (weights_init), beta ~ N(0,0.1) so the
     affine path is exercised.
+    flow_gain scales model_final_flow's weight and bias: a random-init flow head times the x20
+    flow multiplier yields +-40 px flows, which turns 1e-5 rounding differences into >1e-3 pixel
+    differences once they compound through the frame recurrence; trained networks predict flows
+    of a few pixels, which flow_gain=0.1 emulates (test conditioning only).
     """
     rng = np.random.default_rng(seed)
     sd = {}
@@ -130,6 +134,8 @@ def synthetic_state_dict(spec, seed=1, init="uniform_fan_in"):
             a = rng.normal(1.0, 0.02, size=shape)
         else:
             a = rng.normal(0.0, 0.1, size=shape)
+        if key.startswith("model_final_flow."):
+            a = a * flow_gain
         sd[key] = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
     return sd
 
@@ -247,6 +253,12 @@ class Vid2VidModelG:
     def reset(self):
         """`model.fake_B_prev = None` on data['change_seq']."""
         self.prev = None
+
+    def load_prev(self, fake_B_prev):
+        """Set the FIFO from reference-layout tensors: list (finest first) of [tG-1, 3, h, w]."""
+        pcs = ops.round_up(self.nets[0].spec.prev_nc, 4)
+        self.prev = [ops.nchw_to_nhwc(p.reshape(-1, p.shape[-2], p.shape[-1]).to(self.device).contiguous(), pcs)
+                     for p in fake_B_prev]
 
     @torch.no_grad()
     def inference_nhwc(self, pose):
