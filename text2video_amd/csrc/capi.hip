@@ -1,6 +1,7 @@
 // capi.hip -- extern "C" surface of libt2v_hip.so (declared in include/t2v.h) and the conv planner.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "conv_plan.h"

@@ -23,6 +23,8 @@
 //     norm never re-reads the activation to compute statistics.
 //   * blockIdx -> tile mapping is XCD-aware: each XCD's L2 sees a contiguous band of tiles that
 //     share A rows / all B columns.
+#include <stdlib.h>
+
 #include "t2v_internal.h"
 
 namespace t2v {
@@ -59,8 +61,8 @@ struct TileCfg {
     static constexpr int NG = 64 / MF;           // lane groups along k inside one MFMA (2 or 4)
     static constexpr int RQ = 8 / NG;            // ds_read_b128 per fragment per stage (4 or 2)
     static constexpr int STAGE_BYTES = (BM + BN) * 128;
-    static constexpr int LDS_BYTES = 2 * STAGE_BYTES;
-    static_assert(WAVES_M * WAVES_N == 4, "256-thread blocks");
+
+    static_assert(WAVES_M * WAVES_N == 4, "4 MFMA waves (+ 4 loader waves) per block");
     static_assert(BM % 32 == 0, "A loader: 8 rows per wave instruction, 4 waves");
 };
 using CfgL = TileCfg<32, 2, 2, 2, 2>;  // 128 x 128
@@ -79,31 +81,47 @@ __device__ __forceinline__ int reflect_idx(int i, int n) {
 // MODE 0: Cin_s % 32 == 0 (a stage lies inside one tap; tap offsets read with scalar loads)
 // MODE 1: any Cin_s % 4 == 0, regular conv (tap -> (kh,kw) by arithmetic): the 7x7 stems
 // MODE 2: any Cin_s % 4 == 0, tap table looked up per lane: transposed convs of narrow test nets
-template <class Cfg, int MODE, bool STATS>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
+// REFLECT: reflection padding (ResnetBlock 3x3, 7x7 stems/heads) vs zero padding (stride-2 and
+// transposed convs) -- a template parameter so the loader has no runtime branch and each use has
+// its own kernel symbol in profiles (conv_igemm_kernel<CfgL,0,true,true> == the 1024-ch ResnetBlock
+// conv that is 84 % of the FLOPs).
+//
+// Wave specialisation: a block is 8 waves = 4 MFMA waves (one per SIMD) + 4 loader waves (one per
+// SIMD).  With fp32 MFMA a single in-order wave per SIMD cannot hide its own LDS-DMA issue cost
+// (measured: 71 % MFMA-busy when the MFMA waves issued their own global_load_lds); as separate
+// waves the CU interleaves the loaders' address arithmetic + DMA issue with the MFMA stream, and the
+// MFMA waves execute nothing but ds_read_b128 / v_mfma / one s_barrier per stage.
+// RING: LDS ring slots.  3 = every DMA gets two stage times to land (one resident block per CU:
+// launches of <= 256 blocks, the heads); 2 = 64 KiB so that two blocks share a CU and hide each
+// other's prologue / epilogue / DMA latency (launches of many short-K blocks).
+template <class Cfg, int MODE, bool STATS, bool REFLECT, int RING>
+__global__ __launch_bounds__(512) void conv_igemm_kernel(const ConvKParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using MM = Mfma<Cfg::MF>;
     using acc_t = typename MM::acc_t;
     constexpr int BM = Cfg::BM, BN = Cfg::BN, MF = Cfg::MF;
     constexpr int A_ITERS = BM / 32;                      // wave-instructions per wave for A
     constexpr int B_INSTR = BN / 8;                       // wave-instructions for B in total
-    constexpr int B_ITERS = (B_INSTR + 3) / 4;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // 0..7
+    const bool is_loader = wave >= 4;
+    const int wid = wave & 3;  // MFMA wave id / loader share id
 
-    // ---- XCD-aware tile id: block b runs on XCD b%8; give every XCD a contiguous tile band ----
-    int t;
+    // ---- block -> (phase, tile).  Blocks dispatch in blockIdx order and block b runs on XCD b%8.
+    // Phases (sub-pixel phases of a transposed conv, heaviest first) follow blockIdx order, which is
+    // an LPT schedule balanced over all XCDs; inside a phase the tiles are banded per XCD so that
+    // each XCD's L2 sees a contiguous run of tiles sharing A rows / all B columns.
+    const int tiles_per_phase = p.mtiles * p.ntiles;
+    const int phase = blockIdx.x / tiles_per_phase;
+    int rem;
     {
-        const int nb = gridDim.x, b = blockIdx.x;
+        const int nb = tiles_per_phase, b = blockIdx.x - phase * tiles_per_phase;
         const int xcd = b & 7, idx = b >> 3;
         const int q = nb >> 3, r = nb & 7;
-        t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        rem = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int tiles_per_phase = p.mtiles * p.ntiles;
-    const int phase = t / tiles_per_phase;
-    const int rem = t - phase * tiles_per_phase;
     const int mt = rem / p.ntiles;
     const int nt = rem - mt * p.ntiles;
     const int m0 = mt * BM, n0 = nt * BN;
@@ -111,83 +129,84 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
     const float* __restrict__ wbase = p.w + ph.w_off;
 
     // ---- loader lane geometry: a wave instruction moves 8 rows x 128 B; lane -> (row, slot) ----
+    // Everything here is branch-free (selects only) so that the issue of stage kt+1's DMA can be
+    // interleaved, instruction by instruction, between the MFMAs of stage kt.
     const int lrow = lane >> 3;   // 0..7
     const int lslot = lane & 7;   // physical 16-B slot in the row
     int a_by[A_ITERS], a_bx[A_ITERS];
-    bool a_ok[A_ITERS];
-    int a_chunk[A_ITERS];  // data chunk (of 8) this lane fetches = slot ^ swizzle(row)
+    int a_coff[A_ITERS];  // float offset of the data chunk this lane fetches = 4*(slot ^ swizzle(row))
 #pragma unroll
     for (int i = 0; i < A_ITERS; ++i) {
         const int r = wid * (BM / 4) + i * 8 + lrow;
-        const int m = m0 + r;
-        a_ok[i] = m < p.M;
+        // rows past M (ragged last tile) re-read the last valid pixel: finite data whose results
+        // are masked at the store and in the statistics
+        const int m = min(m0 + r, p.M - 1);
         const int my = m / p.Wm, mx = m - my * p.Wm;
         a_by[i] = my * p.stride;
         a_bx[i] = mx * p.stride;
-        a_chunk[i] = lslot ^ ((r >> 1) & 7);
+        a_coff[i] = (lslot ^ ((r >> 1) & 7)) * 4;
     }
+    const long zero_off = p.zero - p.x;  // float offset of the zero page relative to x
 
-    auto stage = [&](int kt, int buf) {
-        char* sA = smem + buf * Cfg::STAGE_BYTES;
-        char* sB = sA + BM * 128;
+    // A-operand DMA instruction i (of A_ITERS per wave) of K-stage kt into ring slot buf
+    auto issue_a = [&](int i, int kt, int buf) {
+        char* dst = smem + buf * Cfg::STAGE_BYTES + (wid * (BM / 4) + i * 8) * 128;
+        int dy, dx, c;
+        bool kin = true;
         if constexpr (MODE == 0) {
             // whole 32-deep stage lies inside one tap: tap index and channel base are scalar
             const int cpt = p.Cin_s >> 5;
             const int tap = kt / cpt;
-            const int c0 = (kt - tap * cpt) << 5;
-            const int dy = p.tdy[ph.tap0 + tap], dx = p.tdx[ph.tap0 + tap];
-#pragma unroll
-            for (int i = 0; i < A_ITERS; ++i) {
-                int iy = a_by[i] + dy, ix = a_bx[i] + dx;
-                bool ok = a_ok[i];
-                if (p.pad_mode == T2V_PAD_REFLECT) {
-                    iy = reflect_idx(iy, p.Hin);
-                    ix = reflect_idx(ix, p.Win);
-                } else {
-                    ok = ok && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
-                }
-                const float* src = ok ? p.x + ((size_t)(iy * p.Win + ix) * p.Cin_s + c0 + a_chunk[i] * 4) : p.zero;
-                glds16(src, sA + (wid * (BM / 4) + i * 8) * 128);
-            }
+            c = ((kt - tap * cpt) << 5) + a_coff[i];
+            dy = p.tdy[ph.tap0 + tap];
+            dx = p.tdx[ph.tap0 + tap];
         } else {
-            // general path (stem convs, Cin_s = 8 / 12): every 16-B chunk resolves its own tap
-            const int K = ph.ntaps * p.Cin_s;
-#pragma unroll
-            for (int i = 0; i < A_ITERS; ++i) {
-                const int k = kt * kBK + a_chunk[i] * 4;
-                const bool kin = k < K;
-                const int tap = kin ? k / p.Cin_s : 0;
-                const int c = k - tap * p.Cin_s;
-                int dy, dx;
-                if constexpr (MODE == 1) {
-                    const int kh = tap / p.KW;
-                    dy = kh - p.pad;
-                    dx = tap - kh * p.KW - p.pad;
-                } else {
-                    dy = p.tdy[ph.tap0 + tap];
-                    dx = p.tdx[ph.tap0 + tap];
-                }
-                int iy = a_by[i] + dy, ix = a_bx[i] + dx;
-                bool ok = a_ok[i] && kin;
-                if (p.pad_mode == T2V_PAD_REFLECT) {
-                    iy = reflect_idx(iy, p.Hin);
-                    ix = reflect_idx(ix, p.Win);
-                    // k >= K lanes may compute wild coordinates: they take the zero page
-                } else {
-                    ok = ok && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
-                }
-                const float* src = ok ? p.x + ((size_t)(iy * p.Win + ix) * p.Cin_s + c) : p.zero;
-                glds16(src, sA + (wid * (BM / 4) + i * 8) * 128);
+            // general path (Cin_s = 8 / 12 stems, narrow test nets): each 16-B chunk has its own tap
+            const int k = kt * kBK + a_coff[i];
+            kin = k < ph.ntaps * p.Cin_s;
+            const int tap = kin ? k / p.Cin_s : 0;
+            c = kin ? k - tap * p.Cin_s : 0;  // k >= K: any finite datum (its weights are zero)
+            if constexpr (MODE == 1) {
+                const int kh = tap / p.KW;
+                dy = kh - p.pad;
+                dx = tap - kh * p.KW - p.pad;
+            } else {
+                dy = p.tdy[ph.tap0 + tap];
+                dx = p.tdx[ph.tap0 + tap];
             }
         }
-#pragma unroll
-        for (int i = 0; i < B_ITERS; ++i) {
-            const int instr = (B_INSTR >= 4) ? wid * B_ITERS + i : wid;
-            if (B_INSTR >= 4 || wid < B_INSTR) {
-                const int r = instr * 8 + lrow;
-                const int chunk = lslot ^ ((r >> 1) & 7);
-                const float* src = wbase + (size_t)(n0 + r) * ph.Kp + kt * kBK + chunk * 4;
-                glds16(src, sB + instr * 8 * 128);
+        int iy = a_by[i] + dy, ix = a_bx[i] + dx;
+        long off;
+        if constexpr (REFLECT) {
+            iy = iy < 0 ? -iy : iy;
+            ix = ix < 0 ? -ix : ix;
+            iy = min(iy, 2 * p.Hin - 2 - iy);
+            ix = min(ix, 2 * p.Win - 2 - ix);
+            off = (long)((unsigned)(iy * p.Win + ix) * (unsigned)p.Cin_s + (unsigned)c);
+        } else {
+            const bool ok = (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
+            off = ok ? (long)((unsigned)(iy * p.Win + ix) * (unsigned)p.Cin_s + (unsigned)c) : zero_off;
+        }
+        glds16(p.x + off, dst);
+    };
+    // B-operand (packed weights [Cout_p][Kp]) DMA instruction `instr` (of BN/8 per block)
+    auto issue_b = [&](int instr, int kt, int buf) {
+        char* dst = smem + buf * Cfg::STAGE_BYTES + BM * 128 + instr * 8 * 128;
+        const int r = instr * 8 + lrow;
+        const int chunk = lslot ^ ((r >> 1) & 7);
+        glds16(wbase + (size_t)(n0 + r) * ph.Kp + kt * kBK + chunk * 4, dst);
+    };
+    // this wave's DMA instruction number `n` of a stage: first its A rows, then its B rows
+    constexpr int B_PER_WAVE = (B_INSTR >= 4) ? B_INSTR / 4 : 1;
+    constexpr int LD_PER_WAVE = A_ITERS + B_PER_WAVE;
+    auto issue = [&](int n, int kt, int buf) {
+        if (n < A_ITERS) {
+            issue_a(n, kt, buf);
+        } else if (n < LD_PER_WAVE) {
+            if constexpr (B_INSTR >= 4) {
+                issue_b(wid * B_PER_WAVE + (n - A_ITERS), kt, buf);
+            } else {
+                if (wid < B_INSTR) issue_b(wid, kt, buf);  // wave-uniform
             }
         }
     };
@@ -208,38 +227,89 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
 #pragma unroll
             for (int r = 0; r < MM::NREG; ++r) acc[i][j][r] = 0.f;
 
-    auto compute = [&](int buf) {
+    // ---- main loop ------------------------------------------------------------------------------
+    // One K stage = RQ groups of 4*TM*TN MFMAs, software-pipelined by hand (one wave per SIMD has
+    // nobody else to hide its latencies):
+    //   * fragments are double-buffered in registers: group q's MFMAs run while the ds_read_b128s
+    //     of group q+1 are in flight (LDS latency always covered by >= 1000 MFMA cycles);
+    //   * the DMA of stage kt+1 is issued by the loader waves right after barrier(kt-1);
+    //   * ONE barrier per stage, placed before the last group's MFMAs: by then every wave has read
+    //     its last fragments of the current slot (slot reusable) and the DMA issued >= 1 group ago
+    //     has landed (vmcnt(0) folded into the barrier), so group 0 of the next stage can be
+    //     prefetched from the other slot under the last group's MFMAs.
+    static_assert(Cfg::RQ % 2 == 0, "fragment register sets alternate per group");
+    f32x4 af[2][Cfg::TM], bf[2][Cfg::TN];
+    auto load_frags = [&](int buf, int q, int set) {
         const char* sA = smem + buf * Cfg::STAGE_BYTES;
         const char* sB = sA + BM * 128;
+        const int slot = ((q * Cfg::NG + g) ^ fsw) * 16;
 #pragma unroll
-        for (int q = 0; q < Cfg::RQ; ++q) {
-            const int slot = ((q * Cfg::NG + g) ^ fsw) * 16;
-            f32x4 af[Cfg::TM], bf[Cfg::TN];
+        for (int i = 0; i < Cfg::TM; ++i)
+            af[set][i] = *reinterpret_cast<const f32x4*>(sA + (a_row0 + i * MF) * 128 + slot);
 #pragma unroll
-            for (int i = 0; i < Cfg::TM; ++i)
-                af[i] = *reinterpret_cast<const f32x4*>(sA + (a_row0 + i * MF) * 128 + slot);
-#pragma unroll
-            for (int j = 0; j < Cfg::TN; ++j)
-                bf[j] = *reinterpret_cast<const f32x4*>(sB + (b_row0 + j * MF) * 128 + slot);
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int i = 0; i < Cfg::TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < Cfg::TN; ++j) acc[i][j] = MM::run(af[i][e], bf[j][e], acc[i][j]);
-        }
+        for (int j = 0; j < Cfg::TN; ++j)
+            bf[set][j] = *reinterpret_cast<const f32x4*>(sB + (b_row0 + j * MF) * 128 + slot);
     };
 
-    // ---- main loop: 2-stage LDS ring, DMA of stage kt+1 in flight under the MFMAs of stage kt ----
     const int nk = ph.nk;
-    stage(0, 0);
-    __syncthreads();
-    int buf = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
-        compute(buf);
-        __syncthreads();
-        buf ^= 1;
+    if (is_loader) {
+        // ---- loader waves ----
+        // Stage kt+2 is issued into the slot that barrier(kt-1) released; before barrier(kt) the
+        // loader only waits (counted vmcnt) for stage kt+1, so every DMA has two stage times to
+        // land and is never on the critical path.  Raw s_barrier + asm waits: __syncthreads()
+        // would drain vmcnt to 0.  Stages past the end re-fetch the last stage (no branches).
+        constexpr int AHEAD = RING - 1;  // stages in flight beyond the one being computed
+#pragma unroll
+        for (int st = 0; st < AHEAD; ++st)
+#pragma unroll
+            for (int n = 0; n < LD_PER_WAVE; ++n) issue(n, min(st, nk - 1), st);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * LD_PER_WAVE) : "memory");
+        __builtin_amdgcn_s_barrier();  // B0: stage 0 has landed
+        int slot = AHEAD;              // slot of stage kt+AHEAD (== slot released by barrier(kt-1))
+        for (int kt = 0; kt < nk; ++kt) {
+#pragma unroll
+            for (int n = 0; n < LD_PER_WAVE; ++n) issue(n, min(kt + AHEAD, nk - 1), slot);
+            // stage kt+1 landed; the younger stage (RING 3) stays in flight across the barrier
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * LD_PER_WAVE) : "memory");
+            __builtin_amdgcn_s_barrier();  // barrier(kt)
+            slot = slot >= RING - 1 ? 0 : slot + 1;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        __syncthreads();  // B0
+        load_frags(0, 0, 0);
+        int buf = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            const int nbuf = buf == RING - 1 ? 0 : buf + 1;
+#pragma unroll
+            for (int q = 0; q < Cfg::RQ; ++q) {
+                const int cur = q & 1;
+                if (q + 1 < Cfg::RQ) load_frags(buf, q + 1, cur ^ 1);
+                if (q + 1 == Cfg::RQ) {
+                    __syncthreads();  // barrier(kt): slot `buf` released, stage kt+1 visible
+                    load_frags(nbuf, 0, cur ^ 1);
+                }
+                // pin the prefetch: DS and MFMA instructions may not cross this point
+                __builtin_amdgcn_sched_barrier(0x2 | 0x4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < Cfg::TN; ++j)
+                            acc[i][j] = MM::run(af[cur][i][e], bf[cur][j][e], acc[i][j]);
+            }
+            buf = nbuf;
+        }
+    }
+    __syncthreads();  // the epilogue reuses the LDS ring
+    if (is_loader) {
+        // loader waves only keep the barrier count of the statistics reduction below in step
+        // (s_barrier counts arrivals of all 8 waves, wherever in the code they arrive from)
+        if constexpr (STATS) {
+            __syncthreads(); __syncthreads(); __syncthreads(); __syncthreads();
+        }
+        return;
     }
 
     // ---- epilogue ----
@@ -347,19 +417,36 @@ void conv_tile_dims(int tile, int* BM, int* BN) {
     }
 }
 
-template <class Cfg, int MODE, bool STATS>
-static int launch_one(hipStream_t s, const ConvKParams& p) {
-    auto kern = conv_igemm_kernel<Cfg, MODE, STATS>;
+template <class Cfg, int MODE, bool STATS, bool REFLECT, int RING>
+static int launch_ring(hipStream_t s, const ConvKParams& p) {
+    auto kern = conv_igemm_kernel<Cfg, MODE, STATS, REFLECT, RING>;
+    constexpr int LDS_BYTES = RING * Cfg::STAGE_BYTES;
     static bool attr_done = false;  // per instantiation
     if (!attr_done) {
         T2V_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         attr_done = true;
     }
     const int nblocks = p.mtiles * p.ntiles * p.nphases;
-    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), Cfg::LDS_BYTES, s, p);
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(512), LDS_BYTES, s, p);
     T2V_HIP_CHECK(hipGetLastError());
     return T2V_OK;
+}
+
+template <class Cfg, int MODE, bool STATS, bool REFLECT>
+static int launch_pad(hipStream_t s, const ConvKParams& p) {
+    // >= 4 blocks per CU queued: let two blocks share the CU (64 KiB ring each); measured on MI355X:
+    // 2048-block stem 0.40 vs 0.47 ms, 1024-block layers 0.33 vs 0.345 ms, <= 512 blocks favour RING 3
+    const long nblocks = (long)p.mtiles * p.ntiles * p.nphases;
+    static const int force = getenv("T2V_CONV_RING") ? atoi(getenv("T2V_CONV_RING")) : 0;
+    const bool two = force ? force == 2 : (Cfg::MF == 32 && nblocks >= 1024);
+    return two ? launch_ring<Cfg, MODE, STATS, REFLECT, 2>(s, p) : launch_ring<Cfg, MODE, STATS, REFLECT, 3>(s, p);
+}
+
+template <class Cfg, int MODE, bool STATS>
+static int launch_one(hipStream_t s, const ConvKParams& p) {
+    return p.pad_mode == T2V_PAD_REFLECT ? launch_pad<Cfg, MODE, STATS, true>(s, p)
+                                         : launch_pad<Cfg, MODE, STATS, false>(s, p);
 }
 
 int launch_conv_igemm(hipStream_t s, const ConvKParams& p, int tile) {
