@@ -1,0 +1,92 @@
+"""CPU tests (no GPU): the C-ABI library loads and exports every symbol include/t2v.h declares, its
+pure-host planning entry points behave, and errors surface as status codes + messages."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_every_declared_symbol_is_exported(lib_built):
+    from text2video_amd import _lib
+    header = open(os.path.join(ROOT, "include", "t2v.h")).read()
+    declared = set(re.findall(r"\b(t2v_[a-z0-9_]+)\s*\(", header))
+    declared -= {"t2v_status"}
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
+    for name in declared:
+        assert getattr(lib_built, name) is not None
+    assert lib_built.t2v_abi_version() == _lib.ABI_VERSION
+
+
+def test_conv_planning_entry_points(lib_built):
+    from text2video_amd import _lib
+    d = _lib.ConvDesc(64, 64, 1024, 1024, 3, 3, 1, 1, _lib.PAD_REFLECT, 0, 0, 1.0)
+    h, w = ctypes.c_int(), ctypes.c_int()
+    assert lib_built.t2v_conv_out_dims(ctypes.byref(d), ctypes.byref(h), ctypes.byref(w)) == 0
+    assert (h.value, w.value) == (64, 64)
+    assert lib_built.t2v_conv_packed_weight_floats(ctypes.byref(d), 1024) == 1024 * 9216
+    assert lib_built.t2v_conv_stats_floats(ctypes.byref(d)) == 32 * 1024 * 2          # 32 M-tiles of 128 pixels
+    dt = _lib.ConvDesc(64, 64, 1024, 512, 3, 3, 2, 1, _lib.PAD_ZERO, 1, 0, 1.0)          # transposed
+    assert lib_built.t2v_conv_out_dims(ctypes.byref(dt), ctypes.byref(h), ctypes.byref(w)) == 0
+    assert (h.value, w.value) == (128, 128)
+    assert lib_built.t2v_conv_packed_weight_floats(ctypes.byref(dt), 1024) == 512 * 9 * 1024  # 4 phases, 9 taps
+    ds = _lib.ConvDesc(512, 512, 9, 128, 7, 7, 1, 3, _lib.PAD_REFLECT, 0, 0, 1.0)        # stem, Cin 9 -> storage 12
+    assert lib_built.t2v_conv_packed_weight_floats(ctypes.byref(ds), 12) == 128 * 608    # K=588 padded to 608
+
+
+def test_errors_are_status_codes_with_messages(lib_built):
+    from text2video_amd import _lib
+    bad = _lib.ConvDesc(64, 64, 1024, 1024, 3, 3, 1, 1, _lib.PAD_REFLECT, 0, 0, 1.0)
+    h, w = ctypes.c_int(), ctypes.c_int()
+    bad.H = 0
+    assert lib_built.t2v_conv_out_dims(ctypes.byref(bad), ctypes.byref(h), ctypes.byref(w)) == -1
+    assert b"bad dims" in lib_built.t2v_last_error()
+    refl = _lib.ConvDesc(2, 2, 8, 8, 7, 7, 1, 3, _lib.PAD_REFLECT, 0, 0, 1.0)
+    assert lib_built.t2v_conv_out_dims(ctypes.byref(refl), ctypes.byref(h), ctypes.byref(w)) == -1
+    assert b"reflection pad" in lib_built.t2v_last_error()
+    tr = _lib.ConvDesc(8, 8, 8, 8, 5, 5, 2, 1, _lib.PAD_ZERO, 1, 0, 1.0)
+    assert lib_built.t2v_conv_out_dims(ctypes.byref(tr), ctypes.byref(h), ctypes.byref(w)) == -1
+    with pytest.raises(RuntimeError, match="status -1"):
+        _lib.check(-1, "unit")
+
+
+def test_generator_layer_list_matches_host_mirror(lib_built):
+    from text2video_amd import _lib
+    from text2video_amd.generator import GeneratorSpec, _gen_desc, layer_keys, layer_shapes
+    for spec, nl in [(GeneratorSpec(), 2 * (1 + 3 + 10) + 8 + 3 + 1 + 8 + 3 + 1),
+                     (GeneratorSpec(no_flow=True), 2 * (1 + 3 + 10) + 8 + 3 + 1),
+                     (GeneratorSpec(ngf=64, n_blocks=3, is_local=True, scale=1), 2 * 2 + 6 + 1 + 1 + 6 + 1 + 1)]:
+        gd = _gen_desc(spec, 512, 512)
+        assert lib_built.t2v_generator_num_layers(ctypes.byref(gd)) == nl == len(layer_keys(spec))
+        assert len(layer_shapes(spec)) > 0
+    # 283.0 M parameters without flow / 364.7 M with flow
+    n = sum(int.__mul__(1, __import__("math").prod(s)) for _, s, _ in layer_shapes(GeneratorSpec(no_flow=True)))
+    assert abs(n / 1e6 - 283.0) < 0.5
+    n = sum(__import__("math").prod(s) for _, s, _ in layer_shapes(GeneratorSpec()))
+    assert abs(n / 1e6 - 364.7) < 0.5
+    gd = _gen_desc(GeneratorSpec(no_flow=True), 512, 512)
+    ws = lib_built.t2v_generator_workspace_bytes(ctypes.byref(gd))
+    assert 0.5e9 < ws < 2e9
+    gd = _gen_desc(GeneratorSpec(), 500, 512)  # H not a multiple of 8
+    assert lib_built.t2v_generator_workspace_bytes(ctypes.byref(gd)) == 0
+    assert b"multiples of 8" in lib_built.t2v_last_error()
+
+
+def test_product_path_fails_loudly_without_gpu(lib_built):
+    """No CPU fallback: asking for a context on a box without a HIP device raises."""
+    import torch
+    from text2video_amd import ops
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.context()
+
+
+def test_bench_flop_model_matches_baseline():
+    import bench
+    assert abs(bench.gflop_per_frame(512, 512, False) - 2572) < 1.0
+    assert abs(bench.gflop_per_frame(512, 512, True) - 3316) < 1.0
+    assert abs(bench.gflop_per_frame(1024, 1024, False) - 10287) < 2.0

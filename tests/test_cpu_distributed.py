@@ -1,0 +1,106 @@
+"""World-size-2 `gloo` tests (CPU) of the multi-GPU path: sequence-chunk assignment and the frame
+all-gather.  The per-rank "generator" here is a stand-in recurrence with the same dependency
+structure as the real one (frame t needs t-1, t-2; reset per chunk); the collective and the
+bookkeeping are the code under test."""
+import os
+import socket
+import zlib
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _poses(seq, n):
+    seed = zlib.crc32(seq.encode())      # str hash() is salted per process
+    return torch.from_numpy(np.random.default_rng(seed).standard_normal((n, 4, 5)).astype(np.float32))
+
+
+def _fake_generate(poses):
+    """stand-in with the real recurrence shape: out_t = g(window of 3 poses, out_{t-1}, out_{t-2})"""
+    prev = [torch.zeros_like(poses[0]), torch.zeros_like(poses[0])]
+    outs = []
+    for t in range(2, poses.shape[0]):
+        o = torch.tanh(poses[t - 2:t + 1].sum(0) * 0.3 + 0.5 * prev[1] - 0.25 * prev[0])
+        prev = [prev[1], o]
+        outs.append(o)
+    return torch.stack(outs)
+
+
+def _worker(rank, world, port, seq_lengths, tmpdir):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from text2video_amd import distributed as D
+    r, lr, w = D.init_from_env("gloo")
+    assert (r, w) == (rank, world)
+    plan = D.assign_chunks(seq_lengths, world)
+    rng = {s: _poses(s, n) for s, n in seq_lengths.items()}
+    mine = []
+    for seq, s, e, first_out in plan[rank]:
+        mine.append(_fake_generate(rng[seq][s:e]))
+    local = torch.cat(mine) if mine else torch.zeros(0, 4, 5)
+    counts = [sum((e - s) - 2 for _, s, e, _ in p) for p in plan]
+    blocks = D.gather_ragged_frames(local, counts)
+    # equal-shape fast path
+    k = min(counts)
+    full = D.gather_frames(local[:k])
+    assert full.shape[0] == world * k
+    for q in range(world):
+        assert torch.equal(full[q * k:(q + 1) * k], blocks[q][:k])
+    if rank == 0:
+        torch.save({"plan": plan, "blocks": blocks}, os.path.join(tmpdir, "out.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("seq_lengths", [{"tmp": 12, "tmp_smooth": 12}, {"only": 21}, {"a": 9, "b": 14, "c": 5}])
+def test_two_rank_gloo_chunk_sharding(tmp_path, seq_lengths):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), seq_lengths, str(tmp_path)), nprocs=world, join=True)
+    res = torch.load(os.path.join(str(tmp_path), "out.pt"), weights_only=False)
+    plan, blocks = res["plan"], res["blocks"]
+    # every output frame of every sequence is produced exactly once
+    covered = {}
+    for r, p in enumerate(plan):
+        off = 0
+        for seq, s, e, first_out in p:
+            n = (e - s) - 2
+            for j in range(n):
+                assert (seq, first_out + j) not in covered
+                covered[(seq, first_out + j)] = blocks[r][off + j]
+            off += n
+    assert set(covered) == {(s, t) for s, n in seq_lengths.items() for t in range(2, n)}
+    assert all(len(p) > 0 for p in plan)     # both ranks have work
+    # each chunk equals a single-process run of the same chunk (sequence-level parity target)
+    for r, p in enumerate(plan):
+        off = 0
+        for seq, s, e, first_out in p:
+            poses = _poses(seq, seq_lengths[seq])
+            want = _fake_generate(poses[s:e])
+            assert torch.equal(blocks[r][off:off + want.shape[0]], want)
+            off += want.shape[0]
+
+
+def test_chunk_bounds_and_assignment_edge_cases():
+    from text2video_amd.distributed import assign_chunks, chunk_bounds
+    assert chunk_bounds(10, 3) == [(0, 4), (4, 7), (7, 10)]
+    assert chunk_bounds(2, 4) == [(0, 1), (1, 2), (2, 2), (2, 2)]
+    plan = assign_chunks({"tmp": 87, "tmp_smooth": 87}, 2)          # config 1: two sequences -> two GPUs
+    assert [len(p) for p in plan] == [1, 1] and plan[0][0][1:3] == (0, 87)
+    plan = assign_chunks({"seq": 514}, 8)                            # config 3: 512 frames -> 8 x 64
+    assert sorted((e - s) - 2 for p in plan for _, s, e, _ in p) == [64] * 8
+    firsts = sorted(fo for p in plan for _, _, _, fo in p)
+    assert firsts == [2 + 64 * i for i in range(8)]
+    assert assign_chunks({"short": 2}, 2) == [[], []]                # shorter than the window: no output
+    plan = assign_chunks({"s": 4}, 4)                                # 2 outputs cannot feed 4 ranks
+    assert sum(len(p) for p in plan) <= 2

@@ -1,0 +1,178 @@
+"""CPU tests: the oracle's anchors, the host-side mirror of the reference interface (options, pose
+rasteriser vs golden vectors captured from the reference's own keypoint2img.py, dataset geometry,
+output layout)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+REF_CMD = ("--name fadg0 --dataroot %s --dataset_mode pose --input_nc 3 --resize_or_crop scaleHeight --loadSize 512 "
+           "--openpose_only --how_many 1200 --no_first_img --random_drop_prob 0")  # text2video_audio.sh:42
+
+
+# ---------------------------------------------------------------- oracle anchors
+def test_trainmode_batchnorm_equals_instancenorm_affine():
+    x = torch.randn(1, 16, 9, 11)
+    bn = torch.nn.BatchNorm2d(16, affine=True).train()
+    with torch.no_grad():
+        bn.weight.normal_(1, 0.1)
+        bn.bias.normal_(0, 0.1)
+        ref = F.instance_norm(x, eps=1e-5) * bn.weight.view(1, -1, 1, 1) + bn.bias.view(1, -1, 1, 1)
+        assert (bn(x) - ref).abs().max().item() < 1e-5
+
+
+def test_oracle_resample_identity_and_corner_alignment():
+    from oracle.generator_ref import resample
+    img = torch.randn(1, 3, 7, 13)
+    assert (resample(img, torch.zeros(1, 2, 7, 13)) - img).abs().max().item() < 1e-5
+    # +1 px flow in x shifts the image by exactly one pixel (pixel units, not normalised units)
+    flow = torch.zeros(1, 2, 7, 13)
+    flow[:, 0] = 1.0
+    out = resample(img, flow)
+    assert (out[..., :-1] - img[..., 1:]).abs().max().item() < 1e-5
+    assert (out[..., -1] - img[..., -1]).abs().max().item() < 1e-5   # border clamp
+
+
+def test_oracle_first_frame_raw_only_and_fifo():
+    from oracle.generator_ref import CompositeGenerator, Vid2VidInferenceRef
+    torch.manual_seed(0)
+    net = CompositeGenerator(9, 3, 6, ngf=8, n_downsampling=2, n_blocks=2, no_flow=False, norm="batch")
+    ref = Vid2VidInferenceRef([net])
+    A = torch.randn(1, 3, 3, 16, 16).clamp(-1, 1)
+    f0 = ref.inference(A)
+    with torch.no_grad():
+        raw = net.train()(A.reshape(1, 9, 16, 16), torch.zeros(1, 6, 16, 16), True)[0]
+    assert torch.equal(f0, raw)
+    assert torch.equal(ref.fake_B_prev[0][1], f0[0]) and ref.fake_B_prev[0][0].abs().max() == 0
+    f1 = ref.inference(A)
+    assert torch.equal(ref.fake_B_prev[0][0], f0[0]) and torch.equal(ref.fake_B_prev[0][1], f1[0])
+
+
+def test_oracle_two_scale_shapes():
+    from oracle.generator_ref import CompositeGenerator, CompositeLocalGenerator, Vid2VidInferenceRef
+    g0 = CompositeGenerator(9, 3, 6, ngf=16, n_downsampling=2, n_blocks=2, no_flow=False)
+    g1 = CompositeLocalGenerator(9, 3, 6, ngf_global=16, n_blocks_local=1, scale=1, no_flow=False)
+    ref = Vid2VidInferenceRef([g0, g1])
+    out = ref.inference(torch.randn(1, 3, 3, 32, 32).clamp(-1, 1))
+    assert out.shape == (1, 3, 32, 32) and ref.fake_B_prev[1].shape == (2, 3, 16, 16)
+
+
+def test_synthetic_weights_load_into_oracle_strictly(lib_built):
+    from oracle.generator_ref import CompositeGenerator
+    from text2video_amd.generator import GeneratorSpec, synthetic_state_dict
+    spec = GeneratorSpec(ngf=8, n_blocks=3)
+    sd = synthetic_state_dict(spec, 3)
+    net = CompositeGenerator(9, 3, 6, 8, 3, 3, False, "batch")
+    missing, unexpected = net.load_state_dict(sd, strict=False)
+    assert not unexpected and all(("running" in k or "num_batches" in k) for k in missing)
+    sd2 = synthetic_state_dict(spec, 3)
+    assert all(torch.equal(sd[k], sd2[k]) for k in sd)   # deterministic
+
+
+# ---------------------------------------------------------------- host mirror vs reference goldens
+def test_rasteriser_matches_reference_golden_maps():
+    """Bit-exact against maps captured from the reference's keypoint2img.read_keypoints
+    (tests/golden/make_host_goldens.py; cv2.circle stubbed => discs excluded)."""
+    from text2video_amd.keypoints import read_keypoints
+    g = np.load(os.path.join(GOLD, "pose_maps_fadg0.npz"))
+    for name, want in zip(g["names"], g["maps"]):
+        got = read_keypoints(os.path.join(GOLD, "keypoints_fadg0", str(name)), (512, 384), hand_discs=False)
+        assert got.dtype == np.uint8 and got.shape == (384, 512, 3)
+        assert np.array_equal(got, want), name
+        assert (want != 0).any(2).sum() > 4000
+        fast = read_keypoints(os.path.join(GOLD, "keypoints_fadg0", str(name)), (512, 384), hand_discs=False,
+                              exact_fit=False)
+        assert (fast != want).any(2).sum() <= 25     # closed form flips <= 25 px per frame
+
+
+def test_rasteriser_hand_discs_and_colour_key():
+    from text2video_amd.keypoints import NOSE_NECK_RGB, read_keypoints
+    p = os.path.join(GOLD, "keypoints_fadg0", "sa1_000_keypoints.json")
+    with_d = read_keypoints(p, (512, 384))
+    without = read_keypoints(p, (512, 384), hand_discs=False)
+    diff = (with_d != without).any(2)
+    ys, xs = np.nonzero(diff)
+    assert 40 < diff.sum() < 120 and ys.max() <= 8 and xs.max() <= 8      # quarter disc of radius 8 at (0,0)
+    assert tuple(with_d[0, 0]) == (255, 0, 0)                              # second (right-hand) disc wins
+    assert (without == np.array(NOSE_NECK_RGB)).all(2).any()               # nose-neck limb colour present
+
+
+def test_l2_driver_goldens_shape_and_monotone_names():
+    g = np.load(os.path.join(GOLD, "l2_driver_Shehadyour.npz"))
+    assert g["tmp"].shape == (87, 285) and g["tmp_smooth"].shape == (87, 285)
+    assert list(g["tmp_names"]) == ["%05d.json" % i for i in range(87)]
+    assert np.isfinite(g["tmp_smooth"]).all()
+
+
+def test_reference_command_line_parses_and_sets_no_flow():
+    from text2video_amd.options import TestOptions
+    opt = TestOptions().parse((REF_CMD % "datasets/fadg0").split())
+    assert opt.name == "fadg0" and opt.loadSize == 512 and opt.how_many == 1200 and opt.no_first_img
+    assert opt.openpose_only and opt.no_flow and opt.batchSize == 1 and opt.n_frames_G == 3
+    assert opt.ngf == 128 and opt.n_blocks == 9 and opt.n_downsample_G == 3 and opt.norm == "batch"
+    opt2 = TestOptions().parse(["--name", "x", "--some_fork_flag", "3"])   # unknown flags do not abort
+    assert opt2.name == "x"
+
+
+def test_readme_train_command_parses():
+    from text2video_amd.options import TrainOptions
+    cmd = ("--name pose2body_256p --dataroot datasets/pose --dataset_mode pose --input_nc 3 --num_D 2 "
+           "--resize_or_crop randomScaleHeight_and_scaledCrop --loadSize 544 --fineSize 512 "
+           "--gpu_ids 0,1,2,3,4,5,6,7 --batchSize 8 --max_frames_per_gpu 2 --niter 500 --niter_decay 5 "
+           "--no_first_img --n_frames_total 12 --max_t_step 4 --niter_step 100 --save_epoch_freq 100 "
+           "--add_face_disc --openpose_only")   # README.md:171-176
+    opt = TrainOptions().parse(cmd.split())
+    assert opt.gpu_ids == list(range(8)) and opt.batchSize == 8 and opt.max_frames_per_gpu == 2 and opt.add_face_disc
+
+
+def test_scale_height_geometry_and_central_crop():
+    from text2video_amd.options import TestOptions
+    from text2video_amd.pose_dataset import central_crop_cols, get_img_params
+    opt = TestOptions().parse((REF_CMD % "x").split())
+    assert get_img_params(opt, (512, 384)) == (680, 512)
+    assert get_img_params(opt, (1280, 720)) == (912, 512)
+    assert central_crop_cols(680) == (180, 500) and central_crop_cols(912) == (232, 680)
+
+
+def test_pose_dataset_windows_names_and_change_seq():
+    from text2video_amd.options import TestOptions
+    from text2video_amd.pose_dataset import PoseDataset
+    opt = TestOptions().parse((REF_CMD % os.path.join(GOLD, "dataset_fadg0_l2")).split())
+    ds = PoseDataset(opt)
+    assert len(ds) == 2 * (6 - 3 + 1)
+    items = list(ds)
+    assert [it["change_seq"] for it in items] == [True, False, False, False] * 2
+    assert items[0]["A"].shape == (3, 512, 320, 3) and items[0]["A"].dtype == np.uint8
+    assert np.array_equal(items[1]["A"][0], items[0]["A"][1])      # sliding window
+    assert os.path.basename(items[0]["A_path"]).startswith("00002") and items[4]["seq"] == "tmp_smooth"
+    opt.no_pose_crop = True
+    assert PoseDataset(opt)[0]["A"].shape == (3, 512, 680, 3)
+
+
+def test_visualizer_output_layout(tmp_path):
+    from text2video_amd.options import TestOptions
+    from text2video_amd.visualizer import Visualizer, tensor2im_np
+    opt = TestOptions().parse(["--name", "fadg0", "--results_dir", str(tmp_path)])
+    vis = Visualizer(opt)
+    img = np.zeros((8, 8, 3), np.uint8)
+    paths = vis.save_images({"real_A": img, "fake_B": img}, "datasets/fadg0/test_img/tmp_smooth/smooth_0002.jpg")
+    vis.flush()
+    want = os.path.join(str(tmp_path), "fadg0", "test_latest", "tmp_smooth", "fake_B_smooth_0002.jpg")
+    assert want in paths and os.path.exists(want)                  # image2video*.py globs fake_B_*.jpg
+    x = np.array([[[-1.0, 0.2, 1.0]]], np.float32).transpose(2, 0, 1)
+    assert tensor2im_np(x).ravel().tolist() == [0, 153, 255] or tensor2im_np(x).ravel().tolist() == [0, 152, 255]
+
+
+def test_test_py_fails_loudly_without_checkpoint(tmp_path):
+    """No checkpoint and no --synthetic_weights: the product path refuses to run (and never falls
+    back to a CPU implementation)."""
+    from text2video_amd import model as M
+    from text2video_amd.options import TestOptions
+    opt = TestOptions().parse((REF_CMD % os.path.join(GOLD, "dataset_fadg0_l2")).split()
+                              + ["--checkpoints_dir", str(tmp_path)])
+    with pytest.raises((FileNotFoundError, RuntimeError)):
+        M.create_model(opt)

@@ -1,0 +1,57 @@
+"""GPU end-to-end test of the drop-in boundary B1: the reference's own test.py command line
+(text2video_audio.sh:42) against a dataset in the layout its L2 driver writes, producing
+results/<name>/test_latest/<seq>/fake_B_*.jpg."""
+import glob
+import os
+import shutil
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+from PIL import Image
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def _make_dataset(tmp):
+    """datasets/fadg0 as interp_landmarks_motion_phoneme_VidTIMIT_smooth.py leaves it: pose JSONs
+    (fixtures captured from the reference driver) + the skeleton jpgs it renders (:220,:266)."""
+    from text2video_amd.keypoints import read_keypoints
+    root = os.path.join(tmp, "vid2vid", "datasets", "fadg0")
+    for seq, pat in (("tmp", "%04d.jpg"), ("tmp_smooth", "smooth_%04d.jpg")):
+        src = os.path.join(GOLD, "dataset_fadg0_l2", "test_openpose", seq)
+        os.makedirs(os.path.join(root, "test_openpose", seq))
+        os.makedirs(os.path.join(root, "test_img", seq))
+        for i, f in enumerate(sorted(os.listdir(src))):
+            shutil.copyfile(os.path.join(src, f), os.path.join(root, "test_openpose", seq, f))
+            Image.fromarray(read_keypoints(os.path.join(src, f), (512, 384))).save(
+                os.path.join(root, "test_img", seq, pat % i))
+    return os.path.join(tmp, "vid2vid")
+
+
+def test_reference_command_line_end_to_end(tmp_path):
+    work = _make_dataset(str(tmp_path))
+    cmd = [sys.executable, os.path.join(ROOT, "vid2vid", "test.py"), "--name", "fadg0", "--dataroot", "datasets/fadg0",
+           "--dataset_mode", "pose", "--input_nc", "3", "--resize_or_crop", "scaleHeight", "--loadSize", "512",
+           "--openpose_only", "--how_many", "1200", "--no_first_img", "--random_drop_prob", "0",
+           # no checkpoint ships with the reference: explicit opt-in to seeded random weights, small net
+           "--synthetic_weights", "1", "--ngf", "32", "--n_blocks", "3", "--timing_json", "timing.json"]
+    env = dict(os.environ, CUDA_VISIBLE_DEVICES="0")
+    r = subprocess.run(cmd, cwd=work, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    res = os.path.join(work, "results", "fadg0", "test_latest")
+    assert sorted(os.path.basename(p) for p in glob.glob(os.path.join(res, "tmp", "fake_B_*.jpg"))) == \
+        ["fake_B_%04d.jpg" % i for i in range(2, 6)]
+    assert sorted(os.path.basename(p) for p in glob.glob(os.path.join(res, "tmp_smooth", "fake_B_*.jpg"))) == \
+        ["fake_B_smooth_%04d.jpg" % i for i in range(2, 6)]
+    assert len(glob.glob(os.path.join(res, "*", "real_A_*.jpg"))) == 8
+    im = np.asarray(Image.open(os.path.join(res, "tmp", "fake_B_0003.jpg")))
+    assert im.shape == (512, 320, 3) and im.std() > 1.0          # 512 x 680 scaleHeight, central-width crop
+    assert "process image..." in r.stdout
+    # without --synthetic_weights the missing checkpoint is a hard error (no silent fallback)
+    r2 = subprocess.run(cmd[:cmd.index("--synthetic_weights")] + ["--ngf", "32"], cwd=work, env=env, capture_output=True,
+                        text=True, timeout=600)
+    assert r2.returncode != 0 and "not found" in (r2.stderr + r2.stdout)

@@ -1,0 +1,203 @@
+"""OpenPose-JSON -> pose-map rasteriser used by the pose dataset (host side, numpy).
+
+Counterpart of the routine the reference's pose dataset calls to build the generator input
+(/root/reference/keypoint2img.py:70-210 `read_keypoints`; semantics catalogued in SURVEY.md
+Appendix D).  Written from that specification, not from the file: the behaviour that has to be
+reproduced bit for bit is
+
+  * BODY_25 pose (10 limbs, head and legs not drawn), 70-point face (8 parts walked in two-point
+    steps), 2x21-point hands (5 fingers x 4 segments); validity thresholds 0.01 / 0.1 / 0.01 applied
+    per point (pose) or per part (face, finger); a point at x == 0 disables its segment;
+  * every segment is a 2-point straight line sampled at int(|delta|) positions along its major
+    axis, coordinates truncated toward zero;
+  * the line is the Levenberg-Marquardt fit scipy.optimize.curve_fit returns, NOT the closed form:
+    LM stops ~1e-5 short of the exact line and after truncation that moves pixels in ~5 % of the
+    frames (SURVEY App. D "Exactness note"), so parity mode calls the same SciPy routine
+    (`exact_fit=True`); `exact_fit=False` is the fast closed-form path;
+  * stamping: offsets range(-bw, bw) (asymmetric), 6x6 for pose/hand, 4x4 white for face;
+    "black -> colour, else average" is decided per offset for the WHOLE segment at once;
+    round end caps (i*i+j*j < 4*bw*bw) for pose/hand segments only;
+  * people are accumulated with uint8 wrap-around addition;
+  * two filled radius-8 discs at hand point 9 of each hand ((0,0) when there are no hands), drawn
+    with an OpenCV-style midpoint circle -- the one part that cannot be checked here (no OpenCV in
+    the container; the golden maps were captured with cv2.circle stubbed out), `hand_discs=True`.
+"""
+import json
+import warnings
+
+import numpy as np
+
+POSE_LIMBS = ((0, 1), (1, 8), (1, 2), (2, 3), (3, 4), (1, 5), (5, 6), (6, 7), (8, 9), (8, 12))
+POSE_RGB = ((153, 0, 51), (153, 0, 0), (153, 51, 0), (153, 102, 0), (153, 153, 0), (102, 153, 0), (51, 153, 0),
+            (0, 153, 0), (0, 153, 51), (0, 153, 102))
+FINGERS = tuple(tuple([0] + list(range(4 * f + 1, 4 * f + 5))) for f in range(5))
+FINGER_RGB = ((204, 0, 0), (163, 204, 0), (0, 204, 82), (0, 82, 204), (163, 0, 204))
+FACE_PARTS = (
+    (tuple(range(0, 17)),),                                   # jaw line
+    (tuple(range(17, 22)),), (tuple(range(22, 27)),),         # eyebrows
+    (tuple(range(27, 31)), tuple(range(31, 36))),             # nose
+    ((36, 37, 38, 39), (39, 40, 41, 36)),                     # left eye
+    ((42, 43, 44, 45), (45, 46, 47, 42)),                     # right eye
+    (tuple(range(48, 55)), (54, 55, 56, 57, 58, 59, 48)),     # outer mouth
+    (tuple(range(60, 65)), (64, 65, 66, 67, 60)),             # inner mouth
+)
+NOSE_NECK_RGB = POSE_RGB[0]  # the colour --add_face_disc keys its face crop on
+
+
+def _affine(x, a, b):
+    return a * x + b
+
+
+def _fit_line(u, v, exact_fit):
+    if exact_fit:
+        from scipy.optimize import curve_fit
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            (a, b), _ = curve_fit(_affine, u, v)
+        return a, b
+    a = (v[1] - v[0]) / (u[1] - u[0])
+    return a, v[0] - a * u[0]
+
+
+def trace_segment(x, y, exact_fit=True):
+    """Integer pixel coordinates (xs, ys) of the 2-point segment; may be empty."""
+    x = np.asarray(x, float)
+    y = np.asarray(y, float)
+    if abs(x[0] - x[1]) < abs(y[0] - y[1]):
+        ys, xs = trace_segment(y, x, exact_fit)
+        return xs, ys
+    n = int(abs(x[1] - x[0]))
+    if n <= 0:
+        return np.empty(0, int), np.empty(0, int)
+    a, b = _fit_line(x, y, exact_fit)
+    lo, hi = (x[0], x[1]) if x[0] <= x[1] else (x[1], x[0])
+    u = np.linspace(lo, hi, n)
+    return u.astype(int), _affine(u, a, b).astype(int)
+
+
+def _blend(img, yy, xx, rgb):
+    cur = img[yy, xx]
+    if (cur == 0).all():
+        img[yy, xx] = rgb
+    else:
+        img[yy, xx] = ((cur.astype(float) + rgb) / 2).astype(np.uint8)
+
+
+def stamp(img, xs, ys, bw, rgb, caps):
+    if xs.size == 0:
+        return
+    h, w = img.shape[:2]
+    rgb = np.asarray(rgb, float)
+    for oy in range(-bw, bw):
+        yy = np.clip(ys + oy, 0, h - 1)
+        for ox in range(-bw, bw):
+            _blend(img, yy, np.clip(xs + ox, 0, w - 1), rgb)
+    if caps:
+        ex, ey = xs[[0, -1]], ys[[0, -1]]
+        for oy in range(-2 * bw, 2 * bw):
+            for ox in range(-2 * bw, 2 * bw):
+                if oy * oy + ox * ox < 4 * bw * bw:
+                    _blend(img, np.clip(ey + oy, 0, h - 1), np.clip(ex + ox, 0, w - 1), rgb)
+
+
+def filled_disc(img, cx, cy, radius, rgb):
+    """Filled circle by the midpoint algorithm with horizontal spans (OpenCV-style; unverifiable
+    here -- see module docstring)."""
+    h, w = img.shape[:2]
+
+    def span(y, x0, x1):
+        if 0 <= y < h:
+            x0, x1 = max(x0, 0), min(x1, w - 1)
+            if x0 <= x1:
+                img[y, x0:x1 + 1] = rgb
+
+    err, dx, dy, plus, minus = 0, radius, 0, 1, 2 * radius - 1
+    while dx >= dy:
+        span(cy - dy, cx - dx, cx + dx)
+        span(cy + dy, cx - dx, cx + dx)
+        span(cy - dx, cx - dy, cx + dy)
+        span(cy + dx, cx - dy, cx + dy)
+        dy += 1
+        err += plus
+        plus += 2
+        if err > 0:
+            err -= minus
+            dx -= 1
+            minus -= 2
+
+
+def _valid_xy(pts, kind):
+    """(n,3) -> (n,2) with invalid points at (0,0)."""
+    out = np.zeros((pts.shape[0], 2))
+    if kind == "pose":
+        ok = pts[:, 2] > 0.01
+        out[ok] = pts[ok, :2]
+    elif kind == "face":
+        for part in FACE_PARTS:
+            for idx in part:
+                idx = list(idx)
+                if (pts[idx, 2] > 0.1).all():
+                    out[idx] = pts[idx, :2]
+    else:
+        for finger in FINGERS:
+            idx = list(finger)
+            if (pts[idx, 2] > 0.01).all():
+                out[idx] = pts[idx, :2]
+    return out
+
+
+def _draw_chain(img, pts, idx, bw, rgb, caps, exact_fit):
+    """consecutive two-point segments along the index list"""
+    for i in range(0, max(1, len(idx) - 1)):
+        sub = list(idx[i:i + 2])
+        x, y = pts[sub, 0], pts[sub, 1]
+        if len(sub) == 2 and not (x == 0).any():
+            xs, ys = trace_segment(x, y, exact_fit)
+            stamp(img, xs, ys, bw, rgb, caps)
+
+
+def render_person(person, size, basic_point_only=False, exact_fit=True, hand_discs=True, drop_prob=0.0, rng=None):
+    w, h = size
+    img = np.zeros((h, w, 3), np.uint8)
+    pose = _valid_xy(np.asarray(person["pose_keypoints_2d"], float).reshape(25, 3), "pose")
+    face = _valid_xy(np.asarray(person["face_keypoints_2d"], float).reshape(70, 3), "face")
+    if len(person.get("hand_left_keypoints_2d", [])) == 0:
+        hands = [np.zeros((21, 2)), np.zeros((21, 2))]
+    else:
+        hands = [_valid_xy(np.asarray(person[k], float).reshape(21, 3), "hand")
+                 for k in ("hand_left_keypoints_2d", "hand_right_keypoints_2d")]
+
+    def keep():
+        return drop_prob <= 0 or rng.random() > drop_prob
+
+    for limb, rgb in zip(POSE_LIMBS, POSE_RGB):
+        if keep():
+            _draw_chain(img, pose, limb, 3, rgb, True, exact_fit)
+    if not basic_point_only:
+        for hand in hands:
+            if keep():
+                for finger, rgb in zip(FINGERS, FINGER_RGB):
+                    _draw_chain(img, hand, finger, 3, rgb, True, exact_fit)
+        if keep():
+            for part in FACE_PARTS:
+                for idx in part:
+                    _draw_chain(img, face, idx, 2, (255, 255, 255), False, exact_fit)
+    if hand_discs:
+        filled_disc(img, int(hands[0][9, 0]), int(hands[0][9, 1]), 8, (0, 255, 0))
+        filled_disc(img, int(hands[1][9, 0]), int(hands[1][9, 1]), 8, (255, 0, 0))
+    return img
+
+
+def read_keypoints(json_input, size, random_drop_prob=0, remove_face_labels=False, basic_point_only=False,
+                   exact_fit=True, hand_discs=True, rng=None):
+    """Same call signature as the reference routine (+ keyword extras).  size = (w, h).
+    Returns uint8 [h, w, 3]."""
+    with open(json_input, encoding="utf-8") as fh:
+        people = json.load(fh)["people"]
+    w, h = size
+    canvas = np.zeros((h, w, 3), np.uint8)
+    if random_drop_prob > 0 and rng is None:
+        rng = np.random.default_rng()
+    for person in people:
+        canvas += render_person(person, size, basic_point_only, exact_fit, hand_discs, random_drop_prob, rng)
+    return canvas

@@ -1,0 +1,134 @@
+"""create_model / frame loop of vid2vid's test.py on the MI355X path.
+
+    opt = TestOptions().parse(); run_test(opt)
+is what `cd ../vid2vid && python test.py --name P --dataroot datasets/P --dataset_mode pose ...`
+(/root/reference/text2video_audio.sh:37-42) executes.
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+from . import ops
+from .generator import GeneratorSpec, HipGenerator, Vid2VidModelG, synthetic_state_dict
+from .pose_dataset import PoseDataset
+from .visualizer import Visualizer
+
+
+def generator_specs(opt):
+    """One GeneratorSpec per spatial scale (coarsest first), as Vid2VidModelG.initialize builds them."""
+    input_nc = opt.label_nc if opt.label_nc != 0 else opt.input_nc
+    specs = []
+    for s in range(opt.n_scales_spatial):
+        specs.append(GeneratorSpec(
+            input_nc=input_nc * opt.n_frames_G, prev_nc=(opt.n_frames_G - 1) * opt.output_nc,
+            output_nc=opt.output_nc, ngf=opt.ngf // (2 ** s), n_downsample=opt.n_downsample_G,
+            n_blocks=opt.n_blocks if s == 0 else opt.n_blocks_local, no_flow=opt.no_flow, norm=opt.norm,
+            is_local=s > 0, scale=s))
+    return specs
+
+
+def load_checkpoint(path):
+    """torch.save'd state-dict (legacy pickle stream of torch 0.4.1 included), tensors only."""
+    sd = torch.load(path, map_location="cpu", weights_only=True)
+    if isinstance(sd, dict) and "state_dict" in sd:
+        sd = sd["state_dict"]
+    out = {}
+    for k, v in sd.items():
+        k = k[7:] if k.startswith("module.") else k
+        if k.endswith(("running_mean", "running_var", "num_batches_tracked")):
+            continue  # BatchNorm runs in train mode at test time: batch statistics only
+        out[k] = v.float()
+    return out
+
+
+def create_model(opt, device="cuda:0"):
+    if opt.fp16:
+        print("warning: --fp16 ignored, the MI355X path computes in exact fp32", file=sys.stderr)
+    nets = []
+    for s, spec in enumerate(generator_specs(opt)):
+        path = os.path.join(opt.checkpoints_dir, opt.name, "%s_net_G%d.pth" % (opt.which_epoch, s))
+        if os.path.exists(path):
+            sd = load_checkpoint(path)
+            if spec.no_flow and any(k.startswith("model_final_flow") for k in sd):
+                print("note: %s holds a flow branch; ignored because of --openpose_only/--no_flow" % path)
+        elif opt.synthetic_weights is not None:
+            print("warning: %s not found -- using seeded random-init weights (seed %d)" % (path, opt.synthetic_weights))
+            sd = synthetic_state_dict(spec, opt.synthetic_weights + s, flow_gain=0.1)
+        else:
+            raise FileNotFoundError("%s not found (pass --synthetic_weights SEED to run without a checkpoint)" % path)
+        nets.append(HipGenerator(spec, device).load_state_dict(sd))
+    return Vid2VidModelG(nets, opt.n_frames_G, opt.output_nc, opt.no_first_img)
+
+
+def _real_A_u8(pose_map_u8):
+    """what util.tensor2im(real_A) writes: the pose map after the Normalize / de-normalize round trip"""
+    x = (pose_map_u8.astype(np.float32) / 255.0 - 0.5) / 0.5
+    return np.clip((x + 1) / 2.0 * 255.0, 0, 255).astype(np.uint8)
+
+
+def run_test(opt, model=None, device="cuda:0"):
+    """The frame loop.  Returns a dict of counters/timings."""
+    t_start = time.perf_counter()
+    dataset = PoseDataset(opt)
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        # one process per GPU (torchrun): sequences / sequence chunks are sharded over the ranks and
+        # every rank writes its own frames -- no collective on the data path
+        from . import distributed as D
+        rank, local_rank, world = D.init_from_env()
+        dataset.restrict(D.assign_chunks(dataset.seq_lengths(), world, opt.n_frames_G)[rank])
+        device = "cuda:%d" % local_rank
+    if model is None:
+        model = create_model(opt, device)
+    vis = Visualizer(opt)
+    dev = torch.device(device)
+    cs = ops.round_up(3 * opt.n_frames_G, 4)
+    window = dev_maps = None
+    pending = None   # (event, pinned uint8 frame, path, real_A) of the previous frame: D2H overlaps the next frame
+    n = 0
+    t_data = t_loop0 = 0.0
+
+    def finish(p):
+        ev, host, a_path, real_a = p
+        ev.synchronize()
+        vis.save_images({"real_A": real_a, "fake_B": host.numpy()[..., :3].copy()}, a_path)
+
+    for i, data in enumerate(dataset):
+        if i >= opt.how_many:
+            break
+        if n == 0:
+            t_loop0 = time.perf_counter()
+        A = data["A"]  # [tG, H, W, 3] uint8
+        H, W = A.shape[1], A.shape[2]
+        if data["change_seq"] or dev_maps is None or window.shape[:2] != (H, W):
+            model.reset()
+            window = torch.zeros(H, W, cs, dtype=torch.float32, device=dev)
+            dev_maps = [torch.from_numpy(A[f]).to(dev) for f in range(opt.n_frames_G)]
+        else:
+            dev_maps = dev_maps[1:] + [torch.from_numpy(A[-1]).to(dev, non_blocking=True)]
+        for f in range(opt.n_frames_G):
+            ops.pose_u8_to_f32(dev_maps[f], window, 3 * f)
+        out = model.inference_nhwc(window)
+        u8 = ops.tensor2im_u8(out)
+        host = torch.empty(u8.shape, dtype=torch.uint8, pin_memory=True)
+        host.copy_(u8, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        if pending is not None:
+            finish(pending)
+        pending = (ev, host, data["A_path"], _real_A_u8(A[-1]))
+        print("process image... %s" % data["A_path"])
+        n += 1
+    if pending is not None:
+        finish(pending)
+    vis.flush()
+    t_end = time.perf_counter()
+    stats = {"frames": n, "seconds_total": t_end - t_start,
+             "fps_loop": n / (t_end - t_loop0) if n else 0.0, "results_dir": vis.save_dir}
+    if opt.timing_json:
+        with open(opt.timing_json, "w") as fh:
+            json.dump(stats, fh)
+    return stats

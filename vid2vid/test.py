@@ -1,0 +1,24 @@
+#!/usr/bin/env python
+"""Drop-in for `../vid2vid/test.py` as the reference invokes it (text2video_audio.sh:37-42):
+
+    CUDA_VISIBLE_DEVICES=1 python test.py --name fadg0 --dataroot datasets/fadg0 --dataset_mode pose \
+        --input_nc 3 --resize_or_crop scaleHeight --loadSize 512 --openpose_only --how_many 1200 \
+        --no_first_img --random_drop_prob 0
+
+Reads datasets/<name>/test_openpose/<seq>/*.json (+ test_img/<seq>/*.jpg for size and names), writes
+results/<name>/test_latest/<seq>/{real_A,fake_B}_*.jpg.  The generator runs on the MI355X through
+libt2v_hip.so; there is no CPU fallback.
+"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from text2video_amd.model import run_test      # noqa: E402
+from text2video_amd.options import TestOptions  # noqa: E402
+
+if __name__ == "__main__":
+    opt = TestOptions().parse()
+    stats = run_test(opt)
+    print("done: %d frames, %.2f fps in the frame loop -> %s" % (stats["frames"], stats["fps_loop"],
+                                                                stats["results_dir"]))
