@@ -111,6 +111,10 @@ int build_conv_plan(const t2v_conv_desc* d, int x_cs, bool need_stats, ConvPlan*
     k.mtiles = (k.M + pl.BM - 1) / pl.BM;
     pl.nparts = k.nphases * k.mtiles;
     T2V_REQUIRE((long)k.mtiles * k.ntiles * k.nphases < (1L << 31), "conv: grid too large");
+    // buffer addressing: 32-bit byte offsets below the out-of-range marker 0x7fff0000
+    T2V_REQUIRE((long)d->H * d->W * x_cs * 4 < 0x7fff0000L, "conv: input tensor too large for 32-bit buffer offsets");
+    for (int ph = 0; ph < k.nphases; ++ph)
+        T2V_REQUIRE((long)pl.Cout_p * k.ph[ph].Kp * 4 < 0x7fff0000L, "conv: weight too large for 32-bit buffer offsets");
     return T2V_OK;
 }
 

@@ -68,9 +68,15 @@ struct TileCfg {
 using CfgL = TileCfg<32, 2, 2, 2, 2>;  // 128 x 128
 using CfgS = TileCfg<16, 4, 1, 4, 1>;  // 256 x 16 (3-channel heads)
 
-__device__ __forceinline__ void glds16(const float* src, char* lds_dst) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+// One LDS-DMA instruction through buffer addressing: 64 lanes x 16 B -> 1 KiB at the wave-uniform LDS
+// address `lds_dst`; source = base + voff (per lane, bytes) + soff (scalar, bytes).  Lanes with
+// voff >= nbytes are out of range and write zeros.  (Device-only builtins: the host pass of hipcc
+// must not see them, or it silently drops the kernel stubs.)
+__device__ __forceinline__ void dma16(const float* base, int nbytes, char* lds_dst, int voff, int soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, nbytes, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (__attribute__((address_space(3))) void*)lds_dst, 16, voff, soff, 0, 0);
+#endif
 }
 
 __device__ __forceinline__ int reflect_idx(int i, int n) {
@@ -129,43 +135,66 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(const ConvKParams p) {
     const float* __restrict__ wbase = p.w + ph.w_off;
 
     // ---- loader lane geometry: a wave instruction moves 8 rows x 128 B; lane -> (row, slot) ----
-    // Everything here is branch-free (selects only) so that the issue of stage kt+1's DMA can be
-    // interleaved, instruction by instruction, between the MFMAs of stage kt.
+    // Buffer addressing (buffer_load_dwordx4 ... lds): address = SRD base + per-lane voffset + scalar
+    // soffset.  The per-lane part (pixel, swizzled 16-B chunk) only changes when the filter tap
+    // changes; the per-stage part (channel block / K position) is an SGPR.  So a K stage costs the
+    // loader waves no VALU work at all in MODE 0, and lanes whose tap falls outside the image (zero
+    // padding), past K or past M use an out-of-range voffset: the hardware writes zeros to LDS.
+    constexpr int kOOB = 0x7fff0000;  // >= num_records of every SRD below (checked on the host)
     const int lrow = lane >> 3;   // 0..7
     const int lslot = lane & 7;   // physical 16-B slot in the row
+    const int x_bytes = p.Hin * p.Win * p.Cin_s * 4;
+    const int w_bytes = p.ntiles * BN * ph.Kp * 4;
     int a_by[A_ITERS], a_bx[A_ITERS];
     int a_coff[A_ITERS];  // float offset of the data chunk this lane fetches = 4*(slot ^ swizzle(row))
+    bool a_ok[A_ITERS];
+    int a_voff[A_ITERS];  // MODE 0: byte offset for the current tap
 #pragma unroll
     for (int i = 0; i < A_ITERS; ++i) {
         const int r = wid * (BM / 4) + i * 8 + lrow;
-        // rows past M (ragged last tile) re-read the last valid pixel: finite data whose results
-        // are masked at the store and in the statistics
-        const int m = min(m0 + r, p.M - 1);
+        const int m = m0 + r;
+        a_ok[i] = m < p.M;
         const int my = m / p.Wm, mx = m - my * p.Wm;
         a_by[i] = my * p.stride;
         a_bx[i] = mx * p.stride;
         a_coff[i] = (lslot ^ ((r >> 1) & 7)) * 4;
+        a_voff[i] = kOOB;
     }
-    const long zero_off = p.zero - p.x;  // float offset of the zero page relative to x
-
+    // byte offset of pixel (by+dy, bx+dx), channel c, or kOOB
+    auto pix_off = [&](int i, int dy, int dx, int c, bool ok) {
+        int iy = a_by[i] + dy, ix = a_bx[i] + dx;
+        if constexpr (REFLECT) {
+            iy = iy < 0 ? -iy : iy;
+            ix = ix < 0 ? -ix : ix;
+            iy = min(iy, 2 * p.Hin - 2 - iy);
+            ix = min(ix, 2 * p.Win - 2 - ix);
+        } else {
+            ok = ok && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
+        }
+        return ok ? ((iy * p.Win + ix) * p.Cin_s + c) * 4 : kOOB;
+    };
+    int cur_tap = -1;
+    // per-tap refresh of the A voffsets (MODE 0): once every Cin_s/32 stages
+    auto set_tap = [&](int tap) {
+        const int dy = p.tdy[ph.tap0 + tap], dx = p.tdx[ph.tap0 + tap];
+#pragma unroll
+        for (int i = 0; i < A_ITERS; ++i) a_voff[i] = pix_off(i, dy, dx, a_coff[i], a_ok[i]);
+        cur_tap = tap;
+    };
     // A-operand DMA instruction i (of A_ITERS per wave) of K-stage kt into ring slot buf
     auto issue_a = [&](int i, int kt, int buf) {
         char* dst = smem + buf * Cfg::STAGE_BYTES + (wid * (BM / 4) + i * 8) * 128;
-        int dy, dx, c;
-        bool kin = true;
         if constexpr (MODE == 0) {
-            // whole 32-deep stage lies inside one tap: tap index and channel base are scalar
             const int cpt = p.Cin_s >> 5;
-            const int tap = kt / cpt;
-            c = ((kt - tap * cpt) << 5) + a_coff[i];
-            dy = p.tdy[ph.tap0 + tap];
-            dx = p.tdx[ph.tap0 + tap];
+            const int c0 = (kt - cur_tap * cpt) << 5;  // set_tap(kt / cpt) was called for this stage
+            dma16(p.x, x_bytes, dst, a_voff[i], c0 * 4);
         } else {
             // general path (Cin_s = 8 / 12 stems, narrow test nets): each 16-B chunk has its own tap
             const int k = kt * kBK + a_coff[i];
-            kin = k < ph.ntaps * p.Cin_s;
+            const bool kin = k < ph.ntaps * p.Cin_s;
             const int tap = kin ? k / p.Cin_s : 0;
-            c = kin ? k - tap * p.Cin_s : 0;  // k >= K: any finite datum (its weights are zero)
+            const int c = k - tap * p.Cin_s;
+            int dy, dx;
             if constexpr (MODE == 1) {
                 const int kh = tap / p.KW;
                 dy = kh - p.pad;
@@ -174,27 +203,16 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(const ConvKParams p) {
                 dy = p.tdy[ph.tap0 + tap];
                 dx = p.tdx[ph.tap0 + tap];
             }
+            dma16(p.x, x_bytes, dst, pix_off(i, dy, dx, c, kin && a_ok[i]), 0);
         }
-        int iy = a_by[i] + dy, ix = a_bx[i] + dx;
-        long off;
-        if constexpr (REFLECT) {
-            iy = iy < 0 ? -iy : iy;
-            ix = ix < 0 ? -ix : ix;
-            iy = min(iy, 2 * p.Hin - 2 - iy);
-            ix = min(ix, 2 * p.Win - 2 - ix);
-            off = (long)((unsigned)(iy * p.Win + ix) * (unsigned)p.Cin_s + (unsigned)c);
-        } else {
-            const bool ok = (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
-            off = ok ? (long)((unsigned)(iy * p.Win + ix) * (unsigned)p.Cin_s + (unsigned)c) : zero_off;
-        }
-        glds16(p.x + off, dst);
     };
     // B-operand (packed weights [Cout_p][Kp]) DMA instruction `instr` (of BN/8 per block)
     auto issue_b = [&](int instr, int kt, int buf) {
         char* dst = smem + buf * Cfg::STAGE_BYTES + BM * 128 + instr * 8 * 128;
         const int r = instr * 8 + lrow;
         const int chunk = lslot ^ ((r >> 1) & 7);
-        glds16(wbase + (size_t)(n0 + r) * ph.Kp + kt * kBK + chunk * 4, dst);
+        const int voff = ((n0 + r) * ph.Kp + chunk * 4) * 4;  // loop invariant per instr
+        dma16(wbase, w_bytes, dst, voff, kt * (kBK * 4));
     };
     // this wave's DMA instruction number `n` of a stage: first its A rows, then its B rows
     constexpr int B_PER_WAVE = (B_INSTR >= 4) ? B_INSTR / 4 : 1;
@@ -209,6 +227,15 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(const ConvKParams p) {
                 if (wid < B_INSTR) issue_b(wid, kt, buf);  // wave-uniform
             }
         }
+    };
+    // all DMA instructions of stage kt (refreshing the tap offsets when the stage enters a new tap)
+    auto issue_stage = [&](int kt, int buf) {
+        if constexpr (MODE == 0) {
+            const int tap = kt / (p.Cin_s >> 5);
+            if (tap != cur_tap) set_tap(tap);
+        }
+#pragma unroll
+        for (int n = 0; n < LD_PER_WAVE; ++n) issue(n, kt, buf);
     };
 
     // ---- MFMA fragment geometry ----
@@ -260,15 +287,12 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(const ConvKParams p) {
         // would drain vmcnt to 0.  Stages past the end re-fetch the last stage (no branches).
         constexpr int AHEAD = RING - 1;  // stages in flight beyond the one being computed
 #pragma unroll
-        for (int st = 0; st < AHEAD; ++st)
-#pragma unroll
-            for (int n = 0; n < LD_PER_WAVE; ++n) issue(n, min(st, nk - 1), st);
+        for (int st = 0; st < AHEAD; ++st) issue_stage(min(st, nk - 1), st);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * LD_PER_WAVE) : "memory");
         __builtin_amdgcn_s_barrier();  // B0: stage 0 has landed
         int slot = AHEAD;              // slot of stage kt+AHEAD (== slot released by barrier(kt-1))
         for (int kt = 0; kt < nk; ++kt) {
-#pragma unroll
-            for (int n = 0; n < LD_PER_WAVE; ++n) issue(n, min(kt + AHEAD, nk - 1), slot);
+            issue_stage(min(kt + AHEAD, nk - 1), slot);
             // stage kt+1 landed; the younger stage (RING 3) stays in flight across the barrier
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * LD_PER_WAVE) : "memory");
             __builtin_amdgcn_s_barrier();  // barrier(kt)
@@ -284,13 +308,16 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(const ConvKParams p) {
 #pragma unroll
             for (int q = 0; q < Cfg::RQ; ++q) {
                 const int cur = q & 1;
-                if (q + 1 < Cfg::RQ) load_frags(buf, q + 1, cur ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
                 if (q + 1 == Cfg::RQ) {
-                    __syncthreads();  // barrier(kt): slot `buf` released, stage kt+1 visible
+                    // barrier(kt): every wave has read its last fragments of slot `buf` (issued during
+                    // the previous group) -> slot released to the loaders; stage kt+1 is visible
+                    __syncthreads();
+                    __builtin_amdgcn_sched_barrier(0);
                     load_frags(nbuf, 0, cur ^ 1);
+                } else {
+                    load_frags(buf, q + 1, cur ^ 1);
                 }
-                // pin the prefetch: DS and MFMA instructions may not cross this point
-                __builtin_amdgcn_sched_barrier(0x2 | 0x4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -298,6 +325,14 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(const ConvKParams p) {
 #pragma unroll
                         for (int j = 0; j < Cfg::TN; ++j)
                             acc[i][j] = MM::run(af[cur][i][e], bf[cur][j][e], acc[i][j]);
+                // issue order inside the group: MFMA, ds_read, MFMA, ds_read, ... so that every
+                // fragment read of the NEXT group issues in the shadow of an executing MFMA
+#pragma unroll
+                for (int r = 0; r < Cfg::TM + Cfg::TN; ++r) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 4 * Cfg::TM * Cfg::TN - (Cfg::TM + Cfg::TN), 0);
             }
             buf = nbuf;
         }
