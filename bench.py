@@ -52,6 +52,18 @@ def gflop_per_frame(H, W, flow, ngf=128, n_down=3, n_blocks=9):
     return f / 1e9
 
 
+def local_gflop_per_frame(H, W, flow, ngf=64, n_blocks=3):
+    """CompositeLocalGenerator add-on at full resolution."""
+    f = 0.0
+    for cin in (9, 6):
+        f += 2 * 49 * cin * ngf * H * W + 2 * 9 * ngf * 2 * ngf * (H // 2) * (W // 2)
+    branch = n_blocks * 2 * 2 * 9 * (2 * ngf) ** 2 * (H // 2) * (W // 2) + 2 * 9 * 2 * ngf * ngf * (H // 2) * (W // 2)
+    f += branch + 2 * 49 * ngf * 3 * H * W
+    if flow:
+        f += branch + 2 * 49 * ngf * 3 * H * W
+    return f / 1e9
+
+
 def synthetic_pose_u8(n, H, W, seed):
     """pose maps as the dataset would hand them over: uint8 HWC, black background, ~1 % coloured pixels"""
     rng = np.random.default_rng(seed)
@@ -69,6 +81,8 @@ def main():
     ap.add_argument("--height", type=int, default=512)
     ap.add_argument("--width", type=int, default=512)
     ap.add_argument("--flow", action="store_true", help="enable the flow-warp compositor branch")
+    ap.add_argument("--scales", type=int, default=1, choices=[1, 2],
+                    help="2 = config 4's two-scale generator: G0 at H/2 x W/2 + local enhancer G1 at H x W")
     ap.add_argument("--cpu-frames", type=int, default=2, help="frames of the CPU-oracle baseline (0 = skip)")
     ap.add_argument("--kernel-iters", type=int, default=20)
     args = ap.parse_args()
@@ -95,8 +109,11 @@ def main():
     H, W, K, Wm = args.height, args.width, args.steps, args.warmup
     spec = GeneratorSpec(ngf=128, n_downsample=3, n_blocks=9, no_flow=not args.flow, norm="batch")
     sd = synthetic_state_dict(spec, seed=1, flow_gain=0.1)
-    net = HipGenerator(spec, dev).load_state_dict(sd)
-    model = Vid2VidModelG([net])
+    nets = [HipGenerator(spec, dev).load_state_dict(sd)]
+    if args.scales == 2:
+        spec1 = GeneratorSpec(ngf=64, n_blocks=3, no_flow=not args.flow, norm="batch", is_local=True, scale=1)
+        nets.append(HipGenerator(spec1, dev).load_state_dict(synthetic_state_dict(spec1, seed=2, flow_gain=0.1)))
+    model = Vid2VidModelG(nets)
 
     nposes = K + Wm + 2
     poses = torch.from_numpy(synthetic_pose_u8(nposes, H, W, seed=rank)).to(dev)   # resident in HBM
@@ -136,7 +153,10 @@ def main():
     result = None
     if rank == 0:
         fps = world * K / elapsed
-        gf = gflop_per_frame(H, W, args.flow)
+        if args.scales == 2:   # G0 on the half-resolution pyramid level + the local enhancer
+            gf = gflop_per_frame(H // 2, W // 2, args.flow) + local_gflop_per_frame(H, W, args.flow)
+        else:
+            gf = gflop_per_frame(H, W, args.flow)
         # ---- dominant kernel, timed live with HIP events on the stream it is launched on ----
         C, hb, wb = 1024, H // 8, W // 8
         desc = ops.conv_desc(hb, wb, C, C, 3, 1, 1, ops.PAD_REFLECT)
@@ -174,7 +194,13 @@ def main():
             cores = torch.get_num_threads()
             ref_net = CompositeGenerator(9, 3, 6, 128, 3, 9, spec.no_flow, "batch")
             ref_net.load_state_dict(sd, strict=False)
-            ref = Vid2VidInferenceRef([ref_net])
+            ref_nets = [ref_net]
+            if args.scales == 2:
+                from oracle.generator_ref import CompositeLocalGenerator
+                loc = CompositeLocalGenerator(9, 3, 6, 128, 3, 1, spec.no_flow, "batch")
+                loc.load_state_dict(synthetic_state_dict(spec1, seed=2, flow_gain=0.1), strict=False)
+                ref_nets.append(loc)
+            ref = Vid2VidInferenceRef(ref_nets)
             pf = ((poses[:args.cpu_frames + 3].cpu().float() / 255.0 - 0.5) / 0.5).permute(0, 3, 1, 2)
             ref.inference(pf[0:3].unsqueeze(0))          # warm-up frame (thread pool, first-frame path)
             c0 = time.perf_counter()
@@ -189,9 +215,11 @@ def main():
             "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
             "ms_per_step": round(1e3 * elapsed / K, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[1]: fadg0 openpose_only %dx%d, %d-frame synthetic pose seq per GPU, "
-                                   "generator-only inference, ngf128 n_down3 n_blocks9, %s"
-                                   % (H, W, K, "flow-warp compositor ON" if args.flow else "no flow branch (--openpose_only)"),
+            "config": {"workload": "%s: fadg0 openpose_only %dx%d, %d-frame synthetic pose seq per GPU, "
+                                   "generator-only inference, ngf128 n_down3 n_blocks9%s, %s"
+                                   % ("configs[1]" if (H, W, args.scales) == (512, 512, 1) else "configs[3]-style", H, W, K,
+                                      " + local enhancer (n_scales_spatial 2)" if args.scales == 2 else "",
+                                      "flow-warp compositor ON" if args.flow else "no flow branch (--openpose_only)"),
                        "frames_per_gpu": K, "parallelism": "sequence-chunk dp%d" % world,
                        "gflop_per_frame": round(gf, 1), "model_tflops": round(fps * gf / 1e3, 2),
                        "model_frac_of_fp32_mfma_peak": round(fps * gf / 1e3 / (PEAK_FP32_MFMA_TFLOPS * world), 4)},

@@ -42,7 +42,8 @@ typedef enum {
 enum { T2V_PAD_ZERO = 0, T2V_PAD_REFLECT = 1 };
 /* epilogue activations fused into the conv (Tanh_updateOutput THCUNN.h:1177,
  * Sigmoid_updateOutput :1098, flow x20 [SURVEY App. A.1]) */
-enum { T2V_ACT_NONE = 0, T2V_ACT_TANH = 1, T2V_ACT_FLOW_W = 2 /* ch0,1: x*20 ; ch2: sigmoid */ };
+enum { T2V_ACT_NONE = 0, T2V_ACT_TANH = 1, T2V_ACT_FLOW_W = 2 /* ch0,1: x*20 ; ch2: sigmoid */,
+       T2V_ACT_LRELU = 3 /* x>0 ? x : act_scale*x  (LeakyReLU_updateOutput THCUNN.h:220) */ };
 
 typedef struct t2v_ctx t2v_ctx;
 
@@ -90,11 +91,15 @@ int t2v_conv2d_forward(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, const
  * (THCUNN.h:33) as reached from F.instance_norm ($SP/torch/nn/functional.py:1258-1301) and
  * Threshold_updateOutput (THCUNN.h:1328).  Biased variance, eps inside the sqrt.
  *   finalize: combines the conv epilogue's partials (Chan et al.) -> mean_rstd[C][2]
- *   apply:    y = [relu]((x-mean)*rstd*gamma+beta) + res1 + res2   (gamma/beta/res* nullable,
- *             y may alias x)
+ *   apply:    y = act((x-mean)*rstd*gamma+beta) + res1 + res2   (gamma/beta/res* nullable,
+ *             y may alias x); relu: 0 none, 1 ReLU, 2 LeakyReLU(0.2) (the discriminators)
+ *   Batch statistics (BatchNorm2d in train mode over a batch of B images, the discriminators):
+ *   run the conv per image with stats_partial + b*t2v_conv_stats_floats(d), then finalize_batch.
  * ------------------------------------------------------------------------------------------ */
 int t2v_instance_norm_finalize(t2v_ctx* ctx, void* stream, const t2v_conv_desc* producer,
                                const float* stats_partial, float eps, float* mean_rstd);
+int t2v_batch_norm_finalize(t2v_ctx* ctx, void* stream, const t2v_conv_desc* producer, int batch,
+                            const float* stats_partial, float eps, float* mean_rstd);
 int t2v_instance_norm_apply(t2v_ctx* ctx, void* stream, const float* x, const float* mean_rstd,
                             const float* gamma, const float* beta, const float* res1,
                             const float* res2, float* y, long npix, int C, int relu);
@@ -113,6 +118,21 @@ int t2v_flow_warp_composite(t2v_ctx* ctx, void* stream, const float* raw, const 
 /* AvgPool2d(3, stride 2, padding 1, count_include_pad=False) -- SpatialAveragePooling_
  * updateOutput (THCUNN.h:579; pooling.py:536-543).  NHWC, C % 4 == 0 not required. */
 int t2v_avgpool3x3s2(t2v_ctx* ctx, void* stream, const float* x, float* y, int H, int W, int C);
+
+/* ------------------------------------------------------------------------------------------
+ * Train-step scalars.
+ *   sum_sq_diff_const : sum (x - c)^2      -> out[0]   (MSECriterion_updateOutput THCUNN.h:356,
+ *                       LSGAN target 1/0; the caller divides by n for 'elementwise_mean')
+ *   sum_abs_diff      : sum |a - b|        -> out[0]   (AbsCriterion_updateOutput THCUNN.h:18)
+ *   adam_step         : torch.optim.Adam.step ($SP/torch/optim/adam.py:48-98), one fused pass:
+ *                       m = b1*m + (1-b1)*g ; v = b2*v + (1-b2)*g*g ;
+ *                       p -= lr*sqrt(1-b2^t)/(1-b1^t) * m / (sqrt(v) + eps)
+ * `scratch` must hold >= 2048 floats.  Deterministic two-level reductions (no atomics).
+ * ------------------------------------------------------------------------------------------ */
+int t2v_sum_sq_diff_const(t2v_ctx* ctx, void* stream, const float* x, float c, long n, float* scratch, float* out);
+int t2v_sum_abs_diff(t2v_ctx* ctx, void* stream, const float* a, const float* b, long n, float* scratch, float* out);
+int t2v_adam_step(t2v_ctx* ctx, void* stream, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                  long n, float lr, float beta1, float beta2, float eps, int step);
 
 /* layout / dtype plumbing on the device */
 int t2v_nchw_to_nhwc(t2v_ctx* ctx, void* stream, const float* src, float* dst, int C, int H, int W, int dst_cs);

@@ -149,6 +149,12 @@ def test_pose_dataset_windows_names_and_change_seq():
     assert items[0]["A"].shape == (3, 512, 320, 3) and items[0]["A"].dtype == np.uint8
     assert np.array_equal(items[1]["A"][0], items[0]["A"][1])      # sliding window
     assert os.path.basename(items[0]["A_path"]).startswith("00002") and items[4]["seq"] == "tmp_smooth"
+    # the process-pool prefetcher yields identical items (bit for bit, same order)
+    pre = list(ds.iter_prefetch(workers=2))
+    assert len(pre) == len(items)
+    for a, b in zip(items, pre):
+        assert np.array_equal(a["A"], b["A"]) and a["A_path"] == b["A_path"] and a["change_seq"] == b["change_seq"]
+    assert len(list(ds.iter_prefetch(workers=2, limit=3))) == 3
     opt.no_pose_crop = True
     assert PoseDataset(opt)[0]["A"].shape == (3, 512, 680, 3)
 

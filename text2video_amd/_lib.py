@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libt2v_hip.so")
 
 T2V_OK = 0
 PAD_ZERO, PAD_REFLECT = 0, 1
-ACT_NONE, ACT_TANH, ACT_FLOW_W = 0, 1, 2
+ACT_NONE, ACT_TANH, ACT_FLOW_W, ACT_LRELU = 0, 1, 2, 3
 ABI_VERSION = 1
 
 
@@ -56,6 +56,11 @@ SIGNATURES = {
     "t2v_conv2d_forward": (c_int, [c_void_p, c_void_p, POINTER(ConvDesc), c_void_p, c_int, c_void_p, c_void_p,
                                    c_void_p, c_int, c_void_p]),
     "t2v_instance_norm_finalize": (c_int, [c_void_p, c_void_p, POINTER(ConvDesc), c_void_p, c_float, c_void_p]),
+    "t2v_batch_norm_finalize": (c_int, [c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_void_p, c_float, c_void_p]),
+    "t2v_sum_sq_diff_const": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_long, c_void_p, c_void_p]),
+    "t2v_sum_abs_diff": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_void_p]),
+    "t2v_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_float, c_float,
+                              c_float, c_float, c_int]),
     "t2v_instance_norm_apply": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_void_p, c_long, c_int, c_int]),
     "t2v_flow_warp_composite": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,

@@ -222,6 +222,30 @@ int t2v_instance_norm_finalize(t2v_ctx* ctx, void* stream, const t2v_conv_desc* 
                                  producer->Cout, eps, mean_rstd);
 }
 
+int t2v_batch_norm_finalize(t2v_ctx* ctx, void* stream, const t2v_conv_desc* producer, int batch,
+                            const float* stats_partial, float eps, float* mean_rstd) {
+    T2V_REQUIRE(ctx && stats_partial && mean_rstd && batch >= 1, "batch_norm_finalize: bad arguments");
+    ConvPlan pl;
+    T2V_TRY(build_conv_plan(producer, round_up(producer ? producer->Cin : 0, 4), true, &pl));
+    // the per-image partial blocks are contiguous: a batch is just `batch` times more partial rows
+    return launch_inorm_finalize((hipStream_t)stream, stats_partial, batch * pl.nparts, pl.kp.mtiles, pl.BM, pl.kp.M,
+                                 producer->Cout, eps, mean_rstd);
+}
+
+int t2v_sum_sq_diff_const(t2v_ctx* ctx, void* stream, const float* x, float c, long n, float* scratch, float* out) {
+    T2V_REQUIRE(ctx && x && scratch && out && n > 0, "sum_sq_diff_const: bad arguments");
+    return launch_reduce((hipStream_t)stream, 0, x, nullptr, c, n, scratch, out);
+}
+int t2v_sum_abs_diff(t2v_ctx* ctx, void* stream, const float* a, const float* b, long n, float* scratch, float* out) {
+    T2V_REQUIRE(ctx && a && b && scratch && out && n > 0, "sum_abs_diff: bad arguments");
+    return launch_reduce((hipStream_t)stream, 1, a, b, 0.f, n, scratch, out);
+}
+int t2v_adam_step(t2v_ctx* ctx, void* stream, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                  long n, float lr, float beta1, float beta2, float eps, int step) {
+    T2V_REQUIRE(ctx && param && grad && exp_avg && exp_avg_sq && n > 0 && step >= 1, "adam_step: bad arguments");
+    return launch_adam((hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, step);
+}
+
 int t2v_instance_norm_apply(t2v_ctx* ctx, void* stream, const float* x, const float* mean_rstd, const float* gamma,
                             const float* beta, const float* res1, const float* res2, float* y, long npix, int C,
                             int relu) {

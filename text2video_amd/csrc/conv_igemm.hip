@@ -433,6 +433,8 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(const ConvKParams p) {
                             v = tanhf(v);
                         } else if (p.act == T2V_ACT_FLOW_W) {
                             v = col[j] < 2 ? v * p.act_scale : 1.f / (1.f + expf(-v));
+                        } else if (p.act == T2V_ACT_LRELU) {
+                            v = v > 0.f ? v : v * p.act_scale;
                         }
                         yrow[col[j]] = col[j] < p.Cout ? v : 0.f;
                     }

@@ -2,6 +2,8 @@
 //   instance-norm finalize/apply(+ReLU+residual), flow-warp compositor, 3x3/s2 average pool,
 //   weight repacking and NCHW<->NHWC / uint8 plumbing.  All NHWC, 16-byte accesses where the
 //   layout allows, grid-stride with <= 2048 blocks (cdna_hip_programming.md Guideline 11/13).
+#include <math.h>
+
 #include "t2v_internal.h"
 
 namespace t2v {
@@ -92,11 +94,16 @@ __global__ __launch_bounds__(256) void inorm_apply_kernel(const float4* __restri
             v.z = v.z * gm.z + bt.z;
             v.w = v.w * gm.w + bt.w;
         }
-        if (relu) {
+        if (relu == 1) {
             v.x = fmaxf(v.x, 0.f);
             v.y = fmaxf(v.y, 0.f);
             v.z = fmaxf(v.z, 0.f);
             v.w = fmaxf(v.w, 0.f);
+        } else if (relu == 2) {  // LeakyReLU(0.2)
+            v.x = v.x > 0.f ? v.x : 0.2f * v.x;
+            v.y = v.y > 0.f ? v.y : 0.2f * v.y;
+            v.z = v.z > 0.f ? v.z : 0.2f * v.z;
+            v.w = v.w > 0.f ? v.w : 0.2f * v.w;
         }
         if (res1) {
             const float4 r = res1[i];
@@ -139,6 +146,77 @@ int launch_add(hipStream_t s, const float* a, const float* b, float* y, long n) 
     hipLaunchKernelGGL(add_kernel, dim3(grid_for(n / 4, 256)), dim3(256), 0, s,
                        reinterpret_cast<const float4*>(a), reinterpret_cast<const float4*>(b),
                        reinterpret_cast<float4*>(y), n / 4);
+    T2V_HIP_CHECK(hipGetLastError());
+    return T2V_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// train-step scalars: deterministic two-level reductions (per-block partial -> one block), Adam
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    if (l == 0) sh[w] = v;
+    __syncthreads();
+    float t = 0.f;
+    if (threadIdx.x == 0)
+        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += sh[i];
+    return t;  // valid in thread 0
+}
+template <int OP>  // 0: (x-c)^2 ; 1: |a-b|
+__global__ __launch_bounds__(256) void reduce_partial_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                             float c, long n, float* __restrict__ part) {
+    __shared__ float sh[4];
+    float s = 0.f;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        if (OP == 0) {
+            const float d = a[i] - c;
+            s += d * d;
+        } else {
+            s += fabsf(a[i] - b[i]);
+        }
+    }
+    const float t = block_sum(s, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+__global__ __launch_bounds__(256) void reduce_final_kernel(const float* __restrict__ part, int np, float* out) {
+    __shared__ float sh[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < np; i += blockDim.x) s += part[i];
+    const float t = block_sum(s, sh);
+    if (threadIdx.x == 0) out[0] = t;
+}
+int launch_reduce(hipStream_t s, int op, const float* a, const float* b, float c, long n, float* scratch, float* out) {
+    const int g = grid_for(n, 256);
+    if (op == 0)
+        hipLaunchKernelGGL(reduce_partial_kernel<0>, dim3(g), dim3(256), 0, s, a, b, c, n, scratch);
+    else
+        hipLaunchKernelGGL(reduce_partial_kernel<1>, dim3(g), dim3(256), 0, s, a, b, c, n, scratch);
+    hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(256), 0, s, scratch, g, out);
+    T2V_HIP_CHECK(hipGetLastError());
+    return T2V_OK;
+}
+
+// torch.optim.Adam.step ($SP/torch/optim/adam.py:86-98), same operation order
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, long n, float b1, float b2, float eps, float step_size) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float gi = g[i];
+        const float mi = m[i] * b1 + (1.f - b1) * gi;
+        const float vi = v[i] * b2 + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] = p[i] - step_size * (mi / (sqrtf(vi) + eps));
+    }
+}
+int launch_adam(hipStream_t s, float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2,
+                float eps, int step) {
+    const double bc1 = 1.0 - pow((double)b1, step), bc2 = 1.0 - pow((double)b2, step);
+    const float step_size = (float)((double)lr * sqrt(bc2) / bc1);
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, p, g, m, v, n, b1, b2, eps, step_size);
     T2V_HIP_CHECK(hipGetLastError());
     return T2V_OK;
 }

@@ -97,6 +97,9 @@ int launch_pack_convT_weight(hipStream_t s, const float* w, float* packed, int C
 void convT_phase_taps_host(int phase, int* ntaps, int kh[4], int kw[4], int dy[4], int dx[4], int* a, int* b);
 int launch_nchw_to_nhwc(hipStream_t s, const float* src, float* dst, int C, int H, int W, int Cs);
 int launch_nhwc_to_nchw(hipStream_t s, const float* src, float* dst, int C, int H, int W, int Cs);
+int launch_reduce(hipStream_t s, int op, const float* a, const float* b, float c, long n, float* scratch, float* out);
+int launch_adam(hipStream_t s, float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2,
+                float eps, int step);
 int launch_add(hipStream_t s, const float* a, const float* b, float* y, long n);
 int launch_warp_composite(hipStream_t s, const float* raw, const float* fw, const float* prev, int prev_cs,
                           int prev_c0, float* out, float* warp_out, int H, int W);

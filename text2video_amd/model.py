@@ -96,9 +96,7 @@ def run_test(opt, model=None, device="cuda:0"):
         ev.synchronize()
         vis.save_images({"real_A": real_a, "fake_B": host.numpy()[..., :3].copy()}, a_path)
 
-    for i, data in enumerate(dataset):
-        if i >= opt.how_many:
-            break
+    for i, data in enumerate(dataset.iter_prefetch(opt.pose_workers, limit=opt.how_many)):
         if n == 0:
             t_loop0 = time.perf_counter()
         A = data["A"]  # [tG, H, W, 3] uint8

@@ -11,7 +11,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import ACT_FLOW_W, ACT_NONE, ACT_TANH, PAD_REFLECT, PAD_ZERO, ConvDesc, check  # noqa: F401
+from ._lib import ACT_FLOW_W, ACT_LRELU, ACT_NONE, ACT_TANH, PAD_REFLECT, PAD_ZERO, ConvDesc, check  # noqa: F401
 
 _contexts = {}
 
@@ -184,3 +184,53 @@ def copy_channels(src, src_c0, dst, dst_c0, nc):
     check(c.lib.t2v_copy_channels(c.handle, _stream(), _p(src), src.shape[-1], src_c0, _p(dst), dst.shape[-1],
                                   dst_c0, nc, npix), "copy_channels")
     return dst
+
+
+# ------------------------------------------------------------------------------------------------
+# train-step pieces
+# ------------------------------------------------------------------------------------------------
+def batch_norm_finalize(stats, desc, batch, eps=1e-5):
+    """BatchNorm2d(train) statistics over a batch: `stats` holds `batch` consecutive per-image
+    partial blocks written by conv2d(..., stats=stats[b * n : (b + 1) * n])."""
+    c = context()
+    mr = torch.empty(desc.Cout, 2, dtype=torch.float32, device=stats.device)
+    check(c.lib.t2v_batch_norm_finalize(c.handle, _stream(), ctypes.byref(desc), batch, _p(stats), eps, _p(mr)),
+          "batch_norm_finalize")
+    return mr
+
+
+_scratch = {}
+
+
+def _reduce_scratch(device):
+    s = _scratch.get(device)
+    if s is None:
+        s = _scratch[device] = torch.empty(2048, dtype=torch.float32, device=device)
+    return s
+
+
+def sum_sq_diff_const(x, c0):
+    """sum((x - c0)^2) as a 1-element device tensor (LSGAN MSE numerator)."""
+    c = context()
+    out = torch.empty(1, dtype=torch.float32, device=x.device)
+    check(c.lib.t2v_sum_sq_diff_const(c.handle, _stream(), _p(x), float(c0), x.numel(), _p(_reduce_scratch(x.device)),
+                                      _p(out)), "sum_sq_diff_const")
+    return out
+
+
+def sum_abs_diff(a, b):
+    """sum(|a - b|) as a 1-element device tensor (L1 feature-matching numerator)."""
+    c = context()
+    assert a.shape == b.shape
+    out = torch.empty(1, dtype=torch.float32, device=a.device)
+    check(c.lib.t2v_sum_abs_diff(c.handle, _stream(), _p(a), _p(b), a.numel(), _p(_reduce_scratch(a.device)), _p(out)),
+          "sum_abs_diff")
+    return out
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step):
+    """In-place fused Adam update of one flat fp32 tensor (torch.optim.Adam.step semantics)."""
+    c = context()
+    check(c.lib.t2v_adam_step(c.handle, _stream(), _p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(),
+                              lr, beta1, beta2, eps, int(step)), "adam_step")
+    return param

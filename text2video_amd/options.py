@@ -54,6 +54,7 @@ def _common(p):
     g("--no_pose_crop", action="store_true", help="keep the full width instead of upstream's central-width crop")
     g("--fast_pose", action="store_true", help="closed-form segment fit in the rasteriser (not bit-identical)")
     g("--no_hand_discs", action="store_true", help="do not draw the two radius-8 hand discs")
+    g("--pose_workers", type=int, default=None, help="processes rasterising pose maps ahead of the GPU")
     g("--timing_json", type=str, default=None, help="write fps / per-stage timing to this file")
 
 
