@@ -98,9 +98,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("T2V_BENCH_FORCE_DIST") == "1":   # the env var exercises the RCCL path on 1 GPU
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from text2video_amd import ops
@@ -119,7 +120,7 @@ def main():
     poses = torch.from_numpy(synthetic_pose_u8(nposes, H, W, seed=rank)).to(dev)   # resident in HBM
     window = torch.zeros(H, W, 12, dtype=torch.float32, device=dev)
     frames = torch.empty(K, H, W, 4, dtype=torch.uint8, device=dev)
-    gathered = torch.empty(world * K, H, W, 4, dtype=torch.uint8, device=dev) if world > 1 else None
+    gathered = torch.empty(world * K, H, W, 4, dtype=torch.uint8, device=dev) if dist else None
 
     def step(t, out_slot):
         for f in range(3):                       # sliding window of tG = 3 pose maps, oldest first
@@ -189,7 +190,7 @@ def main():
                     "ms_per_launch": round(k_ms, 4), "gflop_per_launch": round(k_flop / 1e9, 2)}
         # ---- CPU baseline: the oracle on this box's host cores, bounded sample ----
         cpu = None
-        if args.cpu_frames > 0:
+        if args.cpu_frames > 0 and world == 1:   # reported at N=1 only (rank 0)
             from oracle.generator_ref import CompositeGenerator, Vid2VidInferenceRef
             cores = torch.get_num_threads()
             ref_net = CompositeGenerator(9, 3, 6, 128, 3, 9, spec.no_flow, "batch")
@@ -229,6 +230,11 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
+        try:   # RCCL writes banner lines through C stdio: flush them so the JSON line is the last line
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         print(json.dumps(result), flush=True)
 
 
