@@ -216,3 +216,44 @@ def test_fullsize_resblock_conv_1024():
     y2 = ops.conv2d(xs * 2, pw, b.to(_dev()), desc)
     lin = ((y2 - b.to(_dev())) - 2 * (y - b.to(_dev()))).abs().max().item()
     assert lin <= 1e-4
+
+
+REPEAT_CASES = [
+    # name, H, W, Cin, Cout, k, stride, pad, pad_mode, transposed, stats, launches
+    ("head_7x7_cout3_fullsize", 512, 512, 128, 3, 7, 1, 3, 1, False, False, 60),   # small-Cout tile, 3-slot ring
+    ("resblock_1024_fullsize", 64, 64, 1024, 1024, 3, 1, 1, 1, False, True, 30),   # 128x128 tile, 3-slot ring
+    ("convT_256_fullsize", 256, 256, 256, 128, 3, 2, 1, 0, True, True, 20),        # 4 phases, 2-slot ring
+    ("stem_7x7_cin9_fullsize", 512, 512, 9, 128, 7, 1, 3, 1, False, True, 20),     # MODE 1 loader
+    ("resblock_64x40_quarter_tiles", 64, 40, 1024, 1024, 3, 1, 1, 1, False, True, 30),  # 64x64 tiles
+]
+
+
+@pytest.mark.parametrize("case", REPEAT_CASES, ids=[c[0] for c in REPEAT_CASES])
+def test_conv_bitwise_repeatable_race_screen(case):
+    """Race screen for the LDS-DMA pipeline (counted vmcnt + raw barriers): the same launch must
+    reproduce its first result bit for bit, output and norm partials, on NaN-poisoned buffers.
+    (Caught a real bug: loader waves issuing fewer DMA instructions than the vmcnt count assumed.)"""
+    from text2video_amd import ops
+    name, H, W, Cin, Cout, k, stride, pad, pad_mode, transposed, stats, launches = case
+    dev = _dev()
+    desc = ops.conv_desc(H, W, Cin, Cout, k, stride, pad, pad_mode, transposed,
+                         ops.ACT_TANH if Cout == 3 else ops.ACT_NONE)
+    xcs = ops.round_up(Cin, 4)
+    x = _rand(H, W, xcs, seed=31).to(dev)
+    w = _rand(*((Cin, Cout, k, k) if transposed else (Cout, Cin, k, k)), seed=32, scale=0.02).to(dev)
+    pw = ops.pack_conv_weight(w, desc, xcs)
+    b = _rand(Cout, seed=33).to(dev)
+    ho, wo = ops.conv_out_dims(desc)
+    ycs = Cout if Cout % 4 == 0 else 4
+    sb = ops.conv_stats_buffer(desc, dev) if stats else None
+    ref = ops.conv2d(x, pw, b, desc, y_cs=ycs, stats=sb).clone()
+    ref_s = sb.clone() if stats else None
+    assert torch.isfinite(ref).all()
+    for i in range(launches):
+        y = torch.full((ho, wo, ycs), float("nan"), device=dev)
+        if stats:
+            sb.fill_(float("nan"))
+        ops.conv2d(x, pw, b, desc, y_cs=ycs, stats=sb, out=y)
+        assert torch.equal(y, ref), "launch %d differs" % i
+        if stats:
+            assert torch.equal(sb, ref_s), "launch %d: norm partials differ" % i

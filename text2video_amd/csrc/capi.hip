@@ -109,6 +109,20 @@ int build_conv_plan(const t2v_conv_desc* d, int x_cs, bool need_stats, ConvPlan*
     k.M = Hm * Wm;
     k.Wout = pl.Wout;
     k.mtiles = (k.M + pl.BM - 1) / pl.BM;
+    if (pl.tile == kTileL) {
+        // tile quantisation: with 128x128 tiles a grid that fills the last wave of 256 CUs poorly
+        // (e.g. 160 or 344 tiles at the real fadg0 geometries 512x320 / 512x680) idles a third of
+        // the chip; 64x64 tiles (several co-resident blocks per CU) even that out
+        static const int force = getenv("T2V_CONV_TILE") ? atoi(getenv("T2V_CONV_TILE")) : -1;
+        const long nb = (long)k.mtiles * k.ntiles * k.nphases;
+        const double fill = (double)nb / (double)(((nb + 255) / 256) * 256);
+        if (force == kTileQ || (force < 0 && fill < 0.8 && nb < 1024)) {
+            pl.tile = kTileQ;
+            conv_tile_dims(pl.tile, &pl.BM, &pl.BN);
+            k.ntiles = (d->Cout + pl.BN - 1) / pl.BN;
+            k.mtiles = (k.M + pl.BM - 1) / pl.BM;
+        }
+    }
     pl.nparts = k.nphases * k.mtiles;
     T2V_REQUIRE((long)k.mtiles * k.ntiles * k.nphases < (1L << 31), "conv: grid too large");
     // buffer addressing: 32-bit byte offsets below the out-of-range marker 0x7fff0000

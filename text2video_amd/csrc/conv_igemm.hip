@@ -67,6 +67,7 @@ struct TileCfg {
 };
 using CfgL = TileCfg<32, 2, 2, 2, 2>;  // 128 x 128
 using CfgS = TileCfg<16, 4, 1, 4, 1>;  // 256 x 16 (3-channel heads)
+using CfgQ = TileCfg<32, 2, 2, 1, 1>;  // 64 x 64: finer granularity when 128x128 tiles fill the 256 CUs poorly
 
 // One LDS-DMA instruction through buffer addressing: 64 lanes x 16 B -> 1 KiB at the wave-uniform LDS
 // address `lds_dst`; source = base + voff (per lane, bytes) + soff (scalar, bytes).  Lanes with
@@ -224,7 +225,11 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(const ConvKParams p) {
             if constexpr (B_INSTR >= 4) {
                 issue_b(wid * B_PER_WAVE + (n - A_ITERS), kt, buf);
             } else {
-                if (wid < B_INSTR) issue_b(wid, kt, buf);  // wave-uniform
+                // fewer B instructions than loader waves (small-Cout tile): the spare waves re-issue
+                // one of them (same bytes to the same LDS rows).  Every wave MUST issue exactly
+                // LD_PER_WAVE loads per stage -- the counted s_waitcnt vmcnt below relies on it
+                // (a wave issuing fewer would pass barrier(kt) with a load of stage kt+1 in flight).
+                issue_b(wid % B_INSTR, kt, buf);
             }
         }
     };
@@ -448,6 +453,9 @@ void conv_tile_dims(int tile, int* BM, int* BN) {
     if (tile == kTileS) {
         *BM = CfgS::BM;
         *BN = CfgS::BN;
+    } else if (tile == kTileQ) {
+        *BM = CfgQ::BM;
+        *BN = CfgQ::BN;
     } else {
         *BM = CfgL::BM;
         *BN = CfgL::BN;
@@ -476,7 +484,7 @@ static int launch_pad(hipStream_t s, const ConvKParams& p) {
     // 2048-block stem 0.40 vs 0.47 ms, 1024-block layers 0.33 vs 0.345 ms, <= 512 blocks favour RING 3
     const long nblocks = (long)p.mtiles * p.ntiles * p.nphases;
     static const int force = getenv("T2V_CONV_RING") ? atoi(getenv("T2V_CONV_RING")) : 0;
-    const bool two = force ? force == 2 : (Cfg::MF == 32 && nblocks >= 1024);
+    const bool two = force ? force == 2 : (Cfg::MF == 32 && (nblocks >= 1024 || Cfg::BM == 64));
     return two ? launch_ring<Cfg, MODE, STATS, REFLECT, 2>(s, p) : launch_ring<Cfg, MODE, STATS, REFLECT, 3>(s, p);
 }
 
@@ -494,6 +502,13 @@ int launch_conv_igemm(hipStream_t s, const ConvKParams& p, int tile) {
             case 0: return stats ? launch_one<CfgL, 0, true>(s, p) : launch_one<CfgL, 0, false>(s, p);
             case 1: return stats ? launch_one<CfgL, 1, true>(s, p) : launch_one<CfgL, 1, false>(s, p);
             default: return stats ? launch_one<CfgL, 2, true>(s, p) : launch_one<CfgL, 2, false>(s, p);
+        }
+    }
+    if (tile == kTileQ) {
+        switch (mode) {
+            case 0: return stats ? launch_one<CfgQ, 0, true>(s, p) : launch_one<CfgQ, 0, false>(s, p);
+            case 1: return stats ? launch_one<CfgQ, 1, true>(s, p) : launch_one<CfgQ, 1, false>(s, p);
+            default: return stats ? launch_one<CfgQ, 2, true>(s, p) : launch_one<CfgQ, 2, false>(s, p);
         }
     }
     T2V_REQUIRE(!stats, "small-Cout tile has no instance-norm statistics epilogue");

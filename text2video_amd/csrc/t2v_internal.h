@@ -78,7 +78,7 @@ struct ConvKParams {
     int tdx[kMaxTaps];
 };
 
-enum ConvTile { kTileL = 0 /*128x128, 32x32x2 MFMA*/, kTileS = 1 /*256x16, 16x16x4 MFMA*/ };
+enum ConvTile { kTileL = 0 /*128x128, 32x32x2 MFMA*/, kTileS = 1 /*256x16, 16x16x4 MFMA*/, kTileQ = 2 /*64x64*/ };
 int conv_tile_for(int Cout);
 void conv_tile_dims(int tile, int* BM, int* BN);
 int launch_conv_igemm(hipStream_t s, const ConvKParams& p, int tile);
