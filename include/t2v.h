@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define T2V_ABI_VERSION 1
+#define T2V_ABI_VERSION 2
 
 typedef enum {
     T2V_OK = 0,
@@ -65,9 +65,10 @@ typedef struct {
     int stride;      /* 1 or 2 */
     int pad;         /* padding on each side (reflect: the ReflectionPad2d amount) */
     int pad_mode;    /* T2V_PAD_ZERO | T2V_PAD_REFLECT */
-    int transposed;  /* 1: ConvTranspose2d(k=3, stride=2, padding=1, output_padding=1) */
+    int transposed;  /* 1: ConvTranspose2d(k in {3,4}, stride=2, padding, output_padding) */
     int act;         /* T2V_ACT_* applied after bias */
-    float act_scale; /* T2V_ACT_FLOW_W: multiplier of the two flow channels (20 * 2^scale) */
+    float act_scale; /* T2V_ACT_FLOW_W: flow multiplier (20 * 2^scale); T2V_ACT_LRELU: negative slope */
+    int output_padding; /* transposed only (0 or 1); the generator's up-convs use 1 */
 } t2v_conv_desc;
 
 /* output spatial size */
@@ -118,6 +119,40 @@ int t2v_flow_warp_composite(t2v_ctx* ctx, void* stream, const float* raw, const 
 /* AvgPool2d(3, stride 2, padding 1, count_include_pad=False) -- SpatialAveragePooling_
  * updateOutput (THCUNN.h:579; pooling.py:536-543).  NHWC, C % 4 == 0 not required. */
 int t2v_avgpool3x3s2(t2v_ctx* ctx, void* stream, const float* x, float* y, int H, int W, int C);
+
+/* ------------------------------------------------------------------------------------------
+ * Convolution backward (accGradParameters of SpatialConvolutionMM / SpatialFullDilatedConvolution,
+ * THCUNN.h:664,794).  `d` is the FORWARD conv descriptor.
+ *   backward_weight: dW (packed layout, same as the packed forward weight) = sum over the batch and
+ *       all pixels of dy (x) x through every filter tap; accumulate != 0 adds to dw_packed.
+ *       x: [batch][H][W][x_cs], dy: [batch][Hout][Wout][dy_cs].
+ *   unpack_weight:   packed -> torch layout (inverse of t2v_conv_pack_weight).
+ *   channel_sum:     out[c] = sum over pixels of x[.][c]  (bias gradient).
+ * The data gradient needs no entry point of its own: it is a forward convolution with the adjoint
+ * geometry (stride-2 conv <-> ConvTranspose with the same torch-layout weight; stride-1: flipped /
+ * transposed weight, padding k-1-p) -- text2video_amd/backward.py builds those descriptors.
+ * ------------------------------------------------------------------------------------------ */
+int t2v_conv2d_backward_weight(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, int batch, const float* x,
+                               int x_cs, const float* dy, int dy_cs, float* dw_packed, int accumulate);
+int t2v_conv_unpack_weight(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, int x_cs, const float* packed_dev,
+                           float* w_torch_dev);
+int t2v_channel_sum(t2v_ctx* ctx, void* stream, const float* x, long npix, int C, int cs, float* out);
+/* adjoint of ReflectionPad2d(pad): dxp [H+2pad][W+2pad][C] -> dx [H][W][C]  (SpatialReflectionPadding_updateGradInput) */
+int t2v_reflect_pad_backward(t2v_ctx* ctx, void* stream, const float* dxp, float* dx, int H, int W, int C, int pad);
+/* BatchNormalization_backward(train) / instance norm backward fused with the activation derivative:
+ *   g = dy * act'(gamma*xhat+beta); dx = rstd*gamma*(g - mean(g) - xhat*mean(g*xhat)); dbeta_dgamma[c] = (sum g, sum g*xhat)
+ * x = the conv output that was normalised, npix = pixels in the statistics (all images of a batch-norm batch),
+ * relu as in t2v_instance_norm_apply, scratch >= 64*C*2 floats. */
+int t2v_instance_norm_backward(t2v_ctx* ctx, void* stream, const float* x, const float* dy, const float* mean_rstd,
+                               const float* gamma, const float* beta, int relu, long npix, int C, float* scratch,
+                               float* dx, float* dbeta_dgamma);
+/* dpre = dy * act'(.) from the activation OUTPUT y; act: T2V_ACT_TANH, 2 = sigmoid, T2V_ACT_LRELU (slope), 0 = scale by slope */
+int t2v_act_backward(t2v_ctx* ctx, void* stream, const float* dy, const float* y, int act, float slope, long n,
+                     float* dpre);
+int t2v_avgpool3x3s2_backward(t2v_ctx* ctx, void* stream, const float* dy, float* dx, int H, int W, int C);
+/* gradients of scale*sum((x-c)^2) and scale*sum|a-b| (wrt x / a) */
+int t2v_sum_sq_diff_const_backward(t2v_ctx* ctx, void* stream, const float* x, float c, float scale, long n, float* dx);
+int t2v_sum_abs_diff_backward(t2v_ctx* ctx, void* stream, const float* a, const float* b, float scale, long n, float* da);
 
 /* ------------------------------------------------------------------------------------------
  * Train-step scalars.

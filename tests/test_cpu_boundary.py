@@ -29,11 +29,17 @@ def test_conv_planning_entry_points(lib_built):
     assert (h.value, w.value) == (64, 64)
     assert lib_built.t2v_conv_packed_weight_floats(ctypes.byref(d), 1024) == 1024 * 9216
     assert lib_built.t2v_conv_stats_floats(ctypes.byref(d)) == 32 * 1024 * 2          # 32 M-tiles of 128 pixels
-    dt = _lib.ConvDesc(64, 64, 1024, 512, 3, 3, 2, 1, _lib.PAD_ZERO, 1, 0, 1.0)          # transposed
+    dt = _lib.ConvDesc(64, 64, 1024, 512, 3, 3, 2, 1, _lib.PAD_ZERO, 1, 0, 1.0, 1)       # transposed, output_padding 1
     assert lib_built.t2v_conv_out_dims(ctypes.byref(dt), ctypes.byref(h), ctypes.byref(w)) == 0
     assert (h.value, w.value) == (128, 128)
     assert lib_built.t2v_conv_packed_weight_floats(ctypes.byref(dt), 1024) == 512 * 9 * 1024  # 4 phases, 9 taps
     ds = _lib.ConvDesc(512, 512, 9, 128, 7, 7, 1, 3, _lib.PAD_REFLECT, 0, 0, 1.0)        # stem, Cin 9 -> storage 12
+    dd = _lib.ConvDesc(257, 257, 128, 64, 4, 4, 2, 2, _lib.PAD_ZERO, 1, 0, 1.0, 0)       # dgrad of a D conv k4 s2 p2
+    assert lib_built.t2v_conv_out_dims(ctypes.byref(dd), ctypes.byref(h), ctypes.byref(w)) == 0
+    assert (h.value, w.value) == (512, 512)
+    dd.H = dd.W = 129; dd.output_padding = 1                                             # odd output 257
+    assert lib_built.t2v_conv_out_dims(ctypes.byref(dd), ctypes.byref(h), ctypes.byref(w)) == 0
+    assert (h.value, w.value) == (257, 257)
     assert lib_built.t2v_conv_packed_weight_floats(ctypes.byref(ds), 12) == 128 * 608    # K=588 padded to 608
 
 
@@ -47,7 +53,7 @@ def test_errors_are_status_codes_with_messages(lib_built):
     refl = _lib.ConvDesc(2, 2, 8, 8, 7, 7, 1, 3, _lib.PAD_REFLECT, 0, 0, 1.0)
     assert lib_built.t2v_conv_out_dims(ctypes.byref(refl), ctypes.byref(h), ctypes.byref(w)) == -1
     assert b"reflection pad" in lib_built.t2v_last_error()
-    tr = _lib.ConvDesc(8, 8, 8, 8, 5, 5, 2, 1, _lib.PAD_ZERO, 1, 0, 1.0)
+    tr = _lib.ConvDesc(8, 8, 8, 8, 5, 5, 2, 1, _lib.PAD_ZERO, 1, 0, 1.0, 1)
     assert lib_built.t2v_conv_out_dims(ctypes.byref(tr), ctypes.byref(h), ctypes.byref(w)) == -1
     with pytest.raises(RuntimeError, match="status -1"):
         _lib.check(-1, "unit")

@@ -1,0 +1,157 @@
+"""GPU parity of the backward kernels against torch autograd on the CPU (fp32)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    return torch.from_numpy((np.random.default_rng(seed).standard_normal(shape) * scale).astype(np.float32))
+
+
+def _nhwc_batch(x, cs=None):
+    from text2video_amd import ops
+    return torch.stack([ops.nchw_to_nhwc(x[b].to("cuda:0").contiguous(), cs) for b in range(x.shape[0])])
+
+
+def _ref_forward(x, w, b, k, stride, pad, pad_mode, transposed):
+    if transposed:
+        return F.conv_transpose2d(x, w, b, stride=2, padding=1, output_padding=1)
+    if pad_mode == 1 and pad > 0:
+        x = F.pad(x, (pad, pad, pad, pad), mode="reflect")
+        pad = 0
+    return F.conv2d(x, w, b, stride=stride, padding=pad)
+
+
+WGRAD_CASES = [
+    # name, B, H, W, Cin, Cout, k, stride, pad, pad_mode, transposed
+    ("rb3x3_reflect", 2, 16, 16, 64, 128, 3, 1, 1, 1, False),
+    ("rb3x3_reflect_wide", 1, 12, 20, 160, 192, 3, 1, 1, 1, False),     # 2x2 channel tiles with tails
+    ("down3x3_s2", 2, 16, 16, 32, 64, 3, 2, 1, 0, False),
+    ("convT", 2, 8, 8, 64, 32, 3, 2, 1, 0, True),
+    ("stem7x7_cin9", 1, 20, 20, 9, 32, 7, 1, 3, 1, False),
+    ("head7x7_cout3", 1, 20, 16, 32, 3, 7, 1, 3, 1, False),
+    ("disc4x4_s2_p2", 2, 16, 16, 8, 64, 4, 2, 2, 0, False),
+    ("disc4x4_s1_p2", 1, 9, 9, 64, 1, 4, 1, 2, 0, False),
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_CASES, ids=[c[0] for c in WGRAD_CASES])
+def test_conv_weight_and_bias_gradient(case):
+    from text2video_amd import ops
+    name, B, H, W, Cin, Cout, k, stride, pad, pad_mode, transposed = case
+    x = _rand(B, Cin, H, W, seed=1)
+    w = _rand(*((Cin, Cout, k, k) if transposed else (Cout, Cin, k, k)), seed=2, scale=0.1).requires_grad_()
+    b = _rand(Cout, seed=3, scale=0.1).requires_grad_()
+    y = _ref_forward(x, w, b, k, stride, pad, pad_mode, transposed)
+    dy = _rand(*y.shape, seed=4)
+    y.backward(dy)
+    desc = ops.conv_desc(H, W, Cin, Cout, k, stride, pad, pad_mode, transposed)
+    xs = _nhwc_batch(x)
+    dys = _nhwc_batch(dy)
+    dwp = ops.conv2d_backward_weight(xs, dys, desc)
+    got = ops.unpack_conv_weight(dwp, desc, xs.shape[-1]).cpu()
+    scale = max(1.0, w.grad.abs().max().item())
+    assert got.shape == w.grad.shape
+    assert (got - w.grad).abs().max().item() <= 2e-4 * scale, name
+    # accumulate: a second pass doubles it
+    ops.conv2d_backward_weight(xs, dys, desc, accumulate_into=dwp)
+    got2 = ops.unpack_conv_weight(dwp, desc, xs.shape[-1]).cpu()
+    assert (got2 - 2 * w.grad).abs().max().item() <= 4e-4 * scale
+    db = ops.channel_sum(dys, Cout).cpu()
+    assert (db - b.grad).abs().max().item() <= 1e-4 * max(1.0, b.grad.abs().max().item())
+
+
+def test_pack_unpack_roundtrip():
+    from text2video_amd import ops
+    for (Cin, Cout, k, tr) in [(9, 32, 7, False), (64, 48, 3, False), (32, 16, 3, True)]:
+        desc = ops.conv_desc(16, 16, Cin, Cout, k, 2 if tr else 1, 1 if tr else k // 2, 0, tr)
+        w = _rand(*((Cin, Cout, k, k) if tr else (Cout, Cin, k, k)), seed=5).cuda()
+        xcs = ops.round_up(Cin, 4)
+        assert torch.equal(ops.unpack_conv_weight(ops.pack_conv_weight(w, desc, xcs), desc, xcs), w)
+
+
+DGRAD_CASES = [c for c in WGRAD_CASES if c[0] not in ("stem7x7_cin9",)] + [
+    ("disc4x4_s2_p2_odd", 1, 17, 17, 8, 16, 4, 2, 2, 0, False),      # odd input: output_padding 1, odd convT output
+]
+
+
+@pytest.mark.parametrize("case", DGRAD_CASES, ids=[c[0] for c in DGRAD_CASES])
+def test_conv_data_gradient_via_adjoint_forward_conv(case):
+    from text2video_amd import ops
+    from text2video_amd.backward import ConvDataGrad
+    name, B, H, W, Cin, Cout, k, stride, pad, pad_mode, transposed = case
+    x = _rand(1, Cin, H, W, seed=11).requires_grad_()
+    w = _rand(*((Cin, Cout, k, k) if transposed else (Cout, Cin, k, k)), seed=12, scale=0.1)
+    y = _ref_forward(x, w, None, k, stride, pad, pad_mode, transposed)
+    dy = _rand(*y.shape, seed=13)
+    y.backward(dy)
+    desc = ops.conv_desc(H, W, Cin, Cout, k, stride, pad, pad_mode, transposed)
+    dg = ConvDataGrad(desc).refresh(w.cuda())
+    dx = dg(_nhwc_batch(dy)[0])
+    got = dx[..., :Cin].permute(2, 0, 1).cpu()
+    assert got.shape == x.grad.shape[1:]
+    assert (got - x.grad[0]).abs().max().item() <= 2e-4 * max(1.0, x.grad.abs().max().item()), name
+
+
+@pytest.mark.parametrize("relu,affine", [(0, False), (1, True), (2, True), (1, False)])
+def test_norm_backward_with_fused_activation(relu, affine):
+    from text2video_amd import ops
+    B, C, H, W = 2, 64, 12, 10
+    x = _rand(B, C, H, W, seed=21).requires_grad_()
+    g = (1 + _rand(C, seed=22, scale=0.1)).requires_grad_()
+    bt = _rand(C, seed=23, scale=0.3).requires_grad_()
+    # batch statistics over (B,H,W): BatchNorm2d in train mode
+    y = torch.nn.functional.batch_norm(x, None, None, g if affine else None, bt if affine else None, True, 0.1, 1e-5)
+    y = torch.relu(y) if relu == 1 else (torch.nn.functional.leaky_relu(y, 0.2) if relu == 2 else y)
+    dy = _rand(B, C, H, W, seed=24)
+    y.backward(dy)
+    xs = _nhwc_batch(x.detach())
+    mean = x.detach().mean((0, 2, 3))
+    rstd = 1.0 / torch.sqrt(x.detach().var((0, 2, 3), unbiased=False) + 1e-5)
+    mr = torch.stack([mean, rstd], 1).contiguous().cuda()
+    dx, sums = ops.instance_norm_backward(xs, _nhwc_batch(dy), mr, g.detach().cuda() if affine else None,
+                                          bt.detach().cuda() if affine else None, relu)
+    assert (dx.permute(0, 3, 1, 2).cpu() - x.grad).abs().max().item() <= 2e-5 * max(1.0, x.grad.abs().max().item())
+    if affine:
+        assert (sums[:, 0].cpu() - bt.grad).abs().max().item() <= 1e-4 * max(1.0, bt.grad.abs().max().item())
+        assert (sums[:, 1].cpu() - g.grad).abs().max().item() <= 1e-4 * max(1.0, g.grad.abs().max().item())
+
+
+def test_pointwise_and_pooling_backward():
+    from text2video_amd import ops
+    # reflect pad adjoint
+    x = _rand(1, 8, 9, 11, seed=31).requires_grad_()
+    for p in (1, 3):
+        x.grad = None
+        yp = F.pad(x, (p, p, p, p), mode="reflect")
+        d = _rand(*yp.shape, seed=32)
+        yp.backward(d)
+        got = ops.reflect_pad_backward(_nhwc_batch(d)[0], p)
+        assert (got.permute(2, 0, 1).cpu() - x.grad[0]).abs().max().item() <= 1e-5
+    # avg pool (count_include_pad=False)
+    for (H, W) in [(16, 16), (17, 13)]:
+        a = _rand(1, 4, H, W, seed=33).requires_grad_()
+        y = F.avg_pool2d(a, 3, 2, 1, count_include_pad=False)
+        d = _rand(*y.shape, seed=34)
+        y.backward(d)
+        got = ops.avgpool3x3s2_backward(_nhwc_batch(d)[0], H, W)
+        assert (got.permute(2, 0, 1).cpu() - a.grad[0]).abs().max().item() <= 1e-6
+    # tanh / sigmoid / leaky from the output
+    pre = _rand(1000, seed=35).requires_grad_()
+    for act, fn in [(ops.ACT_TANH, torch.tanh), (2, torch.sigmoid), (ops.ACT_LRELU, lambda t: F.leaky_relu(t, 0.2))]:
+        pre.grad = None
+        y = fn(pre)
+        d = _rand(1000, seed=36)
+        y.backward(d)
+        got = ops.act_backward(d.cuda(), y.detach().cuda(), act, 0.2)
+        assert (got.cpu() - pre.grad).abs().max().item() <= 1e-6
+    # losses
+    a, b = _rand(500, seed=37).requires_grad_(), _rand(500, seed=38)
+    (((a - 1.0) ** 2).sum() * 0.01).backward()
+    assert (ops.sum_sq_diff_const_backward(a.detach().cuda(), 1.0, 0.01).cpu() - a.grad).abs().max().item() <= 1e-6
+    a.grad = None
+    ((a - b).abs().sum() * 0.02).backward()
+    assert (ops.sum_abs_diff_backward(a.detach().cuda(), b.cuda(), 0.02).cpu() - a.grad).abs().max().item() <= 1e-7

@@ -14,14 +14,14 @@ LIB_PATH = os.path.join(_HERE, "lib", "libt2v_hip.so")
 T2V_OK = 0
 PAD_ZERO, PAD_REFLECT = 0, 1
 ACT_NONE, ACT_TANH, ACT_FLOW_W, ACT_LRELU = 0, 1, 2, 3
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class ConvDesc(Structure):
     """t2v_conv_desc (include/t2v.h)."""
     _fields_ = [("H", c_int), ("W", c_int), ("Cin", c_int), ("Cout", c_int), ("kH", c_int), ("kW", c_int),
                 ("stride", c_int), ("pad", c_int), ("pad_mode", c_int), ("transposed", c_int), ("act", c_int),
-                ("act_scale", c_float)]
+                ("act_scale", c_float), ("output_padding", c_int)]
 
 
 class GenDesc(Structure):
@@ -57,6 +57,17 @@ SIGNATURES = {
                                    c_void_p, c_int, c_void_p]),
     "t2v_instance_norm_finalize": (c_int, [c_void_p, c_void_p, POINTER(ConvDesc), c_void_p, c_float, c_void_p]),
     "t2v_batch_norm_finalize": (c_int, [c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_void_p, c_float, c_void_p]),
+    "t2v_conv2d_backward_weight": (c_int, [c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_void_p, c_int, c_void_p,
+                                           c_int, c_void_p, c_int]),
+    "t2v_conv_unpack_weight": (c_int, [c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_void_p, c_void_p]),
+    "t2v_channel_sum": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_void_p]),
+    "t2v_reflect_pad_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int]),
+    "t2v_instance_norm_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                           c_long, c_int, c_void_p, c_void_p, c_void_p]),
+    "t2v_act_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_long, c_void_p]),
+    "t2v_avgpool3x3s2_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int]),
+    "t2v_sum_sq_diff_const_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_float, c_long, c_void_p]),
+    "t2v_sum_abs_diff_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_long, c_void_p]),
     "t2v_sum_sq_diff_const": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_long, c_void_p, c_void_p]),
     "t2v_sum_abs_diff": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_void_p]),
     "t2v_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_float, c_float,

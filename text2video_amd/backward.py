@@ -1,0 +1,60 @@
+"""Data gradients of the convolutions as FORWARD convolutions with the adjoint geometry (the train
+step's `updateGradInput`, THCUNN.h:664,794).  No dedicated kernel: the implicit-GEMM forward kernel
+computes all of them.
+
+    forward                                   data gradient
+    ----------------------------------------  ----------------------------------------------------------
+    conv k, stride 1, zero pad p              conv k, stride 1, zero pad k-1-p, weight flipped+transposed
+    conv k, stride 1, reflect pad p           same with pad k-1 on dY -> [H+2p, W+2p], then the reflect-pad adjoint
+    conv k3/k4, stride 2, pad p               ConvTranspose(k, s2, p, output_padding) with the SAME weight tensor
+                                              ([Cout,Cin,k,k] read as [Cin_T,Cout_T,k,k])
+    ConvTranspose k3 s2 p1 op1                conv k3 s2 p1 with the SAME weight tensor ([Cin,Cout,3,3] read as
+                                              [Cout_c,Cin_c,3,3])
+"""
+import torch
+
+from . import ops
+
+
+class ConvDataGrad:
+    """dX for one forward conv layer.  Weight packings are cached per weight version by the caller
+    (call `refresh(weight)` after every optimiser step)."""
+
+    def __init__(self, fwd_desc):
+        d = self.fwd = fwd_desc
+        self.fold = 0
+        if d.transposed:
+            # forward: [H,W] -> [2H,2W]; gradient: conv k3 s2 p1 on dY
+            self.desc = ops.conv_desc(2 * d.H, 2 * d.W, d.Cout, d.Cin, 3, 2, 1, ops.PAD_ZERO)
+            self.kind = "same"
+        elif d.stride == 2:
+            ho, wo = ops.conv_out_dims(d)
+            # output_padding so that the transposed conv reproduces the forward input size
+            op_h = d.H - ((ho - 1) * 2 - 2 * d.pad + d.kH)
+            op_w = d.W - ((wo - 1) * 2 - 2 * d.pad + d.kW)
+            assert op_h == op_w and op_h in (0, 1), "unsupported stride-2 geometry"
+            self.desc = ops.conv_desc(ho, wo, d.Cout, d.Cin, d.kH, 2, d.pad, ops.PAD_ZERO, True, output_padding=op_h)
+            self.kind = "same"
+        else:
+            ho, wo = ops.conv_out_dims(d)
+            if d.pad_mode == ops.PAD_REFLECT and d.pad > 0:
+                self.fold = d.pad
+                pad = d.kH - 1
+            else:
+                pad = d.kH - 1 - d.pad
+            self.desc = ops.conv_desc(ho, wo, d.Cout, d.Cin, d.kH, 1, pad, ops.PAD_ZERO)
+            self.kind = "flip"
+        self.packed = None
+
+    def refresh(self, weight):
+        """weight: the forward layer's torch-layout weight on the device."""
+        w = weight
+        if self.kind == "flip":
+            w = weight.flip(2, 3).transpose(0, 1).contiguous()   # layout plumbing: [Cin][Cout][k][k] flipped
+        self.packed = ops.pack_conv_weight(w.contiguous(), self.desc, ops.round_up(self.desc.Cin, 4))
+        return self
+
+    def __call__(self, dy):
+        """dy: [Hout, Wout, cs>=Cout] -> dX [H, W, round_up4(Cin)]."""
+        dxp = ops.conv2d(dy, self.packed, None, self.desc)
+        return ops.reflect_pad_backward(dxp, self.fold) if self.fold else dxp

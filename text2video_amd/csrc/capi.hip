@@ -71,12 +71,16 @@ int build_conv_plan(const t2v_conv_desc* d, int x_cs, bool need_stats, ConvPlan*
             }
         pl.wfloats = (size_t)pl.Cout_p * ph.Kp;
     } else {
-        T2V_REQUIRE(d->kH == 3 && d->kW == 3 && d->stride == 2 && d->pad == 1,
-                    "transposed conv: only k=3, stride=2, padding=1, output_padding=1 is on the path");
-        pl.Hout = 2 * d->H;
-        pl.Wout = 2 * d->W;
-        Hm = d->H;
-        Wm = d->W;
+        T2V_REQUIRE(d->kH == d->kW && (d->kH == 3 || d->kH == 4) && d->stride == 2 && d->pad >= 0 && d->pad <= 2 &&
+                        d->output_padding >= 0 && d->output_padding <= 1,
+                    "transposed conv: k in {3,4}, stride 2, padding <= 2, output_padding <= 1 are on the path");
+        pl.Hout = (d->H - 1) * 2 - 2 * d->pad + d->kH + d->output_padding;
+        pl.Wout = (d->W - 1) * 2 - 2 * d->pad + d->kW + d->output_padding;
+        T2V_REQUIRE(pl.Hout > 0 && pl.Wout > 0, "transposed conv: empty output");
+        T2V_REQUIRE(!need_stats || (pl.Hout % 2 == 0 && pl.Wout % 2 == 0),
+                    "transposed conv with fused norm statistics needs an even output (got %dx%d)", pl.Hout, pl.Wout);
+        Hm = (pl.Hout + 1) / 2;   // phase grid; odd outputs: the odd phase's last row/col is masked at the store
+        Wm = (pl.Wout + 1) / 2;
         k.stride = 1;
         k.ostride = 2;
         k.pad_mode = T2V_PAD_ZERO;
@@ -87,7 +91,7 @@ int build_conv_plan(const t2v_conv_desc* d, int x_cs, bool need_stats, ConvPlan*
         long woff = 0;
         for (int p = 0; p < 4; ++p) {
             int nt, kh[4], kw[4], dy[4], dx[4], a, b;
-            convT_phase_taps_host(p, &nt, kh, kw, dy, dx, &a, &b);
+            convT_phase_taps_host(p, d->kH, d->pad, &nt, kh, kw, dy, dx, &a, &b);
             ConvPhase& ph = k.ph[p];
             ph.ntaps = nt;
             ph.tap0 = tap0;
@@ -108,6 +112,7 @@ int build_conv_plan(const t2v_conv_desc* d, int x_cs, bool need_stats, ConvPlan*
     k.Wm = Wm;
     k.M = Hm * Wm;
     k.Wout = pl.Wout;
+    k.Hout = pl.Hout;
     k.mtiles = (k.M + pl.BM - 1) / pl.BM;
     if (pl.tile == kTileL) {
         // tile quantisation: with 128x128 tiles a grid that fills the last wave of 256 CUs poorly
@@ -211,7 +216,7 @@ int t2v_conv_pack_weight(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, int
     if (!d->transposed)
         return launch_pack_conv_weight(s, w_torch_dev, packed_dev, d->Cout, d->Cin, d->kH, d->kW, x_cs, pl.kp.ph[0].Kp,
                                        pl.Cout_p);
-    return launch_pack_convT_weight(s, w_torch_dev, packed_dev, d->Cin, d->Cout, x_cs, pl.Cout_p);
+    return launch_pack_convT_weight(s, w_torch_dev, packed_dev, d->Cin, d->Cout, x_cs, pl.Cout_p, d->kH, d->pad);
 }
 
 size_t t2v_conv_stats_floats(const t2v_conv_desc* d) {
@@ -244,6 +249,82 @@ int t2v_batch_norm_finalize(t2v_ctx* ctx, void* stream, const t2v_conv_desc* pro
     // the per-image partial blocks are contiguous: a batch is just `batch` times more partial rows
     return launch_inorm_finalize((hipStream_t)stream, stats_partial, batch * pl.nparts, pl.kp.mtiles, pl.BM, pl.kp.M,
                                  producer->Cout, eps, mean_rstd);
+}
+
+int t2v_conv2d_backward_weight(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, int batch, const float* x,
+                               int x_cs, const float* dy, int dy_cs, float* dw_packed, int accumulate) {
+    T2V_REQUIRE(ctx && x && dy && dw_packed && batch >= 1, "backward_weight: bad arguments");
+    ConvPlan pl;
+    T2V_TRY(build_conv_plan(d, x_cs, true, &pl));   // 128-row weight granule, plain 128x128 bookkeeping
+    T2V_REQUIRE(dy_cs >= d->Cout && dy_cs % 4 == 0, "backward_weight: dy channel storage %d", dy_cs);
+    const ConvKParams& k = pl.kp;
+    WgradParams w;
+    memset(&w, 0, sizeof(w));
+    w.x = x; w.dy = dy; w.dw = dw_packed;
+    w.batch = batch; w.Hin = d->H; w.Win = d->W; w.Cin_s = x_cs;
+    w.Wm = k.Wm; w.M = k.M;
+    w.Hout = pl.Hout; w.Wout = pl.Wout; w.Cout = d->Cout; w.Cout_s = dy_cs;
+    w.stride = k.stride; w.ostride = k.ostride;
+    w.reflect = k.pad_mode == T2V_PAD_REFLECT; w.accumulate = accumulate;
+    w.ntiles = (d->Cout + 127) / 128; w.ctiles = (x_cs + 127) / 128;
+    int nt = 0;
+    for (int ph = 0; ph < k.nphases; ++ph)
+        for (int t = 0; t < k.ph[ph].ntaps; ++t, ++nt) {
+            w.tdy[nt] = k.tdy[k.ph[ph].tap0 + t]; w.tdx[nt] = k.tdx[k.ph[ph].tap0 + t];
+            w.toy[nt] = k.ph[ph].oy0; w.tox[nt] = k.ph[ph].ox0;
+            w.tap_woff[nt] = k.ph[ph].w_off; w.tap_Kp[nt] = k.ph[ph].Kp; w.tap_kidx[nt] = t;
+        }
+    w.ntaps = nt;
+    T2V_REQUIRE((long)batch * d->H * d->W * x_cs * 4 < 0x7fff0000L && (long)batch * pl.Hout * pl.Wout * dy_cs * 4 < 0x7fff0000L,
+                "backward_weight: tensors too large for 32-bit buffer offsets (split the batch)");
+    return launch_conv_wgrad((hipStream_t)stream, w);
+}
+
+int t2v_conv_unpack_weight(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, int x_cs, const float* packed_dev,
+                           float* w_torch_dev) {
+    T2V_REQUIRE(ctx && packed_dev && w_torch_dev, "unpack_weight: null pointer");
+    ConvPlan pl;
+    T2V_TRY(build_conv_plan(d, x_cs, false, &pl));
+    if (!d->transposed)
+        return launch_unpack_conv_weight((hipStream_t)stream, packed_dev, w_torch_dev, d->Cout, d->Cin, d->kH, d->kW, x_cs,
+                                         pl.kp.ph[0].Kp);
+    return launch_unpack_convT_weight((hipStream_t)stream, packed_dev, w_torch_dev, d->Cin, d->Cout, x_cs, pl.Cout_p,
+                                      d->kH, d->pad);
+}
+
+int t2v_channel_sum(t2v_ctx* ctx, void* stream, const float* x, long npix, int C, int cs, float* out) {
+    T2V_REQUIRE(ctx && x && out && C > 0 && cs >= C, "channel_sum: bad arguments");
+    return launch_channel_sum((hipStream_t)stream, x, npix, C, cs, out);
+}
+
+int t2v_reflect_pad_backward(t2v_ctx* ctx, void* stream, const float* dxp, float* dx, int H, int W, int C, int pad) {
+    T2V_REQUIRE(ctx && dxp && dx && pad >= 0 && H > 2 * pad && W > 2 * pad, "reflect_pad_backward: bad arguments");
+    return launch_reflect_pad_backward((hipStream_t)stream, dxp, dx, H, W, C, pad);
+}
+int t2v_instance_norm_backward(t2v_ctx* ctx, void* stream, const float* x, const float* dy, const float* mean_rstd,
+                               const float* gamma, const float* beta, int relu, long npix, int C, float* scratch,
+                               float* dx, float* dbeta_dgamma) {
+    T2V_REQUIRE(ctx && x && dy && mean_rstd && scratch && dx && dbeta_dgamma && npix > 0 && C > 0,
+                "instance_norm_backward: bad arguments");
+    return launch_inorm_backward((hipStream_t)stream, x, dy, mean_rstd, gamma, beta, relu, npix, C, scratch, dx,
+                                 dbeta_dgamma);
+}
+int t2v_act_backward(t2v_ctx* ctx, void* stream, const float* dy, const float* y, int act, float slope, long n,
+                     float* dpre) {
+    T2V_REQUIRE(ctx && dy && y && dpre && n > 0, "act_backward: bad arguments");
+    return launch_act_backward((hipStream_t)stream, dy, y, act, slope, n, dpre);
+}
+int t2v_avgpool3x3s2_backward(t2v_ctx* ctx, void* stream, const float* dy, float* dx, int H, int W, int C) {
+    T2V_REQUIRE(ctx && dy && dx, "avgpool_backward: null pointer");
+    return launch_avgpool3s2_backward((hipStream_t)stream, dy, dx, H, W, C);
+}
+int t2v_sum_sq_diff_const_backward(t2v_ctx* ctx, void* stream, const float* x, float c, float scale, long n, float* dx) {
+    T2V_REQUIRE(ctx && x && dx && n > 0, "mse backward: bad arguments");
+    return launch_loss_backward((hipStream_t)stream, 0, x, nullptr, c, scale, n, dx);
+}
+int t2v_sum_abs_diff_backward(t2v_ctx* ctx, void* stream, const float* a, const float* b, float scale, long n, float* da) {
+    T2V_REQUIRE(ctx && a && b && da && n > 0, "l1 backward: bad arguments");
+    return launch_loss_backward((hipStream_t)stream, 1, a, b, 0.f, scale, n, da);
 }
 
 int t2v_sum_sq_diff_const(t2v_ctx* ctx, void* stream, const float* x, float c, long n, float* scratch, float* out) {

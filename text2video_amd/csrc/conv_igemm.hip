@@ -429,6 +429,7 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(const ConvKParams p) {
             if (m < p.M) {
                 const int my = m / p.Wm, mx = m - my * p.Wm;
                 const int oy = my * p.ostride + ph.oy0, ox = mx * p.ostride + ph.ox0;
+                if (oy >= p.Hout || ox >= p.Wout) continue;  // odd-sized transposed output: ragged phase grid
                 float* yrow = p.y + (size_t)(oy * p.Wout + ox) * p.Cout_s;
 #pragma unroll
                 for (int j = 0; j < Cfg::TN; ++j) {

@@ -1,0 +1,189 @@
+// conv_wgrad.hip -- fp32 weight-gradient of the generator / discriminator convolutions on gfx950.
+//
+// Backward-by-weight of SpatialConvolutionMM / SpatialFullDilatedConvolution (THCUNN.h:664,794
+// `accGradParameters`): for a (forward) convolution y[m][n] = sum_{tap,c} x[pix(m,tap)][c] * w[n][tap][c]
+//   dW[n][tap][c] = sum_{b, m} dY_b[m][n] * X_b[pix(m, tap)][c]
+// i.e. one GEMM per tap that REDUCES OVER PIXELS.  With NHWC both operands are already stored
+// pixel-major ([pixel][channel], channel contiguous), which is exactly the layout the fp32 MFMA
+// wants when the reduction index is the pixel: lane i reads element [pixel k][channel i] with a
+// conflict-free ds_read_b32 -- no transposes, no swizzle.
+//
+//   block tile : 128 output channels (n) x 128 input channels (c) of ONE tap, 64 accumulator VGPRs/wave
+//   K loop     : 32 pixels per LDS stage (2 x 16 KiB), 3-slot ring, loader waves with buffer-addressed
+//                LDS-DMA (same wave-specialised structure as conv_igemm.hip); padding / tails = OOB lanes
+//   grid       : (Cout/128) x (Cin_s/128) x taps  [x phases for transposed convs]
+//   output     : written straight into the PACKED weight layout [Cout_p][Kp] (K = tap*Cin_s + c), so the
+//                optimiser can run on packed parameters; t2v_conv_unpack_weight converts back.
+// Transposed convolutions reuse this with the roles of the tensors swapped by the caller
+// (dW_T[cin][cout] = sum x[m][cin] * dY[pix][cout]): see build_wgrad_plan in capi.hip.
+#include "t2v_internal.h"
+
+namespace t2v {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ void wg_dma16(const float* base, int nbytes, char* lds_dst, int voff, int soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, nbytes, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (__attribute__((address_space(3))) void*)lds_dst, 16, voff, soff, 0, 0);
+#endif
+}
+
+constexpr int kWgPix = 32;                       // pixels per stage
+constexpr int kWgStage = 2 * kWgPix * 128 * 4;   // dY tile + X tile, 128 channels each
+constexpr int kWgRing = 3;
+
+// REFLECT: the forward conv used reflection padding (taps never fall outside; indices mirror)
+template <bool REFLECT>
+__global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int kOOB = 0x7fff0000;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool is_loader = wave >= 4;
+    const int wid = wave & 3;
+
+    // block -> (tap, n tile, c tile); consecutive blocks share the dY tile (n) across c tiles
+    int t = blockIdx.x;
+    const int ct = t % p.ctiles; t /= p.ctiles;
+    const int nt = t % p.ntiles; t /= p.ntiles;
+    const int tap = t;   // global tap index (all phases)
+    const int n0 = nt * 128, c0 = ct * 128;
+    const int dy = p.tdy[tap], dx = p.tdx[tap];
+    const int P = p.batch * p.M;              // pixels to reduce over
+    const int nk = (P + kWgPix - 1) / kWgPix;
+
+    if (is_loader) {
+        // each loader wave: 4 dY instructions + 4 X instructions per stage; one instruction = 2 pixel rows
+        const int prow = lane >> 5;           // pixel row inside the instruction's pair
+        const int chunk = lane & 31;          // 16-byte chunk inside the 512-byte channel row
+        const bool n_ok = n0 + chunk * 4 < p.Cout_s;
+        const bool c_ok = c0 + chunk * 4 < p.Cin_s;
+        const int dy_bytes = p.batch * p.Hout * p.Wout * p.Cout_s * 4;
+        const int x_bytes = p.batch * p.Hin * p.Win * p.Cin_s * 4;
+        auto issue_stage = [&](int kt, int slot) {
+            char* sY = smem + slot * kWgStage;
+            char* sX = sY + kWgPix * 512;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = wid * 8 + i * 2 + prow;      // pixel row in the stage, 0..31
+                const int pidx = kt * kWgPix + r;          // global pixel (image-major)
+                const bool ok = pidx < P;
+                const int b = pidx / p.M, m = pidx - b * p.M;
+                const int my = m / p.Wm, mx = m - my * p.Wm;
+                // dY: output pixel of GEMM pixel m (strided for the sub-pixel phases of a transposed conv)
+                const int opix = (b * p.Hout + my * p.ostride + p.toy[tap]) * p.Wout + mx * p.ostride + p.tox[tap];
+                const int vy = (ok && n_ok) ? (opix * p.Cout_s + n0 + chunk * 4) * 4 : kOOB;
+                wg_dma16(p.dy, dy_bytes, sY + (wid * 8 + i * 2) * 512, vy, 0);
+                // X: gathered through the tap
+                int iy = my * p.stride + dy, ix = mx * p.stride + dx;
+                bool okx = ok && c_ok;
+                if constexpr (REFLECT) {
+                    iy = iy < 0 ? -iy : iy;
+                    ix = ix < 0 ? -ix : ix;
+                    iy = min(iy, 2 * p.Hin - 2 - iy);
+                    ix = min(ix, 2 * p.Win - 2 - ix);
+                } else {
+                    okx = okx && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
+                }
+                const int vx = okx ? (((b * p.Hin + iy) * p.Win + ix) * p.Cin_s + c0 + chunk * 4) * 4 : kOOB;
+                wg_dma16(p.x, x_bytes, sX + (wid * 8 + i * 2) * 512, vx, 0);
+            }
+        };
+        constexpr int LD = 8;
+        issue_stage(0, 0);
+        issue_stage(min(1, nk - 1), 1);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LD) : "memory");
+        __builtin_amdgcn_s_barrier();
+        int slot = 2;
+        for (int kt = 0; kt < nk; ++kt) {
+            issue_stage(min(kt + 2, nk - 1), slot);  // past the end: harmless re-fetch of the last stage
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LD) : "memory");
+            __builtin_amdgcn_s_barrier();
+            slot = slot == kWgRing - 1 ? 0 : slot + 1;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
+
+    // ---- MFMA waves: 2x2 waves, each 64 (n) x 64 (c) = 2x2 tiles of 32x32 ----
+    const int wn = wid >> 1, wc = wid & 1;
+    const int fi = lane & 31, kk = lane >> 5;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    __syncthreads();  // B0
+    int buf = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const float* sY = reinterpret_cast<const float*>(smem + buf * kWgStage);
+        const float* sX = sY + kWgPix * 128;
+        // stages past the end were re-fetches of the last stage: contribute once only
+#pragma unroll
+        for (int s = 0; s < kWgPix / 2; ++s) {
+            const int px = 2 * s + kk;
+            float a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i] = sY[px * 128 + wn * 64 + i * 32 + fi];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[j] = sX[px * 128 + wc * 64 + j * 32 + fi];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();  // barrier(kt)
+        buf = buf == kWgRing - 1 ? 0 : buf + 1;
+    }
+
+    // ---- epilogue: D[row n][col c] -> packed dW[n][koff + c]  (koff: position of this tap in K) ----
+    float* out = p.dw + p.tap_woff[tap];
+    const int Kp = p.tap_Kp[tap];
+    const int kbase = p.tap_kidx[tap] * p.Cin_s + c0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = n0 + wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+            if (n < p.Cout) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int c = wc * 64 + j * 32 + fi;
+                    if (c0 + c < p.Cin_s) {
+                        float* dst = out + (size_t)n * Kp + kbase + c;
+                        *dst = p.accumulate ? *dst + acc[i][j][r] : acc[i][j][r];
+                    }
+                }
+            }
+        }
+}
+
+int launch_conv_wgrad(hipStream_t s, const WgradParams& p) {
+    static bool attr_done[2] = {false, false};
+    const int lds = kWgRing * kWgStage;
+    const int nblocks = p.ntaps * p.ntiles * p.ctiles;
+    if (p.reflect) {
+        if (!attr_done[1]) {
+            T2V_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<true>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            attr_done[1] = true;
+        }
+        hipLaunchKernelGGL(conv_wgrad_kernel<true>, dim3(nblocks), dim3(512), lds, s, p);
+    } else {
+        if (!attr_done[0]) {
+            T2V_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<false>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            attr_done[0] = true;
+        }
+        hipLaunchKernelGGL(conv_wgrad_kernel<false>, dim3(nblocks), dim3(512), lds, s, p);
+    }
+    T2V_HIP_CHECK(hipGetLastError());
+    return T2V_OK;
+}
+
+}  // namespace t2v

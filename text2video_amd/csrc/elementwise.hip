@@ -248,18 +248,21 @@ int launch_pack_conv_weight(hipStream_t s, const float* w, float* packed, int Co
     return T2V_OK;
 }
 
-// ConvTranspose2d(k3,s2,p1,op1), weight [Cin][Cout][3][3]:  out[2i+a][2j+b] = sum over the taps
-// of phase (a,b).  y = 2i - 1 + kh  =>  a=0: kh=1 (dy 0) ; a=1: kh=2 (dy 0), kh=0 (dy +1).
-// Phase order (heaviest first): (1,1) 4 taps, (1,0) 2, (0,1) 2, (0,0) 1 -- must match
-// the launcher, which shares convT_phase_taps().
-__device__ __host__ inline void convT_phase_taps(int phase, int* ntaps, int kh[4], int kw[4], int dy[4], int dx[4],
-                                                 int* a, int* b) {
+// ConvTranspose2d(k, stride 2, padding p), weight [Cin][Cout][k][k]:  out[2i+a][2j+b] = sum over the
+// taps of phase (a,b).  y = 2i - p + kh  =>  kh has the parity of (a + p); input row i = i' + dy with
+// dy = (a + p - kh) / 2 for output row y = 2i' + a.   (k3 p1: a=0 -> kh=1 dy 0 ; a=1 -> kh=0 dy +1, kh=2 dy 0.)
+// Phase order (heaviest first for k=3): (1,1), (1,0), (0,1), (0,0) -- shared by packer, unpacker and
+// the launch planner through this one function.
+__device__ __host__ inline void convT_phase_taps(int phase, int k, int pad, int* ntaps, int kh[4], int kw[4], int dy[4],
+                                                 int dx[4], int* a, int* b) {
     const int pa[4] = {1, 1, 0, 0}, pb[4] = {1, 0, 1, 0};
     *a = pa[phase];
     *b = pb[phase];
-    int ykh[2], ydy[2], ny, xkw[2], xdx[2], nx;
-    if (*a == 0) { ny = 1; ykh[0] = 1; ydy[0] = 0; } else { ny = 2; ykh[0] = 2; ydy[0] = 0; ykh[1] = 0; ydy[1] = 1; }
-    if (*b == 0) { nx = 1; xkw[0] = 1; xdx[0] = 0; } else { nx = 2; xkw[0] = 2; xdx[0] = 0; xkw[1] = 0; xdx[1] = 1; }
+    int ykh[2], ydy[2], ny = 0, xkw[2], xdx[2], nx = 0;
+    for (int q = k - 1; q >= 0; --q) {   // descending kh: dy ascending (matches the k3 order 2,0)
+        if (((*a + pad - q) & 1) == 0 && ny < 2) { ykh[ny] = q; ydy[ny] = (*a + pad - q) / 2; ++ny; }
+        if (((*b + pad - q) & 1) == 0 && nx < 2) { xkw[nx] = q; xdx[nx] = (*b + pad - q) / 2; ++nx; }
+    }
     int n = 0;
     for (int iy = 0; iy < ny; ++iy)
         for (int ix = 0; ix < nx; ++ix) {
@@ -271,15 +274,15 @@ __device__ __host__ inline void convT_phase_taps(int phase, int* ntaps, int kh[4
 }
 
 __global__ void pack_convT_weight_kernel(const float* __restrict__ w, float* __restrict__ out, int Cin, int Cout,
-                                         int Cout_p, int Cin_s) {
+                                         int Cout_p, int Cin_s, int K, int pad) {
     // one launch per phase via blockIdx.y
     const int phase = blockIdx.y;
     int ntaps, kh[4], kw[4], dy[4], dx[4], a, b;
-    convT_phase_taps(phase, &ntaps, kh, kw, dy, dx, &a, &b);
+    convT_phase_taps(phase, K, pad, &ntaps, kh, kw, dy, dx, &a, &b);
     long off = 0;
     for (int q = 0; q < phase; ++q) {
         int nt, t1[4], t2[4], t3[4], t4[4], aa, bb;
-        convT_phase_taps(q, &nt, t1, t2, t3, t4, &aa, &bb);
+        convT_phase_taps(q, K, pad, &nt, t1, t2, t3, t4, &aa, &bb);
         const int Kq = (nt * Cin_s + kBK - 1) / kBK * kBK;
         off += (long)Cout_p * Kq;
     }
@@ -290,18 +293,272 @@ __global__ void pack_convT_weight_kernel(const float* __restrict__ w, float* __r
         const int n = (int)(i / Kp), k = (int)(i - (long)n * Kp);
         const int tap = k / Cin_s, c = k - tap * Cin_s;
         float v = 0.f;
-        if (n < Cout && tap < ntaps && c < Cin) v = w[(((size_t)c * Cout + n) * 3 + kh[tap]) * 3 + kw[tap]];
+        if (n < Cout && tap < ntaps && c < Cin) v = w[(((size_t)c * Cout + n) * K + kh[tap]) * K + kw[tap]];
         out[off + i] = v;
     }
 }
-void convT_phase_taps_host(int phase, int* ntaps, int kh[4], int kw[4], int dy[4], int dx[4], int* a, int* b) {
-    convT_phase_taps(phase, ntaps, kh, kw, dy, dx, a, b);
+void convT_phase_taps_host(int phase, int k, int pad, int* ntaps, int kh[4], int kw[4], int dy[4], int dx[4], int* a,
+                           int* b) {
+    convT_phase_taps(phase, k, pad, ntaps, kh, kw, dy, dx, a, b);
 }
-int launch_pack_convT_weight(hipStream_t s, const float* w, float* packed, int Cin, int Cout, int Cin_s,
-                             int Cout_p) {
-    const long total = (long)Cout_p * 4 * Cin_s;
+int launch_pack_convT_weight(hipStream_t s, const float* w, float* packed, int Cin, int Cout, int Cin_s, int Cout_p,
+                             int K, int pad) {
+    const long total = (long)Cout_p * 4 * Cin_s;   // per phase: at most 4 taps
     hipLaunchKernelGGL(pack_convT_weight_kernel, dim3(grid_for(total, 256), 4), dim3(256), 0, s, w, packed, Cin,
-                       Cout, Cout_p, Cin_s);
+                       Cout, Cout_p, Cin_s, K, pad);
+    T2V_HIP_CHECK(hipGetLastError());
+    return T2V_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward of the pointwise / norm / padding / pooling ops (train step)
+// ---------------------------------------------------------------------------------------------
+// adjoint of ReflectionPad2d(p): dx[i][j] = sum of dxp over every padded position that mirrors to (i,j)
+__global__ void reflect_pad_backward_kernel(const float* __restrict__ dxp, float* __restrict__ dx, int H, int W, int C,
+                                            int p) {
+    const int Wp = W + 2 * p;
+    const long total = (long)H * W * C;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int c = (int)(i % C);
+        const long pix = i / C;
+        const int x = (int)(pix % W), y = (int)(pix / W);
+        int ys[3], xs[3], ny = 0, nx = 0;
+        ys[ny++] = y + p;
+        if (y >= 1 && y <= p) ys[ny++] = p - y;
+        if (y >= H - 1 - p && y <= H - 2) ys[ny++] = 2 * (H - 1) + p - y;
+        xs[nx++] = x + p;
+        if (x >= 1 && x <= p) xs[nx++] = p - x;
+        if (x >= W - 1 - p && x <= W - 2) xs[nx++] = 2 * (W - 1) + p - x;
+        float s = 0.f;
+        for (int a = 0; a < ny; ++a)
+            for (int b = 0; b < nx; ++b) s += dxp[((long)ys[a] * Wp + xs[b]) * C + c];
+        dx[i] = s;
+    }
+}
+int launch_reflect_pad_backward(hipStream_t s, const float* dxp, float* dx, int H, int W, int C, int p) {
+    hipLaunchKernelGGL(reflect_pad_backward_kernel, dim3(grid_for((long)H * W * C, 256)), dim3(256), 0, s, dxp, dx, H, W,
+                       C, p);
+    T2V_HIP_CHECK(hipGetLastError());
+    return T2V_OK;
+}
+
+// norm backward, stage 1: per channel  S0 = sum g,  S1 = sum g*xhat   with g = dy * act'(gamma*xhat+beta)
+// block = 64 channels x 4 pixel lanes; grid = (C/64, slices); partial[slice][c] (float2), then a final pass.
+__device__ __forceinline__ float act_grad(float pre, int relu) {
+    return relu == 1 ? (pre > 0.f ? 1.f : 0.f) : (relu == 2 ? (pre > 0.f ? 1.f : 0.2f) : 1.f);
+}
+__global__ __launch_bounds__(256) void inorm_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                               const float2* __restrict__ mean_rstd,
+                                                               const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, int relu, long npix, int C,
+                                                               float2* __restrict__ partial) {
+    __shared__ float sh[2][4][64];
+    const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    float s0 = 0.f, s1 = 0.f;
+    if (c < C) {
+        const float2 mr = mean_rstd[c];
+        const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
+        for (long p = (long)blockIdx.y * 4 + sl; p < npix; p += (long)gridDim.y * 4) {
+            const float xh = (x[p * C + c] - mr.x) * mr.y;
+            const float g = dy[p * C + c] * act_grad(ga * xh + be, relu);
+            s0 += g;
+            s1 += g * xh;
+        }
+    }
+    sh[0][sl][cl] = s0;
+    sh[1][sl][cl] = s1;
+    __syncthreads();
+    if (sl == 0 && c < C)
+        partial[(size_t)blockIdx.y * C + c] = make_float2((sh[0][0][cl] + sh[0][1][cl]) + (sh[0][2][cl] + sh[0][3][cl]),
+                                                          (sh[1][0][cl] + sh[1][1][cl]) + (sh[1][2][cl] + sh[1][3][cl]));
+}
+__global__ void inorm_bwd_final_kernel(const float2* __restrict__ partial, int slices, int C, float2* __restrict__ sums) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s0 = 0.f, s1 = 0.f;
+    for (int i = 0; i < slices; ++i) {
+        const float2 v = partial[(size_t)i * C + c];
+        s0 += v.x;
+        s1 += v.y;
+    }
+    sums[c] = make_float2(s0, s1);   // (dbeta, dgamma) of an affine norm
+}
+// stage 2: dx = rstd * gamma * (g - S0/N - xhat * S1/N)      (biased variance, N = pixels in the statistics)
+__global__ __launch_bounds__(256) void inorm_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                              const float2* __restrict__ mean_rstd,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, int relu,
+                                                              const float2* __restrict__ sums, long npix, int C,
+                                                              float* __restrict__ dx) {
+    const long total = npix * C;
+    const float invn = 1.f / (float)npix;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int c = (int)(i % C);
+        const float2 mr = mean_rstd[c];
+        const float2 sm = sums[c];
+        const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
+        const float xh = (x[i] - mr.x) * mr.y;
+        const float g = dy[i] * act_grad(ga * xh + be, relu);
+        dx[i] = mr.y * ga * (g - sm.x * invn - xh * (sm.y * invn));
+    }
+}
+int launch_inorm_backward(hipStream_t s, const float* x, const float* dy, const float* mean_rstd, const float* gamma,
+                          const float* beta, int relu, long npix, int C, float* scratch, float* dx, float* sums) {
+    int slices = (int)((npix + 255) / 256);
+    if (slices > 64) slices = 64;
+    if (slices < 1) slices = 1;
+    hipLaunchKernelGGL(inorm_bwd_reduce_kernel, dim3((C + 63) / 64, slices), dim3(256), 0, s, x, dy,
+                       reinterpret_cast<const float2*>(mean_rstd), gamma, beta, relu, npix, C,
+                       reinterpret_cast<float2*>(scratch));
+    hipLaunchKernelGGL(inorm_bwd_final_kernel, dim3((C + 255) / 256), dim3(256), 0, s,
+                       reinterpret_cast<const float2*>(scratch), slices, C, reinterpret_cast<float2*>(sums));
+    hipLaunchKernelGGL(inorm_bwd_apply_kernel, dim3(grid_for(npix * C, 256)), dim3(256), 0, s, x, dy,
+                       reinterpret_cast<const float2*>(mean_rstd), gamma, beta, relu,
+                       reinterpret_cast<const float2*>(sums), npix, C, dx);
+    T2V_HIP_CHECK(hipGetLastError());
+    return T2V_OK;
+}
+
+// activation backward from the OUTPUT y: tanh' = 1-y^2 ; sigmoid' = y(1-y) ; leaky: y>0 ? 1 : slope ; scale: slope
+__global__ void act_backward_kernel(const float* __restrict__ dy, const float* __restrict__ y, int mode, float slope,
+                                    long n, float* __restrict__ dpre) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float v = y[i], g = dy[i];
+        float d;
+        if (mode == 1) d = g * (1.f - v * v);
+        else if (mode == 2) d = g * v * (1.f - v);
+        else if (mode == 3) d = v > 0.f ? g : g * slope;
+        else d = g * slope;
+        dpre[i] = d;
+    }
+}
+int launch_act_backward(hipStream_t s, const float* dy, const float* y, int mode, float slope, long n, float* dpre) {
+    hipLaunchKernelGGL(act_backward_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, dy, y, mode, slope, n, dpre);
+    T2V_HIP_CHECK(hipGetLastError());
+    return T2V_OK;
+}
+
+// AvgPool2d(3,2,1,count_include_pad=False) backward: gather form (each input pixel sums its <= 4 windows)
+__global__ void avgpool3s2_backward_kernel(const float* __restrict__ dy, float* __restrict__ dx, int H, int W, int C,
+                                           int Ho, int Wo) {
+    const long total = (long)H * W * C;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int c = (int)(i % C);
+        const long pix = i / C;
+        const int x = (int)(pix % W), y = (int)(pix / W);
+        float s = 0.f;
+        for (int oy = (y + 1 - 2 + 1) / 2; oy <= (y + 1) / 2; ++oy) {   // windows with 2*oy-1 <= y <= 2*oy+1
+            if (oy < 0 || oy >= Ho || 2 * oy - 1 > y || 2 * oy + 1 < y) continue;
+            const int ny = min(2 * oy + 1, H - 1) - max(2 * oy - 1, 0) + 1;
+            for (int ox = (x + 1 - 2 + 1) / 2; ox <= (x + 1) / 2; ++ox) {
+                if (ox < 0 || ox >= Wo || 2 * ox - 1 > x || 2 * ox + 1 < x) continue;
+                const int nx = min(2 * ox + 1, W - 1) - max(2 * ox - 1, 0) + 1;
+                s += dy[((long)oy * Wo + ox) * C + c] / (float)(ny * nx);
+            }
+        }
+        dx[i] = s;
+    }
+}
+int launch_avgpool3s2_backward(hipStream_t s, const float* dy, float* dx, int H, int W, int C) {
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    hipLaunchKernelGGL(avgpool3s2_backward_kernel, dim3(grid_for((long)H * W * C, 256)), dim3(256), 0, s, dy, dx, H, W,
+                       C, Ho, Wo);
+    T2V_HIP_CHECK(hipGetLastError());
+    return T2V_OK;
+}
+
+// loss backward: d/dx sum((x-c)^2)*scale = 2*scale*(x-c) ; d/da sum|a-b|*scale = scale*sign(a-b)
+__global__ void loss_backward_kernel(const float* __restrict__ a, const float* __restrict__ b, float c, float scale,
+                                     int op, long n, float* __restrict__ da) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        if (op == 0) {
+            da[i] = 2.f * scale * (a[i] - c);
+        } else {
+            const float d = a[i] - b[i];
+            da[i] = d > 0.f ? scale : (d < 0.f ? -scale : 0.f);
+        }
+    }
+}
+int launch_loss_backward(hipStream_t s, int op, const float* a, const float* b, float c, float scale, long n, float* da) {
+    hipLaunchKernelGGL(loss_backward_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, a, b, c, scale, op, n, da);
+    T2V_HIP_CHECK(hipGetLastError());
+    return T2V_OK;
+}
+
+// inverse of the packers (checkpoint save, gradient export): packed -> torch layout
+__global__ void unpack_conv_weight_kernel(const float* __restrict__ packed, float* __restrict__ w, int Cout, int Cin,
+                                          int KH, int KW, int Cin_s, int Kp, long total) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        long t = i;
+        const int kw = (int)(t % KW); t /= KW;
+        const int kh = (int)(t % KH); t /= KH;
+        const int c = (int)(t % Cin); t /= Cin;
+        const int n = (int)t;
+        w[i] = packed[(size_t)n * Kp + (kh * KW + kw) * Cin_s + c];
+    }
+}
+int launch_unpack_conv_weight(hipStream_t s, const float* packed, float* w, int Cout, int Cin, int KH, int KW, int Cin_s,
+                              int Kp) {
+    const long total = (long)Cout * Cin * KH * KW;
+    hipLaunchKernelGGL(unpack_conv_weight_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, packed, w, Cout, Cin, KH,
+                       KW, Cin_s, Kp, total);
+    T2V_HIP_CHECK(hipGetLastError());
+    return T2V_OK;
+}
+__global__ void unpack_convT_weight_kernel(const float* __restrict__ packed, float* __restrict__ w, int Cin, int Cout,
+                                           int Cout_p, int Cin_s, int K, int pad, long total) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        long t = i;
+        const int kw = (int)(t % K); t /= K;
+        const int kh = (int)(t % K); t /= K;
+        const int n = (int)(t % Cout); t /= Cout;
+        const int c = (int)t;
+        // find the phase / tap holding (kh, kw)
+        long off = 0;
+        float v = 0.f;
+        for (int ph = 0; ph < 4; ++ph) {
+            int nt, pkh[4], pkw[4], pdy[4], pdx[4], a, b;
+            convT_phase_taps(ph, K, pad, &nt, pkh, pkw, pdy, pdx, &a, &b);
+            const int Kq = (nt * Cin_s + kBK - 1) / kBK * kBK;
+            for (int q = 0; q < nt; ++q)
+                if (pkh[q] == kh && pkw[q] == kw) v = packed[off + (size_t)n * Kq + q * Cin_s + c];
+            off += (long)Cout_p * Kq;
+        }
+        w[i] = v;
+    }
+}
+int launch_unpack_convT_weight(hipStream_t s, const float* packed, float* w, int Cin, int Cout, int Cin_s, int Cout_p,
+                               int K, int pad) {
+    const long total = (long)Cin * Cout * K * K;
+    hipLaunchKernelGGL(unpack_convT_weight_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, packed, w, Cin, Cout,
+                       Cout_p, Cin_s, K, pad, total);
+    T2V_HIP_CHECK(hipGetLastError());
+    return T2V_OK;
+}
+
+// per-channel sum over pixels of an NHWC tensor (bias gradient): deterministic, one block per 64 channels
+__global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ x, long npix, int C, int cs,
+                                                          float* __restrict__ out) {
+    __shared__ float sh[4][64];
+    const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    float s = 0.f;
+    if (c < C)
+        for (long p = sl; p < npix; p += 4) s += x[p * cs + c];
+    sh[sl][cl] = s;
+    __syncthreads();
+    if (sl == 0 && c < C) out[c] = (sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl]);
+}
+int launch_channel_sum(hipStream_t s, const float* x, long npix, int C, int cs, float* out) {
+    hipLaunchKernelGGL(channel_sum_kernel, dim3((C + 63) / 64), dim3(256), 0, s, x, npix, C, cs, out);
     T2V_HIP_CHECK(hipGetLastError());
     return T2V_OK;
 }

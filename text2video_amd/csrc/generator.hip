@@ -32,6 +32,7 @@ t2v_conv_desc mk_conv(int H, int W, int Cin, int Cout, int k, int stride, int pa
     t2v_conv_desc d;
     d.H = H; d.W = W; d.Cin = Cin; d.Cout = Cout; d.kH = k; d.kW = k; d.stride = stride; d.pad = pad;
     d.pad_mode = pad_mode; d.transposed = transposed; d.act = act; d.act_scale = act_scale;
+    d.output_padding = transposed ? 1 : 0;
     return d;
 }
 

@@ -67,7 +67,7 @@ struct ConvKParams {
     const float* zero;  // >= 16 bytes of zeros in device memory
     int Hin, Win, Cin_s;
     int Wm, M;
-    int Cout, Cout_s, Wout;
+    int Cout, Cout_s, Wout, Hout;
     int stride, ostride;
     int pad_mode, act;
     float act_scale;  // flow multiplier of T2V_ACT_FLOW_W
@@ -77,6 +77,36 @@ struct ConvKParams {
     int tdy[kMaxTaps];  // ints: read with scalar loads (uniform index), never a vector load
     int tdx[kMaxTaps];
 };
+
+// weight-gradient kernel (conv_wgrad.hip): one block = 128 Cout x 128 Cin of one tap, reduction over pixels
+struct WgradParams {
+    const float* x;    // forward input  [batch][Hin][Win][Cin_s]
+    const float* dy;   // output gradient [batch][Hout][Wout][Cout_s]
+    float* dw;         // packed weight gradient (same layout as the packed forward weight)
+    int batch, Hin, Win, Cin_s;
+    int Wm, M;         // GEMM pixel grid of the forward conv, per image
+    int Hout, Wout, Cout, Cout_s;
+    int stride, ostride;
+    int ntaps, ntiles, ctiles;
+    int reflect, accumulate;
+    int tdy[kMaxTaps], tdx[kMaxTaps];   // input offset of every tap (all phases concatenated)
+    int toy[kMaxTaps], tox[kMaxTaps];   // output offset (sub-pixel phase) of the tap's phase
+    long tap_woff[kMaxTaps];            // float offset of the tap's phase matrix in dw
+    int tap_Kp[kMaxTaps];               // padded K of that phase matrix
+    int tap_kidx[kMaxTaps];             // index of the tap inside its phase
+};
+int launch_conv_wgrad(hipStream_t s, const WgradParams& p);
+int launch_unpack_conv_weight(hipStream_t s, const float* packed, float* w, int Cout, int Cin, int KH, int KW, int Cin_s,
+                              int Kp);
+int launch_unpack_convT_weight(hipStream_t s, const float* packed, float* w, int Cin, int Cout, int Cin_s, int Cout_p,
+                               int K, int pad);
+int launch_reflect_pad_backward(hipStream_t s, const float* dxp, float* dx, int H, int W, int C, int p);
+int launch_inorm_backward(hipStream_t s, const float* x, const float* dy, const float* mean_rstd, const float* gamma,
+                          const float* beta, int relu, long npix, int C, float* scratch, float* dx, float* sums);
+int launch_act_backward(hipStream_t s, const float* dy, const float* y, int mode, float slope, long n, float* dpre);
+int launch_avgpool3s2_backward(hipStream_t s, const float* dy, float* dx, int H, int W, int C);
+int launch_loss_backward(hipStream_t s, int op, const float* a, const float* b, float c, float scale, long n, float* da);
+int launch_channel_sum(hipStream_t s, const float* x, long npix, int C, int cs, float* out);
 
 enum ConvTile { kTileL = 0 /*128x128, 32x32x2 MFMA*/, kTileS = 1 /*256x16, 16x16x4 MFMA*/, kTileQ = 2 /*64x64*/ };
 int conv_tile_for(int Cout);
@@ -91,10 +121,11 @@ int launch_inorm_apply(hipStream_t s, const float* x, const float* mean_rstd, co
                        int relu);
 int launch_pack_conv_weight(hipStream_t s, const float* w, float* packed, int Cout, int Cin, int KH, int KW,
                             int Cin_s, int Kp, int Cout_p);
-int launch_pack_convT_weight(hipStream_t s, const float* w, float* packed, int Cin, int Cout, int Cin_s,
-                             int Cout_p);
+int launch_pack_convT_weight(hipStream_t s, const float* w, float* packed, int Cin, int Cout, int Cin_s, int Cout_p,
+                             int K, int pad);
 // taps of sub-pixel phase `phase` of ConvTranspose2d(k3,s2,p1,op1); shared by packer and launcher
-void convT_phase_taps_host(int phase, int* ntaps, int kh[4], int kw[4], int dy[4], int dx[4], int* a, int* b);
+void convT_phase_taps_host(int phase, int k, int pad, int* ntaps, int kh[4], int kw[4], int dy[4], int dx[4], int* a,
+                           int* b);
 int launch_nchw_to_nhwc(hipStream_t s, const float* src, float* dst, int C, int H, int W, int Cs);
 int launch_nhwc_to_nchw(hipStream_t s, const float* src, float* dst, int C, int H, int W, int Cs);
 int launch_reduce(hipStream_t s, int op, const float* a, const float* b, float c, long n, float* scratch, float* out);

@@ -47,8 +47,10 @@ def round_up(v, m):
 
 
 def conv_desc(H, W, Cin, Cout, k, stride=1, pad=0, pad_mode=PAD_ZERO, transposed=False, act=ACT_NONE,
-              act_scale=1.0):
-    return ConvDesc(H, W, Cin, Cout, k, k, stride, pad, pad_mode, int(transposed), act, act_scale)
+              act_scale=1.0, output_padding=None):
+    if output_padding is None:
+        output_padding = 1 if transposed else 0     # the generator's ConvTranspose2d(k3,s2,p1,op1)
+    return ConvDesc(H, W, Cin, Cout, k, k, stride, pad, pad_mode, int(transposed), act, act_scale, output_padding)
 
 
 def conv_out_dims(desc):
@@ -234,3 +236,98 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step):
     check(c.lib.t2v_adam_step(c.handle, _stream(), _p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(),
                               lr, beta1, beta2, eps, int(step)), "adam_step")
     return param
+
+
+def conv2d_backward_weight(x, dy, desc, accumulate_into=None):
+    """Weight gradient in the PACKED layout.  x: [B,H,W,x_cs], dy: [B,Hout,Wout,dy_cs] (or 3-D, B=1)."""
+    c = context()
+    if x.dim() == 3:
+        x, dy = x.unsqueeze(0), dy.unsqueeze(0)
+    _chk(x, "x")
+    _chk(dy, "dy")
+    B, x_cs, dy_cs = x.shape[0], x.shape[-1], dy.shape[-1]
+    n = c.lib.t2v_conv_packed_weight_floats(ctypes.byref(desc), x_cs)
+    dw = accumulate_into if accumulate_into is not None else torch.zeros(n, dtype=torch.float32, device=x.device)
+    check(c.lib.t2v_conv2d_backward_weight(c.handle, _stream(), ctypes.byref(desc), B, _p(x), x_cs, _p(dy), dy_cs,
+                                           _p(dw), int(accumulate_into is not None)), "conv2d_backward_weight")
+    return dw
+
+
+def unpack_conv_weight(packed, desc, x_cs=None):
+    """packed layout -> torch layout ([Cout,Cin,kH,kW] or [Cin,Cout,3,3])."""
+    c = context()
+    x_cs = round_up(desc.Cin, 4) if x_cs is None else x_cs
+    shape = (desc.Cin, desc.Cout, desc.kH, desc.kW) if desc.transposed else (desc.Cout, desc.Cin, desc.kH, desc.kW)
+    w = torch.empty(shape, dtype=torch.float32, device=packed.device)
+    check(c.lib.t2v_conv_unpack_weight(c.handle, _stream(), ctypes.byref(desc), x_cs, _p(packed), _p(w)),
+          "conv_unpack_weight")
+    return w
+
+
+def channel_sum(x, C=None):
+    """sum over all pixels per channel of an NHWC tensor (bias gradient)."""
+    c = context()
+    _chk(x, "x")
+    cs = x.shape[-1]
+    C = cs if C is None else C
+    out = torch.empty(C, dtype=torch.float32, device=x.device)
+    check(c.lib.t2v_channel_sum(c.handle, _stream(), _p(x), x.numel() // cs, C, cs, _p(out)), "channel_sum")
+    return out
+
+
+def reflect_pad_backward(dxp, pad):
+    """adjoint of ReflectionPad2d(pad): [H+2p, W+2p, C] -> [H, W, C]."""
+    c = context()
+    _chk(dxp, "dxp")
+    Hp, Wp, C = dxp.shape
+    H, W = Hp - 2 * pad, Wp - 2 * pad
+    dx = torch.empty(H, W, C, dtype=torch.float32, device=dxp.device)
+    check(c.lib.t2v_reflect_pad_backward(c.handle, _stream(), _p(dxp), _p(dx), H, W, C, pad), "reflect_pad_backward")
+    return dx
+
+
+def instance_norm_backward(x, dy, mean_rstd, gamma=None, beta=None, relu=0):
+    """x, dy: [..., C] (all leading dims are the pixels of ONE statistics group).  Returns
+    (dx, dbeta_dgamma [C,2])."""
+    c = context()
+    _chk(x, "x")
+    _chk(dy, "dy")
+    C = x.shape[-1]
+    npix = x.numel() // C
+    dx = torch.empty_like(x)
+    sums = torch.empty(C, 2, dtype=torch.float32, device=x.device)
+    scratch = torch.empty(64 * C * 2, dtype=torch.float32, device=x.device)
+    check(c.lib.t2v_instance_norm_backward(c.handle, _stream(), _p(x), _p(dy), _p(mean_rstd), _p(gamma), _p(beta),
+                                           int(relu), npix, C, _p(scratch), _p(dx), _p(sums)), "instance_norm_backward")
+    return dx, sums
+
+
+def act_backward(dy, y, act, slope=1.0):
+    c = context()
+    dpre = torch.empty_like(dy)
+    check(c.lib.t2v_act_backward(c.handle, _stream(), _p(dy), _p(y), act, slope, dy.numel(), _p(dpre)), "act_backward")
+    return dpre
+
+
+def avgpool3x3s2_backward(dy, H, W):
+    c = context()
+    C = dy.shape[-1]
+    dx = torch.empty(H, W, C, dtype=torch.float32, device=dy.device)
+    check(c.lib.t2v_avgpool3x3s2_backward(c.handle, _stream(), _p(dy), _p(dx), H, W, C), "avgpool3x3s2_backward")
+    return dx
+
+
+def sum_sq_diff_const_backward(x, c0, scale):
+    c = context()
+    dx = torch.empty_like(x)
+    check(c.lib.t2v_sum_sq_diff_const_backward(c.handle, _stream(), _p(x), float(c0), float(scale), x.numel(), _p(dx)),
+          "sum_sq_diff_const_backward")
+    return dx
+
+
+def sum_abs_diff_backward(a, b, scale):
+    c = context()
+    da = torch.empty_like(a)
+    check(c.lib.t2v_sum_abs_diff_backward(c.handle, _stream(), _p(a), _p(b), float(scale), a.numel(), _p(da)),
+          "sum_abs_diff_backward")
+    return da
