@@ -1,0 +1,128 @@
+"""GPU parity of one full train iteration (generator + multiscale discriminator, LSGAN + feature
+matching, Adam) on the HIP path against torch autograd over the CPU oracle modules."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    return torch.from_numpy((np.random.default_rng(seed).standard_normal(shape) * scale).astype(np.float32))
+
+
+def _nhwc(x_bchw, cs):
+    """[B,C,H,W] cpu -> [B,H,W,cs] device"""
+    B, C, H, W = x_bchw.shape
+    out = torch.zeros(B, H, W, cs, device="cuda:0")
+    out[..., :C] = x_bchw.permute(0, 2, 3, 1).cuda()
+    return out
+
+
+def _adam_041(p, g, m, v, lr, b1, b2, eps, step):
+    m.mul_(b1).add_(g, alpha=1 - b1)
+    v.mul_(b2).addcmul_(g, g, value=1 - b2)
+    p.addcdiv_(m, v.sqrt().add_(eps), value=-(lr * (1 - b2 ** step) ** 0.5 / (1 - b1 ** step)))
+
+
+def test_one_train_iteration_matches_autograd_oracle():
+    from oracle.generator_ref import CompositeGenerator, MultiscaleDiscriminator, weights_init
+    from text2video_amd import train as T
+    from text2video_amd.generator import GeneratorSpec, synthetic_state_dict
+    H = W = 32
+    spec = GeneratorSpec(ngf=32, n_downsample=2, n_blocks=2, no_flow=True, norm="batch")
+    sd = synthetic_state_dict(spec, 3, "vid2vid")
+    # ---------------- oracle (CPU, torch autograd)
+    Gr = CompositeGenerator(9, 3, 6, 32, 2, 2, True, "batch").train()
+    Gr.load_state_dict(sd, strict=False)
+    Dr = MultiscaleDiscriminator(6, 16, 3, 2, "batch").train()
+    gen = torch.Generator().manual_seed(7)
+    Dr.apply(lambda m: weights_init(m, gen))
+    dsd = {k: v.clone() for k, v in Dr.state_dict().items() if "running" not in k and "num_batches" not in k}
+    poses = _rand(2, 9, H, W, seed=1).clamp(-1, 1)          # two frames (two sliding windows)
+    real = torch.tanh(_rand(2, 3, H, W, seed=2))
+    mse, l1 = torch.nn.MSELoss(), torch.nn.L1Loss()
+
+    def gan(pred, real_target):
+        return sum(mse(p[-1], torch.ones_like(p[-1]) if real_target else torch.zeros_like(p[-1])) for p in pred)
+
+    def fm(pf, pr):
+        return sum(0.5 * 1.0 * l1(pf[i][j], pr[i][j].detach()) * 10.0 for i in range(2) for j in range(4))
+
+    # non-zero previous frames: an all-zero prev image makes the image encoder's norm layers 0/0
+    # (rstd = 1/sqrt(eps) = 316 per layer), which turns its gradients into amplified rounding noise in
+    # ANY fp32 implementation -- not a meaningful parity target
+    prev0 = torch.tanh(_rand(1, 6, H, W, seed=5))
+    f1 = Gr(poses[0:1], prev0, True)[0]
+    f2 = Gr(poses[1:2], torch.cat([prev0[:, 3:], f1.detach()], 1), True)[0]
+    fake = torch.cat([f1, f2], 0)
+    A = poses[:, 6:9]                                          # newest pose map of each window
+    pred_real = Dr(torch.cat([A, real], 1))
+    pred_fake_d = Dr(torch.cat([A, fake.detach()], 1))
+    loss_D = 0.5 * (gan(pred_fake_d, False) + gan(pred_real, True))
+    pred_fake_g = Dr(torch.cat([A, fake], 1))
+    loss_G = gan(pred_fake_g, True) + fm(pred_fake_g, pred_real)
+    gG = torch.autograd.grad(loss_G, list(Gr.parameters()), retain_graph=True)
+    gD = torch.autograd.grad(loss_D, list(Dr.parameters()))
+    ref_gG = {k: g for (k, _), g in zip(Gr.named_parameters(), gG)}
+    ref_gD = {k: g for (k, _), g in zip(Dr.named_parameters(), gD)}
+
+    # ---------------- HIP path
+    Gh = T.TrainableGenerator(spec, sd, "cuda:0")
+    Dh = T.TrainableDiscriminator(6, dsd, 16, 3, 2, "batch", "cuda:0")
+    pz = _nhwc(poses, 12)
+    hprev0 = _nhwc(prev0, 8)
+    h1 = Gh(pz[0:1], hprev0)
+    prev2 = torch.zeros(1, H, W, 8, device="cuda:0")
+    prev2[..., 0:3] = hprev0[..., 3:6]
+    prev2[..., 3:6] = h1.detach()[..., :3]
+    h2 = Gh(pz[1:2], prev2)
+    hfake = torch.cat([h1, h2], 0)
+    assert (hfake[..., :3].permute(0, 3, 1, 2).cpu() - fake.detach()).abs().max().item() <= 1e-4
+    A8 = _nhwc(A, 3)
+    z2 = torch.zeros(2, H, W, 2, device="cuda:0")
+
+    def d_in(img4):
+        return torch.cat([A8, img4[..., :3], z2], -1).contiguous()
+
+    hp_real = Dh(d_in(_nhwc(real, 4)))
+    hp_fake_d = Dh(d_in(hfake.detach()))
+    hloss_D = 0.5 * (T.gan_loss(hp_fake_d, False) + T.gan_loss(hp_real, True))
+    hp_fake_g = Dh(d_in(hfake))
+    hloss_G = T.gan_loss(hp_fake_g, True) + T.feature_matching_loss(hp_fake_g, hp_real)
+    assert abs(hloss_D.item() - loss_D.item()) <= 1e-4 * max(1, abs(loss_D.item()))
+    assert abs(hloss_G.item() - loss_G.item()) <= 1e-4 * max(1, abs(loss_G.item()))
+    hgG = torch.autograd.grad(hloss_G, list(Gh.parameters()), retain_graph=True, allow_unused=True)
+    hgD = torch.autograd.grad(hloss_D, list(Dh.parameters()), allow_unused=True)
+    got_gG = {k: g for (k, _), g in zip(Gh.named_upstream_parameters().items(), hgG)}
+    got_gD = {k: g for (k, _), g in zip(Dh.named_upstream_parameters().items(), hgD)}
+
+    def check(got, ref, tag):
+        errs = {}
+        for k, r in ref.items():
+            g = got[k]
+            assert g is not None, (tag, k)
+            if r.abs().max().item() <= 1e-5:
+                continue   # conv biases in front of a norm: mathematically zero gradient, only rounding noise
+            errs[k] = (g.cpu() - r).abs().max().item() / r.abs().max().item()
+        top = sorted(errs.items(), key=lambda kv: -kv[1])[:4]
+        print(tag, "largest relative gradient errors:", ["%s %.1e" % kv for kv in top],
+              "median %.1e" % float(np.median(list(errs.values()))))
+        assert max(errs.values()) <= 2e-3 and float(np.median(list(errs.values()))) <= 1e-4
+        return max(errs.values())
+
+    wG = check(got_gG, ref_gG, "G")
+    wD = check(got_gD, ref_gD, "D")
+    print("worst relative gradient error  G %.2e  D %.2e" % (wG, wD))
+
+    # ---------------- one Adam step on both sides (torch-0.4.1 update rule)
+    optG = T.FusedAdam(Gh.parameters())
+    for p, g in zip(Gh.parameters(), hgG):
+        p.grad = g
+    optG.step()
+    for (k, p), g in zip(Gr.named_parameters(), gG):
+        pr = p.detach().clone().double()
+        _adam_041(pr, g.double(), torch.zeros_like(pr), torch.zeros_like(pr), 2e-4, 0.5, 0.999, 1e-8, 1)
+        got = Gh.named_upstream_parameters()[k].detach().cpu().double()
+        if g.abs().max().item() > 1e-5:
+            assert (got - pr).abs().max().item() <= 2.5e-4, k    # first Adam step moves every weight by ~lr
