@@ -125,6 +125,8 @@ int t2v_avgpool3x3s2(t2v_ctx* ctx, void* stream, const float* x, float* y, int H
  * THCUNN.h:664,794).  `d` is the FORWARD conv descriptor.
  *   backward_weight: dW (packed layout, same as the packed forward weight) = sum over the batch and
  *       all pixels of dy (x) x through every filter tap; accumulate != 0 adds to dw_packed.
+ *       Narrow high-resolution layers cut the pixel reduction into ranges (deterministic partials in
+ *       `workspace`, summed in a fixed order).
  *       x: [batch][H][W][x_cs], dy: [batch][Hout][Wout][dy_cs].
  *   unpack_weight:   packed -> torch layout (inverse of t2v_conv_pack_weight).
  *   channel_sum:     out[c] = sum over pixels of x[.][c]  (bias gradient).
@@ -132,8 +134,10 @@ int t2v_avgpool3x3s2(t2v_ctx* ctx, void* stream, const float* x, float* y, int H
  * geometry (stride-2 conv <-> ConvTranspose with the same torch-layout weight; stride-1: flipped /
  * transposed weight, padding k-1-p) -- text2video_amd/backward.py builds those descriptors.
  * ------------------------------------------------------------------------------------------ */
+size_t t2v_conv_backward_weight_workspace_floats(const t2v_conv_desc* d, int x_cs, int batch);
 int t2v_conv2d_backward_weight(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, int batch, const float* x,
-                               int x_cs, const float* dy, int dy_cs, float* dw_packed, int accumulate);
+                               int x_cs, const float* dy, int dy_cs, float* dw_packed, int accumulate,
+                               float* workspace /* NULL when ..._workspace_floats() == 0 */);
 int t2v_conv_unpack_weight(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, int x_cs, const float* packed_dev,
                            float* w_torch_dev);
 int t2v_channel_sum(t2v_ctx* ctx, void* stream, const float* x, long npix, int C, int cs, float* out);

@@ -35,6 +35,9 @@ WGRAD_CASES = [
     ("head7x7_cout3", 1, 20, 16, 32, 3, 7, 1, 3, 1, False),
     ("disc4x4_s2_p2", 2, 16, 16, 8, 64, 4, 2, 2, 0, False),
     ("disc4x4_s1_p2", 1, 9, 9, 64, 1, 4, 1, 2, 0, False),
+    ("stem7x7_pixel_split", 1, 96, 96, 9, 32, 7, 1, 3, 1, False),       # 49 blocks, 288 stages -> split reduction
+    ("disc_first_pixel_split", 2, 64, 64, 6, 64, 4, 2, 2, 0, False),
+    ("convT_pixel_split", 1, 48, 48, 32, 32, 3, 2, 1, 0, True),
 ]
 
 
@@ -73,7 +76,7 @@ def test_pack_unpack_roundtrip():
         assert torch.equal(ops.unpack_conv_weight(ops.pack_conv_weight(w, desc, xcs), desc, xcs), w)
 
 
-DGRAD_CASES = [c for c in WGRAD_CASES if c[0] not in ("stem7x7_cin9",)] + [
+DGRAD_CASES = [c for c in WGRAD_CASES if c[0] not in ("stem7x7_cin9",) and "split" not in c[0]] + [
     ("disc4x4_s2_p2_odd", 1, 17, 17, 8, 16, 4, 2, 2, 0, False),      # odd input: output_padding 1, odd convT output
 ]
 

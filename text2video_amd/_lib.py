@@ -57,8 +57,9 @@ SIGNATURES = {
                                    c_void_p, c_int, c_void_p]),
     "t2v_instance_norm_finalize": (c_int, [c_void_p, c_void_p, POINTER(ConvDesc), c_void_p, c_float, c_void_p]),
     "t2v_batch_norm_finalize": (c_int, [c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_void_p, c_float, c_void_p]),
+    "t2v_conv_backward_weight_workspace_floats": (c_size_t, [POINTER(ConvDesc), c_int, c_int]),
     "t2v_conv2d_backward_weight": (c_int, [c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_void_p, c_int, c_void_p,
-                                           c_int, c_void_p, c_int]),
+                                           c_int, c_void_p, c_int, c_void_p]),
     "t2v_conv_unpack_weight": (c_int, [c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_void_p, c_void_p]),
     "t2v_channel_sum": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_void_p]),
     "t2v_reflect_pad_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int]),

@@ -251,8 +251,29 @@ int t2v_batch_norm_finalize(t2v_ctx* ctx, void* stream, const t2v_conv_desc* pro
                                  producer->Cout, eps, mean_rstd);
 }
 
+static int wgrad_splits(const t2v_conv_desc* d, int x_cs, int batch, const ConvPlan& pl) {
+    // few (tap, channel-tile) blocks but a long pixel reduction (high-resolution, narrow layers): cut the
+    // reduction so that >= ~512 blocks exist; partial gradients are summed in a fixed order afterwards
+    int ntaps = 0;
+    for (int ph = 0; ph < pl.kp.nphases; ++ph) ntaps += pl.kp.ph[ph].ntaps;
+    const long blocks = (long)ntaps * ((d->Cout + 127) / 128) * ((x_cs + 127) / 128);
+    const long nk = ((long)batch * pl.kp.M + 31) / 32;
+    long s = (512 + blocks - 1) / blocks;
+    if (s > nk / 8) s = nk / 8;      // at least 8 stages per block
+    if (s > 256) s = 256;
+    return s < 1 ? 1 : (int)s;
+}
+
+size_t t2v_conv_backward_weight_workspace_floats(const t2v_conv_desc* d, int x_cs, int batch) {
+    ConvPlan pl;
+    if (!d || build_conv_plan(d, x_cs, true, &pl) != T2V_OK) return 0;
+    const int s = wgrad_splits(d, x_cs, batch, pl);
+    return s > 1 ? (size_t)s * pl.wfloats : 0;
+}
+
 int t2v_conv2d_backward_weight(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, int batch, const float* x,
-                               int x_cs, const float* dy, int dy_cs, float* dw_packed, int accumulate) {
+                               int x_cs, const float* dy, int dy_cs, float* dw_packed, int accumulate,
+                               float* workspace) {
     T2V_REQUIRE(ctx && x && dy && dw_packed && batch >= 1, "backward_weight: bad arguments");
     ConvPlan pl;
     T2V_TRY(build_conv_plan(d, x_cs, true, &pl));   // 128-row weight granule, plain 128x128 bookkeeping
@@ -277,7 +298,16 @@ int t2v_conv2d_backward_weight(t2v_ctx* ctx, void* stream, const t2v_conv_desc* 
     w.ntaps = nt;
     T2V_REQUIRE((long)batch * d->H * d->W * x_cs * 4 < 0x7fff0000L && (long)batch * pl.Hout * pl.Wout * dy_cs * 4 < 0x7fff0000L,
                 "backward_weight: tensors too large for 32-bit buffer offsets (split the batch)");
-    return launch_conv_wgrad((hipStream_t)stream, w);
+    w.splits = wgrad_splits(d, x_cs, batch, pl);
+    w.dw_floats = (long)pl.wfloats;
+    if (w.splits == 1) return launch_conv_wgrad((hipStream_t)stream, w);
+    T2V_REQUIRE(workspace, "backward_weight: this shape needs a workspace of "
+                           "t2v_conv_backward_weight_workspace_floats() floats");
+    T2V_HIP_CHECK(hipMemsetAsync(workspace, 0, (size_t)w.splits * pl.wfloats * sizeof(float), (hipStream_t)stream));
+    w.dw = workspace;
+    w.accumulate = 0;
+    T2V_TRY(launch_conv_wgrad((hipStream_t)stream, w));
+    return launch_wgrad_reduce((hipStream_t)stream, workspace, w.splits, (long)pl.wfloats, dw_packed, accumulate);
 }
 
 int t2v_conv_unpack_weight(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, int x_cs, const float* packed_dev,

@@ -47,11 +47,15 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradParams p) {
     int t = blockIdx.x;
     const int ct = t % p.ctiles; t /= p.ctiles;
     const int nt = t % p.ntiles; t /= p.ntiles;
-    const int tap = t;   // global tap index (all phases)
+    const int tap = t % p.ntaps; t /= p.ntaps;   // global tap index (all phases)
+    const int split = t;
     const int n0 = nt * 128, c0 = ct * 128;
     const int dy = p.tdy[tap], dx = p.tdx[tap];
     const int P = p.batch * p.M;              // pixels to reduce over
-    const int nk = (P + kWgPix - 1) / kWgPix;
+    const int nk_all = (P + kWgPix - 1) / kWgPix;
+    const int per = (nk_all + p.splits - 1) / p.splits;
+    const int kt0 = split * per;              // this block's stage range [kt0, kt0 + nk)
+    const int nk = max(0, min(per, nk_all - kt0));
 
     if (is_loader) {
         // each loader wave: 4 dY instructions + 4 X instructions per stage; one instruction = 2 pixel rows
@@ -67,7 +71,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradParams p) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int r = wid * 8 + i * 2 + prow;      // pixel row in the stage, 0..31
-                const int pidx = kt * kWgPix + r;          // global pixel (image-major)
+                const int pidx = (kt0 + kt) * kWgPix + r;   // global pixel (image-major)
                 const bool ok = pidx < P;
                 const int b = pidx / p.M, m = pidx - b * p.M;
                 const int my = m / p.Wm, mx = m - my * p.Wm;
@@ -92,12 +96,12 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradParams p) {
         };
         constexpr int LD = 8;
         issue_stage(0, 0);
-        issue_stage(min(1, nk - 1), 1);
+        issue_stage(max(0, min(1, nk - 1)), 1);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LD) : "memory");
         __builtin_amdgcn_s_barrier();
         int slot = 2;
         for (int kt = 0; kt < nk; ++kt) {
-            issue_stage(min(kt + 2, nk - 1), slot);  // past the end: harmless re-fetch of the last stage
+            issue_stage(max(0, min(kt + 2, nk - 1)), slot);  // past the end: harmless re-fetch of the last stage
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LD) : "memory");
             __builtin_amdgcn_s_barrier();
             slot = slot == kWgRing - 1 ? 0 : slot + 1;
@@ -142,7 +146,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradParams p) {
     }
 
     // ---- epilogue: D[row n][col c] -> packed dW[n][koff + c]  (koff: position of this tap in K) ----
-    float* out = p.dw + p.tap_woff[tap];
+    float* out = p.dw + (size_t)split * p.dw_floats + p.tap_woff[tap];
     const int Kp = p.tap_Kp[tap];
     const int kbase = p.tap_kidx[tap] * p.Cin_s + c0;
 #pragma unroll
@@ -163,10 +167,27 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradParams p) {
         }
 }
 
+__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int splits, long n, float* __restrict__ dw,
+                                    int accumulate) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float s = accumulate ? dw[i] : 0.f;
+        for (int k = 0; k < splits; ++k) s += partial[(size_t)k * n + i];   // fixed order: deterministic
+        dw[i] = s;
+    }
+}
+int launch_wgrad_reduce(hipStream_t s, const float* partial, int splits, long n, float* dw, int accumulate) {
+    long g = (n + 255) / 256;
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)g), dim3(256), 0, s, partial, splits, n, dw, accumulate);
+    T2V_HIP_CHECK(hipGetLastError());
+    return T2V_OK;
+}
+
 int launch_conv_wgrad(hipStream_t s, const WgradParams& p) {
     static bool attr_done[2] = {false, false};
     const int lds = kWgRing * kWgStage;
-    const int nblocks = p.ntaps * p.ntiles * p.ctiles;
+    const int nblocks = p.ntaps * p.ntiles * p.ctiles * p.splits;
     if (p.reflect) {
         if (!attr_done[1]) {
             T2V_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<true>),

@@ -89,6 +89,8 @@ struct WgradParams {
     int stride, ostride;
     int ntaps, ntiles, ctiles;
     int reflect, accumulate;
+    int splits;        // the pixel reduction is cut into `splits` ranges (blockIdx major), each writing its own
+    long dw_floats;    // partial gradient at dw + split*dw_floats (deterministic; summed by wgrad_reduce)
     int tdy[kMaxTaps], tdx[kMaxTaps];   // input offset of every tap (all phases concatenated)
     int toy[kMaxTaps], tox[kMaxTaps];   // output offset (sub-pixel phase) of the tap's phase
     long tap_woff[kMaxTaps];            // float offset of the tap's phase matrix in dw
@@ -96,6 +98,7 @@ struct WgradParams {
     int tap_kidx[kMaxTaps];             // index of the tap inside its phase
 };
 int launch_conv_wgrad(hipStream_t s, const WgradParams& p);
+int launch_wgrad_reduce(hipStream_t s, const float* partial, int splits, long n, float* dw, int accumulate);
 int launch_unpack_conv_weight(hipStream_t s, const float* packed, float* w, int Cout, int Cin, int KH, int KW, int Cin_s,
                               int Kp);
 int launch_unpack_convT_weight(hipStream_t s, const float* packed, float* w, int Cin, int Cout, int Cin_s, int Cout_p,
