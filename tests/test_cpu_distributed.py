@@ -104,3 +104,28 @@ def test_chunk_bounds_and_assignment_edge_cases():
     assert assign_chunks({"short": 2}, 2) == [[], []]                # shorter than the window: no output
     plan = assign_chunks({"s": 4}, 4)                                # 2 outputs cannot feed 4 ranks
     assert sum(len(p) for p in plan) <= 2
+
+
+def _ar_worker(rank, world, port, tmpdir):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from text2video_amd import distributed as D
+    from text2video_amd.train import allreduce_gradients
+    D.init_from_env("gloo")
+    torch.manual_seed(0)
+    params = [torch.nn.Parameter(torch.zeros(n)) for n in (5, 70000, 3, 1 << 18, 17)]
+    for i, p in enumerate(params):
+        p.grad = torch.full_like(p, float(rank + 1) * (i + 1))
+    params.append(torch.nn.Parameter(torch.zeros(4)))          # a parameter without gradient is skipped
+    nbytes = allreduce_gradients(params, bucket_mb=1)           # several buckets
+    assert nbytes == 4 * sum(p.numel() for p in params[:-1])
+    for i, p in enumerate(params[:-1]):
+        want = (1 + 2) / 2.0 * (i + 1)                          # mean over the two ranks
+        assert torch.allclose(p.grad, torch.full_like(p, want))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_gradient_allreduce(tmp_path):
+    """Bucketed, averaged gradient all-reduce of the train step (replaces DataParallel's GPU-0 star)."""
+    mp.spawn(_ar_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)

@@ -55,3 +55,25 @@ def test_reference_command_line_end_to_end(tmp_path):
     r2 = subprocess.run(cmd[:cmd.index("--synthetic_weights")] + ["--ngf", "32"], cwd=work, env=env, capture_output=True,
                         text=True, timeout=600)
     assert r2.returncode != 0 and "not found" in (r2.stderr + r2.stdout)
+
+
+def test_train_py_then_test_py_roundtrip(tmp_path):
+    """train.py (reference flag surface, synthetic sequences: G + multiscale D + face D, Adam) writes
+    upstream-format checkpoints that test.py loads and renders frames from."""
+    work = _make_dataset(str(tmp_path))
+    env = dict(os.environ, CUDA_VISIBLE_DEVICES="0")
+    common = ["--name", "fadg0", "--dataset_mode", "pose", "--input_nc", "3", "--openpose_only", "--no_first_img",
+              "--ngf", "32", "--n_blocks", "3"]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "vid2vid", "train.py")] + common +
+                       ["--num_D", "2", "--fineSize", "128", "--batchSize", "1", "--max_frames_per_gpu", "2", "--niter", "2",
+                        "--add_face_disc", "--synthetic_data"], cwd=work, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "G_GAN" in r.stdout and "D_f" in r.stdout
+    for f in ("latest_net_G0.pth", "latest_net_D.pth", "latest_net_D_f.pth"):
+        assert os.path.exists(os.path.join(work, "checkpoints", "fadg0", f))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "vid2vid", "test.py")] + common +
+                       ["--dataroot", "datasets/fadg0", "--resize_or_crop", "scaleHeight", "--loadSize", "512",
+                        "--how_many", "3", "--random_drop_prob", "0"], cwd=work, env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert len(glob.glob(os.path.join(work, "results", "fadg0", "test_latest", "tmp", "fake_B_*.jpg"))) == 3

@@ -147,3 +147,4 @@ class TrainOptions(BaseOptions):
         g("--niter_step", type=int, default=5)
         g("--niter_fix_global", type=int, default=0)
         g("--add_face_disc", action="store_true")
+        g("--synthetic_data", action="store_true", help="train on seeded synthetic sequences (no dataset needed)")

@@ -339,3 +339,187 @@ def allreduce_gradients(params, bucket_mb=64):
     if bucket:
         nbytes += flush(bucket)
     return nbytes
+
+
+# ------------------------------------------------------------------------------------------------
+# face discriminator crop (--add_face_disc) and the training loop
+# ------------------------------------------------------------------------------------------------
+def get_face_region(pose_map_u8, fine_size):
+    """(ys, ye, xs, xe) of the face crop: centred on the pixels of the nose-neck limb colour
+    [153,0,51] (keypoint2img.py:180) in the uint8 pose map, side fine_size//32*8 (=128 at 512)
+    [RECALL upstream Vid2VidModelD.get_face_region]."""
+    import numpy as np
+    from .keypoints import NOSE_NECK_RGB
+    H, W = pose_map_u8.shape[:2]
+    side = max(8, fine_size // 32 * 8)
+    ys, xs = np.nonzero((pose_map_u8 == np.array(NOSE_NECK_RGB, np.uint8)).all(2))
+    if ys.size:
+        # the limb runs from the nose down to the neck: the face sits around its upper end
+        cy, cx = int(ys.min()), int(xs[ys.argmin()])
+    else:
+        cy, cx = H // 4, W // 2
+    y0 = min(max(cy - side // 2, 0), H - side)
+    x0 = min(max(cx - side // 2, 0), W - side)
+    return y0, y0 + side, x0, x0 + side
+
+
+def discriminator_state_dict(input_nc, ndf, n_layers, num_D, norm, seed):
+    """seeded random init in upstream key names (weights_init: N(0,0.02) convs, N(1,0.02) BN weight)."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    sd = {}
+    for i in range(num_D):
+        nd = min(ndf * 2 ** (num_D - 1 - i), 64)
+        chans = [(input_nc, nd, False)]
+        nf = nd
+        for _ in range(1, n_layers):
+            nf_prev, nf = nf, min(nf * 2, 512)
+            chans.append((nf_prev, nf, True))
+        nf_prev, nf = nf, min(nf * 2, 512)
+        chans += [(nf_prev, nf, True), (nf, 1, False)]
+        for j, (cin, cout, has_norm) in enumerate(chans):
+            pre = "scale%d_layer%d" % (i, j)
+            sd[pre + ".0.weight"] = torch.from_numpy(rng.normal(0, 0.02, (cout, cin, 4, 4)).astype("float32"))
+            b = 1.0 / (cin * 16) ** 0.5
+            sd[pre + ".0.bias"] = torch.from_numpy(rng.uniform(-b, b, (cout,)).astype("float32"))
+            if has_norm and norm == "batch":
+                sd[pre + ".1.weight"] = torch.from_numpy(rng.normal(1, 0.02, (cout,)).astype("float32"))
+                sd[pre + ".1.bias"] = torch.zeros(cout)
+    return sd
+
+
+class Vid2VidTrainer:
+    """One rank of the data-parallel train step: 1 sequence per GPU, `max_frames_per_gpu`
+    frames per chunk, previous frames detached (max_frames_backpropagate 1)."""
+
+    def __init__(self, opt, device="cuda:0", seed=1):
+        self.opt, self.device = opt, device
+        input_nc = opt.label_nc if opt.label_nc != 0 else opt.input_nc
+        self.spec = GeneratorSpec(input_nc=input_nc * opt.n_frames_G, prev_nc=(opt.n_frames_G - 1) * opt.output_nc,
+                                  ngf=opt.ngf, n_downsample=opt.n_downsample_G, n_blocks=opt.n_blocks, no_flow=True,
+                                  norm=opt.norm)
+        if not opt.no_flow:
+            raise NotImplementedError("train step covers the --openpose_only / --no_flow generator; the flow branch "
+                                      "needs FlowNet2 ground truth that is not in the reference tree")
+        self.G = TrainableGenerator(self.spec, synthetic_state_dict(self.spec, seed, "vid2vid"), device)
+        d_in = input_nc + opt.output_nc
+        self.D = TrainableDiscriminator(d_in, discriminator_state_dict(d_in, opt.ndf, opt.n_layers_D, opt.num_D, opt.norm,
+                                                                       seed + 1), opt.ndf, opt.n_layers_D, opt.num_D,
+                                        opt.norm, device)
+        self.Df = None
+        if opt.add_face_disc:
+            nf = max(1, opt.num_D - 2)
+            self.Df = TrainableDiscriminator(d_in, discriminator_state_dict(d_in, opt.ndf, opt.n_layers_D, nf, opt.norm,
+                                                                            seed + 2), opt.ndf, opt.n_layers_D, nf,
+                                             opt.norm, device)
+        d_params = list(self.D.parameters()) + (list(self.Df.parameters()) if self.Df else [])
+        self.optG = FusedAdam(self.G.parameters(), opt.lr, (opt.beta1, 0.999))
+        self.optD = FusedAdam(d_params, opt.lr, (opt.beta1, 0.999))
+        self.comm_bytes = 0
+
+    def _d_input(self, A3, img4):
+        z = torch.zeros(A3.shape[:-1] + (2,), dtype=torch.float32, device=A3.device)
+        return torch.cat([A3, img4[..., :3], z], -1).contiguous()
+
+    def train_step(self, pose, real, face_boxes=None, prev=None):
+        """pose [F,H,W,12] (sliding windows), real [F,H,W,4] NHWC on the device; face_boxes: list of
+        (ys,ye,xs,xe) per frame.  Returns dict of scalar losses."""
+        opt, dev = self.opt, pose.device
+        F_, H, W = pose.shape[0], pose.shape[1], pose.shape[2]
+        if prev is None:
+            prev = torch.zeros(1, H, W, ops.round_up(self.spec.prev_nc, 4), dtype=torch.float32, device=dev)
+        fakes = []
+        for f in range(F_):
+            fk = self.G(pose[f:f + 1], prev)
+            fakes.append(fk)
+            nprev = torch.zeros_like(prev)
+            nprev[..., :3] = prev[..., 3:6]
+            nprev[..., 3:6] = fk.detach()[..., :3]
+            prev = nprev
+        fake = torch.cat(fakes, 0)
+        A3 = pose[..., 6:9]
+        pr = self.D(self._d_input(A3, real))
+        pfd = self.D(self._d_input(A3, fake.detach()))
+        loss_D = 0.5 * (gan_loss(pfd, False) + gan_loss(pr, True))
+        pfg = self.D(self._d_input(A3, fake))
+        loss_G_gan = gan_loss(pfg, True)
+        loss_G_fm = feature_matching_loss(pfg, pr, opt.n_layers_D, opt.lambda_feat) if not opt.no_ganFeat else 0.0
+        loss_G = loss_G_gan + loss_G_fm
+        def _f(t):
+            return float(t.detach()) if torch.is_tensor(t) else float(t)
+
+        losses = {"G_GAN": _f(loss_G_gan), "G_GAN_Feat": _f(loss_G_fm), "D": _f(loss_D)}
+        if self.Df is not None and face_boxes is not None:
+            def crop(t):
+                return torch.stack([t[i, b[0]:b[1], b[2]:b[3]] for i, b in enumerate(face_boxes)]).contiguous()
+            fr = self.Df(self._d_input(crop(A3), crop(real)))
+            ffd = self.Df(self._d_input(crop(A3), crop(fake.detach())))
+            loss_Df = 0.5 * (gan_loss(ffd, False) + gan_loss(fr, True))
+            ffg = self.Df(self._d_input(crop(A3), crop(fake)))
+            lg = gan_loss(ffg, True)
+            lf = feature_matching_loss(ffg, fr, opt.n_layers_D, opt.lambda_feat) if not opt.no_ganFeat else 0.0
+            loss_G = loss_G + lg + lf
+            loss_D = loss_D + loss_Df
+            losses.update({"G_f_GAN": _f(lg), "G_f_GAN_Feat": _f(lf), "D_f": _f(loss_Df)})
+        g_params = list(self.G.parameters())
+        d_params = self.optD.params
+        gG = torch.autograd.grad(loss_G, g_params, retain_graph=True, allow_unused=True)
+        gD = torch.autograd.grad(loss_D, d_params, allow_unused=True)
+        for p, g in zip(g_params, gG):
+            p.grad = g
+        for p, g in zip(d_params, gD):
+            p.grad = g
+        self.comm_bytes = allreduce_gradients(g_params) + allreduce_gradients(d_params)
+        self.optG.step()
+        self.optD.step()
+        return losses, prev
+
+    def save(self, epoch_label):
+        import os
+        d = os.path.join(self.opt.checkpoints_dir, self.opt.name)
+        os.makedirs(d, exist_ok=True)
+        torch.save({k: v.detach().cpu() for k, v in self.G.named_upstream_parameters().items()},
+                   os.path.join(d, "%s_net_G0.pth" % epoch_label))
+        torch.save({k: v.detach().cpu() for k, v in self.D.named_upstream_parameters().items()},
+                   os.path.join(d, "%s_net_D.pth" % epoch_label))
+        if self.Df is not None:
+            torch.save({k: v.detach().cpu() for k, v in self.Df.named_upstream_parameters().items()},
+                       os.path.join(d, "%s_net_D_f.pth" % epoch_label))
+
+
+def run_train(opt, steps=None):
+    """train.py main: one process per GPU under torchrun (the reference used nn.DataParallel threads)."""
+    import os
+    import time
+    import numpy as np
+    from . import distributed as Dm
+    rank, local_rank, world = Dm.init_from_env() if "WORLD_SIZE" in os.environ else (0, 0, 1)
+    dev = "cuda:%d" % local_rank
+    torch.cuda.set_device(local_rank)
+    trainer = Vid2VidTrainer(opt, dev)
+    if not getattr(opt, "synthetic_data", False):
+        raise NotImplementedError("training data loader for real datasets is not built yet (round 2); "
+                                  "pass --synthetic_data to run the train step on synthetic sequences")
+    H = W = opt.fineSize
+    F_ = opt.max_frames_per_gpu
+    rng = np.random.default_rng(100 + rank)          # every rank has its own sequence (batchSize = world)
+    steps = steps if steps is not None else opt.niter
+    t0, stats = time.perf_counter(), []
+    for it in range(steps):
+        pose_np = np.where(rng.random((F_, H, W, 1)) < 0.02, rng.uniform(-1, 1, (F_, H, W, 9)), -1.0).astype(np.float32)
+        pose = torch.zeros(F_, H, W, 12, device=dev)
+        pose[..., :9] = torch.from_numpy(pose_np).to(dev)
+        real = torch.zeros(F_, H, W, 4, device=dev)
+        real[..., :3] = torch.tanh(torch.from_numpy(rng.standard_normal((F_, H, W, 3)).astype(np.float32))).to(dev)
+        side = max(8, opt.fineSize // 32 * 8)
+        boxes = [(H // 8, H // 8 + side, (W - side) // 2, (W - side) // 2 + side)] * F_ if opt.add_face_disc else None
+        ts = time.perf_counter()
+        losses, _ = trainer.train_step(pose, real, boxes)
+        torch.cuda.synchronize()
+        stats.append(time.perf_counter() - ts)
+        if rank == 0 and (it % max(1, opt.print_freq // 100) == 0 or it == steps - 1):
+            print("(iter %d, %.0f ms, all-reduce %.1f MB) %s" % (it, 1e3 * stats[-1], trainer.comm_bytes / 2**20,
+                                                                 " ".join("%s: %.3f" % kv for kv in losses.items())), flush=True)
+    if rank == 0:
+        trainer.save("latest")
+    return {"ms_per_step": 1e3 * float(np.median(stats)), "steps": steps, "world": world}

@@ -1,0 +1,26 @@
+#!/usr/bin/env python
+"""Drop-in for `../vid2vid/train.py` with the reference's flag surface (README.md:171-176):
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 train.py \
+        --name pose2body_512p --dataroot datasets/pose --dataset_mode pose --input_nc 3 --num_D 2 \
+        --resize_or_crop randomScaleHeight_and_scaledCrop --loadSize 544 --fineSize 512 --batchSize 8 \
+        --max_frames_per_gpu 2 --niter 500 --niter_decay 5 --no_first_img --n_frames_total 12 --max_t_step 4 \
+        --add_face_disc --openpose_only --synthetic_data
+
+One process per GPU (the reference used nn.DataParallel over --gpu_ids; here every rank owns one
+sequence of the batch and gradients are all-reduced over RCCL).  Round 1 builds the train STEP
+(generator, multiscale + face discriminators, LSGAN + feature matching, Adam) on synthetic sequences;
+the real-data loader, VGG and FlowNet2 losses are not built.
+"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from text2video_amd.options import TrainOptions  # noqa: E402
+from text2video_amd.train import run_train       # noqa: E402
+
+if __name__ == "__main__":
+    opt = TrainOptions().parse(save=False)
+    stats = run_train(opt)
+    print("done: %d steps, median %.1f ms/step on %d GPU(s)" % (stats["steps"], stats["ms_per_step"], stats["world"]))
