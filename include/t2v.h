@@ -140,7 +140,8 @@ int t2v_conv2d_backward_weight(t2v_ctx* ctx, void* stream, const t2v_conv_desc* 
                                float* workspace /* NULL when ..._workspace_floats() == 0 */);
 int t2v_conv_unpack_weight(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, int x_cs, const float* packed_dev,
                            float* w_torch_dev);
-int t2v_channel_sum(t2v_ctx* ctx, void* stream, const float* x, long npix, int C, int cs, float* out);
+int t2v_channel_sum(t2v_ctx* ctx, void* stream, const float* x, long npix, int C, int cs,
+                    float* scratch /* >= 256*C floats */, float* out);
 /* adjoint of ReflectionPad2d(pad): dxp [H+2pad][W+2pad][C] -> dx [H][W][C]  (SpatialReflectionPadding_updateGradInput) */
 int t2v_reflect_pad_backward(t2v_ctx* ctx, void* stream, const float* dxp, float* dx, int H, int W, int C, int pad);
 /* BatchNormalization_backward(train) / instance norm backward fused with the activation derivative:

@@ -1,0 +1,92 @@
+"""CPU edge cases of the host side: empty / short sequences, how_many, unusual JSON content."""
+import json
+import os
+import shutil
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+REF_CMD = ("--name fadg0 --dataroot %s --dataset_mode pose --input_nc 3 --resize_or_crop scaleHeight --loadSize 512 "
+           "--openpose_only --how_many 1200 --no_first_img --random_drop_prob 0")
+
+
+def _opt(dataroot, extra=()):
+    from text2video_amd.options import TestOptions
+    return TestOptions().parse((REF_CMD % dataroot).split() + list(extra))
+
+
+def _mk(tmp, seqs):
+    """seqs: {name: n_frames}; frames are copies of a fixture JSON"""
+    src = os.path.join(GOLD, "keypoints_fadg0", "sa1_000_keypoints.json")
+    for name, n in seqs.items():
+        d = os.path.join(tmp, "test_openpose", name)
+        os.makedirs(d)
+        for i in range(n):
+            shutil.copyfile(src, os.path.join(d, "%05d.json" % i))
+    return tmp
+
+
+def test_missing_dataroot_and_empty_sequences(tmp_path):
+    from text2video_amd.pose_dataset import PoseDataset
+    with pytest.raises(FileNotFoundError):
+        PoseDataset(_opt(str(tmp_path / "nope")))
+    root = _mk(str(tmp_path / "a"), {"empty": 0, "short": 2, "ok": 3})
+    ds = PoseDataset(_opt(root, ["--fast_pose"]))
+    # `empty` has no files (ignored), `short` has fewer pose maps than n_frames_G (no output), `ok` yields 1 frame
+    assert len(ds) == 1 and ds[0]["seq"] == "ok" and ds[0]["change_seq"]
+    assert ds.seq_lengths() == {"ok": 3, "short": 2}
+    assert len(list(ds.iter_prefetch(workers=1))) == 1
+    assert list(ds.iter_prefetch(workers=2, limit=0)) == []
+
+
+def test_mismatched_image_count_is_an_error(tmp_path):
+    from PIL import Image
+    from text2video_amd.pose_dataset import PoseDataset
+    root = _mk(str(tmp_path / "b"), {"s": 4})
+    os.makedirs(os.path.join(root, "test_img", "s"))
+    for i in range(3):   # one image short
+        Image.new("RGB", (512, 384)).save(os.path.join(root, "test_img", "s", "%04d.jpg" % i))
+    with pytest.raises(ValueError, match="4 pose files vs 3 images"):
+        PoseDataset(_opt(root))
+
+
+def test_rasteriser_degenerate_json(tmp_path):
+    """no people / zero-confidence people / coincident points produce a black (or partial) map, never an error"""
+    from text2video_amd.keypoints import read_keypoints
+    p = str(tmp_path / "k.json")
+    json.dump({"people": []}, open(p, "w"))
+    assert read_keypoints(p, (64, 48)).sum() == 0
+    person = {"pose_keypoints_2d": [0.0] * 75, "face_keypoints_2d": [0.0] * 210, "hand_left_keypoints_2d": [],
+              "hand_right_keypoints_2d": []}
+    json.dump({"people": [person]}, open(p, "w"))
+    m = read_keypoints(p, (64, 48), hand_discs=False)
+    assert m.shape == (48, 64, 3) and m.sum() == 0
+    # two identical valid points: zero-length segment -> nothing drawn; points off-canvas are clamped
+    person["pose_keypoints_2d"][0:6] = [10.0, 10.0, 0.9, 10.0, 10.0, 0.9]
+    person["pose_keypoints_2d"][6:9] = [500.0, 400.0, 0.9]     # far outside a 64x48 canvas
+    json.dump({"people": [person]}, open(p, "w"))
+    m = read_keypoints(p, (64, 48), hand_discs=False)
+    assert m.shape == (48, 64, 3)
+    # two people accumulate with uint8 wrap-around
+    json.dump({"people": [person, person]}, open(p, "w"))
+    m2 = read_keypoints(p, (64, 48), hand_discs=False)
+    assert np.array_equal(m2, (m.astype(np.uint16) * 2 % 256).astype(np.uint8))
+
+
+def test_chunk_restriction_resets_recurrence(tmp_path):
+    from text2video_amd.distributed import assign_chunks
+    from text2video_amd.pose_dataset import PoseDataset
+    root = _mk(str(tmp_path / "c"), {"only": 9})
+    ds = PoseDataset(_opt(root, ["--fast_pose"]))
+    plan = assign_chunks(ds.seq_lengths(), 2)
+    assert sum(len(p) for p in plan) == 2
+    outs = []
+    for r in range(2):
+        d = PoseDataset(_opt(root, ["--fast_pose"]))
+        d.restrict(plan[r])
+        items = [(it["A_path"], it["change_seq"]) for it in d]
+        assert items[0][1] and not any(c for _, c in items[1:])      # exactly one recurrence reset per chunk
+        outs += [os.path.basename(p) for p, _ in items]
+    assert sorted(outs) == ["%05d.json" % i for i in range(2, 9)]    # every output frame exactly once

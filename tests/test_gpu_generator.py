@@ -159,3 +159,36 @@ def test_fullsize_frame_512_flow_property():
     w = r1["flow_w"][..., 2:3]
     assert (w >= 0).all() and (w <= 1).all() and torch.isfinite(r1["out"]).all()
     assert (r1["raw"][..., :3].abs() <= 1).all()
+
+
+def test_generator_edge_geometries_and_argument_errors():
+    """smallest legal frame (bottleneck 2x2), strongly non-square frames, and the C ABI's refusals."""
+    import ctypes
+    from text2video_amd import _lib
+    from text2video_amd.generator import GeneratorSpec, HipGenerator, _gen_desc, synthetic_state_dict
+    kw = dict(ngf=32, n_downsample=3, n_blocks=2, no_flow=False, norm="batch")
+    for (H, W) in [(16, 16), (16, 72), (72, 16)]:
+        ref, hip = _build(kw, 1)
+        A = _pose_seq(3, H, W, seed=8).unsqueeze(0)
+        want = ref.inference(A)
+        got, _ = hip.inference(A.to("cuda:0"))
+        assert (got.cpu() - want).abs().max().item() <= TOL, (H, W)
+    spec = GeneratorSpec(**kw)
+    net = HipGenerator(spec, "cuda:0")
+    with pytest.raises(RuntimeError, match="before load_state_dict"):
+        net.forward(torch.zeros(16, 16, 12, device="cuda:0"), torch.zeros(16, 16, 8, device="cuda:0"))
+    net.load_state_dict(synthetic_state_dict(spec, 1))
+    with pytest.raises(RuntimeError, match="multiples of 8"):      # H not divisible by 2^n_downsample
+        net.forward(torch.zeros(20, 16, 12, device="cuda:0"), torch.zeros(20, 16, 8, device="cuda:0"))
+    lib = _lib.load()
+    gd = _gen_desc(spec, 8, 8)                                       # bottleneck 1x1: reflection pad impossible
+    assert lib.t2v_generator_workspace_bytes(ctypes.byref(gd)) == 0 and b"too small" in lib.t2v_last_error()
+    # too small a workspace is reported, not written past
+    gd = _gen_desc(spec, 16, 16)
+    io = _lib.GenIO()
+    x = torch.zeros(16, 16, 12, device="cuda:0")
+    io.pose, io.prev, io.out = x.data_ptr(), x.data_ptr(), x.data_ptr()
+    ws = torch.empty(256, dtype=torch.uint8, device="cuda:0")
+    st = lib.t2v_generator_forward(net.ctx.handle, None, ctypes.byref(gd), net._layers, len(net.keys), ctypes.byref(io),
+                                   ctypes.c_void_p(ws.data_ptr()), ws.numel())
+    assert st == -3 and b"workspace" in lib.t2v_last_error()

@@ -322,9 +322,9 @@ int t2v_conv_unpack_weight(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, i
                                       d->kH, d->pad);
 }
 
-int t2v_channel_sum(t2v_ctx* ctx, void* stream, const float* x, long npix, int C, int cs, float* out) {
-    T2V_REQUIRE(ctx && x && out && C > 0 && cs >= C, "channel_sum: bad arguments");
-    return launch_channel_sum((hipStream_t)stream, x, npix, C, cs, out);
+int t2v_channel_sum(t2v_ctx* ctx, void* stream, const float* x, long npix, int C, int cs, float* scratch, float* out) {
+    T2V_REQUIRE(ctx && x && out && scratch && C > 0 && cs >= C, "channel_sum: bad arguments");
+    return launch_channel_sum((hipStream_t)stream, x, npix, C, cs, scratch, out);
 }
 
 int t2v_reflect_pad_backward(t2v_ctx* ctx, void* stream, const float* dxp, float* dx, int H, int W, int C, int pad) {

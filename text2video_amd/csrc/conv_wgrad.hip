@@ -121,28 +121,43 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    __syncthreads();  // B0
-    int buf = 0;
-    for (int kt = 0; kt < nk; ++kt) {
+    // Software pipeline (one MFMA wave per SIMD has nobody to hide its LDS latency): the operands of
+    // pixel pair s+1 are read while the 4 MFMAs of pair s run; the stage barrier sits before the last
+    // pair's MFMAs so the first pair of the next stage is fetched under them.
+    float av[2][2], bv[2][2];
+    auto load_pair = [&](int buf, int s, int set) {
         const float* sY = reinterpret_cast<const float*>(smem + buf * kWgStage);
         const float* sX = sY + kWgPix * 128;
-        // stages past the end were re-fetches of the last stage: contribute once only
+        const int px = 2 * s + kk;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) av[set][i] = sY[px * 128 + wn * 64 + i * 32 + fi];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bv[set][j] = sX[px * 128 + wc * 64 + j * 32 + fi];
+    };
+    __syncthreads();  // B0
+    load_pair(0, 0, 0);
+    int buf = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int nbuf = buf == kWgRing - 1 ? 0 : buf + 1;
 #pragma unroll
         for (int s = 0; s < kWgPix / 2; ++s) {
-            const int px = 2 * s + kk;
-            float a[2], b[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = sY[px * 128 + wn * 64 + i * 32 + fi];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) b[j] = sX[px * 128 + wc * 64 + j * 32 + fi];
+            const int cur = s & 1;
+            __builtin_amdgcn_sched_barrier(0);
+            if (s + 1 < kWgPix / 2) {
+                load_pair(buf, s + 1, cur ^ 1);
+            } else {
+                __syncthreads();  // barrier(kt): slot `buf` fully read, stage kt+1 visible
+                __builtin_amdgcn_sched_barrier(0);
+                load_pair(nbuf, 0, cur ^ 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][i], bv[cur][j], acc[i][j], 0, 0, 0);
         }
-        __syncthreads();  // barrier(kt)
-        buf = buf == kWgRing - 1 ? 0 : buf + 1;
+        buf = nbuf;
     }
 
     // ---- epilogue: D[row n][col c] -> packed dW[n][koff + c]  (koff: position of this tap in K) ----

@@ -544,21 +544,33 @@ int launch_unpack_convT_weight(hipStream_t s, const float* packed, float* w, int
     return T2V_OK;
 }
 
-// per-channel sum over pixels of an NHWC tensor (bias gradient): deterministic, one block per 64 channels
-__global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ x, long npix, int C, int cs,
-                                                          float* __restrict__ out) {
+// per-channel sum over pixels of an NHWC tensor (bias gradient): deterministic two-level reduction,
+// grid = (C/64, pixel slices) partials + one final pass
+__global__ __launch_bounds__(256) void channel_sum_partial_kernel(const float* __restrict__ x, long npix, int C, int cs,
+                                                                  float* __restrict__ partial) {
     __shared__ float sh[4][64];
     const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl;
     float s = 0.f;
     if (c < C)
-        for (long p = sl; p < npix; p += 4) s += x[p * cs + c];
+        for (long p = (long)blockIdx.y * 4 + sl; p < npix; p += (long)gridDim.y * 4) s += x[p * cs + c];
     sh[sl][cl] = s;
     __syncthreads();
-    if (sl == 0 && c < C) out[c] = (sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl]);
+    if (sl == 0 && c < C) partial[(size_t)blockIdx.y * C + c] = (sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl]);
 }
-int launch_channel_sum(hipStream_t s, const float* x, long npix, int C, int cs, float* out) {
-    hipLaunchKernelGGL(channel_sum_kernel, dim3((C + 63) / 64), dim3(256), 0, s, x, npix, C, cs, out);
+__global__ void channel_sum_final_kernel(const float* __restrict__ partial, int slices, int C, float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int i = 0; i < slices; ++i) s += partial[(size_t)i * C + c];
+    out[c] = s;
+}
+int launch_channel_sum(hipStream_t s, const float* x, long npix, int C, int cs, float* scratch, float* out) {
+    int slices = (int)((npix + 511) / 512);
+    if (slices > 256) slices = 256;
+    if (slices < 1) slices = 1;
+    hipLaunchKernelGGL(channel_sum_partial_kernel, dim3((C + 63) / 64, slices), dim3(256), 0, s, x, npix, C, cs, scratch);
+    hipLaunchKernelGGL(channel_sum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, s, scratch, slices, C, out);
     T2V_HIP_CHECK(hipGetLastError());
     return T2V_OK;
 }

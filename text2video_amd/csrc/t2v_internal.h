@@ -109,7 +109,7 @@ int launch_inorm_backward(hipStream_t s, const float* x, const float* dy, const 
 int launch_act_backward(hipStream_t s, const float* dy, const float* y, int mode, float slope, long n, float* dpre);
 int launch_avgpool3s2_backward(hipStream_t s, const float* dy, float* dx, int H, int W, int C);
 int launch_loss_backward(hipStream_t s, int op, const float* a, const float* b, float c, float scale, long n, float* da);
-int launch_channel_sum(hipStream_t s, const float* x, long npix, int C, int cs, float* out);
+int launch_channel_sum(hipStream_t s, const float* x, long npix, int C, int cs, float* scratch, float* out);
 
 enum ConvTile { kTileL = 0 /*128x128, 32x32x2 MFMA*/, kTileS = 1 /*256x16, 16x16x4 MFMA*/, kTileQ = 2 /*64x64*/ };
 int conv_tile_for(int Cout);

@@ -273,7 +273,9 @@ def channel_sum(x, C=None):
     cs = x.shape[-1]
     C = cs if C is None else C
     out = torch.empty(C, dtype=torch.float32, device=x.device)
-    check(c.lib.t2v_channel_sum(c.handle, _stream(), _p(x), x.numel() // cs, C, cs, _p(out)), "channel_sum")
+    scratch = torch.empty(256 * C, dtype=torch.float32, device=x.device)
+    check(c.lib.t2v_channel_sum(c.handle, _stream(), _p(x), x.numel() // cs, C, cs, _p(scratch), _p(out)),
+          "channel_sum")
     return out
 
 

@@ -89,7 +89,8 @@ class _ConvBlock(torch.autograd.Function):
                 tot = s_i if tot is None else tot + s_i
             if affine:
                 dbeta, dgamma = tot[:, 0].contiguous(), tot[:, 1].contiguous()
-        db = ops.channel_sum(dc, desc.Cout)
+        # a bias in front of a norm layer has an exactly zero gradient (the norm removes the channel mean)
+        db = ops.channel_sum(dc, desc.Cout) if norm is None else torch.zeros(desc.Cout, dtype=torch.float32, device=x.device)
         dwp = ops.conv2d_backward_weight(x, dc, fdesc)
         dw = ops.unpack_conv_weight(dwp, fdesc, x.shape[-1])
         dx = None
