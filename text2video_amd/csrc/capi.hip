@@ -142,6 +142,19 @@ int run_conv(t2v_ctx* ctx, hipStream_t s, const ConvPlan& pl, const float* x, co
     T2V_REQUIRE(ctx && x && w && y, "conv: null pointer");
     T2V_REQUIRE(y_cs >= pl.kp.Cout && y_cs <= pl.Cout_p, "conv: output channel storage %d out of range [%d,%d]", y_cs,
                 pl.kp.Cout, pl.Cout_p);
+    {
+        // the generator heads: dedicated halo-tile kernel (conv_head.hip)
+        static const int use_head = getenv("T2V_CONV_HEAD") ? atoi(getenv("T2V_CONV_HEAD")) : 1;
+        const ConvKParams& q = pl.kp;
+        if (use_head && !stats && q.nphases == 1 && q.ph[0].ntaps == 49 && q.KW == 7 && q.pad == 3 && q.stride == 1 &&
+            q.pad_mode == T2V_PAD_REFLECT && q.Cout <= 3 && q.Cin_s % 16 == 0 && q.Hin >= 4 && q.Win >= 4) {
+            HeadParams h;
+            h.x = x; h.w = w; h.bias = bias; h.y = y;
+            h.H = q.Hin; h.W = q.Win; h.Cin_s = q.Cin_s; h.Kp = q.ph[0].Kp; h.Cout = q.Cout; h.Cout_s = y_cs;
+            h.act = q.act; h.act_scale = q.act_scale;
+            return launch_conv_head7x7(s, h);
+        }
+    }
     ConvKParams k = pl.kp;
     k.x = x;
     k.w = w;

@@ -1,0 +1,134 @@
+// conv_head.hip -- the generator's 7x7 heads (ReflectionPad2d(3) + Conv2d(C, <=4, 7) + tanh | flow*20,sigmoid)
+// on gfx950.  SURVEY.md section 8a rows a5/a10.
+//
+// Why not the implicit-GEMM kernel: with 3 output channels an MFMA tile is >= 80 % padding, and the
+// 49-tap gather re-reads every input pixel 49 times through L2 (6.6 GB at 512x512, the measured
+// bound of the MFMA version: 0.5 ms = 19 TFLOP/s).  This kernel is shaped by the data instead:
+//   * one block = a 16x16 pixel tile, one thread per pixel, 3 fp32 accumulators per thread;
+//   * the 22x22 input halo of the tile is staged ONCE per 16-channel chunk into LDS (LDS-DMA, buffer
+//     addressing: per-lane halo offsets with reflection are computed once per block, the chunk is an
+//     SGPR soffset) and reused by all 49 taps: L2 traffic 1.9x the input instead of 49x;
+//   * LDS image is [4-channel group][halo pixel] so a wave's ds_read_b128 of one tap is contiguous;
+//   * weights are wave-uniform: they stream through SGPRs (s_load from the SAME packed [Cout_p][Kp]
+//     matrix the MFMA kernels use) and feed v_fmac directly -- no LDS or VGPR traffic for B;
+//   * single-buffered 32 KiB halo => 4 blocks (16 waves) per CU: while one block stages its next chunk
+//     the others compute -- thread-level parallelism hides DMA, scalar-load and LDS latency, and the
+//     tap loop stays rolled (48 live weight scalars; a fully unrolled row spilled SGPRs).
+// Bound: fp32 VALU (12 FMAs per ds_read_b128), 9.87 GFLOP per 512x512 launch.
+#include "t2v_internal.h"
+
+namespace t2v {
+
+__device__ __forceinline__ void hd_dma16(const float* base, int nbytes, char* lds_dst, int voff, int soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, nbytes, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (__attribute__((address_space(3))) void*)lds_dst, 16, voff, soff, 0, 0);
+#endif
+}
+
+constexpr int kHdTile = 16;                 // 16 x 16 output pixels per block
+constexpr int kHdHalo = kHdTile + 6;        // 22
+constexpr int kHdPlane = 512 * 16;          // bytes of one 4-channel plane (484 halo pixels, padded to 8 DMA instr)
+constexpr int kHdBuf = 4 * kHdPlane;        // 16 channels
+constexpr int kHdLds = kHdBuf;
+
+__global__ __launch_bounds__(256) void conv_head7x7_kernel(const HeadParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // also the 4-channel group this wave stages
+    const int tx = tid & 15, ty = tid >> 4;
+    const int x0 = blockIdx.x * kHdTile, y0 = blockIdx.y * kHdTile;
+
+    // halo pixel -> byte offset in x (reflection resolved once per block)
+    int voff[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int hp = i * 64 + lane;
+        const int hy = hp / kHdHalo, hx = hp - hy * kHdHalo;
+        int gy = y0 - 3 + hy, gx = x0 - 3 + hx;
+        gy = gy < 0 ? -gy : gy;
+        gx = gx < 0 ? -gx : gx;
+        gy = min(gy, 2 * p.H - 2 - gy);
+        gx = min(gx, 2 * p.W - 2 - gx);
+        gy = max(gy, 0);      // tiles hanging over the bottom/right edge: any valid pixel (their outputs are masked)
+        gx = max(gx, 0);
+        voff[i] = hp < kHdHalo * kHdHalo ? ((gy * p.W + gx) * p.Cin_s + wave * 4) * 4 : 0x7fff0000;
+    }
+    const int x_bytes = p.H * p.W * p.Cin_s * 4;
+    auto stage = [&](int chunk, int buf) {
+        char* dst = smem + buf * kHdBuf + wave * kHdPlane;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) hd_dma16(p.x, x_bytes, dst + i * 1024, voff[i], chunk * 64);
+    };
+
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;
+    const int nchunks = p.Cin_s >> 4;
+    const float* __restrict__ w0 = p.w;                 // row 0 of the packed [Cout_p][Kp] weight
+    const float* __restrict__ w1 = p.w + p.Kp;
+    const float* __restrict__ w2 = p.w + 2 * p.Kp;
+    const int lbase = (ty * kHdHalo + tx) * 16;
+
+    const char* sb = smem + lbase;
+    for (int ch = 0; ch < nchunks; ++ch) {
+        stage(ch, 0);
+        __syncthreads();   // chunk landed (the barrier's fence drains vmcnt)
+        for (int kh = 0; kh < 7; ++kh) {
+#pragma unroll 1
+            for (int kw = 0; kw < 7; ++kw) {
+                const int kofs = (kh * 7 + kw) * p.Cin_s + ch * 16;   // wave-uniform: scalar loads below
+                const char* st = sb + (kh * kHdHalo + kw) * 16;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 xv = *reinterpret_cast<const float4*>(st + q * kHdPlane);
+                    const float4 a = *reinterpret_cast<const float4*>(w0 + kofs + q * 4);
+                    const float4 b = *reinterpret_cast<const float4*>(w1 + kofs + q * 4);
+                    const float4 c = *reinterpret_cast<const float4*>(w2 + kofs + q * 4);
+                    acc0 = fmaf(xv.x, a.x, acc0); acc0 = fmaf(xv.y, a.y, acc0); acc0 = fmaf(xv.z, a.z, acc0); acc0 = fmaf(xv.w, a.w, acc0);
+                    acc1 = fmaf(xv.x, b.x, acc1); acc1 = fmaf(xv.y, b.y, acc1); acc1 = fmaf(xv.z, b.z, acc1); acc1 = fmaf(xv.w, b.w, acc1);
+                    acc2 = fmaf(xv.x, c.x, acc2); acc2 = fmaf(xv.y, c.y, acc2); acc2 = fmaf(xv.z, c.z, acc2); acc2 = fmaf(xv.w, c.w, acc2);
+                }
+            }
+        }
+        __syncthreads();   // everyone is done with the halo before the next chunk overwrites it
+    }
+
+    const int oy = y0 + ty, ox = x0 + tx;
+    if (oy < p.H && ox < p.W) {
+        float v0 = acc0 + (p.bias ? p.bias[0] : 0.f);
+        float v1 = acc1 + (p.bias && p.Cout > 1 ? p.bias[1] : 0.f);
+        float v2 = acc2 + (p.bias && p.Cout > 2 ? p.bias[2] : 0.f);
+        if (p.act == T2V_ACT_TANH) {
+            v0 = tanhf(v0); v1 = tanhf(v1); v2 = tanhf(v2);
+        } else if (p.act == T2V_ACT_FLOW_W) {
+            v0 *= p.act_scale; v1 *= p.act_scale; v2 = 1.f / (1.f + expf(-v2));
+        } else if (p.act == T2V_ACT_LRELU) {
+            v0 = v0 > 0.f ? v0 : v0 * p.act_scale; v1 = v1 > 0.f ? v1 : v1 * p.act_scale; v2 = v2 > 0.f ? v2 : v2 * p.act_scale;
+        }
+        if (p.Cout < 2) v1 = 0.f;
+        if (p.Cout < 3) v2 = 0.f;
+        float* dst = p.y + (size_t)(oy * p.W + ox) * p.Cout_s;
+        if (p.Cout_s == 4) {
+            *reinterpret_cast<float4*>(dst) = make_float4(v0, v1, v2, 0.f);
+        } else {
+            dst[0] = v0;
+            if (p.Cout_s > 1) dst[1] = v1;
+            if (p.Cout_s > 2) dst[2] = v2;
+            for (int c = 3; c < p.Cout_s; ++c) dst[c] = 0.f;
+        }
+    }
+}
+
+int launch_conv_head7x7(hipStream_t s, const HeadParams& p) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        T2V_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_head7x7_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, kHdLds));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(conv_head7x7_kernel, dim3((p.W + kHdTile - 1) / kHdTile, (p.H + kHdTile - 1) / kHdTile), dim3(256),
+                       kHdLds, s, p);
+    T2V_HIP_CHECK(hipGetLastError());
+    return T2V_OK;
+}
+
+}  // namespace t2v

@@ -111,6 +111,17 @@ int launch_avgpool3s2_backward(hipStream_t s, const float* dy, float* dx, int H,
 int launch_loss_backward(hipStream_t s, int op, const float* a, const float* b, float c, float scale, long n, float* da);
 int launch_channel_sum(hipStream_t s, const float* x, long npix, int C, int cs, float* scratch, float* out);
 
+// 7x7 reflect-padded head convolution with <= 3 output channels (conv_head.hip)
+struct HeadParams {
+    const float* x;
+    const float* w;      // the packed [Cout_p][Kp] weight of the implicit-GEMM kernels (rows 0..2 used)
+    const float* bias;
+    float* y;
+    int H, W, Cin_s, Kp, Cout, Cout_s, act;
+    float act_scale;
+};
+int launch_conv_head7x7(hipStream_t s, const HeadParams& p);
+
 enum ConvTile { kTileL = 0 /*128x128, 32x32x2 MFMA*/, kTileS = 1 /*256x16, 16x16x4 MFMA*/, kTileQ = 2 /*64x64*/ };
 int conv_tile_for(int Cout);
 void conv_tile_dims(int tile, int* BM, int* BN);
