@@ -11,8 +11,7 @@
  *     channel *storage* stride (a multiple of 4 >= the logical channel count; extra channels
  *     must hold finite values and are ignored / written as zero).
  *   - ownership: the caller allocates every device buffer (tensors, packed weights, workspace)
- *     and keeps it alive until the stream has drained.  The library allocates nothing after
- *     t2v_create() (which owns one 4 KiB zero page).
+ *     and keeps it alive until the stream has drained.  The library never allocates device memory.
  *   - asynchronous: work is enqueued on the hipStream_t passed as `void* stream`
  *     (torch.cuda.current_stream().cuda_stream on the Python side); nothing synchronises.
  *   - errors: every call returns T2V_OK (0) or a negative t2v_status; t2v_last_error() returns a

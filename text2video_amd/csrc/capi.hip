@@ -162,7 +162,6 @@ int run_conv(t2v_ctx* ctx, hipStream_t s, const ConvPlan& pl, const float* x, co
     k.y = y;
     k.Cout_s = y_cs;
     k.stats = stats;
-    k.zero = ctx->zero_page;
     return launch_conv_igemm(s, k, pl.tile);
 }
 
@@ -187,21 +186,12 @@ int t2v_create(t2v_ctx** out, int device) {
                 "libt2v_hip is built for gfx950 (MI355X) only; device %d is %s", device, prop.gcnArchName);
     t2v_ctx* c = new t2v_ctx();
     c->device = device;
-    c->zero_page = nullptr;
-    hipError_t e = hipMalloc(&c->zero_page, 4096);
-    if (e == hipSuccess) e = hipMemset(c->zero_page, 0, 4096);
-    if (e != hipSuccess) {
-        set_error("t2v_create: zero page: %s", hipGetErrorString(e));
-        delete c;
-        return T2V_ERR_HIP;
-    }
     *out = c;
     return T2V_OK;
 }
 
 int t2v_destroy(t2v_ctx* ctx) {
     if (!ctx) return T2V_OK;
-    if (ctx->zero_page) (void)hipFree(ctx->zero_page);
     delete ctx;
     return T2V_OK;
 }

@@ -9,15 +9,16 @@
 //     (32 floats = 128 B) is one contiguous, coalesced 128-byte run of the input.
 //   * Operands go HBM/L2 -> LDS with the gfx950 LDS-DMA (global_load_lds_dwordx4): no VGPR
 //     round trip, no ds_write pass.  Reflection / zero padding and ragged edges are resolved in
-//     the per-lane SOURCE address (out-of-range -> a zero page); the im2col matrix never exists.
+//     the per-lane SOURCE offset of a buffer load (out-of-range lanes are zero-filled by the
+//     hardware); the im2col matrix never exists.
 //   * LDS image is lane-linear (DMA constraint); the 16-byte slot a lane fetches is XOR-swizzled
 //     on the source side, (row>>1)&7, and un-swizzled on the ds_read_b128 side, so fragment reads
 //     are bank-conflict free (cdna_hip_programming.md rule 21 / T2).
 //   * Exact fp32 on the matrix cores: v_mfma_f32_32x32x2_f32 (big layers) / 16x16x4 (3-channel
 //     heads).  One ds_read_b128 feeds 4 MFMAs: the k-order inside a stage is permuted
 //     identically for A and B, which only reorders the fp32 summation.
-//   * 128x128 block tile, 4 waves (one per SIMD) each 64x64 => 64 accumulator VGPRs, 2-stage LDS
-//     ring, one barrier per 32-deep K stage (4096 MFMA cycles per stage per wave).
+//   * 128x128 block tile; 4 MFMA waves (one per SIMD, 64x64 each => 64 accumulator VGPRs) + 4 loader
+//     waves; 3-slot LDS ring with counted vmcnt, one barrier per 32-deep K stage (4096 MFMA cycles).
 //   * Epilogue fuses bias, the head activations (tanh | flow*20 + sigmoid) and the instance-norm
 //     partial statistics (per block: mean and M2 over its pixels, two-pass in registers) so the
 //     norm never re-reads the activation to compute statistics.
@@ -78,11 +79,6 @@ __device__ __forceinline__ void dma16(const float* base, int nbytes, char* lds_d
     const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, nbytes, 0x00020000);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (__attribute__((address_space(3))) void*)lds_dst, 16, voff, soff, 0, 0);
 #endif
-}
-
-__device__ __forceinline__ int reflect_idx(int i, int n) {
-    i = i < 0 ? -i : i;
-    return i >= n ? 2 * n - 2 - i : i;
 }
 
 // MODE 0: Cin_s % 32 == 0 (a stage lies inside one tap; tap offsets read with scalar loads)

@@ -14,8 +14,8 @@
 //   grid       : (Cout/128) x (Cin_s/128) x taps  [x phases for transposed convs]
 //   output     : written straight into the PACKED weight layout [Cout_p][Kp] (K = tap*Cin_s + c), so the
 //                optimiser can run on packed parameters; t2v_conv_unpack_weight converts back.
-// Transposed convolutions reuse this with the roles of the tensors swapped by the caller
-// (dW_T[cin][cout] = sum x[m][cin] * dY[pix][cout]): see build_wgrad_plan in capi.hip.
+// Transposed convolutions are the same reduction per sub-pixel phase: dY is sampled at the phase's
+// strided output positions (ostride / toy / tox), X at the phase taps (t2v_conv2d_backward_weight).
 #include "t2v_internal.h"
 
 namespace t2v {

@@ -64,7 +64,6 @@ struct ConvKParams {
     const float* bias;
     float* y;
     float* stats;  // [nparts][Cout][2] (mean_b, M2_b) or nullptr
-    const float* zero;  // >= 16 bytes of zeros in device memory
     int Hin, Win, Cin_s;
     int Wm, M;
     int Cout, Cout_s, Wout, Hout;
@@ -158,5 +157,4 @@ int launch_copy_channels(hipStream_t s, const float* src, int src_cs, int src_c0
 
 struct t2v_ctx {
     int device;
-    float* zero_page;  // 4 KiB of zeros (owned)
 };
