@@ -264,6 +264,17 @@ static int wgrad_splits(const t2v_conv_desc* d, int x_cs, int batch, const ConvP
     long s = (512 + blocks - 1) / blocks;
     if (s > nk / 8) s = nk / 8;      // at least 8 stages per block
     if (s > 256) s = 256;
+    if (s < 1) s = 1;
+    if (blocks >= 256 && nk >= 64) {
+        // wave quantisation: one block per CU is resident (96 KiB ring), so 576 blocks = 2.25 rounds of the
+        // 256 CUs idle a quarter of the chip; pick the split (<= 4) that fills the last round best
+        double best = 0.0;
+        for (long c = 1; c <= 4; ++c) {
+            const long nb = blocks * c;
+            const double fill = (double)nb / (double)(((nb + 255) / 256) * 256);
+            if (fill > best + 0.02) { best = fill; s = c; }
+        }
+    }
     return s < 1 ? 1 : (int)s;
 }
 
