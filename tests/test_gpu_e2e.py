@@ -77,3 +77,37 @@ def test_train_py_then_test_py_roundtrip(tmp_path):
                        timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert len(glob.glob(os.path.join(work, "results", "fadg0", "test_latest", "tmp", "fake_B_*.jpg"))) == 3
+
+
+def test_fifo_server_serves_requests(tmp_path):
+    """test_fifo.py: model resident, one utterance per line written to the named pipe."""
+    import time
+    work = _make_dataset(str(tmp_path))
+    fifo = os.path.join(str(tmp_path), "t2v.fifo")
+    os.mkfifo(fifo)
+    env = dict(os.environ, CUDA_VISIBLE_DEVICES="0", PYTHONUNBUFFERED="1")
+    cmd = [sys.executable, os.path.join(ROOT, "vid2vid", "test_fifo.py"), "--fifo", fifo, "--name", "fadg0", "--dataroot",
+           "datasets/fadg0", "--dataset_mode", "pose", "--input_nc", "3", "--resize_or_crop", "scaleHeight", "--loadSize",
+           "512", "--openpose_only", "--how_many", "1200", "--no_first_img", "--random_drop_prob", "0",
+           "--synthetic_weights", "1", "--ngf", "32", "--n_blocks", "3"]
+    proc = subprocess.Popen(cmd, cwd=work, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    try:
+        done = os.path.join(work, "results", "fadg0", "test_latest", ".done")
+        for req, expect in (("run", "8"), ("how_many=3", "3")):
+            if os.path.exists(done):
+                os.remove(done)
+            with open(fifo, "w") as fh:          # blocks until the server opens the pipe for reading
+                fh.write(req + "\n")
+            t0 = time.time()
+            while not os.path.exists(done):
+                assert proc.poll() is None, proc.stdout.read()[-2000:]
+                assert time.time() - t0 < 300
+                time.sleep(0.2)
+            time.sleep(0.2)
+            assert open(done).read().strip() == expect
+        with open(fifo, "w") as fh:
+            fh.write("quit\n")
+        assert proc.wait(timeout=60) == 0
+    finally:
+        if proc.poll() is None:
+            proc.kill()
