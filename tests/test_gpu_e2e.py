@@ -111,3 +111,31 @@ def test_fifo_server_serves_requests(tmp_path):
     finally:
         if proc.poll() is None:
             proc.kill()
+
+
+def test_checkpoint_decides_flow_branch_and_legacy_keys(tmp_path):
+    """A checkpoint that carries model_final_flow.* enables the flow-warp compositor even under
+    --openpose_only (the architecture follows the checkpoint); `module.` prefixes and
+    BatchNorm running statistics of old checkpoints are dropped."""
+    import torch
+    from text2video_amd import model as M
+    from text2video_amd.generator import GeneratorSpec, synthetic_state_dict
+    from text2video_amd.options import TestOptions
+    ck = tmp_path / "ckpt" / "p"
+    ck.mkdir(parents=True)
+    spec = GeneratorSpec(ngf=32, n_blocks=2, no_flow=False)
+    sd = {"module." + k: v for k, v in synthetic_state_dict(spec, 1).items()}
+    sd["module.model_down_seg.2.running_mean"] = torch.zeros(32)
+    sd["module.model_down_seg.2.num_batches_tracked"] = torch.tensor(5)
+    torch.save(sd, str(ck / "latest_net_G0.pth"))
+    base = ["--name", "p", "--checkpoints_dir", str(tmp_path / "ckpt"), "--ngf", "32", "--n_blocks", "2", "--openpose_only",
+            "--no_first_img"]
+    m = M.create_model(TestOptions().parse(base))
+    assert m.nets[0].spec.no_flow is False
+    m = M.create_model(TestOptions().parse(base + ["--no_flow"]))       # explicit flag wins
+    assert m.nets[0].spec.no_flow is True
+    spec_nf = GeneratorSpec(ngf=32, n_blocks=2, no_flow=True)
+    torch.save(synthetic_state_dict(spec_nf, 1), str(ck / "latest_net_G0.pth"))
+    m = M.create_model(TestOptions().parse(["--name", "p", "--checkpoints_dir", str(tmp_path / "ckpt"), "--ngf", "32",
+                                            "--n_blocks", "2", "--no_first_img"]))
+    assert m.nets[0].spec.no_flow is True                                # no flow keys -> no flow branch

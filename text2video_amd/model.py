@@ -53,8 +53,14 @@ def create_model(opt, device="cuda:0"):
         path = os.path.join(opt.checkpoints_dir, opt.name, "%s_net_G%d.pth" % (opt.which_epoch, s))
         if os.path.exists(path):
             sd = load_checkpoint(path)
-            if spec.no_flow and any(k.startswith("model_final_flow") for k in sd):
-                print("note: %s holds a flow branch; ignored because of --openpose_only/--no_flow" % path)
+            has_flow = any(k.startswith("model_final_flow") for k in sd)
+            if spec.no_flow and has_flow and not getattr(opt, "no_flow_explicit", False):
+                # the architecture follows the checkpoint: it was trained with the flow branch
+                print("note: %s carries a flow branch -> flow-warp compositor enabled" % path)
+                spec.no_flow = False
+            elif not spec.no_flow and not has_flow:
+                print("note: %s has no flow branch -> running without flow" % path)
+                spec.no_flow = True
         elif opt.synthetic_weights is not None:
             print("warning: %s not found -- using seeded random-init weights (seed %d)" % (path, opt.synthetic_weights))
             sd = synthetic_state_dict(spec, opt.synthetic_weights + s, flow_gain=0.1)

@@ -77,8 +77,11 @@ class BaseOptions:
         opt.gpu_ids = [int(i) for i in str(opt.gpu_ids).split(",") if i.strip() != "" and int(i) >= 0]
         # CUDA_VISIBLE_DEVICES from the reference's shell is honoured by the ROCm runtime as well
         # (HIP reads CUDA_VISIBLE_DEVICES when HIP_VISIBLE_DEVICES is unset): nothing to translate.
+        # upstream very likely forces no_flow for --openpose_only (recollection): treat it as the
+        # default, but let a checkpoint that carries a flow branch override it (create_model)
+        opt.no_flow_explicit = bool(opt.no_flow)
         if opt.openpose_only:
-            opt.no_flow = True   # upstream: `if opt.openpose_only: opt.no_flow = True`
+            opt.no_flow = True
         if save:
             d = os.path.join(opt.checkpoints_dir, opt.name)
             os.makedirs(d, exist_ok=True)
