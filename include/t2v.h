@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define T2V_ABI_VERSION 2
+#define T2V_ABI_VERSION 3
 
 typedef enum {
     T2V_OK = 0,
@@ -43,6 +43,11 @@ enum { T2V_PAD_ZERO = 0, T2V_PAD_REFLECT = 1 };
  * Sigmoid_updateOutput :1098, flow x20 [SURVEY App. A.1]) */
 enum { T2V_ACT_NONE = 0, T2V_ACT_TANH = 1, T2V_ACT_FLOW_W = 2 /* ch0,1: x*20 ; ch2: sigmoid */,
        T2V_ACT_LRELU = 3 /* x>0 ? x : act_scale*x  (LeakyReLU_updateOutput THCUNN.h:220) */ };
+
+/* Convolution algorithm.  WINOGRAD = F(2x2,3x3) in fp32: input transform -> 16 batched GEMMs on the
+ * implicit-GEMM kernel -> output transform fused with bias and the norm statistics (2.25x fewer MFMA
+ * FLOPs).  Only where t2v_conv_winograd_supported() says so; packed weights differ per algorithm. */
+enum { T2V_ALGO_DIRECT = 0, T2V_ALGO_WINOGRAD = 1 };
 
 typedef struct t2v_ctx t2v_ctx;
 
@@ -68,6 +73,7 @@ typedef struct {
     int act;         /* T2V_ACT_* applied after bias */
     float act_scale; /* T2V_ACT_FLOW_W: flow multiplier (20 * 2^scale); T2V_ACT_LRELU: negative slope */
     int output_padding; /* transposed only (0 or 1); the generator's up-convs use 1 */
+    int algo;           /* T2V_ALGO_DIRECT | T2V_ALGO_WINOGRAD (3x3 stride-1 reflect-pad-1 convs only) */
 } t2v_conv_desc;
 
 /* output spatial size */
@@ -85,6 +91,16 @@ size_t t2v_conv_stats_floats(const t2v_conv_desc* d);
 int t2v_conv2d_forward(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, const float* x, int x_cs,
                        const float* w_packed, const float* bias, float* y, int y_cs,
                        float* stats_partial);
+
+/* 1 when `d` (with algo ignored) can run as Winograd: 3x3, stride 1, ReflectionPad 1, Cin % 32 == 0 == x_cs,
+ * Cout % 4 == 0, H and W even, (H/2)*(W/2) a multiple of 128. */
+int t2v_conv_winograd_supported(const t2v_conv_desc* d, int x_cs);
+/* floats of scratch (transformed input V + transformed output M) a Winograd forward needs */
+size_t t2v_conv_winograd_workspace_floats(const t2v_conv_desc* d, int x_cs);
+/* forward with d->algo == T2V_ALGO_WINOGRAD; same contract as t2v_conv2d_forward plus the workspace */
+int t2v_conv2d_forward_winograd(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, const float* x, int x_cs,
+                                const float* w_packed, const float* bias, float* y, int y_cs, float* stats_partial,
+                                float* workspace);
 
 /* ------------------------------------------------------------------------------------------
  * Instance norm (+affine) + ReLU + residual.  Replaces BatchNormalization_updateOutput(train)
@@ -214,6 +230,7 @@ typedef struct {
     int is_local;       /* 0: CompositeGenerator, 1: CompositeLocalGenerator */
     float flow_multiplier; /* 20 * 2^scale */
     float eps;          /* 1e-5 */
+    int conv_algo;      /* 0: Winograd F(2x2,3x3) for the ResnetBlock convs wherever supported; 1: direct only */
 } t2v_gen_desc;
 
 typedef struct {
@@ -237,7 +254,8 @@ typedef struct {
 } t2v_gen_io;
 
 int t2v_generator_num_layers(const t2v_gen_desc* d);
-/* conv descriptor of layer i (what to pack weights with) and its input storage stride */
+/* conv descriptor of layer i (what to pack weights with -- its `algo` depends on d->H, d->W and
+ * d->conv_algo) and its input storage stride */
 int t2v_generator_layer_desc(const t2v_gen_desc* d, int i, t2v_conv_desc* out, int* x_cs);
 size_t t2v_generator_workspace_bytes(const t2v_gen_desc* d);
 int t2v_generator_forward(t2v_ctx* ctx, void* stream, const t2v_gen_desc* d, const t2v_layer* layers,

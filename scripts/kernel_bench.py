@@ -10,11 +10,13 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--shapes", default="rb1024")
 ap.add_argument("--iters", type=int, default=40)
 ap.add_argument("--warmup", type=int, default=80)
+ap.add_argument("--winograd", action="store_true")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 for name in args.shapes.split(","):
     H, W, Cin, Cout, k, st, pad, pm, tr, stats = SHAPES[name]
-    desc = ops.conv_desc(H, W, Cin, Cout, k, st, pad, pm, tr, ops.ACT_TANH if Cout == 3 else ops.ACT_NONE)
+    desc = ops.conv_desc(H, W, Cin, Cout, k, st, pad, pm, tr, ops.ACT_TANH if Cout == 3 else ops.ACT_NONE,
+                         algo=1 if args.winograd else 0)
     xcs = ops.round_up(Cin, 4)
     x = torch.randn(H, W, xcs, device=dev)
     w = torch.randn(*((Cin, Cout, k, k) if tr else (Cout, Cin, k, k)), device=dev) * 0.02
@@ -25,12 +27,14 @@ for name in args.shapes.split(","):
     ycs = Cout if Cout % 4 == 0 else 4
     y = torch.empty(ho, wo, ycs, device=dev)
     flop = 2.0 * k * k * Cin * Cout * (H * W if tr else ho * wo)
+    run = (lambda: ops.conv2d_winograd(x, pw, b, desc, stats=sb, out=y)) if args.winograd else \
+        (lambda: ops.conv2d(x, pw, b, desc, y_cs=ycs, stats=sb, out=y))
     for _ in range(args.warmup):  # clocks ramp over tens of ms: warm up long enough
-        ops.conv2d(x, pw, b, desc, y_cs=ycs, stats=sb, out=y)
+        run()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(args.iters):
-        ops.conv2d(x, pw, b, desc, y_cs=ycs, stats=sb, out=y)
+        run()
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / args.iters
     print("%-8s %8.4f ms  %7.2f GFLOP  %7.2f TFLOP/s" % (name, ms, flop / 1e9, flop / ms / 1e9), flush=True)

@@ -46,7 +46,46 @@ CASES = [
     ("flow_ragged_680like", dict(ngf=32, n_downsample=3, n_blocks=2, no_flow=False, norm="batch"), 1, 64, 88),
     ("two_scale_flow", dict(ngf=64, n_downsample=2, n_blocks=2, no_flow=False, norm="batch"), 2, 64, 64),
     ("two_scale_noflow", dict(ngf=64, n_downsample=2, n_blocks=2, no_flow=True, norm="instance"), 2, 64, 96),
+    # bottleneck 32x16 / 16x32 (128 Winograd tiles): the ResnetBlock convs take the Winograd F(2x2,3x3) path
+    ("winograd_noflow", dict(ngf=16, n_downsample=2, n_blocks=3, no_flow=True, norm="instance"), 1, 128, 64),
+    ("winograd_flow", dict(ngf=16, n_downsample=2, n_blocks=2, no_flow=False, norm="batch"), 1, 64, 128),
 ]
+
+
+def test_winograd_is_selected_and_matches_direct():
+    """t2v_generator_layer_desc reports Winograd for the ResnetBlock convs where the geometry allows, the
+    direct kernel elsewhere / when conv_algo=1; both whole-frame paths agree to fp32 rounding."""
+    import ctypes
+    from text2video_amd import _lib
+    from text2video_amd.generator import GeneratorSpec, HipGenerator, _gen_desc, layer_keys, synthetic_state_dict
+    lib = _lib.load()
+    spec = GeneratorSpec(ngf=16, n_downsample=2, n_blocks=3, no_flow=True, norm="instance")
+    keys = layer_keys(spec)
+
+    def algos(H, W, conv_algo):
+        gd = _gen_desc(spec, H, W, conv_algo)
+        out = []
+        for i in range(len(keys)):
+            cd, xcs = _lib.ConvDesc(), ctypes.c_int()
+            assert lib.t2v_generator_layer_desc(ctypes.byref(gd), i, ctypes.byref(cd), ctypes.byref(xcs)) == 0
+            out.append(cd.algo)
+        return out
+
+    a = algos(128, 64, 0)
+    rb = [i for i, (ck, nk, kind) in enumerate(keys) if ".conv_block" in str(ck)]
+    assert len(rb) >= 6 and [i for i, v in enumerate(a) if v == _lib.ALGO_WINOGRAD] == rb, (a, rb)
+    assert sum(algos(128, 64, 1)) == 0 and sum(algos(64, 64, 0)) == 0
+
+    sd = synthetic_state_dict(spec, 3)
+    pose = _pose_seq(3, 128, 64, seed=2)
+    x = torch.zeros(128, 64, 12, device="cuda:0")
+    x[..., :9] = pose.reshape(9, 128, 64).permute(1, 2, 0).to("cuda:0")
+    prev = torch.rand(128, 64, 8, device="cuda:0") * 2 - 1
+    prev[..., 6:] = 0
+    y_w = HipGenerator(spec, "cuda:0", conv_algo=0).load_state_dict(sd).forward(x, prev)["out"]
+    y_d = HipGenerator(spec, "cuda:0", conv_algo=1).load_state_dict(sd).forward(x, prev)["out"]
+    err = (y_w - y_d).abs().max().item()
+    assert 0 < err <= TOL_FORCED, err
 
 
 TOL_FORCED = 2e-4  # same inputs in, fp32 summation-order differences only (observed ~1e-5)
@@ -185,6 +224,7 @@ def test_generator_edge_geometries_and_argument_errors():
     assert lib.t2v_generator_workspace_bytes(ctypes.byref(gd)) == 0 and b"too small" in lib.t2v_last_error()
     # too small a workspace is reported, not written past
     gd = _gen_desc(spec, 16, 16)
+    net._workspace(16, 16)                                           # packs the weights for this geometry
     io = _lib.GenIO()
     x = torch.zeros(16, 16, 12, device="cuda:0")
     io.pose, io.prev, io.out = x.data_ptr(), x.data_ptr(), x.data_ptr()

@@ -14,21 +14,23 @@ LIB_PATH = os.path.join(_HERE, "lib", "libt2v_hip.so")
 T2V_OK = 0
 PAD_ZERO, PAD_REFLECT = 0, 1
 ACT_NONE, ACT_TANH, ACT_FLOW_W, ACT_LRELU = 0, 1, 2, 3
-ABI_VERSION = 2
+ABI_VERSION = 3
+ALGO_DIRECT, ALGO_WINOGRAD = 0, 1
 
 
 class ConvDesc(Structure):
     """t2v_conv_desc (include/t2v.h)."""
     _fields_ = [("H", c_int), ("W", c_int), ("Cin", c_int), ("Cout", c_int), ("kH", c_int), ("kW", c_int),
                 ("stride", c_int), ("pad", c_int), ("pad_mode", c_int), ("transposed", c_int), ("act", c_int),
-                ("act_scale", c_float), ("output_padding", c_int)]
+                ("act_scale", c_float), ("output_padding", c_int), ("algo", c_int)]
 
 
 class GenDesc(Structure):
     """t2v_gen_desc (include/t2v.h)."""
     _fields_ = [("H", c_int), ("W", c_int), ("input_nc", c_int), ("prev_nc", c_int), ("output_nc", c_int),
                 ("ngf", c_int), ("n_downsample", c_int), ("n_blocks", c_int), ("no_flow", c_int),
-                ("norm_affine", c_int), ("is_local", c_int), ("flow_multiplier", c_float), ("eps", c_float)]
+                ("norm_affine", c_int), ("is_local", c_int), ("flow_multiplier", c_float), ("eps", c_float),
+                ("conv_algo", c_int)]
 
 
 class Layer(Structure):
@@ -55,6 +57,10 @@ SIGNATURES = {
     "t2v_conv_stats_floats": (c_size_t, [POINTER(ConvDesc)]),
     "t2v_conv2d_forward": (c_int, [c_void_p, c_void_p, POINTER(ConvDesc), c_void_p, c_int, c_void_p, c_void_p,
                                    c_void_p, c_int, c_void_p]),
+    "t2v_conv_winograd_supported": (c_int, [POINTER(ConvDesc), c_int]),
+    "t2v_conv_winograd_workspace_floats": (c_size_t, [POINTER(ConvDesc), c_int]),
+    "t2v_conv2d_forward_winograd": (c_int, [c_void_p, c_void_p, POINTER(ConvDesc), c_void_p, c_int, c_void_p, c_void_p,
+                                            c_void_p, c_int, c_void_p, c_void_p]),
     "t2v_instance_norm_finalize": (c_int, [c_void_p, c_void_p, POINTER(ConvDesc), c_void_p, c_float, c_void_p]),
     "t2v_batch_norm_finalize": (c_int, [c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_void_p, c_float, c_void_p]),
     "t2v_conv_backward_weight_workspace_floats": (c_size_t, [POINTER(ConvDesc), c_int, c_int]),

@@ -109,6 +109,8 @@ int build_conv_plan(const t2v_conv_desc* d, int x_cs, bool need_stats, ConvPlan*
         }
         pl.wfloats = (size_t)woff;
     }
+    k.group_mtiles = 1 << 30;
+    k.group_w_stride = 0;
     k.Wm = Wm;
     k.M = Hm * Wm;
     k.Wout = pl.Wout;
@@ -134,6 +136,27 @@ int build_conv_plan(const t2v_conv_desc* d, int x_cs, bool need_stats, ConvPlan*
     T2V_REQUIRE((long)d->H * d->W * x_cs * 4 < 0x7fff0000L, "conv: input tensor too large for 32-bit buffer offsets");
     for (int ph = 0; ph < k.nphases; ++ph)
         T2V_REQUIRE((long)pl.Cout_p * k.ph[ph].Kp * 4 < 0x7fff0000L, "conv: weight too large for 32-bit buffer offsets");
+    return T2V_OK;
+}
+
+bool winograd_supported(const t2v_conv_desc* d, int x_cs) {
+    if (!d || d->transposed || d->kH != 3 || d->kW != 3 || d->stride != 1 || d->pad != 1 || d->pad_mode != T2V_PAD_REFLECT)
+        return false;
+    if (d->Cin % 32 != 0 || x_cs != d->Cin || d->Cout % 4 != 0 || (d->H & 1) || (d->W & 1) || d->H < 2 || d->W < 2) return false;
+    const long T = (long)(d->H / 2) * (d->W / 2);
+    return T % 128 == 0 && d->act == T2V_ACT_NONE;
+}
+
+// the batched GEMM of a Winograd conv as a plan of the implicit-GEMM kernel: a 1x1 conv over a 16 x T image
+int build_winograd_gemm_plan(const t2v_conv_desc* d, ConvPlan* pl) {
+    const int T = (d->H / 2) * (d->W / 2);
+    t2v_conv_desc g;
+    memset(&g, 0, sizeof(g));
+    g.H = 16; g.W = T; g.Cin = d->Cin; g.Cout = d->Cout; g.kH = g.kW = 1; g.stride = 1; g.pad = 0;
+    g.pad_mode = T2V_PAD_ZERO; g.act = T2V_ACT_NONE; g.act_scale = 1.f;
+    T2V_TRY(build_conv_plan(&g, d->Cin, false, pl));
+    pl->kp.group_mtiles = T / pl->BM;               // T % 128 == 0 and BM in {128, 64}
+    pl->kp.group_w_stride = (long)pl->Cout_p * d->Cin;
     return T2V_OK;
 }
 
@@ -207,7 +230,33 @@ int t2v_conv_out_dims(const t2v_conv_desc* d, int* Hout, int* Wout) {
 size_t t2v_conv_packed_weight_floats(const t2v_conv_desc* d, int x_cs) {
     ConvPlan pl;
     if (build_conv_plan(d, x_cs, false, &pl) != T2V_OK) return 0;
+    if (d->algo == T2V_ALGO_WINOGRAD) return winograd_supported(d, x_cs) ? (size_t)16 * pl.Cout_p * x_cs : 0;
     return pl.wfloats;
+}
+
+int t2v_conv_winograd_supported(const t2v_conv_desc* d, int x_cs) { return winograd_supported(d, x_cs) ? 1 : 0; }
+
+size_t t2v_conv_winograd_workspace_floats(const t2v_conv_desc* d, int x_cs) {
+    if (!winograd_supported(d, x_cs)) return 0;
+    const size_t T = (size_t)(d->H / 2) * (d->W / 2);
+    return 16 * T * ((size_t)d->Cin + (size_t)d->Cout);
+}
+
+int t2v_conv2d_forward_winograd(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, const float* x, int x_cs,
+                                const float* w_packed, const float* bias, float* y, int y_cs, float* stats_partial,
+                                float* workspace) {
+    T2V_REQUIRE(ctx && x && w_packed && y && workspace, "winograd forward: null pointer");
+    T2V_REQUIRE(winograd_supported(d, x_cs), "winograd forward: shape not supported (t2v_conv_winograd_supported)");
+    T2V_REQUIRE(y_cs == d->Cout, "winograd forward: output channel storage must equal Cout");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t T = (size_t)(d->H / 2) * (d->W / 2);
+    float* V = workspace;
+    float* Mm = workspace + 16 * T * d->Cin;
+    T2V_TRY(launch_winograd_input(s, x, V, d->H, d->W, d->Cin));
+    ConvPlan pl;
+    T2V_TRY(build_winograd_gemm_plan(d, &pl));
+    T2V_TRY(run_conv(ctx, s, pl, V, w_packed, nullptr, Mm, d->Cout, nullptr));
+    return launch_winograd_output(s, Mm, bias, y, stats_partial, d->H, d->W, d->Cout);
 }
 
 int t2v_conv_pack_weight(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, int x_cs, const float* w_torch_dev,
@@ -216,6 +265,10 @@ int t2v_conv_pack_weight(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, int
     ConvPlan pl;
     T2V_TRY(build_conv_plan(d, x_cs, false, &pl));
     hipStream_t s = (hipStream_t)stream;
+    if (d->algo == T2V_ALGO_WINOGRAD) {
+        T2V_REQUIRE(winograd_supported(d, x_cs), "pack_weight: Winograd not supported for this shape");
+        return launch_winograd_weight(s, w_torch_dev, packed_dev, d->Cout, d->Cin, pl.Cout_p, x_cs);
+    }
     if (!d->transposed)
         return launch_pack_conv_weight(s, w_torch_dev, packed_dev, d->Cout, d->Cin, d->kH, d->kW, x_cs, pl.kp.ph[0].Kp,
                                        pl.Cout_p);
@@ -223,6 +276,7 @@ int t2v_conv_pack_weight(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, int
 }
 
 size_t t2v_conv_stats_floats(const t2v_conv_desc* d) {
+    if (d && d->algo == T2V_ALGO_WINOGRAD) return (size_t)(d->H * d->W / 128) * d->Cout * 2;   // one partial per 128 pixels
     ConvPlan pl;
     if (!d || build_conv_plan(d, round_up(d->Cin, 4), true, &pl) != T2V_OK) return 0;
     return (size_t)pl.nparts * d->Cout * 2;
@@ -230,6 +284,7 @@ size_t t2v_conv_stats_floats(const t2v_conv_desc* d) {
 
 int t2v_conv2d_forward(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, const float* x, int x_cs,
                        const float* w_packed, const float* bias, float* y, int y_cs, float* stats_partial) {
+    T2V_REQUIRE(d && d->algo == T2V_ALGO_DIRECT, "conv2d_forward: use t2v_conv2d_forward_winograd for algo=WINOGRAD");
     ConvPlan pl;
     T2V_TRY(build_conv_plan(d, x_cs, stats_partial != nullptr, &pl));
     return run_conv(ctx, (hipStream_t)stream, pl, x, w_packed, bias, y, y_cs, stats_partial);
@@ -238,6 +293,11 @@ int t2v_conv2d_forward(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, const
 int t2v_instance_norm_finalize(t2v_ctx* ctx, void* stream, const t2v_conv_desc* producer, const float* stats_partial,
                                float eps, float* mean_rstd) {
     T2V_REQUIRE(ctx && stats_partial && mean_rstd, "inorm_finalize: null pointer");
+    if (producer && producer->algo == T2V_ALGO_WINOGRAD) {   // the output transform emits one partial per 128 pixels
+        const int M = producer->H * producer->W;
+        return launch_inorm_finalize((hipStream_t)stream, stats_partial, M / 128, M / 128, 128, M, producer->Cout, eps,
+                                     mean_rstd);
+    }
     ConvPlan pl;
     T2V_TRY(build_conv_plan(producer, round_up(producer ? producer->Cin : 0, 4), true, &pl));
     return launch_inorm_finalize((hipStream_t)stream, stats_partial, pl.nparts, pl.kp.mtiles, pl.BM, pl.kp.M,

@@ -129,7 +129,7 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(const ConvKParams p) {
     const int nt = rem - mt * p.ntiles;
     const int m0 = mt * BM, n0 = nt * BN;
     const ConvPhase ph = p.ph[phase];
-    const float* __restrict__ wbase = p.w + ph.w_off;
+    const float* __restrict__ wbase = p.w + ph.w_off + (long)(mt / p.group_mtiles) * p.group_w_stride;
 
     // ---- loader lane geometry: a wave instruction moves 8 rows x 128 B; lane -> (row, slot) ----
     // Buffer addressing (buffer_load_dwordx4 ... lds): address = SRD base + per-lane voffset + scalar

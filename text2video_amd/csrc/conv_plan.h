@@ -15,6 +15,8 @@ struct ConvPlan {
 };
 
 int build_conv_plan(const t2v_conv_desc* d, int x_cs, bool need_stats, ConvPlan* out);
+bool winograd_supported(const t2v_conv_desc* d, int x_cs);
+int build_winograd_gemm_plan(const t2v_conv_desc* d, ConvPlan* pl);
 int run_conv(t2v_ctx* ctx, hipStream_t s, const ConvPlan& pl, const float* x, const float* w, const float* bias,
              float* y, int y_cs, float* stats);
 

@@ -33,6 +33,7 @@ t2v_conv_desc mk_conv(int H, int W, int Cin, int Cout, int k, int stride, int pa
     d.H = H; d.W = W; d.Cin = Cin; d.Cout = Cout; d.kH = k; d.kW = k; d.stride = stride; d.pad = pad;
     d.pad_mode = pad_mode; d.transposed = transposed; d.act = act; d.act_scale = act_scale;
     d.output_padding = transposed ? 1 : 0;
+    d.algo = T2V_ALGO_DIRECT;
     return d;
 }
 
@@ -53,8 +54,10 @@ void enumerate_layers(const t2v_gen_desc& g, std::vector<LayerSpec>& out) {
     };
     auto rbs = [&](int count) {
         const int C = G << n;
-        for (int i = 0; i < 2 * count; ++i)
-            out.push_back({mk_conv(H >> n, W >> n, C, C, 3, 1, 1, T2V_PAD_REFLECT, 0), C, true});
+        t2v_conv_desc cd = mk_conv(H >> n, W >> n, C, C, 3, 1, 1, T2V_PAD_REFLECT, 0);
+        // the ResnetBlock convs (84 % of the FLOPs) run as Winograd F(2x2,3x3) wherever the geometry allows
+        if (g.conv_algo == 0 && winograd_supported(&cd, C)) cd.algo = T2V_ALGO_WINOGRAD;
+        for (int i = 0; i < 2 * count; ++i) out.push_back({cd, C, true});
     };
     auto ups = [&]() {
         for (int i = 0; i < n; ++i) {
@@ -98,6 +101,7 @@ struct Buffers {
     float *raw, *fw;
     float* stats;
     float* mean_rstd;
+    float* wino;   // Winograd scratch: transformed input V + transformed output M
 };
 
 void plan_buffers(const t2v_gen_desc& g, const std::vector<LayerSpec>& layers, Arena& a, Buffers& b) {
@@ -129,6 +133,13 @@ void plan_buffers(const t2v_gen_desc& g, const std::vector<LayerSpec>& layers, A
     }
     b.stats = a.alloc(max_stats);
     b.mean_rstd = a.alloc((size_t)max_c * 2);
+    size_t max_wino = 0;
+    for (const LayerSpec& L : layers)
+        if (L.cd.algo == T2V_ALGO_WINOGRAD) {
+            const size_t w = (size_t)16 * (L.cd.H / 2) * (L.cd.W / 2) * ((size_t)L.cd.Cin + L.cd.Cout);
+            if (w > max_wino) max_wino = w;
+        }
+    b.wino = max_wino ? a.alloc(max_wino) : nullptr;
 }
 
 struct Runner {
@@ -147,8 +158,22 @@ struct Runner {
         const t2v_layer& w = layers[li];
         ++li;
         ConvPlan pl;
-        T2V_TRY(build_conv_plan(&L.cd, L.x_cs, true, &pl));
         const int Cout = L.cd.Cout;
+        if (L.cd.algo == T2V_ALGO_WINOGRAD) {
+            const int H = L.cd.H, W = L.cd.W, M = H * W;
+            float* V = b.wino;
+            float* Mm = b.wino + (size_t)16 * (H / 2) * (W / 2) * L.cd.Cin;
+            T2V_TRY(launch_winograd_input(s, x, V, H, W, L.cd.Cin));
+            T2V_TRY(build_winograd_gemm_plan(&L.cd, &pl));
+            T2V_TRY(run_conv(ctx, s, pl, V, w.w, nullptr, Mm, Cout, nullptr));
+            T2V_TRY(launch_winograd_output(s, Mm, w.bias, y, b.stats, H, W, Cout));
+            T2V_TRY(launch_inorm_finalize(s, b.stats, M / 128, M / 128, 128, M, Cout, g.eps, b.mean_rstd));
+            const float* gam = g.norm_affine ? w.gamma : nullptr;
+            const float* bet = g.norm_affine ? w.beta : nullptr;
+            if (g.norm_affine) T2V_REQUIRE(gam && bet, "layer %d: norm_affine=1 but gamma/beta missing", li - 1);
+            return launch_inorm_apply(s, y, b.mean_rstd, gam, bet, res1, res2, y, (long)M, Cout, relu);
+        }
+        T2V_TRY(build_conv_plan(&L.cd, L.x_cs, true, &pl));
         T2V_TRY(run_conv(ctx, s, pl, x, w.w, w.bias, y, Cout, b.stats));
         T2V_TRY(launch_inorm_finalize(s, b.stats, pl.nparts, pl.kp.mtiles, pl.BM, pl.kp.M, Cout, g.eps, b.mean_rstd));
         const float* gamma = g.norm_affine ? w.gamma : nullptr;

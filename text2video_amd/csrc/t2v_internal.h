@@ -71,6 +71,8 @@ struct ConvKParams {
     int pad_mode, act;
     float act_scale;  // flow multiplier of T2V_ACT_FLOW_W
     int mtiles, ntiles, nphases;
+    int group_mtiles;     // M tiles per weight group (Winograd: one weight matrix per transform position)
+    long group_w_stride;  // float offset between the groups' weight matrices (0: a single matrix)
     int KW, pad;  // MODE 1 (Cin_s % 32 != 0, regular conv): tap -> (kh,kw) by arithmetic
     ConvPhase ph[kMaxPhases];
     int tdy[kMaxTaps];  // ints: read with scalar loads (uniform index), never a vector load
@@ -108,6 +110,9 @@ int launch_inorm_backward(hipStream_t s, const float* x, const float* dy, const 
 int launch_act_backward(hipStream_t s, const float* dy, const float* y, int mode, float slope, long n, float* dpre);
 int launch_avgpool3s2_backward(hipStream_t s, const float* dy, float* dx, int H, int W, int C);
 int launch_loss_backward(hipStream_t s, int op, const float* a, const float* b, float c, float scale, long n, float* da);
+int launch_winograd_weight(hipStream_t s, const float* w, float* U, int Cout, int Cin, int Cout_p, int Cin_s);
+int launch_winograd_input(hipStream_t s, const float* x, float* V, int H, int W, int C);
+int launch_winograd_output(hipStream_t s, const float* Mm, const float* bias, float* y, float* stats, int H, int W, int N);
 int launch_channel_sum(hipStream_t s, const float* x, long npix, int C, int cs, float* scratch, float* out);
 
 // 7x7 reflect-padded head convolution with <= 3 output channels (conv_head.hip)

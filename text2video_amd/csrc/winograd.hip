@@ -1,0 +1,200 @@
+// winograd.hip -- Winograd F(2x2,3x3) transforms for the ResnetBlock convolutions (3x3, stride 1,
+// ReflectionPad2d(1), C -> C at the bottleneck: 84 % of the generator's FLOPs).  fp32 throughout.
+//
+//   Y = A^T [ sum_c (G g G^T) (.) (B^T d B) ] A        per 2x2 output tile, 4x4 input patch d
+//
+// 16 element-wise products per (tile, cin, cout) instead of 36 multiply-adds: 2.25x less MFMA work.
+// The contraction over cin for each of the 16 transform positions xi is a plain GEMM
+//   M[xi][tile][n] = sum_c V[xi][tile][c] * U[xi][n][c]
+// which runs on the implicit-GEMM kernel unchanged (a 1x1 "conv" over a 16 x T "image" whose weight
+// matrix is selected per group of M tiles, conv_igemm.hip `group_*`).  This file holds the three
+// memory-bound pieces around it:
+//   winograd_weight_kernel : U = G g G^T, packed [16][Cout_p][Cin_s]           (once, at load)
+//   winograd_input_kernel  : V = B^T d B with the reflection padding folded into the patch gather
+//   winograd_output_kernel : y = A^T M A + bias, plus the instance-norm partial statistics
+//                            (mean, M2 per 128 output pixels) that the direct kernel's epilogue emits
+// Layouts: V [16][T][C], M [16][T][N] (T = H/2 * W/2 tiles, channels contiguous) -- both are NHWC
+// tensors of 16*T "pixels", so the GEMM kernel's loader / epilogue need nothing new.
+#include "t2v_internal.h"
+
+namespace t2v {
+
+static inline int wg_grid(long n, int block) {
+    long g = (n + block - 1) / block;
+    if (g > 4096) g = 4096;
+    return g < 1 ? 1 : (int)g;
+}
+
+// U[xi][n][c] = (G g G^T)[xi],  G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
+__global__ void winograd_weight_kernel(const float* __restrict__ w, float* __restrict__ U, int Cout, int Cin, int Cout_p,
+                                       int Cin_s) {
+    const long total = (long)Cout_p * Cin_s;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int n = (int)(i / Cin_s), c = (int)(i - (long)n * Cin_s);
+        float g[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) g[a][b] = (n < Cout && c < Cin) ? w[(((size_t)n * Cin + c) * 3 + a) * 3 + b] : 0.f;
+        float t[4][3];
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            t[0][b] = g[0][b];
+            t[1][b] = 0.5f * (g[0][b] + g[1][b] + g[2][b]);
+            t[2][b] = 0.5f * (g[0][b] - g[1][b] + g[2][b]);
+            t[3][b] = g[2][b];
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const float u0 = t[a][0], u1 = 0.5f * (t[a][0] + t[a][1] + t[a][2]), u2 = 0.5f * (t[a][0] - t[a][1] + t[a][2]),
+                        u3 = t[a][2];
+            U[((size_t)(a * 4 + 0) * Cout_p + n) * Cin_s + c] = u0;
+            U[((size_t)(a * 4 + 1) * Cout_p + n) * Cin_s + c] = u1;
+            U[((size_t)(a * 4 + 2) * Cout_p + n) * Cin_s + c] = u2;
+            U[((size_t)(a * 4 + 3) * Cout_p + n) * Cin_s + c] = u3;
+        }
+    }
+}
+int launch_winograd_weight(hipStream_t s, const float* w, float* U, int Cout, int Cin, int Cout_p, int Cin_s) {
+    hipLaunchKernelGGL(winograd_weight_kernel, dim3(wg_grid((long)Cout_p * Cin_s, 256)), dim3(256), 0, s, w, U, Cout, Cin,
+                       Cout_p, Cin_s);
+    T2V_HIP_CHECK(hipGetLastError());
+    return T2V_OK;
+}
+
+// V[xi][tile][c] = (B^T d B)[xi],  d = 4x4 patch at rows 2ty-1.., cols 2tx-1.. (reflection pad 1)
+// B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]].  One thread = one tile x 4 channels (float4).
+__global__ __launch_bounds__(256) void winograd_input_kernel(const float4* __restrict__ x, float4* __restrict__ V, int H,
+                                                             int W, int C4) {
+    const int TW = W >> 1;
+    const long T = (long)(H >> 1) * TW;
+    const long total = T * C4;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const long tile = i / C4;
+        const int c4 = (int)(i - tile * C4);
+        const int ty = (int)(tile / TW), tx = (int)(tile - (long)ty * TW);
+        int ry[4], rx[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            int yy = 2 * ty - 1 + k, xx = 2 * tx - 1 + k;
+            yy = yy < 0 ? -yy : yy;
+            xx = xx < 0 ? -xx : xx;
+            ry[k] = min(yy, 2 * H - 2 - yy);
+            rx[k] = min(xx, 2 * W - 2 - xx);
+        }
+        float4 d[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) d[a][b] = x[((long)ry[a] * W + rx[b]) * C4 + c4];
+        // rows: t = B^T d
+        float4 t[4][4];
+#define T2V_SUB(o, p, q) o.x = p.x - q.x; o.y = p.y - q.y; o.z = p.z - q.z; o.w = p.w - q.w;
+#define T2V_ADD(o, p, q) o.x = p.x + q.x; o.y = p.y + q.y; o.z = p.z + q.z; o.w = p.w + q.w;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            T2V_SUB(t[0][b], d[0][b], d[2][b])
+            T2V_ADD(t[1][b], d[1][b], d[2][b])
+            T2V_SUB(t[2][b], d[2][b], d[1][b])
+            T2V_SUB(t[3][b], d[1][b], d[3][b])
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            float4 v0, v1, v2, v3;
+            T2V_SUB(v0, t[a][0], t[a][2])
+            T2V_ADD(v1, t[a][1], t[a][2])
+            T2V_SUB(v2, t[a][2], t[a][1])
+            T2V_SUB(v3, t[a][1], t[a][3])
+            V[((long)(a * 4 + 0) * T + tile) * C4 + c4] = v0;
+            V[((long)(a * 4 + 1) * T + tile) * C4 + c4] = v1;
+            V[((long)(a * 4 + 2) * T + tile) * C4 + c4] = v2;
+            V[((long)(a * 4 + 3) * T + tile) * C4 + c4] = v3;
+        }
+    }
+}
+int launch_winograd_input(hipStream_t s, const float* x, float* V, int H, int W, int C) {
+    const long total = (long)(H / 2) * (W / 2) * (C / 4);
+    hipLaunchKernelGGL(winograd_input_kernel, dim3(wg_grid(total, 256)), dim3(256), 0, s,
+                       reinterpret_cast<const float4*>(x), reinterpret_cast<float4*>(V), H, W, C / 4);
+    T2V_HIP_CHECK(hipGetLastError());
+    return T2V_OK;
+}
+
+// y = A^T M A + bias,  A^T = [[1,1,1,0],[0,1,-1,-1]];  block = 64 channels x 4 tile lanes, 32 tiles = 128
+// output pixels per block => exactly the (mean_b, M2_b) partial per 128 pixels that inorm_finalize merges.
+__global__ __launch_bounds__(256) void winograd_output_kernel(const float* __restrict__ Mm, const float* __restrict__ bias,
+                                                              float* __restrict__ y, float2* __restrict__ stats, int H,
+                                                              int W, int N) {
+    __shared__ float sh[4][64];
+    const int TW = W >> 1;
+    const long T = (long)(H >> 1) * TW;
+    const int cl = threadIdx.x & 63, tl = threadIdx.x >> 6;
+    const int n = blockIdx.y * 64 + cl;
+    const bool ok = n < N;
+    const float bv = (ok && bias) ? bias[n] : 0.f;
+    float out[8][4];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const long tile = (long)blockIdx.x * 32 + tl + 4 * i;
+        float m[4][4];
+#pragma unroll
+        for (int a = 0; a < 16; ++a) m[a >> 2][a & 3] = ok ? Mm[((long)a * T + tile) * N + n] : 0.f;
+        float r[2][4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            r[0][b] = m[0][b] + m[1][b] + m[2][b];
+            r[1][b] = m[1][b] - m[2][b] - m[3][b];
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            out[i][a * 2 + 0] = r[a][0] + r[a][1] + r[a][2] + bv;
+            out[i][a * 2 + 1] = r[a][1] - r[a][2] - r[a][3] + bv;
+        }
+        if (ok) {
+            const int ty = (int)(tile / TW), tx = (int)(tile - (long)ty * TW);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) y[((long)(2 * ty + a) * W + 2 * tx + b) * N + n] = out[i][a * 2 + b];
+        }
+    }
+    if (stats == nullptr) return;
+    // two-pass (mean, M2) over the block's 128 pixels, tree-summed (exact for constant maps)
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        float v[32];
+        const float mean_b = pass ? sum : 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float dlt = out[i][k] - mean_b;
+                v[i * 4 + k] = pass ? dlt * dlt : out[i][k];
+            }
+#pragma unroll
+        for (int w = 16; w >= 1; w >>= 1)
+#pragma unroll
+            for (int i = 0; i < w; ++i) v[i] += v[i + w];
+        sh[tl][cl] = v[0];
+        __syncthreads();
+        const float tot = (sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl]);
+        __syncthreads();
+        if (pass == 0) {
+            sum = tot * (1.f / 128.f);
+        } else if (tl == 0 && ok) {
+            stats[(size_t)blockIdx.x * N + n] = make_float2(sum, tot);
+        }
+    }
+}
+int launch_winograd_output(hipStream_t s, const float* Mm, const float* bias, float* y, float* stats, int H, int W, int N) {
+    const long T = (long)(H / 2) * (W / 2);
+    hipLaunchKernelGGL(winograd_output_kernel, dim3((int)(T / 32), (N + 63) / 64), dim3(256), 0, s, Mm, bias, y,
+                       reinterpret_cast<float2*>(stats), H, W, N);
+    T2V_HIP_CHECK(hipGetLastError());
+    return T2V_OK;
+}
+
+}  // namespace t2v

@@ -78,9 +78,10 @@ def layer_keys(spec):
     return out
 
 
-def _gen_desc(spec, H, W):
+def _gen_desc(spec, H, W, conv_algo=0):
     return GenDesc(H, W, spec.input_nc, spec.prev_nc, spec.output_nc, spec.ngf, spec.n_downsample, spec.n_blocks,
-                   int(spec.no_flow), int(spec.norm == "batch"), int(spec.is_local), 20.0 * (2 ** spec.scale), 1e-5)
+                   int(spec.no_flow), int(spec.norm == "batch"), int(spec.is_local), 20.0 * (2 ** spec.scale), 1e-5,
+                   conv_algo)
 
 
 def layer_shapes(spec):
@@ -141,62 +142,72 @@ def synthetic_state_dict(spec, seed=1, init="uniform_fan_in", flow_gain=1.0):
 
 
 class HipGenerator:
-    """One generator scale resident on the GPU: packed weights + workspace + forward()."""
+    """One generator scale resident on the GPU: packed weights + workspace + forward().
 
-    def __init__(self, spec, device="cuda"):
+    Weights are packed lazily per frame geometry: the ResnetBlock convs use Winograd-transformed
+    weights wherever the geometry supports it (t2v_generator_layer_desc reports the algorithm)."""
+
+    def __init__(self, spec, device="cuda", conv_algo=None):
+        import os
         self.spec = spec
         self.device = torch.device(device)
         self.ctx = ops.context(self.device)
         self.lib = self.ctx.lib
         self.keys = layer_keys(spec)
-        self._params = []      # keeps device tensors alive
+        self.conv_algo = int(os.environ.get("T2V_CONV_ALGO", "0")) if conv_algo is None else conv_algo
+        self._raw = None       # upstream-named fp32 tensors on the device
+        self._packed = None    # keeps the packed tensors of the current geometry alive
         self._layers = None
         self._ws = None
         self._ws_hw = None
 
     # -- weights ---------------------------------------------------------------------------------
     def load_state_dict(self, sd):
-        """sd: upstream-named tensors (CPU or GPU).  Repacks every conv weight on the device."""
-        spec = self.spec
-        gd = _gen_desc(spec, 64, 64)
+        """sd: upstream-named tensors (CPU or GPU)."""
+        self._raw = {}
+        for ck, nk, kind in self.keys:
+            cks = ck if isinstance(ck, tuple) else (ck,)
+            for k in cks:
+                for leaf in (".weight", ".bias"):
+                    self._raw[k + leaf] = sd[k + leaf].detach().to(self.device, torch.float32).contiguous()
+            if nk is not None and self.spec.norm == "batch":
+                for leaf in (".weight", ".bias"):
+                    self._raw[nk + leaf] = sd[nk + leaf].detach().to(self.device, torch.float32).contiguous()
+        self._layers = None
+        self._ws_hw = None
+        return self
+
+    def _pack(self, gd):
         n = len(self.keys)
         arr = (Layer * n)()
-        self._params = []
-
-        def dev(t):
-            t = t.detach().to(self.device, torch.float32).contiguous()
-            self._params.append(t)
-            return t
-
+        keep = []
         for i, (ck, nk, kind) in enumerate(self.keys):
             cd, xcs = _lib.ConvDesc(), ctypes.c_int()
             check(self.lib.t2v_generator_layer_desc(ctypes.byref(gd), i, ctypes.byref(cd), ctypes.byref(xcs)),
                   "layer_desc")
             if kind == "flow_w":
-                w = torch.cat([sd[ck[0] + ".weight"], sd[ck[1] + ".weight"]], 0)
-                b = torch.cat([sd[ck[0] + ".bias"], sd[ck[1] + ".bias"]], 0)
+                w = torch.cat([self._raw[ck[0] + ".weight"], self._raw[ck[1] + ".weight"]], 0)
+                b = torch.cat([self._raw[ck[0] + ".bias"], self._raw[ck[1] + ".bias"]], 0)
             else:
-                w, b = sd[ck + ".weight"], sd[ck + ".bias"]
-            # raw torch-layout weight is transient: the pack kernel runs on the current stream and the
-            # caching allocator recycles the buffer in stream order
-            packed = ops.pack_conv_weight(w.detach().to(self.device, torch.float32).contiguous(), cd, xcs.value)
-            self._params.append(packed)
+                w, b = self._raw[ck + ".weight"], self._raw[ck + ".bias"]
+            packed = ops.pack_conv_weight(w, cd, xcs.value)
+            keep += [packed, b]
             arr[i].w = packed.data_ptr()
-            arr[i].bias = dev(b).data_ptr()
-            if nk is not None and spec.norm == "batch":
-                arr[i].gamma = dev(sd[nk + ".weight"]).data_ptr()
-                arr[i].beta = dev(sd[nk + ".bias"]).data_ptr()
+            arr[i].bias = b.data_ptr()
+            if nk is not None and self.spec.norm == "batch":
+                arr[i].gamma = self._raw[nk + ".weight"].data_ptr()
+                arr[i].beta = self._raw[nk + ".bias"].data_ptr()
         torch.cuda.current_stream().synchronize()
-        self._layers = arr
-        return self
+        self._packed, self._layers = keep, arr
 
     # -- forward ---------------------------------------------------------------------------------
     def _workspace(self, H, W):
         if self._ws_hw != (H, W):
-            gd = _gen_desc(self.spec, H, W)
+            gd = _gen_desc(self.spec, H, W, self.conv_algo)
             nbytes = self.lib.t2v_generator_workspace_bytes(ctypes.byref(gd))
             if nbytes == 0:
                 raise RuntimeError("generator: %s" % self.lib.t2v_last_error().decode())
+            self._pack(gd)
             self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
             self._ws_hw = (H, W)
             self._gd = gd
@@ -206,7 +217,7 @@ class HipGenerator:
                 want=("out",)):
         """pose [H,W,round_up4(input_nc)], prev [H,W,round_up4(prev_nc)] NHWC fp32 on the device.
         Returns dict of NHWC tensors for the names in `want` ⊆ {out, raw, flow_w, img_feat, flow_feat}."""
-        if self._layers is None:
+        if self._raw is None:
             raise RuntimeError("HipGenerator.forward before load_state_dict")
         H, W = pose.shape[0], pose.shape[1]
         ws = self._workspace(H, W)

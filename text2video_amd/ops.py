@@ -47,10 +47,29 @@ def round_up(v, m):
 
 
 def conv_desc(H, W, Cin, Cout, k, stride=1, pad=0, pad_mode=PAD_ZERO, transposed=False, act=ACT_NONE,
-              act_scale=1.0, output_padding=None):
+              act_scale=1.0, output_padding=None, algo=0):
     if output_padding is None:
         output_padding = 1 if transposed else 0     # the generator's ConvTranspose2d(k3,s2,p1,op1)
-    return ConvDesc(H, W, Cin, Cout, k, k, stride, pad, pad_mode, int(transposed), act, act_scale, output_padding)
+    return ConvDesc(H, W, Cin, Cout, k, k, stride, pad, pad_mode, int(transposed), act, act_scale, output_padding,
+                    algo)
+
+
+def winograd_supported(desc, x_cs=None):
+    x_cs = round_up(desc.Cin, 4) if x_cs is None else x_cs
+    return bool(_lib.load().t2v_conv_winograd_supported(ctypes.byref(desc), x_cs))
+
+
+def conv2d_winograd(x, packed_u, bias, desc, stats=None, out=None):
+    """3x3 stride-1 reflect-pad-1 conv through Winograd F(2x2,3x3) (desc.algo must be ALGO_WINOGRAD)."""
+    c = context()
+    _chk(x, "x")
+    x_cs = x.shape[-1]
+    nws = c.lib.t2v_conv_winograd_workspace_floats(ctypes.byref(desc), x_cs)
+    ws = torch.empty(nws, dtype=torch.float32, device=x.device)
+    y = out if out is not None else torch.empty(desc.H, desc.W, desc.Cout, dtype=torch.float32, device=x.device)
+    check(c.lib.t2v_conv2d_forward_winograd(c.handle, _stream(), ctypes.byref(desc), _p(x), x_cs, _p(packed_u), _p(bias),
+                                            _p(y), desc.Cout, _p(stats), _p(ws)), "conv2d_forward_winograd")
+    return y
 
 
 def conv_out_dims(desc):
