@@ -13,8 +13,9 @@ are all-gathered over RCCL inside the timed region.  Weights are random-init (se
 synthetic: there is no network for checkpoints.
 
 Prints ONE JSON line (rank 0) with the driver's contract fields plus
-  "roofline":     dominant kernel (1024->1024 3x3 ResnetBlock conv, 77.3 GFLOP per launch) timed with
-                  HIP events on the launch stream vs the fp32 MFMA peak (157.3 TFLOP/s)
+  "roofline":     dominant kernel (the batched-GEMM stage of the Winograd F(4x4,3x3) 1024->1024 ResnetBlock
+                  conv: 19.3 GFLOP of executed fp32 MFMA work per launch at 512x512) timed with HIP events on
+                  the launch stream vs the fp32 MFMA peak (157.3 TFLOP/s); "layer" = the whole conv
   "cpu_baseline": the CPU oracle (stock torch fp32) timed on this box's host cores on a bounded
                   sample of the same workload.
 """
@@ -159,8 +160,24 @@ def main():
         else:
             gf = gflop_per_frame(H, W, args.flow)
         # ---- dominant kernel, timed live with HIP events on the stream it is launched on ----
+        # The 1024->1024 3x3 ResnetBlock conv (28 per frame, 84 % of the algorithmic FLOPs) runs as Winograd
+        # F(4x4,3x3) [F(2x2,3x3)]: input transform -> 36 [16] batched GEMMs [T x 1024] x [1024 x 1024] on the
+        # implicit-GEMM kernel -> output transform.  The GEMM launch is the dominant kernel; its roofline is
+        # priced on the MFMA FLOPs it EXECUTES (2*36*T*C*C = 1/4 [4/9] of the direct conv's algorithmic
+        # 2*9*C*C*H*W), never on the direct-conv-equivalent figure.  Where the geometry has no Winograd path the direct kernel is timed.
         C, hb, wb = 1024, H // 8, W // 8
-        desc = ops.conv_desc(hb, wb, C, C, 3, 1, 1, ops.PAD_REFLECT)
+        direct = ops.conv_desc(hb, wb, C, C, 3, 1, 1, ops.PAD_REFLECT)
+        # same selection as the generator (generator.hip enumerate_layers): F(4x4,3x3) > F(2x2,3x3) > direct
+        cap = int(os.environ.get("T2V_CONV_ALGO", "0"))
+        algo = ops.ALGO_DIRECT
+        if cap == 0 and ops.winograd_supported(direct, C, ops.ALGO_WINOGRAD_F4):
+            algo = ops.ALGO_WINOGRAD_F4
+        elif cap in (0, 2) and ops.winograd_supported(direct, C, ops.ALGO_WINOGRAD):
+            algo = ops.ALGO_WINOGRAD
+        use_wino = algo != ops.ALGO_DIRECT
+        wm = 4 if algo == ops.ALGO_WINOGRAD_F4 else 2
+        npos, ntile = (wm + 2) ** 2, (hb // wm) * (wb // wm)
+        desc = ops.conv_desc(hb, wb, C, C, 3, 1, 1, ops.PAD_REFLECT, algo=algo) if use_wino else direct
         # inputs as the kernel sees them in a frame: conv1 of a ResnetBlock reads the residual stream
         # (dense, signed), conv2 reads a ReLU output (half zeros) -- alternate the two
         xs = [torch.randn(hb, wb, C, device=dev), torch.relu(torch.randn(hb, wb, C, device=dev))]
@@ -168,28 +185,56 @@ def main():
         bias = sd["model_res_img.0.conv_block.1.bias"].to(dev)
         stats = ops.conv_stats_buffer(desc, dev)
         y = torch.empty(hb, wb, C, device=dev)
+        if use_wino:
+            wss = [ops.winograd_workspace(desc, C, dev) for _ in range(2)]
+            for i in range(2):   # transformed inputs of both kinds, one workspace each
+                ops.conv2d_winograd(xs[i], wt, bias, desc, stats=stats, out=y, workspace=wss[i], stages=1)
+
+            def launch(i, stages=2):
+                ops.conv2d_winograd(xs[i & 1], wt, bias, desc, stats=stats, out=y, workspace=wss[i & 1], stages=stages)
+        else:
+            def launch(i, stages=0):
+                ops.conv2d(xs[i & 1], wt, bias, desc, y_cs=C, stats=stats, out=y)
         for i in range(64):   # ~35 ms: the clocks ramp back up for tens of ms after the host-side gap above
-            ops.conv2d(xs[i & 1], wt, bias, desc, y_cs=C, stats=stats, out=y)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            launch(i)
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
         e0.record()
         for i in range(args.kernel_iters):
-            ops.conv2d(xs[i & 1], wt, bias, desc, y_cs=C, stats=stats, out=y)
+            launch(i)
         e1.record()
+        for i in range(args.kernel_iters):   # the whole conv (all three stages / the direct kernel)
+            launch(i, 7)
+        e2.record()
         torch.cuda.synchronize()
         k_ms = e0.elapsed_time(e1) / args.kernel_iters
-        k_flop = 2.0 * 9 * C * C * hb * wb
+        conv_ms = e1.elapsed_time(e2) / args.kernel_iters
+        conv_flop = 2.0 * 9 * C * C * hb * wb                       # algorithmic (direct-conv) FLOPs of the layer
+        k_flop = 2.0 * npos * ntile * C * C if use_wino else conv_flop
         achieved = k_flop / (k_ms * 1e-3) / 1e12
         traffic = None
         prof = os.path.join(ROOT, "profiles", "pmc_summary.json")
         if os.path.exists(prof):
             try:
-                traffic = json.load(open(prof)).get("conv_igemm_rb_hbm_bytes_per_launch")
+                traffic = json.load(open(prof)).get({0: "conv_igemm_rb_hbm_bytes_per_launch",
+                                                     1: "winograd_f2_gemm_hbm_bytes_per_launch",
+                                                     2: "winograd_f4_gemm_hbm_bytes_per_launch"}[algo]
+                                                    if (hb, wb) == (64, 64) else "-")
             except Exception:
                 traffic = None
-        roofline = {"bound": "mfma", "kernel": "conv_igemm_kernel<128x128,fp32 32x32x2,reflect,stats> 1024->1024 3x3 @%dx%d" % (hb, wb),
+        kname = ("conv_igemm_kernel<%s,fp32 32x32x2> as %d batched GEMMs [%d x 1024]x[1024 x 1024]: Winograd "
+                 "F(%dx%d,3x3) stage of the 1024->1024 3x3 ResnetBlock conv @%dx%d"
+                 % ("128x128" if npos * ntile // 128 * 8 >= 0.8 * 256 * -(-(npos * ntile // 128 * 8) // 256) else "64x64",
+                    npos, ntile, wm, wm, hb, wb)
+                 if use_wino else
+                 "conv_igemm_kernel<128x128,fp32 32x32x2,reflect,stats> 1024->1024 3x3 @%dx%d" % (hb, wb))
+        roofline = {"bound": "mfma", "kernel": kname,
                     "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
-                    "ms_per_launch": round(k_ms, 4), "gflop_per_launch": round(k_flop / 1e9, 2)}
+                    "ms_per_launch": round(k_ms, 4), "gflop_per_launch": round(k_flop / 1e9, 2),
+                    "flops_counted": "executed MFMA FLOPs of the launch" if use_wino else "algorithmic conv FLOPs",
+                    "layer": {"algo": "winograd_f%dx%d_3x3" % (wm, wm) if use_wino else "direct", "ms_per_conv": round(conv_ms, 4),
+                              "algorithmic_gflop": round(conv_flop / 1e9, 2),
+                              "algorithmic_tflops": round(conv_flop / (conv_ms * 1e-3) / 1e12, 2)}}
         # ---- CPU baseline: the oracle on this box's host cores, bounded sample ----
         cpu = None
         if args.cpu_frames > 0 and world == 1:   # reported at N=1 only (rank 0)
@@ -224,8 +269,8 @@ def main():
                                       " + local enhancer (n_scales_spatial 2)" if args.scales == 2 else "",
                                       "flow-warp compositor ON" if args.flow else "no flow branch (--openpose_only)"),
                        "frames_per_gpu": K, "parallelism": "sequence-chunk dp%d" % world,
-                       "gflop_per_frame": round(gf, 1), "model_tflops": round(fps * gf / 1e3, 2),
-                       "model_frac_of_fp32_mfma_peak": round(fps * gf / 1e3 / (PEAK_FP32_MFMA_TFLOPS * world), 4)},
+                       "algorithmic_gflop_per_frame": round(gf, 1),
+                       "algorithmic_tflops": round(fps * gf / 1e3, 2)},
             "roofline": roofline, "cpu_baseline": cpu,
         }
     if dist:

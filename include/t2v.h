@@ -44,10 +44,13 @@ enum { T2V_PAD_ZERO = 0, T2V_PAD_REFLECT = 1 };
 enum { T2V_ACT_NONE = 0, T2V_ACT_TANH = 1, T2V_ACT_FLOW_W = 2 /* ch0,1: x*20 ; ch2: sigmoid */,
        T2V_ACT_LRELU = 3 /* x>0 ? x : act_scale*x  (LeakyReLU_updateOutput THCUNN.h:220) */ };
 
-/* Convolution algorithm.  WINOGRAD = F(2x2,3x3) in fp32: input transform -> 16 batched GEMMs on the
+/* Convolution algorithm, all fp32.  WINOGRAD = F(2x2,3x3): input transform -> 16 batched GEMMs on the
  * implicit-GEMM kernel -> output transform fused with bias and the norm statistics (2.25x fewer MFMA
- * FLOPs).  Only where t2v_conv_winograd_supported() says so; packed weights differ per algorithm. */
-enum { T2V_ALGO_DIRECT = 0, T2V_ALGO_WINOGRAD = 1 };
+ * FLOPs than the direct conv).  WINOGRAD_F4 = F(4x4,3x3), 36 batched GEMMs, 4x fewer MFMA FLOPs,
+ * interpolation points {0, +-3/4, +-3/2, inf} (rounding error ~4x the direct kernel's, 1.5e-6 of the
+ * output's std per conv).  Only where t2v_conv_winograd_supported() says so; packed weights differ
+ * per algorithm. */
+enum { T2V_ALGO_DIRECT = 0, T2V_ALGO_WINOGRAD = 1, T2V_ALGO_WINOGRAD_F4 = 2 };
 
 typedef struct t2v_ctx t2v_ctx;
 
@@ -92,15 +95,21 @@ int t2v_conv2d_forward(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, const
                        const float* w_packed, const float* bias, float* y, int y_cs,
                        float* stats_partial);
 
-/* 1 when `d` (with algo ignored) can run as Winograd: 3x3, stride 1, ReflectionPad 1, Cin % 32 == 0 == x_cs,
- * Cout % 4 == 0, H and W even, (H/2)*(W/2) a multiple of 128. */
+/* Bit mask of the Winograd variants `d` (algo ignored) can run as: 1 = F(2x2,3x3), 2 = F(4x4,3x3).
+ * Needs 3x3, stride 1, ReflectionPad 1, Cin % 32 == 0 == x_cs, Cout % 4 == 0, H and W multiples of the
+ * output tile m (2 | 4) and (H/m)*(W/m) a multiple of 128. */
 int t2v_conv_winograd_supported(const t2v_conv_desc* d, int x_cs);
 /* floats of scratch (transformed input V + transformed output M) a Winograd forward needs */
 size_t t2v_conv_winograd_workspace_floats(const t2v_conv_desc* d, int x_cs);
-/* forward with d->algo == T2V_ALGO_WINOGRAD; same contract as t2v_conv2d_forward plus the workspace */
+/* forward with d->algo == T2V_ALGO_WINOGRAD | T2V_ALGO_WINOGRAD_F4; same contract as t2v_conv2d_forward plus the workspace */
 int t2v_conv2d_forward_winograd(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, const float* x, int x_cs,
                                 const float* w_packed, const float* bias, float* y, int y_cs, float* stats_partial,
                                 float* workspace);
+/* the same, one stage at a time (measurement and tests): `stages` is a bit mask of
+ * 1 = input transform x -> V, 2 = the 16 | 36 batched GEMMs V,U -> M, 4 = output transform M -> y (+bias, stats). */
+int t2v_conv2d_forward_winograd_stages(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, const float* x, int x_cs,
+                                       const float* w_packed, const float* bias, float* y, int y_cs,
+                                       float* stats_partial, float* workspace, int stages);
 
 /* ------------------------------------------------------------------------------------------
  * Instance norm (+affine) + ReLU + residual.  Replaces BatchNormalization_updateOutput(train)
@@ -230,7 +239,8 @@ typedef struct {
     int is_local;       /* 0: CompositeGenerator, 1: CompositeLocalGenerator */
     float flow_multiplier; /* 20 * 2^scale */
     float eps;          /* 1e-5 */
-    int conv_algo;      /* 0: Winograd F(2x2,3x3) for the ResnetBlock convs wherever supported; 1: direct only */
+    int conv_algo;      /* ResnetBlock convs: 0 = best supported of F(4x4,3x3) > F(2x2,3x3) > direct;
+                         * 1 = direct only; 2 = F(2x2,3x3) or direct */
 } t2v_gen_desc;
 
 typedef struct {

@@ -10,13 +10,14 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--shapes", default="rb1024")
 ap.add_argument("--iters", type=int, default=40)
 ap.add_argument("--warmup", type=int, default=80)
-ap.add_argument("--winograd", action="store_true")
+ap.add_argument("--winograd", type=int, nargs="?", const=1, default=0, help="1 = F(2x2,3x3), 2 = F(4x4,3x3)")
+ap.add_argument("--stages", type=int, default=7, help="Winograd stage mask: 1 input transform, 2 GEMM, 4 output transform")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 for name in args.shapes.split(","):
     H, W, Cin, Cout, k, st, pad, pm, tr, stats = SHAPES[name]
     desc = ops.conv_desc(H, W, Cin, Cout, k, st, pad, pm, tr, ops.ACT_TANH if Cout == 3 else ops.ACT_NONE,
-                         algo=1 if args.winograd else 0)
+                         algo=args.winograd)
     xcs = ops.round_up(Cin, 4)
     x = torch.randn(H, W, xcs, device=dev)
     w = torch.randn(*((Cin, Cout, k, k) if tr else (Cout, Cin, k, k)), device=dev) * 0.02
@@ -27,7 +28,10 @@ for name in args.shapes.split(","):
     ycs = Cout if Cout % 4 == 0 else 4
     y = torch.empty(ho, wo, ycs, device=dev)
     flop = 2.0 * k * k * Cin * Cout * (H * W if tr else ho * wo)
-    run = (lambda: ops.conv2d_winograd(x, pw, b, desc, stats=sb, out=y)) if args.winograd else \
+    wws = ops.winograd_workspace(desc, xcs, dev) if args.winograd else None
+    if args.winograd:
+        ops.conv2d_winograd(x, pw, b, desc, stats=sb, out=y, workspace=wws)
+    run = (lambda: ops.conv2d_winograd(x, pw, b, desc, stats=sb, out=y, workspace=wws, stages=args.stages)) if args.winograd else \
         (lambda: ops.conv2d(x, pw, b, desc, y_cs=ycs, stats=sb, out=y))
     for _ in range(args.warmup):  # clocks ramp over tens of ms: warm up long enough
         run()

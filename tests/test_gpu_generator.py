@@ -49,6 +49,9 @@ CASES = [
     # bottleneck 32x16 / 16x32 (128 Winograd tiles): the ResnetBlock convs take the Winograd F(2x2,3x3) path
     ("winograd_noflow", dict(ngf=16, n_downsample=2, n_blocks=3, no_flow=True, norm="instance"), 1, 128, 64),
     ("winograd_flow", dict(ngf=16, n_downsample=2, n_blocks=2, no_flow=False, norm="batch"), 1, 64, 128),
+    # bottleneck 64x32 / 32x64 (128 tiles of 4x4): Winograd F(4x4,3x3)
+    ("winograd_f4_noflow", dict(ngf=16, n_downsample=2, n_blocks=3, no_flow=True, norm="instance"), 1, 256, 128),
+    ("winograd_f4_flow", dict(ngf=16, n_downsample=2, n_blocks=2, no_flow=False, norm="batch"), 1, 128, 256),
 ]
 
 
@@ -75,6 +78,9 @@ def test_winograd_is_selected_and_matches_direct():
     rb = [i for i, (ck, nk, kind) in enumerate(keys) if ".conv_block" in str(ck)]
     assert len(rb) >= 6 and [i for i, v in enumerate(a) if v == _lib.ALGO_WINOGRAD] == rb, (a, rb)
     assert sum(algos(128, 64, 1)) == 0 and sum(algos(64, 64, 0)) == 0
+    a4 = algos(256, 128, 0)     # enough 4x4 tiles: F(4x4,3x3); conv_algo=2 caps it at F(2x2,3x3)
+    assert [i for i, v in enumerate(a4) if v == _lib.ALGO_WINOGRAD_F4] == rb and sum(a4) == 2 * len(rb)
+    assert [i for i, v in enumerate(algos(256, 128, 2)) if v == _lib.ALGO_WINOGRAD] == rb
 
     sd = synthetic_state_dict(spec, 3)
     pose = _pose_seq(3, 128, 64, seed=2)
@@ -86,6 +92,11 @@ def test_winograd_is_selected_and_matches_direct():
     y_d = HipGenerator(spec, "cuda:0", conv_algo=1).load_state_dict(sd).forward(x, prev)["out"]
     err = (y_w - y_d).abs().max().item()
     assert 0 < err <= TOL_FORCED, err
+    x4 = torch.cat([x, x.flip(0)], 0).repeat(1, 2, 1).contiguous()      # 256 x 128
+    p4 = torch.cat([prev, prev.flip(1)], 0).repeat(1, 2, 1).contiguous()
+    ys = [HipGenerator(spec, "cuda:0", conv_algo=a).load_state_dict(sd).forward(x4, p4)["out"] for a in (0, 2, 1)]
+    e4, e2 = (ys[0] - ys[2]).abs().max().item(), (ys[1] - ys[2]).abs().max().item()
+    assert 0 < e2 <= TOL_FORCED and 0 < e4 <= TOL_FORCED, (e4, e2)
 
 
 TOL_FORCED = 2e-4  # same inputs in, fp32 summation-order differences only (observed ~1e-5)

@@ -259,30 +259,39 @@ def test_conv_bitwise_repeatable_race_screen(case):
             assert torch.equal(sb, ref_s), "launch %d: norm partials differ" % i
 
 
-@pytest.mark.parametrize("shape", [(32, 16, 32, 64), (64, 64, 64, 96), (16, 64, 128, 32)], ids=["T128", "T1024", "T512"])
-def test_winograd_conv_matches_direct_and_reference(shape):
-    """F(2x2,3x3) path: input transform -> 16 grouped GEMMs -> output transform (+bias, +norm statistics)."""
+@pytest.mark.parametrize("case", [(1, 32, 16, 32, 64), (1, 64, 64, 64, 96), (1, 16, 64, 128, 32),
+                                  (2, 64, 32, 32, 64), (2, 64, 64, 64, 96), (2, 32, 128, 128, 32), (2, 128, 128, 32, 32)],
+                         ids=["F2-T128", "F2-T1024", "F2-T512", "F4-T128", "F4-T256", "F4-T256w", "F4-T1024"])
+def test_winograd_conv_matches_direct_and_reference(case):
+    """F(2x2,3x3) / F(4x4,3x3): input transform -> 16 | 36 grouped GEMMs -> output transform (+bias, +norm statistics)."""
     from text2video_amd import ops
-    H, W, Cin, Cout = shape
+    algo, H, W, Cin, Cout = case
+    npos = 16 if algo == 1 else 36
     x = _rand(Cin, H, W, seed=41)
     w = _rand(Cout, Cin, 3, 3, seed=42, scale=0.1)
     b = _rand(Cout, seed=43, scale=0.1)
     ref = _ref_conv(x, w, b, 3, 1, 1, 1, False)
-    desc_w = ops.conv_desc(H, W, Cin, Cout, 3, 1, 1, ops.PAD_REFLECT, algo=1)
+    desc_w = ops.conv_desc(H, W, Cin, Cout, 3, 1, 1, ops.PAD_REFLECT, algo=algo)
     assert ops.winograd_supported(desc_w, Cin)
     xs = _to_nhwc(x)
     U = ops.pack_conv_weight(w.to(_dev()), desc_w, Cin)
-    assert U.numel() == 16 * ((Cout + 127) // 128 * 128) * Cin
+    assert U.numel() == npos * ((Cout + 127) // 128 * 128) * Cin
     stats = ops.conv_stats_buffer(desc_w, _dev())
     y = ops.conv2d_winograd(xs, U, b.to(_dev()), desc_w, stats=stats)
     assert (_from_nhwc(y, Cout) - ref).abs().max().item() <= 2e-4 * max(1.0, ref.abs().max().item())
+    # staged execution (what bench.py times) gives the same bits
+    ws = ops.winograd_workspace(desc_w, Cin, _dev())
+    y2 = torch.empty_like(y)
+    for st in (1, 2, 4):
+        ops.conv2d_winograd(xs, U, b.to(_dev()), desc_w, stats=stats, out=y2, workspace=ws, stages=st)
+    assert torch.equal(y, y2)
     # the statistics it emits feed the same finalize/apply as the direct kernel's
     mr = ops.instance_norm_finalize(stats, desc_w)
     yn = ops.instance_norm_apply(y, mr, relu=True)
     ref_n = F.relu(F.instance_norm(ref.unsqueeze(0), eps=1e-5))[0]
     assert (_from_nhwc(yn, Cout) - ref_n).abs().max().item() <= 3e-4
     # unsupported shapes are refused, not silently run
-    bad = ops.conv_desc(10, 10, Cin, Cout, 3, 1, 1, ops.PAD_REFLECT, algo=1)
+    bad = ops.conv_desc(10, 10, Cin, Cout, 3, 1, 1, ops.PAD_REFLECT, algo=algo)
     assert not ops.winograd_supported(bad, Cin)
     with pytest.raises(RuntimeError):
         ops.pack_conv_weight(w.to(_dev()), bad, Cin)

@@ -15,7 +15,7 @@ T2V_OK = 0
 PAD_ZERO, PAD_REFLECT = 0, 1
 ACT_NONE, ACT_TANH, ACT_FLOW_W, ACT_LRELU = 0, 1, 2, 3
 ABI_VERSION = 3
-ALGO_DIRECT, ALGO_WINOGRAD = 0, 1
+ALGO_DIRECT, ALGO_WINOGRAD, ALGO_WINOGRAD_F4 = 0, 1, 2
 
 
 class ConvDesc(Structure):
@@ -61,6 +61,8 @@ SIGNATURES = {
     "t2v_conv_winograd_workspace_floats": (c_size_t, [POINTER(ConvDesc), c_int]),
     "t2v_conv2d_forward_winograd": (c_int, [c_void_p, c_void_p, POINTER(ConvDesc), c_void_p, c_int, c_void_p, c_void_p,
                                             c_void_p, c_int, c_void_p, c_void_p]),
+    "t2v_conv2d_forward_winograd_stages": (c_int, [c_void_p, c_void_p, POINTER(ConvDesc), c_void_p, c_int, c_void_p,
+                                                   c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int]),
     "t2v_instance_norm_finalize": (c_int, [c_void_p, c_void_p, POINTER(ConvDesc), c_void_p, c_float, c_void_p]),
     "t2v_batch_norm_finalize": (c_int, [c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_void_p, c_float, c_void_p]),
     "t2v_conv_backward_weight_workspace_floats": (c_size_t, [POINTER(ConvDesc), c_int, c_int]),

@@ -139,20 +139,24 @@ int build_conv_plan(const t2v_conv_desc* d, int x_cs, bool need_stats, ConvPlan*
     return T2V_OK;
 }
 
-bool winograd_supported(const t2v_conv_desc* d, int x_cs) {
-    if (!d || d->transposed || d->kH != 3 || d->kW != 3 || d->stride != 1 || d->pad != 1 || d->pad_mode != T2V_PAD_REFLECT)
+bool winograd_supported(const t2v_conv_desc* d, int x_cs, int algo) {
+    if (!d || !is_winograd(algo)) return false;
+    if (d->transposed || d->kH != 3 || d->kW != 3 || d->stride != 1 || d->pad != 1 || d->pad_mode != T2V_PAD_REFLECT)
         return false;
-    if (d->Cin % 32 != 0 || x_cs != d->Cin || d->Cout % 4 != 0 || (d->H & 1) || (d->W & 1) || d->H < 2 || d->W < 2) return false;
-    const long T = (long)(d->H / 2) * (d->W / 2);
+    const int m = wino_m(algo);
+    if (d->Cin % 32 != 0 || x_cs != d->Cin || d->Cout % 4 != 0 || d->H % m || d->W % m || d->H < m || d->W < m) return false;
+    // T tiles: whole 128-row GEMM tiles per transform position, whole 128-pixel blocks in the output transform
+    const long T = (long)(d->H / m) * (d->W / m);
     return T % 128 == 0 && d->act == T2V_ACT_NONE;
 }
 
-// the batched GEMM of a Winograd conv as a plan of the implicit-GEMM kernel: a 1x1 conv over a 16 x T image
+// the batched GEMM of a Winograd conv as a plan of the implicit-GEMM kernel: a 1x1 conv over a 16|36 x T image
 int build_winograd_gemm_plan(const t2v_conv_desc* d, ConvPlan* pl) {
-    const int T = (d->H / 2) * (d->W / 2);
+    const int m = wino_m(d->algo);
+    const int T = (d->H / m) * (d->W / m);
     t2v_conv_desc g;
     memset(&g, 0, sizeof(g));
-    g.H = 16; g.W = T; g.Cin = d->Cin; g.Cout = d->Cout; g.kH = g.kW = 1; g.stride = 1; g.pad = 0;
+    g.H = wino_pos(d->algo); g.W = T; g.Cin = d->Cin; g.Cout = d->Cout; g.kH = g.kW = 1; g.stride = 1; g.pad = 0;
     g.pad_mode = T2V_PAD_ZERO; g.act = T2V_ACT_NONE; g.act_scale = 1.f;
     T2V_TRY(build_conv_plan(&g, d->Cin, false, pl));
     pl->kp.group_mtiles = T / pl->BM;               // T % 128 == 0 and BM in {128, 64}
@@ -186,6 +190,26 @@ int run_conv(t2v_ctx* ctx, hipStream_t s, const ConvPlan& pl, const float* x, co
     k.Cout_s = y_cs;
     k.stats = stats;
     return launch_conv_igemm(s, k, pl.tile);
+}
+
+// all of a Winograd conv (shared with the generator orchestrator): stages bit 1 = input transform,
+// 2 = batched GEMM, 4 = output transform
+int winograd_forward(t2v_ctx* ctx, hipStream_t s, const t2v_conv_desc* d, const float* x, const float* w_packed,
+                     const float* bias, float* y, float* stats_partial, float* workspace, int stages) {
+    const int m = wino_m(d->algo);
+    const size_t T = (size_t)(d->H / m) * (d->W / m);
+    float* V = workspace;
+    float* Mm = workspace + wino_pos(d->algo) * T * d->Cin;
+    const bool f4 = d->algo == T2V_ALGO_WINOGRAD_F4;
+    if (stages & 1) T2V_TRY((f4 ? launch_winograd4_input : launch_winograd_input)(s, x, V, d->H, d->W, d->Cin));
+    if (stages & 2) {
+        ConvPlan pl;
+        T2V_TRY(build_winograd_gemm_plan(d, &pl));
+        T2V_TRY(run_conv(ctx, s, pl, V, w_packed, nullptr, Mm, d->Cout, nullptr));
+    }
+    if (stages & 4)
+        T2V_TRY((f4 ? launch_winograd4_output : launch_winograd_output)(s, Mm, bias, y, stats_partial, d->H, d->W, d->Cout));
+    return T2V_OK;
 }
 
 }  // namespace t2v
@@ -230,33 +254,33 @@ int t2v_conv_out_dims(const t2v_conv_desc* d, int* Hout, int* Wout) {
 size_t t2v_conv_packed_weight_floats(const t2v_conv_desc* d, int x_cs) {
     ConvPlan pl;
     if (build_conv_plan(d, x_cs, false, &pl) != T2V_OK) return 0;
-    if (d->algo == T2V_ALGO_WINOGRAD) return winograd_supported(d, x_cs) ? (size_t)16 * pl.Cout_p * x_cs : 0;
+    if (is_winograd(d->algo)) return winograd_supported(d, x_cs, d->algo) ? (size_t)wino_pos(d->algo) * pl.Cout_p * x_cs : 0;
     return pl.wfloats;
 }
 
-int t2v_conv_winograd_supported(const t2v_conv_desc* d, int x_cs) { return winograd_supported(d, x_cs) ? 1 : 0; }
+int t2v_conv_winograd_supported(const t2v_conv_desc* d, int x_cs) {
+    return (winograd_supported(d, x_cs, T2V_ALGO_WINOGRAD) ? 1 : 0) | (winograd_supported(d, x_cs, T2V_ALGO_WINOGRAD_F4) ? 2 : 0);
+}
 
 size_t t2v_conv_winograd_workspace_floats(const t2v_conv_desc* d, int x_cs) {
-    if (!winograd_supported(d, x_cs)) return 0;
-    const size_t T = (size_t)(d->H / 2) * (d->W / 2);
-    return 16 * T * ((size_t)d->Cin + (size_t)d->Cout);
+    if (!d || !winograd_supported(d, x_cs, d->algo)) return 0;
+    return winograd_workspace_floats(d);
+}
+
+int t2v_conv2d_forward_winograd_stages(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, const float* x, int x_cs,
+                                       const float* w_packed, const float* bias, float* y, int y_cs,
+                                       float* stats_partial, float* workspace, int stages) {
+    T2V_REQUIRE(ctx && d && x && w_packed && y && workspace, "winograd forward: null pointer");
+    T2V_REQUIRE(winograd_supported(d, x_cs, d->algo),
+                "winograd forward: shape/algo not supported (t2v_conv_winograd_supported)");
+    T2V_REQUIRE(y_cs == d->Cout, "winograd forward: output channel storage must equal Cout");
+    return winograd_forward(ctx, (hipStream_t)stream, d, x, w_packed, bias, y, stats_partial, workspace, stages);
 }
 
 int t2v_conv2d_forward_winograd(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, const float* x, int x_cs,
                                 const float* w_packed, const float* bias, float* y, int y_cs, float* stats_partial,
                                 float* workspace) {
-    T2V_REQUIRE(ctx && x && w_packed && y && workspace, "winograd forward: null pointer");
-    T2V_REQUIRE(winograd_supported(d, x_cs), "winograd forward: shape not supported (t2v_conv_winograd_supported)");
-    T2V_REQUIRE(y_cs == d->Cout, "winograd forward: output channel storage must equal Cout");
-    hipStream_t s = (hipStream_t)stream;
-    const size_t T = (size_t)(d->H / 2) * (d->W / 2);
-    float* V = workspace;
-    float* Mm = workspace + 16 * T * d->Cin;
-    T2V_TRY(launch_winograd_input(s, x, V, d->H, d->W, d->Cin));
-    ConvPlan pl;
-    T2V_TRY(build_winograd_gemm_plan(d, &pl));
-    T2V_TRY(run_conv(ctx, s, pl, V, w_packed, nullptr, Mm, d->Cout, nullptr));
-    return launch_winograd_output(s, Mm, bias, y, stats_partial, d->H, d->W, d->Cout);
+    return t2v_conv2d_forward_winograd_stages(ctx, stream, d, x, x_cs, w_packed, bias, y, y_cs, stats_partial, workspace, 7);
 }
 
 int t2v_conv_pack_weight(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, int x_cs, const float* w_torch_dev,
@@ -265,9 +289,10 @@ int t2v_conv_pack_weight(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, int
     ConvPlan pl;
     T2V_TRY(build_conv_plan(d, x_cs, false, &pl));
     hipStream_t s = (hipStream_t)stream;
-    if (d->algo == T2V_ALGO_WINOGRAD) {
-        T2V_REQUIRE(winograd_supported(d, x_cs), "pack_weight: Winograd not supported for this shape");
-        return launch_winograd_weight(s, w_torch_dev, packed_dev, d->Cout, d->Cin, pl.Cout_p, x_cs);
+    if (is_winograd(d->algo)) {
+        T2V_REQUIRE(winograd_supported(d, x_cs, d->algo), "pack_weight: Winograd not supported for this shape");
+        return (d->algo == T2V_ALGO_WINOGRAD_F4 ? launch_winograd4_weight : launch_winograd_weight)(
+            s, w_torch_dev, packed_dev, d->Cout, d->Cin, pl.Cout_p, x_cs);
     }
     if (!d->transposed)
         return launch_pack_conv_weight(s, w_torch_dev, packed_dev, d->Cout, d->Cin, d->kH, d->kW, x_cs, pl.kp.ph[0].Kp,
@@ -276,7 +301,7 @@ int t2v_conv_pack_weight(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, int
 }
 
 size_t t2v_conv_stats_floats(const t2v_conv_desc* d) {
-    if (d && d->algo == T2V_ALGO_WINOGRAD) return (size_t)(d->H * d->W / 128) * d->Cout * 2;   // one partial per 128 pixels
+    if (d && is_winograd(d->algo)) return (size_t)(d->H * d->W / 128) * d->Cout * 2;   // one partial per 128 pixels
     ConvPlan pl;
     if (!d || build_conv_plan(d, round_up(d->Cin, 4), true, &pl) != T2V_OK) return 0;
     return (size_t)pl.nparts * d->Cout * 2;
@@ -293,7 +318,7 @@ int t2v_conv2d_forward(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, const
 int t2v_instance_norm_finalize(t2v_ctx* ctx, void* stream, const t2v_conv_desc* producer, const float* stats_partial,
                                float eps, float* mean_rstd) {
     T2V_REQUIRE(ctx && stats_partial && mean_rstd, "inorm_finalize: null pointer");
-    if (producer && producer->algo == T2V_ALGO_WINOGRAD) {   // the output transform emits one partial per 128 pixels
+    if (producer && is_winograd(producer->algo)) {   // the output transform emits one partial per 128 pixels
         const int M = producer->H * producer->W;
         return launch_inorm_finalize((hipStream_t)stream, stats_partial, M / 128, M / 128, 128, M, producer->Cout, eps,
                                      mean_rstd);

@@ -15,8 +15,17 @@ struct ConvPlan {
 };
 
 int build_conv_plan(const t2v_conv_desc* d, int x_cs, bool need_stats, ConvPlan* out);
-bool winograd_supported(const t2v_conv_desc* d, int x_cs);
+inline bool is_winograd(int algo) { return algo == T2V_ALGO_WINOGRAD || algo == T2V_ALGO_WINOGRAD_F4; }
+inline int wino_m(int algo) { return algo == T2V_ALGO_WINOGRAD_F4 ? 4 : 2; }          // output tile edge
+inline int wino_pos(int algo) { return (wino_m(algo) + 2) * (wino_m(algo) + 2); }    // transform positions: 16 | 36
+inline size_t winograd_workspace_floats(const t2v_conv_desc* d) {                    // V + M
+    const int m = wino_m(d->algo);
+    return (size_t)wino_pos(d->algo) * (d->H / m) * (d->W / m) * ((size_t)d->Cin + d->Cout);
+}
+bool winograd_supported(const t2v_conv_desc* d, int x_cs, int algo);
 int build_winograd_gemm_plan(const t2v_conv_desc* d, ConvPlan* pl);
+int winograd_forward(t2v_ctx* ctx, hipStream_t s, const t2v_conv_desc* d, const float* x, const float* w_packed,
+                     const float* bias, float* y, float* stats_partial, float* workspace, int stages);
 int run_conv(t2v_ctx* ctx, hipStream_t s, const ConvPlan& pl, const float* x, const float* w, const float* bias,
              float* y, int y_cs, float* stats);
 

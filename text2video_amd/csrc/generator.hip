@@ -56,7 +56,10 @@ void enumerate_layers(const t2v_gen_desc& g, std::vector<LayerSpec>& out) {
         const int C = G << n;
         t2v_conv_desc cd = mk_conv(H >> n, W >> n, C, C, 3, 1, 1, T2V_PAD_REFLECT, 0);
         // the ResnetBlock convs (84 % of the FLOPs) run as Winograd F(2x2,3x3) wherever the geometry allows
-        if (g.conv_algo == 0 && winograd_supported(&cd, C)) cd.algo = T2V_ALGO_WINOGRAD;
+        if (g.conv_algo == 0 && winograd_supported(&cd, C, T2V_ALGO_WINOGRAD_F4))
+            cd.algo = T2V_ALGO_WINOGRAD_F4;
+        else if ((g.conv_algo == 0 || g.conv_algo == 2) && winograd_supported(&cd, C, T2V_ALGO_WINOGRAD))
+            cd.algo = T2V_ALGO_WINOGRAD;
         for (int i = 0; i < 2 * count; ++i) out.push_back({cd, C, true});
     };
     auto ups = [&]() {
@@ -135,8 +138,8 @@ void plan_buffers(const t2v_gen_desc& g, const std::vector<LayerSpec>& layers, A
     b.mean_rstd = a.alloc((size_t)max_c * 2);
     size_t max_wino = 0;
     for (const LayerSpec& L : layers)
-        if (L.cd.algo == T2V_ALGO_WINOGRAD) {
-            const size_t w = (size_t)16 * (L.cd.H / 2) * (L.cd.W / 2) * ((size_t)L.cd.Cin + L.cd.Cout);
+        if (is_winograd(L.cd.algo)) {
+            const size_t w = winograd_workspace_floats(&L.cd);
             if (w > max_wino) max_wino = w;
         }
     b.wino = max_wino ? a.alloc(max_wino) : nullptr;
@@ -159,14 +162,9 @@ struct Runner {
         ++li;
         ConvPlan pl;
         const int Cout = L.cd.Cout;
-        if (L.cd.algo == T2V_ALGO_WINOGRAD) {
-            const int H = L.cd.H, W = L.cd.W, M = H * W;
-            float* V = b.wino;
-            float* Mm = b.wino + (size_t)16 * (H / 2) * (W / 2) * L.cd.Cin;
-            T2V_TRY(launch_winograd_input(s, x, V, H, W, L.cd.Cin));
-            T2V_TRY(build_winograd_gemm_plan(&L.cd, &pl));
-            T2V_TRY(run_conv(ctx, s, pl, V, w.w, nullptr, Mm, Cout, nullptr));
-            T2V_TRY(launch_winograd_output(s, Mm, w.bias, y, b.stats, H, W, Cout));
+        if (is_winograd(L.cd.algo)) {
+            const int M = L.cd.H * L.cd.W;
+            T2V_TRY(winograd_forward(ctx, s, &L.cd, x, w.w, w.bias, y, b.stats, b.wino, 7));
             T2V_TRY(launch_inorm_finalize(s, b.stats, M / 128, M / 128, 128, M, Cout, g.eps, b.mean_rstd));
             const float* gam = g.norm_affine ? w.gamma : nullptr;
             const float* bet = g.norm_affine ? w.beta : nullptr;

@@ -113,6 +113,9 @@ int launch_loss_backward(hipStream_t s, int op, const float* a, const float* b, 
 int launch_winograd_weight(hipStream_t s, const float* w, float* U, int Cout, int Cin, int Cout_p, int Cin_s);
 int launch_winograd_input(hipStream_t s, const float* x, float* V, int H, int W, int C);
 int launch_winograd_output(hipStream_t s, const float* Mm, const float* bias, float* y, float* stats, int H, int W, int N);
+int launch_winograd4_weight(hipStream_t s, const float* w, float* U, int Cout, int Cin, int Cout_p, int Cin_s);
+int launch_winograd4_input(hipStream_t s, const float* x, float* V, int H, int W, int C);
+int launch_winograd4_output(hipStream_t s, const float* Mm, const float* bias, float* y, float* stats, int H, int W, int N);
 int launch_channel_sum(hipStream_t s, const float* x, long npix, int C, int cs, float* scratch, float* out);
 
 // 7x7 reflect-padded head convolution with <= 3 output channels (conv_head.hip)

@@ -16,6 +16,7 @@
 // Layouts: V [16][T][C], M [16][T][N] (T = H/2 * W/2 tiles, channels contiguous) -- both are NHWC
 // tensors of 16*T "pixels", so the GEMM kernel's loader / epilogue need nothing new.
 #include "t2v_internal.h"
+#include "winograd_f4_consts.h"
 
 namespace t2v {
 
@@ -122,6 +123,36 @@ int launch_winograd_input(hipStream_t s, const float* x, float* V, int H, int W,
     return T2V_OK;
 }
 
+// (mean, M2) of a block's 128 output pixels per channel: each of the 4 tile lanes holds 32 of them.
+// Two passes, tree-summed (exact for constant maps), written as the partial inorm_finalize merges.
+__device__ __forceinline__ void block_stats_128(const float (&val)[32], float (*sh)[64], int tl, int cl, bool ok,
+                                                float2* __restrict__ stats, int N, int n) {
+    if (stats == nullptr) return;
+    float mean_b = 0.f;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        float v[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const float dlt = val[i] - mean_b;
+            v[i] = pass ? dlt * dlt : val[i];
+        }
+#pragma unroll
+        for (int w = 16; w >= 1; w >>= 1)
+#pragma unroll
+            for (int i = 0; i < w; ++i) v[i] += v[i + w];
+        sh[tl][cl] = v[0];
+        __syncthreads();
+        const float tot = (sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl]);
+        __syncthreads();
+        if (pass == 0) {
+            mean_b = tot * (1.f / 128.f);
+        } else if (tl == 0 && ok) {
+            stats[(size_t)blockIdx.x * N + n] = make_float2(mean_b, tot);
+        }
+    }
+}
+
 // y = A^T M A + bias,  A^T = [[1,1,1,0],[0,1,-1,-1]];  block = 64 channels x 4 tile lanes, 32 tiles = 128
 // output pixels per block => exactly the (mean_b, M2_b) partial per 128 pixels that inorm_finalize merges.
 __global__ __launch_bounds__(256) void winograd_output_kernel(const float* __restrict__ Mm, const float* __restrict__ bias,
@@ -135,7 +166,6 @@ __global__ __launch_bounds__(256) void winograd_output_kernel(const float* __res
     const bool ok = n < N;
     const float bv = (ok && bias) ? bias[n] : 0.f;
     float out[8][4];
-    float sum = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const long tile = (long)blockIdx.x * 32 + tl + 4 * i;
@@ -161,37 +191,172 @@ __global__ __launch_bounds__(256) void winograd_output_kernel(const float* __res
                 for (int b = 0; b < 2; ++b) y[((long)(2 * ty + a) * W + 2 * tx + b) * N + n] = out[i][a * 2 + b];
         }
     }
-    if (stats == nullptr) return;
-    // two-pass (mean, M2) over the block's 128 pixels, tree-summed (exact for constant maps)
+    float v[32];
 #pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-        float v[32];
-        const float mean_b = pass ? sum : 0.f;
+    for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float dlt = out[i][k] - mean_b;
-                v[i * 4 + k] = pass ? dlt * dlt : out[i][k];
-            }
-#pragma unroll
-        for (int w = 16; w >= 1; w >>= 1)
-#pragma unroll
-            for (int i = 0; i < w; ++i) v[i] += v[i + w];
-        sh[tl][cl] = v[0];
-        __syncthreads();
-        const float tot = (sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl]);
-        __syncthreads();
-        if (pass == 0) {
-            sum = tot * (1.f / 128.f);
-        } else if (tl == 0 && ok) {
-            stats[(size_t)blockIdx.x * N + n] = make_float2(sum, tot);
-        }
-    }
+        for (int k = 0; k < 4; ++k) v[i * 4 + k] = out[i][k];
+    block_stats_128(v, sh, tl, cl, ok, stats, N, n);
 }
 int launch_winograd_output(hipStream_t s, const float* Mm, const float* bias, float* y, float* stats, int H, int W, int N) {
     const long T = (long)(H / 2) * (W / 2);
     hipLaunchKernelGGL(winograd_output_kernel, dim3((int)(T / 32), (N + 63) / 64), dim3(256), 0, s, Mm, bias, y,
+                       reinterpret_cast<float2*>(stats), H, W, N);
+    T2V_HIP_CHECK(hipGetLastError());
+    return T2V_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// F(4x4,3x3): 36 products per 16 outputs (2.25 per output; F(2x2) needs 4, the direct conv 9).  6x6 input
+// patches at stride 4, interpolation points {0, +-3/4, +-3/2, inf} (winograd_f4_consts.h: the textbook
+// {0, +-1, +-2} cost ~2x the fp32 rounding error).  V / M shrink to 36/16 = 2.25x the activation (F(2x2): 4x),
+// so the memory-bound transforms get cheaper as well.  Same layouts: U [36][Cout_p][Cin_s], V [36][T][C],
+// M [36][T][N] with T = H/4 * W/4.
+template <int K>
+__device__ __forceinline__ float cdot(const double (&row)[K], const float (&v)[K]) {
+    float acc = 0.f;
+    bool first = true;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        if (row[k] != 0.0) {   // compile-time after unrolling: x * 0 is not foldable under IEEE rules
+            const float t = (float)row[k] * v[k];
+            acc = first ? t : acc + t;
+            first = false;
+        }
+    }
+    return acc;
+}
+
+__global__ void winograd4_weight_kernel(const float* __restrict__ w, float* __restrict__ U, int Cout, int Cin, int Cout_p,
+                                        int Cin_s) {
+    const long total = (long)Cout_p * Cin_s;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int n = (int)(i / Cin_s), c = (int)(i - (long)n * Cin_s);
+        double g[3][3], t[6][3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) g[a][b] = (n < Cout && c < Cin) ? (double)w[(((size_t)n * Cin + c) * 3 + a) * 3 + b] : 0.0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) t[a][b] = f4::kG[a][0] * g[0][b] + f4::kG[a][1] * g[1][b] + f4::kG[a][2] * g[2][b];
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int b = 0; b < 6; ++b) {
+                const double u = t[a][0] * f4::kG[b][0] + t[a][1] * f4::kG[b][1] + t[a][2] * f4::kG[b][2];
+                U[((size_t)(a * 6 + b) * Cout_p + n) * Cin_s + c] = (float)u;   // transformed in fp64, rounded once
+            }
+    }
+}
+int launch_winograd4_weight(hipStream_t s, const float* w, float* U, int Cout, int Cin, int Cout_p, int Cin_s) {
+    hipLaunchKernelGGL(winograd4_weight_kernel, dim3(wg_grid((long)Cout_p * Cin_s, 256)), dim3(256), 0, s, w, U, Cout, Cin,
+                       Cout_p, Cin_s);
+    T2V_HIP_CHECK(hipGetLastError());
+    return T2V_OK;
+}
+
+// V[a*6+b][tile][c] = (B^T d B)[a][b]; one thread = one tile x 2 channels (float2; 36 live values each)
+__global__ __launch_bounds__(256) void winograd4_input_kernel(const float2* __restrict__ x, float2* __restrict__ V, int H,
+                                                              int W, int C2) {
+    const int TW = W >> 2;
+    const long T = (long)(H >> 2) * TW;
+    const long total = T * C2;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const long tile = i / C2;
+        const int c2 = (int)(i - tile * C2);
+        const int ty = (int)(tile / TW), tx = (int)(tile - (long)ty * TW);
+        int ry[6], rx[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            int yy = 4 * ty - 1 + k, xx = 4 * tx - 1 + k;
+            yy = yy < 0 ? -yy : yy;
+            xx = xx < 0 ? -xx : xx;
+            ry[k] = min(yy, 2 * H - 2 - yy);
+            rx[k] = min(xx, 2 * W - 2 - xx);
+        }
+        // rows first: r[a][j] = sum_b B^T[j][b] d[a][b]
+        float rxv[6][6], ryv[6][6];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            float dx[6], dy[6];
+#pragma unroll
+            for (int b = 0; b < 6; ++b) {
+                const float2 d = x[((long)ry[a] * W + rx[b]) * C2 + c2];
+                dx[b] = d.x;
+                dy[b] = d.y;
+            }
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                rxv[a][j] = cdot<6>(f4::kBT[j], dx);
+                ryv[a][j] = cdot<6>(f4::kBT[j], dy);
+            }
+        }
+        // columns: v[a2][j] = sum_a B^T[a2][a] r[a][j]
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            float cx[6], cy[6];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                cx[a] = rxv[a][j];
+                cy[a] = ryv[a][j];
+            }
+#pragma unroll
+            for (int a2 = 0; a2 < 6; ++a2)
+                V[((long)(a2 * 6 + j) * T + tile) * C2 + c2] = make_float2(cdot<6>(f4::kBT[a2], cx), cdot<6>(f4::kBT[a2], cy));
+        }
+    }
+}
+int launch_winograd4_input(hipStream_t s, const float* x, float* V, int H, int W, int C) {
+    const long total = (long)(H / 4) * (W / 4) * (C / 2);
+    hipLaunchKernelGGL(winograd4_input_kernel, dim3(wg_grid(total, 256)), dim3(256), 0, s,
+                       reinterpret_cast<const float2*>(x), reinterpret_cast<float2*>(V), H, W, C / 2);
+    T2V_HIP_CHECK(hipGetLastError());
+    return T2V_OK;
+}
+
+// y = A^T M A + bias; block = 64 channels x 4 tile lanes, 8 tiles (2 per thread) = 128 output pixels
+__global__ __launch_bounds__(256) void winograd4_output_kernel(const float* __restrict__ Mm, const float* __restrict__ bias,
+                                                               float* __restrict__ y, float2* __restrict__ stats, int H,
+                                                               int W, int N) {
+    __shared__ float sh[4][64];
+    const int TW = W >> 2;
+    const long T = (long)(H >> 2) * TW;
+    const int cl = threadIdx.x & 63, tl = threadIdx.x >> 6;
+    const int n = blockIdx.y * 64 + cl;
+    const bool ok = n < N;
+    const float bv = (ok && bias) ? bias[n] : 0.f;
+    float out[32];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const long tile = (long)blockIdx.x * 8 + tl + 4 * i;
+        float r[4][6];   // r[i2][b] = sum_a A^T[i2][a] m[a][b]
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+            float m[6];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) m[a] = ok ? Mm[((long)(a * 6 + b) * T + tile) * N + n] : 0.f;
+#pragma unroll
+            for (int i2 = 0; i2 < 4; ++i2) r[i2][b] = cdot<6>(f4::kAT[i2], m);
+        }
+        const int ty = (int)(tile / TW), tx = (int)(tile - (long)ty * TW);
+#pragma unroll
+        for (int i2 = 0; i2 < 4; ++i2)
+#pragma unroll
+            for (int j2 = 0; j2 < 4; ++j2) {
+                const float v = cdot<6>(f4::kAT[j2], r[i2]) + bv;
+                out[i * 16 + i2 * 4 + j2] = v;
+                if (ok) y[((long)(4 * ty + i2) * W + 4 * tx + j2) * N + n] = v;
+            }
+    }
+    block_stats_128(out, sh, tl, cl, ok, stats, N, n);
+}
+int launch_winograd4_output(hipStream_t s, const float* Mm, const float* bias, float* y, float* stats, int H, int W, int N) {
+    const long T = (long)(H / 4) * (W / 4);
+    hipLaunchKernelGGL(winograd4_output_kernel, dim3((int)(T / 8), (N + 63) / 64), dim3(256), 0, s, Mm, bias, y,
                        reinterpret_cast<float2*>(stats), H, W, N);
     T2V_HIP_CHECK(hipGetLastError());
     return T2V_OK;

@@ -11,7 +11,8 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import ACT_FLOW_W, ACT_LRELU, ACT_NONE, ACT_TANH, PAD_REFLECT, PAD_ZERO, ConvDesc, check  # noqa: F401
+from ._lib import (ACT_FLOW_W, ACT_LRELU, ACT_NONE, ACT_TANH, ALGO_DIRECT, ALGO_WINOGRAD,  # noqa: F401
+                   ALGO_WINOGRAD_F4, PAD_REFLECT, PAD_ZERO, ConvDesc, check)
 
 _contexts = {}
 
@@ -54,21 +55,32 @@ def conv_desc(H, W, Cin, Cout, k, stride=1, pad=0, pad_mode=PAD_ZERO, transposed
                     algo)
 
 
-def winograd_supported(desc, x_cs=None):
+def winograd_supported(desc, x_cs=None, algo=None):
+    """True when `desc` can run as the Winograd variant `algo` (default: desc.algo, or F(2x2,3x3) for a direct desc)."""
     x_cs = round_up(desc.Cin, 4) if x_cs is None else x_cs
-    return bool(_lib.load().t2v_conv_winograd_supported(ctypes.byref(desc), x_cs))
+    algo = (desc.algo or ALGO_WINOGRAD) if algo is None else algo
+    mask = _lib.load().t2v_conv_winograd_supported(ctypes.byref(desc), x_cs)
+    return bool(mask & (2 if algo == ALGO_WINOGRAD_F4 else 1))
 
 
-def conv2d_winograd(x, packed_u, bias, desc, stats=None, out=None):
-    """3x3 stride-1 reflect-pad-1 conv through Winograd F(2x2,3x3) (desc.algo must be ALGO_WINOGRAD)."""
+def winograd_workspace(desc, x_cs, device):
+    n = _lib.load().t2v_conv_winograd_workspace_floats(ctypes.byref(desc), x_cs)
+    if n == 0:
+        raise RuntimeError("winograd_workspace: shape not supported")
+    return torch.empty(n, dtype=torch.float32, device=device)
+
+
+def conv2d_winograd(x, packed_u, bias, desc, stats=None, out=None, workspace=None, stages=7):
+    """3x3 stride-1 reflect-pad-1 conv through Winograd (desc.algo: ALGO_WINOGRAD F(2x2,3x3) | ALGO_WINOGRAD_F4 F(4x4,3x3)).
+    stages: bit mask 1 = input transform, 2 = batched GEMM, 4 = output transform (all by default)."""
     c = context()
     _chk(x, "x")
     x_cs = x.shape[-1]
-    nws = c.lib.t2v_conv_winograd_workspace_floats(ctypes.byref(desc), x_cs)
-    ws = torch.empty(nws, dtype=torch.float32, device=x.device)
+    ws = workspace if workspace is not None else winograd_workspace(desc, x_cs, x.device)
     y = out if out is not None else torch.empty(desc.H, desc.W, desc.Cout, dtype=torch.float32, device=x.device)
-    check(c.lib.t2v_conv2d_forward_winograd(c.handle, _stream(), ctypes.byref(desc), _p(x), x_cs, _p(packed_u), _p(bias),
-                                            _p(y), desc.Cout, _p(stats), _p(ws)), "conv2d_forward_winograd")
+    check(c.lib.t2v_conv2d_forward_winograd_stages(c.handle, _stream(), ctypes.byref(desc), _p(x), x_cs, _p(packed_u),
+                                                   _p(bias), _p(y), desc.Cout, _p(stats), _p(ws), stages),
+          "conv2d_forward_winograd")
     return y
 
 
