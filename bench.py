@@ -165,7 +165,8 @@ def main():
         # implicit-GEMM kernel -> output transform.  The GEMM launch is the dominant kernel; its roofline is
         # priced on the MFMA FLOPs it EXECUTES (2*36*T*C*C = 1/4 [4/9] of the direct conv's algorithmic
         # 2*9*C*C*H*W), never on the direct-conv-equivalent figure.  Where the geometry has no Winograd path the direct kernel is timed.
-        C, hb, wb = 1024, H // 8, W // 8
+        g0h, g0w = (H // 2, W // 2) if args.scales == 2 else (H, W)   # G0 runs on the half-resolution pyramid level
+        C, hb, wb = 1024, g0h // 8, g0w // 8
         direct = ops.conv_desc(hb, wb, C, C, 3, 1, 1, ops.PAD_REFLECT)
         # same selection as the generator (generator.hip enumerate_layers): F(4x4,3x3) > F(2x2,3x3) > direct
         cap = int(os.environ.get("T2V_CONV_ALGO", "0"))
