@@ -96,8 +96,9 @@ int t2v_conv2d_forward(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, const
                        float* stats_partial);
 
 /* Bit mask of the Winograd variants `d` (algo ignored) can run as: 1 = F(2x2,3x3), 2 = F(4x4,3x3).
- * Needs 3x3, stride 1, ReflectionPad 1, Cin % 32 == 0 == x_cs, Cout % 4 == 0, H and W multiples of the
- * output tile m (2 | 4) and (H/m)*(W/m) a multiple of 128. */
+ * Needs 3x3, stride 1, ReflectionPad 1, Cin % 32 == 0 == x_cs, Cout % 4 == 0, no activation.  Any H, W >= 2:
+ * the ceil(H/m) x ceil(W/m) tile grid (m = 2 | 4) is ragged at the bottom / right edge and padded with
+ * empty tiles to a multiple of 128 (extra GEMM rows, masked in the output transform). */
 int t2v_conv_winograd_supported(const t2v_conv_desc* d, int x_cs);
 /* floats of scratch (transformed input V + transformed output M) a Winograd forward needs */
 size_t t2v_conv_winograd_workspace_floats(const t2v_conv_desc* d, int x_cs);

@@ -52,6 +52,8 @@ CASES = [
     # bottleneck 64x32 / 32x64 (128 tiles of 4x4): Winograd F(4x4,3x3)
     ("winograd_f4_noflow", dict(ngf=16, n_downsample=2, n_blocks=3, no_flow=True, norm="instance"), 1, 256, 128),
     ("winograd_f4_flow", dict(ngf=16, n_downsample=2, n_blocks=2, no_flow=False, norm="batch"), 1, 128, 256),
+    # odd bottleneck 32x85 (ragged 4x4 tile grid, zero-tile padding): the 512x680 fadg0 geometry scaled down
+    ("winograd_ragged_680like", dict(ngf=16, n_downsample=2, n_blocks=2, no_flow=False, norm="batch"), 1, 128, 340),
 ]
 
 
@@ -77,7 +79,9 @@ def test_winograd_is_selected_and_matches_direct():
     a = algos(128, 64, 0)
     rb = [i for i, (ck, nk, kind) in enumerate(keys) if ".conv_block" in str(ck)]
     assert len(rb) >= 6 and [i for i, v in enumerate(a) if v == _lib.ALGO_WINOGRAD] == rb, (a, rb)
-    assert sum(algos(128, 64, 1)) == 0 and sum(algos(64, 64, 0)) == 0
+    assert sum(algos(128, 64, 1)) == 0 and sum(algos(16, 16, 0)) == 0     # 4x4 bottleneck: padding to 128 tiles never pays
+    a85 = algos(64, 4 * 85, 0)       # odd 16x85 bottleneck (the 512x680 geometry in small): ragged F(4x4) grid
+    assert [i for i, v in enumerate(a85) if v == _lib.ALGO_WINOGRAD_F4] == rb
     a4 = algos(256, 128, 0)     # enough 4x4 tiles: F(4x4,3x3); conv_algo=2 caps it at F(2x2,3x3)
     assert [i for i, v in enumerate(a4) if v == _lib.ALGO_WINOGRAD_F4] == rb and sum(a4) == 2 * len(rb)
     assert [i for i, v in enumerate(algos(256, 128, 2)) if v == _lib.ALGO_WINOGRAD] == rb

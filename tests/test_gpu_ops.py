@@ -260,8 +260,14 @@ def test_conv_bitwise_repeatable_race_screen(case):
 
 
 @pytest.mark.parametrize("case", [(1, 32, 16, 32, 64), (1, 64, 64, 64, 96), (1, 16, 64, 128, 32),
-                                  (2, 64, 32, 32, 64), (2, 64, 64, 64, 96), (2, 32, 128, 128, 32), (2, 128, 128, 32, 32)],
-                         ids=["F2-T128", "F2-T1024", "F2-T512", "F4-T128", "F4-T256", "F4-T256w", "F4-T1024"])
+                                  (2, 64, 32, 32, 64), (2, 64, 64, 64, 96), (2, 32, 128, 128, 32), (2, 128, 128, 32, 32),
+                                  # ragged tile grids: odd sizes, sizes that are no multiple of the output tile,
+                                  # tile counts that need zero-tile padding to 128 (the real fadg0 geometries
+                                  # 512x680 / 512x320 have 64x85 / 64x40 bottlenecks)
+                                  (1, 64, 85, 32, 64), (2, 64, 85, 32, 64), (2, 64, 40, 64, 32), (1, 9, 7, 32, 32),
+                                  (2, 9, 7, 32, 32), (2, 2, 2, 32, 32), (1, 3, 2, 32, 4), (2, 34, 130, 32, 32)],
+                         ids=["F2-T128", "F2-T1024", "F2-T512", "F4-T128", "F4-T256", "F4-T256w", "F4-T1024",
+                              "F2-64x85", "F4-64x85", "F4-64x40", "F2-9x7", "F4-9x7", "F4-2x2", "F2-3x2", "F4-34x130"])
 def test_winograd_conv_matches_direct_and_reference(case):
     """F(2x2,3x3) / F(4x4,3x3): input transform -> 16 | 36 grouped GEMMs -> output transform (+bias, +norm statistics)."""
     from text2video_amd import ops
@@ -291,7 +297,7 @@ def test_winograd_conv_matches_direct_and_reference(case):
     ref_n = F.relu(F.instance_norm(ref.unsqueeze(0), eps=1e-5))[0]
     assert (_from_nhwc(yn, Cout) - ref_n).abs().max().item() <= 3e-4
     # unsupported shapes are refused, not silently run
-    bad = ops.conv_desc(10, 10, Cin, Cout, 3, 1, 1, ops.PAD_REFLECT, algo=algo)
+    bad = ops.conv_desc(10, 1, Cin, Cout, 3, 1, 1, ops.PAD_REFLECT, algo=algo)   # reflection needs >= 2 pixels
     assert not ops.winograd_supported(bad, Cin)
     with pytest.raises(RuntimeError):
         ops.pack_conv_weight(w.to(_dev()), bad, Cin)

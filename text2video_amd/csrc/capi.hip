@@ -143,23 +143,21 @@ bool winograd_supported(const t2v_conv_desc* d, int x_cs, int algo) {
     if (!d || !is_winograd(algo)) return false;
     if (d->transposed || d->kH != 3 || d->kW != 3 || d->stride != 1 || d->pad != 1 || d->pad_mode != T2V_PAD_REFLECT)
         return false;
-    const int m = wino_m(algo);
-    if (d->Cin % 32 != 0 || x_cs != d->Cin || d->Cout % 4 != 0 || d->H % m || d->W % m || d->H < m || d->W < m) return false;
-    // T tiles: whole 128-row GEMM tiles per transform position, whole 128-pixel blocks in the output transform
-    const long T = (long)(d->H / m) * (d->W / m);
-    return T % 128 == 0 && d->act == T2V_ACT_NONE;
+    // any H, W >= 2 (reflection needs 2): ragged tiles are masked, the tile count is padded to 128
+    if (d->Cin % 32 != 0 || x_cs != d->Cin || d->Cout % 4 != 0 || d->H < 2 || d->W < 2) return false;
+    return d->act == T2V_ACT_NONE;
 }
 
 // the batched GEMM of a Winograd conv as a plan of the implicit-GEMM kernel: a 1x1 conv over a 16|36 x T image
 int build_winograd_gemm_plan(const t2v_conv_desc* d, ConvPlan* pl) {
-    const int m = wino_m(d->algo);
-    const int T = (d->H / m) * (d->W / m);
+    const int T = wino_tiles_padded(d, d->algo);
     t2v_conv_desc g;
     memset(&g, 0, sizeof(g));
     g.H = wino_pos(d->algo); g.W = T; g.Cin = d->Cin; g.Cout = d->Cout; g.kH = g.kW = 1; g.stride = 1; g.pad = 0;
     g.pad_mode = T2V_PAD_ZERO; g.act = T2V_ACT_NONE; g.act_scale = 1.f;
-    T2V_TRY(build_conv_plan(&g, d->Cin, false, pl));
-    pl->kp.group_mtiles = T / pl->BM;               // T % 128 == 0 and BM in {128, 64}
+    T2V_TRY(build_conv_plan(&g, d->Cin, /*need_stats: 128- or 64-row tiles only*/ true, pl));
+    pl->kp.group_mtiles = T / pl->BM;               // T % 128 == 0 and BM in {128, 64, 256?}: checked below
+    T2V_REQUIRE(T % pl->BM == 0, "winograd gemm: tile rows %d do not divide %d", pl->BM, T);
     pl->kp.group_w_stride = (long)pl->Cout_p * d->Cin;
     return T2V_OK;
 }
@@ -196,8 +194,7 @@ int run_conv(t2v_ctx* ctx, hipStream_t s, const ConvPlan& pl, const float* x, co
 // 2 = batched GEMM, 4 = output transform
 int winograd_forward(t2v_ctx* ctx, hipStream_t s, const t2v_conv_desc* d, const float* x, const float* w_packed,
                      const float* bias, float* y, float* stats_partial, float* workspace, int stages) {
-    const int m = wino_m(d->algo);
-    const size_t T = (size_t)(d->H / m) * (d->W / m);
+    const size_t T = (size_t)wino_tiles_padded(d, d->algo);
     float* V = workspace;
     float* Mm = workspace + wino_pos(d->algo) * T * d->Cin;
     const bool f4 = d->algo == T2V_ALGO_WINOGRAD_F4;
@@ -301,7 +298,8 @@ int t2v_conv_pack_weight(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, int
 }
 
 size_t t2v_conv_stats_floats(const t2v_conv_desc* d) {
-    if (d && is_winograd(d->algo)) return (size_t)(d->H * d->W / 128) * d->Cout * 2;   // one partial per 128 pixels
+    if (d && is_winograd(d->algo))   // one partial per 128 output-pixel slots of the padded tile grid
+        return (size_t)(wino_tiles_padded(d, d->algo) * wino_m(d->algo) * wino_m(d->algo) / 128) * d->Cout * 2;
     ConvPlan pl;
     if (!d || build_conv_plan(d, round_up(d->Cin, 4), true, &pl) != T2V_OK) return 0;
     return (size_t)pl.nparts * d->Cout * 2;
@@ -319,9 +317,8 @@ int t2v_instance_norm_finalize(t2v_ctx* ctx, void* stream, const t2v_conv_desc* 
                                float eps, float* mean_rstd) {
     T2V_REQUIRE(ctx && stats_partial && mean_rstd, "inorm_finalize: null pointer");
     if (producer && is_winograd(producer->algo)) {   // the output transform emits one partial per 128 pixels
-        const int M = producer->H * producer->W;
-        return launch_inorm_finalize((hipStream_t)stream, stats_partial, M / 128, M / 128, 128, M, producer->Cout, eps,
-                                     mean_rstd);
+        return launch_inorm_finalize_winograd((hipStream_t)stream, stats_partial, wino_m(producer->algo), producer->H,
+                                              producer->W, producer->Cout, eps, mean_rstd);
     }
     ConvPlan pl;
     T2V_TRY(build_conv_plan(producer, round_up(producer ? producer->Cin : 0, 4), true, &pl));

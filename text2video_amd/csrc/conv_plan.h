@@ -18,10 +18,17 @@ int build_conv_plan(const t2v_conv_desc* d, int x_cs, bool need_stats, ConvPlan*
 inline bool is_winograd(int algo) { return algo == T2V_ALGO_WINOGRAD || algo == T2V_ALGO_WINOGRAD_F4; }
 inline int wino_m(int algo) { return algo == T2V_ALGO_WINOGRAD_F4 ? 4 : 2; }          // output tile edge
 inline int wino_pos(int algo) { return (wino_m(algo) + 2) * (wino_m(algo) + 2); }    // transform positions: 16 | 36
-inline size_t winograd_workspace_floats(const t2v_conv_desc* d) {                    // V + M
-    const int m = wino_m(d->algo);
-    return (size_t)wino_pos(d->algo) * (d->H / m) * (d->W / m) * ((size_t)d->Cin + d->Cout);
+// tiles of the ceil(H/m) x ceil(W/m) grid, padded to whole 128-row GEMM tiles per transform position
+inline int wino_tiles_padded(const t2v_conv_desc* d, int algo) {
+    const int m = wino_m(algo);
+    const int T = ((d->H + m - 1) / m) * ((d->W + m - 1) / m);
+    return (T + 127) / 128 * 128;
 }
+inline size_t winograd_workspace_floats(const t2v_conv_desc* d) {                    // V + M
+    return (size_t)wino_pos(d->algo) * wino_tiles_padded(d, d->algo) * ((size_t)d->Cin + d->Cout);
+}
+// GEMM rows of the whole conv (all positions): what the algorithm choice compares
+inline long wino_gemm_rows(const t2v_conv_desc* d, int algo) { return (long)wino_pos(algo) * wino_tiles_padded(d, algo); }
 bool winograd_supported(const t2v_conv_desc* d, int x_cs, int algo);
 int build_winograd_gemm_plan(const t2v_conv_desc* d, ConvPlan* pl);
 int winograd_forward(t2v_ctx* ctx, hipStream_t s, const t2v_conv_desc* d, const float* x, const float* w_packed,

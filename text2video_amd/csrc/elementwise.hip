@@ -35,17 +35,31 @@ __device__ __forceinline__ void chan_merge(Moments& a, float nb, float mb, float
 }
 
 // block = 16 slices x 16 channels; grid = ceil(C/16)
+// Pixel count of partial `part`: conv-kernel partials cover BM consecutive GEMM rows of a phase; the Winograd
+// output transform's partials (wm = 2 | 4 > 0) cover 128/wm^2 consecutive wm x wm tiles of the ceil(H/wm) x
+// ceil(W/wm) tile grid, ragged at the bottom / right edge and padded with empty tiles at the end.
 __global__ __launch_bounds__(256) void inorm_finalize_kernel(const float2* __restrict__ stats, int nparts, int mtiles,
                                                              int BM, int M, int C, float eps,
-                                                             float2* __restrict__ mean_rstd) {
+                                                             float2* __restrict__ mean_rstd, int wm, int H, int W) {
     __shared__ float sh[3][16][17];
     const int cc = threadIdx.x & 15, sl = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cc;
     Moments a{0.f, 0.f, 0.f};
     if (c < C) {
         for (int part = sl; part < nparts; part += 16) {
-            const int mt = part % mtiles;
-            const int nb = min(BM, M - mt * BM);
+            int nb;
+            if (wm == 0) {
+                const int mt = part % mtiles;
+                nb = min(BM, M - mt * BM);
+            } else {
+                const int TW = (W + wm - 1) / wm, T = ((H + wm - 1) / wm) * TW, tpb = 128 / (wm * wm);
+                nb = 0;
+                for (int t = part * tpb; t < min((part + 1) * tpb, T); ++t) {
+                    const int ty = t / TW, tx = t - ty * TW;
+                    nb += min(wm, H - wm * ty) * min(wm, W - wm * tx);
+                }
+                if (nb == 0) continue;
+            }
             const float2 v = stats[(size_t)part * C + c];
             chan_merge(a, (float)nb, v.x, v.y);
         }
@@ -65,7 +79,18 @@ int launch_inorm_finalize(hipStream_t s, const float* stats, int nparts, int mti
                           float eps, float* mean_rstd) {
     hipLaunchKernelGGL(inorm_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, s,
                        reinterpret_cast<const float2*>(stats), nparts, mtiles, BM, M, C, eps,
-                       reinterpret_cast<float2*>(mean_rstd));
+                       reinterpret_cast<float2*>(mean_rstd), 0, 0, 0);
+    T2V_HIP_CHECK(hipGetLastError());
+    return T2V_OK;
+}
+// partials written by the Winograd output transform F(wm x wm, 3x3) of an H x W map
+int launch_inorm_finalize_winograd(hipStream_t s, const float* stats, int wm, int H, int W, int C, float eps,
+                                   float* mean_rstd) {
+    const int T = ((H + wm - 1) / wm) * ((W + wm - 1) / wm), Tp = (T + 127) / 128 * 128;
+    const int nparts = Tp / (128 / (wm * wm));
+    hipLaunchKernelGGL(inorm_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, s,
+                       reinterpret_cast<const float2*>(stats), nparts, 1, 0, H * W, C, eps,
+                       reinterpret_cast<float2*>(mean_rstd), wm, H, W);
     T2V_HIP_CHECK(hipGetLastError());
     return T2V_OK;
 }

@@ -56,9 +56,12 @@ void enumerate_layers(const t2v_gen_desc& g, std::vector<LayerSpec>& out) {
         const int C = G << n;
         t2v_conv_desc cd = mk_conv(H >> n, W >> n, C, C, 3, 1, 1, T2V_PAD_REFLECT, 0);
         // the ResnetBlock convs (84 % of the FLOPs) run as Winograd F(2x2,3x3) wherever the geometry allows
-        if (g.conv_algo == 0 && winograd_supported(&cd, C, T2V_ALGO_WINOGRAD_F4))
+        // F(4x4) unless the zero tiles that pad its coarser grid to 128 make F(2x2) the smaller GEMM (tiny maps)
+        const bool f4 = g.conv_algo == 0 && winograd_supported(&cd, C, T2V_ALGO_WINOGRAD_F4);
+        const bool f2 = (g.conv_algo == 0 || g.conv_algo == 2) && winograd_supported(&cd, C, T2V_ALGO_WINOGRAD);
+        if (f4 && (!f2 || wino_gemm_rows(&cd, T2V_ALGO_WINOGRAD_F4) <= wino_gemm_rows(&cd, T2V_ALGO_WINOGRAD)))
             cd.algo = T2V_ALGO_WINOGRAD_F4;
-        else if ((g.conv_algo == 0 || g.conv_algo == 2) && winograd_supported(&cd, C, T2V_ALGO_WINOGRAD))
+        else if (f2 && wino_gemm_rows(&cd, T2V_ALGO_WINOGRAD) < 9L * cd.H * cd.W)
             cd.algo = T2V_ALGO_WINOGRAD;
         for (int i = 0; i < 2 * count; ++i) out.push_back({cd, C, true});
     };
@@ -128,7 +131,11 @@ void plan_buffers(const t2v_gen_desc& g, const std::vector<LayerSpec>& layers, A
     int max_c = 4;
     for (const LayerSpec& L : layers) {
         ConvPlan pl;
-        if (L.has_norm && build_conv_plan(&L.cd, L.x_cs, true, &pl) == T2V_OK) {
+        if (L.has_norm && is_winograd(L.cd.algo)) {
+            const int m = wino_m(L.cd.algo);
+            const size_t s = (size_t)(wino_tiles_padded(&L.cd, L.cd.algo) * m * m / 128) * L.cd.Cout * 2;
+            if (s > max_stats) max_stats = s;
+        } else if (L.has_norm && build_conv_plan(&L.cd, L.x_cs, true, &pl) == T2V_OK) {
             const size_t s = (size_t)pl.nparts * L.cd.Cout * 2;
             if (s > max_stats) max_stats = s;
         }
@@ -165,7 +172,7 @@ struct Runner {
         if (is_winograd(L.cd.algo)) {
             const int M = L.cd.H * L.cd.W;
             T2V_TRY(winograd_forward(ctx, s, &L.cd, x, w.w, w.bias, y, b.stats, b.wino, 7));
-            T2V_TRY(launch_inorm_finalize(s, b.stats, M / 128, M / 128, 128, M, Cout, g.eps, b.mean_rstd));
+            T2V_TRY(launch_inorm_finalize_winograd(s, b.stats, wino_m(L.cd.algo), L.cd.H, L.cd.W, Cout, g.eps, b.mean_rstd));
             const float* gam = g.norm_affine ? w.gamma : nullptr;
             const float* bet = g.norm_affine ? w.beta : nullptr;
             if (g.norm_affine) T2V_REQUIRE(gam && bet, "layer %d: norm_affine=1 but gamma/beta missing", li - 1);

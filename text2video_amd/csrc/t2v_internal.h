@@ -135,6 +135,8 @@ void conv_tile_dims(int tile, int* BM, int* BN);
 int launch_conv_igemm(hipStream_t s, const ConvKParams& p, int tile);
 
 // elementwise.hip
+int launch_inorm_finalize_winograd(hipStream_t s, const float* stats, int wm, int H, int W, int C, float eps,
+                                   float* mean_rstd);
 int launch_inorm_finalize(hipStream_t s, const float* stats, int nparts, int mtiles, int BM, int M, int C,
                           float eps, float* mean_rstd);
 int launch_inorm_apply(hipStream_t s, const float* x, const float* mean_rstd, const float* gamma,

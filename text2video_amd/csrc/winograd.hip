@@ -13,8 +13,10 @@
 //   winograd_input_kernel  : V = B^T d B with the reflection padding folded into the patch gather
 //   winograd_output_kernel : y = A^T M A + bias, plus the instance-norm partial statistics
 //                            (mean, M2 per 128 output pixels) that the direct kernel's epilogue emits
-// Layouts: V [16][T][C], M [16][T][N] (T = H/2 * W/2 tiles, channels contiguous) -- both are NHWC
-// tensors of 16*T "pixels", so the GEMM kernel's loader / epilogue need nothing new.
+// Layouts: V [16][Tp][C], M [16][Tp][N] (channels contiguous) -- both are NHWC tensors of 16*Tp "pixels", so the
+// GEMM kernel's loader / epilogue need nothing new.  Any H, W >= 2: the tile grid is ceil(H/2) x ceil(W/2) = T tiles
+// (ragged last row / column: the transforms read clamped indices and mask their writes), padded with zero tiles to
+// Tp = a multiple of 128 so that every transform position owns whole GEMM tiles.
 #include "t2v_internal.h"
 #include "winograd_f4_consts.h"
 
@@ -67,14 +69,18 @@ int launch_winograd_weight(hipStream_t s, const float* w, float* U, int Cout, in
 // V[xi][tile][c] = (B^T d B)[xi],  d = 4x4 patch at rows 2ty-1.., cols 2tx-1.. (reflection pad 1)
 // B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]].  One thread = one tile x 4 channels (float4).
 __global__ __launch_bounds__(256) void winograd_input_kernel(const float4* __restrict__ x, float4* __restrict__ V, int H,
-                                                             int W, int C4) {
-    const int TW = W >> 1;
-    const long T = (long)(H >> 1) * TW;
-    const long total = T * C4;
+                                                             int W, int C4, int TW, int T, int Tp) {
+    const long total = (long)Tp * C4;
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
         const long tile = i / C4;
         const int c4 = (int)(i - tile * C4);
+        if (tile >= T) {   // padding tiles: zeros (their GEMM rows are never read back)
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int xi = 0; xi < 16; ++xi) V[((long)xi * Tp + tile) * C4 + c4] = z;
+            continue;
+        }
         const int ty = (int)(tile / TW), tx = (int)(tile - (long)ty * TW);
         int ry[4], rx[4];
 #pragma unroll
@@ -82,8 +88,9 @@ __global__ __launch_bounds__(256) void winograd_input_kernel(const float4* __res
             int yy = 2 * ty - 1 + k, xx = 2 * tx - 1 + k;
             yy = yy < 0 ? -yy : yy;
             xx = xx < 0 ? -xx : xx;
-            ry[k] = min(yy, 2 * H - 2 - yy);
-            rx[k] = min(xx, 2 * W - 2 - xx);
+            // rows / columns past the reflected border only feed outputs of a ragged tile that are masked
+            ry[k] = max(min(yy, 2 * H - 2 - yy), 0);
+            rx[k] = max(min(xx, 2 * W - 2 - xx), 0);
         }
         float4 d[4][4];
 #pragma unroll
@@ -108,26 +115,33 @@ __global__ __launch_bounds__(256) void winograd_input_kernel(const float4* __res
             T2V_ADD(v1, t[a][1], t[a][2])
             T2V_SUB(v2, t[a][2], t[a][1])
             T2V_SUB(v3, t[a][1], t[a][3])
-            V[((long)(a * 4 + 0) * T + tile) * C4 + c4] = v0;
-            V[((long)(a * 4 + 1) * T + tile) * C4 + c4] = v1;
-            V[((long)(a * 4 + 2) * T + tile) * C4 + c4] = v2;
-            V[((long)(a * 4 + 3) * T + tile) * C4 + c4] = v3;
+            V[((long)(a * 4 + 0) * Tp + tile) * C4 + c4] = v0;
+            V[((long)(a * 4 + 1) * Tp + tile) * C4 + c4] = v1;
+            V[((long)(a * 4 + 2) * Tp + tile) * C4 + c4] = v2;
+            V[((long)(a * 4 + 3) * Tp + tile) * C4 + c4] = v3;
         }
     }
 }
 int launch_winograd_input(hipStream_t s, const float* x, float* V, int H, int W, int C) {
-    const long total = (long)(H / 2) * (W / 2) * (C / 4);
-    hipLaunchKernelGGL(winograd_input_kernel, dim3(wg_grid(total, 256)), dim3(256), 0, s,
-                       reinterpret_cast<const float4*>(x), reinterpret_cast<float4*>(V), H, W, C / 4);
+    const int TW = (W + 1) / 2, T = ((H + 1) / 2) * TW, Tp = (T + 127) / 128 * 128;
+    hipLaunchKernelGGL(winograd_input_kernel, dim3(wg_grid((long)Tp * (C / 4), 256)), dim3(256), 0, s,
+                       reinterpret_cast<const float4*>(x), reinterpret_cast<float4*>(V), H, W, C / 4, TW, T, Tp);
     T2V_HIP_CHECK(hipGetLastError());
     return T2V_OK;
 }
 
-// (mean, M2) of a block's 128 output pixels per channel: each of the 4 tile lanes holds 32 of them.
-// Two passes, tree-summed (exact for constant maps), written as the partial inorm_finalize merges.
-__device__ __forceinline__ void block_stats_128(const float (&val)[32], float (*sh)[64], int tl, int cl, bool ok,
-                                                float2* __restrict__ stats, int N, int n) {
+// (mean, M2) of a block's <= 128 valid output pixels per channel: each of the 4 tile lanes holds 32 pixel
+// slots, `mask` marks the ones inside the image (all of them except in ragged / padding tiles).  Two passes,
+// tree-summed (exact for constant maps over power-of-two counts), written as the partial inorm_finalize
+// merges; the partial's pixel count is recomputed there from the geometry.
+__device__ __forceinline__ void block_stats_128(const float (&val)[32], unsigned mask, float (*sh)[64], int tl, int cl,
+                                                bool ok, float2* __restrict__ stats, int N, int n) {
     if (stats == nullptr) return;
+    sh[tl][cl] = (float)__popc(mask);
+    __syncthreads();
+    const float cnt = (sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl]);
+    __syncthreads();
+    const float inv_cnt = cnt > 0.f ? 1.f / cnt : 0.f;
     float mean_b = 0.f;
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
@@ -135,7 +149,7 @@ __device__ __forceinline__ void block_stats_128(const float (&val)[32], float (*
 #pragma unroll
         for (int i = 0; i < 32; ++i) {
             const float dlt = val[i] - mean_b;
-            v[i] = pass ? dlt * dlt : val[i];
+            v[i] = ((mask >> i) & 1u) ? (pass ? dlt * dlt : val[i]) : 0.f;
         }
 #pragma unroll
         for (int w = 16; w >= 1; w >>= 1)
@@ -146,7 +160,7 @@ __device__ __forceinline__ void block_stats_128(const float (&val)[32], float (*
         const float tot = (sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl]);
         __syncthreads();
         if (pass == 0) {
-            mean_b = tot * (1.f / 128.f);
+            mean_b = tot * inv_cnt;
         } else if (tl == 0 && ok) {
             stats[(size_t)blockIdx.x * N + n] = make_float2(mean_b, tot);
         }
@@ -157,51 +171,47 @@ __device__ __forceinline__ void block_stats_128(const float (&val)[32], float (*
 // output pixels per block => exactly the (mean_b, M2_b) partial per 128 pixels that inorm_finalize merges.
 __global__ __launch_bounds__(256) void winograd_output_kernel(const float* __restrict__ Mm, const float* __restrict__ bias,
                                                               float* __restrict__ y, float2* __restrict__ stats, int H,
-                                                              int W, int N) {
+                                                              int W, int N, int TW, int T, int Tp) {
     __shared__ float sh[4][64];
-    const int TW = W >> 1;
-    const long T = (long)(H >> 1) * TW;
     const int cl = threadIdx.x & 63, tl = threadIdx.x >> 6;
     const int n = blockIdx.y * 64 + cl;
     const bool ok = n < N;
     const float bv = (ok && bias) ? bias[n] : 0.f;
-    float out[8][4];
+    float out[32];
+    unsigned mask = 0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const long tile = (long)blockIdx.x * 32 + tl + 4 * i;
+        const bool tv = tile < T;
         float m[4][4];
 #pragma unroll
-        for (int a = 0; a < 16; ++a) m[a >> 2][a & 3] = ok ? Mm[((long)a * T + tile) * N + n] : 0.f;
+        for (int a = 0; a < 16; ++a) m[a >> 2][a & 3] = (ok && tv) ? Mm[((long)a * Tp + tile) * N + n] : 0.f;
         float r[2][4];
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             r[0][b] = m[0][b] + m[1][b] + m[2][b];
             r[1][b] = m[1][b] - m[2][b] - m[3][b];
         }
+        const int ty = (int)(tile / TW), tx = (int)(tile - (long)ty * TW);
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            out[i][a * 2 + 0] = r[a][0] + r[a][1] + r[a][2] + bv;
-            out[i][a * 2 + 1] = r[a][1] - r[a][2] - r[a][3] + bv;
-        }
-        if (ok) {
-            const int ty = (int)(tile / TW), tx = (int)(tile - (long)ty * TW);
+        for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int b = 0; b < 2; ++b) y[((long)(2 * ty + a) * W + 2 * tx + b) * N + n] = out[i][a * 2 + b];
-        }
+            for (int b = 0; b < 2; ++b) {
+                const float v = (b == 0 ? r[a][0] + r[a][1] + r[a][2] : r[a][1] - r[a][2] - r[a][3]) + bv;
+                out[i * 4 + a * 2 + b] = v;
+                const int oy = 2 * ty + a, ox = 2 * tx + b;
+                if (tv && oy < H && ox < W) {
+                    mask |= 1u << (i * 4 + a * 2 + b);
+                    if (ok) y[((long)oy * W + ox) * N + n] = v;
+                }
+            }
     }
-    float v[32];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) v[i * 4 + k] = out[i][k];
-    block_stats_128(v, sh, tl, cl, ok, stats, N, n);
+    block_stats_128(out, mask, sh, tl, cl, ok, stats, N, n);
 }
 int launch_winograd_output(hipStream_t s, const float* Mm, const float* bias, float* y, float* stats, int H, int W, int N) {
-    const long T = (long)(H / 2) * (W / 2);
-    hipLaunchKernelGGL(winograd_output_kernel, dim3((int)(T / 32), (N + 63) / 64), dim3(256), 0, s, Mm, bias, y,
-                       reinterpret_cast<float2*>(stats), H, W, N);
+    const int TW = (W + 1) / 2, T = ((H + 1) / 2) * TW, Tp = (T + 127) / 128 * 128;
+    hipLaunchKernelGGL(winograd_output_kernel, dim3(Tp / 32, (N + 63) / 64), dim3(256), 0, s, Mm, bias, y,
+                       reinterpret_cast<float2*>(stats), H, W, N, TW, T, Tp);
     T2V_HIP_CHECK(hipGetLastError());
     return T2V_OK;
 }
@@ -210,8 +220,8 @@ int launch_winograd_output(hipStream_t s, const float* Mm, const float* bias, fl
 // F(4x4,3x3): 36 products per 16 outputs (2.25 per output; F(2x2) needs 4, the direct conv 9).  6x6 input
 // patches at stride 4, interpolation points {0, +-3/4, +-3/2, inf} (winograd_f4_consts.h: the textbook
 // {0, +-1, +-2} cost ~2x the fp32 rounding error).  V / M shrink to 36/16 = 2.25x the activation (F(2x2): 4x),
-// so the memory-bound transforms get cheaper as well.  Same layouts: U [36][Cout_p][Cin_s], V [36][T][C],
-// M [36][T][N] with T = H/4 * W/4.
+// so the memory-bound transforms get cheaper as well.  Same layouts: U [36][Cout_p][Cin_s], V [36][Tp][C],
+// M [36][Tp][N], T = ceil(H/4) * ceil(W/4) tiles padded to Tp (multiple of 128).
 template <int K>
 __device__ __forceinline__ float cdot(const double (&row)[K], const float (&v)[K]) {
     float acc = 0.f;
@@ -260,14 +270,17 @@ int launch_winograd4_weight(hipStream_t s, const float* w, float* U, int Cout, i
 
 // V[a*6+b][tile][c] = (B^T d B)[a][b]; one thread = one tile x 2 channels (float2; 36 live values each)
 __global__ __launch_bounds__(256) void winograd4_input_kernel(const float2* __restrict__ x, float2* __restrict__ V, int H,
-                                                              int W, int C2) {
-    const int TW = W >> 2;
-    const long T = (long)(H >> 2) * TW;
-    const long total = T * C2;
+                                                              int W, int C2, int TW, int T, int Tp) {
+    const long total = (long)Tp * C2;
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
         const long tile = i / C2;
         const int c2 = (int)(i - tile * C2);
+        if (tile >= T) {   // padding tiles: zeros
+#pragma unroll
+            for (int xi = 0; xi < 36; ++xi) V[((long)xi * Tp + tile) * C2 + c2] = make_float2(0.f, 0.f);
+            continue;
+        }
         const int ty = (int)(tile / TW), tx = (int)(tile - (long)ty * TW);
         int ry[6], rx[6];
 #pragma unroll
@@ -275,8 +288,8 @@ __global__ __launch_bounds__(256) void winograd4_input_kernel(const float2* __re
             int yy = 4 * ty - 1 + k, xx = 4 * tx - 1 + k;
             yy = yy < 0 ? -yy : yy;
             xx = xx < 0 ? -xx : xx;
-            ry[k] = min(yy, 2 * H - 2 - yy);
-            rx[k] = min(xx, 2 * W - 2 - xx);
+            ry[k] = max(min(yy, 2 * H - 2 - yy), 0);   // past the reflected border: ragged tile, outputs masked
+            rx[k] = max(min(xx, 2 * W - 2 - xx), 0);
         }
         // rows first: r[a][j] = sum_b B^T[j][b] d[a][b]
         float rxv[6][6], ryv[6][6];
@@ -306,14 +319,14 @@ __global__ __launch_bounds__(256) void winograd4_input_kernel(const float2* __re
             }
 #pragma unroll
             for (int a2 = 0; a2 < 6; ++a2)
-                V[((long)(a2 * 6 + j) * T + tile) * C2 + c2] = make_float2(cdot<6>(f4::kBT[a2], cx), cdot<6>(f4::kBT[a2], cy));
+                V[((long)(a2 * 6 + j) * Tp + tile) * C2 + c2] = make_float2(cdot<6>(f4::kBT[a2], cx), cdot<6>(f4::kBT[a2], cy));
         }
     }
 }
 int launch_winograd4_input(hipStream_t s, const float* x, float* V, int H, int W, int C) {
-    const long total = (long)(H / 4) * (W / 4) * (C / 2);
-    hipLaunchKernelGGL(winograd4_input_kernel, dim3(wg_grid(total, 256)), dim3(256), 0, s,
-                       reinterpret_cast<const float2*>(x), reinterpret_cast<float2*>(V), H, W, C / 2);
+    const int TW = (W + 3) / 4, T = ((H + 3) / 4) * TW, Tp = (T + 127) / 128 * 128;
+    hipLaunchKernelGGL(winograd4_input_kernel, dim3(wg_grid((long)Tp * (C / 2), 256)), dim3(256), 0, s,
+                       reinterpret_cast<const float2*>(x), reinterpret_cast<float2*>(V), H, W, C / 2, TW, T, Tp);
     T2V_HIP_CHECK(hipGetLastError());
     return T2V_OK;
 }
@@ -321,24 +334,24 @@ int launch_winograd4_input(hipStream_t s, const float* x, float* V, int H, int W
 // y = A^T M A + bias; block = 64 channels x 4 tile lanes, 8 tiles (2 per thread) = 128 output pixels
 __global__ __launch_bounds__(256) void winograd4_output_kernel(const float* __restrict__ Mm, const float* __restrict__ bias,
                                                                float* __restrict__ y, float2* __restrict__ stats, int H,
-                                                               int W, int N) {
+                                                               int W, int N, int TW, int T, int Tp) {
     __shared__ float sh[4][64];
-    const int TW = W >> 2;
-    const long T = (long)(H >> 2) * TW;
     const int cl = threadIdx.x & 63, tl = threadIdx.x >> 6;
     const int n = blockIdx.y * 64 + cl;
     const bool ok = n < N;
     const float bv = (ok && bias) ? bias[n] : 0.f;
     float out[32];
+    unsigned mask = 0;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const long tile = (long)blockIdx.x * 8 + tl + 4 * i;
+        const bool tv = tile < T;
         float r[4][6];   // r[i2][b] = sum_a A^T[i2][a] m[a][b]
 #pragma unroll
         for (int b = 0; b < 6; ++b) {
             float m[6];
 #pragma unroll
-            for (int a = 0; a < 6; ++a) m[a] = ok ? Mm[((long)(a * 6 + b) * T + tile) * N + n] : 0.f;
+            for (int a = 0; a < 6; ++a) m[a] = (ok && tv) ? Mm[((long)(a * 6 + b) * Tp + tile) * N + n] : 0.f;
 #pragma unroll
             for (int i2 = 0; i2 < 4; ++i2) r[i2][b] = cdot<6>(f4::kAT[i2], m);
         }
@@ -349,15 +362,19 @@ __global__ __launch_bounds__(256) void winograd4_output_kernel(const float* __re
             for (int j2 = 0; j2 < 4; ++j2) {
                 const float v = cdot<6>(f4::kAT[j2], r[i2]) + bv;
                 out[i * 16 + i2 * 4 + j2] = v;
-                if (ok) y[((long)(4 * ty + i2) * W + 4 * tx + j2) * N + n] = v;
+                const int oy = 4 * ty + i2, ox = 4 * tx + j2;
+                if (tv && oy < H && ox < W) {
+                    mask |= 1u << (i * 16 + i2 * 4 + j2);
+                    if (ok) y[((long)oy * W + ox) * N + n] = v;
+                }
             }
     }
-    block_stats_128(out, sh, tl, cl, ok, stats, N, n);
+    block_stats_128(out, mask, sh, tl, cl, ok, stats, N, n);
 }
 int launch_winograd4_output(hipStream_t s, const float* Mm, const float* bias, float* y, float* stats, int H, int W, int N) {
-    const long T = (long)(H / 4) * (W / 4);
-    hipLaunchKernelGGL(winograd4_output_kernel, dim3((int)(T / 8), (N + 63) / 64), dim3(256), 0, s, Mm, bias, y,
-                       reinterpret_cast<float2*>(stats), H, W, N);
+    const int TW = (W + 3) / 4, T = ((H + 3) / 4) * TW, Tp = (T + 127) / 128 * 128;
+    hipLaunchKernelGGL(winograd4_output_kernel, dim3(Tp / 8, (N + 63) / 64), dim3(256), 0, s, Mm, bias, y,
+                       reinterpret_cast<float2*>(stats), H, W, N, TW, T, Tp);
     T2V_HIP_CHECK(hipGetLastError());
     return T2V_OK;
 }
