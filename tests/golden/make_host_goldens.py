@@ -10,6 +10,10 @@ data fixtures so the GPU box never needs the reference:
         (their rasterisation rule is OpenCV's and cannot be reproduced without OpenCV)
   tests/golden/l2_driver_Shehadyour.npz                  the 87 tmp + 87 tmp_smooth pose vectors the
         reference L2 driver (interp_landmarks_motion_phoneme_VidTIMIT_smooth.py) writes for config 1
+  tests/golden/l2_driver_pinyin_nihaoa.npz               the same for interp_landmarks_motion.py (pinyin
+        driver) on the 16-frame utterance input_timestamp/henan/<ni hao a>.txt
+  tests/golden/l2_inputs/                                the reference DATA files those two runs read
+        (time stamps, unit tables, key-pose JSONs), verbatim, in the reference's directory layout
 
 Usage:  python tests/golden/make_host_goldens.py
 """
@@ -112,7 +116,69 @@ def l2_driver():
     shutil.rmtree(work)
 
 
+def _run_reference_driver(script, utterance, person, data_links):
+    """exec one of the reference's L2 driver scripts in a scratch copy of its directory layout;
+    -> {seq: [json paths]} of what it wrote under ../vid2vid/datasets/<person>/test_openpose/."""
+    work = tempfile.mkdtemp()
+    t2v = os.path.join(work, "Text2Video")
+    os.makedirs(t2v)
+    for name in [script, "keypoint2img.py", "input_timestamp"] + data_links:
+        os.symlink(os.path.join(REF, name), os.path.join(t2v, name))
+    for sub in ["test_openpose/tmp", "test_openpose/tmp_smooth", "test_img/tmp", "test_img/tmp_smooth"]:
+        os.makedirs(os.path.join(work, "vid2vid", "datasets", person, sub))
+    cwd, argv = os.getcwd(), sys.argv
+    os.chdir(t2v)
+    sys.path.insert(0, t2v)
+    sys.argv = ["interp", utterance, person]
+    try:
+        exec(compile(open(script).read(), script, "exec"), {"__name__": "__main__"})
+    finally:
+        sys.argv = argv
+        os.chdir(cwd)
+    out = {seq: sorted(glob.glob(os.path.join(work, "vid2vid", "datasets", person, "test_openpose", seq, "*.json")))
+           for seq in ["tmp", "tmp_smooth"]}
+    return work, out
+
+
+def _vec(path):
+    p = json.load(open(path))["people"][0]
+    return np.concatenate([np.asarray(p["pose_keypoints_2d"], float).ravel(),
+                           np.asarray(p["face_keypoints_2d"], float).ravel()])
+
+
+def l2_inputs_and_pinyin():
+    """(1) golden for the pinyin driver (interp_landmarks_motion.py) on a 16-frame utterance;
+    (2) the INPUT data files both L2 goldens depend on (time stamps, unit tables, the key-pose JSONs the
+    drivers touch), copied verbatim in the reference's directory layout under tests/golden/l2_inputs/ so
+    that the parity test of text2video_amd/l2_driver.py runs without /root/reference."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from text2video_amd import l2_driver as L
+    work, out = _run_reference_driver("interp_landmarks_motion.py", "你好啊", "henan", ["*pinyin_data", "dict_henan.txt"])
+    gold = {}
+    for seq, files in out.items():
+        gold[seq] = np.stack([_vec(f) for f in files])
+        gold[seq + "_names"] = np.array([os.path.basename(f) for f in files])
+    np.savez_compressed(os.path.join(HERE, "l2_driver_pinyin_nihaoa.npz"), **gold)
+    print("l2 pinyin driver:", gold["tmp"].shape, gold["tmp_smooth"].shape)
+    shutil.rmtree(work)
+    dst = os.path.join(HERE, "l2_inputs")
+    cases = [("She had your dark suit in greasy wash water all year.", "fadg0", L.PHONEME),
+             ("你好啊", "henan", L.PINYIN)]
+    for text, person, spec in cases:
+        bank = L.KeyPoseBank(REF, person, spec)
+        L.synthesize(text, person, REF, spec, bank=bank)
+        tsp = L.timestamps_path(REF, person, text, spec)
+        tables = [tsp, os.path.join(REF, "*phoneme_data", "VidTIMIT", "%s.txt" % person) if spec.kind == "phoneme"
+                  else os.path.join(REF, "dict_%s.txt" % person)]
+        for src in tables + [os.path.join(bank.dir, n) for n in bank.touched]:
+            to = os.path.join(dst, os.path.relpath(src, REF))
+            os.makedirs(os.path.dirname(to), exist_ok=True)
+            shutil.copyfile(src, to)
+        print("l2 inputs:", person, len(bank.touched), "key-pose files")
+
+
 if __name__ == "__main__":
     _stub_modules()
     pose_maps()
     l2_driver()
+    l2_inputs_and_pinyin()

@@ -139,3 +139,34 @@ def test_checkpoint_decides_flow_branch_and_legacy_keys(tmp_path):
     m = M.create_model(TestOptions().parse(["--name", "p", "--checkpoints_dir", str(tmp_path / "ckpt"), "--ngf", "32",
                                             "--n_blocks", "2", "--no_first_img"]))
     assert m.nets[0].spec.no_flow is True                                # no flow keys -> no flow branch
+
+
+def test_in_memory_pipeline_equals_file_pipeline(tmp_path):
+    """The whole L0 recipe on the reference's data: drop-in L2 driver script (files) + test.py, against the
+    in-memory pipeline (no JSON / skeleton-JPEG round trip).  Same frames, same names."""
+    t2v = tmp_path / "Text2Video"
+    shutil.copytree(os.path.join(GOLD, "l2_inputs"), t2v)                     # the reference's data layout
+    env = dict(os.environ, CUDA_VISIBLE_DEVICES="0")
+    text, person = "She had your dark suit in greasy wash water all year.", "fadg0"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "Text2Video", "interp_landmarks_motion_phoneme_VidTIMIT_smooth.py"),
+                        text, person], cwd=t2v, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    ds = tmp_path / "vid2vid" / "datasets" / person
+    assert len(os.listdir(ds / "test_openpose" / "tmp")) == 87 == len(os.listdir(ds / "test_img" / "tmp_smooth"))
+    flags = ["--name", person, "--dataroot", "datasets/" + person, "--dataset_mode", "pose", "--input_nc", "3",
+             "--resize_or_crop", "scaleHeight", "--loadSize", "512", "--openpose_only", "--how_many", "12",
+             "--no_first_img", "--random_drop_prob", "0", "--synthetic_weights", "1", "--ngf", "32", "--n_blocks", "3"]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "vid2vid", "test.py")] + flags, cwd=tmp_path / "vid2vid",
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    files = sorted(glob.glob(str(tmp_path / "vid2vid" / "results" / person / "test_latest" / "tmp" / "fake_B_*.jpg")))
+    assert [os.path.basename(f) for f in files] == ["fake_B_%04d.jpg" % i for i in range(2, 14)]
+    # in-memory: same utterance, results into another directory
+    r = subprocess.run([sys.executable, "-m", "text2video_amd.pipeline", text, person] + flags[flags.index("--how_many"):] +
+                       ["--results_dir", str(tmp_path / "mem")], cwd=t2v, env=dict(env, PYTHONPATH=ROOT),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    mem = sorted(glob.glob(str(tmp_path / "mem" / person / "test_latest" / "tmp" / "fake_B_*.jpg")))
+    assert [os.path.basename(f) for f in mem] == [os.path.basename(f) for f in files]
+    for a, b in zip(files, mem):
+        assert np.array_equal(np.asarray(Image.open(a)), np.asarray(Image.open(b))), (a, b)

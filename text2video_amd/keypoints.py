@@ -191,9 +191,12 @@ def render_person(person, size, basic_point_only=False, exact_fit=True, hand_dis
 def read_keypoints(json_input, size, random_drop_prob=0, remove_face_labels=False, basic_point_only=False,
                    exact_fit=True, hand_discs=True, rng=None):
     """Same call signature as the reference routine (+ keyword extras).  size = (w, h).
-    Returns uint8 [h, w, 3]."""
-    with open(json_input, encoding="utf-8") as fh:
-        people = json.load(fh)["people"]
+    Returns uint8 [h, w, 3].  `json_input` may also be an already parsed OpenPose dict (in-memory L2 driver)."""
+    if isinstance(json_input, dict):
+        people = json_input["people"]
+    else:
+        with open(json_input, encoding="utf-8") as fh:
+            people = json.load(fh)["people"]
     w, h = size
     canvas = np.zeros((h, w, 3), np.uint8)
     if random_drop_prob > 0 and rng is None:

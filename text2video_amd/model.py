@@ -76,10 +76,11 @@ def _real_A_u8(pose_map_u8):
     return np.clip((x + 1) / 2.0 * 255.0, 0, 255).astype(np.uint8)
 
 
-def run_test(opt, model=None, device="cuda:0"):
-    """The frame loop.  Returns a dict of counters/timings."""
+def run_test(opt, model=None, device="cuda:0", dataset=None):
+    """The frame loop.  Returns a dict of counters/timings.  `dataset`: a ready PoseDataset (e.g.
+    PoseDataset.from_memory for the in-memory L2 driver) instead of the one scanned from opt.dataroot."""
     t_start = time.perf_counter()
-    dataset = PoseDataset(opt)
+    dataset = dataset if dataset is not None else PoseDataset(opt)
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
         # one process per GPU (torchrun): sequences / sequence chunks are sharded over the ranks and
         # every rank writes its own frames -- no collective on the data path (SURVEY 8e)

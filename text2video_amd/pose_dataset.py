@@ -89,6 +89,31 @@ class PoseDataset:
         self._window_key = None
         self._sizes = {}
 
+    @classmethod
+    def from_memory(cls, opt, sequences, size=(512, 384), names=None):
+        """Dataset over in-memory OpenPose frames: {sequence name: [parsed JSON dict per frame]} -- what
+        l2_driver.synthesize() returns -- rasterised on a `size` = (w, h) canvas.  Same windows, same
+        recurrence resets and same output naming as the directory form (names default to the files the
+        reference's L2 driver would have written)."""
+        self = cls.__new__(cls)
+        self.opt, self.tG = opt, opt.n_frames_G
+        self.op = {seq: list(frames) for seq, frames in sequences.items()}
+        self.img = {seq: [] for seq in self.op}
+        stem = {"tmp": "%04d.jpg", "tmp_smooth": "smooth_%04d.jpg"}   # the skeleton images the L2 driver writes
+        self.names = {seq: list((names or {}).get(seq) or [os.path.join(seq, stem.get(seq, "%04d.jpg") % i)
+                                                           for i in range(len(fr))])
+                      for seq, fr in self.op.items()}
+        self.items = [(seq, i) for seq, fr in self.op.items()
+                      for i in range(self.tG - 1 + getattr(opt, "start_frame", 0), len(fr))]
+        self._window = self._window_key = None
+        self._sizes = {seq: tuple(size) for seq in self.op}
+        return self
+
+    def _name(self, seq, i):
+        if getattr(self, "names", None):
+            return self.names[seq][i]
+        return self.img[seq][i] if self.img[seq] else self.op[seq][i]
+
     def __len__(self):
         return len(self.items)
 
@@ -165,8 +190,7 @@ class PoseDataset:
                     del cache[key]
                 change_seq = idx == 0 or self.items[idx - 1][0] != seq or \
                     (seq, i) in getattr(self, "_unit_starts", ())
-                name_src = self.img[seq][i] if self.img[seq] else self.op[seq][i]
-                yield {"A": np.stack(win), "A_path": name_src, "seq": seq, "change_seq": change_seq}
+                yield {"A": np.stack(win), "A_path": self._name(seq, i), "seq": seq, "change_seq": change_seq}
 
     def __getitem__(self, idx):
         seq, i = self.items[idx]
@@ -176,8 +200,7 @@ class PoseDataset:
         else:
             self._window = [self._pose_map(seq, j) for j in range(i - self.tG + 1, i + 1)]
         self._window_key = (seq, i)
-        name_src = self.img[seq][i] if self.img[seq] else self.op[seq][i]
-        return {"A": np.stack(self._window), "A_path": name_src, "seq": seq, "change_seq": change_seq}
+        return {"A": np.stack(self._window), "A_path": self._name(seq, i), "seq": seq, "change_seq": change_seq}
 
     def __iter__(self):
         for i in range(len(self)):
