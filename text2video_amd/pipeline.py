@@ -5,9 +5,10 @@ then `test.py` re-reads them [REF text2video_audio.sh:31-42].  Here the driver's
 and feed the pose dataset directly; frames, names and results layout are those of the two-step form
 (tests/test_gpu_e2e.py::test_in_memory_pipeline_equals_file_pipeline).
 
-    python -m text2video_amd.pipeline "<utterance>" <person> [--pinyin] [test.py flags ...]
-run from the reference's Text2Video directory (time stamps, unit tables and key poses are read relative
-to it, results go where test.py puts them).
+    python -m text2video_amd.pipeline "<utterance>" <person> [--pinyin] [--l2_root DIR] [test.py flags ...]
+`--l2_root` = the reference's Text2Video directory (time stamps, unit tables and key poses are read
+relative to it; default "."); checkpoints / results resolve relative to the working directory exactly as
+for test.py, so run it from ../vid2vid with `--l2_root ../Text2Video`.
 """
 import sys
 
@@ -31,6 +32,11 @@ def main(argv=None):
     if "--pinyin" in argv:
         argv.remove("--pinyin")
         spec = l2_driver.PINYIN
+    root = "."
+    if "--l2_root" in argv:
+        i = argv.index("--l2_root")
+        root = argv[i + 1]
+        del argv[i:i + 2]
     if len(argv) < 2:
         raise SystemExit(__doc__)
     text, person, rest = argv[0], argv[1], argv[2:]
@@ -38,7 +44,7 @@ def main(argv=None):
                 "--resize_or_crop", "scaleHeight", "--loadSize", "512", "--openpose_only", "--how_many", "1200",
                 "--no_first_img", "--random_drop_prob", "0"]                      # [REF text2video_audio.sh:42]
     opt = TestOptions().parse(defaults + rest)
-    stats = text_to_frames(text, person, opt, spec=spec)
+    stats = text_to_frames(text, person, opt, root=root, spec=spec)
     print("%d frames, %.1f frames/s -> %s" % (stats["frames"], stats["fps_loop"], stats["results_dir"]))
 
 
