@@ -15,6 +15,8 @@
 //     the others compute -- thread-level parallelism hides DMA, scalar-load and LDS latency, and the
 //     tap loop stays rolled (48 live weight scalars; a fully unrolled row spilled SGPRs).
 // Bound: fp32 VALU (12 FMAs per ds_read_b128), 9.87 GFLOP per 512x512 launch.
+#include <stdlib.h>
+
 #include "t2v_internal.h"
 
 namespace t2v {
@@ -29,15 +31,28 @@ __device__ __forceinline__ void hd_dma16(const float* base, int nbytes, char* ld
 constexpr int kHdTile = 16;                 // 16 x 16 output pixels per block
 constexpr int kHdHalo = kHdTile + 6;        // 22
 constexpr int kHdPlane = 512 * 16;          // bytes of one 4-channel plane (484 halo pixels, padded to 8 DMA instr)
-constexpr int kHdBuf = 4 * kHdPlane;        // 16 channels
-constexpr int kHdLds = kHdBuf;
-
+// CH = channels staged per pass: 16 (32 KiB, 4 blocks/CU) or 32 (64 KiB, 2 blocks/CU; one full 128-byte line
+// per halo pixel per pass)
+template <int CH>
 __global__ __launch_bounds__(256) void conv_head7x7_kernel(const HeadParams p) {
+    constexpr int kPlanes = CH / 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // also the 4-channel group this wave stages
     const int tx = tid & 15, ty = tid >> 4;
-    const int x0 = blockIdx.x * kHdTile, y0 = blockIdx.y * kHdTile;
+    // block b runs on XCD b % 8: give every XCD a contiguous band of tile rows, so that the halo overlap of
+    // neighbouring tiles (22x22 fetched per 16x16 outputs = 1.9x) and the two 64-B chunk halves of a 128-B
+    // line are served by that XCD's own L2 -- inside a frame the input was just written by another kernel
+    // and does not sit in the Infinity Cache (measured: 457 vs 315 us without this).
+    int tile;
+    {
+        const int nb = gridDim.x, b = blockIdx.x;
+        const int xcd = b & 7, idx = b >> 3;
+        const int q = nb >> 3, r = nb & 7;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tiles_x = (p.W + kHdTile - 1) / kHdTile;
+    const int x0 = (tile % tiles_x) * kHdTile, y0 = (tile / tiles_x) * kHdTile;
 
     // halo pixel -> byte offset in x (reflection resolved once per block)
     int voff[8];
@@ -56,13 +71,16 @@ __global__ __launch_bounds__(256) void conv_head7x7_kernel(const HeadParams p) {
     }
     const int x_bytes = p.H * p.W * p.Cin_s * 4;
     auto stage = [&](int chunk, int buf) {
-        char* dst = smem + buf * kHdBuf + wave * kHdPlane;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) hd_dma16(p.x, x_bytes, dst + i * 1024, voff[i], chunk * 64);
+        for (int h = 0; h < kPlanes / 4; ++h) {   // this wave's 4-channel planes: wave, wave + 4
+            char* dst = smem + (wave + 4 * h) * kHdPlane;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) hd_dma16(p.x, x_bytes, dst + i * 1024, voff[i], chunk * (CH * 4) + h * 64);
+        }
     };
 
     float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;
-    const int nchunks = p.Cin_s >> 4;
+    const int nchunks = p.Cin_s / CH;
     const float* __restrict__ w0 = p.w;                 // row 0 of the packed [Cout_p][Kp] weight
     const float* __restrict__ w1 = p.w + p.Kp;
     const float* __restrict__ w2 = p.w + 2 * p.Kp;
@@ -75,10 +93,10 @@ __global__ __launch_bounds__(256) void conv_head7x7_kernel(const HeadParams p) {
         for (int kh = 0; kh < 7; ++kh) {
 #pragma unroll 1
             for (int kw = 0; kw < 7; ++kw) {
-                const int kofs = (kh * 7 + kw) * p.Cin_s + ch * 16;   // wave-uniform: scalar loads below
+                const int kofs = (kh * 7 + kw) * p.Cin_s + ch * CH;   // wave-uniform: scalar loads below
                 const char* st = sb + (kh * kHdHalo + kw) * 16;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
+                for (int q = 0; q < kPlanes; ++q) {
                     const float4 xv = *reinterpret_cast<const float4*>(st + q * kHdPlane);
                     const float4 a = *reinterpret_cast<const float4*>(w0 + kofs + q * 4);
                     const float4 b = *reinterpret_cast<const float4*>(w1 + kofs + q * 4);
@@ -118,17 +136,24 @@ __global__ __launch_bounds__(256) void conv_head7x7_kernel(const HeadParams p) {
     }
 }
 
-int launch_conv_head7x7(hipStream_t s, const HeadParams& p) {
+template <int CH>
+static int launch_head(hipStream_t s, const HeadParams& p) {
+    constexpr int lds = (CH / 4) * kHdPlane;
+    auto kern = conv_head7x7_kernel<CH>;
     static bool attr_done = false;
     if (!attr_done) {
-        T2V_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_head7x7_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, kHdLds));
+        T2V_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_done = true;
     }
-    hipLaunchKernelGGL(conv_head7x7_kernel, dim3((p.W + kHdTile - 1) / kHdTile, (p.H + kHdTile - 1) / kHdTile), dim3(256),
-                       kHdLds, s, p);
+    hipLaunchKernelGGL(kern, dim3(((p.W + kHdTile - 1) / kHdTile) * ((p.H + kHdTile - 1) / kHdTile)), dim3(256), lds, s, p);
     T2V_HIP_CHECK(hipGetLastError());
     return T2V_OK;
+}
+
+int launch_conv_head7x7(hipStream_t s, const HeadParams& p) {
+    static const int force = getenv("T2V_HEAD_CH") ? atoi(getenv("T2V_HEAD_CH")) : 0;
+    const bool wide = force ? force == 32 : (p.Cin_s % 32 == 0);
+    return wide ? launch_head<32>(s, p) : launch_head<16>(s, p);
 }
 
 }  // namespace t2v
