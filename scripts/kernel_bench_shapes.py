@@ -12,4 +12,14 @@ SHAPES = {
     "rb1024_320": (64, 40, 1024, 1024, 3, 1, 1, 1, False, True),
     "rb1024_680": (64, 85, 1024, 1024, 3, 1, 1, 1, False, True),
     "head3": (512, 512, 128, 3, 7, 1, 3, 1, False, False),
+    # the tiny maps of the train-step parity test (32x32 frames, ngf 32): few tiles, 64x64 tile config, M < BM
+    "t_rb128": (8, 8, 128, 128, 3, 1, 1, 1, False, True),
+    "t_down32": (32, 32, 32, 64, 3, 2, 1, 0, False, True),
+    "t_down64": (16, 16, 64, 128, 3, 2, 1, 0, False, True),
+    "t_up128": (8, 8, 128, 64, 3, 2, 1, 0, True, True),
+    "t_up64": (16, 16, 64, 32, 3, 2, 1, 0, True, True),
+    "t_dgrad_up": (16, 16, 32, 64, 3, 2, 1, 0, False, False),     # data gradient of t_up64: a stride-2 conv
+    "t_dgrad_down": (8, 8, 128, 64, 3, 2, 1, 0, True, False),     # data gradient of t_down64: a transposed conv
+    "t_stem": (32, 32, 9, 32, 7, 1, 3, 1, False, True),
+    "t_d4x4": (32, 32, 6, 16, 4, 2, 2, 0, False, False),
 }

@@ -230,12 +230,24 @@ int t2v_create(t2v_ctx** out, int device) {
                 "libt2v_hip is built for gfx950 (MI355X) only; device %d is %s", device, prop.gcnArchName);
     t2v_ctx* c = new t2v_ctx();
     c->device = device;
+    c->side = nullptr;
+    c->ev_fork = c->ev_join = nullptr;
+    if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
+        t2v_destroy(c);
+        set_error("t2v_create: cannot create the side stream / events");
+        return T2V_ERR_HIP;
+    }
     *out = c;
     return T2V_OK;
 }
 
 int t2v_destroy(t2v_ctx* ctx) {
     if (!ctx) return T2V_OK;
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    if (ctx->side) (void)hipStreamDestroy(ctx->side);
     delete ctx;
     return T2V_OK;
 }

@@ -254,12 +254,6 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(const ConvKParams p) {
         for (int j = 0; j < Cfg::TN; ++j)
 #pragma unroll
             for (int r = 0; r < MM::NREG; ++r) acc[i][j][r] = 0.f;
-    // single-tile waves (64x64 block tile): a second accumulator for the odd k steps, so that consecutive
-    // MFMAs of the wave never depend on each other; summed into acc in the epilogue
-    constexpr bool kDual = Cfg::TM * Cfg::TN == 1;
-    acc_t acc_odd;
-#pragma unroll
-    for (int r = 0; r < MM::NREG; ++r) acc_odd[r] = 0.f;
 
     // ---- main loop ------------------------------------------------------------------------------
     // One K stage = RQ groups of 4*TM*TN MFMAs, software-pipelined by hand (one wave per SIMD has
@@ -331,10 +325,7 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(const ConvKParams p) {
                     for (int i = 0; i < Cfg::TM; ++i)
 #pragma unroll
                         for (int j = 0; j < Cfg::TN; ++j)
-                            if (kDual && (e & 1))
-                                acc_odd = MM::run(af[cur][i][e], bf[cur][j][e], acc_odd);
-                            else
-                                acc[i][j] = MM::run(af[cur][i][e], bf[cur][j][e], acc[i][j]);
+                            acc[i][j] = MM::run(af[cur][i][e], bf[cur][j][e], acc[i][j]);
                 // issue order inside the group: MFMA, ds_read, MFMA, ds_read, ... so that every
                 // fragment read of the NEXT group issues in the shadow of an executing MFMA
 #pragma unroll
@@ -358,10 +349,6 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(const ConvKParams p) {
     }
 
     // ---- epilogue ----
-    if constexpr (kDual) {
-#pragma unroll
-        for (int r = 0; r < MM::NREG; ++r) acc[0][0][r] += acc_odd[r];
-    }
     float bias_v[Cfg::TN];
     int col[Cfg::TN];
 #pragma unroll

@@ -34,19 +34,21 @@ __device__ __forceinline__ void chan_merge(Moments& a, float nb, float mb, float
     a.n = n;
 }
 
-// block = 16 slices x 16 channels; grid = ceil(C/16)
+// block = kFinSlices slices x 16 channels; grid = ceil(C/16).  64 slices: the 512x512 layers have 2048 partials per
+// channel and only 8 blocks' worth of channels -- the loop over partials is the whole run time (54 -> 14 us)
 // Pixel count of partial `part`: conv-kernel partials cover BM consecutive GEMM rows of a phase; the Winograd
 // output transform's partials (wm = 2 | 4 > 0) cover 128/wm^2 consecutive wm x wm tiles of the ceil(H/wm) x
 // ceil(W/wm) tile grid, ragged at the bottom / right edge and padded with empty tiles at the end.
-__global__ __launch_bounds__(256) void inorm_finalize_kernel(const float2* __restrict__ stats, int nparts, int mtiles,
+constexpr int kFinSlices = 64;
+__global__ __launch_bounds__(16 * kFinSlices) void inorm_finalize_kernel(const float2* __restrict__ stats, int nparts, int mtiles,
                                                              int BM, int M, int C, float eps,
                                                              float2* __restrict__ mean_rstd, int wm, int H, int W) {
-    __shared__ float sh[3][16][17];
+    __shared__ float sh[3][kFinSlices][17];
     const int cc = threadIdx.x & 15, sl = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cc;
     Moments a{0.f, 0.f, 0.f};
     if (c < C) {
-        for (int part = sl; part < nparts; part += 16) {
+        for (int part = sl; part < nparts; part += kFinSlices) {
             int nb;
             if (wm == 0) {
                 const int mt = part % mtiles;
@@ -69,7 +71,7 @@ __global__ __launch_bounds__(256) void inorm_finalize_kernel(const float2* __res
     sh[2][sl][cc] = a.m2;
     __syncthreads();
     if (sl == 0 && c < C) {
-        for (int s = 1; s < 16; ++s) chan_merge(a, sh[0][s][cc], sh[1][s][cc], sh[2][s][cc]);
+        for (int s = 1; s < kFinSlices; ++s) chan_merge(a, sh[0][s][cc], sh[1][s][cc], sh[2][s][cc]);
         const float var = a.m2 / a.n;
         mean_rstd[c] = make_float2(a.mean, 1.0f / sqrtf(var + eps));
     }
@@ -77,7 +79,7 @@ __global__ __launch_bounds__(256) void inorm_finalize_kernel(const float2* __res
 
 int launch_inorm_finalize(hipStream_t s, const float* stats, int nparts, int mtiles, int BM, int M, int C,
                           float eps, float* mean_rstd) {
-    hipLaunchKernelGGL(inorm_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, s,
+    hipLaunchKernelGGL(inorm_finalize_kernel, dim3((C + 15) / 16), dim3(16 * kFinSlices), 0, s,
                        reinterpret_cast<const float2*>(stats), nparts, mtiles, BM, M, C, eps,
                        reinterpret_cast<float2*>(mean_rstd), 0, 0, 0);
     T2V_HIP_CHECK(hipGetLastError());
@@ -88,7 +90,7 @@ int launch_inorm_finalize_winograd(hipStream_t s, const float* stats, int wm, in
                                    float* mean_rstd) {
     const int T = ((H + wm - 1) / wm) * ((W + wm - 1) / wm), Tp = (T + 127) / 128 * 128;
     const int nparts = Tp / (128 / (wm * wm));
-    hipLaunchKernelGGL(inorm_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, s,
+    hipLaunchKernelGGL(inorm_finalize_kernel, dim3((C + 15) / 16), dim3(16 * kFinSlices), 0, s,
                        reinterpret_cast<const float2*>(stats), nparts, 1, 0, H * W, C, eps,
                        reinterpret_cast<float2*>(mean_rstd), wm, H, W);
     T2V_HIP_CHECK(hipGetLastError());

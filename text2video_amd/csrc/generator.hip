@@ -101,13 +101,15 @@ int check_desc(const t2v_gen_desc* g) {
 struct Buffers {
     float *encA[8], *encB[8];  // encoder activations per level (A: pose/seg, B: prev-image)
     float* bt[4];              // bottleneck temporaries (resnet chains)
+    float* bt2[3];             // ... of the branch that runs on the side stream
     float* d;                  // encoder sum
     float *dimg, *dflow;       // local generator: d + coarse features
     float *decI[8], *decF[8];  // decoder activations per level
     float *raw, *fw;
-    float* stats;
-    float* mean_rstd;
-    float* wino;   // Winograd scratch: transformed input V + transformed output M
+    // per-stream scratch [0]: caller's stream, [1]: side stream
+    float* stats[2];
+    float* mean_rstd[2];
+    float* wino[2];   // Winograd scratch: transformed input V + transformed output M
 };
 
 void plan_buffers(const t2v_gen_desc& g, const std::vector<LayerSpec>& layers, Arena& a, Buffers& b) {
@@ -118,6 +120,7 @@ void plan_buffers(const t2v_gen_desc& g, const std::vector<LayerSpec>& layers, A
         b.encB[l] = a.alloc(lvl(l));
     }
     for (int i = 0; i < 4; ++i) b.bt[i] = a.alloc(lvl(n));
+    for (int i = 0; i < 3; ++i) b.bt2[i] = a.alloc(lvl(n));
     b.d = a.alloc(lvl(n));
     b.dimg = a.alloc(lvl(n));
     b.dflow = a.alloc(lvl(n));
@@ -141,15 +144,17 @@ void plan_buffers(const t2v_gen_desc& g, const std::vector<LayerSpec>& layers, A
         }
         if (L.cd.Cout > max_c) max_c = L.cd.Cout;
     }
-    b.stats = a.alloc(max_stats);
-    b.mean_rstd = a.alloc((size_t)max_c * 2);
+    for (int k = 0; k < 2; ++k) {
+        b.stats[k] = a.alloc(max_stats);
+        b.mean_rstd[k] = a.alloc((size_t)max_c * 2);
+    }
     size_t max_wino = 0;
     for (const LayerSpec& L : layers)
         if (is_winograd(L.cd.algo)) {
             const size_t w = winograd_workspace_floats(&L.cd);
             if (w > max_wino) max_wino = w;
         }
-    b.wino = max_wino ? a.alloc(max_wino) : nullptr;
+    for (int k = 0; k < 2; ++k) b.wino[k] = max_wino ? a.alloc(max_wino) : nullptr;
 }
 
 struct Runner {
@@ -160,6 +165,7 @@ struct Runner {
     const t2v_layer* layers;
     Buffers& b;
     int li = 0;
+    int sc = 0;   // which per-stream scratch set this runner uses
 
     // conv (+ fused stats) -> finalize -> apply.  y receives the conv output and is normalised in
     // place: y = [relu](norm(conv(x))) + res1 + res2
@@ -171,20 +177,21 @@ struct Runner {
         const int Cout = L.cd.Cout;
         if (is_winograd(L.cd.algo)) {
             const int M = L.cd.H * L.cd.W;
-            T2V_TRY(winograd_forward(ctx, s, &L.cd, x, w.w, w.bias, y, b.stats, b.wino, 7));
-            T2V_TRY(launch_inorm_finalize_winograd(s, b.stats, wino_m(L.cd.algo), L.cd.H, L.cd.W, Cout, g.eps, b.mean_rstd));
+            T2V_TRY(winograd_forward(ctx, s, &L.cd, x, w.w, w.bias, y, b.stats[sc], b.wino[sc], 7));
+            T2V_TRY(launch_inorm_finalize_winograd(s, b.stats[sc], wino_m(L.cd.algo), L.cd.H, L.cd.W, Cout, g.eps,
+                                                   b.mean_rstd[sc]));
             const float* gam = g.norm_affine ? w.gamma : nullptr;
             const float* bet = g.norm_affine ? w.beta : nullptr;
             if (g.norm_affine) T2V_REQUIRE(gam && bet, "layer %d: norm_affine=1 but gamma/beta missing", li - 1);
-            return launch_inorm_apply(s, y, b.mean_rstd, gam, bet, res1, res2, y, (long)M, Cout, relu);
+            return launch_inorm_apply(s, y, b.mean_rstd[sc], gam, bet, res1, res2, y, (long)M, Cout, relu);
         }
         T2V_TRY(build_conv_plan(&L.cd, L.x_cs, true, &pl));
-        T2V_TRY(run_conv(ctx, s, pl, x, w.w, w.bias, y, Cout, b.stats));
-        T2V_TRY(launch_inorm_finalize(s, b.stats, pl.nparts, pl.kp.mtiles, pl.BM, pl.kp.M, Cout, g.eps, b.mean_rstd));
+        T2V_TRY(run_conv(ctx, s, pl, x, w.w, w.bias, y, Cout, b.stats[sc]));
+        T2V_TRY(launch_inorm_finalize(s, b.stats[sc], pl.nparts, pl.kp.mtiles, pl.BM, pl.kp.M, Cout, g.eps, b.mean_rstd[sc]));
         const float* gamma = g.norm_affine ? w.gamma : nullptr;
         const float* beta = g.norm_affine ? w.beta : nullptr;
         if (g.norm_affine) T2V_REQUIRE(gamma && beta, "layer %d: norm_affine=1 but gamma/beta missing", li - 1);
-        return launch_inorm_apply(s, y, b.mean_rstd, gamma, beta, res1, res2, y, (long)pl.Hout * pl.Wout, Cout, relu);
+        return launch_inorm_apply(s, y, b.mean_rstd[sc], gamma, beta, res1, res2, y, (long)pl.Hout * pl.Wout, Cout, relu);
     }
 
     int head(const float* x, float* y) {
@@ -302,28 +309,47 @@ int t2v_generator_forward(t2v_ctx* ctx, void* stream, const t2v_gen_desc* d, con
         return T2V_ERR_WORKSPACE;
     }
     hipStream_t s = (hipStream_t)stream;
-    Runner r{ctx, s, *d, specs, layers, b};
+    // Two streams: the pose encoder and the previous-frame encoder are independent until their sum, and so
+    // are the image and flow branches after it.  Each branch is a chain of ~50-100 kernels, a third of them
+    // small (norm finalize / apply, Winograd transforms: 5-13 us, launch- and tail-bound); run side by side
+    // the other branch's GEMM blocks fill those gaps.  T2V_STREAMS=1 runs everything on the caller's stream.
+    static const bool two_streams = !(getenv("T2V_STREAMS") && atoi(getenv("T2V_STREAMS")) == 1);
+    hipStream_t s2 = two_streams ? ctx->side : s;
+    auto fork = [&]() -> int {
+        if (!two_streams) return T2V_OK;
+        T2V_HIP_CHECK(hipEventRecord(ctx->ev_fork, s));
+        T2V_HIP_CHECK(hipStreamWaitEvent(s2, ctx->ev_fork, 0));
+        return T2V_OK;
+    };
+    auto join = [&]() -> int {
+        if (!two_streams) return T2V_OK;
+        T2V_HIP_CHECK(hipEventRecord(ctx->ev_join, s2));
+        T2V_HIP_CHECK(hipStreamWaitEvent(s, ctx->ev_join, 0));
+        return T2V_OK;
+    };
     const int n = d->is_local ? 1 : d->n_downsample;
     const int G = d->ngf;
     const size_t bott = (size_t)(d->H >> n) * (d->W >> n) * (G << n);
     const int nb_enc = d->is_local ? 0 : d->n_blocks - d->n_blocks / 2;
     const int nb_res = d->is_local ? d->n_blocks : d->n_blocks / 2;
-    float* tmp[3] = {b.bt[0], b.bt[1], b.bt[2]};
+    const int enc_layers = 1 + n + 2 * nb_enc;                 // layers of one encoder
+    const int branch_layers = 2 * nb_res + n + 1;              // res trunk + decoder + head of one branch
+    Runner r{ctx, s, *d, specs, layers, b};
+    Runner r2{ctx, s2, *d, specs, layers, b};
+    r2.sc = two_streams ? 1 : 0;
 
-    // d = model_down_seg(x) + model_down_img(prev): the sum is fused into the last apply of the
-    // second encoder (residual input), so `d` is never a separate pass.
-    const float* segout;
-    T2V_TRY(r.encoder(io->pose, b.encA, nb_enc, tmp, nullptr, &segout));
-    // keep segout alive: the second encoder must not use its buffer as a temporary
-    float* tmp2[3];
-    {
-        float* cand[5] = {b.bt[0], b.bt[1], b.bt[2], b.bt[3], b.d};
-        int k = 0;
-        for (int i = 0; i < 5 && k < 3; ++i)
-            if (cand[i] != segout) tmp2[k++] = cand[i];
-    }
-    const float* dsum;
-    T2V_TRY(r.encoder(io->prev, b.encB, nb_enc, tmp2, segout, &dsum));
+    // d = model_down_seg(x) + model_down_img(prev)
+    float* tmpA[3] = {b.bt[0], b.bt[1], b.bt[2]};
+    float* tmpB[3] = {b.bt2[0], b.bt2[1], b.bt2[2]};
+    const float *segout, *imgout;
+    T2V_TRY(fork());
+    r2.li = enc_layers;
+    T2V_TRY(r2.encoder(io->prev, b.encB, nb_enc, tmpB, nullptr, &imgout));
+    T2V_TRY(r.encoder(io->pose, b.encA, nb_enc, tmpA, nullptr, &segout));
+    T2V_TRY(join());
+    T2V_TRY(launch_add(s, imgout, segout, b.d, (long)bott));   // (norm + x) + seg: the order the fused form summed in
+    const float* dsum = b.d;
+    r.li = 2 * enc_layers;
 
     const float* img_in = dsum;
     const float* flow_in = dsum;
@@ -335,32 +361,32 @@ int t2v_generator_forward(t2v_ctx* ctx, void* stream, const t2v_gen_desc* d, con
             flow_in = b.dflow;
         }
     }
-    // temporaries for the residual trunks: anything that is not dsum / img_in / flow_in
-    float* tmp3[3];
-    {
-        float* cand[7] = {b.bt[0], b.bt[1], b.bt[2], b.bt[3], b.d, b.encA[n], b.encB[n]};
-        int k = 0;
-        for (int i = 0; i < 7 && k < 3; ++i)
-            if (cand[i] != dsum && cand[i] != img_in && cand[i] != flow_in) tmp3[k++] = cand[i];
-    }
-    const float *res_img, *img_feat;
-    T2V_TRY(r.res_chain(img_in, nb_res, tmp3, nullptr, &res_img));
-    T2V_TRY(r.decoder(res_img, b.decI, &img_feat));
     const bool blend = !(d->no_flow || io->use_raw_only);
     float* raw = io->raw ? io->raw : (blend ? b.raw : io->out);
+    float* fw = io->flow_w ? io->flow_w : b.fw;
+    if (!d->no_flow) {
+        // flow branch on the side stream (temporaries bt2: the encoders are done with them)
+        T2V_TRY(fork());
+        r2.li = 2 * enc_layers + branch_layers;
+        const float *res_flow, *flow_feat;
+        T2V_TRY(r2.res_chain(flow_in, nb_res, tmpB, nullptr, &res_flow));
+        T2V_TRY(r2.decoder(res_flow, b.decF, &flow_feat));
+        T2V_TRY(r2.head(flow_feat, fw));
+        if (io->flow_feat)
+            T2V_HIP_CHECK(hipMemcpyAsync(io->flow_feat, flow_feat, (size_t)d->H * d->W * G * sizeof(float),
+                                         hipMemcpyDeviceToDevice, s2));
+    }
+    const float *res_img, *img_feat;
+    T2V_TRY(r.res_chain(img_in, nb_res, tmpA, nullptr, &res_img));
+    T2V_TRY(r.decoder(res_img, b.decI, &img_feat));
     T2V_TRY(r.head(img_feat, raw));
     if (io->img_feat)
         T2V_HIP_CHECK(hipMemcpyAsync(io->img_feat, img_feat, (size_t)d->H * d->W * G * sizeof(float),
                                      hipMemcpyDeviceToDevice, s));
     if (!d->no_flow) {
-        const float *res_flow, *flow_feat;
-        T2V_TRY(r.res_chain(flow_in, nb_res, tmp3, nullptr, &res_flow));
-        T2V_TRY(r.decoder(res_flow, b.decF, &flow_feat));
-        float* fw = io->flow_w ? io->flow_w : b.fw;
-        T2V_TRY(r.head(flow_feat, fw));
-        if (io->flow_feat)
-            T2V_HIP_CHECK(hipMemcpyAsync(io->flow_feat, flow_feat, (size_t)d->H * d->W * G * sizeof(float),
-                                         hipMemcpyDeviceToDevice, s));
+        T2V_TRY(join());
+        r.li += branch_layers;
+        T2V_REQUIRE(r2.li == n_layers, "internal: flow branch consumed up to layer %d of %d", r2.li, n_layers);
         if (blend) {
             const int prev_cs = round_up(d->prev_nc, 4);
             T2V_TRY(launch_warp_composite(s, raw, fw, io->prev, prev_cs, d->prev_nc - 3, io->out, nullptr, d->H,

@@ -167,4 +167,9 @@ int launch_copy_channels(hipStream_t s, const float* src, int src_cs, int src_c0
 
 struct t2v_ctx {
     int device;
+    // side stream + fork/join events: the generator runs its two independent encoders (and, with the flow
+    // branch, its two decoder branches) concurrently; everything is joined back into the caller's stream
+    // before the entry point returns
+    hipStream_t side;
+    hipEvent_t ev_fork, ev_join;
 };
