@@ -96,10 +96,15 @@ int t2v_conv2d_forward(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, const
                        float* stats_partial);
 
 /* Bit mask of the Winograd variants `d` (algo ignored) can run as: 1 = F(2x2,3x3), 2 = F(4x4,3x3).
- * Needs 3x3, stride 1, ReflectionPad 1, Cin % 32 == 0 == x_cs, Cout % 4 == 0, no activation.  Any H, W >= 2:
+ * Needs 3x3, stride 1, ReflectionPad 1 or zero padding 0..2 (pad 2: the data gradient of the pad-1 conv),
+ * Cin % 32 == 0 == x_cs, Cout % 4 == 0, no activation.  Any H, W >= 2:
  * the ceil(H/m) x ceil(W/m) tile grid (m = 2 | 4) is ragged at the bottom / right edge and padded with
  * empty tiles to a multiple of 128 (extra GEMM rows, masked in the output transform). */
 int t2v_conv_winograd_supported(const t2v_conv_desc* d, int x_cs);
+/* The algorithm the library itself would pick for `d` (d->algo ignored): the one with the fewest GEMM rows among
+ * direct (9 per output pixel), F(2x2,3x3) and F(4x4,3x3) (16 | 36 per tile, tile count padded to 128).
+ * cap: 0 = any, 1 = direct only, 2 = at most F(2x2,3x3).  Returns a T2V_ALGO_* value. */
+int t2v_conv_best_algo(const t2v_conv_desc* d, int x_cs, int cap);
 /* floats of scratch (transformed input V + transformed output M) a Winograd forward needs */
 size_t t2v_conv_winograd_workspace_floats(const t2v_conv_desc* d, int x_cs);
 /* forward with d->algo == T2V_ALGO_WINOGRAD | T2V_ALGO_WINOGRAD_F4; same contract as t2v_conv2d_forward plus the workspace */

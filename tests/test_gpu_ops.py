@@ -301,3 +301,29 @@ def test_winograd_conv_matches_direct_and_reference(case):
     assert not ops.winograd_supported(bad, Cin)
     with pytest.raises(RuntimeError):
         ops.pack_conv_weight(w.to(_dev()), bad, Cin)
+
+
+@pytest.mark.parametrize("algo", [1, 2], ids=["F2", "F4"])
+@pytest.mark.parametrize("pad", [0, 1, 2])
+def test_winograd_zero_padding(algo, pad):
+    """Zero padding 0..2 (pad 2 = the data gradient of the pad-1 ResnetBlock conv: (H+2) x (W+2) outputs)."""
+    from text2video_amd import ops
+    H, W, Cin, Cout = 18, 30, 32, 64
+    x = _rand(Cin, H, W, seed=51)
+    w = _rand(Cout, Cin, 3, 3, seed=52, scale=0.1)
+    b = _rand(Cout, seed=53, scale=0.1)
+    ref = F.conv2d(x.unsqueeze(0), w, b, padding=pad)[0]
+    desc = ops.conv_desc(H, W, Cin, Cout, 3, 1, pad, ops.PAD_ZERO, algo=algo)
+    assert ops.winograd_supported(desc, Cin)
+    U = ops.pack_conv_weight(w.to(_dev()), desc, Cin)
+    stats = ops.conv_stats_buffer(desc, _dev())
+    y = ops.conv2d_auto(_to_nhwc(x), U, b.to(_dev()), desc, stats=stats)
+    assert tuple(y.shape) == (H + 2 * pad - 2, W + 2 * pad - 2, Cout)
+    assert (_from_nhwc(y, Cout) - ref).abs().max().item() <= 2e-4 * max(1.0, ref.abs().max().item())
+    yn = ops.instance_norm_apply(y, ops.instance_norm_finalize(stats, desc))
+    assert (_from_nhwc(yn, Cout) - F.instance_norm(ref.unsqueeze(0), eps=1e-5)[0]).abs().max().item() <= 3e-4
+    # the direct kernel agrees, and best_conv_algo never proposes what is not supported
+    yd = ops.conv2d(_to_nhwc(x), ops.pack_conv_weight(w.to(_dev()), ops.with_algo(desc, 0), Cin), b.to(_dev()), ops.with_algo(desc, 0))
+    assert (y - yd).abs().max().item() <= 2e-4 * max(1.0, ref.abs().max().item())
+    assert ops.best_conv_algo(ops.conv_desc(H, W, Cin, Cout, 3, 2, 1, ops.PAD_ZERO), Cin) == ops.ALGO_DIRECT
+    assert ops.best_conv_algo(ops.conv_desc(4, 4, Cin, Cout, 3, 1, 1, ops.PAD_ZERO), Cin) == ops.ALGO_DIRECT

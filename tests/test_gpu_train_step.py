@@ -25,11 +25,16 @@ def _adam_041(p, g, m, v, lr, b1, b2, eps, step):
     p.addcdiv_(m, v.sqrt().add_(eps), value=-(lr * (1 - b2 ** step) ** 0.5 / (1 - b1 ** step)))
 
 
-def test_one_train_iteration_matches_autograd_oracle():
+@pytest.mark.parametrize("size", [32, 64], ids=["32_direct", "64_winograd"])
+def test_one_train_iteration_matches_autograd_oracle(size):
     from oracle.generator_ref import CompositeGenerator, MultiscaleDiscriminator, weights_init
     from text2video_amd import train as T
     from text2video_amd.generator import GeneratorSpec, synthetic_state_dict
-    H = W = 32
+    H = W = size
+    if size == 64:   # 16x16 bottleneck: the ResnetBlock convs and their data gradients take the Winograd path
+        from text2video_amd import ops
+        assert ops.best_conv_algo(ops.conv_desc(16, 16, 128, 128, 3, 1, 1, ops.PAD_REFLECT), 128) != ops.ALGO_DIRECT
+        assert ops.best_conv_algo(ops.conv_desc(16, 16, 128, 128, 3, 1, 2, ops.PAD_ZERO), 128) != ops.ALGO_DIRECT
     spec = GeneratorSpec(ngf=32, n_downsample=2, n_blocks=2, no_flow=True, norm="batch")
     sd = synthetic_state_dict(spec, 3, "vid2vid")
     # ---------------- oracle (CPU, torch autograd)

@@ -58,6 +58,7 @@ SIGNATURES = {
     "t2v_conv2d_forward": (c_int, [c_void_p, c_void_p, POINTER(ConvDesc), c_void_p, c_int, c_void_p, c_void_p,
                                    c_void_p, c_int, c_void_p]),
     "t2v_conv_winograd_supported": (c_int, [POINTER(ConvDesc), c_int]),
+    "t2v_conv_best_algo": (c_int, [POINTER(ConvDesc), c_int, c_int]),
     "t2v_conv_winograd_workspace_floats": (c_size_t, [POINTER(ConvDesc), c_int]),
     "t2v_conv2d_forward_winograd": (c_int, [c_void_p, c_void_p, POINTER(ConvDesc), c_void_p, c_int, c_void_p, c_void_p,
                                             c_void_p, c_int, c_void_p, c_void_p]),

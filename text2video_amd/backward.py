@@ -11,6 +11,8 @@ computes all of them.
     ConvTranspose k3 s2 p1 op1                conv k3 s2 p1 with the SAME weight tensor ([Cin,Cout,3,3] read as
                                               [Cout_c,Cin_c,3,3])
 """
+import os
+
 import torch
 
 from . import ops
@@ -44,6 +46,12 @@ class ConvDataGrad:
                 pad = d.kH - 1 - d.pad
             self.desc = ops.conv_desc(ho, wo, d.Cout, d.Cin, d.kH, 1, pad, ops.PAD_ZERO)
             self.kind = "flip"
+            # the gradient of a 3x3 stride-1 conv is again one: Winograd where that is the smaller GEMM
+            cap = int(os.environ.get("T2V_CONV_ALGO", "0"))
+            if d.kH == 3 and d.Cin % 4 == 0 and cap != 1:
+                algo = ops.best_conv_algo(self.desc, ops.round_up(self.desc.Cin, 4), cap)
+                if algo != ops.ALGO_DIRECT:
+                    self.desc = ops.with_algo(self.desc, algo)
         self.packed = None
 
     def refresh(self, weight):
@@ -56,5 +64,5 @@ class ConvDataGrad:
 
     def __call__(self, dy):
         """dy: [Hout, Wout, cs>=Cout] -> dX [H, W, round_up4(Cin)]."""
-        dxp = ops.conv2d(dy, self.packed, None, self.desc)
+        dxp = ops.conv2d_auto(dy, self.packed, None, self.desc)
         return ops.reflect_pad_backward(dxp, self.fold) if self.fold else dxp

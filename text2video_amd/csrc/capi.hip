@@ -141,11 +141,26 @@ int build_conv_plan(const t2v_conv_desc* d, int x_cs, bool need_stats, ConvPlan*
 
 bool winograd_supported(const t2v_conv_desc* d, int x_cs, int algo) {
     if (!d || !is_winograd(algo)) return false;
-    if (d->transposed || d->kH != 3 || d->kW != 3 || d->stride != 1 || d->pad != 1 || d->pad_mode != T2V_PAD_REFLECT)
-        return false;
+    if (d->transposed || d->kH != 3 || d->kW != 3 || d->stride != 1) return false;
+    // ReflectionPad2d(1) (forward ResnetBlock conv) or zero padding 0..2 (pad 2: that conv's data gradient)
+    if (d->pad_mode == T2V_PAD_REFLECT ? d->pad != 1 : (d->pad < 0 || d->pad > 2)) return false;
+    if (wino_out_h(d) < 1 || wino_out_w(d) < 1) return false;
     // any H, W >= 2 (reflection needs 2): ragged tiles are masked, the tile count is padded to 128
     if (d->Cin % 32 != 0 || x_cs != d->Cin || d->Cout % 4 != 0 || d->H < 2 || d->W < 2) return false;
     return d->act == T2V_ACT_NONE;
+}
+
+// F(4x4) unless the zero tiles that pad its coarser grid to 128 make F(2x2) the smaller GEMM (tiny maps); direct
+// when neither beats 9 rows per output pixel
+int best_conv_algo(const t2v_conv_desc* d, int x_cs, int cap) {
+    const bool f4 = cap == 0 && winograd_supported(d, x_cs, T2V_ALGO_WINOGRAD_F4);
+    const bool f2 = (cap == 0 || cap == 2) && winograd_supported(d, x_cs, T2V_ALGO_WINOGRAD);
+    const long direct_rows = 9L * wino_out_h(d) * wino_out_w(d);
+    if (f4 && (!f2 || wino_gemm_rows(d, T2V_ALGO_WINOGRAD_F4) <= wino_gemm_rows(d, T2V_ALGO_WINOGRAD)) &&
+        wino_gemm_rows(d, T2V_ALGO_WINOGRAD_F4) < direct_rows)
+        return T2V_ALGO_WINOGRAD_F4;
+    if (f2 && wino_gemm_rows(d, T2V_ALGO_WINOGRAD) < direct_rows) return T2V_ALGO_WINOGRAD;
+    return T2V_ALGO_DIRECT;
 }
 
 // the batched GEMM of a Winograd conv as a plan of the implicit-GEMM kernel: a 1x1 conv over a 16|36 x T image
@@ -198,14 +213,17 @@ int winograd_forward(t2v_ctx* ctx, hipStream_t s, const t2v_conv_desc* d, const 
     float* V = workspace;
     float* Mm = workspace + wino_pos(d->algo) * T * d->Cin;
     const bool f4 = d->algo == T2V_ALGO_WINOGRAD_F4;
-    if (stages & 1) T2V_TRY((f4 ? launch_winograd4_input : launch_winograd_input)(s, x, V, d->H, d->W, d->Cin));
+    if (stages & 1)
+        T2V_TRY((f4 ? launch_winograd4_input : launch_winograd_input)(s, x, V, d->H, d->W, d->Cin, d->pad,
+                                                                      d->pad_mode == T2V_PAD_REFLECT));
     if (stages & 2) {
         ConvPlan pl;
         T2V_TRY(build_winograd_gemm_plan(d, &pl));
         T2V_TRY(run_conv(ctx, s, pl, V, w_packed, nullptr, Mm, d->Cout, nullptr));
     }
     if (stages & 4)
-        T2V_TRY((f4 ? launch_winograd4_output : launch_winograd_output)(s, Mm, bias, y, stats_partial, d->H, d->W, d->Cout));
+        T2V_TRY((f4 ? launch_winograd4_output : launch_winograd_output)(s, Mm, bias, y, stats_partial, wino_out_h(d),
+                                                                        wino_out_w(d), d->Cout));
     return T2V_OK;
 }
 
@@ -271,6 +289,8 @@ int t2v_conv_winograd_supported(const t2v_conv_desc* d, int x_cs) {
     return (winograd_supported(d, x_cs, T2V_ALGO_WINOGRAD) ? 1 : 0) | (winograd_supported(d, x_cs, T2V_ALGO_WINOGRAD_F4) ? 2 : 0);
 }
 
+int t2v_conv_best_algo(const t2v_conv_desc* d, int x_cs, int cap) { return d ? best_conv_algo(d, x_cs, cap) : T2V_ALGO_DIRECT; }
+
 size_t t2v_conv_winograd_workspace_floats(const t2v_conv_desc* d, int x_cs) {
     if (!d || !winograd_supported(d, x_cs, d->algo)) return 0;
     return winograd_workspace_floats(d);
@@ -329,8 +349,8 @@ int t2v_instance_norm_finalize(t2v_ctx* ctx, void* stream, const t2v_conv_desc* 
                                float eps, float* mean_rstd) {
     T2V_REQUIRE(ctx && stats_partial && mean_rstd, "inorm_finalize: null pointer");
     if (producer && is_winograd(producer->algo)) {   // the output transform emits one partial per 128 pixels
-        return launch_inorm_finalize_winograd((hipStream_t)stream, stats_partial, wino_m(producer->algo), producer->H,
-                                              producer->W, producer->Cout, eps, mean_rstd);
+        return launch_inorm_finalize_winograd((hipStream_t)stream, stats_partial, wino_m(producer->algo),
+                                              wino_out_h(producer), wino_out_w(producer), producer->Cout, eps, mean_rstd, 1);
     }
     ConvPlan pl;
     T2V_TRY(build_conv_plan(producer, round_up(producer ? producer->Cin : 0, 4), true, &pl));
@@ -341,6 +361,9 @@ int t2v_instance_norm_finalize(t2v_ctx* ctx, void* stream, const t2v_conv_desc* 
 int t2v_batch_norm_finalize(t2v_ctx* ctx, void* stream, const t2v_conv_desc* producer, int batch,
                             const float* stats_partial, float eps, float* mean_rstd) {
     T2V_REQUIRE(ctx && stats_partial && mean_rstd && batch >= 1, "batch_norm_finalize: bad arguments");
+    if (producer && is_winograd(producer->algo))
+        return launch_inorm_finalize_winograd((hipStream_t)stream, stats_partial, wino_m(producer->algo), wino_out_h(producer),
+                                              wino_out_w(producer), producer->Cout, eps, mean_rstd, batch);
     ConvPlan pl;
     T2V_TRY(build_conv_plan(producer, round_up(producer ? producer->Cin : 0, 4), true, &pl));
     // the per-image partial blocks are contiguous: a batch is just `batch` times more partial rows

@@ -19,9 +19,11 @@ inline bool is_winograd(int algo) { return algo == T2V_ALGO_WINOGRAD || algo == 
 inline int wino_m(int algo) { return algo == T2V_ALGO_WINOGRAD_F4 ? 4 : 2; }          // output tile edge
 inline int wino_pos(int algo) { return (wino_m(algo) + 2) * (wino_m(algo) + 2); }    // transform positions: 16 | 36
 // tiles of the ceil(H/m) x ceil(W/m) grid, padded to whole 128-row GEMM tiles per transform position
+inline int wino_out_h(const t2v_conv_desc* d) { return d->H + 2 * d->pad - 2; }   // 3x3, stride 1
+inline int wino_out_w(const t2v_conv_desc* d) { return d->W + 2 * d->pad - 2; }
 inline int wino_tiles_padded(const t2v_conv_desc* d, int algo) {
     const int m = wino_m(algo);
-    const int T = ((d->H + m - 1) / m) * ((d->W + m - 1) / m);
+    const int T = ((wino_out_h(d) + m - 1) / m) * ((wino_out_w(d) + m - 1) / m);
     return (T + 127) / 128 * 128;
 }
 inline size_t winograd_workspace_floats(const t2v_conv_desc* d) {                    // V + M
@@ -30,6 +32,7 @@ inline size_t winograd_workspace_floats(const t2v_conv_desc* d) {               
 // GEMM rows of the whole conv (all positions): what the algorithm choice compares
 inline long wino_gemm_rows(const t2v_conv_desc* d, int algo) { return (long)wino_pos(algo) * wino_tiles_padded(d, algo); }
 bool winograd_supported(const t2v_conv_desc* d, int x_cs, int algo);
+int best_conv_algo(const t2v_conv_desc* d, int x_cs, int cap);
 int build_winograd_gemm_plan(const t2v_conv_desc* d, ConvPlan* pl);
 int winograd_forward(t2v_ctx* ctx, hipStream_t s, const t2v_conv_desc* d, const float* x, const float* w_packed,
                      const float* bias, float* y, float* stats_partial, float* workspace, int stages);

@@ -55,8 +55,9 @@ __global__ __launch_bounds__(16 * kFinSlices) void inorm_finalize_kernel(const f
                 nb = min(BM, M - mt * BM);
             } else {
                 const int TW = (W + wm - 1) / wm, T = ((H + wm - 1) / wm) * TW, tpb = 128 / (wm * wm);
+                const int pi = part % mtiles;   // partial index inside its image (mtiles = partials per image)
                 nb = 0;
-                for (int t = part * tpb; t < min((part + 1) * tpb, T); ++t) {
+                for (int t = pi * tpb; t < min((pi + 1) * tpb, T); ++t) {
                     const int ty = t / TW, tx = t - ty * TW;
                     nb += min(wm, H - wm * ty) * min(wm, W - wm * tx);
                 }
@@ -87,11 +88,11 @@ int launch_inorm_finalize(hipStream_t s, const float* stats, int nparts, int mti
 }
 // partials written by the Winograd output transform F(wm x wm, 3x3) of an H x W map
 int launch_inorm_finalize_winograd(hipStream_t s, const float* stats, int wm, int H, int W, int C, float eps,
-                                   float* mean_rstd) {
+                                   float* mean_rstd, int batch) {
     const int T = ((H + wm - 1) / wm) * ((W + wm - 1) / wm), Tp = (T + 127) / 128 * 128;
-    const int nparts = Tp / (128 / (wm * wm));
+    const int nparts = Tp / (128 / (wm * wm));   // per image; a batch's partial blocks are contiguous
     hipLaunchKernelGGL(inorm_finalize_kernel, dim3((C + 15) / 16), dim3(16 * kFinSlices), 0, s,
-                       reinterpret_cast<const float2*>(stats), nparts, 1, 0, H * W, C, eps,
+                       reinterpret_cast<const float2*>(stats), batch * nparts, nparts, 0, H * W, C, eps,
                        reinterpret_cast<float2*>(mean_rstd), wm, H, W);
     T2V_HIP_CHECK(hipGetLastError());
     return T2V_OK;

@@ -56,13 +56,7 @@ void enumerate_layers(const t2v_gen_desc& g, std::vector<LayerSpec>& out) {
         const int C = G << n;
         t2v_conv_desc cd = mk_conv(H >> n, W >> n, C, C, 3, 1, 1, T2V_PAD_REFLECT, 0);
         // the ResnetBlock convs (84 % of the FLOPs) run as Winograd F(2x2,3x3) wherever the geometry allows
-        // F(4x4) unless the zero tiles that pad its coarser grid to 128 make F(2x2) the smaller GEMM (tiny maps)
-        const bool f4 = g.conv_algo == 0 && winograd_supported(&cd, C, T2V_ALGO_WINOGRAD_F4);
-        const bool f2 = (g.conv_algo == 0 || g.conv_algo == 2) && winograd_supported(&cd, C, T2V_ALGO_WINOGRAD);
-        if (f4 && (!f2 || wino_gemm_rows(&cd, T2V_ALGO_WINOGRAD_F4) <= wino_gemm_rows(&cd, T2V_ALGO_WINOGRAD)))
-            cd.algo = T2V_ALGO_WINOGRAD_F4;
-        else if (f2 && wino_gemm_rows(&cd, T2V_ALGO_WINOGRAD) < 9L * cd.H * cd.W)
-            cd.algo = T2V_ALGO_WINOGRAD;
+        cd.algo = best_conv_algo(&cd, C, g.conv_algo);
         for (int i = 0; i < 2 * count; ++i) out.push_back({cd, C, true});
     };
     auto ups = [&]() {
@@ -179,7 +173,7 @@ struct Runner {
             const int M = L.cd.H * L.cd.W;
             T2V_TRY(winograd_forward(ctx, s, &L.cd, x, w.w, w.bias, y, b.stats[sc], b.wino[sc], 7));
             T2V_TRY(launch_inorm_finalize_winograd(s, b.stats[sc], wino_m(L.cd.algo), L.cd.H, L.cd.W, Cout, g.eps,
-                                                   b.mean_rstd[sc]));
+                                                   b.mean_rstd[sc], 1));
             const float* gam = g.norm_affine ? w.gamma : nullptr;
             const float* bet = g.norm_affine ? w.beta : nullptr;
             if (g.norm_affine) T2V_REQUIRE(gam && bet, "layer %d: norm_affine=1 but gamma/beta missing", li - 1);

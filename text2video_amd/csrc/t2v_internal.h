@@ -111,10 +111,10 @@ int launch_act_backward(hipStream_t s, const float* dy, const float* y, int mode
 int launch_avgpool3s2_backward(hipStream_t s, const float* dy, float* dx, int H, int W, int C);
 int launch_loss_backward(hipStream_t s, int op, const float* a, const float* b, float c, float scale, long n, float* da);
 int launch_winograd_weight(hipStream_t s, const float* w, float* U, int Cout, int Cin, int Cout_p, int Cin_s);
-int launch_winograd_input(hipStream_t s, const float* x, float* V, int H, int W, int C);
+int launch_winograd_input(hipStream_t s, const float* x, float* V, int H, int W, int C, int pad, int reflect);
 int launch_winograd_output(hipStream_t s, const float* Mm, const float* bias, float* y, float* stats, int H, int W, int N);
 int launch_winograd4_weight(hipStream_t s, const float* w, float* U, int Cout, int Cin, int Cout_p, int Cin_s);
-int launch_winograd4_input(hipStream_t s, const float* x, float* V, int H, int W, int C);
+int launch_winograd4_input(hipStream_t s, const float* x, float* V, int H, int W, int C, int pad, int reflect);
 int launch_winograd4_output(hipStream_t s, const float* Mm, const float* bias, float* y, float* stats, int H, int W, int N);
 int launch_channel_sum(hipStream_t s, const float* x, long npix, int C, int cs, float* scratch, float* out);
 
@@ -136,7 +136,7 @@ int launch_conv_igemm(hipStream_t s, const ConvKParams& p, int tile);
 
 // elementwise.hip
 int launch_inorm_finalize_winograd(hipStream_t s, const float* stats, int wm, int H, int W, int C, float eps,
-                                   float* mean_rstd);
+                                   float* mean_rstd, int batch);
 int launch_inorm_finalize(hipStream_t s, const float* stats, int nparts, int mtiles, int BM, int M, int C,
                           float eps, float* mean_rstd);
 int launch_inorm_apply(hipStream_t s, const float* x, const float* mean_rstd, const float* gamma,

@@ -68,8 +68,10 @@ int launch_winograd_weight(hipStream_t s, const float* w, float* U, int Cout, in
 
 // V[xi][tile][c] = (B^T d B)[xi],  d = 4x4 patch at rows 2ty-1.., cols 2tx-1.. (reflection pad 1)
 // B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]].  One thread = one tile x 4 channels (float4).
+// pad / reflect: ReflectionPad2d(1) (the forward ResnetBlock conv) or zero padding `pad` in {0,1,2} (pad 2 = the
+// data gradient of that conv: a full correlation producing (H+2) x (W+2)).  The tile grid covers the OUTPUT.
 __global__ __launch_bounds__(256) void winograd_input_kernel(const float4* __restrict__ x, float4* __restrict__ V, int H,
-                                                             int W, int C4, int TW, int T, int Tp) {
+                                                             int W, int C4, int TW, int T, int Tp, int pad, int reflect) {
     const long total = (long)Tp * C4;
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
@@ -83,9 +85,12 @@ __global__ __launch_bounds__(256) void winograd_input_kernel(const float4* __res
         }
         const int ty = (int)(tile / TW), tx = (int)(tile - (long)ty * TW);
         int ry[4], rx[4];
+        bool oky[4], okx[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            int yy = 2 * ty - 1 + k, xx = 2 * tx - 1 + k;
+            int yy = 2 * ty - pad + k, xx = 2 * tx - pad + k;
+            oky[k] = reflect || ((unsigned)yy < (unsigned)H);
+            okx[k] = reflect || ((unsigned)xx < (unsigned)W);
             yy = yy < 0 ? -yy : yy;
             xx = xx < 0 ? -xx : xx;
             // rows / columns past the reflected border only feed outputs of a ragged tile that are masked
@@ -96,7 +101,8 @@ __global__ __launch_bounds__(256) void winograd_input_kernel(const float4* __res
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
-            for (int b = 0; b < 4; ++b) d[a][b] = x[((long)ry[a] * W + rx[b]) * C4 + c4];
+            for (int b = 0; b < 4; ++b)
+                d[a][b] = (oky[a] && okx[b]) ? x[((long)ry[a] * W + rx[b]) * C4 + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
         // rows: t = B^T d
         float4 t[4][4];
 #define T2V_SUB(o, p, q) o.x = p.x - q.x; o.y = p.y - q.y; o.z = p.z - q.z; o.w = p.w - q.w;
@@ -122,10 +128,12 @@ __global__ __launch_bounds__(256) void winograd_input_kernel(const float4* __res
         }
     }
 }
-int launch_winograd_input(hipStream_t s, const float* x, float* V, int H, int W, int C) {
-    const int TW = (W + 1) / 2, T = ((H + 1) / 2) * TW, Tp = (T + 127) / 128 * 128;
+int launch_winograd_input(hipStream_t s, const float* x, float* V, int H, int W, int C, int pad, int reflect) {
+    const int Ho = H + 2 * pad - 2, Wo = W + 2 * pad - 2;
+    const int TW = (Wo + 1) / 2, T = ((Ho + 1) / 2) * TW, Tp = (T + 127) / 128 * 128;
     hipLaunchKernelGGL(winograd_input_kernel, dim3(wg_grid((long)Tp * (C / 4), 256)), dim3(256), 0, s,
-                       reinterpret_cast<const float4*>(x), reinterpret_cast<float4*>(V), H, W, C / 4, TW, T, Tp);
+                       reinterpret_cast<const float4*>(x), reinterpret_cast<float4*>(V), H, W, C / 4, TW, T, Tp, pad,
+                       reflect);
     T2V_HIP_CHECK(hipGetLastError());
     return T2V_OK;
 }
@@ -270,7 +278,7 @@ int launch_winograd4_weight(hipStream_t s, const float* w, float* U, int Cout, i
 
 // V[a*6+b][tile][c] = (B^T d B)[a][b]; one thread = one tile x 2 channels (float2; 36 live values each)
 __global__ __launch_bounds__(256) void winograd4_input_kernel(const float2* __restrict__ x, float2* __restrict__ V, int H,
-                                                              int W, int C2, int TW, int T, int Tp) {
+                                                              int W, int C2, int TW, int T, int Tp, int pad, int reflect) {
     const long total = (long)Tp * C2;
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
@@ -283,9 +291,12 @@ __global__ __launch_bounds__(256) void winograd4_input_kernel(const float2* __re
         }
         const int ty = (int)(tile / TW), tx = (int)(tile - (long)ty * TW);
         int ry[6], rx[6];
+        bool oky[6], okx[6];
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
-            int yy = 4 * ty - 1 + k, xx = 4 * tx - 1 + k;
+            int yy = 4 * ty - pad + k, xx = 4 * tx - pad + k;
+            oky[k] = reflect || ((unsigned)yy < (unsigned)H);
+            okx[k] = reflect || ((unsigned)xx < (unsigned)W);
             yy = yy < 0 ? -yy : yy;
             xx = xx < 0 ? -xx : xx;
             ry[k] = max(min(yy, 2 * H - 2 - yy), 0);   // past the reflected border: ragged tile, outputs masked
@@ -298,7 +309,7 @@ __global__ __launch_bounds__(256) void winograd4_input_kernel(const float2* __re
             float dx[6], dy[6];
 #pragma unroll
             for (int b = 0; b < 6; ++b) {
-                const float2 d = x[((long)ry[a] * W + rx[b]) * C2 + c2];
+                const float2 d = (oky[a] && okx[b]) ? x[((long)ry[a] * W + rx[b]) * C2 + c2] : make_float2(0.f, 0.f);
                 dx[b] = d.x;
                 dy[b] = d.y;
             }
@@ -323,10 +334,12 @@ __global__ __launch_bounds__(256) void winograd4_input_kernel(const float2* __re
         }
     }
 }
-int launch_winograd4_input(hipStream_t s, const float* x, float* V, int H, int W, int C) {
-    const int TW = (W + 3) / 4, T = ((H + 3) / 4) * TW, Tp = (T + 127) / 128 * 128;
+int launch_winograd4_input(hipStream_t s, const float* x, float* V, int H, int W, int C, int pad, int reflect) {
+    const int Ho = H + 2 * pad - 2, Wo = W + 2 * pad - 2;
+    const int TW = (Wo + 3) / 4, T = ((Ho + 3) / 4) * TW, Tp = (T + 127) / 128 * 128;
     hipLaunchKernelGGL(winograd4_input_kernel, dim3(wg_grid((long)Tp * (C / 2), 256)), dim3(256), 0, s,
-                       reinterpret_cast<const float2*>(x), reinterpret_cast<float2*>(V), H, W, C / 2, TW, T, Tp);
+                       reinterpret_cast<const float2*>(x), reinterpret_cast<float2*>(V), H, W, C / 2, TW, T, Tp, pad,
+                       reflect);
     T2V_HIP_CHECK(hipGetLastError());
     return T2V_OK;
 }

@@ -63,6 +63,26 @@ def winograd_supported(desc, x_cs=None, algo=None):
     return bool(mask & (2 if algo == ALGO_WINOGRAD_F4 else 1))
 
 
+def best_conv_algo(desc, x_cs=None, cap=0):
+    """ALGO_* the library would pick for `desc` (fewest GEMM rows; generator.hip uses the same rule)."""
+    x_cs = round_up(desc.Cin, 4) if x_cs is None else x_cs
+    return _lib.load().t2v_conv_best_algo(ctypes.byref(desc), x_cs, cap)
+
+
+def conv2d_auto(x, packed_w, bias, desc, y_cs=None, stats=None, out=None):
+    """conv2d or conv2d_winograd, whichever desc.algo (and the weight packing that goes with it) says."""
+    if desc.algo in (ALGO_WINOGRAD, ALGO_WINOGRAD_F4):
+        assert y_cs is None or y_cs == desc.Cout
+        return conv2d_winograd(x, packed_w, bias, desc, stats=stats, out=out)
+    return conv2d(x, packed_w, bias, desc, y_cs=y_cs, stats=stats, out=out)
+
+
+def with_algo(desc, algo):
+    """copy of a conv descriptor with another algorithm"""
+    return ConvDesc(desc.H, desc.W, desc.Cin, desc.Cout, desc.kH, desc.kW, desc.stride, desc.pad, desc.pad_mode,
+                    desc.transposed, desc.act, desc.act_scale, desc.output_padding, algo)
+
+
 def winograd_workspace(desc, x_cs, device):
     n = _lib.load().t2v_conv_winograd_workspace_floats(ctypes.byref(desc), x_cs)
     if n == 0:
@@ -77,7 +97,8 @@ def conv2d_winograd(x, packed_u, bias, desc, stats=None, out=None, workspace=Non
     _chk(x, "x")
     x_cs = x.shape[-1]
     ws = workspace if workspace is not None else winograd_workspace(desc, x_cs, x.device)
-    y = out if out is not None else torch.empty(desc.H, desc.W, desc.Cout, dtype=torch.float32, device=x.device)
+    ho, wo = conv_out_dims(desc)
+    y = out if out is not None else torch.empty(ho, wo, desc.Cout, dtype=torch.float32, device=x.device)
     check(c.lib.t2v_conv2d_forward_winograd_stages(c.handle, _stream(), ctypes.byref(desc), _p(x), x_cs, _p(packed_u),
                                                    _p(bias), _p(y), desc.Cout, _p(stats), _p(ws), stages),
           "conv2d_forward_winograd")

@@ -12,6 +12,8 @@ generator (no flow branch), multiscale image discriminator (--num_D 2), face dis
 all-reduce.  Not built: VGG and FlowNet2-based losses / temporal discriminator (external weights that
 are not in the reference tree).
 """
+import os
+
 import torch
 
 from . import ops
@@ -38,18 +40,25 @@ class _ConvBlock(torch.autograd.Function):
         ycs = ops.round_up(desc.Cout, 4)
         fdesc = ops.conv_desc(desc.H, desc.W, desc.Cin, desc.Cout, desc.kH, desc.stride, desc.pad, desc.pad_mode,
                               bool(desc.transposed), act if norm is None else ops.ACT_NONE, 0.2, desc.output_padding)
+        # 3x3 stride-1 layers (the ResnetBlock convs) run as Winograd where that is the smaller GEMM; the weight
+        # gradient keeps the direct layout (ddesc)
+        ddesc = fdesc
+        if fdesc.act == ops.ACT_NONE and ycs == desc.Cout and int(os.environ.get("T2V_CONV_ALGO", "0")) != 1:
+            algo = ops.best_conv_algo(fdesc, xcs, int(os.environ.get("T2V_CONV_ALGO", "0")))
+            if algo != ops.ALGO_DIRECT:
+                fdesc = ops.with_algo(fdesc, algo)
         pw = ops.pack_conv_weight(w.detach().contiguous(), fdesc, xcs)
         c = torch.empty(B, ho, wo, ycs, dtype=torch.float32, device=dev)
         mrs = None
         if norm is None:
             for i in range(B):
-                ops.conv2d(x[i], pw, b.detach(), fdesc, y_cs=ycs, out=c[i])
+                ops.conv2d_auto(x[i], pw, b.detach(), fdesc, y_cs=ycs, out=c[i])
             y = c
         else:
             n = ops.conv_stats_buffer(fdesc, dev).numel()
             stats = torch.empty(B * n, dtype=torch.float32, device=dev)
             for i in range(B):
-                ops.conv2d(x[i], pw, b.detach(), fdesc, y_cs=ycs, stats=stats[i * n:(i + 1) * n], out=c[i])
+                ops.conv2d_auto(x[i], pw, b.detach(), fdesc, y_cs=ycs, stats=stats[i * n:(i + 1) * n], out=c[i])
             y = torch.empty_like(c)
             g = gamma.detach() if gamma is not None else None
             bt = beta.detach() if beta is not None else None
@@ -63,7 +72,7 @@ class _ConvBlock(torch.autograd.Function):
                     ops.instance_norm_apply(c[i], mrs[i], g, bt, relu=relu, out=y[i])
         if res is not None:
             y = y + res   # residual add (plumbing-level elementwise; its gradient is the identity)
-        ctx.meta = (desc, fdesc, norm, relu, act, need_dx, mrs, gamma is not None)
+        ctx.meta = (desc, ddesc, norm, relu, act, need_dx, mrs, gamma is not None)
         ctx.save_for_backward(x, w, c, gamma, beta, y if (norm is None and act != ops.ACT_NONE) else None)
         return y
 
