@@ -168,6 +168,16 @@ size_t t2v_conv_backward_weight_workspace_floats(const t2v_conv_desc* d, int x_c
 int t2v_conv2d_backward_weight(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, int batch, const float* x,
                                int x_cs, const float* dy, int dy_cs, float* dw_packed, int accumulate,
                                float* workspace /* NULL when ..._workspace_floats() == 0 */);
+/* Weight gradient of a 3x3 stride-1 conv in the Winograd domain, F(4x4,3x3): dU[xi] = sum over tiles of
+ * (A dy A^T)[xi] x (B^T x B)[xi] -- 36 pixel-reduction GEMMs of a quarter of the direct gradient's FLOPs -- then
+ * dW = G^T dU G, written in TORCH layout [Cout][Cin][3][3] (accumulate: += ).  Where
+ * t2v_conv_backward_weight_winograd_supported() says so (the forward conditions of F(4x4,3x3) plus dy_cs == Cout). */
+int t2v_conv_backward_weight_winograd_supported(const t2v_conv_desc* d, int x_cs, int dy_cs);
+size_t t2v_conv_backward_weight_winograd_workspace_floats(const t2v_conv_desc* d, int x_cs, int batch);
+int t2v_conv2d_backward_weight_winograd(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, int batch, const float* x,
+                                        int x_cs, const float* dy, int dy_cs, float* dw_torch, int accumulate,
+                                        float* workspace);
+
 int t2v_conv_unpack_weight(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, int x_cs, const float* packed_dev,
                            float* w_torch_dev);
 int t2v_channel_sum(t2v_ctx* ctx, void* stream, const float* x, long npix, int C, int cs,

@@ -158,3 +158,31 @@ def test_pointwise_and_pooling_backward():
     a.grad = None
     ((a - b).abs().sum() * 0.02).backward()
     assert (ops.sum_abs_diff_backward(a.detach().cuda(), b.cuda(), 0.02).cpu() - a.grad).abs().max().item() <= 1e-7
+
+
+@pytest.mark.parametrize("case", [(1, 64, 32, 32, 64, 1, 1), (2, 16, 32, 64, 32, 1, 1), (1, 18, 30, 32, 32, 0, 2), (1, 64, 85, 32, 32, 1, 1)],
+                         ids=["T128", "batch2", "zero_pad2", "ragged_64x85"])
+def test_weight_gradient_in_winograd_domain(case):
+    """dW through F(4x4,3x3) transforms + 36 pixel-reduction GEMMs == torch autograd (and the direct kernel)."""
+    import torch.nn.functional as F
+    from text2video_amd import ops
+    B, H, W, Cin, Cout, reflect, pad = case
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * 0.1).requires_grad_(True)
+    xp = F.pad(x, (1, 1, 1, 1), mode="reflect") if reflect else F.pad(x, (pad, pad, pad, pad))
+    y = F.conv2d(xp, w)
+    dy = torch.randn(y.shape, generator=g)
+    (y * dy).sum().backward()
+    desc = ops.conv_desc(H, W, Cin, Cout, 3, 1, pad, ops.PAD_REFLECT if reflect else ops.PAD_ZERO)
+    xh = x.permute(0, 2, 3, 1).contiguous().cuda()
+    dyh = dy.permute(0, 2, 3, 1).contiguous().cuda()
+    assert ops.backward_weight_winograd_supported(desc, Cin, Cout)
+    dw = ops.conv2d_backward_weight_winograd(xh, dyh, desc)
+    ref = w.grad
+    assert (dw.cpu() - ref).abs().max().item() <= 2e-4 * ref.abs().max().item()
+    dwd = ops.unpack_conv_weight(ops.conv2d_backward_weight(xh, dyh, desc), desc, Cin)
+    assert (dw - dwd).abs().max().item() <= 2e-4 * ref.abs().max().item()
+    # accumulate
+    dw2 = ops.conv2d_backward_weight_winograd(xh, dyh, desc, accumulate_into=dw.clone())
+    assert (dw2 - 2 * dw).abs().max().item() <= 1e-5 * ref.abs().max().item()

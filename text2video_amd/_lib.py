@@ -67,6 +67,10 @@ SIGNATURES = {
     "t2v_instance_norm_finalize": (c_int, [c_void_p, c_void_p, POINTER(ConvDesc), c_void_p, c_float, c_void_p]),
     "t2v_batch_norm_finalize": (c_int, [c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_void_p, c_float, c_void_p]),
     "t2v_conv_backward_weight_workspace_floats": (c_size_t, [POINTER(ConvDesc), c_int, c_int]),
+    "t2v_conv_backward_weight_winograd_supported": (c_int, [POINTER(ConvDesc), c_int, c_int]),
+    "t2v_conv_backward_weight_winograd_workspace_floats": (c_size_t, [POINTER(ConvDesc), c_int, c_int]),
+    "t2v_conv2d_backward_weight_winograd": (c_int, [c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_void_p, c_int,
+                                                    c_void_p, c_int, c_void_p, c_int, c_void_p]),
     "t2v_conv2d_backward_weight": (c_int, [c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_void_p, c_int, c_void_p,
                                            c_int, c_void_p, c_int, c_void_p]),
     "t2v_conv_unpack_weight": (c_int, [c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_void_p, c_void_p]),

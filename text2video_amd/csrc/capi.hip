@@ -213,9 +213,11 @@ int winograd_forward(t2v_ctx* ctx, hipStream_t s, const t2v_conv_desc* d, const 
     float* V = workspace;
     float* Mm = workspace + wino_pos(d->algo) * T * d->Cin;
     const bool f4 = d->algo == T2V_ALGO_WINOGRAD_F4;
-    if (stages & 1)
-        T2V_TRY((f4 ? launch_winograd4_input : launch_winograd_input)(s, x, V, d->H, d->W, d->Cin, d->pad,
-                                                                      d->pad_mode == T2V_PAD_REFLECT));
+    if (stages & 1) {
+        const int reflect = d->pad_mode == T2V_PAD_REFLECT;
+        T2V_TRY(f4 ? launch_winograd4_input(s, x, V, d->H, d->W, d->Cin, d->pad, reflect)
+                   : launch_winograd_input(s, x, V, d->H, d->W, d->Cin, d->pad, reflect));
+    }
     if (stages & 2) {
         ConvPlan pl;
         T2V_TRY(build_winograd_gemm_plan(d, &pl));
@@ -439,6 +441,63 @@ int t2v_conv2d_backward_weight(t2v_ctx* ctx, void* stream, const t2v_conv_desc* 
     w.accumulate = 0;
     T2V_TRY(launch_conv_wgrad((hipStream_t)stream, w));
     return launch_wgrad_reduce((hipStream_t)stream, workspace, w.splits, (long)pl.wfloats, dw_packed, accumulate);
+}
+
+// ---- weight gradient in the Winograd domain (F(4x4,3x3)) -------------------------------------------------
+static bool wgrad_winograd_ok(const t2v_conv_desc* d, int x_cs, int dy_cs) {
+    return winograd_supported(d, x_cs, T2V_ALGO_WINOGRAD_F4) && dy_cs == d->Cout && d->Cout % 4 == 0;
+}
+int t2v_conv_backward_weight_winograd_supported(const t2v_conv_desc* d, int x_cs, int dy_cs) {
+    return d && wgrad_winograd_ok(d, x_cs, dy_cs) ? 1 : 0;
+}
+size_t t2v_conv_backward_weight_winograd_workspace_floats(const t2v_conv_desc* d, int x_cs, int batch) {
+    if (!d || batch < 1 || !winograd_supported(d, x_cs, T2V_ALGO_WINOGRAD_F4)) return 0;
+    const size_t Tp = (size_t)wino_tiles_padded(d, T2V_ALGO_WINOGRAD_F4);
+    const size_t Cout_p = (size_t)round_up(d->Cout, 128), Kp = (size_t)round_up(x_cs, kBK);
+    return 36 * batch * Tp * ((size_t)x_cs + d->Cout) + 36 * Cout_p * Kp;
+}
+int t2v_conv2d_backward_weight_winograd(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, int batch, const float* x,
+                                        int x_cs, const float* dy, int dy_cs, float* dw_torch, int accumulate,
+                                        float* workspace) {
+    T2V_REQUIRE(ctx && d && x && dy && dw_torch && workspace && batch >= 1, "backward_weight_winograd: bad arguments");
+    T2V_REQUIRE(wgrad_winograd_ok(d, x_cs, dy_cs), "backward_weight_winograd: shape not supported "
+                                                  "(t2v_conv_backward_weight_winograd_supported)");
+    hipStream_t s = (hipStream_t)stream;
+    const int Ho = wino_out_h(d), Wo = wino_out_w(d);
+    const int Tp = wino_tiles_padded(d, T2V_ALGO_WINOGRAD_F4), Tt = batch * Tp;
+    const int Cout_p = round_up(d->Cout, 128), Kp = round_up(x_cs, kBK);
+    float* V = workspace;
+    float* Md = V + (size_t)36 * Tt * x_cs;
+    float* dU = Md + (size_t)36 * Tt * d->Cout;
+    T2V_REQUIRE((long)36 * Tt * x_cs * 4 < 0x7fff0000L && (long)36 * Tt * d->Cout * 4 < 0x7fff0000L,
+                "backward_weight_winograd: transformed tensors too large for 32-bit buffer offsets (split the batch)");
+    for (int b = 0; b < batch; ++b) {
+        T2V_TRY(launch_winograd4_input(s, x + (size_t)b * d->H * d->W * x_cs, V, d->H, d->W, x_cs, d->pad,
+                                       d->pad_mode == T2V_PAD_REFLECT, batch, b));
+        T2V_TRY(launch_winograd4_dy(s, dy + (size_t)b * Ho * Wo * dy_cs, Md, Ho, Wo, d->Cout, dy_cs, batch, b));
+    }
+    // 36 reductions over the tiles on the pixel-reduction GEMM: position xi = row xi of a [36][Tt] image, taken
+    // by "tap" xi (input row offset xi, output row offset xi, its own output matrix)
+    WgradParams w;
+    memset(&w, 0, sizeof(w));
+    w.x = V; w.dy = Md; w.dw = dU;
+    w.batch = 1; w.Hin = 36; w.Win = Tt; w.Cin_s = x_cs;
+    w.Wm = Tt; w.M = Tt;
+    w.Hout = 36; w.Wout = Tt; w.Cout = d->Cout; w.Cout_s = d->Cout;
+    w.stride = 1; w.ostride = 1;
+    w.reflect = 0; w.accumulate = 0;
+    w.ntiles = (d->Cout + 127) / 128; w.ctiles = (x_cs + 127) / 128;
+    static_assert(kMaxTaps >= 36, "one tap slot per Winograd transform position");
+    for (int xi = 0; xi < 36; ++xi) {
+        w.tdy[xi] = xi; w.tdx[xi] = 0;
+        w.toy[xi] = xi; w.tox[xi] = 0;
+        w.tap_woff[xi] = (long)xi * Cout_p * Kp; w.tap_Kp[xi] = Kp; w.tap_kidx[xi] = 0;
+    }
+    w.ntaps = 36;
+    w.splits = 1;
+    w.dw_floats = (long)36 * Cout_p * Kp;
+    T2V_TRY(launch_conv_wgrad(s, w));
+    return launch_winograd4_dw(s, dU, dw_torch, d->Cout, d->Cin, Cout_p, Kp, accumulate);
 }
 
 int t2v_conv_unpack_weight(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, int x_cs, const float* packed_dev,

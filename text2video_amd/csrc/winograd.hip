@@ -277,8 +277,10 @@ int launch_winograd4_weight(hipStream_t s, const float* w, float* U, int Cout, i
 }
 
 // V[a*6+b][tile][c] = (B^T d B)[a][b]; one thread = one tile x 2 channels (float2; 36 live values each)
+// Tt / t0: V is [36][Tt][C] and this image's tiles start at row t0 (a batch of images shares one matrix)
 __global__ __launch_bounds__(256) void winograd4_input_kernel(const float2* __restrict__ x, float2* __restrict__ V, int H,
-                                                              int W, int C2, int TW, int T, int Tp, int pad, int reflect) {
+                                                              int W, int C2, int TW, int T, int Tp, int pad, int reflect,
+                                                              int Tt, int t0) {
     const long total = (long)Tp * C2;
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
@@ -286,7 +288,7 @@ __global__ __launch_bounds__(256) void winograd4_input_kernel(const float2* __re
         const int c2 = (int)(i - tile * C2);
         if (tile >= T) {   // padding tiles: zeros
 #pragma unroll
-            for (int xi = 0; xi < 36; ++xi) V[((long)xi * Tp + tile) * C2 + c2] = make_float2(0.f, 0.f);
+            for (int xi = 0; xi < 36; ++xi) V[((long)xi * Tt + t0 + tile) * C2 + c2] = make_float2(0.f, 0.f);
             continue;
         }
         const int ty = (int)(tile / TW), tx = (int)(tile - (long)ty * TW);
@@ -330,16 +332,17 @@ __global__ __launch_bounds__(256) void winograd4_input_kernel(const float2* __re
             }
 #pragma unroll
             for (int a2 = 0; a2 < 6; ++a2)
-                V[((long)(a2 * 6 + j) * Tp + tile) * C2 + c2] = make_float2(cdot<6>(f4::kBT[a2], cx), cdot<6>(f4::kBT[a2], cy));
+                V[((long)(a2 * 6 + j) * Tt + t0 + tile) * C2 + c2] = make_float2(cdot<6>(f4::kBT[a2], cx), cdot<6>(f4::kBT[a2], cy));
         }
     }
 }
-int launch_winograd4_input(hipStream_t s, const float* x, float* V, int H, int W, int C, int pad, int reflect) {
+int launch_winograd4_input(hipStream_t s, const float* x, float* V, int H, int W, int C, int pad, int reflect, int batch,
+                           int image) {
     const int Ho = H + 2 * pad - 2, Wo = W + 2 * pad - 2;
     const int TW = (Wo + 3) / 4, T = ((Ho + 3) / 4) * TW, Tp = (T + 127) / 128 * 128;
     hipLaunchKernelGGL(winograd4_input_kernel, dim3(wg_grid((long)Tp * (C / 2), 256)), dim3(256), 0, s,
                        reinterpret_cast<const float2*>(x), reinterpret_cast<float2*>(V), H, W, C / 2, TW, T, Tp, pad,
-                       reflect);
+                       reflect, batch * Tp, image * Tp);
     T2V_HIP_CHECK(hipGetLastError());
     return T2V_OK;
 }
@@ -388,6 +391,124 @@ int launch_winograd4_output(hipStream_t s, const float* Mm, const float* bias, f
     const int TW = (W + 3) / 4, T = ((H + 3) / 4) * TW, Tp = (T + 127) / 128 * 128;
     hipLaunchKernelGGL(winograd4_output_kernel, dim3(Tp / 8, (N + 63) / 64), dim3(256), 0, s, Mm, bias, y,
                        reinterpret_cast<float2*>(stats), H, W, N, TW, T, Tp);
+    T2V_HIP_CHECK(hipGetLastError());
+    return T2V_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Weight gradient in the Winograd domain (F(4x4,3x3)).  Forward: y_tile = A^T [U (.) V] A, U = G g G^T,
+// V = B^T d B.  So
+//   dU[xi][n][c] = sum_tiles (A dy_tile A^T)[xi][n] * V[xi][tile][c]          (36 reductions over tiles)
+//   dg[n][c]     = G^T dU[.][n][c] G
+// The reductions over tiles are 36 pixel-reduction GEMMs of 1/4 of the direct weight gradient's FLOPs; they run
+// on conv_wgrad_kernel unchanged (the transform position plays the role of the tap: row xi of a [36][T] "image").
+// winograd4_dy_kernel: Mdy[a*6+b][t0+tile][n] = (A dy A^T)[a][b], dy tile 4x4 (zero outside the map)
+__global__ __launch_bounds__(256) void winograd4_dy_kernel(const float2* __restrict__ dy, float2* __restrict__ Md, int Ho,
+                                                           int Wo, int C2, int cs2, int TW, int T, int Tp, int Tt, int t0) {
+    const long total = (long)Tp * C2;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const long tile = i / C2;
+        const int c2 = (int)(i - tile * C2);
+        if (tile >= T) {
+#pragma unroll
+            for (int xi = 0; xi < 36; ++xi) Md[((long)xi * Tt + t0 + tile) * C2 + c2] = make_float2(0.f, 0.f);
+            continue;
+        }
+        const int ty = (int)(tile / TW), tx = (int)(tile - (long)ty * TW);
+        // rows first: r[i][b] = sum_j dy[i][j] A^T[j][b]
+        float rx[4][6], ry[4][6];
+#pragma unroll
+        for (int i2 = 0; i2 < 4; ++i2) {
+            float vx[4], vy[4];
+#pragma unroll
+            for (int j2 = 0; j2 < 4; ++j2) {
+                const int oy = 4 * ty + i2, ox = 4 * tx + j2;
+                const float2 d = (oy < Ho && ox < Wo) ? dy[((long)oy * Wo + ox) * cs2 + c2] : make_float2(0.f, 0.f);
+                vx[j2] = d.x;
+                vy[j2] = d.y;
+            }
+#pragma unroll
+            for (int b = 0; b < 6; ++b) {
+                float ax = 0.f, ay = 0.f;
+                bool first = true;
+#pragma unroll
+                for (int j2 = 0; j2 < 4; ++j2)
+                    if (f4::kAT[j2][b] != 0.0) {
+                        const float tx_ = (float)f4::kAT[j2][b] * vx[j2], ty_ = (float)f4::kAT[j2][b] * vy[j2];
+                        ax = first ? tx_ : ax + tx_;
+                        ay = first ? ty_ : ay + ty_;
+                        first = false;
+                    }
+                rx[i2][b] = ax;
+                ry[i2][b] = ay;
+            }
+        }
+        // columns: m[a][b] = sum_i A^T[i][a] r[i][b]
+#pragma unroll
+        for (int b = 0; b < 6; ++b)
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                float ax = 0.f, ay = 0.f;
+                bool first = true;
+#pragma unroll
+                for (int i2 = 0; i2 < 4; ++i2)
+                    if (f4::kAT[i2][a] != 0.0) {
+                        const float tx_ = (float)f4::kAT[i2][a] * rx[i2][b], ty_ = (float)f4::kAT[i2][a] * ry[i2][b];
+                        ax = first ? tx_ : ax + tx_;
+                        ay = first ? ty_ : ay + ty_;
+                        first = false;
+                    }
+                Md[((long)(a * 6 + b) * Tt + t0 + tile) * C2 + c2] = make_float2(ax, ay);
+            }
+    }
+}
+int launch_winograd4_dy(hipStream_t s, const float* dy, float* Md, int Ho, int Wo, int N, int dy_cs, int batch, int image) {
+    const int TW = (Wo + 3) / 4, T = ((Ho + 3) / 4) * TW, Tp = (T + 127) / 128 * 128;
+    hipLaunchKernelGGL(winograd4_dy_kernel, dim3(wg_grid((long)Tp * (N / 2), 256)), dim3(256), 0, s,
+                       reinterpret_cast<const float2*>(dy), reinterpret_cast<float2*>(Md), Ho, Wo, N / 2, dy_cs / 2, TW, T, Tp,
+                       batch * Tp, image * Tp);
+    T2V_HIP_CHECK(hipGetLastError());
+    return T2V_OK;
+}
+
+// dg[n][c][i][j] = sum_{a,b} G[a][i] G[b][j] dU[a*6+b][n][c]   (torch layout [Cout][Cin][3][3]); fp64 like the
+// forward filter transform
+__global__ void winograd4_dw_kernel(const float* __restrict__ dU, float* __restrict__ dw, int Cout, int Cin, int Cout_p,
+                                    int Kp, int accumulate) {
+    const long total = (long)Cout * Cin;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int n = (int)(i / Cin), c = (int)(i - (long)n * Cin);
+        double t[3][6];   // t[i][b] = sum_a G[a][i] dU[a][b]
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+            double u[6];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) u[a] = (double)dU[((size_t)(a * 6 + b) * Cout_p + n) * Kp + c];
+#pragma unroll
+            for (int i2 = 0; i2 < 3; ++i2) {
+                double acc = 0.0;
+#pragma unroll
+                for (int a = 0; a < 6; ++a) acc += f4::kG[a][i2] * u[a];
+                t[i2][b] = acc;
+            }
+        }
+#pragma unroll
+        for (int i2 = 0; i2 < 3; ++i2)
+#pragma unroll
+            for (int j2 = 0; j2 < 3; ++j2) {
+                double acc = 0.0;
+#pragma unroll
+                for (int b = 0; b < 6; ++b) acc += t[i2][b] * f4::kG[b][j2];
+                float* dst = dw + ((size_t)n * Cin + c) * 9 + i2 * 3 + j2;
+                *dst = accumulate ? *dst + (float)acc : (float)acc;
+            }
+    }
+}
+int launch_winograd4_dw(hipStream_t s, const float* dU, float* dw, int Cout, int Cin, int Cout_p, int Kp, int accumulate) {
+    hipLaunchKernelGGL(winograd4_dw_kernel, dim3(wg_grid((long)Cout * Cin, 256)), dim3(256), 0, s, dU, dw, Cout, Cin, Cout_p,
+                       Kp, accumulate);
     T2V_HIP_CHECK(hipGetLastError());
     return T2V_OK;
 }

@@ -307,6 +307,31 @@ def conv2d_backward_weight(x, dy, desc, accumulate_into=None):
     return dw
 
 
+def backward_weight_winograd_supported(desc, x_cs, dy_cs):
+    return bool(_lib.load().t2v_conv_backward_weight_winograd_supported(ctypes.byref(desc), x_cs, dy_cs))
+
+
+def conv2d_backward_weight_winograd(x, dy, desc, accumulate_into=None):
+    """Weight gradient of a 3x3 stride-1 conv through the Winograd domain (F(4x4,3x3)), TORCH layout
+    [Cout,Cin,3,3].  x: [B,H,W,Cin], dy: [B,Ho,Wo,Cout] (or 3-D, B=1)."""
+    c = context()
+    if x.dim() == 3:
+        x, dy = x.unsqueeze(0), dy.unsqueeze(0)
+    _chk(x, "x")
+    _chk(dy, "dy")
+    B, x_cs, dy_cs = x.shape[0], x.shape[-1], dy.shape[-1]
+    dw = accumulate_into if accumulate_into is not None else \
+        torch.empty(desc.Cout, desc.Cin, 3, 3, dtype=torch.float32, device=x.device)
+    nws = c.lib.t2v_conv_backward_weight_winograd_workspace_floats(ctypes.byref(desc), x_cs, B)
+    if nws == 0:
+        raise RuntimeError("conv2d_backward_weight_winograd: shape not supported")
+    ws = torch.empty(nws, dtype=torch.float32, device=x.device)
+    check(c.lib.t2v_conv2d_backward_weight_winograd(c.handle, _stream(), ctypes.byref(desc), B, _p(x), x_cs, _p(dy), dy_cs,
+                                                    _p(dw), int(accumulate_into is not None), _p(ws)),
+          "conv2d_backward_weight_winograd")
+    return dw
+
+
 def unpack_conv_weight(packed, desc, x_cs=None):
     """packed layout -> torch layout ([Cout,Cin,kH,kW] or [Cin,Cout,3,3])."""
     c = context()

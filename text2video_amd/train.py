@@ -72,13 +72,16 @@ class _ConvBlock(torch.autograd.Function):
                     ops.instance_norm_apply(c[i], mrs[i], g, bt, relu=relu, out=y[i])
         if res is not None:
             y = y + res   # residual add (plumbing-level elementwise; its gradient is the identity)
-        ctx.meta = (desc, ddesc, norm, relu, act, need_dx, mrs, gamma is not None)
+        # weight gradient in the Winograd domain where the forward took F(4x4,3x3) (a quarter of the FLOPs)
+        wino_wgrad = fdesc.algo == ops.ALGO_WINOGRAD_F4 and ops.backward_weight_winograd_supported(ddesc, xcs, ycs) \
+            and os.environ.get("T2V_WGRAD_WINOGRAD", "1") != "0"
+        ctx.meta = (desc, ddesc, norm, relu, act, need_dx, mrs, gamma is not None, wino_wgrad)
         ctx.save_for_backward(x, w, c, gamma, beta, y if (norm is None and act != ops.ACT_NONE) else None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        desc, fdesc, norm, relu, act, need_dx, mrs, affine = ctx.meta
+        desc, fdesc, norm, relu, act, need_dx, mrs, affine, wino_wgrad = ctx.meta
         x, w, c, gamma, beta, y_act = ctx.saved_tensors
         dy = dy.contiguous()
         B = x.shape[0]
@@ -100,8 +103,11 @@ class _ConvBlock(torch.autograd.Function):
                 dbeta, dgamma = tot[:, 0].contiguous(), tot[:, 1].contiguous()
         # a bias in front of a norm layer has an exactly zero gradient (the norm removes the channel mean)
         db = ops.channel_sum(dc, desc.Cout) if norm is None else torch.zeros(desc.Cout, dtype=torch.float32, device=x.device)
-        dwp = ops.conv2d_backward_weight(x, dc, fdesc)
-        dw = ops.unpack_conv_weight(dwp, fdesc, x.shape[-1])
+        if wino_wgrad:
+            dw = ops.conv2d_backward_weight_winograd(x, dc, fdesc)
+        else:
+            dwp = ops.conv2d_backward_weight(x, dc, fdesc)
+            dw = ops.unpack_conv_weight(dwp, fdesc, x.shape[-1])
         dx = None
         if need_dx:
             dg = ConvDataGrad(fdesc).refresh(w.detach())
