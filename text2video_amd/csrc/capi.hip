@@ -373,12 +373,20 @@ int t2v_batch_norm_finalize(t2v_ctx* ctx, void* stream, const t2v_conv_desc* pro
                                  producer->Cout, eps, mean_rstd);
 }
 
+// narrow-input regular convs (7x7 stems: 12 / 8 channels; the discriminators' 4x4 first layers: 8): fold the taps
+// into the 128-wide channel side of the block tile
+static bool wgrad_fold(const t2v_conv_desc* d, int x_cs) {
+    static const bool off = getenv("T2V_WGRAD_FOLD") && atoi(getenv("T2V_WGRAD_FOLD")) == 0;
+    return !off && !d->transposed && x_cs < 64 && d->kH * d->kW > 1;
+}
+
 static int wgrad_splits(const t2v_conv_desc* d, int x_cs, int batch, const ConvPlan& pl) {
     // few (tap, channel-tile) blocks but a long pixel reduction (high-resolution, narrow layers): cut the
     // reduction so that >= ~512 blocks exist; partial gradients are summed in a fixed order afterwards
     int ntaps = 0;
     for (int ph = 0; ph < pl.kp.nphases; ++ph) ntaps += pl.kp.ph[ph].ntaps;
-    const long blocks = (long)ntaps * ((d->Cout + 127) / 128) * ((x_cs + 127) / 128);
+    const long blocks = wgrad_fold(d, x_cs) ? (long)((d->Cout + 127) / 128) * ((ntaps * x_cs + 127) / 128)
+                                            : (long)ntaps * ((d->Cout + 127) / 128) * ((x_cs + 127) / 128);
     const long nk = ((long)batch * pl.kp.M + 31) / 32;
     long s = (512 + blocks - 1) / blocks;
     if (s > nk / 8) s = nk / 8;      // at least 8 stages per block
@@ -429,6 +437,11 @@ int t2v_conv2d_backward_weight(t2v_ctx* ctx, void* stream, const t2v_conv_desc* 
             w.tap_woff[nt] = k.ph[ph].w_off; w.tap_Kp[nt] = k.ph[ph].Kp; w.tap_kidx[nt] = t;
         }
     w.ntaps = nt;
+    if (wgrad_fold(d, x_cs)) {
+        w.fold = 1; w.fold_taps = nt; w.KW = d->kW; w.pad = d->pad;
+        w.ctiles = (nt * x_cs + 127) / 128;
+        w.ntaps = 1;
+    }
     T2V_REQUIRE((long)batch * d->H * d->W * x_cs * 4 < 0x7fff0000L && (long)batch * pl.Hout * pl.Wout * dy_cs * 4 < 0x7fff0000L,
                 "backward_weight: tensors too large for 32-bit buffer offsets (split the batch)");
     w.splits = wgrad_splits(d, x_cs, batch, pl);

@@ -50,7 +50,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradParams p) {
     const int tap = t % p.ntaps; t /= p.ntaps;   // global tap index (all phases)
     const int split = t;
     const int n0 = nt * 128, c0 = ct * 128;
-    const int dy = p.tdy[tap], dx = p.tdx[tap];
+    const int dy = p.fold ? 0 : p.tdy[tap], dx = p.fold ? 0 : p.tdx[tap];
     const int P = p.batch * p.M;              // pixels to reduce over
     const int nk_all = (P + kWgPix - 1) / kWgPix;
     const int per = (nk_all + p.splits - 1) / p.splits;
@@ -62,7 +62,18 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradParams p) {
         const int prow = lane >> 5;           // pixel row inside the instruction's pair
         const int chunk = lane & 31;          // 16-byte chunk inside the 512-byte channel row
         const bool n_ok = n0 + chunk * 4 < p.Cout_s;
-        const bool c_ok = c0 + chunk * 4 < p.Cin_s;
+        // folded taps: this lane's chunk is 4 channels of tap (c0 + 4*chunk) / Cin_s, fixed for the whole block
+        int ldy = dy, ldx = dx, lc = c0 + chunk * 4;
+        bool c_ok = lc < p.Cin_s;
+        if (p.fold) {
+            const int kidx = c0 + chunk * 4;
+            const int ltap = kidx / p.Cin_s;
+            lc = kidx - ltap * p.Cin_s;
+            c_ok = ltap < p.fold_taps;
+            const int kh = ltap / p.KW;
+            ldy = kh - p.pad;
+            ldx = ltap - kh * p.KW - p.pad;
+        }
         const int dy_bytes = p.batch * p.Hout * p.Wout * p.Cout_s * 4;
         const int x_bytes = p.batch * p.Hin * p.Win * p.Cin_s * 4;
         auto issue_stage = [&](int kt, int slot) {
@@ -80,7 +91,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradParams p) {
                 const int vy = (ok && n_ok) ? (opix * p.Cout_s + n0 + chunk * 4) * 4 : kOOB;
                 wg_dma16(p.dy, dy_bytes, sY + (wid * 8 + i * 2) * 512, vy, 0);
                 // X: gathered through the tap
-                int iy = my * p.stride + dy, ix = mx * p.stride + dx;
+                int iy = my * p.stride + ldy, ix = mx * p.stride + ldx;
                 bool okx = ok && c_ok;
                 if constexpr (REFLECT) {
                     iy = iy < 0 ? -iy : iy;
@@ -90,7 +101,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradParams p) {
                 } else {
                     okx = okx && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
                 }
-                const int vx = okx ? (((b * p.Hin + iy) * p.Win + ix) * p.Cin_s + c0 + chunk * 4) * 4 : kOOB;
+                const int vx = okx ? (((b * p.Hin + iy) * p.Win + ix) * p.Cin_s + lc) * 4 : kOOB;
                 wg_dma16(p.x, x_bytes, sX + (wid * 8 + i * 2) * 512, vx, 0);
             }
         };
@@ -163,7 +174,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradParams p) {
     // ---- epilogue: D[row n][col c] -> packed dW[n][koff + c]  (koff: position of this tap in K) ----
     float* out = p.dw + (size_t)split * p.dw_floats + p.tap_woff[tap];
     const int Kp = p.tap_Kp[tap];
-    const int kbase = p.tap_kidx[tap] * p.Cin_s + c0;
+    const int kbase = p.fold ? c0 : p.tap_kidx[tap] * p.Cin_s + c0;
+    const int klimit = p.fold ? p.fold_taps * p.Cin_s - c0 : p.Cin_s - c0;   // valid columns of this tile
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -173,7 +185,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradParams p) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int c = wc * 64 + j * 32 + fi;
-                    if (c0 + c < p.Cin_s) {
+                    if (c < klimit) {
                         float* dst = out + (size_t)n * Kp + kbase + c;
                         *dst = p.accumulate ? *dst + acc[i][j][r] : acc[i][j][r];
                     }

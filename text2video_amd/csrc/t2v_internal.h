@@ -90,6 +90,9 @@ struct WgradParams {
     int stride, ostride;
     int ntaps, ntiles, ctiles;
     int reflect, accumulate;
+    // fold: narrow inputs (Cin_s < 64, regular conv).  The 128-wide input-channel side of the block tile then
+    // runs over K = tap*Cin_s + c of ALL taps (tap per lane chunk), instead of one tap with 128 - Cin_s idle columns
+    int fold, fold_taps, KW, pad;
     int splits;        // the pixel reduction is cut into `splits` ranges (blockIdx major), each writing its own
     long dw_floats;    // partial gradient at dw + split*dw_floats (deterministic; summed by wgrad_reduce)
     int tdy[kMaxTaps], tdx[kMaxTaps];   // input offset of every tap (all phases concatenated)
