@@ -33,6 +33,11 @@ WGRAD_CASES = [
     ("convT", 2, 8, 8, 64, 32, 3, 2, 1, 0, True),
     ("stem7x7_cin9", 1, 20, 20, 9, 32, 7, 1, 3, 1, False),
     ("head7x7_cout3", 1, 20, 16, 32, 3, 7, 1, 3, 1, False),
+    # few output channels on a wide input: taps folded onto the dY side over a padded copy of x
+    ("head7x7_cout3_wide", 1, 20, 16, 128, 3, 7, 1, 3, 1, False),
+    ("head7x7_cout3_wide_batch", 2, 18, 24, 64, 3, 7, 1, 3, 1, False),
+    ("k3_cout4_zero_pad", 2, 16, 16, 96, 4, 3, 1, 1, 0, False),
+    ("k3_cout6_nopad", 1, 16, 20, 64, 6, 3, 1, 0, 0, False),
     ("disc4x4_s2_p2", 2, 16, 16, 8, 64, 4, 2, 2, 0, False),
     ("disc4x4_s1_p2", 1, 9, 9, 64, 1, 4, 1, 2, 0, False),
     ("stem7x7_pixel_split", 1, 96, 96, 9, 32, 7, 1, 3, 1, False),       # 49 blocks, 288 stages -> split reduction

@@ -380,6 +380,16 @@ static bool wgrad_fold(const t2v_conv_desc* d, int x_cs) {
     return !off && !d->transposed && x_cs < 64 && d->kH * d->kW > 1;
 }
 
+// few output channels (the 7x7 heads: 3 -> dy_cs 4) on a wide input: fold the taps onto the dY side
+static bool wgrad_fold_n(const t2v_conv_desc* d, int x_cs, int dy_cs) {
+    static const bool off = getenv("T2V_WGRAD_FOLD") && atoi(getenv("T2V_WGRAD_FOLD")) == 0;
+    return !off && !d->transposed && d->stride == 1 && dy_cs <= 16 && x_cs >= 64 && d->kH * d->kW > 1 &&
+           d->kH * d->kW <= kMaxTaps;
+}
+static size_t wgrad_padded_floats(const t2v_conv_desc* d, int x_cs, int batch) {
+    return (size_t)batch * (d->H + 2 * d->pad) * (d->W + 2 * d->pad) * x_cs;
+}
+
 static int wgrad_splits(const t2v_conv_desc* d, int x_cs, int batch, const ConvPlan& pl) {
     // few (tap, channel-tile) blocks but a long pixel reduction (high-resolution, narrow layers): cut the
     // reduction so that >= ~512 blocks exist; partial gradients are summed in a fixed order afterwards
@@ -408,6 +418,14 @@ static int wgrad_splits(const t2v_conv_desc* d, int x_cs, int batch, const ConvP
 size_t t2v_conv_backward_weight_workspace_floats(const t2v_conv_desc* d, int x_cs, int batch) {
     ConvPlan pl;
     if (!d || build_conv_plan(d, x_cs, true, &pl) != T2V_OK) return 0;
+    const int dy_cs = round_up(d->Cout, 4);
+    if (wgrad_fold_n(d, x_cs, dy_cs)) {   // padded input copy + the partials of its own split rule
+        const long nk = ((long)batch * (d->H + 2 * d->pad) * (d->W + 2 * d->pad) + 31) / 32;
+        long s = nk / 16;
+        if (s > 256) s = 256;
+        if (s < 1) s = 1;
+        return wgrad_padded_floats(d, x_cs, batch) + (size_t)s * d->Cout * pl.kp.ph[0].Kp;   // partials: the Cout real rows
+    }
     const int s = wgrad_splits(d, x_cs, batch, pl);
     return s > 1 ? (size_t)s * pl.wfloats : 0;
 }
@@ -437,6 +455,36 @@ int t2v_conv2d_backward_weight(t2v_ctx* ctx, void* stream, const t2v_conv_desc* 
             w.tap_woff[nt] = k.ph[ph].w_off; w.tap_Kp[nt] = k.ph[ph].Kp; w.tap_kidx[nt] = t;
         }
     w.ntaps = nt;
+    if (wgrad_fold_n(d, x_cs, dy_cs) && dy_cs == round_up(d->Cout, 4)) {
+        // x -> padded copy (reflection / zeros resolved once), taps folded onto the dY side of the tile
+        T2V_REQUIRE(workspace, "backward_weight: this shape needs a workspace of "
+                               "t2v_conv_backward_weight_workspace_floats() floats");
+        hipStream_t st = (hipStream_t)stream;
+        const int Hp = d->H + 2 * d->pad, Wp = d->W + 2 * d->pad;
+        float* xp = workspace;
+        float* partial = workspace + wgrad_padded_floats(d, x_cs, batch);
+        T2V_TRY(launch_pad_copy(st, x, xp, batch, d->H, d->W, x_cs, d->pad, k.pad_mode == T2V_PAD_REFLECT));
+        T2V_REQUIRE((long)batch * Hp * Wp * x_cs * 4 < 0x7fff0000L, "backward_weight: padded input too large for 32-bit offsets");
+        w.x = xp; w.Hin = Hp; w.Win = Wp; w.Wm = Wp; w.M = Hp * Wp;
+        w.reflect = 0;
+        w.fold = 2; w.fold_taps = nt; w.KW = d->kW; w.pad = 0;
+        w.ntiles = (nt * dy_cs + 127) / 128;
+        w.ntaps = 1;
+        for (int t = 0; t < kMaxTaps; ++t) w.tdy[t] = w.tdx[t] = 0;
+        const long nk = ((long)batch * Hp * Wp + 31) / 32;
+        long sp = nk / 16;
+        if (sp > 256) sp = 256;
+        if (sp < 1) sp = 1;
+        w.splits = (int)sp;
+        // only the first Cout rows of the packed [Cout_p][Kp] matrix are ever written: partials hold just those
+        const long part = (long)d->Cout * k.ph[0].Kp;
+        w.dw_floats = part;
+        T2V_HIP_CHECK(hipMemsetAsync(partial, 0, (size_t)w.splits * part * sizeof(float), st));
+        w.dw = partial;
+        w.accumulate = 0;
+        T2V_TRY(launch_conv_wgrad(st, w));
+        return launch_wgrad_reduce(st, partial, w.splits, part, dw_packed, accumulate);
+    }
     if (wgrad_fold(d, x_cs)) {
         w.fold = 1; w.fold_taps = nt; w.KW = d->kW; w.pad = d->pad;
         w.ctiles = (nt * x_cs + 127) / 128;

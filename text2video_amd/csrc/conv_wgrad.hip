@@ -51,6 +51,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradParams p) {
     const int split = t;
     const int n0 = nt * 128, c0 = ct * 128;
     const int dy = p.fold ? 0 : p.tdy[tap], dx = p.fold ? 0 : p.tdx[tap];
+    const bool fold_n = p.fold == 2;
     const int P = p.batch * p.M;              // pixels to reduce over
     const int nk_all = (P + kWgPix - 1) / kWgPix;
     const int per = (nk_all + p.splits - 1) / p.splits;
@@ -61,11 +62,18 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradParams p) {
         // each loader wave: 4 dY instructions + 4 X instructions per stage; one instruction = 2 pixel rows
         const int prow = lane >> 5;           // pixel row inside the instruction's pair
         const int chunk = lane & 31;          // 16-byte chunk inside the 512-byte channel row
-        const bool n_ok = n0 + chunk * 4 < p.Cout_s;
+        bool n_ok = n0 + chunk * 4 < p.Cout_s;
         // folded taps: this lane's chunk is 4 channels of tap (c0 + 4*chunk) / Cin_s, fixed for the whole block
         int ldy = dy, ldx = dx, lc = c0 + chunk * 4;
         bool c_ok = lc < p.Cin_s;
-        if (p.fold) {
+        int ny = 0, nx = 0, ln = n0 + chunk * 4;     // fold on the dY side: this lane's tap shift and channel
+        if (fold_n) {
+            const int ltap = ln / p.Cout_s;
+            ln -= ltap * p.Cout_s;
+            n_ok = ltap < p.fold_taps;
+            ny = ltap / p.KW;
+            nx = ltap - ny * p.KW;
+        } else if (p.fold) {
             const int kidx = c0 + chunk * 4;
             const int ltap = kidx / p.Cin_s;
             lc = kidx - ltap * p.Cin_s;
@@ -87,8 +95,14 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradParams p) {
                 const int b = pidx / p.M, m = pidx - b * p.M;
                 const int my = m / p.Wm, mx = m - my * p.Wm;
                 // dY: output pixel of GEMM pixel m (strided for the sub-pixel phases of a transposed conv)
-                const int opix = (b * p.Hout + my * p.ostride + p.toy[tap]) * p.Wout + mx * p.ostride + p.tox[tap];
-                const int vy = (ok && n_ok) ? (opix * p.Cout_s + n0 + chunk * 4) * 4 : kOOB;
+                int opix = (b * p.Hout + my * p.ostride + p.toy[tap]) * p.Wout + mx * p.ostride + p.tox[tap];
+                bool oky = ok && n_ok;
+                if (fold_n) {   // GEMM pixel = pixel q of the padded input; y pixel q - (kh, kw), zero outside
+                    const int oy = my - ny, ox = mx - nx;
+                    oky = oky && (unsigned)oy < (unsigned)p.Hout && (unsigned)ox < (unsigned)p.Wout;
+                    opix = (b * p.Hout + oy) * p.Wout + ox;
+                }
+                const int vy = oky ? (opix * p.Cout_s + (fold_n ? ln : n0 + chunk * 4)) * 4 : kOOB;
                 wg_dma16(p.dy, dy_bytes, sY + (wid * 8 + i * 2) * 512, vy, 0);
                 // X: gathered through the tap
                 int iy = my * p.stride + ldy, ix = mx * p.stride + ldx;
@@ -174,19 +188,27 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradParams p) {
     // ---- epilogue: D[row n][col c] -> packed dW[n][koff + c]  (koff: position of this tap in K) ----
     float* out = p.dw + (size_t)split * p.dw_floats + p.tap_woff[tap];
     const int Kp = p.tap_Kp[tap];
-    const int kbase = p.fold ? c0 : p.tap_kidx[tap] * p.Cin_s + c0;
-    const int klimit = p.fold ? p.fold_taps * p.Cin_s - c0 : p.Cin_s - c0;   // valid columns of this tile
+    const int kbase = p.fold == 1 ? c0 : p.tap_kidx[tap] * p.Cin_s + c0;
+    const int klimit = p.fold == 1 ? p.fold_taps * p.Cin_s - c0 : p.Cin_s - c0;   // valid columns of this tile
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int n = n0 + wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
-            if (n < p.Cout) {
+            int n = n0 + wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+            int koff = kbase;
+            bool row_ok = n < p.Cout;
+            if (fold_n) {   // row n' = tap*Cout_s + n
+                const int ltap = n / p.Cout_s;
+                n -= ltap * p.Cout_s;
+                row_ok = ltap < p.fold_taps && n < p.Cout;
+                koff = ltap * p.Cin_s + c0;
+            }
+            if (row_ok) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int c = wc * 64 + j * 32 + fi;
                     if (c < klimit) {
-                        float* dst = out + (size_t)n * Kp + kbase + c;
+                        float* dst = out + (size_t)n * Kp + koff + c;
                         *dst = p.accumulate ? *dst + acc[i][j][r] : acc[i][j][r];
                     }
                 }

@@ -341,6 +341,40 @@ int launch_pack_convT_weight(hipStream_t s, const float* w, float* packed, int C
 // ---------------------------------------------------------------------------------------------
 // backward of the pointwise / norm / padding / pooling ops (train step)
 // ---------------------------------------------------------------------------------------------
+// xp[b][H+2p][W+2p][C] = pad(x[b]): reflection (no edge repeat) or zeros; float4 over channels
+__global__ __launch_bounds__(256) void pad_copy_kernel(const float4* __restrict__ x, float4* __restrict__ xp, int batch, int H,
+                                                       int W, int C4, int pad, int reflect) {
+    const int Hp = H + 2 * pad, Wp = W + 2 * pad;
+    const long total = (long)batch * Hp * Wp * C4;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int c4 = (int)(i % C4);
+        long pix = i / C4;
+        const int qx = (int)(pix % Wp);
+        pix /= Wp;
+        const int qy = (int)(pix % Hp), b = (int)(pix / Hp);
+        int iy = qy - pad, ix = qx - pad;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (reflect) {
+            iy = iy < 0 ? -iy : iy;
+            ix = ix < 0 ? -ix : ix;
+            iy = min(iy, 2 * H - 2 - iy);
+            ix = min(ix, 2 * W - 2 - ix);
+            v = x[(((long)b * H + iy) * W + ix) * C4 + c4];
+        } else if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+            v = x[(((long)b * H + iy) * W + ix) * C4 + c4];
+        }
+        xp[i] = v;
+    }
+}
+int launch_pad_copy(hipStream_t s, const float* x, float* xp, int batch, int H, int W, int C, int pad, int reflect) {
+    const long n4 = (long)batch * (H + 2 * pad) * (W + 2 * pad) * (C / 4);
+    hipLaunchKernelGGL(pad_copy_kernel, dim3(grid_for(n4, 256)), dim3(256), 0, s, reinterpret_cast<const float4*>(x),
+                       reinterpret_cast<float4*>(xp), batch, H, W, C / 4, pad, reflect);
+    T2V_HIP_CHECK(hipGetLastError());
+    return T2V_OK;
+}
+
 // adjoint of ReflectionPad2d(p): dx[i][j] = sum of dxp over every padded position that mirrors to (i,j)
 __global__ void reflect_pad_backward_kernel(const float* __restrict__ dxp, float* __restrict__ dx, int H, int W, int C,
                                             int p) {

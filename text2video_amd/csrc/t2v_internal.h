@@ -93,6 +93,8 @@ struct WgradParams {
     // fold: narrow inputs (Cin_s < 64, regular conv).  The 128-wide input-channel side of the block tile then
     // runs over K = tap*Cin_s + c of ALL taps (tap per lane chunk), instead of one tap with 128 - Cin_s idle columns
     int fold, fold_taps, KW, pad;
+    // fold == 2: few output channels (the 3-channel heads).  x is a padded copy (no tap shifts on the X side), the
+    // taps are folded into the 128-wide dY side instead: row n' = tap*Cout_s + n reads dY at pixel q - (kh, kw)
     int splits;        // the pixel reduction is cut into `splits` ranges (blockIdx major), each writing its own
     long dw_floats;    // partial gradient at dw + split*dw_floats (deterministic; summed by wgrad_reduce)
     int tdy[kMaxTaps], tdx[kMaxTaps];   // input offset of every tap (all phases concatenated)
@@ -107,6 +109,7 @@ int launch_unpack_conv_weight(hipStream_t s, const float* packed, float* w, int 
                               int Kp);
 int launch_unpack_convT_weight(hipStream_t s, const float* packed, float* w, int Cin, int Cout, int Cin_s, int Cout_p,
                                int K, int pad);
+int launch_pad_copy(hipStream_t s, const float* x, float* xp, int batch, int H, int W, int C, int pad, int reflect);
 int launch_reflect_pad_backward(hipStream_t s, const float* dxp, float* dx, int H, int W, int C, int p);
 int launch_inorm_backward(hipStream_t s, const float* x, const float* dy, const float* mean_rstd, const float* gamma,
                           const float* beta, int relu, long npix, int C, float* scratch, float* dx, float* sums);
