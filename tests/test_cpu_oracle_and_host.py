@@ -182,3 +182,45 @@ def test_test_py_fails_loudly_without_checkpoint(tmp_path):
                               + ["--checkpoints_dir", str(tmp_path)])
     with pytest.raises((FileNotFoundError, RuntimeError)):
         M.create_model(opt)
+
+
+def test_train_dataset_sampling(tmp_path):
+    """TrainPoseDataset: clip sampling (length, stride, start), one augmentation per clip, seeded determinism."""
+    import shutil
+    from PIL import Image
+    from text2video_amd.keypoints import read_keypoints
+    from text2video_amd.options import TrainOptions
+    from text2video_amd.pose_dataset import TrainPoseDataset, get_train_img_params, get_video_params
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "keypoints_fadg0")
+    files = sorted(f for f in os.listdir(gold) if f.startswith("sa1_"))
+    root = tmp_path / "ds"
+    for seq, reps in (("a", 3), ("b", 2)):
+        os.makedirs(root / "train_openpose" / seq)
+        os.makedirs(root / "train_img" / seq)
+        for i, f in enumerate(files * reps):
+            shutil.copyfile(os.path.join(gold, f), root / "train_openpose" / seq / ("%04d.json" % i))
+            Image.fromarray(read_keypoints(os.path.join(gold, f), (256, 192))).save(root / "train_img" / seq / ("%04d.jpg" % i))
+    opt = TrainOptions().parse(["--name", "x", "--dataroot", str(root), "--dataset_mode", "pose", "--input_nc", "3",
+                                "--resize_or_crop", "randomScaleHeight_and_scaledCrop", "--loadSize", "136", "--fineSize", "128",
+                                "--n_frames_total", "6", "--max_t_step", "3", "--random_drop_prob", "0", "--fast_pose"])
+    ds = TrainPoseDataset(opt, seed=5)
+    assert len(ds) == 2
+    c = ds.sample(0)
+    # 6 output frames + tG-1 = 2 warm-up frames; crop: height fineSize, width fineSize*w/h -> multiple of 32
+    assert c["A"].shape == c["B"].shape == (8, 128, 160, 3) and c["A"].dtype == np.uint8
+    assert 1 <= c["t_step"] <= 2 and c["start"] + 7 * c["t_step"] < 18            # 18-frame sequence: step <= (18-1)//7
+    assert 128 <= c["params"]["new_size"][1] <= 136 and c["params"]["crop_size"] == (160, 128)
+    assert c["A"].any() and c["B"].any()
+    c2 = TrainPoseDataset(opt, seed=5).sample(0)
+    assert np.array_equal(c["A"], c2["A"]) and np.array_equal(c["B"], c2["B"])     # seeded
+    assert ds.sample(1)["seq"] == "b"
+    # short sequence: the clip shrinks to what exists
+    rng = np.random.default_rng(0)
+    n, start, step = get_video_params(opt, 30, 12, rng)
+    assert n == 12 and step == 1 and start == 0
+    ds.update_training_batch(1)
+    assert ds.n_frames_total == 12
+    # plain `scaleHeight` (no crop) keeps the inference geometry
+    opt.resize_or_crop = "scaleHeight"
+    p = get_train_img_params(opt, (512, 384), rng)
+    assert p["new_size"] == p["crop_size"] and p["crop_pos"] == (0, 0)

@@ -79,6 +79,33 @@ def test_train_py_then_test_py_roundtrip(tmp_path):
     assert len(glob.glob(os.path.join(work, "results", "fadg0", "test_latest", "tmp", "fake_B_*.jpg"))) == 3
 
 
+def test_train_py_on_a_real_layout_dataset(tmp_path):
+    """The reference's training recipe (README.md:171-176) on <dataroot>/train_openpose + train_img: random scale +
+    scaled crop, clips of n_frames_total frames walked in chunks of max_frames_per_gpu with the recurrence carried."""
+    from text2video_amd.keypoints import read_keypoints
+    root = tmp_path / "vid2vid" / "datasets" / "fadg0"
+    src = os.path.join(GOLD, "keypoints_fadg0")
+    files = sorted(f for f in os.listdir(src) if f.startswith("sa1_"))
+    for seq in ("clipA", "clipB"):
+        os.makedirs(root / "train_openpose" / seq)
+        os.makedirs(root / "train_img" / seq)
+        for i, f in enumerate(files + files[::-1]):
+            shutil.copyfile(os.path.join(src, f), root / "train_openpose" / seq / ("%04d_keypoints.json" % i))
+            Image.fromarray(read_keypoints(os.path.join(src, f), (256, 192))).save(root / "train_img" / seq / ("%04d.jpg" % i))
+    env = dict(os.environ, CUDA_VISIBLE_DEVICES="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "vid2vid", "train.py"), "--name", "fadg0", "--dataroot",
+                        "datasets/fadg0", "--dataset_mode", "pose", "--input_nc", "3", "--openpose_only", "--num_D", "2",
+                        "--resize_or_crop", "randomScaleHeight_and_scaledCrop", "--loadSize", "136", "--fineSize", "128",
+                        "--batchSize", "1", "--max_frames_per_gpu", "2", "--niter", "3", "--no_first_img",
+                        "--n_frames_total", "5", "--max_t_step", "2", "--niter_step", "100", "--add_face_disc",
+                        "--random_drop_prob", "0", "--ngf", "16", "--n_blocks", "2"],
+                       cwd=tmp_path / "vid2vid", env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("(iter")]
+    assert len(lines) == 3 and "5 frames 128x160" in lines[0] and "D_f" in lines[0], r.stdout[-1500:]
+    assert os.path.exists(tmp_path / "vid2vid" / "checkpoints" / "fadg0" / "latest_net_G0.pth")
+
+
 def test_fifo_server_serves_requests(tmp_path):
     """test_fifo.py: model resident, one utterance per line written to the named pipe."""
     import time

@@ -205,3 +205,111 @@ class PoseDataset:
     def __iter__(self):
         for i in range(len(self)):
             yield self[i]
+
+
+# ------------------------------------------------------------------------------------------------
+# Training side (README.md:171-176 recipe: --dataset_mode pose --resize_or_crop
+# randomScaleHeight_and_scaledCrop --loadSize 544 --fineSize 512 --n_frames_total 12 --max_t_step 4
+# --random_drop_prob 0).  The sampling rules are upstream vid2vid's base_dataset.get_img_params /
+# get_video_params [RECALL: un-vendored, SURVEY App. F]; nothing in the reference tree pins them.
+# ------------------------------------------------------------------------------------------------
+def make_power_2(n, base=32):
+    return max(base, int(round(n / base)) * base)
+
+
+def get_train_img_params(opt, size, rng):
+    """One random scale + crop for a whole clip.  -> dict(new_size=(w,h), crop_size=(w,h), crop_pos=(x,y))."""
+    w, h = size
+    mode = opt.resize_or_crop
+    new_w, new_h = w, h
+    if "resize" in mode:
+        new_h = new_w = opt.loadSize
+    elif "randomScaleWidth" in mode:
+        new_w = int(rng.integers(opt.fineSize, opt.loadSize + 1))
+        new_h = new_w * h // w
+    elif "randomScaleHeight" in mode:
+        new_h = int(rng.integers(opt.fineSize, opt.loadSize + 1))
+        new_w = new_h * w // h
+    elif "scaleWidth" in mode:
+        new_w, new_h = opt.loadSize, opt.loadSize * h // w
+    elif "scaleHeight" in mode:
+        new_h, new_w = opt.loadSize, opt.loadSize * w // h
+    new_w, new_h = int(round(new_w / 4)) * 4, int(round(new_h / 4)) * 4
+    crop_x = crop_y = crop_w = crop_h = 0
+    if "crop" in mode or "scaledCrop" in mode:
+        if "scaledCrop" in mode:
+            if "Width" in mode:
+                crop_w, crop_h = opt.fineSize, opt.fineSize * h // w
+            else:
+                crop_h, crop_w = opt.fineSize, opt.fineSize * w // h
+        else:
+            crop_w = crop_h = opt.fineSize
+        crop_w, crop_h = min(make_power_2(crop_w), new_w // 4 * 4), min(make_power_2(crop_h), new_h // 4 * 4)
+        x_span = (new_w - crop_w) // 2
+        crop_x = int(max(0, min(x_span * 2, int(rng.standard_normal() * x_span / 3 + x_span))))
+        crop_y = int(rng.integers(0, min(max(0, new_h - crop_h), new_h // 8) + 1))
+    else:
+        new_w, new_h = make_power_2(new_w), make_power_2(new_h)
+        crop_w, crop_h = new_w, new_h
+    return {"new_size": (new_w, new_h), "crop_size": (crop_w, crop_h), "crop_pos": (crop_x, crop_y)}
+
+
+def get_video_params(opt, n_frames_total, seq_len, rng):
+    """-> (n_frames incl. the tG-1 warm-up frames, start index, frame step)."""
+    tG = opt.n_frames_G
+    n = min(n_frames_total, seq_len - tG + 1) + tG - 1
+    max_t_step = max(1, min(opt.max_t_step, (seq_len - 1) // max(1, n - 1)))
+    t_step = int(rng.integers(1, max_t_step + 1))
+    offset_max = max(1, seq_len - (n - 1) * t_step)
+    return n, int(rng.integers(0, offset_max)), t_step
+
+
+class TrainPoseDataset:
+    """<dataroot>/train_openpose/<seq>/*.json + <dataroot>/train_img/<seq>/*.jpg (one image per JSON).
+    sample(i) -> a clip: pose maps A and frames B as uint8 [T,H,W,3] with ONE augmentation for the clip."""
+
+    def __init__(self, opt, seed=0):
+        self.opt = opt
+        self.op = {s: [f for f in fs if f.endswith(".json")]
+                   for s, fs in _seq_dirs(os.path.join(opt.dataroot, "train_openpose")).items()}
+        self.img = {s: [f for f in fs if f.lower().endswith(IMG_EXT)]
+                    for s, fs in _seq_dirs(os.path.join(opt.dataroot, "train_img")).items()}
+        self.seqs = [s for s in self.op if self.op[s]]
+        if not self.seqs:
+            raise FileNotFoundError("no training sequences under %s" % os.path.join(opt.dataroot, "train_openpose"))
+        for s in self.seqs:
+            if len(self.img.get(s, [])) != len(self.op[s]):
+                raise ValueError("sequence %s: %d pose files vs %d images" % (s, len(self.op[s]), len(self.img.get(s, []))))
+            if len(self.op[s]) < opt.n_frames_G:
+                raise ValueError("sequence %s is shorter than n_frames_G=%d" % (s, opt.n_frames_G))
+        self.rng = np.random.default_rng(seed)
+        self.n_frames_total = opt.n_frames_total
+
+    def __len__(self):
+        return len(self.seqs)
+
+    def update_training_batch(self, ratio):
+        """upstream doubles the clip length every --niter_step epochs: n_frames_total * 2**ratio (capped)."""
+        self.n_frames_total = min(getattr(self.opt, "max_frames_total", 10 ** 9), self.opt.n_frames_total * (2 ** ratio))
+
+    def sample(self, index):
+        opt, rng = self.opt, self.rng
+        seq = self.seqs[index % len(self.seqs)]
+        n, start, step = get_video_params(opt, self.n_frames_total, len(self.op[seq]), rng)
+        with Image.open(self.img[seq][0]) as im:
+            size = im.size
+        prm = get_train_img_params(opt, size, rng)
+        (nw, nh), (cw, ch), (cx, cy) = prm["new_size"], prm["crop_size"], prm["crop_pos"]
+        A, B = [], []
+        for i in range(n):
+            t = start + i * step
+            a = keypoints.read_keypoints(self.op[seq][t], size, opt.random_drop_prob, opt.remove_face_labels,
+                                         opt.basic_point_only, exact_fit=not opt.fast_pose,
+                                         hand_discs=not opt.no_hand_discs, rng=rng)
+            a = Image.fromarray(a).resize((nw, nh), Image.NEAREST)
+            with Image.open(self.img[seq][t]) as im:
+                b = im.convert("RGB").resize((nw, nh), Image.BICUBIC)
+            box = (cx, cy, cx + cw, cy + ch)
+            A.append(np.asarray(a.crop(box)))
+            B.append(np.asarray(b.crop(box)))
+        return {"A": np.stack(A), "B": np.stack(B), "seq": seq, "start": start, "t_step": step, "params": prm}

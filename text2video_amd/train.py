@@ -513,29 +513,58 @@ def run_train(opt, steps=None):
     dev = "cuda:%d" % local_rank
     torch.cuda.set_device(local_rank)
     trainer = Vid2VidTrainer(opt, dev)
-    if not getattr(opt, "synthetic_data", False):
-        raise NotImplementedError("training data loader for real datasets is not built yet (round 2); "
-                                  "pass --synthetic_data to run the train step on synthetic sequences")
-    H = W = opt.fineSize
     F_ = opt.max_frames_per_gpu
-    rng = np.random.default_rng(100 + rank)          # every rank has its own sequence (batchSize = world)
     steps = steps if steps is not None else opt.niter
     t0, stats = time.perf_counter(), []
-    for it in range(steps):
-        pose_np = np.where(rng.random((F_, H, W, 1)) < 0.02, rng.uniform(-1, 1, (F_, H, W, 9)), -1.0).astype(np.float32)
-        pose = torch.zeros(F_, H, W, 12, device=dev)
-        pose[..., :9] = torch.from_numpy(pose_np).to(dev)
-        real = torch.zeros(F_, H, W, 4, device=dev)
-        real[..., :3] = torch.tanh(torch.from_numpy(rng.standard_normal((F_, H, W, 3)).astype(np.float32))).to(dev)
-        side = max(8, opt.fineSize // 32 * 8)
-        boxes = [(H // 8, H // 8 + side, (W - side) // 2, (W - side) // 2 + side)] * F_ if opt.add_face_disc else None
-        ts = time.perf_counter()
-        losses, _ = trainer.train_step(pose, real, boxes)
-        torch.cuda.synchronize()
-        stats.append(time.perf_counter() - ts)
-        if rank == 0 and (it % max(1, opt.print_freq // 100) == 0 or it == steps - 1):
-            print("(iter %d, %.0f ms, all-reduce %.1f MB) %s" % (it, 1e3 * stats[-1], trainer.comm_bytes / 2**20,
-                                                                 " ".join("%s: %.3f" % kv for kv in losses.items())), flush=True)
+    if getattr(opt, "synthetic_data", False):
+        H = W = opt.fineSize
+        rng = np.random.default_rng(100 + rank)          # every rank has its own sequence (batchSize = world)
+        for it in range(steps):
+            pose_np = np.where(rng.random((F_, H, W, 1)) < 0.02, rng.uniform(-1, 1, (F_, H, W, 9)), -1.0).astype(np.float32)
+            pose = torch.zeros(F_, H, W, 12, device=dev)
+            pose[..., :9] = torch.from_numpy(pose_np).to(dev)
+            real = torch.zeros(F_, H, W, 4, device=dev)
+            real[..., :3] = torch.tanh(torch.from_numpy(rng.standard_normal((F_, H, W, 3)).astype(np.float32))).to(dev)
+            side = max(8, opt.fineSize // 32 * 8)
+            boxes = [(H // 8, H // 8 + side, (W - side) // 2, (W - side) // 2 + side)] * F_ if opt.add_face_disc else None
+            ts = time.perf_counter()
+            losses, _ = trainer.train_step(pose, real, boxes)
+            torch.cuda.synchronize()
+            stats.append(time.perf_counter() - ts)
+            if rank == 0 and (it % max(1, opt.print_freq // 100) == 0 or it == steps - 1):
+                print("(iter %d, %.0f ms, all-reduce %.1f MB) %s" % (it, 1e3 * stats[-1], trainer.comm_bytes / 2**20,
+                                                                     " ".join("%s: %.3f" % kv for kv in losses.items())), flush=True)
+    else:
+        # real data: <dataroot>/train_openpose + train_img.  One clip per rank per iteration (batchSize = world
+        # size), walked in chunks of max_frames_per_gpu frames with the generated frames carried over
+        # (detached) from chunk to chunk, one optimiser step per chunk -- upstream's truncated recurrence.
+        from .pose_dataset import TrainPoseDataset
+        ds = TrainPoseDataset(opt, seed=1000 + rank)
+        tG = opt.n_frames_G
+        for it in range(steps):
+            epoch = it // max(1, len(ds) // world)     # one clip per sequence and epoch
+            ds.update_training_batch(epoch // max(1, opt.niter_step))
+            clip = ds.sample(it * world + rank)
+            A = torch.from_numpy(clip["A"]).to(dev)                      # [T,H,W,3] uint8
+            B = torch.from_numpy(clip["B"]).to(dev)
+            T_, H, W = A.shape[0], A.shape[1], A.shape[2]
+            prev, ts = None, time.perf_counter()
+            for c0 in range(tG - 1, T_, F_):
+                fr = list(range(c0, min(c0 + F_, T_)))
+                pose = torch.zeros(len(fr), H, W, 12, device=dev)
+                for j, t in enumerate(fr):
+                    for f in range(tG):                                    # window: oldest frame first
+                        ops.pose_u8_to_f32(A[t - tG + 1 + f], pose[j], 3 * f)
+                real = torch.zeros(len(fr), H, W, 4, device=dev)
+                real[..., :3] = (B[fr].float() / 255.0 - 0.5) / 0.5
+                boxes = [get_face_region(clip["A"][t], min(H, W)) for t in fr] if opt.add_face_disc else None
+                losses, prev = trainer.train_step(pose, real, boxes, prev)
+            torch.cuda.synchronize()
+            stats.append(time.perf_counter() - ts)
+            if rank == 0 and (it % max(1, opt.print_freq // 100) == 0 or it == steps - 1):
+                print("(iter %d, seq %s, %d frames %dx%d step %d, %.0f ms, all-reduce %.1f MB) %s"
+                      % (it, clip["seq"], T_ - tG + 1, H, W, clip["t_step"], 1e3 * stats[-1], trainer.comm_bytes / 2**20,
+                         " ".join("%s: %.3f" % kv for kv in losses.items())), flush=True)
     if rank == 0:
         trainer.save("latest")
     return {"ms_per_step": 1e3 * float(np.median(stats)), "steps": steps, "world": world}
