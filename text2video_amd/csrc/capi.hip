@@ -171,6 +171,13 @@ int build_winograd_gemm_plan(const t2v_conv_desc* d, ConvPlan* pl) {
     g.H = wino_pos(d->algo); g.W = T; g.Cin = d->Cin; g.Cout = d->Cout; g.kH = g.kW = 1; g.stride = 1; g.pad = 0;
     g.pad_mode = T2V_PAD_ZERO; g.act = T2V_ACT_NONE; g.act_scale = 1.f;
     T2V_TRY(build_conv_plan(&g, d->Cin, /*need_stats: 128- or 64-row tiles only*/ true, pl));
+    if (T % pl->BM != 0 && pl->tile == kTileL) {   // tile count padded to 64 only: the 64x64 tile config
+        pl->tile = kTileQ;
+        conv_tile_dims(pl->tile, &pl->BM, &pl->BN);
+        pl->kp.ntiles = (g.Cout + pl->BN - 1) / pl->BN;
+        pl->kp.mtiles = (pl->kp.M + pl->BM - 1) / pl->BM;
+        pl->nparts = pl->kp.nphases * pl->kp.mtiles;
+    }
     pl->kp.group_mtiles = T / pl->BM;               // T % 128 == 0 and BM in {128, 64, 256?}: checked below
     T2V_REQUIRE(T % pl->BM == 0, "winograd gemm: tile rows %d do not divide %d", pl->BM, T);
     pl->kp.group_w_stride = (long)pl->Cout_p * d->Cin;

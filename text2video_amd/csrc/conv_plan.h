@@ -24,7 +24,7 @@ inline int wino_out_w(const t2v_conv_desc* d) { return d->W + 2 * d->pad - 2; }
 inline int wino_tiles_padded(const t2v_conv_desc* d, int algo) {
     const int m = wino_m(algo);
     const int T = ((wino_out_h(d) + m - 1) / m) * ((wino_out_w(d) + m - 1) / m);
-    return (T + 127) / 128 * 128;
+    return wino_pad_tiles(T);
 }
 inline size_t winograd_workspace_floats(const t2v_conv_desc* d) {                    // V + M
     return (size_t)wino_pos(d->algo) * wino_tiles_padded(d, d->algo) * ((size_t)d->Cin + d->Cout);

@@ -89,7 +89,7 @@ int launch_inorm_finalize(hipStream_t s, const float* stats, int nparts, int mti
 // partials written by the Winograd output transform F(wm x wm, 3x3) of an H x W map
 int launch_inorm_finalize_winograd(hipStream_t s, const float* stats, int wm, int H, int W, int C, float eps,
                                    float* mean_rstd, int batch) {
-    const int T = ((H + wm - 1) / wm) * ((W + wm - 1) / wm), Tp = (T + 127) / 128 * 128;
+    const int T = ((H + wm - 1) / wm) * ((W + wm - 1) / wm), Tp = wino_pad_tiles(T);
     const int nparts = Tp / (128 / (wm * wm));   // per image; a batch's partial blocks are contiguous
     hipLaunchKernelGGL(inorm_finalize_kernel, dim3((C + 15) / 16), dim3(16 * kFinSlices), 0, s,
                        reinterpret_cast<const float2*>(stats), batch * nparts, nparts, 0, H * W, C, eps,

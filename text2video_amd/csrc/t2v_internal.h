@@ -116,6 +116,13 @@ int launch_inorm_backward(hipStream_t s, const float* x, const float* dy, const 
 int launch_act_backward(hipStream_t s, const float* dy, const float* y, int mode, float slope, long n, float* dpre);
 int launch_avgpool3s2_backward(hipStream_t s, const float* dy, float* dx, int H, int W, int C);
 int launch_loss_backward(hipStream_t s, int op, const float* a, const float* b, float c, float scale, long n, float* da);
+// Winograd tile count padded so that every transform position owns whole GEMM tiles: a multiple of 128 (128x128
+// tiles), or of 64 (forces the 64x64 tile config) when that drops at least an eighth of the rows -- e.g. the
+// 66x66 data gradient of a 64x64 map: 289 tiles -> 320 instead of 384
+inline int wino_pad_tiles(int T) {
+    const int a = (T + 63) / 64 * 64, b = (T + 127) / 128 * 128;
+    return (b - a) * 8 >= b ? a : b;
+}
 int launch_winograd_weight(hipStream_t s, const float* w, float* U, int Cout, int Cin, int Cout_p, int Cin_s);
 int launch_winograd_input(hipStream_t s, const float* x, float* V, int H, int W, int C, int pad, int reflect);
 int launch_winograd_output(hipStream_t s, const float* Mm, const float* bias, float* y, float* stats, int H, int W, int N);

@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void winograd_input_kernel(const float4* __res
 }
 int launch_winograd_input(hipStream_t s, const float* x, float* V, int H, int W, int C, int pad, int reflect) {
     const int Ho = H + 2 * pad - 2, Wo = W + 2 * pad - 2;
-    const int TW = (Wo + 1) / 2, T = ((Ho + 1) / 2) * TW, Tp = (T + 127) / 128 * 128;
+    const int TW = (Wo + 1) / 2, T = ((Ho + 1) / 2) * TW, Tp = wino_pad_tiles(T);
     hipLaunchKernelGGL(winograd_input_kernel, dim3(wg_grid((long)Tp * (C / 4), 256)), dim3(256), 0, s,
                        reinterpret_cast<const float4*>(x), reinterpret_cast<float4*>(V), H, W, C / 4, TW, T, Tp, pad,
                        reflect);
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256) void winograd_output_kernel(const float* __res
     block_stats_128(out, mask, sh, tl, cl, ok, stats, N, n);
 }
 int launch_winograd_output(hipStream_t s, const float* Mm, const float* bias, float* y, float* stats, int H, int W, int N) {
-    const int TW = (W + 1) / 2, T = ((H + 1) / 2) * TW, Tp = (T + 127) / 128 * 128;
+    const int TW = (W + 1) / 2, T = ((H + 1) / 2) * TW, Tp = wino_pad_tiles(T);
     hipLaunchKernelGGL(winograd_output_kernel, dim3(Tp / 32, (N + 63) / 64), dim3(256), 0, s, Mm, bias, y,
                        reinterpret_cast<float2*>(stats), H, W, N, TW, T, Tp);
     T2V_HIP_CHECK(hipGetLastError());
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(256) void winograd4_input_kernel(const float2* __re
 int launch_winograd4_input(hipStream_t s, const float* x, float* V, int H, int W, int C, int pad, int reflect, int batch,
                            int image) {
     const int Ho = H + 2 * pad - 2, Wo = W + 2 * pad - 2;
-    const int TW = (Wo + 3) / 4, T = ((Ho + 3) / 4) * TW, Tp = (T + 127) / 128 * 128;
+    const int TW = (Wo + 3) / 4, T = ((Ho + 3) / 4) * TW, Tp = wino_pad_tiles(T);
     hipLaunchKernelGGL(winograd4_input_kernel, dim3(wg_grid((long)Tp * (C / 2), 256)), dim3(256), 0, s,
                        reinterpret_cast<const float2*>(x), reinterpret_cast<float2*>(V), H, W, C / 2, TW, T, Tp, pad,
                        reflect, batch * Tp, image * Tp);
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(256) void winograd4_output_kernel(const float* __re
     block_stats_128(out, mask, sh, tl, cl, ok, stats, N, n);
 }
 int launch_winograd4_output(hipStream_t s, const float* Mm, const float* bias, float* y, float* stats, int H, int W, int N) {
-    const int TW = (W + 3) / 4, T = ((H + 3) / 4) * TW, Tp = (T + 127) / 128 * 128;
+    const int TW = (W + 3) / 4, T = ((H + 3) / 4) * TW, Tp = wino_pad_tiles(T);
     hipLaunchKernelGGL(winograd4_output_kernel, dim3(Tp / 8, (N + 63) / 64), dim3(256), 0, s, Mm, bias, y,
                        reinterpret_cast<float2*>(stats), H, W, N, TW, T, Tp);
     T2V_HIP_CHECK(hipGetLastError());
@@ -464,7 +464,7 @@ __global__ __launch_bounds__(256) void winograd4_dy_kernel(const float2* __restr
     }
 }
 int launch_winograd4_dy(hipStream_t s, const float* dy, float* Md, int Ho, int Wo, int N, int dy_cs, int batch, int image) {
-    const int TW = (Wo + 3) / 4, T = ((Ho + 3) / 4) * TW, Tp = (T + 127) / 128 * 128;
+    const int TW = (Wo + 3) / 4, T = ((Ho + 3) / 4) * TW, Tp = wino_pad_tiles(T);
     hipLaunchKernelGGL(winograd4_dy_kernel, dim3(wg_grid((long)Tp * (N / 2), 256)), dim3(256), 0, s,
                        reinterpret_cast<const float2*>(dy), reinterpret_cast<float2*>(Md), Ho, Wo, N / 2, dy_cs / 2, TW, T, Tp,
                        batch * Tp, image * Tp);
