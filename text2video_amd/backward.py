@@ -13,7 +13,6 @@ computes all of them.
 """
 import os
 
-import torch
 
 from . import ops
 
