@@ -29,7 +29,9 @@ int build_conv_plan(const t2v_conv_desc* d, int x_cs, bool need_stats, ConvPlan*
     ConvKParams& k = pl.kp;
     // the small-Cout tile has no statistics epilogue; weights are always packed to the 128-row
     // granule so either tile can read them
-    pl.tile = need_stats ? kTileL : conv_tile_for(d->Cout);
+    // narrow outputs (<= 64 channels: the 1024x1024 local enhancer's stems) use the 64x64 tile: half of a 128-wide
+    // tile would be padding
+    pl.tile = need_stats ? (d->Cout <= 64 ? kTileQ : kTileL) : (d->Cout > 16 && d->Cout <= 64 ? kTileQ : conv_tile_for(d->Cout));
     conv_tile_dims(pl.tile, &pl.BM, &pl.BN);
     k.Hin = d->H;
     k.Win = d->W;

@@ -18,24 +18,16 @@ static inline int grid_for(long n, int block) {
 // ---------------------------------------------------------------------------------------------
 // Instance norm.  Semantics: F.instance_norm -> batch_norm(training=True) on [1,B*C,H,W]
 // ($SP/torch/nn/functional.py:1258-1301): biased variance, y=(x-mean)/sqrt(var+eps)*gamma+beta.
-// Statistics arrive as per-tile (mean_b, M2_b) partials from the conv epilogue; they are merged
-// with Chan's parallel update (numerically a two-pass variance, no E[x^2]-E[x]^2 cancellation).
+// Statistics arrive as per-tile (mean_b, M2_b) partials from the conv epilogue; they are pooled as
+// count-weighted moments about a reference mean in fp64 (numerically a two-pass variance, no E[x^2]-E[x]^2
+// cancellation).
 // ---------------------------------------------------------------------------------------------
-struct Moments {
-    float n, mean, m2;
-};
-__device__ __forceinline__ void chan_merge(Moments& a, float nb, float mb, float m2b) {
-    if (nb <= 0.f) return;
-    const float n = a.n + nb;
-    const float delta = mb - a.mean;
-    const float f = nb / n;
-    a.mean += delta * f;
-    a.m2 += m2b + delta * delta * a.n * f;
-    a.n = n;
-}
-
-// block = kFinSlices slices x 16 channels; grid = ceil(C/16).  64 slices: the 512x512 layers have 2048 partials per
-// channel and only 8 blocks' worth of channels -- the loop over partials is the whole run time (54 -> 14 us)
+// block = kFinSlices slices x 16 channels; grid = ceil(C/16).  The high-resolution layers have thousands of
+// partials per channel (2048 at 512x512, 8192 at 1024x1024) and only a few blocks' worth of channels, so the loop
+// over partials IS the run time: it carries no dependent chain -- each slice accumulates count-weighted power
+// sums of (mean_b - ref) in fp64 (ref = the first partial's mean: no cancellation, and a constant map gives
+// exactly mean = ref, M2 = 0), the slices are tree-free summed in a fixed order at the end:
+//   mean = ref + S1/S0,   M2 = sum M2_b + S2 - S1^2/S0        (the pooled-variance identity Chan's update telescopes)
 // Pixel count of partial `part`: conv-kernel partials cover BM consecutive GEMM rows of a phase; the Winograd
 // output transform's partials (wm = 2 | 4 > 0) cover 128/wm^2 consecutive wm x wm tiles of the ceil(H/wm) x
 // ceil(W/wm) tile grid, ragged at the bottom / right edge and padded with empty tiles at the end.
@@ -43,38 +35,57 @@ constexpr int kFinSlices = 64;
 __global__ __launch_bounds__(16 * kFinSlices) void inorm_finalize_kernel(const float2* __restrict__ stats, int nparts, int mtiles,
                                                              int BM, int M, int C, float eps,
                                                              float2* __restrict__ mean_rstd, int wm, int H, int W) {
-    __shared__ float sh[3][kFinSlices][17];
+    __shared__ double sh[4][kFinSlices][17];
     const int cc = threadIdx.x & 15, sl = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cc;
-    Moments a{0.f, 0.f, 0.f};
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, sm2 = 0.0;
+    float ref = 0.f;
     if (c < C) {
+        ref = stats[c].x;
+        const bool uniform = wm == 0 && M % BM == 0;   // every partial covers BM pixels: no per-partial count
+#pragma unroll 4
         for (int part = sl; part < nparts; part += kFinSlices) {
-            int nb;
-            if (wm == 0) {
-                const int mt = part % mtiles;
-                nb = min(BM, M - mt * BM);
-            } else {
-                const int TW = (W + wm - 1) / wm, T = ((H + wm - 1) / wm) * TW, tpb = 128 / (wm * wm);
-                const int pi = part % mtiles;   // partial index inside its image (mtiles = partials per image)
-                nb = 0;
-                for (int t = pi * tpb; t < min((pi + 1) * tpb, T); ++t) {
-                    const int ty = t / TW, tx = t - ty * TW;
-                    nb += min(wm, H - wm * ty) * min(wm, W - wm * tx);
+            int nb = BM;
+            if (!uniform) {
+                if (wm == 0) {
+                    const int mt = part % mtiles;
+                    nb = min(BM, M - mt * BM);
+                } else {
+                    const int TW = (W + wm - 1) / wm, T = ((H + wm - 1) / wm) * TW, tpb = 128 / (wm * wm);
+                    const int pi = part % mtiles;   // partial index inside its image (mtiles = partials per image)
+                    nb = 0;
+                    for (int t = pi * tpb; t < min((pi + 1) * tpb, T); ++t) {
+                        const int ty = t / TW, tx = t - ty * TW;
+                        nb += min(wm, H - wm * ty) * min(wm, W - wm * tx);
+                    }
+                    if (nb == 0) continue;
                 }
-                if (nb == 0) continue;
             }
             const float2 v = stats[(size_t)part * C + c];
-            chan_merge(a, (float)nb, v.x, v.y);
+            const double d = (double)(v.x - ref), n = (double)nb;
+            s0 += n;
+            s1 += n * d;
+            s2 += n * d * d;
+            sm2 += (double)v.y;
         }
     }
-    sh[0][sl][cc] = a.n;
-    sh[1][sl][cc] = a.mean;
-    sh[2][sl][cc] = a.m2;
+    sh[0][sl][cc] = s0;
+    sh[1][sl][cc] = s1;
+    sh[2][sl][cc] = s2;
+    sh[3][sl][cc] = sm2;
     __syncthreads();
     if (sl == 0 && c < C) {
-        for (int s = 1; s < kFinSlices; ++s) chan_merge(a, sh[0][s][cc], sh[1][s][cc], sh[2][s][cc]);
-        const float var = a.m2 / a.n;
-        mean_rstd[c] = make_float2(a.mean, 1.0f / sqrtf(var + eps));
+        for (int s = 1; s < kFinSlices; ++s) {
+            s0 += sh[0][s][cc];
+            s1 += sh[1][s][cc];
+            s2 += sh[2][s][cc];
+            sm2 += sh[3][s][cc];
+        }
+        const double mean_d = s1 / s0;
+        double m2 = sm2 + s2 - s1 * mean_d;
+        m2 = m2 > 0.0 ? m2 : 0.0;
+        const float var = (float)(m2 / s0);
+        mean_rstd[c] = make_float2(ref + (float)mean_d, 1.0f / sqrtf(var + eps));
     }
 }
 
