@@ -34,7 +34,11 @@ static inline int grid_for(long n, int block) {
 constexpr int kFinSlices = 64;
 __global__ __launch_bounds__(16 * kFinSlices) void inorm_finalize_kernel(const float2* __restrict__ stats, int nparts, int mtiles,
                                                              int BM, int M, int C, float eps,
-                                                             float2* __restrict__ mean_rstd, int wm, int H, int W) {
+                                                             float2* __restrict__ mean_rstd, int wm, int H, int W,
+                                                             double* __restrict__ scratch) {
+    // gridDim.y > 1 (scratch given): block y pools every gridDim.y-th group of partials and leaves its four sums
+    // in scratch[y][c][4]; inorm_finalize_merge_kernel adds the groups up.  One block per 16 channels cannot pull
+    // a 1024x1024 layer's 16384 x 64 partials (8 MB) through a single CU in less than ~1 ms.
     __shared__ double sh[4][kFinSlices][17];
     const int cc = threadIdx.x & 15, sl = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cc;
@@ -44,7 +48,7 @@ __global__ __launch_bounds__(16 * kFinSlices) void inorm_finalize_kernel(const f
         ref = stats[c].x;
         const bool uniform = wm == 0 && M % BM == 0;   // every partial covers BM pixels: no per-partial count
 #pragma unroll 4
-        for (int part = sl; part < nparts; part += kFinSlices) {
+        for (int part = blockIdx.y * kFinSlices + sl; part < nparts; part += kFinSlices * gridDim.y) {
             int nb = BM;
             if (!uniform) {
                 if (wm == 0) {
@@ -81,6 +85,11 @@ __global__ __launch_bounds__(16 * kFinSlices) void inorm_finalize_kernel(const f
             s2 += sh[2][s][cc];
             sm2 += sh[3][s][cc];
         }
+        if (scratch != nullptr) {
+            double* o = scratch + ((size_t)blockIdx.y * C + c) * 4;
+            o[0] = s0; o[1] = s1; o[2] = s2; o[3] = sm2;
+            return;
+        }
         const double mean_d = s1 / s0;
         double m2 = sm2 + s2 - s1 * mean_d;
         m2 = m2 > 0.0 ? m2 : 0.0;
@@ -89,24 +98,56 @@ __global__ __launch_bounds__(16 * kFinSlices) void inorm_finalize_kernel(const f
     }
 }
 
-int launch_inorm_finalize(hipStream_t s, const float* stats, int nparts, int mtiles, int BM, int M, int C,
-                          float eps, float* mean_rstd) {
-    hipLaunchKernelGGL(inorm_finalize_kernel, dim3((C + 15) / 16), dim3(16 * kFinSlices), 0, s,
+__global__ void inorm_finalize_merge_kernel(const float2* __restrict__ stats, const double* __restrict__ scratch, int groups,
+                                            int C, float eps, float2* __restrict__ mean_rstd) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, sm2 = 0.0;
+    for (int g = 0; g < groups; ++g) {   // fixed order
+        const double* o = scratch + ((size_t)g * C + c) * 4;
+        s0 += o[0]; s1 += o[1]; s2 += o[2]; sm2 += o[3];
+    }
+    const double mean_d = s1 / s0;
+    double m2 = sm2 + s2 - s1 * mean_d;
+    m2 = m2 > 0.0 ? m2 : 0.0;
+    mean_rstd[c] = make_float2(stats[c].x + (float)mean_d, 1.0f / sqrtf((float)(m2 / s0) + eps));
+}
+
+// groups of partial blocks for a launch: 1 (single kernel) unless a scratch buffer is given and the layer is big
+static int finalize_groups(int nparts, int C, const double* scratch) {
+    if (scratch == nullptr || nparts < 2048) return 1;
+    int g = nparts / 512;                       // >= 8 partials per thread
+    const int want = 512 / ((C + 15) / 16);     // ~2 blocks per CU in total
+    if (g > want) g = want;
+    if (g > kFinalizeMaxGroups) g = kFinalizeMaxGroups;
+    return g < 1 ? 1 : g;
+}
+static int run_finalize(hipStream_t s, const float* stats, int nparts, int mtiles, int BM, int M, int C, float eps,
+                        float* mean_rstd, int wm, int H, int W, double* scratch) {
+    const int groups = finalize_groups(nparts, C, scratch);
+    hipLaunchKernelGGL(inorm_finalize_kernel, dim3((C + 15) / 16, groups), dim3(16 * kFinSlices), 0, s,
                        reinterpret_cast<const float2*>(stats), nparts, mtiles, BM, M, C, eps,
-                       reinterpret_cast<float2*>(mean_rstd), 0, 0, 0);
+                       reinterpret_cast<float2*>(mean_rstd), wm, H, W, groups > 1 ? scratch : nullptr);
     T2V_HIP_CHECK(hipGetLastError());
+    if (groups > 1) {
+        hipLaunchKernelGGL(inorm_finalize_merge_kernel, dim3((C + 255) / 256), dim3(256), 0, s,
+                           reinterpret_cast<const float2*>(stats), scratch, groups, C, eps,
+                           reinterpret_cast<float2*>(mean_rstd));
+        T2V_HIP_CHECK(hipGetLastError());
+    }
     return T2V_OK;
+}
+
+int launch_inorm_finalize(hipStream_t s, const float* stats, int nparts, int mtiles, int BM, int M, int C,
+                          float eps, float* mean_rstd, double* scratch) {
+    return run_finalize(s, stats, nparts, mtiles, BM, M, C, eps, mean_rstd, 0, 0, 0, scratch);
 }
 // partials written by the Winograd output transform F(wm x wm, 3x3) of an H x W map
 int launch_inorm_finalize_winograd(hipStream_t s, const float* stats, int wm, int H, int W, int C, float eps,
-                                   float* mean_rstd, int batch) {
+                                   float* mean_rstd, int batch, double* scratch) {
     const int T = ((H + wm - 1) / wm) * ((W + wm - 1) / wm), Tp = wino_pad_tiles(T);
     const int nparts = Tp / (128 / (wm * wm));   // per image; a batch's partial blocks are contiguous
-    hipLaunchKernelGGL(inorm_finalize_kernel, dim3((C + 15) / 16), dim3(16 * kFinSlices), 0, s,
-                       reinterpret_cast<const float2*>(stats), batch * nparts, nparts, 0, H * W, C, eps,
-                       reinterpret_cast<float2*>(mean_rstd), wm, H, W);
-    T2V_HIP_CHECK(hipGetLastError());
-    return T2V_OK;
+    return run_finalize(s, stats, batch * nparts, nparts, 0, H * W, C, eps, mean_rstd, wm, H, W, scratch);
 }
 
 // y = [relu]((x-mean)*rstd*gamma+beta) + res1 + res2 ; float4 over NHWC, C % 4 == 0

@@ -104,6 +104,7 @@ struct Buffers {
     float* stats[2];
     float* mean_rstd[2];
     float* wino[2];   // Winograd scratch: transformed input V + transformed output M
+    double* fin[2];   // norm finalize scratch (pooled moments per group of partials)
 };
 
 void plan_buffers(const t2v_gen_desc& g, const std::vector<LayerSpec>& layers, Arena& a, Buffers& b) {
@@ -141,6 +142,7 @@ void plan_buffers(const t2v_gen_desc& g, const std::vector<LayerSpec>& layers, A
     for (int k = 0; k < 2; ++k) {
         b.stats[k] = a.alloc(max_stats);
         b.mean_rstd[k] = a.alloc((size_t)max_c * 2);
+        b.fin[k] = reinterpret_cast<double*>(a.alloc((size_t)kFinalizeMaxGroups * max_c * 4 * 2));
     }
     size_t max_wino = 0;
     for (const LayerSpec& L : layers)
@@ -173,7 +175,7 @@ struct Runner {
             const int M = L.cd.H * L.cd.W;
             T2V_TRY(winograd_forward(ctx, s, &L.cd, x, w.w, w.bias, y, b.stats[sc], b.wino[sc], 7));
             T2V_TRY(launch_inorm_finalize_winograd(s, b.stats[sc], wino_m(L.cd.algo), L.cd.H, L.cd.W, Cout, g.eps,
-                                                   b.mean_rstd[sc], 1));
+                                                   b.mean_rstd[sc], 1, b.fin[sc]));
             const float* gam = g.norm_affine ? w.gamma : nullptr;
             const float* bet = g.norm_affine ? w.beta : nullptr;
             if (g.norm_affine) T2V_REQUIRE(gam && bet, "layer %d: norm_affine=1 but gamma/beta missing", li - 1);
@@ -181,7 +183,8 @@ struct Runner {
         }
         T2V_TRY(build_conv_plan(&L.cd, L.x_cs, true, &pl));
         T2V_TRY(run_conv(ctx, s, pl, x, w.w, w.bias, y, Cout, b.stats[sc]));
-        T2V_TRY(launch_inorm_finalize(s, b.stats[sc], pl.nparts, pl.kp.mtiles, pl.BM, pl.kp.M, Cout, g.eps, b.mean_rstd[sc]));
+        T2V_TRY(launch_inorm_finalize(s, b.stats[sc], pl.nparts, pl.kp.mtiles, pl.BM, pl.kp.M, Cout, g.eps, b.mean_rstd[sc],
+                                      b.fin[sc]));
         const float* gamma = g.norm_affine ? w.gamma : nullptr;
         const float* beta = g.norm_affine ? w.beta : nullptr;
         if (g.norm_affine) T2V_REQUIRE(gamma && beta, "layer %d: norm_affine=1 but gamma/beta missing", li - 1);

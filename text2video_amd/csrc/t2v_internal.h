@@ -151,10 +151,12 @@ void conv_tile_dims(int tile, int* BM, int* BN);
 int launch_conv_igemm(hipStream_t s, const ConvKParams& p, int tile);
 
 // elementwise.hip
+// scratch (optional): kFinalizeMaxGroups * C * 4 doubles -- lets big layers pool their partials on many CUs
+constexpr int kFinalizeMaxGroups = 64;
 int launch_inorm_finalize_winograd(hipStream_t s, const float* stats, int wm, int H, int W, int C, float eps,
-                                   float* mean_rstd, int batch);
+                                   float* mean_rstd, int batch, double* scratch = nullptr);
 int launch_inorm_finalize(hipStream_t s, const float* stats, int nparts, int mtiles, int BM, int M, int C,
-                          float eps, float* mean_rstd);
+                          float eps, float* mean_rstd, double* scratch = nullptr);
 int launch_inorm_apply(hipStream_t s, const float* x, const float* mean_rstd, const float* gamma,
                        const float* beta, const float* res1, const float* res2, float* y, long npix, int C,
                        int relu);
