@@ -1,6 +1,8 @@
 """GPU parity of the train-step pieces built so far (forward only):
 PatchGAN / multiscale discriminator, LSGAN + feature-matching losses, fused Adam -- vs the CPU
 oracle modules (oracle/generator_ref.py) and torch.optim.Adam."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -102,3 +104,68 @@ def test_reductions_are_deterministic_and_accurate():
     assert got[0] == got[1] == got[2] and abs(got[0] - want) <= 1e-5 * want
     want2 = ((a.double() - 1.0) ** 2).sum().item()
     assert abs(ops.sum_sq_diff_const(a.cuda(), 1.0).item() - want2) <= 1e-5 * want2
+
+
+def test_temporal_discriminator_input_and_gradients():
+    """netD_T (13 channels = 3 frames x RGB + 2 zero flows): forward features, input gradient and parameter gradients
+    of the HIP discriminator against torch autograd on the oracle module."""
+    from oracle.generator_ref import MultiscaleDiscriminator, weights_init
+    from text2video_amd import train as T
+    H, W, B = 48, 32, 2
+    ref = MultiscaleDiscriminator(13, 16, 3, 2, "batch").train()
+    gen = torch.Generator().manual_seed(3)
+    ref.apply(lambda m: weights_init(m, gen))
+    sd = {k: v.clone() for k, v in ref.state_dict().items() if "running" not in k and "num_batches" not in k}
+    hip = T.TrainableDiscriminator(13, sd, 16, 3, 2, "batch", "cuda:0")
+    x = torch.randn(B, 13, H, W, generator=gen)
+    x[:, 9:] = 0                                   # the flow channels are zero
+    xr = x.clone().requires_grad_(True)
+    pr = ref(xr)
+    loss_r = sum((p[-1] - 1).pow(2).mean() for p in pr) + sum(f.abs().mean() for p in pr for f in p[:-1])
+    gx_ref, = torch.autograd.grad(loss_r, [xr], retain_graph=True)
+    gp_ref = torch.autograd.grad(loss_r, list(ref.parameters()))
+    xh = torch.zeros(B, H, W, 16, device="cuda:0")
+    xh[..., :13] = x.permute(0, 2, 3, 1).cuda()
+    xh.requires_grad_(True)
+    ph = hip(xh)
+    loss_h = sum((p[-1][..., :1] - 1).pow(2).mean() for p in ph) + \
+        sum(f[..., :r.shape[1]].abs().mean() for p, q in zip(ph, pr) for f, r in zip(p[:-1], q[:-1]))
+    assert abs(loss_h.item() - loss_r.item()) <= 1e-4 * abs(loss_r.item())
+    gx, = torch.autograd.grad(loss_h, [xh], retain_graph=True)
+    assert (gx[..., :13].permute(0, 3, 1, 2).cpu() - gx_ref).abs().max().item() <= 2e-4 * gx_ref.abs().max().item()
+    gp = torch.autograd.grad(loss_h, list(hip.parameters()), allow_unused=True)
+    got = {k: g for (k, _), g in zip(hip.named_upstream_parameters().items(), gp)}
+    for (k, _), r in zip(ref.named_parameters(), gp_ref):
+        if r.abs().max().item() > 1e-5:
+            assert (got[k].cpu() - r).abs().max().item() <= 2e-3 * r.abs().max().item(), k
+
+
+def test_trainer_uses_temporal_discriminators_across_chunks(tmp_path):
+    """Vid2VidTrainer: windows (t-2d, t-d, t), d = 3^s, built from the sequence history across chunks of 2 frames."""
+    from text2video_amd import train as T
+    from text2video_amd.options import TrainOptions
+    opt = TrainOptions().parse(["--name", "x", "--dataset_mode", "pose", "--input_nc", "3", "--openpose_only", "--no_first_img",
+                                "--ngf", "16", "--n_blocks", "2", "--num_D", "1", "--fineSize", "64", "--n_scales_temporal", "2",
+                                "--max_frames_per_gpu", "2", "--checkpoints_dir", str(tmp_path), "--synthetic_data"])
+    tr = T.Vid2VidTrainer(opt, "cuda:0")
+    assert len(tr.DT) == 2 and tr.DT[0].input_nc == 13
+    g = torch.Generator().manual_seed(0)
+    w0 = [p.detach().clone() for p in tr.DT[0].parameters()]
+    w1 = [p.detach().clone() for p in tr.DT[1].parameters()]
+    prev, seen = None, []
+    for chunk in range(4):                                   # frames 0..7 of one sequence
+        pose = torch.zeros(2, 64, 64, 12, device="cuda:0")
+        pose[..., :9] = torch.rand(2, 64, 64, 9, generator=g).cuda() * 2 - 1
+        real = torch.zeros(2, 64, 64, 4, device="cuda:0")
+        real[..., :3] = torch.tanh(torch.randn(2, 64, 64, 3, generator=g)).cuda()
+        losses, prev = tr.train_step(pose, real, None, prev)
+        seen.append(sorted(k for k in losses if k.startswith("D_T")))
+        assert all(np.isfinite(v) for v in losses.values())
+    # scale 0 needs 3 consecutive frames (first window ends on frame 2), scale 1 frames 0,3,6 (ends on frame 6)
+    assert seen == [[], ["D_T0"], ["D_T0"], ["D_T0", "D_T1"]]
+    assert any(not torch.equal(a, b) for a, b in zip(w0, tr.DT[0].parameters()))
+    assert any(not torch.equal(a, b) for a, b in zip(w1, tr.DT[1].parameters()))
+    _, prev = tr.train_step(pose, real, None, None)          # prev=None: a new sequence, history cleared
+    assert len(tr._hist_real) == 2
+    tr.save("latest")
+    assert sorted(os.listdir(tmp_path / "x")) == ["latest_net_D.pth", "latest_net_D_T0.pth", "latest_net_D_T1.pth", "latest_net_G0.pth"]

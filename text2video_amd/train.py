@@ -428,7 +428,20 @@ class Vid2VidTrainer:
             self.Df = TrainableDiscriminator(d_in, discriminator_state_dict(d_in, opt.ndf, opt.n_layers_D, nf, opt.norm,
                                                                             seed + 2), opt.ndf, opt.n_layers_D, nf,
                                              opt.norm, device)
+        # temporal discriminators netD_T{s}: a multiscale PatchGAN over n_frames_D frames spaced
+        # n_frames_D**s apart + the n_frames_D-1 optical flows between them (13 channels).  FlowNet2 is not in the
+        # reference tree, so the flow channels are zero; the frame channels train as upstream.
+        self.tD = opt.n_frames_D
+        self.DT = []
+        for s in range(max(0, opt.n_scales_temporal)):
+            dt_in = opt.output_nc * self.tD + 2 * (self.tD - 1)
+            self.DT.append(TrainableDiscriminator(dt_in, discriminator_state_dict(dt_in, opt.ndf, opt.n_layers_D, opt.num_D,
+                                                                                  opt.norm, seed + 10 + s),
+                                                  opt.ndf, opt.n_layers_D, opt.num_D, opt.norm, device))
+        self._hist_real, self._hist_fake = [], []    # frames of the running sequence (fakes detached)
         d_params = list(self.D.parameters()) + (list(self.Df.parameters()) if self.Df else [])
+        for dt in self.DT:
+            d_params += list(dt.parameters())
         self.optG = FusedAdam(self.G.parameters(), opt.lr, (opt.beta1, 0.999))
         self.optD = FusedAdam(d_params, opt.lr, (opt.beta1, 0.999))
         self.comm_bytes = 0
@@ -442,8 +455,9 @@ class Vid2VidTrainer:
         (ys,ye,xs,xe) per frame.  Returns dict of scalar losses."""
         opt, dev = self.opt, pose.device
         F_, H, W = pose.shape[0], pose.shape[1], pose.shape[2]
-        if prev is None:
+        if prev is None:   # a new sequence starts
             prev = torch.zeros(1, H, W, ops.round_up(self.spec.prev_nc, 4), dtype=torch.float32, device=dev)
+            self._hist_real, self._hist_fake = [], []
         fakes = []
         for f in range(F_):
             fk = self.G(pose[f:f + 1], prev)
@@ -477,6 +491,37 @@ class Vid2VidTrainer:
             loss_G = loss_G + lg + lf
             loss_D = loss_D + loss_Df
             losses.update({"G_f_GAN": _f(lg), "G_f_GAN_Feat": _f(lf), "D_f": _f(loss_Df)})
+        # temporal discriminators: every window (t-2d, t-d, t), d = n_frames_D**s, that ends on a frame of this chunk;
+        # older frames come from the sequence history (generated ones detached)
+        if self.DT:
+            n_old = len(self._hist_real)
+            reals = self._hist_real + [real[i] for i in range(F_)]
+            fks = self._hist_fake + [fake[i] for i in range(F_)]
+            for sc, dt in enumerate(self.DT):
+                d = self.tD ** sc
+                ends = [t for t in range(n_old, n_old + F_) if t - (self.tD - 1) * d >= 0]
+                if not ends:
+                    continue
+                def stack(frames):
+                    rows = []
+                    for t in ends:
+                        w = [frames[t - (self.tD - 1 - k) * d][..., :3] for k in range(self.tD)]
+                        z = torch.zeros(H, W, ops.round_up(dt.input_nc, 4) - 3 * self.tD, dtype=torch.float32, device=dev)
+                        rows.append(torch.cat(w + [z], -1))
+                    return torch.stack(rows).contiguous()
+                tr, tf = stack(reals), stack(fks)
+                pr_t = dt(tr)
+                pfd_t = dt(tf.detach())
+                l_dt = 0.5 * (gan_loss(pfd_t, False) + gan_loss(pr_t, True))
+                pfg_t = dt(tf)
+                lg = gan_loss(pfg_t, True)
+                lf = feature_matching_loss(pfg_t, pr_t, opt.n_layers_D, opt.lambda_feat) if not opt.no_ganFeat else 0.0
+                loss_G = loss_G + lg + lf
+                loss_D = loss_D + l_dt
+                losses.update({"G_T_GAN%d" % sc: _f(lg), "G_T_GAN_Feat%d" % sc: _f(lf), "D_T%d" % sc: _f(l_dt)})
+            keep = (self.tD - 1) * self.tD ** (len(self.DT) - 1)
+            self._hist_real = [r.detach() for r in reals][-keep:]
+            self._hist_fake = [f.detach() for f in fks][-keep:]
         g_params = list(self.G.parameters())
         d_params = self.optD.params
         gG = torch.autograd.grad(loss_G, g_params, retain_graph=True, allow_unused=True)
@@ -501,6 +546,9 @@ class Vid2VidTrainer:
         if self.Df is not None:
             torch.save({k: v.detach().cpu() for k, v in self.Df.named_upstream_parameters().items()},
                        os.path.join(d, "%s_net_D_f.pth" % epoch_label))
+        for sc, dt in enumerate(self.DT):
+            torch.save({k: v.detach().cpu() for k, v in dt.named_upstream_parameters().items()},
+                       os.path.join(d, "%s_net_D_T%d.pth" % (epoch_label, sc)))
 
 
 def run_train(opt, steps=None):
@@ -548,6 +596,11 @@ def run_train(opt, steps=None):
             A = torch.from_numpy(clip["A"]).to(dev)                      # [T,H,W,3] uint8
             B = torch.from_numpy(clip["B"]).to(dev)
             T_, H, W = A.shape[0], A.shape[1], A.shape[2]
+            if world > 1:   # every rank must run the same number of chunks (one gradient all-reduce per chunk)
+                import torch.distributed as dist
+                tmin = torch.tensor([T_], device=dev)
+                dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
+                T_ = int(tmin.item())
             prev, ts = None, time.perf_counter()
             for c0 in range(tG - 1, T_, F_):
                 fr = list(range(c0, min(c0 + F_, T_)))
