@@ -187,7 +187,7 @@ int t2v_reflect_pad_backward(t2v_ctx* ctx, void* stream, const float* dxp, float
 /* BatchNormalization_backward(train) / instance norm backward fused with the activation derivative:
  *   g = dy * act'(gamma*xhat+beta); dx = rstd*gamma*(g - mean(g) - xhat*mean(g*xhat)); dbeta_dgamma[c] = (sum g, sum g*xhat)
  * x = the conv output that was normalised, npix = pixels in the statistics (all images of a batch-norm batch),
- * relu as in t2v_instance_norm_apply, scratch >= 64*C*2 floats. */
+ * relu as in t2v_instance_norm_apply, C % 4 == 0, scratch >= 128*C*2 floats. */
 int t2v_instance_norm_backward(t2v_ctx* ctx, void* stream, const float* x, const float* dy, const float* mean_rstd,
                                const float* gamma, const float* beta, int relu, long npix, int C, float* scratch,
                                float* dx, float* dbeta_dgamma);

@@ -462,31 +462,55 @@ int launch_reflect_pad_backward(hipStream_t s, const float* dxp, float* dx, int 
 __device__ __forceinline__ float act_grad(float pre, int relu) {
     return relu == 1 ? (pre > 0.f ? 1.f : 0.f) : (relu == 2 ? (pre > 0.f ? 1.f : 0.2f) : 1.f);
 }
-__global__ __launch_bounds__(256) void inorm_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+__global__ __launch_bounds__(256) void inorm_bwd_reduce_kernel(const float4* __restrict__ x, const float4* __restrict__ dy,
                                                                const float2* __restrict__ mean_rstd,
                                                                const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, int relu, long npix, int C,
                                                                float2* __restrict__ partial) {
-    __shared__ float sh[2][4][64];
-    const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
-    float s0 = 0.f, s1 = 0.f;
-    if (c < C) {
-        const float2 mr = mean_rstd[c];
-        const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
-        for (long p = (long)blockIdx.y * 4 + sl; p < npix; p += (long)gridDim.y * 4) {
-            const float xh = (x[p * C + c] - mr.x) * mr.y;
-            const float g = dy[p * C + c] * act_grad(ga * xh + be, relu);
-            s0 += g;
-            s1 += g * xh;
+    // block = 16 channel quads (64 channels, float4 loads: 256 contiguous bytes per pixel) x 16 pixel lanes
+    __shared__ float sh[2][16][64];
+    const int ql = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int c0 = blockIdx.x * 64 + ql * 4;
+    const int C4 = C >> 2;
+    float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c0 < C) {
+        float mean[4], rstd[4], ga[4], be[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float2 mr = mean_rstd[c0 + k];
+            mean[k] = mr.x;
+            rstd[k] = mr.y;
+            ga[k] = gamma ? gamma[c0 + k] : 1.f;
+            be[k] = beta ? beta[c0 + k] : 0.f;
+        }
+        for (long p = (long)blockIdx.y * 16 + sl; p < npix; p += (long)gridDim.y * 16) {
+            const float4 xv = x[p * C4 + (c0 >> 2)], gv = dy[p * C4 + (c0 >> 2)];
+            const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, gs[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float xh = (xs[k] - mean[k]) * rstd[k];
+                const float g = gs[k] * act_grad(ga[k] * xh + be[k], relu);
+                s0[k] += g;
+                s1[k] += g * xh;
+            }
         }
     }
-    sh[0][sl][cl] = s0;
-    sh[1][sl][cl] = s1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        sh[0][sl][ql * 4 + k] = s0[k];
+        sh[1][sl][ql * 4 + k] = s1[k];
+    }
     __syncthreads();
-    if (sl == 0 && c < C)
-        partial[(size_t)blockIdx.y * C + c] = make_float2((sh[0][0][cl] + sh[0][1][cl]) + (sh[0][2][cl] + sh[0][3][cl]),
-                                                          (sh[1][0][cl] + sh[1][1][cl]) + (sh[1][2][cl] + sh[1][3][cl]));
+    if (threadIdx.x < 64 && blockIdx.x * 64 + threadIdx.x < C) {
+        const int cl = threadIdx.x;
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {   // fixed order
+            a0 += sh[0][i][cl];
+            a1 += sh[1][i][cl];
+        }
+        partial[(size_t)blockIdx.y * C + blockIdx.x * 64 + cl] = make_float2(a0, a1);
+    }
 }
 __global__ void inorm_bwd_final_kernel(const float2* __restrict__ partial, int slices, int C, float2* __restrict__ sums) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -521,10 +545,15 @@ __global__ __launch_bounds__(256) void inorm_bwd_apply_kernel(const float* __res
 }
 int launch_inorm_backward(hipStream_t s, const float* x, const float* dy, const float* mean_rstd, const float* gamma,
                           const float* beta, int relu, long npix, int C, float* scratch, float* dx, float* sums) {
-    int slices = (int)((npix + 255) / 256);
-    if (slices > 64) slices = 64;
+    T2V_REQUIRE(C % 4 == 0, "inorm_backward: C=%d must be a multiple of 4", C);
+    // enough (channel group, pixel slice) blocks to cover the chip a few times over; scratch holds 256*C float2
+    int slices = (int)((npix + 63) / 64);
+    const int want = 1024 / ((C + 63) / 64);
+    if (slices > want) slices = want;
+    if (slices > 128) slices = 128;
     if (slices < 1) slices = 1;
-    hipLaunchKernelGGL(inorm_bwd_reduce_kernel, dim3((C + 63) / 64, slices), dim3(256), 0, s, x, dy,
+    hipLaunchKernelGGL(inorm_bwd_reduce_kernel, dim3((C + 63) / 64, slices), dim3(256), 0, s,
+                       reinterpret_cast<const float4*>(x), reinterpret_cast<const float4*>(dy),
                        reinterpret_cast<const float2*>(mean_rstd), gamma, beta, relu, npix, C,
                        reinterpret_cast<float2*>(scratch));
     hipLaunchKernelGGL(inorm_bwd_final_kernel, dim3((C + 255) / 256), dim3(256), 0, s,

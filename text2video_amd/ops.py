@@ -377,7 +377,7 @@ def instance_norm_backward(x, dy, mean_rstd, gamma=None, beta=None, relu=0):
     npix = x.numel() // C
     dx = torch.empty_like(x)
     sums = torch.empty(C, 2, dtype=torch.float32, device=x.device)
-    scratch = torch.empty(64 * C * 2, dtype=torch.float32, device=x.device)
+    scratch = torch.empty(128 * C * 2, dtype=torch.float32, device=x.device)
     check(c.lib.t2v_instance_norm_backward(c.handle, _stream(), _p(x), _p(dy), _p(mean_rstd), _p(gamma), _p(beta),
                                            int(relu), npix, C, _p(scratch), _p(dx), _p(sums)), "instance_norm_backward")
     return dx, sums
