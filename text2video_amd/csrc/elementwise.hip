@@ -512,16 +512,25 @@ __global__ __launch_bounds__(256) void inorm_bwd_reduce_kernel(const float4* __r
         partial[(size_t)blockIdx.y * C + blockIdx.x * 64 + cl] = make_float2(a0, a1);
     }
 }
-__global__ void inorm_bwd_final_kernel(const float2* __restrict__ partial, int slices, int C, float2* __restrict__ sums) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// block = 64 channels x 4 slice lanes (fixed summation order: lane-strided partial sums, then the 4 lanes)
+__global__ __launch_bounds__(256) void inorm_bwd_final_kernel(const float2* __restrict__ partial, int slices, int C,
+                                                              float2* __restrict__ sums) {
+    __shared__ float sh[2][4][64];
+    const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
     float s0 = 0.f, s1 = 0.f;
-    for (int i = 0; i < slices; ++i) {
-        const float2 v = partial[(size_t)i * C + c];
-        s0 += v.x;
-        s1 += v.y;
-    }
-    sums[c] = make_float2(s0, s1);   // (dbeta, dgamma) of an affine norm
+    if (c < C)
+        for (int i = sl; i < slices; i += 4) {
+            const float2 v = partial[(size_t)i * C + c];
+            s0 += v.x;
+            s1 += v.y;
+        }
+    sh[0][sl][cl] = s0;
+    sh[1][sl][cl] = s1;
+    __syncthreads();
+    if (sl == 0 && c < C)   // (dbeta, dgamma) of an affine norm
+        sums[c] = make_float2((sh[0][0][cl] + sh[0][1][cl]) + (sh[0][2][cl] + sh[0][3][cl]),
+                              (sh[1][0][cl] + sh[1][1][cl]) + (sh[1][2][cl] + sh[1][3][cl]));
 }
 // stage 2: dx = rstd * gamma * (g - S0/N - xhat * S1/N)      (biased variance, N = pixels in the statistics)
 __global__ __launch_bounds__(256) void inorm_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
@@ -556,7 +565,7 @@ int launch_inorm_backward(hipStream_t s, const float* x, const float* dy, const 
                        reinterpret_cast<const float4*>(x), reinterpret_cast<const float4*>(dy),
                        reinterpret_cast<const float2*>(mean_rstd), gamma, beta, relu, npix, C,
                        reinterpret_cast<float2*>(scratch));
-    hipLaunchKernelGGL(inorm_bwd_final_kernel, dim3((C + 255) / 256), dim3(256), 0, s,
+    hipLaunchKernelGGL(inorm_bwd_final_kernel, dim3((C + 63) / 64), dim3(256), 0, s,
                        reinterpret_cast<const float2*>(scratch), slices, C, reinterpret_cast<float2*>(sums));
     hipLaunchKernelGGL(inorm_bwd_apply_kernel, dim3(grid_for(npix * C, 256)), dim3(256), 0, s, x, dy,
                        reinterpret_cast<const float2*>(mean_rstd), gamma, beta, relu,
