@@ -197,3 +197,28 @@ def test_in_memory_pipeline_equals_file_pipeline(tmp_path):
     assert [os.path.basename(f) for f in mem] == [os.path.basename(f) for f in files]
     for a, b in zip(files, mem):
         assert np.array_equal(np.asarray(Image.open(a)), np.asarray(Image.open(b))), (a, b)
+
+
+def test_bench_contract_line():
+    """bench.py prints ONE JSON line with the driver's contract fields plus roofline and cpu_baseline."""
+    import json
+    env = dict(os.environ, CUDA_VISIBLE_DEVICES="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2",
+                        "--cpu-frames", "1", "--kernel-iters", "4"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and r.stdout.rstrip().endswith(lines[0])
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 2 and d["dtype"] == "f32" and d["unit"] == "frames/s"
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert abs(d["value"] - 1e3 / d["ms_per_step"]) <= 0.01 * d["value"] and d["value"] > 30.0      # north_star: >= 30 fps
+    assert "configs[1]" in d["config"]["workload"] and "model" not in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 157.3
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and 0.3 < rf["frac"] <= 1.0
+    assert abs(rf["achieved"] - rf["gflop_per_launch"] / rf["ms_per_launch"]) <= 0.02 * rf["achieved"]
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["unit"] == "frames/s" and cb["cores"] >= 1 and 0 < cb["value"] < d["value"]
