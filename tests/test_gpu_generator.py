@@ -247,3 +247,29 @@ def test_generator_edge_geometries_and_argument_errors():
     st = lib.t2v_generator_forward(net.ctx.handle, None, ctypes.byref(gd), net._layers, len(net.keys), ctypes.byref(io),
                                    ctypes.c_void_p(ws.data_ptr()), ws.numel())
     assert st == -3 and b"workspace" in lib.t2v_last_error()
+
+
+@pytest.mark.parametrize("no_flow", [True, False], ids=["noflow", "flow"])
+def test_two_stream_frames_are_reproducible(no_flow):
+    """Race screen for the two-stream orchestration (encoders / image+flow branches run concurrently on the
+    caller's stream and the context's side stream): the same sequence twice, on the same buffers, gives the same bits,
+    for the full-width bottleneck (Winograd path) as well."""
+    from text2video_amd.generator import GeneratorSpec, HipGenerator, Vid2VidModelG, synthetic_state_dict
+    spec = GeneratorSpec(ngf=32, n_downsample=3, n_blocks=4, no_flow=no_flow, norm="batch")
+    sd = synthetic_state_dict(spec, 9, flow_gain=0.1)
+    H, W, n = 256, 256, 8
+    seq = _pose_seq(n + 2, H, W, seed=4)
+    wins = []
+    for t in range(n):
+        w = torch.zeros(H, W, 12, device="cuda:0")
+        w[..., :9] = seq[t:t + 3].reshape(9, H, W).permute(1, 2, 0).to("cuda:0")
+        wins.append(w)
+    model = Vid2VidModelG([HipGenerator(spec, "cuda:0").load_state_dict(sd)])
+    runs = []
+    for _ in range(3):
+        model.reset()
+        runs.append([model.inference_nhwc(w).clone() for w in wins])
+        torch.cuda.synchronize()
+    for t in range(n):
+        assert torch.equal(runs[0][t], runs[1][t]) and torch.equal(runs[0][t], runs[2][t]), t
+        assert torch.isfinite(runs[0][t]).all()
