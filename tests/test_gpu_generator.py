@@ -273,3 +273,4 @@ def test_two_stream_frames_are_reproducible(no_flow):
     for t in range(n):
         assert torch.equal(runs[0][t], runs[1][t]) and torch.equal(runs[0][t], runs[2][t]), t
         assert torch.isfinite(runs[0][t]).all()
+
