@@ -17,7 +17,8 @@ Prints ONE JSON line (rank 0) with the driver's contract fields plus
                   conv: 19.3 GFLOP of executed fp32 MFMA work per launch at 512x512) timed with HIP events on
                   the launch stream vs the fp32 MFMA peak (157.3 TFLOP/s); "layer" = the whole conv
   "cpu_baseline": the CPU oracle (stock torch fp32) timed on this box's host cores on a bounded
-                  sample of the same workload.
+                  sample of the same workload; its frames are also compared with the timed HIP model's
+                  ("parity": max |delta| per pixel, teacher-forced, tolerance 1e-3 = north_star).
 """
 import argparse
 import json
@@ -251,14 +252,24 @@ def main():
                 ref_nets.append(loc)
             ref = Vid2VidInferenceRef(ref_nets)
             pf = ((poses[:args.cpu_frames + 3].cpu().float() / 255.0 - 0.5) / 0.5).permute(0, 3, 1, 2)
-            ref.inference(pf[0:3].unsqueeze(0))          # warm-up frame (thread pool, first-frame path)
-            c0 = time.perf_counter()
+            # the same frames through the measured HIP path, teacher-forced on the oracle's previous frames: the
+            # timed model's output against the oracle's, reported next to the speed (outside the timed region)
+            model.reset()
+            wants = [ref.inference(pf[0:3].unsqueeze(0))]   # warm-up frame (thread pool, first-frame path)
+            gots = [model.inference(pf[0:3].unsqueeze(0).to(dev))[0].cpu()]
+            csec = 0.0
             for t in range(1, 1 + args.cpu_frames):
-                ref.inference(pf[t:t + 3].unsqueeze(0))
-            csec = time.perf_counter() - c0
+                model.load_prev(ref.fake_B_prev)
+                c0 = time.perf_counter()
+                wants.append(ref.inference(pf[t:t + 3].unsqueeze(0)))
+                csec += time.perf_counter() - c0
+                gots.append(model.inference(pf[t:t + 3].unsqueeze(0).to(dev))[0].cpu())
+            parity = {"max_abs_delta_vs_oracle": float("%.3g" % max((g - w).abs().max().item() for g, w in zip(gots, wants))),
+                      "frames": len(wants), "tolerance": 1e-3,
+                      "how": "frames 0..%d of the sequence, previous frames taken from the oracle (teacher-forced)" % args.cpu_frames}
             cpu = {"value": round(args.cpu_frames / csec, 4), "unit": "frames/s", "cores": cores, "kind": "port",
                    "sample": "%d frames %dx%d after 1 warm-up frame, torch %s CPU fp32, %d threads"
-                             % (args.cpu_frames, H, W, torch.__version__, cores)}
+                             % (args.cpu_frames, H, W, torch.__version__, cores), "parity": parity}
         result = {
             "metric": "frames/sec 512x512 pose->RGB (vid2vid generator)",
             "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,

@@ -222,3 +222,4 @@ def test_bench_contract_line():
     assert abs(rf["achieved"] - rf["gflop_per_launch"] / rf["ms_per_launch"]) <= 0.02 * rf["achieved"]
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["unit"] == "frames/s" and cb["cores"] >= 1 and 0 < cb["value"] < d["value"]
+    assert cb["parity"]["frames"] == 2 and 0 < cb["parity"]["max_abs_delta_vs_oracle"] <= cb["parity"]["tolerance"] == 1e-3
