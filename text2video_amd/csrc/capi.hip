@@ -125,7 +125,9 @@ int build_conv_plan(const t2v_conv_desc* d, int x_cs, bool need_stats, ConvPlan*
         static const int force = getenv("T2V_CONV_TILE") ? atoi(getenv("T2V_CONV_TILE")) : -1;
         const long nb = (long)k.mtiles * k.ntiles * k.nphases;
         const double fill = (double)nb / (double)(((nb + 255) / 256) * 256);
-        if (force == kTileQ || (force < 0 && fill < 0.8 && nb < 1024)) {
+        // transposed convs with few blocks: the four phases have 1/2/2/4 taps, and one 128x128 block per CU cannot
+        // balance such unequal blocks (1024->512 up-sampling: 0.317 -> 0.286 ms with 64x64 tiles)
+        if (force == kTileQ || (force < 0 && ((fill < 0.8 && nb < 1024) || (k.nphases > 1 && nb <= 512)))) {
             pl.tile = kTileQ;
             conv_tile_dims(pl.tile, &pl.BM, &pl.BN);
             k.ntiles = (d->Cout + pl.BN - 1) / pl.BN;

@@ -481,7 +481,11 @@ static int launch_pad(hipStream_t s, const ConvKParams& p) {
     // 2048-block stem 0.40 vs 0.47 ms, 1024-block layers 0.33 vs 0.345 ms, <= 512 blocks favour RING 3
     const long nblocks = (long)p.mtiles * p.ntiles * p.nphases;
     static const int force = getenv("T2V_CONV_RING") ? atoi(getenv("T2V_CONV_RING")) : 0;
-    const bool two = force ? force == 2 : (Cfg::MF == 32 && (nblocks >= 1024 || Cfg::BM == 64));
+    // (swept per layer shape with scripts/kernel_bench.py: single-phase launches like two co-resident blocks from 512
+    // blocks on; 64x64 tiles of a multi-phase launch prefer the deeper ring)
+    const bool two = force ? force == 2
+                           : (Cfg::MF == 32 && (Cfg::BM == 64 ? p.nphases == 1
+                                                              : (nblocks >= 1024 || (p.nphases == 1 && nblocks >= 512))));
     return two ? launch_ring<Cfg, MODE, STATS, REFLECT, 2>(s, p) : launch_ring<Cfg, MODE, STATS, REFLECT, 3>(s, p);
 }
 
