@@ -12,6 +12,12 @@ SHAPES = {
     "rb1024_320": (64, 40, 1024, 1024, 3, 1, 1, 1, False, True),
     "rb1024_680": (64, 85, 1024, 1024, 3, 1, 1, 1, False, True),
     "head3": (512, 512, 128, 3, 7, 1, 3, 1, False, False),
+    # local enhancer of the two-scale 1024x1024 generator (ngf 64)
+    "l_stem": (1024, 1024, 9, 64, 7, 1, 3, 1, False, True),
+    "l_down": (1024, 1024, 64, 128, 3, 2, 1, 0, False, True),
+    "l_rb": (512, 512, 128, 128, 3, 1, 1, 1, False, True),
+    "l_up": (512, 512, 128, 64, 3, 2, 1, 0, True, True),
+    "l_head": (1024, 1024, 64, 3, 7, 1, 3, 1, False, False),
     # the tiny maps of the train-step parity test (32x32 frames, ngf 32): few tiles, 64x64 tile config, M < BM
     "t_rb128": (8, 8, 128, 128, 3, 1, 1, 1, False, True),
     "t_down32": (32, 32, 32, 64, 3, 2, 1, 0, False, True),

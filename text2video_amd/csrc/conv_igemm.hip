@@ -484,7 +484,7 @@ static int launch_pad(hipStream_t s, const ConvKParams& p) {
     // (swept per layer shape with scripts/kernel_bench.py: single-phase launches like two co-resident blocks from 512
     // blocks on; 64x64 tiles of a multi-phase launch prefer the deeper ring)
     const bool two = force ? force == 2
-                           : (Cfg::MF == 32 && (Cfg::BM == 64 ? p.nphases == 1
+                           : (Cfg::MF == 32 && (Cfg::BM == 64 ? (p.nphases == 1 || nblocks >= 4096)
                                                               : (nblocks >= 1024 || (p.nphases == 1 && nblocks >= 512))));
     return two ? launch_ring<Cfg, MODE, STATS, REFLECT, 2>(s, p) : launch_ring<Cfg, MODE, STATS, REFLECT, 3>(s, p);
 }
