@@ -49,6 +49,11 @@ CONV_CASES = [
     ("rb3x3_Cout8", 8, 8, 32, 8, 3, 1, 1, 1, False),
     ("stem7x7_cin9", 24, 24, 9, 128, 7, 1, 3, 1, False),
     ("stem7x7_cin6", 16, 20, 6, 16, 7, 1, 3, 1, False),
+    # sizes / widths the halo-in-LDS stem kernel (conv_stem.hip) takes when norm statistics are requested
+    ("stem_kernel_cin9_c128", 32, 48, 9, 128, 7, 1, 3, 1, False),
+    ("stem_kernel_cin6_c128", 16, 16, 6, 128, 7, 1, 3, 1, False),
+    ("stem_kernel_cin9_c64", 48, 32, 9, 64, 7, 1, 3, 1, False),
+    ("stem_kernel_cin6_c64", 64, 16, 6, 64, 7, 1, 3, 1, False),
     ("down3x3_s2", 32, 32, 32, 64, 3, 2, 1, 0, False),
     ("down3x3_s2_narrow", 16, 24, 8, 16, 3, 2, 1, 0, False),
     ("convT_fast", 8, 8, 64, 32, 3, 2, 1, 0, True),

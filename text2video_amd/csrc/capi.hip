@@ -134,6 +134,15 @@ int build_conv_plan(const t2v_conv_desc* d, int x_cs, bool need_stats, ConvPlan*
             k.mtiles = (k.M + pl.BM - 1) / pl.BM;
         }
     }
+    if (need_stats && !d->transposed && d->kH == 7 && d->kW == 7 && d->stride == 1 && d->pad == 3 &&
+        d->pad_mode == T2V_PAD_REFLECT && d->act == T2V_ACT_NONE && conv_stem7x7_supported(d->H, d->W, x_cs, d->Cout)) {
+        // the 7x7 stems: halo-in-LDS MFMA kernel (conv_stem.hip); statistics per 16x16 pixel tile
+        pl.tile = kTileStem;
+        pl.BM = 256;
+        pl.BN = d->Cout;
+        k.mtiles = k.M / 256;
+        k.ntiles = 1;
+    }
     pl.nparts = k.nphases * k.mtiles;
     T2V_REQUIRE((long)k.mtiles * k.ntiles * k.nphases < (1L << 31), "conv: grid too large");
     // buffer addressing: 32-bit byte offsets below the out-of-range marker 0x7fff0000
@@ -206,6 +215,13 @@ int run_conv(t2v_ctx* ctx, hipStream_t s, const ConvPlan& pl, const float* x, co
             return launch_conv_head7x7(s, h);
         }
     }
+    if (pl.tile == kTileStem && stats) {
+        StemParams sp;
+        sp.x = x; sp.w = w; sp.bias = bias; sp.y = y; sp.stats = stats;
+        sp.H = pl.kp.Hin; sp.W = pl.kp.Win; sp.Cin_s = pl.kp.Cin_s; sp.Kp = pl.kp.ph[0].Kp; sp.Cout = pl.kp.Cout; sp.Cout_s = y_cs;
+        return launch_conv_stem7x7(s, sp);
+    }
+    T2V_REQUIRE(pl.tile != kTileStem, "conv: the stem plan needs a statistics buffer");
     ConvKParams k = pl.kp;
     k.x = x;
     k.w = w;

@@ -152,7 +152,19 @@ struct HeadParams {
 };
 int launch_conv_head7x7(hipStream_t s, const HeadParams& p);
 
-enum ConvTile { kTileL = 0 /*128x128, 32x32x2 MFMA*/, kTileS = 1 /*256x16, 16x16x4 MFMA*/, kTileQ = 2 /*64x64*/ };
+struct StemParams {
+    const float* x;
+    const float* w;      // the packed [Cout_p][Kp] weight of the implicit-GEMM kernels
+    const float* bias;
+    float* y;
+    float* stats;        // [tiles][Cout] (mean, M2) per 16x16 pixel tile
+    int H, W, Cin_s, Kp, Cout, Cout_s;
+};
+bool conv_stem7x7_supported(int H, int W, int Cin_s, int Cout);
+int launch_conv_stem7x7(hipStream_t s, const StemParams& p);
+
+enum ConvTile { kTileL = 0 /*128x128, 32x32x2 MFMA*/, kTileS = 1 /*256x16, 16x16x4 MFMA*/, kTileQ = 2 /*64x64*/,
+                kTileStem = 3 /*conv_stem.hip: 16x16 pixel tile x all channels*/ };
 int conv_tile_for(int Cout);
 void conv_tile_dims(int tile, int* BM, int* BN);
 int launch_conv_igemm(hipStream_t s, const ConvKParams& p, int tile);
