@@ -235,16 +235,14 @@ int run_conv(t2v_ctx* ctx, hipStream_t s, const ConvPlan& pl, const float* x, co
 // all of a Winograd conv (shared with the generator orchestrator): stages bit 1 = input transform,
 // 2 = batched GEMM, 4 = output transform
 int winograd_forward(t2v_ctx* ctx, hipStream_t s, const t2v_conv_desc* d, const float* x, const float* w_packed,
-                     const float* bias, float* y, float* stats_partial, float* workspace, int stages,
-                     const PendingNorm* norm) {
+                     const float* bias, float* y, float* stats_partial, float* workspace, int stages) {
     const size_t T = (size_t)wino_tiles_padded(d, d->algo);
     float* V = workspace;
     float* Mm = workspace + wino_pos(d->algo) * T * d->Cin;
     const bool f4 = d->algo == T2V_ALGO_WINOGRAD_F4;
     if (stages & 1) {
         const int reflect = d->pad_mode == T2V_PAD_REFLECT;
-        T2V_REQUIRE(norm == nullptr || f4, "a deferred norm can only be folded into the F(4x4,3x3) input transform");
-        T2V_TRY(f4 ? launch_winograd4_input(s, x, V, d->H, d->W, d->Cin, d->pad, reflect, 1, 0, norm)
+        T2V_TRY(f4 ? launch_winograd4_input(s, x, V, d->H, d->W, d->Cin, d->pad, reflect)
                    : launch_winograd_input(s, x, V, d->H, d->W, d->Cin, d->pad, reflect));
     }
     if (stages & 2) {

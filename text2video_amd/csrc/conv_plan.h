@@ -35,8 +35,7 @@ bool winograd_supported(const t2v_conv_desc* d, int x_cs, int algo);
 int best_conv_algo(const t2v_conv_desc* d, int x_cs, int cap);
 int build_winograd_gemm_plan(const t2v_conv_desc* d, ConvPlan* pl);
 int winograd_forward(t2v_ctx* ctx, hipStream_t s, const t2v_conv_desc* d, const float* x, const float* w_packed,
-                     const float* bias, float* y, float* stats_partial, float* workspace, int stages,
-                     const PendingNorm* norm = nullptr);
+                     const float* bias, float* y, float* stats_partial, float* workspace, int stages);
 int run_conv(t2v_ctx* ctx, hipStream_t s, const ConvPlan& pl, const float* x, const float* w, const float* bias,
              float* y, int y_cs, float* stats);
 

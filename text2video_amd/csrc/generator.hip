@@ -162,42 +162,23 @@ struct Runner {
     Buffers& b;
     int li = 0;
     int sc = 0;   // which per-stream scratch set this runner uses
-    PendingNorm pending;        // norm (+ReLU) of the previous conv_norm, left for this conv's input transform
-    bool has_pending = false;
 
     // conv (+ fused stats) -> finalize -> apply.  y receives the conv output and is normalised in
     // place: y = [relu](norm(conv(x))) + res1 + res2
-    // defer: leave y un-normalised (raw conv output + finalized statistics); the NEXT conv_norm, which must be an
-    // F(4x4,3x3) layer reading y and nothing else may read y, applies norm + ReLU while it gathers its patches
-    int conv_norm(const float* x, float* y, int relu, const float* res1, const float* res2, bool defer = false) {
+    int conv_norm(const float* x, float* y, int relu, const float* res1, const float* res2) {
         const LayerSpec& L = specs[li];
         const t2v_layer& w = layers[li];
         ++li;
         ConvPlan pl;
         const int Cout = L.cd.Cout;
-        const PendingNorm* in_norm = has_pending ? &pending : nullptr;
-        PendingNorm mine = pending;   // (copy: `pending` is overwritten below when this layer defers too)
-        if (has_pending) in_norm = &mine;
-        has_pending = false;
-        T2V_REQUIRE(in_norm == nullptr || L.cd.algo == T2V_ALGO_WINOGRAD_F4, "internal: deferred norm into a non-F4 layer");
         if (is_winograd(L.cd.algo)) {
             const int M = L.cd.H * L.cd.W;
-            T2V_TRY(winograd_forward(ctx, s, &L.cd, x, w.w, w.bias, y, b.stats[sc], b.wino[sc], 7, in_norm));
+            T2V_TRY(winograd_forward(ctx, s, &L.cd, x, w.w, w.bias, y, b.stats[sc], b.wino[sc], 7));
             T2V_TRY(launch_inorm_finalize_winograd(s, b.stats[sc], wino_m(L.cd.algo), L.cd.H, L.cd.W, Cout, g.eps,
                                                    b.mean_rstd[sc], 1, b.fin[sc]));
             const float* gam = g.norm_affine ? w.gamma : nullptr;
             const float* bet = g.norm_affine ? w.beta : nullptr;
             if (g.norm_affine) T2V_REQUIRE(gam && bet, "layer %d: norm_affine=1 but gamma/beta missing", li - 1);
-            if (defer && !res1 && !res2 && relu <= 1) {
-                // the statistics live in a second buffer: this stream's mean_rstd is rewritten by the next finalize
-                // only AFTER the next input transform has read it (same stream, program order)
-                pending.mean_rstd = b.mean_rstd[sc];
-                pending.gamma = gam;
-                pending.beta = bet;
-                pending.relu = relu;
-                has_pending = true;
-                return T2V_OK;
-            }
             return launch_inorm_apply(s, y, b.mean_rstd[sc], gam, bet, res1, res2, y, (long)M, Cout, relu);
         }
         T2V_TRY(build_conv_plan(&L.cd, L.x_cs, true, &pl));
@@ -221,11 +202,7 @@ struct Runner {
 
     // x + [pad1,conv3,N,ReLU,pad1,conv3,N](x) (+ extra)
     int resblock(const float* x, float* t, float* y, const float* extra) {
-        // the inner activation t is read by the second conv only: if both convs run as F(4x4,3x3) its norm + ReLU
-        // is folded into the second conv's input transform (one read + write pass of t less)
-        static const bool fuse = !(getenv("T2V_FUSE_NORM") && atoi(getenv("T2V_FUSE_NORM")) == 0);
-        const bool defer = fuse && specs[li].cd.algo == T2V_ALGO_WINOGRAD_F4 && specs[li + 1].cd.algo == T2V_ALGO_WINOGRAD_F4;
-        T2V_TRY(conv_norm(x, t, 1, nullptr, nullptr, defer));
+        T2V_TRY(conv_norm(x, t, 1, nullptr, nullptr));
         return conv_norm(t, y, 0, x, extra);
     }
 

@@ -127,15 +127,8 @@ int launch_winograd_weight(hipStream_t s, const float* w, float* U, int Cout, in
 int launch_winograd_input(hipStream_t s, const float* x, float* V, int H, int W, int C, int pad, int reflect);
 int launch_winograd_output(hipStream_t s, const float* Mm, const float* bias, float* y, float* stats, int H, int W, int N);
 int launch_winograd4_weight(hipStream_t s, const float* w, float* U, int Cout, int Cin, int Cout_p, int Cin_s);
-// a norm (+ReLU) the producer of x left un-applied: the input transform applies it to every value it loads
-struct PendingNorm {
-    const float* mean_rstd = nullptr;   // [C][2]
-    const float* gamma = nullptr;       // [C] or null
-    const float* beta = nullptr;
-    int relu = 0;                       // 0 | 1 (ReLU)
-};
 int launch_winograd4_input(hipStream_t s, const float* x, float* V, int H, int W, int C, int pad, int reflect, int batch = 1,
-                           int image = 0, const PendingNorm* norm = nullptr);
+                           int image = 0);
 int launch_winograd4_dy(hipStream_t s, const float* dy, float* Md, int Ho, int Wo, int N, int dy_cs, int batch, int image);
 int launch_winograd4_dw(hipStream_t s, const float* dU, float* dw, int Cout, int Cin, int Cout_p, int Kp, int accumulate);
 int launch_winograd4_output(hipStream_t s, const float* Mm, const float* bias, float* y, float* stats, int H, int W, int N);

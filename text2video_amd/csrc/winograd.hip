@@ -280,9 +280,7 @@ int launch_winograd4_weight(hipStream_t s, const float* w, float* U, int Cout, i
 // Tt / t0: V is [36][Tt][C] and this image's tiles start at row t0 (a batch of images shares one matrix)
 __global__ __launch_bounds__(256) void winograd4_input_kernel(const float2* __restrict__ x, float2* __restrict__ V, int H,
                                                               int W, int C2, int TW, int T, int Tp, int pad, int reflect,
-                                                              int Tt, int t0, PendingNorm nrm) {
-    // nrm.mean_rstd != null: x is a raw conv output whose instance norm (+affine, +ReLU) was deferred to this
-    // kernel -- same arithmetic, in the same order, as inorm_apply_kernel; saves that kernel's read + write pass
+                                                              int Tt, int t0) {
     const long total = (long)Tp * C2;
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
@@ -294,18 +292,6 @@ __global__ __launch_bounds__(256) void winograd4_input_kernel(const float2* __re
             continue;
         }
         const int ty = (int)(tile / TW), tx = (int)(tile - (long)ty * TW);
-        float2 n_mean = make_float2(0.f, 0.f), n_rstd = make_float2(1.f, 1.f), n_ga = make_float2(1.f, 1.f),
-               n_be = make_float2(0.f, 0.f);
-        const bool normed = nrm.mean_rstd != nullptr;
-        if (normed) {
-            const float4 mr = reinterpret_cast<const float4*>(nrm.mean_rstd)[c2];   // (m0, r0, m1, r1)
-            n_mean = make_float2(mr.x, mr.z);
-            n_rstd = make_float2(mr.y, mr.w);
-            if (nrm.gamma) {
-                n_ga = reinterpret_cast<const float2*>(nrm.gamma)[c2];
-                n_be = reinterpret_cast<const float2*>(nrm.beta)[c2];
-            }
-        }
         int ry[6], rx[6];
         bool oky[6], okx[6];
 #pragma unroll
@@ -325,22 +311,7 @@ __global__ __launch_bounds__(256) void winograd4_input_kernel(const float2* __re
             float dx[6], dy[6];
 #pragma unroll
             for (int b = 0; b < 6; ++b) {
-                float2 d = make_float2(0.f, 0.f);
-                if (oky[a] && okx[b]) {
-                    d = x[((long)ry[a] * W + rx[b]) * C2 + c2];
-                    if (normed) {
-                        d.x = (d.x - n_mean.x) * n_rstd.x;
-                        d.y = (d.y - n_mean.y) * n_rstd.y;
-                        if (nrm.gamma) {
-                            d.x = d.x * n_ga.x + n_be.x;
-                            d.y = d.y * n_ga.y + n_be.y;
-                        }
-                        if (nrm.relu == 1) {
-                            d.x = fmaxf(d.x, 0.f);
-                            d.y = fmaxf(d.y, 0.f);
-                        }
-                    }
-                }
+                const float2 d = (oky[a] && okx[b]) ? x[((long)ry[a] * W + rx[b]) * C2 + c2] : make_float2(0.f, 0.f);
                 dx[b] = d.x;
                 dy[b] = d.y;
             }
@@ -366,12 +337,12 @@ __global__ __launch_bounds__(256) void winograd4_input_kernel(const float2* __re
     }
 }
 int launch_winograd4_input(hipStream_t s, const float* x, float* V, int H, int W, int C, int pad, int reflect, int batch,
-                           int image, const PendingNorm* norm) {
+                           int image) {
     const int Ho = H + 2 * pad - 2, Wo = W + 2 * pad - 2;
     const int TW = (Wo + 3) / 4, T = ((Ho + 3) / 4) * TW, Tp = wino_pad_tiles(T);
     hipLaunchKernelGGL(winograd4_input_kernel, dim3(wg_grid((long)Tp * (C / 2), 256)), dim3(256), 0, s,
                        reinterpret_cast<const float2*>(x), reinterpret_cast<float2*>(V), H, W, C / 2, TW, T, Tp, pad,
-                       reflect, batch * Tp, image * Tp, norm ? *norm : PendingNorm());
+                       reflect, batch * Tp, image * Tp);
     T2V_HIP_CHECK(hipGetLastError());
     return T2V_OK;
 }
