@@ -54,6 +54,8 @@ CONV_CASES = [
     ("stem_kernel_cin6_c128", 16, 16, 6, 128, 7, 1, 3, 1, False),
     ("stem_kernel_cin9_c64", 48, 32, 9, 64, 7, 1, 3, 1, False),
     ("stem_kernel_cin6_c64", 64, 16, 6, 64, 7, 1, 3, 1, False),
+    ("stem_kernel_ragged_cin9", 40, 52, 9, 128, 7, 1, 3, 1, False),        # 3 x 4 tiles, ragged bottom row and right column
+    ("stem_kernel_ragged_cin6", 17, 85, 6, 64, 7, 1, 3, 1, False),
     ("down3x3_s2", 32, 32, 32, 64, 3, 2, 1, 0, False),
     ("down3x3_s2_narrow", 16, 24, 8, 16, 3, 2, 1, 0, False),
     ("convT_fast", 8, 8, 64, 32, 3, 2, 1, 0, True),

@@ -140,7 +140,7 @@ int build_conv_plan(const t2v_conv_desc* d, int x_cs, bool need_stats, ConvPlan*
         pl.tile = kTileStem;
         pl.BM = 256;
         pl.BN = d->Cout;
-        k.mtiles = k.M / 256;
+        k.mtiles = ((d->H + 15) / 16) * ((d->W + 15) / 16);
         k.ntiles = 1;
     }
     pl.nparts = k.nphases * k.mtiles;
@@ -383,6 +383,9 @@ int t2v_instance_norm_finalize(t2v_ctx* ctx, void* stream, const t2v_conv_desc* 
     }
     ConvPlan pl;
     T2V_TRY(build_conv_plan(producer, round_up(producer ? producer->Cin : 0, 4), true, &pl));
+    if (pl.tile == kTileStem)
+        return launch_inorm_finalize_tiles((hipStream_t)stream, stats_partial, 16, producer->H, producer->W, producer->Cout, eps,
+                                           mean_rstd, 1);
     return launch_inorm_finalize((hipStream_t)stream, stats_partial, pl.nparts, pl.kp.mtiles, pl.BM, pl.kp.M,
                                  producer->Cout, eps, mean_rstd);
 }
@@ -395,6 +398,9 @@ int t2v_batch_norm_finalize(t2v_ctx* ctx, void* stream, const t2v_conv_desc* pro
                                               wino_out_w(producer), producer->Cout, eps, mean_rstd, batch);
     ConvPlan pl;
     T2V_TRY(build_conv_plan(producer, round_up(producer ? producer->Cin : 0, 4), true, &pl));
+    if (pl.tile == kTileStem)
+        return launch_inorm_finalize_tiles((hipStream_t)stream, stats_partial, 16, producer->H, producer->W, producer->Cout, eps,
+                                           mean_rstd, batch);
     // the per-image partial blocks are contiguous: a batch is just `batch` times more partial rows
     return launch_inorm_finalize((hipStream_t)stream, stats_partial, batch * pl.nparts, pl.kp.mtiles, pl.BM, pl.kp.M,
                                  producer->Cout, eps, mean_rstd);

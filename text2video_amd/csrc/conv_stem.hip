@@ -67,7 +67,7 @@ __global__ __launch_bounds__(512) void conv_stem7x7_kernel(const StemParams p) {
         const int q = nb >> 3, r = nb & 7;
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int tiles_x = p.W / C::TILE;
+    const int tiles_x = (p.W + C::TILE - 1) / C::TILE;   // ragged right / bottom tiles: clamped gather, masked epilogue
     const int x0 = (tile % tiles_x) * C::TILE, y0 = (tile / tiles_x) * C::TILE;
 
     // ---- stage the halo (once) and zero its slack ----
@@ -82,8 +82,8 @@ __global__ __launch_bounds__(512) void conv_stem7x7_kernel(const StemParams p) {
             int gy = y0 - 3 + hy, gx = x0 - 3 + hx;
             gy = gy < 0 ? -gy : gy;
             gx = gx < 0 ? -gx : gx;
-            gy = min(gy, 2 * p.H - 2 - gy);
-            gx = min(gx, 2 * p.W - 2 - gx);
+            gy = max(min(gy, 2 * p.H - 2 - gy), 0);   // (past the reflected border: only feeds masked outputs)
+            gx = max(min(gx, 2 * p.W - 2 - gx), 0);
             const int voff = pix < C::NPIX ? ((gy * p.W + gx) * CS + 4 * j) * 4 : 0x7fff0000;
             st_dma16(p.x, x_bytes, s_halo + instr * 1024, voff, 0);
         }
@@ -145,6 +145,14 @@ __global__ __launch_bounds__(512) void conv_stem7x7_kernel(const StemParams p) {
 #pragma unroll
         for (int k = 0; k < 16; ++k) acc[t][k] += bias_v[t];
     }
+    const int vh = min(C::TILE, p.H - y0), vw = min(C::TILE, p.W - x0);   // valid part of a ragged tile
+    const float inv_cnt = 1.f / (float)(vh * vw);
+    unsigned okmask = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int row = (k & 3) + 8 * (k >> 2) + 4 * g;
+        if (2 * wave + (row >> 4) < vh && (row & 15) < vw) okmask |= 1u << k;
+    }
     float mean_b[NT];
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
@@ -154,7 +162,7 @@ __global__ __launch_bounds__(512) void conv_stem7x7_kernel(const StemParams p) {
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
                 const float d = acc[t][k] - (pass ? mean_b[t] : 0.f);
-                v[k] = pass ? d * d : d;
+                v[k] = ((okmask >> k) & 1u) ? (pass ? d * d : d) : 0.f;
             }
 #pragma unroll
             for (int w2 = 8; w2 >= 1; w2 >>= 1)
@@ -171,7 +179,7 @@ __global__ __launch_bounds__(512) void conv_stem7x7_kernel(const StemParams p) {
             const float tot = ((s_red[c] + s_red[C::N + c]) + (s_red[2 * C::N + c] + s_red[3 * C::N + c])) +
                               ((s_red[4 * C::N + c] + s_red[5 * C::N + c]) + (s_red[6 * C::N + c] + s_red[7 * C::N + c]));
             if (pass == 0) {
-                mean_b[t] = tot * (1.f / 256.f);
+                mean_b[t] = tot * inv_cnt;
             } else if (wave == 0 && g == 0) {
                 reinterpret_cast<float2*>(p.stats)[(size_t)tile * p.Cout + c] = make_float2(mean_b[t], tot);
             }
@@ -181,6 +189,7 @@ __global__ __launch_bounds__(512) void conv_stem7x7_kernel(const StemParams p) {
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         const int row = (k & 3) + 8 * (k >> 2) + 4 * g;          // pixel of this wave, 0..31
+        if (!((okmask >> k) & 1u)) continue;
         const int oy = y0 + 2 * wave + (row >> 4), ox = x0 + (row & 15);
         float* dst = p.y + ((size_t)oy * p.W + ox) * p.Cout_s;
 #pragma unroll
@@ -197,14 +206,14 @@ static int launch_stem(hipStream_t s, const StemParams& p) {
         T2V_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
         attr_done = true;
     }
-    hipLaunchKernelGGL(kern, dim3((p.H / C::TILE) * (p.W / C::TILE)), dim3(512), C::LDS, s, p);
+    hipLaunchKernelGGL(kern, dim3(((p.H + C::TILE - 1) / C::TILE) * ((p.W + C::TILE - 1) / C::TILE)), dim3(512), C::LDS, s, p);
     T2V_HIP_CHECK(hipGetLastError());
     return T2V_OK;
 }
 
 bool conv_stem7x7_supported(int H, int W, int Cin_s, int Cout) {
     static const bool off = getenv("T2V_CONV_STEM") && atoi(getenv("T2V_CONV_STEM")) == 0;
-    return !off && H % 16 == 0 && W % 16 == 0 && H >= 16 && W >= 16 && (Cin_s == 8 || Cin_s == 12) && (Cout == 64 || Cout == 128);
+    return !off && H >= 16 && W >= 16 && (Cin_s == 8 || Cin_s == 12) && (Cout == 64 || Cout == 128);
 }
 
 int launch_conv_stem7x7(hipStream_t s, const StemParams& p) {

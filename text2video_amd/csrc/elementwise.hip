@@ -51,7 +51,11 @@ __global__ __launch_bounds__(16 * kFinSlices) void inorm_finalize_kernel(const f
         for (int part = blockIdx.y * kFinSlices + sl; part < nparts; part += kFinSlices * gridDim.y) {
             int nb = BM;
             if (!uniform) {
-                if (wm == 0) {
+                if (wm < 0) {   // square pixel tiles of edge -wm (conv_stem.hip), ragged at the right / bottom
+                    const int e = -wm, TW = (W + e - 1) / e;
+                    const int pi = part % mtiles, ty = pi / TW, tx = pi - ty * TW;
+                    nb = min(e, H - e * ty) * min(e, W - e * tx);
+                } else if (wm == 0) {
                     const int mt = part % mtiles;
                     nb = min(BM, M - mt * BM);
                 } else {
@@ -142,6 +146,13 @@ int launch_inorm_finalize(hipStream_t s, const float* stats, int nparts, int mti
                           float eps, float* mean_rstd, double* scratch) {
     return run_finalize(s, stats, nparts, mtiles, BM, M, C, eps, mean_rstd, 0, 0, 0, scratch);
 }
+// partials of square edge x edge pixel tiles (the stem kernel), `batch` images back to back
+int launch_inorm_finalize_tiles(hipStream_t s, const float* stats, int edge, int H, int W, int C, float eps,
+                                float* mean_rstd, int batch, double* scratch) {
+    const int nparts = ((H + edge - 1) / edge) * ((W + edge - 1) / edge);
+    return run_finalize(s, stats, batch * nparts, nparts, edge * edge, H * W, C, eps, mean_rstd, -edge, H, W, scratch);
+}
+
 // partials written by the Winograd output transform F(wm x wm, 3x3) of an H x W map
 int launch_inorm_finalize_winograd(hipStream_t s, const float* stats, int wm, int H, int W, int C, float eps,
                                    float* mean_rstd, int batch, double* scratch) {

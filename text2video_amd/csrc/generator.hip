@@ -183,8 +183,11 @@ struct Runner {
         }
         T2V_TRY(build_conv_plan(&L.cd, L.x_cs, true, &pl));
         T2V_TRY(run_conv(ctx, s, pl, x, w.w, w.bias, y, Cout, b.stats[sc]));
-        T2V_TRY(launch_inorm_finalize(s, b.stats[sc], pl.nparts, pl.kp.mtiles, pl.BM, pl.kp.M, Cout, g.eps, b.mean_rstd[sc],
-                                      b.fin[sc]));
+        if (pl.tile == kTileStem)
+            T2V_TRY(launch_inorm_finalize_tiles(s, b.stats[sc], 16, L.cd.H, L.cd.W, Cout, g.eps, b.mean_rstd[sc], 1, b.fin[sc]));
+        else
+            T2V_TRY(launch_inorm_finalize(s, b.stats[sc], pl.nparts, pl.kp.mtiles, pl.BM, pl.kp.M, Cout, g.eps, b.mean_rstd[sc],
+                                          b.fin[sc]));
         const float* gamma = g.norm_affine ? w.gamma : nullptr;
         const float* beta = g.norm_affine ? w.beta : nullptr;
         if (g.norm_affine) T2V_REQUIRE(gamma && beta, "layer %d: norm_affine=1 but gamma/beta missing", li - 1);

@@ -167,6 +167,8 @@ int launch_conv_igemm(hipStream_t s, const ConvKParams& p, int tile);
 constexpr int kFinalizeMaxGroups = 64;
 int launch_inorm_finalize_winograd(hipStream_t s, const float* stats, int wm, int H, int W, int C, float eps,
                                    float* mean_rstd, int batch, double* scratch = nullptr);
+int launch_inorm_finalize_tiles(hipStream_t s, const float* stats, int edge, int H, int W, int C, float eps,
+                                float* mean_rstd, int batch, double* scratch = nullptr);
 int launch_inorm_finalize(hipStream_t s, const float* stats, int nparts, int mtiles, int BM, int M, int C,
                           float eps, float* mean_rstd, double* scratch = nullptr);
 int launch_inorm_apply(hipStream_t s, const float* x, const float* mean_rstd, const float* gamma,
