@@ -127,7 +127,12 @@ int build_conv_plan(const t2v_conv_desc* d, int x_cs, bool need_stats, ConvPlan*
         const double fill = (double)nb / (double)(((nb + 255) / 256) * 256);
         // transposed convs with few blocks: the four phases have 1/2/2/4 taps, and one 128x128 block per CU cannot
         // balance such unequal blocks (1024->512 up-sampling: 0.317 -> 0.286 ms with 64x64 tiles)
-        if (force == kTileQ || (force < 0 && ((fill < 0.8 && nb < 1024) || (k.nphases > 1 && nb <= 512)))) {
+        // ... or when four times as many 64x64 blocks fill the chip's rounds clearly better (864 tiles of the 64x85
+        // Winograd GEMM: 0.84 -> 0.96, 0.259 -> 0.244 ms)
+        const long nbq = 4 * nb;
+        const double fillq = (double)nbq / (double)(((nbq + 255) / 256) * 256);
+        if (force == kTileQ || (force < 0 && ((fill < 0.8 && nb < 1024) || (k.nphases > 1 && nb <= 512) ||
+                                              (fillq - fill >= 0.1 && nb < 2048)))) {
             pl.tile = kTileQ;
             conv_tile_dims(pl.tile, &pl.BM, &pl.BN);
             k.ntiles = (d->Cout + pl.BN - 1) / pl.BN;
