@@ -96,3 +96,33 @@ def test_bench_flop_model_matches_baseline():
     assert abs(bench.gflop_per_frame(512, 512, False) - 2572) < 1.0
     assert abs(bench.gflop_per_frame(512, 512, True) - 3316) < 1.0
     assert abs(bench.gflop_per_frame(1024, 1024, False) - 10287) < 2.0
+
+
+def test_algorithm_choice_and_winograd_bookkeeping(lib_built):
+    """Host-side planning needs no GPU: which algorithm a 3x3 layer gets, and the buffer sizes that follow."""
+    from text2video_amd import _lib
+    from text2video_amd._lib import ConvDesc
+
+    def desc(H, W, C=1024, k=3, stride=1, pad=1, pad_mode=_lib.PAD_REFLECT, algo=0):
+        return ConvDesc(H, W, C, C, k, k, stride, pad, pad_mode, 0, _lib.ACT_NONE, 1.0, 0, algo)
+
+    best = lambda d, cap=0: lib_built.t2v_conv_best_algo(ctypes.byref(d), d.Cin, cap)
+    assert best(desc(64, 64)) == _lib.ALGO_WINOGRAD_F4                       # 512x512 frames: 256 tiles of 4x4
+    assert best(desc(64, 40)) == _lib.ALGO_WINOGRAD_F4                       # 512x320: 160 tiles, padded to 192
+    assert best(desc(64, 85)) == _lib.ALGO_WINOGRAD_F4                       # 512x680: ragged 16 x 22 grid
+    assert best(desc(16, 16)) == _lib.ALGO_WINOGRAD                          # 64 tiles of 2x2 pad to 128 < 9 rows/pixel
+    assert best(desc(8, 8)) == _lib.ALGO_DIRECT                              # padding to 128 tiles never pays
+    assert best(desc(64, 64), 1) == _lib.ALGO_DIRECT and best(desc(64, 64), 2) == _lib.ALGO_WINOGRAD
+    assert best(desc(64, 64, stride=2, pad_mode=_lib.PAD_ZERO)) == _lib.ALGO_DIRECT
+    assert best(desc(64, 64, pad=2, pad_mode=_lib.PAD_ZERO)) == _lib.ALGO_WINOGRAD_F4      # the data gradient's geometry
+    assert best(desc(64, 64, C=24)) == _lib.ALGO_DIRECT                      # channels must be a multiple of 32
+    f4 = desc(64, 64, algo=_lib.ALGO_WINOGRAD_F4)
+    assert lib_built.t2v_conv_winograd_supported(ctypes.byref(f4), 1024) == 3
+    assert lib_built.t2v_conv_packed_weight_floats(ctypes.byref(f4), 1024) == 36 * 1024 * 1024
+    assert lib_built.t2v_conv_winograd_workspace_floats(ctypes.byref(f4), 1024) == 36 * 256 * 2048
+    assert lib_built.t2v_conv_stats_floats(ctypes.byref(f4)) == 32 * 1024 * 2      # one partial per 128 output pixels
+    r = desc(64, 40, algo=_lib.ALGO_WINOGRAD_F4)
+    assert lib_built.t2v_conv_winograd_workspace_floats(ctypes.byref(r), 1024) == 36 * 192 * 2048   # 160 tiles -> 192
+    assert lib_built.t2v_conv_backward_weight_winograd_supported(ctypes.byref(f4), 1024, 1024) == 1
+    assert lib_built.t2v_conv_backward_weight_winograd_workspace_floats(ctypes.byref(f4), 1024, 2) == \
+        36 * 2 * 256 * 2048 + 36 * 1024 * 1024
