@@ -62,14 +62,18 @@ class _ConvBlock(torch.autograd.Function):
             y = torch.empty_like(c)
             g = gamma.detach() if gamma is not None else None
             bt = beta.detach() if beta is not None else None
+            # the residual add rides in the norm-apply pass (its gradient is the identity)
+            rs = res.detach().contiguous() if (res is not None and res.shape == y.shape) else None
             if norm == "batch":
                 mrs = [ops.batch_norm_finalize(stats, fdesc, B)]
-                ops.instance_norm_apply(c, mrs[0], g, bt, relu=relu, out=y)
+                ops.instance_norm_apply(c, mrs[0], g, bt, res1=rs, relu=relu, out=y)
             else:
                 mrs = []
                 for i in range(B):
                     mrs.append(ops.instance_norm_finalize(stats[i * n:(i + 1) * n], fdesc))
-                    ops.instance_norm_apply(c[i], mrs[i], g, bt, relu=relu, out=y[i])
+                    ops.instance_norm_apply(c[i], mrs[i], g, bt, res1=rs[i] if rs is not None else None, relu=relu, out=y[i])
+            if rs is not None:
+                res = None
         if res is not None:
             y = y + res   # residual add (plumbing-level elementwise; its gradient is the identity)
         # weight gradient in the Winograd domain where the forward took F(4x4,3x3) (a quarter of the FLOPs)
