@@ -430,25 +430,25 @@ static size_t wgrad_padded_floats(const t2v_conv_desc* d, int x_cs, int batch) {
 
 static int wgrad_splits(const t2v_conv_desc* d, int x_cs, int batch, const ConvPlan& pl) {
     // few (tap, channel-tile) blocks but a long pixel reduction (high-resolution, narrow layers): cut the
-    // reduction so that >= ~512 blocks exist; partial gradients are summed in a fixed order afterwards
+    // reduction into ranges; partial gradients are summed in a fixed order afterwards
     int ntaps = 0;
     for (int ph = 0; ph < pl.kp.nphases; ++ph) ntaps += pl.kp.ph[ph].ntaps;
     const long blocks = wgrad_fold(d, x_cs) ? (long)((d->Cout + 127) / 128) * ((ntaps * x_cs + 127) / 128)
                                             : (long)ntaps * ((d->Cout + 127) / 128) * ((x_cs + 127) / 128);
     const long nk = ((long)batch * pl.kp.M + 31) / 32;
-    long s = (512 + blocks - 1) / blocks;
-    if (s > nk / 8) s = nk / 8;      // at least 8 stages per block
-    if (s > 256) s = 256;
-    if (s < 1) s = 1;
-    if (blocks >= 256 && nk >= 64) {
-        // wave quantisation: one block per CU is resident (96 KiB ring), so 576 blocks = 2.25 rounds of the
-        // 256 CUs idle a quarter of the chip; pick the split (<= 4) that fills the last round best
-        double best = 0.0;
-        for (long c = 1; c <= 4; ++c) {
-            const long nb = blocks * c;
-            const double fill = (double)nb / (double)(((nb + 255) / 256) * 256);
-            if (fill > best + 0.02) { best = fill; s = c; }
-        }
+    // one block per CU is resident (96 KiB ring): a launch costs rounds x (stages per block + ~3 stages of
+    // prologue / epilogue) stage times; 576 blocks = 2.25 rounds of the 256 CUs idle a quarter of the chip where
+    // 504 fill two rounds.  Fewest stage times wins, ties to the smaller split (less partial-gradient traffic).
+    long smax = nk / 8;              // at least 8 stages per block
+    if (smax > 256) smax = 256;
+    if (smax < 1) smax = 1;
+    long s = 1, best = -1;
+    for (long c = 1; c <= smax; ++c) {
+        const long rounds = (blocks * c + 255) / 256;
+        // + zeroing, writing and re-reading c partial gradients at ~15 MB per stage time
+        const long cost = rounds * ((nk + c - 1) / c + 3) + (c > 1 ? c * (long)pl.wfloats * 12 / 15000000 : 0);
+        if (best < 0 || cost < best) { best = cost; s = c; }
+        if (blocks * c >= 4096) break;
     }
     return s < 1 ? 1 : (int)s;
 }

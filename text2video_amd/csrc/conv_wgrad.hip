@@ -84,16 +84,35 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradParams p) {
         }
         const int dy_bytes = p.batch * p.Hout * p.Wout * p.Cout_s * 4;
         const int x_bytes = p.batch * p.Hin * p.Win * p.Cin_s * 4;
+        // (image, row, column) of this lane's four pixels in the stage being issued: set up once with divisions,
+        // then stepped by kWgPix pixels per stage (stages are issued in increasing order)
+        const int Hm = p.M / p.Wm;
+        int pb[4], py[4], px[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int pidx = kt0 * kWgPix + wid * 8 + i * 2 + prow;   // global pixel (image-major)
+            pb[i] = pidx / p.M;
+            const int m = pidx - pb[i] * p.M;
+            py[i] = m / p.Wm;
+            px[i] = m - py[i] * p.Wm;
+        }
+        int cur = 0;
         auto issue_stage = [&](int kt, int slot) {
             char* sY = smem + slot * kWgStage;
             char* sX = sY + kWgPix * 512;
+            if (kt > cur) {   // kt == cur + 1
+                cur = kt;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    px[i] += kWgPix;
+                    while (px[i] >= p.Wm) { px[i] -= p.Wm; ++py[i]; }
+                    while (py[i] >= Hm) { py[i] -= Hm; ++pb[i]; }
+                }
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int r = wid * 8 + i * 2 + prow;      // pixel row in the stage, 0..31
-                const int pidx = (kt0 + kt) * kWgPix + r;   // global pixel (image-major)
-                const bool ok = pidx < P;
-                const int b = pidx / p.M, m = pidx - b * p.M;
-                const int my = m / p.Wm, mx = m - my * p.Wm;
+                const int b = pb[i], my = py[i], mx = px[i];
+                const bool ok = b < p.batch;
                 // dY: output pixel of GEMM pixel m (strided for the sub-pixel phases of a transposed conv)
                 int opix = (b * p.Hout + my * p.ostride + p.toy[tap]) * p.Wout + mx * p.ostride + p.tox[tap];
                 bool oky = ok && n_ok;
@@ -146,41 +165,53 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // Software pipeline (one MFMA wave per SIMD has nobody to hide its LDS latency): the operands of
-    // pixel pair s+1 are read while the 4 MFMAs of pair s run; the stage barrier sits before the last
-    // pair's MFMAs so the first pair of the next stage is fetched under them.
-    float av[2][2], bv[2][2];
-    auto load_pair = [&](int buf, int s, int set) {
+    // Software pipeline (one MFMA wave per SIMD has nobody to hide its LDS latency): the stage's 16 pixel pairs
+    // run as 4 groups of 4 pairs = 16 MFMAs; the operands of group q+1 are read in the shadow of group q's MFMAs
+    // (issue order MFMA, ds_read, MFMA, ds_read, ...); the stage barrier sits before the last group's reads,
+    // which are the first of the next stage.
+    constexpr int NQ = kWgPix / 8;
+    float av[2][4][2], bv[2][4][2];
+    auto load_group = [&](int buf, int q, int set) {
         const float* sY = reinterpret_cast<const float*>(smem + buf * kWgStage);
         const float* sX = sY + kWgPix * 128;
-        const int px = 2 * s + kk;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) av[set][i] = sY[px * 128 + wn * 64 + i * 32 + fi];
+        for (int e = 0; e < 4; ++e) {
+            const int px = 8 * q + 2 * e + kk;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) bv[set][j] = sX[px * 128 + wc * 64 + j * 32 + fi];
+            for (int i = 0; i < 2; ++i) av[set][e][i] = sY[px * 128 + wn * 64 + i * 32 + fi];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bv[set][e][j] = sX[px * 128 + wc * 64 + j * 32 + fi];
+        }
     };
     __syncthreads();  // B0
-    load_pair(0, 0, 0);
+    load_group(0, 0, 0);
     int buf = 0;
     for (int kt = 0; kt < nk; ++kt) {
         const int nbuf = buf == kWgRing - 1 ? 0 : buf + 1;
 #pragma unroll
-        for (int s = 0; s < kWgPix / 2; ++s) {
-            const int cur = s & 1;
+        for (int q = 0; q < NQ; ++q) {
+            const int cur = q & 1;
             __builtin_amdgcn_sched_barrier(0);
-            if (s + 1 < kWgPix / 2) {
-                load_pair(buf, s + 1, cur ^ 1);
-            } else {
+            if (q + 1 == NQ) {
                 __syncthreads();  // barrier(kt): slot `buf` fully read, stage kt+1 visible
                 __builtin_amdgcn_sched_barrier(0);
-                load_pair(nbuf, 0, cur ^ 1);
+                load_group(nbuf, 0, cur ^ 1);
+            } else {
+                load_group(buf, q + 1, cur ^ 1);
             }
-            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int e = 0; e < 4; ++e)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][i], bv[cur][j], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][e][i], bv[cur][e][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
         }
         buf = nbuf;
     }
