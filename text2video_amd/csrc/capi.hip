@@ -436,15 +436,16 @@ static int wgrad_splits(const t2v_conv_desc* d, int x_cs, int batch, const ConvP
     const long blocks = wgrad_fold(d, x_cs) ? (long)((d->Cout + 127) / 128) * ((ntaps * x_cs + 127) / 128)
                                             : (long)ntaps * ((d->Cout + 127) / 128) * ((x_cs + 127) / 128);
     const long nk = ((long)batch * pl.kp.M + 31) / 32;
-    // one block per CU is resident (96 KiB ring): a launch costs rounds x (stages per block + ~3 stages of
-    // prologue / epilogue) stage times; 576 blocks = 2.25 rounds of the 256 CUs idle a quarter of the chip where
-    // 504 fill two rounds.  Fewest stage times wins, ties to the smaller split (less partial-gradient traffic).
+    // a launch costs rounds x (stages per block + ~3 stages of prologue / epilogue) stage times, a round being
+    // one set of resident blocks: a block count just above a whole number of rounds idles most of the chip for
+    // the last one.  Fewest stage times wins, ties to the smaller split (less partial-gradient traffic).
     long smax = nk / 8;              // at least 8 stages per block
     if (smax > 256) smax = 256;
     if (smax < 1) smax = 1;
     long s = 1, best = -1;
+    const long slots = 2 * 256;      // two blocks (2 x 64 KiB of LDS, 104 VGPRs) are resident per CU
     for (long c = 1; c <= smax; ++c) {
-        const long rounds = (blocks * c + 255) / 256;
+        const long rounds = (blocks * c + slots - 1) / slots;
         // + zeroing, writing and re-reading c partial gradients at ~15 MB per stage time
         const long cost = rounds * ((nk + c - 1) / c + 3) + (c > 1 ? c * (long)pl.wfloats * 12 / 15000000 : 0);
         if (best < 0 || cost < best) { best = cost; s = c; }

@@ -9,7 +9,7 @@
 // conflict-free ds_read_b32 -- no transposes, no swizzle.
 //
 //   block tile : 128 output channels (n) x 128 input channels (c) of ONE tap, 64 accumulator VGPRs/wave
-//   K loop     : 32 pixels per LDS stage (2 x 16 KiB), 3-slot ring, loader waves with buffer-addressed
+//   K loop     : 32 pixels per LDS stage (2 x 16 KiB), 2-slot ring (two blocks per CU), loader waves with buffer-addressed
 //                LDS-DMA (same wave-specialised structure as conv_igemm.hip); padding / tails = OOB lanes
 //   grid       : (Cout/128) x (Cin_s/128) x taps  [x phases for transposed convs]
 //   output     : written straight into the PACKED weight layout [Cout_p][Kp] (K = tap*Cin_s + c), so the
@@ -31,7 +31,7 @@ __device__ __forceinline__ void wg_dma16(const float* base, int nbytes, char* ld
 
 constexpr int kWgPix = 32;                       // pixels per stage
 constexpr int kWgStage = 2 * kWgPix * 128 * 4;   // dY tile + X tile, 128 channels each
-constexpr int kWgRing = 3;
+constexpr int kWgRing = 2;
 
 // REFLECT: the forward conv used reflection padding (taps never fall outside; indices mirror)
 template <bool REFLECT>
@@ -138,15 +138,16 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradParams p) {
                 wg_dma16(p.x, x_bytes, sX + (wid * 8 + i * 2) * 512, vx, 0);
             }
         };
-        constexpr int LD = 8;
-        issue_stage(0, 0);
-        issue_stage(max(0, min(1, nk - 1)), 1);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LD) : "memory");
+        constexpr int LD = 8;               // DMA instructions per loader wave and stage
+        constexpr int AHEAD = kWgRing - 1;  // stages in flight beyond the one being computed
+#pragma unroll
+        for (int st = 0; st < AHEAD; ++st) issue_stage(max(0, min(st, nk - 1)), st);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * LD) : "memory");
         __builtin_amdgcn_s_barrier();
-        int slot = 2;
+        int slot = AHEAD % kWgRing;
         for (int kt = 0; kt < nk; ++kt) {
-            issue_stage(max(0, min(kt + 2, nk - 1)), slot);  // past the end: harmless re-fetch of the last stage
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LD) : "memory");
+            issue_stage(max(0, min(kt + AHEAD, nk - 1)), slot);  // past the end: harmless re-fetch of the last stage
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * LD) : "memory");
             __builtin_amdgcn_s_barrier();
             slot = slot == kWgRing - 1 ? 0 : slot + 1;
         }
