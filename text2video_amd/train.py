@@ -24,6 +24,28 @@ from .generator import GeneratorSpec, layer_keys, synthetic_state_dict  # noqa: 
 # ------------------------------------------------------------------------------------------------
 # differentiable building blocks
 # ------------------------------------------------------------------------------------------------
+_PACKS = {}   # weight storage address -> (tensor version, {layout key: packed / transformed weight})
+
+
+def cached_pack(w, key, make):
+    """Packed (or Winograd-transformed) layout of parameter `w`, kept until the optimiser next writes it: a step
+    runs every generator layer once per frame and every discriminator layer on real and fake inputs, all with the
+    same weights.  T2V_TRAIN_PACK_CACHE=0 re-packs per call (saves the memory of the transformed copies)."""
+    if os.environ.get("T2V_TRAIN_PACK_CACHE", "1") == "0":
+        return make()
+    ent = _PACKS.get(w.data_ptr())
+    if ent is None or ent[0] != w._version or ent[2] != w.shape:
+        ent = (w._version, {}, w.shape)
+        _PACKS[w.data_ptr()] = ent
+    if key not in ent[1]:
+        ent[1][key] = make()
+    return ent[1][key]
+
+
+def _desc_key(d, xcs):
+    return (d.H, d.W, d.Cin, d.Cout, d.kH, d.stride, d.pad, d.pad_mode, d.transposed, d.output_padding, d.algo, xcs)
+
+
 class _ConvBlock(torch.autograd.Function):
     """y = act(norm(conv(x) + b)) + res  on a batch [B,H,W,cs].
 
@@ -47,7 +69,7 @@ class _ConvBlock(torch.autograd.Function):
             algo = ops.best_conv_algo(fdesc, xcs, int(os.environ.get("T2V_CONV_ALGO", "0")))
             if algo != ops.ALGO_DIRECT:
                 fdesc = ops.with_algo(fdesc, algo)
-        pw = ops.pack_conv_weight(w.detach().contiguous(), fdesc, xcs)
+        pw = cached_pack(w, ("fwd",) + _desc_key(fdesc, xcs), lambda: ops.pack_conv_weight(w.detach().contiguous(), fdesc, xcs))
         c = torch.empty(B, ho, wo, ycs, dtype=torch.float32, device=dev)
         mrs = None
         if norm is None:
@@ -114,7 +136,8 @@ class _ConvBlock(torch.autograd.Function):
             dw = ops.unpack_conv_weight(dwp, fdesc, x.shape[-1])
         dx = None
         if need_dx:
-            dg = ConvDataGrad(fdesc).refresh(w.detach())
+            dg = ConvDataGrad(fdesc)
+            dg.packed = cached_pack(w, ("dgrad",) + _desc_key(fdesc, x.shape[-1]), lambda: dg.refresh(w.detach()).packed)
             dx = torch.stack([dg(dc[i]) for i in range(B)])
             if dx.shape[-1] != x.shape[-1]:
                 pad = torch.zeros(x.shape, dtype=torch.float32, device=x.device)
@@ -326,6 +349,7 @@ class FusedAdam:
             if p.grad is not None:
                 ops.adam_step(p.data, p.grad.contiguous(), m, v, self.lr, self.betas[0], self.betas[1], self.eps,
                               self.step_no)
+                _PACKS.pop(p.data_ptr(), None)   # written through the raw pointer: no tensor version bump
 
 
 def allreduce_gradients(params, bucket_mb=64):
