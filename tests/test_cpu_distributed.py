@@ -122,6 +122,21 @@ def _ar_worker(rank, world, port, tmpdir):
     for i, p in enumerate(params[:-1]):
         want = (1 + 2) / 2.0 * (i + 1)                          # mean over the two ranks
         assert torch.allclose(p.grad, torch.full_like(p, want))
+    # two exchanges in flight at once (generator gradients under the discriminators' backward pass)
+    from text2video_amd.train import allreduce_gradients_begin
+    a = [torch.nn.Parameter(torch.zeros(n)) for n in (300000, 9)]
+    b = [torch.nn.Parameter(torch.zeros(n)) for n in (7, 40000)]
+    for i, p in enumerate(a):
+        p.grad = torch.full_like(p, float(rank) + i)
+    xa = allreduce_gradients_begin(a, bucket_mb=1)
+    for i, p in enumerate(b):                                   # "backward of D" while xa is in flight
+        p.grad = torch.full_like(p, 10.0 * rank - i)
+    xb = allreduce_gradients_begin(b, bucket_mb=1)
+    assert xa.finish() == 4 * 300009 and xb.finish() == 4 * 40007
+    for i, p in enumerate(a):
+        assert torch.allclose(p.grad, torch.full_like(p, 0.5 + i))
+    for i, p in enumerate(b):
+        assert torch.allclose(p.grad, torch.full_like(p, 5.0 - i))
     dist.barrier()
     dist.destroy_process_group()
 

@@ -13,6 +13,7 @@ all-reduce.  Not built: VGG and FlowNet2-based losses / temporal discriminator (
 are not in the reference tree).
 """
 import os
+import time
 
 import torch
 
@@ -24,19 +25,17 @@ from .generator import GeneratorSpec, layer_keys, synthetic_state_dict  # noqa: 
 # ------------------------------------------------------------------------------------------------
 # differentiable building blocks
 # ------------------------------------------------------------------------------------------------
-_PACKS = {}   # weight storage address -> (tensor version, {layout key: packed / transformed weight})
-
-
 def cached_pack(w, key, make):
     """Packed (or Winograd-transformed) layout of parameter `w`, kept until the optimiser next writes it: a step
     runs every generator layer once per frame and every discriminator layer on real and fake inputs, all with the
-    same weights.  T2V_TRAIN_PACK_CACHE=0 re-packs per call (saves the memory of the transformed copies)."""
+    same weights.  The cache lives on the parameter object itself (freed with it; autograd hands the same object to
+    backward).  T2V_TRAIN_PACK_CACHE=0 re-packs per call (saves the memory of the transformed copies)."""
     if os.environ.get("T2V_TRAIN_PACK_CACHE", "1") == "0":
         return make()
-    ent = _PACKS.get(w.data_ptr())
-    if ent is None or ent[0] != w._version or ent[2] != w.shape:
-        ent = (w._version, {}, w.shape)
-        _PACKS[w.data_ptr()] = ent
+    ent = getattr(w, "_t2v_packs", None)
+    if ent is None or ent[0] != w._version:
+        ent = (w._version, {})
+        w._t2v_packs = ent
     if key not in ent[1]:
         ent[1][key] = make()
     return ent[1][key]
@@ -349,40 +348,59 @@ class FusedAdam:
             if p.grad is not None:
                 ops.adam_step(p.data, p.grad.contiguous(), m, v, self.lr, self.betas[0], self.betas[1], self.eps,
                               self.step_no)
-                _PACKS.pop(p.data_ptr(), None)   # written through the raw pointer: no tensor version bump
+                p._t2v_packs = None   # written through the raw pointer: no tensor version bump
+
+
+class GradientExchange:
+    """Bucketed gradient all-reduce in flight (`allreduce_gradients_begin`).  Every bucket is one asynchronous
+    collective on the process group's own stream (RCCL over xGMI; gloo on CPU), so the exchange of the
+    generator's gradients (1.13 GB at ngf 128) runs under the discriminators' backward pass; `finish()` waits,
+    averages over the ranks and scatters the buckets back into the .grad tensors."""
+
+    def __init__(self, params, bucket_mb=64):
+        import torch.distributed as dist
+        self.pending, self.nbytes = [], 0
+        self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        if self.world == 1:
+            return
+        limit = bucket_mb * (1 << 20) // 4
+        bucket, size = [], 0
+        for g in [p.grad for p in params if p.grad is not None]:
+            if size + g.numel() > limit and bucket:
+                self._launch(bucket)
+                bucket, size = [], 0
+            bucket.append(g)
+            size += g.numel()
+        if bucket:
+            self._launch(bucket)
+
+    def _launch(self, bucket):
+        import torch.distributed as dist
+        flat = torch.cat([g.reshape(-1) for g in bucket])
+        self.pending.append((dist.all_reduce(flat, async_op=True), flat, bucket))
+        self.nbytes += flat.numel() * 4
+
+    def finish(self):
+        for work, flat, bucket in self.pending:
+            work.wait()
+            flat /= self.world
+            off = 0
+            for g in bucket:
+                g.copy_(flat[off:off + g.numel()].view_as(g))
+                off += g.numel()
+        self.pending = []
+        return self.nbytes
+
+
+def allreduce_gradients_begin(params, bucket_mb=64):
+    return GradientExchange(params, bucket_mb)
 
 
 def allreduce_gradients(params, bucket_mb=64):
-    """Data-parallel gradient exchange: bucketed all-reduce (RCCL over xGMI; gloo on CPU), averaged over
-    ranks.  Replaces DataParallel's reduce-to-GPU-0 + re-broadcast: replicas are
-    persistent, so one all-reduce per bucket is all the communication a step needs."""
-    import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return 0
-    world = dist.get_world_size()
-    grads = [p.grad for p in params if p.grad is not None]
-    limit = bucket_mb * (1 << 20) // 4
-    nbytes, bucket, size = 0, [], 0
-
-    def flush(bucket):
-        flat = torch.cat([g.reshape(-1) for g in bucket])
-        dist.all_reduce(flat)
-        flat /= world
-        off = 0
-        for g in bucket:
-            g.copy_(flat[off:off + g.numel()].view_as(g))
-            off += g.numel()
-        return flat.numel() * 4
-
-    for g in grads:
-        if size + g.numel() > limit and bucket:
-            nbytes += flush(bucket)
-            bucket, size = [], 0
-        bucket.append(g)
-        size += g.numel()
-    if bucket:
-        nbytes += flush(bucket)
-    return nbytes
+    """Data-parallel gradient exchange: bucketed all-reduce, averaged over ranks; returns the bytes exchanged.
+    Replaces DataParallel's reduce-to-GPU-0 + re-broadcast: replicas are persistent, so one
+    all-reduce per bucket is all the communication a step needs."""
+    return GradientExchange(params, bucket_mb).finish()
 
 
 # ------------------------------------------------------------------------------------------------
@@ -472,7 +490,8 @@ class Vid2VidTrainer:
             d_params += list(dt.parameters())
         self.optG = FusedAdam(self.G.parameters(), opt.lr, (opt.beta1, 0.999))
         self.optD = FusedAdam(d_params, opt.lr, (opt.beta1, 0.999))
-        self.comm_bytes = 0
+        self.comm_bytes, self.comm_ms = 0, 0.0
+        self.time_comm = os.environ.get("T2V_TRAIN_COMM_TIMING", "0") == "1"
 
     def _d_input(self, A3, img4):
         z = torch.zeros(A3.shape[:-1] + (2,), dtype=torch.float32, device=A3.device)
@@ -553,12 +572,18 @@ class Vid2VidTrainer:
         g_params = list(self.G.parameters())
         d_params = self.optD.params
         gG = torch.autograd.grad(loss_G, g_params, retain_graph=True, allow_unused=True)
-        gD = torch.autograd.grad(loss_D, d_params, allow_unused=True)
         for p, g in zip(g_params, gG):
             p.grad = g
+        xg = allreduce_gradients_begin(g_params)     # in flight under the discriminators' backward pass
+        gD = torch.autograd.grad(loss_D, d_params, allow_unused=True)
         for p, g in zip(d_params, gD):
             p.grad = g
-        self.comm_bytes = allreduce_gradients(g_params) + allreduce_gradients(d_params)
+        xd = allreduce_gradients_begin(d_params)
+        t0 = time.perf_counter()
+        self.comm_bytes = xg.finish() + xd.finish()
+        if self.time_comm and self.comm_bytes:       # exposed (not hidden) part of the exchange
+            torch.cuda.synchronize()
+            self.comm_ms = 1e3 * (time.perf_counter() - t0)
         self.optG.step()
         self.optD.step()
         return losses, prev
@@ -608,8 +633,9 @@ def run_train(opt, steps=None):
             torch.cuda.synchronize()
             stats.append(time.perf_counter() - ts)
             if rank == 0 and (it % max(1, opt.print_freq // 100) == 0 or it == steps - 1):
-                print("(iter %d, %.0f ms, all-reduce %.1f MB) %s" % (it, 1e3 * stats[-1], trainer.comm_bytes / 2**20,
-                                                                     " ".join("%s: %.3f" % kv for kv in losses.items())), flush=True)
+                print("(iter %d, %.0f ms, all-reduce %.1f MB%s) %s" % (it, 1e3 * stats[-1], trainer.comm_bytes / 2**20,
+                                                                       ", %.1f ms exposed" % trainer.comm_ms if trainer.time_comm else "",
+                                                                       " ".join("%s: %.3f" % kv for kv in losses.items())), flush=True)
     else:
         # real data: <dataroot>/train_openpose + train_img.  One clip per rank per iteration (batchSize = world
         # size), walked in chunks of max_frames_per_gpu frames with the generated frames carried over
