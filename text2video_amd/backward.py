@@ -61,7 +61,9 @@ class ConvDataGrad:
         self.packed = ops.pack_conv_weight(w.contiguous(), self.desc, ops.round_up(self.desc.Cin, 4))
         return self
 
-    def __call__(self, dy):
-        """dy: [Hout, Wout, cs>=Cout] -> dX [H, W, round_up4(Cin)]."""
+    def __call__(self, dy, out=None):
+        """dy: [Hout, Wout, cs>=Cout] -> dX [H, W, round_up4(Cin)] (written into `out` if given)."""
+        if not self.fold:
+            return ops.conv2d_auto(dy, self.packed, None, self.desc, out=out)
         dxp = ops.conv2d_auto(dy, self.packed, None, self.desc)
-        return ops.reflect_pad_backward(dxp, self.fold) if self.fold else dxp
+        return ops.reflect_pad_backward(dxp, self.fold, out=out)

@@ -356,18 +356,19 @@ def channel_sum(x, C=None):
     return out
 
 
-def reflect_pad_backward(dxp, pad):
+def reflect_pad_backward(dxp, pad, out=None):
     """adjoint of ReflectionPad2d(pad): [H+2p, W+2p, C] -> [H, W, C]."""
     c = context()
     _chk(dxp, "dxp")
     Hp, Wp, C = dxp.shape
     H, W = Hp - 2 * pad, Wp - 2 * pad
-    dx = torch.empty(H, W, C, dtype=torch.float32, device=dxp.device)
+    dx = out if out is not None else torch.empty(H, W, C, dtype=torch.float32, device=dxp.device)
+    _chk(dx, "dx")
     check(c.lib.t2v_reflect_pad_backward(c.handle, _stream(), _p(dxp), _p(dx), H, W, C, pad), "reflect_pad_backward")
     return dx
 
 
-def instance_norm_backward(x, dy, mean_rstd, gamma=None, beta=None, relu=0):
+def instance_norm_backward(x, dy, mean_rstd, gamma=None, beta=None, relu=0, out=None):
     """x, dy: [..., C] (all leading dims are the pixels of ONE statistics group).  Returns
     (dx, dbeta_dgamma [C,2])."""
     c = context()
@@ -375,7 +376,8 @@ def instance_norm_backward(x, dy, mean_rstd, gamma=None, beta=None, relu=0):
     _chk(dy, "dy")
     C = x.shape[-1]
     npix = x.numel() // C
-    dx = torch.empty_like(x)
+    dx = out if out is not None else torch.empty_like(x)
+    _chk(dx, "dx")
     sums = torch.empty(C, 2, dtype=torch.float32, device=x.device)
     scratch = torch.empty(128 * C * 2, dtype=torch.float32, device=x.device)
     check(c.lib.t2v_instance_norm_backward(c.handle, _stream(), _p(x), _p(dy), _p(mean_rstd), _p(gamma), _p(beta),

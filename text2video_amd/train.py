@@ -41,6 +41,17 @@ def cached_pack(w, key, make):
     return ent[1][key]
 
 
+_ZEROS = {}
+
+
+def _zeros(n, device):
+    """shared read-only zero vector (the exactly-zero bias gradients in front of norm layers)"""
+    z = _ZEROS.get((n, device))
+    if z is None:
+        z = _ZEROS[(n, device)] = torch.zeros(n, dtype=torch.float32, device=device)
+    return z
+
+
 def _desc_key(d, xcs):
     return (d.H, d.W, d.Cin, d.Cout, d.kH, d.stride, d.pad, d.pad_mode, d.transposed, d.output_padding, d.algo, xcs)
 
@@ -116,18 +127,17 @@ class _ConvBlock(torch.autograd.Function):
         elif norm == "batch":
             dc, sums = ops.instance_norm_backward(c, dy, mrs[0], gamma, beta, relu)
             if affine:
-                dbeta, dgamma = sums[:, 0].contiguous(), sums[:, 1].contiguous()
+                dbeta, dgamma = sums.t().contiguous().unbind(0)
         else:
             dc = torch.empty_like(c)
             tot = None
             for i in range(B):
-                d_i, s_i = ops.instance_norm_backward(c[i], dy[i], mrs[i], gamma, beta, relu)
-                dc[i] = d_i
+                _, s_i = ops.instance_norm_backward(c[i], dy[i], mrs[i], gamma, beta, relu, out=dc[i])
                 tot = s_i if tot is None else tot + s_i
             if affine:
-                dbeta, dgamma = tot[:, 0].contiguous(), tot[:, 1].contiguous()
+                dbeta, dgamma = tot.t().contiguous().unbind(0)
         # a bias in front of a norm layer has an exactly zero gradient (the norm removes the channel mean)
-        db = ops.channel_sum(dc, desc.Cout) if norm is None else torch.zeros(desc.Cout, dtype=torch.float32, device=x.device)
+        db = ops.channel_sum(dc, desc.Cout) if norm is None else _zeros(desc.Cout, x.device)
         if wino_wgrad:
             dw = ops.conv2d_backward_weight_winograd(x, dc, fdesc)
         else:
@@ -137,11 +147,13 @@ class _ConvBlock(torch.autograd.Function):
         if need_dx:
             dg = ConvDataGrad(fdesc)
             dg.packed = cached_pack(w, ("dgrad",) + _desc_key(fdesc, x.shape[-1]), lambda: dg.refresh(w.detach()).packed)
-            dx = torch.stack([dg(dc[i]) for i in range(B)])
-            if dx.shape[-1] != x.shape[-1]:
-                pad = torch.zeros(x.shape, dtype=torch.float32, device=x.device)
-                pad[..., :dx.shape[-1]] = dx
-                dx = pad
+            if ops.round_up(fdesc.Cin, 4) == x.shape[-1]:
+                dx = torch.empty_like(x)
+                for i in range(B):
+                    dg(dc[i], out=dx[i])
+            else:   # x carries more channel storage than the layer reads: zero gradient there
+                dx = torch.zeros_like(x)
+                dx[..., :ops.round_up(fdesc.Cin, 4)] = torch.stack([dg(dc[i]) for i in range(B)])
         return dx, dw, db, dgamma, dbeta, (dy if ctx.needs_input_grad[5] else None), None, None, None, None, None
 
 
