@@ -20,3 +20,15 @@ def lib_built():
         import __graft_entry__
         __graft_entry__.build()
     return _lib.load()
+
+
+@pytest.fixture(autouse=True)
+def _seeded():
+    """Every test starts from the same torch / numpy global RNG state: modules built with torch's default
+    initialisers (e.g. the conv biases that vid2vid's weights_init leaves alone) are then the same in every
+    process, so a run is reproducible instead of a fresh random draw."""
+    import numpy as np
+    import torch
+    torch.manual_seed(0)
+    np.random.seed(0)
+    yield

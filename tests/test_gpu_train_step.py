@@ -31,6 +31,11 @@ def test_one_train_iteration_matches_autograd_oracle(size):
     from text2video_amd import train as T
     from text2video_amd.generator import GeneratorSpec, synthetic_state_dict
     H = W = size
+    # the discriminator's conv biases keep torch's default init (weights_init only draws the weights): seed it.
+    # Unseeded, about a third of the draws put some pre-activation of these tiny maps (8x8 bottleneck) within
+    # rounding distance of its ReLU / LeakyReLU kink, where the two fp32 implementations take different gates
+    # and single weight gradients move by 1e-2 of their scale -- a property of the comparison, not of either side
+    torch.manual_seed(0)
     if size == 64:   # 16x16 bottleneck: the ResnetBlock convs and their data gradients take the Winograd path
         from text2video_amd import ops
         assert ops.best_conv_algo(ops.conv_desc(16, 16, 128, 128, 3, 1, 1, ops.PAD_REFLECT), 128) != ops.ALGO_DIRECT
