@@ -534,8 +534,8 @@ class Vid2VidTrainer:
         loss_G_gan = gan_loss(pfg, True)
         loss_G_fm = feature_matching_loss(pfg, pr, opt.n_layers_D, opt.lambda_feat) if not opt.no_ganFeat else 0.0
         loss_G = loss_G_gan + loss_G_fm
-        def _f(t):
-            return float(t.detach()) if torch.is_tensor(t) else float(t)
+        def _f(t):   # kept on the device: one host read at the end of the step instead of a sync per loss term
+            return t.detach() if torch.is_tensor(t) else float(t)
 
         losses = {"G_GAN": _f(loss_G_gan), "G_GAN_Feat": _f(loss_G_fm), "D": _f(loss_D)}
         if self.Df is not None and face_boxes is not None:
@@ -598,6 +598,10 @@ class Vid2VidTrainer:
             self.comm_ms = 1e3 * (time.perf_counter() - t0)
         self.optG.step()
         self.optD.step()
+        keys = [k for k, v in losses.items() if torch.is_tensor(v)]
+        if keys:
+            for k, v in zip(keys, torch.stack([losses[k].reshape(()) for k in keys]).tolist()):
+                losses[k] = v
         return losses, prev
 
     def save(self, epoch_label):
