@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define T2V_ABI_VERSION 3
+#define T2V_ABI_VERSION 4
 
 typedef enum {
     T2V_OK = 0,
@@ -177,6 +177,14 @@ size_t t2v_conv_backward_weight_winograd_workspace_floats(const t2v_conv_desc* d
 int t2v_conv2d_backward_weight_winograd(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, int batch, const float* x,
                                         int x_cs, const float* dy, int dy_cs, float* dw_torch, int accumulate,
                                         float* workspace);
+/* The same in two stages, for callers that meet the images of one reduction at different times (the frames of a
+ * training clip run through the same layer one after the other, and so do their backward passes): stages & 1
+ * transforms images [b0, b0+nb) (x, dy point at image b0) into their slots of a workspace sized for `batch`
+ * images; stages & 2 reduces over all `batch` slots and writes dW.  One reduction over K = batch * tiles instead
+ * of `batch` short ones: the per-block fixed work of the 36 GEMMs and the filter transform are paid once. */
+int t2v_conv2d_backward_weight_winograd_stages(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, int batch, int b0,
+                                               int nb, const float* x, int x_cs, const float* dy, int dy_cs,
+                                               float* dw_torch, int accumulate, float* workspace, int stages);
 
 int t2v_conv_unpack_weight(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, int x_cs, const float* packed_dev,
                            float* w_torch_dev);

@@ -28,6 +28,9 @@ A = pose[..., 6:9]
 z2 = torch.zeros(F, H, W, 2, device=dev)
 def d_in(img): return torch.cat([A, img[..., :3], z2], -1).contiguous()
 def step():
+    with T.batched_weight_gradients(optG.params):
+        return _step()
+def _step():
     prev = torch.tanh(torch.randn(1, H, W, 8, device=dev)); prev[..., 6:] = 0
     fakes = []
     for f in range(F):

@@ -169,3 +169,42 @@ def test_trainer_uses_temporal_discriminators_across_chunks(tmp_path):
     assert len(tr._hist_real) == 2
     tr.save("latest")
     assert sorted(os.listdir(tmp_path / "x")) == ["latest_net_D.pth", "latest_net_D_T0.pth", "latest_net_D_T1.pth", "latest_net_G0.pth"]
+
+
+def test_trainer_batches_the_frames_winograd_weight_gradients(tmp_path, monkeypatch):
+    """The two frames of a chunk run through every ResnetBlock conv; their Winograd-domain weight gradients are
+    reduced together by the backward node that runs last (one K = 2 x tiles reduction).  Same gradients as the
+    frame-by-frame reductions (T2V_WGRAD_BATCH=0) up to fp32 summation order."""
+    from text2video_amd import train as T
+    from text2video_amd.options import TrainOptions
+    args = ["--name", "x", "--dataset_mode", "pose", "--input_nc", "3", "--openpose_only", "--no_first_img", "--ngf", "32",
+            "--n_blocks", "2", "--n_downsample_G", "2", "--num_D", "1", "--fineSize", "128", "--max_frames_per_gpu", "2",
+            "--checkpoints_dir", str(tmp_path), "--synthetic_data"]    # 32x32 bottleneck: F(4x4,3x3) territory
+    g = torch.Generator().manual_seed(0)
+    S = 128
+    pose = torch.zeros(2, S, S, 12, device="cuda:0")
+    pose[..., :9] = torch.rand(2, S, S, 9, generator=g).cuda() * 2 - 1
+    real = torch.zeros(2, S, S, 4, device="cuda:0")
+    real[..., :3] = torch.tanh(torch.randn(2, S, S, 3, generator=g)).cuda()
+    prev = torch.zeros(1, S, S, 8, device="cuda:0")
+    prev[..., :6] = torch.tanh(torch.randn(1, S, S, 6, generator=g)).cuda()
+    calls, grads = [], {}
+    orig = T._batched_winograd_wgrad
+    monkeypatch.setattr(T, "_batched_winograd_wgrad", lambda w, x, dc, d: (calls.append(x.shape[0]), orig(w, x, dc, d))[1])
+    for mode in ("1", "0"):
+        monkeypatch.setenv("T2V_WGRAD_BATCH", mode)
+        tr = T.Vid2VidTrainer(TrainOptions().parse(args), "cuda:0")
+        n0 = len(calls)
+        tr.train_step(pose, real, None, prev.clone())
+        grads[mode] = [p.grad.clone() for p in tr.optG.params]
+        if mode == "1":
+            # n_blocks 2 -> one ResnetBlock in each encoder tail + one in the trunk: 3 blocks x 2 convs, 2 frames
+            assert len(calls) - n0 == 2 * 6, "every ResnetBlock conv of both frames takes the batched path"
+            assert all(getattr(p, "_t2v_wg_state", None) is None for p in tr.optG.params), "every reduction was flushed"
+        else:
+            assert len(calls) == n0
+    worst = 0.0
+    for a, b in zip(grads["1"], grads["0"]):
+        worst = max(worst, (a - b).abs().max().item() / max(1e-12, b.abs().max().item()))
+    print("batched vs frame-by-frame weight gradients: worst relative difference %.1e" % worst)
+    assert worst <= 1e-4

@@ -556,10 +556,11 @@ size_t t2v_conv_backward_weight_winograd_workspace_floats(const t2v_conv_desc* d
     const size_t Cout_p = (size_t)round_up(d->Cout, 128), Kp = (size_t)round_up(x_cs, kBK);
     return 36 * batch * Tp * ((size_t)x_cs + d->Cout) + 36 * Cout_p * Kp;
 }
-int t2v_conv2d_backward_weight_winograd(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, int batch, const float* x,
-                                        int x_cs, const float* dy, int dy_cs, float* dw_torch, int accumulate,
-                                        float* workspace) {
-    T2V_REQUIRE(ctx && d && x && dy && dw_torch && workspace && batch >= 1, "backward_weight_winograd: bad arguments");
+int t2v_conv2d_backward_weight_winograd_stages(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, int batch, int b0,
+                                               int nb, const float* x, int x_cs, const float* dy, int dy_cs,
+                                               float* dw_torch, int accumulate, float* workspace, int stages) {
+    T2V_REQUIRE(ctx && d && workspace && batch >= 1 && b0 >= 0 && nb >= 0 && b0 + nb <= batch,
+                "backward_weight_winograd: bad arguments");
     T2V_REQUIRE(wgrad_winograd_ok(d, x_cs, dy_cs), "backward_weight_winograd: shape not supported "
                                                   "(t2v_conv_backward_weight_winograd_supported)");
     hipStream_t s = (hipStream_t)stream;
@@ -571,11 +572,16 @@ int t2v_conv2d_backward_weight_winograd(t2v_ctx* ctx, void* stream, const t2v_co
     float* dU = Md + (size_t)36 * Tt * d->Cout;
     T2V_REQUIRE((long)36 * Tt * x_cs * 4 < 0x7fff0000L && (long)36 * Tt * d->Cout * 4 < 0x7fff0000L,
                 "backward_weight_winograd: transformed tensors too large for 32-bit buffer offsets (split the batch)");
-    for (int b = 0; b < batch; ++b) {
-        T2V_TRY(launch_winograd4_input(s, x + (size_t)b * d->H * d->W * x_cs, V, d->H, d->W, x_cs, d->pad,
-                                       d->pad_mode == T2V_PAD_REFLECT, batch, b));
-        T2V_TRY(launch_winograd4_dy(s, dy + (size_t)b * Ho * Wo * dy_cs, Md, Ho, Wo, d->Cout, dy_cs, batch, b));
+    if (stages & 1) {   // transforms of images [b0, b0 + nb) into their slots of the batch-wide tile lists
+        T2V_REQUIRE(x && dy, "backward_weight_winograd: null image pointers");
+        for (int b = 0; b < nb; ++b) {
+            T2V_TRY(launch_winograd4_input(s, x + (size_t)b * d->H * d->W * x_cs, V, d->H, d->W, x_cs, d->pad,
+                                           d->pad_mode == T2V_PAD_REFLECT, batch, b0 + b));
+            T2V_TRY(launch_winograd4_dy(s, dy + (size_t)b * Ho * Wo * dy_cs, Md, Ho, Wo, d->Cout, dy_cs, batch, b0 + b));
+        }
     }
+    if (!(stages & 2)) return T2V_OK;
+    T2V_REQUIRE(dw_torch, "backward_weight_winograd: null gradient pointer");
     // 36 reductions over the tiles on the pixel-reduction GEMM: position xi = row xi of a [36][Tt] image, taken
     // by "tap" xi (input row offset xi, output row offset xi, its own output matrix)
     WgradParams w;
@@ -598,6 +604,14 @@ int t2v_conv2d_backward_weight_winograd(t2v_ctx* ctx, void* stream, const t2v_co
     w.dw_floats = (long)36 * Cout_p * Kp;
     T2V_TRY(launch_conv_wgrad(s, w));
     return launch_winograd4_dw(s, dU, dw_torch, d->Cout, d->Cin, Cout_p, Kp, accumulate);
+}
+
+int t2v_conv2d_backward_weight_winograd(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, int batch, const float* x,
+                                        int x_cs, const float* dy, int dy_cs, float* dw_torch, int accumulate,
+                                        float* workspace) {
+    T2V_REQUIRE(x && dy && dw_torch, "backward_weight_winograd: bad arguments");
+    return t2v_conv2d_backward_weight_winograd_stages(ctx, stream, d, batch, 0, batch, x, x_cs, dy, dy_cs, dw_torch,
+                                                      accumulate, workspace, 3);
 }
 
 int t2v_conv_unpack_weight(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, int x_cs, const float* packed_dev,

@@ -332,6 +332,30 @@ def conv2d_backward_weight_winograd(x, dy, desc, accumulate_into=None):
     return dw
 
 
+def backward_weight_winograd_workspace(desc, x_cs, batch, device):
+    n = _lib.load().t2v_conv_backward_weight_winograd_workspace_floats(ctypes.byref(desc), x_cs, batch)
+    if n == 0:
+        raise RuntimeError("backward_weight_winograd_workspace: shape not supported")
+    return torch.empty(n, dtype=torch.float32, device=device)
+
+
+def conv2d_backward_weight_winograd_stages(x, dy, desc, ws, batch, b0, reduce):
+    """Staged form: transform the images x, dy ([nb,H,W,C] / [nb,Ho,Wo,Cout]) into slots [b0, b0+nb) of `ws`
+    (backward_weight_winograd_workspace(desc, x_cs, batch)); with reduce=True also run the reduction over all
+    `batch` slots and return dW in torch layout, else return None."""
+    c = context()
+    if x.dim() == 3:
+        x, dy = x.unsqueeze(0), dy.unsqueeze(0)
+    _chk(x, "x")
+    _chk(dy, "dy")
+    dw = torch.empty(desc.Cout, desc.Cin, 3, 3, dtype=torch.float32, device=x.device) if reduce else None
+    check(c.lib.t2v_conv2d_backward_weight_winograd_stages(c.handle, _stream(), ctypes.byref(desc), batch, b0, x.shape[0],
+                                                           _p(x), x.shape[-1], _p(dy), dy.shape[-1], _p(dw), 0, _p(ws),
+                                                           3 if reduce else 1),
+          "conv2d_backward_weight_winograd_stages")
+    return dw
+
+
 def unpack_conv_weight(packed, desc, x_cs=None):
     """packed layout -> torch layout ([Cout,Cin,kH,kW] or [Cin,Cout,3,3])."""
     c = context()

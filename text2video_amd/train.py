@@ -12,6 +12,7 @@ generator (no flow branch), multiscale image discriminator (--num_D 2), face dis
 all-reduce.  Not built: VGG and FlowNet2-based losses / temporal discriminator (external weights that
 are not in the reference tree).
 """
+import contextlib
 import os
 import time
 
@@ -39,6 +40,46 @@ def cached_pack(w, key, make):
     if key not in ent[1]:
         ent[1][key] = make()
     return ent[1][key]
+
+
+_WG_BATCH = [False]
+
+
+@contextlib.contextmanager
+def batched_weight_gradients(params):
+    """Scope of one train step (forward and backward inside): layers that run once per frame reduce their
+    Winograd-domain weight gradients over all frames at once.  The per-weight counters are cleared on entry, so a
+    graph that was built but never back-propagated cannot leave a stale count behind.  T2V_WGRAD_BATCH=0: off."""
+    for p in params:
+        p._t2v_wg_images, p._t2v_wg_state = 0, None
+    _WG_BATCH[0] = os.environ.get("T2V_WGRAD_BATCH", "1") != "0"
+    try:
+        yield
+    finally:
+        _WG_BATCH[0] = False
+
+
+def _batched_winograd_wgrad(w, x, dc, fdesc):
+    """Weight gradient of one use of a layer whose forward counted `w._t2v_wg_images` images in this graph: the
+    images are transformed into their slots of a workspace kept on the weight; the node that brings the last ones
+    runs the single reduction over all of them and returns dW, the earlier ones return None (a zero gradient --
+    autograd sums the nodes' results).  One K = images x tiles reduction instead of one short one per frame."""
+    total = getattr(w, "_t2v_wg_images", 0)
+    if total < x.shape[0]:     # no count on this object: reduce on the spot
+        return ops.conv2d_backward_weight_winograd(x, dc, fdesc)
+    st = getattr(w, "_t2v_wg_state", None)
+    if st is None:
+        st = [ops.backward_weight_winograd_workspace(fdesc, x.shape[-1], total, x.device), 0, _desc_key(fdesc, x.shape[-1])]
+        w._t2v_wg_state = st
+    assert st[2] == _desc_key(fdesc, x.shape[-1]), "one layer, two geometries in one step: set T2V_WGRAD_BATCH=0"
+    ws, done = st[0], st[1]
+    last = done + x.shape[0] == total
+    dw = ops.conv2d_backward_weight_winograd_stages(x, dc, fdesc, ws, total, done, last)
+    if last:
+        w._t2v_wg_state, w._t2v_wg_images = None, 0
+    else:
+        st[1] = done + x.shape[0]
+    return dw
 
 
 _ZEROS = {}
@@ -111,6 +152,11 @@ class _ConvBlock(torch.autograd.Function):
         # weight gradient in the Winograd domain where the forward took F(4x4,3x3) (a quarter of the FLOPs)
         wino_wgrad = fdesc.algo == ops.ALGO_WINOGRAD_F4 and ops.backward_weight_winograd_supported(ddesc, xcs, ycs) \
             and os.environ.get("T2V_WGRAD_WINOGRAD", "1") != "0"
+        # every use of the layer in this graph (one per frame of the clip) is counted on the weight: their Winograd-
+        # domain gradients are reduced together by the last backward node to run (T2V_WGRAD_BATCH=0: one by one)
+        if wino_wgrad and w.requires_grad and _WG_BATCH[0]:
+            w._t2v_wg_images = getattr(w, "_t2v_wg_images", 0) + B
+            wino_wgrad = 2
         ctx.meta = (desc, ddesc, norm, relu, act, need_dx, mrs, gamma is not None, wino_wgrad)
         ctx.save_for_backward(x, w, c, gamma, beta, y if (norm is None and act != ops.ACT_NONE) else None)
         return y
@@ -138,7 +184,9 @@ class _ConvBlock(torch.autograd.Function):
                 dbeta, dgamma = tot.t().contiguous().unbind(0)
         # a bias in front of a norm layer has an exactly zero gradient (the norm removes the channel mean)
         db = ops.channel_sum(dc, desc.Cout) if norm is None else _zeros(desc.Cout, x.device)
-        if wino_wgrad:
+        if wino_wgrad == 2:
+            dw = _batched_winograd_wgrad(w, x, dc, fdesc)
+        elif wino_wgrad:
             dw = ops.conv2d_backward_weight_winograd(x, dc, fdesc)
         else:
             dwp = ops.conv2d_backward_weight(x, dc, fdesc)
@@ -512,6 +560,10 @@ class Vid2VidTrainer:
     def train_step(self, pose, real, face_boxes=None, prev=None):
         """pose [F,H,W,12] (sliding windows), real [F,H,W,4] NHWC on the device; face_boxes: list of
         (ys,ye,xs,xe) per frame.  Returns dict of scalar losses."""
+        with batched_weight_gradients(self.optG.params):
+            return self._train_step(pose, real, face_boxes, prev)
+
+    def _train_step(self, pose, real, face_boxes, prev):
         opt, dev = self.opt, pose.device
         F_, H, W = pose.shape[0], pose.shape[1], pose.shape[2]
         if prev is None:   # a new sequence starts
