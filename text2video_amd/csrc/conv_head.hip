@@ -79,7 +79,10 @@ __global__ __launch_bounds__(256) void conv_head7x7_kernel(const HeadParams p) {
         }
     };
 
-    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;
+    // packed fp32 FMAs (v_pk_fma_f32: two lanes of a register pair per instruction): every output channel keeps an
+    // (even, odd) input-channel pair of partial sums, so one ds_read_b128 feeds 6 packed FMAs instead of 12 scalar ones
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 acc0 = {0.f, 0.f}, acc1 = {0.f, 0.f}, acc2 = {0.f, 0.f};
     const int nchunks = p.Cin_s / CH;
     const float* __restrict__ w0 = p.w;                 // row 0 of the packed [Cout_p][Kp] weight
     const float* __restrict__ w1 = p.w + p.Kp;
@@ -101,9 +104,13 @@ __global__ __launch_bounds__(256) void conv_head7x7_kernel(const HeadParams p) {
                     const float4 a = *reinterpret_cast<const float4*>(w0 + kofs + q * 4);
                     const float4 b = *reinterpret_cast<const float4*>(w1 + kofs + q * 4);
                     const float4 c = *reinterpret_cast<const float4*>(w2 + kofs + q * 4);
-                    acc0 = fmaf(xv.x, a.x, acc0); acc0 = fmaf(xv.y, a.y, acc0); acc0 = fmaf(xv.z, a.z, acc0); acc0 = fmaf(xv.w, a.w, acc0);
-                    acc1 = fmaf(xv.x, b.x, acc1); acc1 = fmaf(xv.y, b.y, acc1); acc1 = fmaf(xv.z, b.z, acc1); acc1 = fmaf(xv.w, b.w, acc1);
-                    acc2 = fmaf(xv.x, c.x, acc2); acc2 = fmaf(xv.y, c.y, acc2); acc2 = fmaf(xv.z, c.z, acc2); acc2 = fmaf(xv.w, c.w, acc2);
+                    const f32x2 xlo = {xv.x, xv.y}, xhi = {xv.z, xv.w};
+                    acc0 = __builtin_elementwise_fma(xlo, (f32x2){a.x, a.y}, acc0);
+                    acc1 = __builtin_elementwise_fma(xlo, (f32x2){b.x, b.y}, acc1);
+                    acc2 = __builtin_elementwise_fma(xlo, (f32x2){c.x, c.y}, acc2);
+                    acc0 = __builtin_elementwise_fma(xhi, (f32x2){a.z, a.w}, acc0);
+                    acc1 = __builtin_elementwise_fma(xhi, (f32x2){b.z, b.w}, acc1);
+                    acc2 = __builtin_elementwise_fma(xhi, (f32x2){c.z, c.w}, acc2);
                 }
             }
         }
@@ -112,9 +119,9 @@ __global__ __launch_bounds__(256) void conv_head7x7_kernel(const HeadParams p) {
 
     const int oy = y0 + ty, ox = x0 + tx;
     if (oy < p.H && ox < p.W) {
-        float v0 = acc0 + (p.bias ? p.bias[0] : 0.f);
-        float v1 = acc1 + (p.bias && p.Cout > 1 ? p.bias[1] : 0.f);
-        float v2 = acc2 + (p.bias && p.Cout > 2 ? p.bias[2] : 0.f);
+        float v0 = (acc0.x + acc0.y) + (p.bias ? p.bias[0] : 0.f);
+        float v1 = (acc1.x + acc1.y) + (p.bias && p.Cout > 1 ? p.bias[1] : 0.f);
+        float v2 = (acc2.x + acc2.y) + (p.bias && p.Cout > 2 ? p.bias[2] : 0.f);
         if (p.act == T2V_ACT_TANH) {
             v0 = tanhf(v0); v1 = tanhf(v1); v2 = tanhf(v2);
         } else if (p.act == T2V_ACT_FLOW_W) {
