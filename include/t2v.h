@@ -203,6 +203,11 @@ int t2v_instance_norm_backward(t2v_ctx* ctx, void* stream, const float* x, const
 int t2v_act_backward(t2v_ctx* ctx, void* stream, const float* dy, const float* y, int act, float slope, long n,
                      float* dpre);
 int t2v_avgpool3x3s2_backward(t2v_ctx* ctx, void* stream, const float* dy, float* dx, int H, int W, int C);
+/* MaxPool2d(2,2), floor mode (torchvision vgg19 `features`, $SP/torchvision/models/vgg.py:82 cfg 'E' -- the VGG
+ * perceptual loss): x [H][W][C] -> y [H/2][W/2][C]; backward routes dy to the first maximum of
+ * each window in row-major order and writes zeros elsewhere. */
+int t2v_maxpool2x2(t2v_ctx* ctx, void* stream, const float* x, float* y, int H, int W, int C);
+int t2v_maxpool2x2_backward(t2v_ctx* ctx, void* stream, const float* x, const float* dy, float* dx, int H, int W, int C);
 /* gradients of scale*sum((x-c)^2) and scale*sum|a-b| (wrt x / a) */
 int t2v_sum_sq_diff_const_backward(t2v_ctx* ctx, void* stream, const float* x, float c, float scale, long n, float* dx);
 int t2v_sum_abs_diff_backward(t2v_ctx* ctx, void* stream, const float* a, const float* b, float scale, long n, float* da);

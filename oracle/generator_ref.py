@@ -214,6 +214,46 @@ class MultiscaleDiscriminator(nn.Module):
         return result
 
 
+class VGG19Features(nn.Module):
+    """torchvision `vgg19().features` up to relu5_1 ($SP/torchvision/models/vgg.py:82 cfg 'E': 64 64 M 128 128 M
+    256x4 M 512x4 M 512...; 3x3 convs, padding 1, ReLU; MaxPool2d(2,2)), sliced at relu1_1, relu2_1, relu3_1,
+    relu4_1, relu5_1 = features[1], [6], [11], [20], [29] [RECALL upstream models/networks.py Vgg19].  Parameter
+    names follow torchvision (features.N.weight / .bias) so its state dict loads directly."""
+
+    CFG = [64, 64, "M", 128, 128, "M", 256, 256, 256, 256, "M", 512, 512, 512, 512, "M", 512]
+    TAPS = (1, 6, 11, 20, 29)
+
+    def __init__(self):
+        super().__init__()
+        layers, cin = [], 3
+        for v in self.CFG:
+            if v == "M":
+                layers.append(nn.MaxPool2d(2, 2))
+            else:
+                layers += [nn.Conv2d(cin, v, 3, padding=1), nn.ReLU(inplace=False)]
+                cin = v
+        self.features = nn.Sequential(*layers)
+
+    def forward(self, x):
+        out = []
+        for i, m in enumerate(self.features):
+            x = m(x)
+            if i in self.TAPS:
+                out.append(x)
+        return out
+
+
+def vgg_loss_ref(vgg, fake, real):
+    """VGGLoss [RECALL upstream models/networks.py]: sum_i w_i * L1(vgg(x)_i, vgg(y)_i.detach()), weights
+    1/32, 1/16, 1/8, 1/4, 1; no input normalisation; 2x average-pool while wider than 1024."""
+    weights = (1.0 / 32, 1.0 / 16, 1.0 / 8, 1.0 / 4, 1.0)
+    while fake.shape[3] > 1024:
+        fake = F.avg_pool2d(fake, 3, 2, 1, count_include_pad=False)
+        real = F.avg_pool2d(real, 3, 2, 1, count_include_pad=False)
+    fx, fy = vgg(fake), vgg(real)
+    return sum(w * F.l1_loss(a, b.detach()) for w, a, b in zip(weights, fx, fy))
+
+
 def weights_init(m, gen):
     """vid2vid `weights_init` [RECALL]: Conv* weight ~ N(0,0.02); BatchNorm2d weight ~ N(1,0.02), bias 0."""
     name = m.__class__.__name__

@@ -12,6 +12,7 @@ ap.add_argument("--size", type=int, default=512)
 ap.add_argument("--ngf", type=int, default=128)
 ap.add_argument("--frames", type=int, default=2)
 ap.add_argument("--iters", type=int, default=3)
+ap.add_argument("--vgg", action="store_true", help="add the VGG19 perceptual loss (seeded random weights)")
 args = ap.parse_args()
 dev = "cuda:0"
 H = W = args.size
@@ -21,6 +22,7 @@ Dr = MultiscaleDiscriminator(6, 64, 3, 2, "batch")
 gen = torch.Generator().manual_seed(1); Dr.apply(lambda m: weights_init(m, gen))
 D = T.TrainableDiscriminator(6, Dr.state_dict(), 64, 3, 2, "batch", dev)
 optG, optD = T.FusedAdam(G.parameters()), T.FusedAdam(D.parameters())
+vgg = T.HipVGG19Features(T.vgg19_random_state_dict(5), dev) if args.vgg else None
 F = args.frames
 pose = torch.randn(F, H, W, 12, device=dev).clamp(-1, 1); pose[..., 9:] = 0
 real = torch.tanh(torch.randn(F, H, W, 4, device=dev)); real[..., 3] = 0
@@ -41,6 +43,8 @@ def _step():
     loss_D = 0.5 * (T.gan_loss(pfd, False) + T.gan_loss(pr, True))
     pfg = D(d_in(fake))
     loss_G = T.gan_loss(pfg, True) + T.feature_matching_loss(pfg, pr)
+    if vgg is not None:
+        loss_G = loss_G + T.vgg_loss(vgg, fake, real) * 10.0
     optG.zero_grad(); optD.zero_grad()
     gG = torch.autograd.grad(loss_G, list(G.parameters()), retain_graph=True)
     gD = torch.autograd.grad(loss_D, list(D.parameters()))

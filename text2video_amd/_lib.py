@@ -94,6 +94,8 @@ SIGNATURES = {
     "t2v_flow_warp_composite": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
                                         c_void_p, c_int, c_int]),
     "t2v_avgpool3x3s2": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int]),
+    "t2v_maxpool2x2": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int]),
+    "t2v_maxpool2x2_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int]),
     "t2v_nchw_to_nhwc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int]),
     "t2v_nhwc_to_nchw": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int]),
     "t2v_pose_u8_to_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_int]),

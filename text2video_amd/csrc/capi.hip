@@ -652,6 +652,14 @@ int t2v_avgpool3x3s2_backward(t2v_ctx* ctx, void* stream, const float* dy, float
     T2V_REQUIRE(ctx && dy && dx, "avgpool_backward: null pointer");
     return launch_avgpool3s2_backward((hipStream_t)stream, dy, dx, H, W, C);
 }
+int t2v_maxpool2x2(t2v_ctx* ctx, void* stream, const float* x, float* y, int H, int W, int C) {
+    T2V_REQUIRE(ctx && x && y && H >= 2 && W >= 2 && C >= 1, "maxpool2x2: bad arguments");
+    return launch_maxpool2x2((hipStream_t)stream, x, y, H, W, C);
+}
+int t2v_maxpool2x2_backward(t2v_ctx* ctx, void* stream, const float* x, const float* dy, float* dx, int H, int W, int C) {
+    T2V_REQUIRE(ctx && x && dy && dx && H >= 2 && W >= 2 && C >= 1, "maxpool2x2_backward: bad arguments");
+    return launch_maxpool2x2_backward((hipStream_t)stream, x, dy, dx, H, W, C);
+}
 int t2v_sum_sq_diff_const_backward(t2v_ctx* ctx, void* stream, const float* x, float c, float scale, long n, float* dx) {
     T2V_REQUIRE(ctx && x && dx && n > 0, "mse backward: bad arguments");
     return launch_loss_backward((hipStream_t)stream, 0, x, nullptr, c, scale, n, dx);

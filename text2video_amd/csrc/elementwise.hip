@@ -627,6 +627,57 @@ __global__ void avgpool3s2_backward_kernel(const float* __restrict__ dy, float* 
         dx[i] = s;
     }
 }
+// MaxPool2d(2, 2) (floor mode; VGG19): NHWC, batch folded into the row count by the caller
+__global__ void maxpool2x2_kernel(const float* __restrict__ x, float* __restrict__ y, int W, int C, int Ho, int Wo) {
+    const long total = (long)Ho * Wo * C;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int c = (int)(i % C);
+        const long pix = i / C;
+        const int ox = (int)(pix % Wo), oy = (int)(pix / Wo);
+        const float* r0 = x + ((long)(2 * oy) * W + 2 * ox) * C + c;
+        const float* r1 = r0 + (long)W * C;
+        y[i] = fmaxf(fmaxf(r0[0], r0[C]), fmaxf(r1[0], r1[C]));
+    }
+}
+// backward: the gradient goes to the first maximum of the window in row-major order (torch's scan order); rows /
+// columns past the last full window get zero
+__global__ void maxpool2x2_backward_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                           float* __restrict__ dx, int H, int W, int C, int Ho, int Wo) {
+    const long total = (long)H * W * C;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int c = (int)(i % C);
+        const long pix = i / C;
+        const int ix = (int)(pix % W), iy = (int)(pix / W);
+        const int ox = ix >> 1, oy = iy >> 1;
+        float g = 0.f;
+        if (ox < Wo && oy < Ho) {
+            const float* r0 = x + ((long)(2 * oy) * W + 2 * ox) * C + c;
+            const float* r1 = r0 + (long)W * C;
+            const float v[4] = {r0[0], r0[C], r1[0], r1[C]};
+            int arg = 0;
+#pragma unroll
+            for (int k = 1; k < 4; ++k)
+                if (v[k] > v[arg]) arg = k;
+            if (arg == ((iy & 1) * 2 + (ix & 1))) g = dy[((long)oy * Wo + ox) * C + c];
+        }
+        dx[i] = g;
+    }
+}
+int launch_maxpool2x2(hipStream_t s, const float* x, float* y, int H, int W, int C) {
+    const int Ho = H / 2, Wo = W / 2;
+    hipLaunchKernelGGL(maxpool2x2_kernel, dim3(grid_for((long)Ho * Wo * C, 256)), dim3(256), 0, s, x, y, W, C, Ho, Wo);
+    T2V_HIP_CHECK(hipGetLastError());
+    return T2V_OK;
+}
+int launch_maxpool2x2_backward(hipStream_t s, const float* x, const float* dy, float* dx, int H, int W, int C) {
+    const int Ho = H / 2, Wo = W / 2;
+    hipLaunchKernelGGL(maxpool2x2_backward_kernel, dim3(grid_for((long)H * W * C, 256)), dim3(256), 0, s, x, dy, dx, H, W,
+                       C, Ho, Wo);
+    T2V_HIP_CHECK(hipGetLastError());
+    return T2V_OK;
+}
 int launch_avgpool3s2_backward(hipStream_t s, const float* dy, float* dx, int H, int W, int C) {
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     hipLaunchKernelGGL(avgpool3s2_backward_kernel, dim3(grid_for((long)H * W * C, 256)), dim3(256), 0, s, dy, dx, H, W,

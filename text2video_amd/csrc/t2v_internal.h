@@ -115,6 +115,8 @@ int launch_inorm_backward(hipStream_t s, const float* x, const float* dy, const 
                           const float* beta, int relu, long npix, int C, float* scratch, float* dx, float* sums);
 int launch_act_backward(hipStream_t s, const float* dy, const float* y, int mode, float slope, long n, float* dpre);
 int launch_avgpool3s2_backward(hipStream_t s, const float* dy, float* dx, int H, int W, int C);
+int launch_maxpool2x2(hipStream_t s, const float* x, float* y, int H, int W, int C);
+int launch_maxpool2x2_backward(hipStream_t s, const float* x, const float* dy, float* dx, int H, int W, int C);
 int launch_loss_backward(hipStream_t s, int op, const float* a, const float* b, float c, float scale, long n, float* da);
 // Winograd tile count padded so that every transform position owns whole GEMM tiles: a multiple of 128 (128x128
 // tiles), or of 64 (forces the 64x64 tile config) when that drops at least an eighth of the rows -- e.g. the

@@ -356,6 +356,33 @@ def conv2d_backward_weight_winograd_stages(x, dy, desc, ws, batch, b0, reduce):
     return dw
 
 
+def maxpool2x2(x):
+    """MaxPool2d(2,2) on [H,W,C] or [B,H,W,C] (H even for a batch: the images are pooled as one tall image)."""
+    c = context()
+    _chk(x, "x")
+    if x.dim() == 4:
+        B, H, W, C = x.shape
+        assert H % 2 == 0, "batched maxpool2x2 needs an even height"
+        return maxpool2x2(x.reshape(B * H, W, C)).reshape(B, H // 2, W // 2, C)
+    H, W, C = x.shape
+    y = torch.empty(H // 2, W // 2, C, dtype=torch.float32, device=x.device)
+    check(c.lib.t2v_maxpool2x2(c.handle, _stream(), _p(x), _p(y), H, W, C), "maxpool2x2")
+    return y
+
+
+def maxpool2x2_backward(x, dy):
+    c = context()
+    _chk(x, "x")
+    _chk(dy, "dy")
+    if x.dim() == 4:
+        B, H, W, C = x.shape
+        return maxpool2x2_backward(x.reshape(B * H, W, C), dy.reshape(B * (H // 2), W // 2, C)).reshape(B, H, W, C)
+    H, W, C = x.shape
+    dx = torch.empty_like(x)
+    check(c.lib.t2v_maxpool2x2_backward(c.handle, _stream(), _p(x), _p(dy), _p(dx), H, W, C), "maxpool2x2_backward")
+    return dx
+
+
 def unpack_conv_weight(packed, desc, x_cs=None):
     """packed layout -> torch layout ([Cout,Cin,kH,kW] or [Cin,Cout,3,3])."""
     c = context()

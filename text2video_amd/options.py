@@ -140,6 +140,9 @@ class TrainOptions(BaseOptions):
         g("--lambda_T", type=float, default=10.0)
         g("--no_ganFeat", action="store_true")
         g("--no_vgg", action="store_true")
+        g("--vgg_weights", type=str, default="", help="torchvision vgg19 state dict (.pth) for the perceptual loss; the "
+          "reference lets torchvision download it, which this tree cannot")
+        g("--vgg_random_init", action="store_true", help="run the VGG loss path on seeded random weights (timing / tests)")
         g("--no_lsgan", action="store_true")
         g("--n_frames_D", type=int, default=3)
         g("--n_scales_temporal", type=int, default=2)

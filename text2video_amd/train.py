@@ -9,8 +9,8 @@ step.  Channel concat / crop / detach / scalar loss arithmetic stay torch-native
 Scope (what the reference's training command README.md:171-176 exercises with --openpose_only):
 generator (no flow branch), multiscale image discriminator (--num_D 2), face discriminator
 (--add_face_disc), LSGAN + feature-matching losses, Adam(lr 2e-4, beta1 0.5), data-parallel gradient
-all-reduce.  Not built: VGG and FlowNet2-based losses / temporal discriminator (external weights that
-are not in the reference tree).
+all-reduce, and the VGG19 perceptual loss (frozen torchvision weights supplied with --vgg_weights).  Not built:
+FlowNet2-based flow losses (network and weights are not in the reference tree).
 """
 import contextlib
 import os
@@ -105,14 +105,14 @@ class _ConvBlock(torch.autograd.Function):
     activation `act` (ACT_NONE / ACT_TANH / ACT_LRELU) is fused into the conv epilogue."""
 
     @staticmethod
-    def forward(ctx, x, w, b, gamma, beta, res, desc, norm, relu, act, need_dx):
+    def forward(ctx, x, w, b, gamma, beta, res, desc, norm, relu, act, need_dx, slope=0.2):
         B = x.shape[0]
         dev = x.device
         xcs = x.shape[-1]
         ho, wo = ops.conv_out_dims(desc)
         ycs = ops.round_up(desc.Cout, 4)
         fdesc = ops.conv_desc(desc.H, desc.W, desc.Cin, desc.Cout, desc.kH, desc.stride, desc.pad, desc.pad_mode,
-                              bool(desc.transposed), act if norm is None else ops.ACT_NONE, 0.2, desc.output_padding)
+                              bool(desc.transposed), act if norm is None else ops.ACT_NONE, slope, desc.output_padding)
         # 3x3 stride-1 layers (the ResnetBlock convs) run as Winograd where that is the smaller GEMM; the weight
         # gradient keeps the direct layout (ddesc)
         ddesc = fdesc
@@ -157,19 +157,19 @@ class _ConvBlock(torch.autograd.Function):
         if wino_wgrad and w.requires_grad and _WG_BATCH[0]:
             w._t2v_wg_images = getattr(w, "_t2v_wg_images", 0) + B
             wino_wgrad = 2
-        ctx.meta = (desc, ddesc, norm, relu, act, need_dx, mrs, gamma is not None, wino_wgrad)
+        ctx.meta = (desc, ddesc, norm, relu, act, need_dx, mrs, gamma is not None, wino_wgrad, slope)
         ctx.save_for_backward(x, w, c, gamma, beta, y if (norm is None and act != ops.ACT_NONE) else None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        desc, fdesc, norm, relu, act, need_dx, mrs, affine, wino_wgrad = ctx.meta
+        desc, fdesc, norm, relu, act, need_dx, mrs, affine, wino_wgrad, slope = ctx.meta
         x, w, c, gamma, beta, y_act = ctx.saved_tensors
         dy = dy.contiguous()
         B = x.shape[0]
         dgamma = dbeta = None
         if norm is None:
-            dc = ops.act_backward(dy, y_act, act, 0.2) if act != ops.ACT_NONE else dy
+            dc = ops.act_backward(dy, y_act, act, slope) if act != ops.ACT_NONE else dy
         elif norm == "batch":
             dc, sums = ops.instance_norm_backward(c, dy, mrs[0], gamma, beta, relu)
             if affine:
@@ -183,8 +183,12 @@ class _ConvBlock(torch.autograd.Function):
             if affine:
                 dbeta, dgamma = tot.t().contiguous().unbind(0)
         # a bias in front of a norm layer has an exactly zero gradient (the norm removes the channel mean)
-        db = ops.channel_sum(dc, desc.Cout) if norm is None else _zeros(desc.Cout, x.device)
-        if wino_wgrad == 2:
+        db = None
+        if ctx.needs_input_grad[2]:
+            db = ops.channel_sum(dc, desc.Cout) if norm is None else _zeros(desc.Cout, x.device)
+        if not ctx.needs_input_grad[1]:      # frozen weights (the VGG19 feature extractor): data gradient only
+            dw = None
+        elif wino_wgrad == 2:
             dw = _batched_winograd_wgrad(w, x, dc, fdesc)
         elif wino_wgrad:
             dw = ops.conv2d_backward_weight_winograd(x, dc, fdesc)
@@ -202,12 +206,13 @@ class _ConvBlock(torch.autograd.Function):
             else:   # x carries more channel storage than the layer reads: zero gradient there
                 dx = torch.zeros_like(x)
                 dx[..., :ops.round_up(fdesc.Cin, 4)] = torch.stack([dg(dc[i]) for i in range(B)])
-        return dx, dw, db, dgamma, dbeta, (dy if ctx.needs_input_grad[5] else None), None, None, None, None, None
+        return dx, dw, db, dgamma, dbeta, (dy if ctx.needs_input_grad[5] else None), None, None, None, None, None, None
 
 
 def conv_block(x, w, b, desc, gamma=None, beta=None, res=None, norm="instance", relu=1, act=ops.ACT_NONE,
-               need_dx=True):
-    return _ConvBlock.apply(x, w, b, gamma, beta, res, desc, norm, relu, act, need_dx)
+               need_dx=True, slope=0.2):
+    """slope: negative-side factor of act == ACT_LRELU (0.2 in the discriminators; 0 makes it a ReLU)."""
+    return _ConvBlock.apply(x, w, b, gamma, beta, res, desc, norm, relu, act, need_dx, slope)
 
 
 class _AvgPool(torch.autograd.Function):
@@ -370,6 +375,86 @@ class TrainableDiscriminator(torch.nn.Module):
             if i != self.num_D - 1:
                 x = _AvgPool.apply(x)
         return result
+
+
+class _MaxPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return ops.maxpool2x2(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return ops.maxpool2x2_backward(x, dy.contiguous())
+
+
+# torchvision vgg19 `features` ($SP/torchvision/models/vgg.py:82, cfg 'E'): conv indices and their widths up to
+# relu5_1; 'M' = MaxPool2d(2,2).  The five taps are relu1_1, relu2_1, relu3_1, relu4_1, relu5_1 (features[1], [6],
+# [11], [20], [29]) [RECALL upstream models/networks.py Vgg19 slices].
+VGG19_CFG = [(0, 3, 64, True), (2, 64, 64, False), "M", (5, 64, 128, True), (7, 128, 128, False), "M",
+             (10, 128, 256, True), (12, 256, 256, False), (14, 256, 256, False), (16, 256, 256, False), "M",
+             (19, 256, 512, True), (21, 512, 512, False), (23, 512, 512, False), (25, 512, 512, False), "M",
+             (28, 512, 512, True)]
+VGG_WEIGHTS = (1.0 / 32, 1.0 / 16, 1.0 / 8, 1.0 / 4, 1.0)
+
+
+def vgg19_random_state_dict(seed=0):
+    """He-initialised stand-in for torchvision's vgg19 weights (which are not in the reference tree): the same keys
+    and shapes, for tests and timing."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    sd = {}
+    for item in VGG19_CFG:
+        if item == "M":
+            continue
+        idx, cin, cout, _ = item
+        sd["features.%d.weight" % idx] = torch.from_numpy(
+            (rng.standard_normal((cout, cin, 3, 3)) * (2.0 / (9 * cin)) ** 0.5).astype(np.float32))
+        sd["features.%d.bias" % idx] = torch.from_numpy((rng.standard_normal(cout) * 0.05).astype(np.float32))
+    return sd
+
+
+class HipVGG19Features(torch.nn.Module):
+    """Frozen VGG19 feature extractor of the perceptual loss: 3x3 zero-padded convs with the
+    ReLU fused in the conv epilogue, 2x2 max-pools; forward returns the five relu*_1 maps.  Weights: a torchvision
+    `vgg19` state dict (keys features.N.weight / .bias)."""
+
+    def __init__(self, state_dict, device="cuda"):
+        super().__init__()
+        self.w = {}
+        for item in VGG19_CFG:
+            if item == "M":
+                continue
+            idx = item[0]
+            self.w[idx] = (state_dict["features.%d.weight" % idx].to(device, torch.float32).contiguous(),
+                           state_dict["features.%d.bias" % idx].to(device, torch.float32).contiguous())
+
+    def forward(self, x):
+        """x [B,H,W,cs>=3] in [-1,1] (no ImageNet normalisation, as upstream) -> [relu1_1, ..., relu5_1]."""
+        taps, cur = [], x
+        for item in VGG19_CFG:
+            if item == "M":
+                cur = _MaxPool.apply(cur)
+                continue
+            idx, cin, cout, tap = item
+            desc = ops.conv_desc(cur.shape[1], cur.shape[2], cin, cout, 3, 1, 1, ops.PAD_ZERO)
+            w, b = self.w[idx]
+            cur = conv_block(cur, w, b, desc, norm=None, relu=0, act=ops.ACT_LRELU, slope=0.0)
+            if tap:
+                taps.append(cur)
+        return taps
+
+
+def vgg_loss(vgg, fake, real):
+    """VGGLoss [RECALL upstream models/networks.py]: sum_i w_i * L1(vgg(fake)_i, vgg(real)_i.detach()),
+    w = 1/32, 1/16, 1/8, 1/4, 1; inputs above 1024 px wide are 2x average-pooled first."""
+    while fake.shape[2] > 1024:
+        fake, real = _AvgPool.apply(fake), _AvgPool.apply(real)
+    with torch.no_grad():
+        fr = vgg(real)
+    ff = vgg(fake)
+    return sum(wi * _L1.apply(a, b, a.numel()) for wi, a, b in zip(VGG_WEIGHTS, ff, fr))
 
 
 def gan_loss(pred_scales, target_is_real):
@@ -548,6 +633,17 @@ class Vid2VidTrainer:
         d_params = list(self.D.parameters()) + (list(self.Df.parameters()) if self.Df else [])
         for dt in self.DT:
             d_params += list(dt.parameters())
+        # perceptual loss (the reference trains with it: README.md:171-176 passes no --no_vgg); its weights come from
+        # torchvision's download in the reference and from --vgg_weights here
+        self.vgg = None
+        if not opt.no_vgg:
+            if getattr(opt, "vgg_weights", ""):
+                self.vgg = HipVGG19Features(torch.load(opt.vgg_weights, map_location="cpu"), device)
+            elif getattr(opt, "vgg_random_init", False):
+                self.vgg = HipVGG19Features(vgg19_random_state_dict(seed + 20), device)
+            else:
+                print("VGG loss off: no --vgg_weights <torchvision vgg19 .pth> given (the file is not in the reference "
+                      "tree; --no_vgg silences this)", flush=True)
         self.optG = FusedAdam(self.G.parameters(), opt.lr, (opt.beta1, 0.999))
         self.optD = FusedAdam(d_params, opt.lr, (opt.beta1, 0.999))
         self.comm_bytes, self.comm_ms = 0, 0.0
@@ -586,10 +682,16 @@ class Vid2VidTrainer:
         loss_G_gan = gan_loss(pfg, True)
         loss_G_fm = feature_matching_loss(pfg, pr, opt.n_layers_D, opt.lambda_feat) if not opt.no_ganFeat else 0.0
         loss_G = loss_G_gan + loss_G_fm
+        loss_G_vgg = None
+        if self.vgg is not None:   # [RECALL upstream: criterionVGG(fake_B, real_B) * lambda_feat]
+            loss_G_vgg = vgg_loss(self.vgg, fake, real) * opt.lambda_feat
+            loss_G = loss_G + loss_G_vgg
         def _f(t):   # kept on the device: one host read at the end of the step instead of a sync per loss term
             return t.detach() if torch.is_tensor(t) else float(t)
 
         losses = {"G_GAN": _f(loss_G_gan), "G_GAN_Feat": _f(loss_G_fm), "D": _f(loss_D)}
+        if loss_G_vgg is not None:
+            losses["G_VGG"] = _f(loss_G_vgg)
         if self.Df is not None and face_boxes is not None:
             def crop(t):
                 return torch.stack([t[i, b[0]:b[1], b[2]:b[3]] for i, b in enumerate(face_boxes)]).contiguous()
