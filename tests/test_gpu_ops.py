@@ -334,3 +334,24 @@ def test_winograd_zero_padding(algo, pad):
     assert (y - yd).abs().max().item() <= 2e-4 * max(1.0, ref.abs().max().item())
     assert ops.best_conv_algo(ops.conv_desc(H, W, Cin, Cout, 3, 2, 1, ops.PAD_ZERO), Cin) == ops.ALGO_DIRECT
     assert ops.best_conv_algo(ops.conv_desc(4, 4, Cin, Cout, 3, 1, 1, ops.PAD_ZERO), Cin) == ops.ALGO_DIRECT
+
+
+@pytest.mark.parametrize("slope", [0.0, 0.2], ids=["relu", "lrelu"])
+def test_winograd_f4_output_transform_applies_the_activation(slope):
+    """Convs without a norm (VGG19 loss network: conv + ReLU) keep their activation on the F(4x4,3x3) path; F(2x2)
+    and activation + statistics are refused."""
+    from text2video_amd import ops
+    H, W, Cin, Cout = 20, 36, 64, 64
+    x = _rand(Cin, H, W, seed=61)
+    w = _rand(Cout, Cin, 3, 3, seed=62, scale=0.1)
+    b = _rand(Cout, seed=63, scale=0.1)
+    ref = F.leaky_relu(F.conv2d(x.unsqueeze(0), w, b, padding=1)[0], slope)
+    desc = ops.conv_desc(H, W, Cin, Cout, 3, 1, 1, ops.PAD_ZERO, False, ops.ACT_LRELU, slope, algo=ops.ALGO_WINOGRAD_F4)
+    assert ops.winograd_supported(desc, Cin)
+    assert ops.best_conv_algo(ops.with_algo(desc, 0), Cin) == ops.ALGO_WINOGRAD_F4
+    assert not ops.winograd_supported(ops.with_algo(desc, ops.ALGO_WINOGRAD), Cin)
+    U = ops.pack_conv_weight(w.to(_dev()), desc, Cin)
+    y = ops.conv2d_auto(_to_nhwc(x), U, b.to(_dev()), desc)
+    assert (_from_nhwc(y, Cout) - ref).abs().max().item() <= 2e-4 * max(1.0, ref.abs().max().item())
+    with pytest.raises(RuntimeError):
+        ops.conv2d_auto(_to_nhwc(x), U, b.to(_dev()), desc, stats=ops.conv_stats_buffer(desc, _dev()))

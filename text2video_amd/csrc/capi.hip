@@ -165,7 +165,8 @@ bool winograd_supported(const t2v_conv_desc* d, int x_cs, int algo) {
     if (wino_out_h(d) < 1 || wino_out_w(d) < 1) return false;
     // any H, W >= 2 (reflection needs 2): ragged tiles are masked, the tile count is padded to 128
     if (d->Cin % 32 != 0 || x_cs != d->Cin || d->Cout % 4 != 0 || d->H < 2 || d->W < 2) return false;
-    return d->act == T2V_ACT_NONE;
+    // the F(4x4) output transform can apply a (Leaky)ReLU (convs without a norm: the VGG19 loss network)
+    return d->act == T2V_ACT_NONE || (algo == T2V_ALGO_WINOGRAD_F4 && d->act == T2V_ACT_LRELU);
 }
 
 // F(4x4) unless the zero tiles that pad its coarser grid to 128 make F(2x2) the smaller GEMM (tiny maps); direct
@@ -255,9 +256,14 @@ int winograd_forward(t2v_ctx* ctx, hipStream_t s, const t2v_conv_desc* d, const 
         T2V_TRY(build_winograd_gemm_plan(d, &pl));
         T2V_TRY(run_conv(ctx, s, pl, V, w_packed, nullptr, Mm, d->Cout, nullptr));
     }
-    if (stages & 4)
-        T2V_TRY((f4 ? launch_winograd4_output : launch_winograd_output)(s, Mm, bias, y, stats_partial, wino_out_h(d),
-                                                                        wino_out_w(d), d->Cout));
+    if (stages & 4) {
+        T2V_REQUIRE(d->act == T2V_ACT_NONE || !stats_partial, "winograd: an activation and norm statistics do not combine");
+        if (f4)
+            T2V_TRY(launch_winograd4_output(s, Mm, bias, y, stats_partial, wino_out_h(d), wino_out_w(d), d->Cout,
+                                            d->act == T2V_ACT_LRELU, d->act_scale));
+        else
+            T2V_TRY(launch_winograd_output(s, Mm, bias, y, stats_partial, wino_out_h(d), wino_out_w(d), d->Cout));
+    }
     return T2V_OK;
 }
 

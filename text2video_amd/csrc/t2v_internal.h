@@ -133,7 +133,8 @@ int launch_winograd4_input(hipStream_t s, const float* x, float* V, int H, int W
                            int image = 0);
 int launch_winograd4_dy(hipStream_t s, const float* dy, float* Md, int Ho, int Wo, int N, int dy_cs, int batch, int image);
 int launch_winograd4_dw(hipStream_t s, const float* dU, float* dw, int Cout, int Cin, int Cout_p, int Kp, int accumulate);
-int launch_winograd4_output(hipStream_t s, const float* Mm, const float* bias, float* y, float* stats, int H, int W, int N);
+int launch_winograd4_output(hipStream_t s, const float* Mm, const float* bias, float* y, float* stats, int H, int W, int N,
+                            int lrelu, float slope);
 int launch_channel_sum(hipStream_t s, const float* x, long npix, int C, int cs, float* scratch, float* out);
 
 // 7x7 reflect-padded head convolution with <= 3 output channels (conv_head.hip)

@@ -350,7 +350,8 @@ int launch_winograd4_input(hipStream_t s, const float* x, float* V, int H, int W
 // y = A^T M A + bias; block = 64 channels x 4 tile lanes, 8 tiles (2 per thread) = 128 output pixels
 __global__ __launch_bounds__(256) void winograd4_output_kernel(const float* __restrict__ Mm, const float* __restrict__ bias,
                                                                float* __restrict__ y, float2* __restrict__ stats, int H,
-                                                               int W, int N, int TW, int T, int Tp) {
+                                                               int W, int N, int TW, int T, int Tp, int lrelu,
+                                                               float slope) {
     __shared__ float sh[4][64];
     const int cl = threadIdx.x & 63, tl = threadIdx.x >> 6;
     const int n = blockIdx.y * 64 + cl;
@@ -381,16 +382,18 @@ __global__ __launch_bounds__(256) void winograd4_output_kernel(const float* __re
                 const int oy = 4 * ty + i2, ox = 4 * tx + j2;
                 if (tv && oy < H && ox < W) {
                     mask |= 1u << (i * 16 + i2 * 4 + j2);
-                    if (ok) y[((long)oy * W + ox) * N + n] = v;
+                    // (Leaky)ReLU of layers without a norm (the VGG19 loss network); never together with statistics
+                    if (ok) y[((long)oy * W + ox) * N + n] = (lrelu && v < 0.f) ? v * slope : v;
                 }
             }
     }
     block_stats_128(out, mask, sh, tl, cl, ok, stats, N, n);
 }
-int launch_winograd4_output(hipStream_t s, const float* Mm, const float* bias, float* y, float* stats, int H, int W, int N) {
+int launch_winograd4_output(hipStream_t s, const float* Mm, const float* bias, float* y, float* stats, int H, int W, int N,
+                            int lrelu, float slope) {
     const int TW = (W + 3) / 4, T = ((H + 3) / 4) * TW, Tp = wino_pad_tiles(T);
     hipLaunchKernelGGL(winograd4_output_kernel, dim3(Tp / 8, (N + 63) / 64), dim3(256), 0, s, Mm, bias, y,
-                       reinterpret_cast<float2*>(stats), H, W, N, TW, T, Tp);
+                       reinterpret_cast<float2*>(stats), H, W, N, TW, T, Tp, lrelu, slope);
     T2V_HIP_CHECK(hipGetLastError());
     return T2V_OK;
 }
