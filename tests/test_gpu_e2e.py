@@ -93,17 +93,32 @@ def test_train_py_on_a_real_layout_dataset(tmp_path):
             shutil.copyfile(os.path.join(src, f), root / "train_openpose" / seq / ("%04d_keypoints.json" % i))
             Image.fromarray(read_keypoints(os.path.join(src, f), (256, 192))).save(root / "train_img" / seq / ("%04d.jpg" % i))
     env = dict(os.environ, CUDA_VISIBLE_DEVICES="0")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "vid2vid", "train.py"), "--name", "fadg0", "--dataroot",
-                        "datasets/fadg0", "--dataset_mode", "pose", "--input_nc", "3", "--openpose_only", "--num_D", "2",
-                        "--resize_or_crop", "randomScaleHeight_and_scaledCrop", "--loadSize", "136", "--fineSize", "128",
-                        "--batchSize", "1", "--max_frames_per_gpu", "2", "--niter", "3", "--no_first_img",
-                        "--n_frames_total", "5", "--max_t_step", "2", "--niter_step", "100", "--add_face_disc",
-                        "--random_drop_prob", "0", "--ngf", "16", "--n_blocks", "2"],
-                       cwd=tmp_path / "vid2vid", env=env, capture_output=True, text=True, timeout=900)
+    cmd = [sys.executable, os.path.join(ROOT, "vid2vid", "train.py"), "--name", "fadg0", "--dataroot",
+           "datasets/fadg0", "--dataset_mode", "pose", "--input_nc", "3", "--openpose_only", "--num_D", "2",
+           "--resize_or_crop", "randomScaleHeight_and_scaledCrop", "--loadSize", "136", "--fineSize", "128",
+           "--batchSize", "1", "--max_frames_per_gpu", "2", "--no_first_img",
+           "--n_frames_total", "5", "--max_t_step", "2", "--niter_step", "100", "--add_face_disc",
+           "--random_drop_prob", "0", "--ngf", "16", "--n_blocks", "2"]
+    # 2 epochs at the initial learning rate + 1 of decay, one clip per sequence and epoch: 3 x 2 iterations
+    r = subprocess.run(cmd + ["--niter", "2", "--niter_decay", "1"], cwd=tmp_path / "vid2vid", env=env, capture_output=True,
+                       text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("(iter")]
-    assert len(lines) == 3 and "5 frames 128x160" in lines[0] and "D_f" in lines[0], r.stdout[-1500:]
-    assert os.path.exists(tmp_path / "vid2vid" / "checkpoints" / "fadg0" / "latest_net_G0.pth")
+    assert len(lines) == 6 and "5 frames 128x160" in lines[0] and "D_f" in lines[0], r.stdout[-1500:]
+    assert [l.split(",")[1].strip() for l in lines] == ["epoch 1"] * 2 + ["epoch 2"] * 2 + ["epoch 3"] * 2
+    assert r.stdout.count("update learning rate") == 1        # after epoch 3 (> niter)
+    ck = tmp_path / "vid2vid" / "checkpoints" / "fadg0"
+    for f in ("latest_net_G0.pth", "3_net_G0.pth", "3_net_D.pth", "3_net_D_f.pth", "iter.txt"):
+        assert os.path.exists(ck / f), f
+    assert open(ck / "iter.txt").read().split() == ["4", "0"]
+    # --continue_train: reloads the latest nets, reads iter.txt, runs the one epoch that a longer schedule adds
+    r = subprocess.run(cmd + ["--niter", "2", "--niter_decay", "2", "--continue_train"], cwd=tmp_path / "vid2vid", env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "Resuming from epoch 4 at iteration 0" in r.stdout and "not found" not in r.stdout
+    lines = [l for l in r.stdout.splitlines() if l.startswith("(iter")]
+    assert len(lines) == 2 and all("epoch 4" in l for l in lines)
+    assert os.path.exists(ck / "4_net_G0.pth")
 
 
 def test_fifo_server_serves_requests(tmp_path):

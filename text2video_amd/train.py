@@ -762,6 +762,29 @@ class Vid2VidTrainer:
                 losses[k] = v
         return losses, prev
 
+    def update_learning_rate(self, epoch):
+        """linear decay to zero over the niter_decay epochs after `niter` [RECALL upstream update_learning_rate]"""
+        lr = self.opt.lr * max(0.0, 1.0 - (epoch - self.opt.niter) / float(max(1, self.opt.niter_decay)))
+        print("update learning rate: %f -> %f" % (self.optG.lr, lr), flush=True)
+        self.optG.lr = self.optD.lr = lr
+
+    def load(self, epoch_label):
+        """--continue_train: the nets saved by save() (upstream file names); missing files keep their initialisation"""
+        import os
+        d = os.path.join(self.opt.checkpoints_dir, self.opt.name)
+        nets = [("G0", self.G), ("D", self.D)] + ([("D_f", self.Df)] if self.Df is not None else []) + \
+               [("D_T%d" % sc, dt) for sc, dt in enumerate(self.DT)]
+        for tag, net in nets:
+            path = os.path.join(d, "%s_net_%s.pth" % (epoch_label, tag))
+            if not os.path.exists(path):
+                print("continue_train: %s not found, keeping the initial weights" % path, flush=True)
+                continue
+            sd = torch.load(path, map_location="cpu")
+            with torch.no_grad():
+                for k, p in net.named_upstream_parameters().items():
+                    p.copy_(sd[k].to(p.device, torch.float32))
+                    p._t2v_packs = None
+
     def save(self, epoch_label):
         import os
         d = os.path.join(self.opt.checkpoints_dir, self.opt.name)
@@ -779,7 +802,14 @@ class Vid2VidTrainer:
 
 
 def run_train(opt, steps=None):
-    """train.py main: one process per GPU under torchrun (the reference used nn.DataParallel threads)."""
+    """train.py main: one process per GPU under torchrun (the reference used nn.DataParallel threads).
+
+    Epoch structure of upstream train.py [RECALL]: `niter` epochs at the initial learning rate + `niter_decay` epochs
+    of linear decay to zero; an epoch is one clip per training sequence (batchSize = number of ranks clips per
+    iteration); `latest` checkpoints every `save_latest_freq` samples and at every `save_epoch_freq`-th epoch end (also
+    under the epoch number), with `iter.txt` = (epoch, samples done in it) beside them; `--continue_train` reloads
+    the `which_epoch` nets, reads iter.txt and resumes there (fresh Adam moments: upstream saves none).
+    `steps` caps the total number of iterations (tests, benches)."""
     import os
     import time
     import numpy as np
@@ -789,63 +819,99 @@ def run_train(opt, steps=None):
     torch.cuda.set_device(local_rank)
     trainer = Vid2VidTrainer(opt, dev)
     F_ = opt.max_frames_per_gpu
-    steps = steps if steps is not None else opt.niter
-    t0, stats = time.perf_counter(), []
-    if getattr(opt, "synthetic_data", False):
-        H = W = opt.fineSize
-        rng = np.random.default_rng(100 + rank)          # every rank has its own sequence (batchSize = world)
-        for it in range(steps):
-            pose_np = np.where(rng.random((F_, H, W, 1)) < 0.02, rng.uniform(-1, 1, (F_, H, W, 9)), -1.0).astype(np.float32)
-            pose = torch.zeros(F_, H, W, 12, device=dev)
-            pose[..., :9] = torch.from_numpy(pose_np).to(dev)
-            real = torch.zeros(F_, H, W, 4, device=dev)
-            real[..., :3] = torch.tanh(torch.from_numpy(rng.standard_normal((F_, H, W, 3)).astype(np.float32))).to(dev)
-            side = max(8, opt.fineSize // 32 * 8)
-            boxes = [(H // 8, H // 8 + side, (W - side) // 2, (W - side) // 2 + side)] * F_ if opt.add_face_disc else None
-            ts = time.perf_counter()
-            losses, _ = trainer.train_step(pose, real, boxes)
-            torch.cuda.synchronize()
-            stats.append(time.perf_counter() - ts)
-            if rank == 0 and (it % max(1, opt.print_freq // 100) == 0 or it == steps - 1):
-                print("(iter %d, %.0f ms, all-reduce %.1f MB%s) %s" % (it, 1e3 * stats[-1], trainer.comm_bytes / 2**20,
-                                                                       ", %.1f ms exposed" % trainer.comm_ms if trainer.time_comm else "",
-                                                                       " ".join("%s: %.3f" % kv for kv in losses.items())), flush=True)
-    else:
-        # real data: <dataroot>/train_openpose + train_img.  One clip per rank per iteration (batchSize = world
-        # size), walked in chunks of max_frames_per_gpu frames with the generated frames carried over
-        # (detached) from chunk to chunk, one optimiser step per chunk -- upstream's truncated recurrence.
+    synthetic = getattr(opt, "synthetic_data", False)
+    ds = None
+    if not synthetic:
         from .pose_dataset import TrainPoseDataset
         ds = TrainPoseDataset(opt, seed=1000 + rank)
-        tG = opt.n_frames_G
-        for it in range(steps):
-            epoch = it // max(1, len(ds) // world)     # one clip per sequence and epoch
-            ds.update_training_batch(epoch // max(1, opt.niter_step))
-            clip = ds.sample(it * world + rank)
-            A = torch.from_numpy(clip["A"]).to(dev)                      # [T,H,W,3] uint8
-            B = torch.from_numpy(clip["B"]).to(dev)
-            T_, H, W = A.shape[0], A.shape[1], A.shape[2]
-            if world > 1:   # every rank must run the same number of chunks (one gradient all-reduce per chunk)
-                import torch.distributed as dist
-                tmin = torch.tensor([T_], device=dev)
-                dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
-                T_ = int(tmin.item())
-            prev, ts = None, time.perf_counter()
-            for c0 in range(tG - 1, T_, F_):
-                fr = list(range(c0, min(c0 + F_, T_)))
-                pose = torch.zeros(len(fr), H, W, 12, device=dev)
-                for j, t in enumerate(fr):
-                    for f in range(tG):                                    # window: oldest frame first
-                        ops.pose_u8_to_f32(A[t - tG + 1 + f], pose[j], 3 * f)
-                real = torch.zeros(len(fr), H, W, 4, device=dev)
-                real[..., :3] = (B[fr].float() / 255.0 - 0.5) / 0.5
-                boxes = [get_face_region(clip["A"][t], min(H, W)) for t in fr] if opt.add_face_disc else None
-                losses, prev = trainer.train_step(pose, real, boxes, prev)
+    per_epoch = 1 if synthetic else max(1, len(ds) // world)          # iterations per epoch (world clips each)
+    iter_path = os.path.join(opt.checkpoints_dir, opt.name, "iter.txt")
+    start_epoch, epoch_iter = 1, 0
+    if opt.continue_train:
+        trainer.load(opt.which_epoch)
+        try:
+            start_epoch, epoch_iter = [int(v) for v in np.loadtxt(iter_path, delimiter=",", dtype=int)]
+        except (OSError, ValueError):
+            start_epoch, epoch_iter = 1, 0
+        if rank == 0:
+            print("Resuming from epoch %d at iteration %d" % (start_epoch, epoch_iter), flush=True)
+        if start_epoch > opt.niter:
+            trainer.update_learning_rate(start_epoch - 1)
+        if ds is not None and start_epoch > opt.niter_step:
+            ds.update_training_batch((start_epoch - 1) // max(1, opt.niter_step))
+
+    def checkpoint(label, epoch, done):
+        if rank == 0:
+            trainer.save(label)
+            np.savetxt(iter_path, (epoch, done), delimiter=",", fmt="%d")
+
+    rng = np.random.default_rng(100 + rank)          # synthetic data: every rank has its own sequence
+    tG = opt.n_frames_G
+    stats, it, total_samples = [], 0, (start_epoch - 1) * per_epoch * world + epoch_iter
+    last_epoch = opt.niter + opt.niter_decay
+    for epoch in range(start_epoch, last_epoch + 1):
+        for k in range(epoch_iter // world, per_epoch):
+            if steps is not None and it >= steps:
+                break
+            ts = time.perf_counter()
+            if synthetic:
+                H = W = opt.fineSize
+                pose_np = np.where(rng.random((F_, H, W, 1)) < 0.02, rng.uniform(-1, 1, (F_, H, W, 9)), -1.0).astype(np.float32)
+                pose = torch.zeros(F_, H, W, 12, device=dev)
+                pose[..., :9] = torch.from_numpy(pose_np).to(dev)
+                real = torch.zeros(F_, H, W, 4, device=dev)
+                real[..., :3] = torch.tanh(torch.from_numpy(rng.standard_normal((F_, H, W, 3)).astype(np.float32))).to(dev)
+                side = max(8, opt.fineSize // 32 * 8)
+                boxes = [(H // 8, H // 8 + side, (W - side) // 2, (W - side) // 2 + side)] * F_ if opt.add_face_disc else None
+                losses, _ = trainer.train_step(pose, real, boxes)
+                what = ""
+            else:
+                # one clip per rank per iteration, walked in chunks of max_frames_per_gpu frames with the generated
+                # frames carried over (detached) from chunk to chunk, one optimiser step per chunk -- upstream's
+                # truncated recurrence
+                clip = ds.sample(((epoch - 1) * per_epoch + k) * world + rank)
+                A = torch.from_numpy(clip["A"]).to(dev)                      # [T,H,W,3] uint8
+                B = torch.from_numpy(clip["B"]).to(dev)
+                T_, H, W = A.shape[0], A.shape[1], A.shape[2]
+                if world > 1:   # every rank must run the same number of chunks (one gradient all-reduce per chunk)
+                    import torch.distributed as dist
+                    tmin = torch.tensor([T_], device=dev)
+                    dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
+                    T_ = int(tmin.item())
+                prev = None
+                for c0 in range(tG - 1, T_, F_):
+                    fr = list(range(c0, min(c0 + F_, T_)))
+                    pose = torch.zeros(len(fr), H, W, 12, device=dev)
+                    for j, t in enumerate(fr):
+                        for f in range(tG):                                    # window: oldest frame first
+                            ops.pose_u8_to_f32(A[t - tG + 1 + f], pose[j], 3 * f)
+                    real = torch.zeros(len(fr), H, W, 4, device=dev)
+                    real[..., :3] = (B[fr].float() / 255.0 - 0.5) / 0.5
+                    boxes = [get_face_region(clip["A"][t], min(H, W)) for t in fr] if opt.add_face_disc else None
+                    losses, prev = trainer.train_step(pose, real, boxes, prev)
+                what = ", seq %s, %d frames %dx%d step %d" % (clip["seq"], T_ - tG + 1, H, W, clip["t_step"])
             torch.cuda.synchronize()
             stats.append(time.perf_counter() - ts)
-            if rank == 0 and (it % max(1, opt.print_freq // 100) == 0 or it == steps - 1):
-                print("(iter %d, seq %s, %d frames %dx%d step %d, %.0f ms, all-reduce %.1f MB) %s"
-                      % (it, clip["seq"], T_ - tG + 1, H, W, clip["t_step"], 1e3 * stats[-1], trainer.comm_bytes / 2**20,
+            it += 1
+            total_samples += world
+            if rank == 0 and ((it - 1) % max(1, opt.print_freq // 100) == 0 or it == steps):
+                print("(iter %d, epoch %d%s, %.0f ms, all-reduce %.1f MB%s) %s"
+                      % (it - 1, epoch, what, 1e3 * stats[-1], trainer.comm_bytes / 2**20,
+                         ", %.1f ms exposed" % trainer.comm_ms if trainer.time_comm else "",
                          " ".join("%s: %.3f" % kv for kv in losses.items())), flush=True)
+            if total_samples % max(1, opt.save_latest_freq) < world:
+                checkpoint("latest", epoch, (k + 1) * world)
+        else:
+            epoch_iter = 0
+            if epoch % max(1, opt.save_epoch_freq) == 0:
+                checkpoint("latest", epoch + 1, 0)
+                checkpoint(str(epoch), epoch + 1, 0)
+            if epoch > opt.niter:
+                trainer.update_learning_rate(epoch)
+            if ds is not None and epoch % max(1, opt.niter_step) == 0:
+                ds.update_training_batch(epoch // max(1, opt.niter_step))
+            continue
+        break   # the step cap was reached
     if rank == 0:
         trainer.save("latest")
-    return {"ms_per_step": 1e3 * float(np.median(stats)), "steps": steps, "world": world}
+    return {"ms_per_step": 1e3 * float(np.median(stats)) if stats else 0.0, "steps": it, "world": world}

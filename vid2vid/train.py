@@ -8,9 +8,11 @@
         --add_face_disc --openpose_only --synthetic_data
 
 One process per GPU (the reference used nn.DataParallel over --gpu_ids; here every rank owns one
-sequence of the batch and gradients are all-reduced over RCCL).  Round 1 builds the train STEP
-(generator, multiscale + face discriminators, LSGAN + feature matching, Adam) on synthetic sequences;
-the real-data loader, VGG and FlowNet2 losses are not built.
+sequence of the batch and gradients are all-reduced over RCCL).  Built: the train step (generator,
+multiscale + face + temporal discriminators, LSGAN + feature matching + VGG19 perceptual loss, Adam), the
+real-data loader (train_openpose / train_img), the epoch schedule with learning-rate decay, periodic
+checkpoints and --continue_train; --synthetic_data runs it without a dataset.  FlowNet2-based losses are not
+built (DESIGN.md).
 """
 import os
 import sys
