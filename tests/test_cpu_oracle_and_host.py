@@ -224,3 +224,21 @@ def test_train_dataset_sampling(tmp_path):
     opt.resize_or_crop = "scaleHeight"
     p = get_train_img_params(opt, (512, 384), rng)
     assert p["new_size"] == p["crop_size"] and p["crop_pos"] == (0, 0)
+
+
+def test_oracle_vgg19_taps_match_the_references_torchvision():
+    """oracle.generator_ref.VGG19Features against taps produced by the reference's own vendored torchvision
+    vgg19 (tests/golden/make_vgg_golden.py imports it from /root/reference): same seeded weights and input."""
+    import numpy as np
+    from oracle.generator_ref import VGG19Features
+    from text2video_amd.train import vgg19_random_state_dict
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vgg19_taps.npz"))
+    net = VGG19Features().eval()
+    net.load_state_dict(vgg19_random_state_dict(int(gold["seed"])))
+    with torch.no_grad():
+        taps = net(torch.from_numpy(gold["x"]))
+    assert len(taps) == 5
+    for i, t in enumerate(taps):
+        ref = gold["tap%d" % i]
+        assert tuple(t.shape) == ref.shape
+        assert np.abs(t.numpy() - ref).max() <= 1e-6 * max(1.0, np.abs(ref).max()), i
