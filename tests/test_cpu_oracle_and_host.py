@@ -242,3 +242,18 @@ def test_oracle_vgg19_taps_match_the_references_torchvision():
         ref = gold["tap%d" % i]
         assert tuple(t.shape) == ref.shape
         assert np.abs(t.numpy() - ref).max() <= 1e-6 * max(1.0, np.abs(ref).max()), i
+
+
+def test_oracle_adam_matches_the_references_torch041_optimizer():
+    """oracle.optim_ref.adam_041_step against parameters produced by the reference's vendored torch-0.4.1 adam.py
+    (tests/golden/make_adam_golden.py): five steps with gradients from 1e-6 to 30 and a few exact zeros."""
+    import numpy as np
+    from oracle.optim_ref import adam_041_step
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "adam041.npz"))
+    p = torch.from_numpy(gold["p0"].copy())
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    for s in range(gold["grads"].shape[0]):
+        adam_041_step(p, torch.from_numpy(gold["grads"][s]), m, v, float(gold["lr"]), float(gold["beta1"]),
+                      float(gold["beta2"]), float(gold["eps"]), s + 1)
+        assert np.array_equal(p.numpy(), gold["p_after"][s]), s        # same fp32 operations in the same order
+    assert np.array_equal(m.numpy(), gold["exp_avg"]) and np.array_equal(v.numpy(), gold["exp_avg_sq"])

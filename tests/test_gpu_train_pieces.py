@@ -71,14 +71,7 @@ def test_face_discriminator_128_crop():
         assert (got[0][j][..., :w.shape[1]].permute(0, 3, 1, 2).cpu() - w).abs().max().item() <= 2e-4 * max(1.0, w.abs().max().item())
 
 
-def _adam_041(p, g, m, v, lr, b1, b2, eps, step):
-    """torch-0.4.1 Adam.step restated ($SP/torch/optim/adam.py:90-98): eps is added to sqrt(v)
-    BEFORE the bias correction is folded into the step size (modern torch adds it after)."""
-    m.mul_(b1).add_(g, alpha=1 - b1)
-    v.mul_(b2).addcmul_(g, g, value=1 - b2)
-    denom = v.sqrt().add_(eps)
-    step_size = lr * (1 - b2 ** step) ** 0.5 / (1 - b1 ** step)
-    p.addcdiv_(m, denom, value=-step_size)
+from oracle.optim_ref import adam_041_step as _adam_041   # pinned to the reference's torch-0.4.1 adam.py (tests/golden/adam041.npz)
 
 
 def test_fused_adam_matches_torch041_semantics():
@@ -94,6 +87,15 @@ def test_fused_adam_matches_torch041_semantics():
         ops.adam_step(p, gs.cuda(), m, v, 2e-4, 0.5, 0.999, 1e-8, step)
         assert (p.cpu().double() - pr).abs().max().item() <= 6e-7   # fp32 ulp of |p| < 8 is 4.8e-7
         assert (m.cpu().double() - mr).abs().max().item() <= 1e-7
+    # the golden steps of the reference's own optimiser file (gradients from 1e-6 to 30, some exact zeros)
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "adam041.npz"))
+    p = torch.from_numpy(gold["p0"].copy()).cuda()
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    for s in range(gold["grads"].shape[0]):
+        ops.adam_step(p, torch.from_numpy(gold["grads"][s]).cuda(), m, v, float(gold["lr"]), float(gold["beta1"]),
+                      float(gold["beta2"]), float(gold["eps"]), s + 1)
+        assert np.abs(p.cpu().numpy() - gold["p_after"][s]).max() <= 3e-8    # |p| < 0.25: a few fp32 ulps
+    assert np.abs(m.cpu().numpy() - gold["exp_avg"]).max() <= 1e-6 * np.abs(gold["exp_avg"]).max()
 
 
 def test_reductions_are_deterministic_and_accurate():

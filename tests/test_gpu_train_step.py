@@ -19,10 +19,7 @@ def _nhwc(x_bchw, cs):
     return out
 
 
-def _adam_041(p, g, m, v, lr, b1, b2, eps, step):
-    m.mul_(b1).add_(g, alpha=1 - b1)
-    v.mul_(b2).addcmul_(g, g, value=1 - b2)
-    p.addcdiv_(m, v.sqrt().add_(eps), value=-(lr * (1 - b2 ** step) ** 0.5 / (1 - b1 ** step)))
+from oracle.optim_ref import adam_041_step as _adam_041   # pinned to the reference's torch-0.4.1 adam.py
 
 
 @pytest.mark.parametrize("size", [32, 64], ids=["32_direct", "64_winograd"])
