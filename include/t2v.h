@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define T2V_ABI_VERSION 4
+#define T2V_ABI_VERSION 5
 
 typedef enum {
     T2V_OK = 0,
@@ -140,11 +140,24 @@ int t2v_instance_norm_apply(t2v_ctx* ctx, void* stream, const float* x, const fl
  * grid_sample functional.py:2046-2093, corner aligned, border padding) plus the blend
  * out = raw*w + warp(prev, flow)*(1-w) [SURVEY App. A.1].  fw = [H,W,3] (flow_x, flow_y in
  * pixels, weight).  prev: NHWC with storage stride prev_cs, the 3 channels starting at prev_c0.
- * warp_out (nullable) receives the warped image.
+ * warp_out (nullable) receives the warped image.  raw == NULL: plain `resample(prev, flow)` (the
+ * train step's warp losses); the warped image goes to warp_out and, if given, out.
+ *
+ * _backward replaces SpatialGridSamplerBilinear_updateGradInput (THCUNN.h:1055: gradInput AND
+ * gradGrid) fused with the blend's adjoint.  d_out: gradient of `out`, d_warp: gradient of
+ * `warp_out` (either may be NULL, not both; d_out needs raw).  Writes d_raw [H,W,4] (nullable) =
+ * d_out*w, d_fw [H,W,4] = (d flow_x, d flow_y, d weight, 0), and -- only if d_prev != NULL --
+ * ACCUMULATES the image gradient into d_prev (same layout / channels as prev; the caller zero-fills;
+ * atomic adds, so its summation order is not fixed).  Border rule as torch 0.4.1's kernel: bilinear
+ * weights from the unclipped position, corner indices clipped into the image => the gradient with
+ * respect to a coordinate is zero outside the image and exactly on its last row / column.
  * ------------------------------------------------------------------------------------------ */
 int t2v_flow_warp_composite(t2v_ctx* ctx, void* stream, const float* raw, const float* fw,
                             const float* prev, int prev_cs, int prev_c0, float* out, float* warp_out,
                             int H, int W);
+int t2v_flow_warp_composite_backward(t2v_ctx* ctx, void* stream, const float* d_out, const float* d_warp,
+                                     const float* raw, const float* fw, const float* prev, int prev_cs,
+                                     int prev_c0, float* d_raw, float* d_fw, float* d_prev, int H, int W);
 
 /* AvgPool2d(3, stride 2, padding 1, count_include_pad=False) -- SpatialAveragePooling_
  * updateOutput (THCUNN.h:579; pooling.py:536-543).  NHWC, C % 4 == 0 not required. */
@@ -199,7 +212,8 @@ int t2v_reflect_pad_backward(t2v_ctx* ctx, void* stream, const float* dxp, float
 int t2v_instance_norm_backward(t2v_ctx* ctx, void* stream, const float* x, const float* dy, const float* mean_rstd,
                                const float* gamma, const float* beta, int relu, long npix, int C, float* scratch,
                                float* dx, float* dbeta_dgamma);
-/* dpre = dy * act'(.) from the activation OUTPUT y; act: T2V_ACT_TANH, 2 = sigmoid, T2V_ACT_LRELU (slope), 0 = scale by slope */
+/* dpre = dy * act'(.) from the activation OUTPUT y; act: T2V_ACT_TANH, 2 = sigmoid, T2V_ACT_LRELU (slope), 0 = scale by slope,
+ * 4 = the fused flow / weight head (T2V_ACT_FLOW_W) on [.,4] storage: ch 0,1 scale by slope, ch 2 sigmoid, ch 3 zero */
 int t2v_act_backward(t2v_ctx* ctx, void* stream, const float* dy, const float* y, int act, float slope, long n,
                      float* dpre);
 int t2v_avgpool3x3s2_backward(t2v_ctx* ctx, void* stream, const float* dy, float* dx, int H, int W, int C);
@@ -224,8 +238,17 @@ int t2v_sum_abs_diff_backward(t2v_ctx* ctx, void* stream, const float* a, const 
  * ------------------------------------------------------------------------------------------ */
 int t2v_sum_sq_diff_const(t2v_ctx* ctx, void* stream, const float* x, float c, long n, float* scratch, float* out);
 int t2v_sum_abs_diff(t2v_ctx* ctx, void* stream, const float* a, const float* b, long n, float* scratch, float* out);
+/* sum over pixels and the channels [c0, c0+C) of mask[pix] * |a - b| on [npix][cs] tensors (b NULL: zero target; mask
+ * NULL: all ones) -- the numerator of vid2vid's MaskedL1Loss (flow, warp and weight losses; AbsCriterion THCUNN.h:18
+ * on the masked operands); _backward: da = scale * mask * sign(a - b), zero in all other channels. */
+int t2v_sum_abs_diff_masked(t2v_ctx* ctx, void* stream, const float* a, const float* b, const float* mask, long npix,
+                            int c0, int C, int cs, float* scratch, float* out);
+int t2v_sum_abs_diff_masked_backward(t2v_ctx* ctx, void* stream, const float* a, const float* b, const float* mask,
+                                     float scale, long npix, int c0, int C, int cs, float* da);
+/* lr, betas and eps are doubles, as adam.py holds them: 1-beta, the bias corrections and the step size are evaluated
+ * in double and rounded to fp32 once (adam.py:86-96 does the same through Python floats). */
 int t2v_adam_step(t2v_ctx* ctx, void* stream, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
-                  long n, float lr, float beta1, float beta2, float eps, int step);
+                  long n, double lr, double beta1, double beta2, double eps, int step);
 
 /* layout / dtype plumbing on the device */
 int t2v_nchw_to_nhwc(t2v_ctx* ctx, void* stream, const float* src, float* dst, int C, int H, int W, int dst_cs);

@@ -57,8 +57,51 @@ def _c7(i, o):
 
 
 def resample(image, flow):
-    """SURVEY App. A.1 `resample`: base grid linspace(-1,1) + flow/((W-1)/2,(H-1)/2),
-    bilinear, border padding, corner aligned."""
+    """SURVEY App. A.1 `resample`: base grid linspace(-1,1) + flow/((W-1)/2,(H-1)/2), then grid_sample(bilinear,
+    border), corner aligned -- written out the way torch 0.4.1's SpatialGridSamplerBilinear kernel evaluates it
+    (declared $SP/torch/lib/THCUNN.h:1048-1062, reached from $SP/torch/nn/functional.py:2046-2093; the .cu body is
+    not vendored: [RECALL]): un-normalise ix = ((x+1)/2)*(W-1); the four corners are floor(ix), floor(ix)+1 (same
+    in y); bilinear weights from the UNCLIPPED position; for padding 'border' the corner INDICES are clipped into
+    the image.  Autograd through this expression gives exactly that kernel's updateGradInput: gradGrid from the
+    (clipped) corner values times the weight derivatives -- zero with respect to a coordinate that lies outside
+    the image or exactly on the last row / column (both corners clip to the same pixel).  Modern
+    F.grid_sample(align_corners=True, padding_mode='border') returns the same forward values and the same
+    gradients strictly inside the image (tests/test_cpu_oracle_and_host.py pins both).  The two differ only on a
+    set of measure zero: a coordinate exactly on the border (modern torch reports a zero gradient on the first AND
+    the last row / column, this rule only on the last) or exactly on an integer position, where the bilinear
+    interpolant has a kink and either one-sided derivative is "the" gradient."""
+    b, c, h, w = image.shape
+    hor = torch.linspace(-1.0, 1.0, w).view(1, 1, 1, w).expand(b, -1, h, -1)
+    ver = torch.linspace(-1.0, 1.0, h).view(1, 1, h, 1).expand(b, -1, -1, w)
+    grid = torch.cat([hor, ver], 1)
+    flow = torch.cat([flow[:, 0:1] / ((w - 1.0) / 2.0), flow[:, 1:2] / ((h - 1.0) / 2.0)], 1)
+    final = grid + flow
+    ix = ((final[:, 0] + 1.0) / 2.0) * (w - 1)          # [b,h,w]
+    iy = ((final[:, 1] + 1.0) / 2.0) * (h - 1)
+    # Outside the image both clipped corners of an axis are the same pixel, so the value is that pixel's and the
+    # gradient with respect to that coordinate vanishes: clamping the coordinate's value (gradient cut where it
+    # was clamped) and taking corners floor, min(floor+1, last) selects the same taps with the same weights.
+    ixd, iyd = ix.detach(), iy.detach()
+    ixc, iyc = ixd.clamp(0, w - 1), iyd.clamp(0, h - 1)
+    x0, y0 = ixc.floor(), iyc.floor()
+    x1, y1 = (x0 + 1).clamp(max=w - 1), (y0 + 1).clamp(max=h - 1)
+    inx = ((ixd >= 0) & (ixd <= w - 1)).to(ix.dtype)
+    iny = ((iyd >= 0) & (iyd <= h - 1)).to(iy.dtype)
+    fx = (ixc - x0) + (ix - ixd) * inx
+    fy = (iyc - y0) + (iy - iyd) * iny
+    flat = image.reshape(b, c, h * w)
+
+    def tap(yy, xx):
+        idx = (yy * w + xx).long().reshape(b, 1, h * w).expand(-1, c, -1)
+        return flat.gather(2, idx).reshape(b, c, h, w)
+
+    wx1, wy1 = fx.unsqueeze(1), fy.unsqueeze(1)
+    wx0, wy0 = 1.0 - wx1, 1.0 - wy1
+    return tap(y0, x0) * (wx0 * wy0) + tap(y0, x1) * (wx1 * wy0) + tap(y1, x0) * (wx0 * wy1) + tap(y1, x1) * (wx1 * wy1)
+
+
+def resample_modern(image, flow):
+    """the same operation through modern torch's F.grid_sample (cross-check of `resample`)"""
     b, c, h, w = image.shape
     hor = torch.linspace(-1.0, 1.0, w).view(1, 1, 1, w).expand(b, -1, h, -1)
     ver = torch.linspace(-1.0, 1.0, h).view(1, 1, h, 1).expand(b, -1, -1, w)

@@ -257,3 +257,33 @@ def test_oracle_adam_matches_the_references_torch041_optimizer():
                       float(gold["beta2"]), float(gold["eps"]), s + 1)
         assert np.array_equal(p.numpy(), gold["p_after"][s]), s        # same fp32 operations in the same order
     assert np.array_equal(m.numpy(), gold["exp_avg"]) and np.array_equal(v.numpy(), gold["exp_avg_sq"])
+
+
+def test_oracle_resample_restatement_matches_modern_grid_sample():
+    """oracle.resample writes torch 0.4.1's grid sampler out (unclipped bilinear weights, clipped corner indices);
+    modern F.grid_sample(align_corners=True, padding_mode='border') must give the same values everywhere and the
+    same gradients wherever the sampling position is strictly inside the image and off the integer lattice."""
+    import torch
+    from oracle.generator_ref import resample, resample_modern
+    torch.manual_seed(0)
+    for (h, w, scale) in [(17, 23, 6.0), (32, 32, 0.8), (9, 40, 30.0)]:
+        img = torch.randn(2, 3, h, w, requires_grad=True)
+        flow = (torch.randn(2, 2, h, w) * scale).requires_grad_()
+        a, b = resample(img, flow), resample_modern(img, flow)
+        assert (a - b).abs().max().item() <= 2e-6
+        g = torch.randn_like(a)
+        ga = torch.autograd.grad((a * g).sum(), [img, flow])
+        gb = torch.autograd.grad((b * g).sum(), [img, flow])
+        assert (ga[0] - gb[0]).abs().max().item() <= 1e-5
+        xs = torch.arange(w).view(1, 1, w) + flow.detach()[:, 0]
+        ys = torch.arange(h).view(1, h, 1) + flow.detach()[:, 1]
+        safe = ((xs > 0.01) & (xs < w - 1.01) & (ys > 0.01) & (ys < h - 1.01)
+                & ((xs - xs.round()).abs() > 1e-3) & ((ys - ys.round()).abs() > 1e-3)).unsqueeze(1)
+        assert ((ga[1] - gb[1]).abs() * safe).max().item() <= 1e-4 * max(1.0, gb[1].abs().max().item())
+        # outside the image the coordinate's gradient is exactly zero (both clipped corners are the same pixel)
+        outx = (xs < 0) | (xs > w - 1)
+        if outx.any():
+            assert ga[1][:, 0][outx].abs().max().item() == 0.0
+    # identity flow returns the image (corner-aligned base grid), the anchor SURVEY 8c names
+    img = torch.randn(1, 3, 12, 20)
+    assert (resample(img, torch.zeros(1, 2, 12, 20)) - img).abs().max().item() <= 1e-5

@@ -96,6 +96,24 @@ def test_fused_adam_matches_torch041_semantics():
                       float(gold["beta2"]), float(gold["eps"]), s + 1)
         assert np.abs(p.cpu().numpy() - gold["p_after"][s]).max() <= 3e-8    # |p| < 0.25: a few fp32 ulps
     assert np.abs(m.cpu().numpy() - gold["exp_avg"]).max() <= 1e-6 * np.abs(gold["exp_avg"]).max()
+    # second moments too: 1 - beta2 is formed in double and rounded once, as adam.py does (0.999f would give 9.9999e-4)
+    assert np.abs(v.cpu().numpy() - gold["exp_avg_sq"]).max() <= 1e-6 * np.abs(gold["exp_avg_sq"]).max()
+
+
+def test_fused_adam_counts_steps_per_parameter():
+    """adam.py:58-60,82: state['step'] belongs to the parameter and only advances when it has a gradient."""
+    from text2video_amd import train as T
+    a = torch.nn.Parameter(torch.ones(8, device="cuda:0"))
+    b = torch.nn.Parameter(torch.ones(8, device="cuda:0"))
+    opt = T.FusedAdam([a, b], lr=1e-2)
+    g = torch.full((8,), 0.5, device="cuda:0")
+    a.grad, b.grad = g.clone(), None
+    opt.step()
+    a.grad, b.grad = g.clone(), g.clone()
+    opt.step()
+    assert opt.steps == [2, 1]
+    # b's first update is bias-corrected as step 1: exactly one lr-sized move (m/sqrt(v) = 1 after correction)
+    assert abs((1.0 - b.detach().cpu()[0].item()) - 1e-2) <= 1e-6
 
 
 def test_reductions_are_deterministic_and_accurate():
@@ -181,7 +199,7 @@ def test_trainer_batches_the_frames_winograd_weight_gradients(tmp_path, monkeypa
     from text2video_amd.options import TrainOptions
     args = ["--name", "x", "--dataset_mode", "pose", "--input_nc", "3", "--openpose_only", "--no_first_img", "--ngf", "32",
             "--n_blocks", "2", "--n_downsample_G", "2", "--num_D", "1", "--fineSize", "128", "--max_frames_per_gpu", "2",
-            "--checkpoints_dir", str(tmp_path), "--synthetic_data"]    # 32x32 bottleneck: F(4x4,3x3) territory
+            "--checkpoints_dir", str(tmp_path), "--synthetic_data", "--no_flow"]    # 32x32 bottleneck: F(4x4,3x3) territory
     g = torch.Generator().manual_seed(0)
     S = 128
     pose = torch.zeros(2, S, S, 12, device="cuda:0")

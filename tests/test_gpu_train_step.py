@@ -135,3 +135,151 @@ def test_one_train_iteration_matches_autograd_oracle(size):
         got = Gh.named_upstream_parameters()[k].detach().cpu().double()
         if g.abs().max().item() > 1e-5:
             assert (got - pr).abs().max().item() <= 2.5e-4, k    # first Adam step moves every weight by ~lr
+
+
+@pytest.mark.parametrize("size", [32, 64], ids=["32_direct", "64_winograd"])
+def test_flow_branch_train_iteration_matches_autograd_oracle(size):
+    """The generator WITH its flow branch: frame 1 raw-only (--no_first_img), frame 2 through the flow-warp
+    compositor; LSGAN + feature matching on the blended AND the raw frames, the flow / warp / weight losses against
+    a zero reference flow.  Every parameter gradient -- model_res_flow, model_up_flow, model_final_flow and
+    model_final_w included -- against torch autograd on oracle.CompositeGenerator (whose `resample` restates
+    torch 0.4.1's grid sampler), i.e. the adjoint of raw*w + warp*(1-w) into raw, weight and flow."""
+    from oracle.generator_ref import CompositeGenerator, MultiscaleDiscriminator, resample, weights_init
+    from text2video_amd import train as T
+    from text2video_amd.generator import GeneratorSpec, synthetic_state_dict
+    H = W = size
+    torch.manual_seed(0)
+    spec = GeneratorSpec(ngf=32, n_downsample=2, n_blocks=2, no_flow=False, norm="batch")
+    # flow_gain 0.1: flows of a few pixels, as a trained network predicts (a random flow head x20 throws every
+    # sample +-40 px away, where 1e-6 differences in the flow pick other taps)
+    sd = synthetic_state_dict(spec, 3, "vid2vid", flow_gain=0.1)
+    Gr = CompositeGenerator(9, 3, 6, 32, 2, 2, False, "batch").train()
+    missing = Gr.load_state_dict(sd, strict=False)
+    assert not missing.unexpected_keys and all("running_" in k or "num_batches" in k for k in missing.missing_keys)
+    Dr = MultiscaleDiscriminator(6, 16, 3, 2, "batch").train()
+    gen = torch.Generator().manual_seed(7)
+    Dr.apply(lambda m: weights_init(m, gen))
+    dsd = {k: v.clone() for k, v in Dr.state_dict().items() if "running" not in k and "num_batches" not in k}
+    poses = _rand(2, 9, H, W, seed=1).clamp(-1, 1)
+    real = torch.tanh(_rand(2, 3, H, W, seed=2))
+    real_prev = torch.cat([torch.tanh(_rand(1, 3, H, W, seed=4)), real[:1]], 0)
+    # a confidence mask with both values (the rule ||real - real_prev|| < 0.02 is all-zero on random frames)
+    conf = (torch.from_numpy(np.random.default_rng(9).random((2, 1, H, W))) < 0.7).float()
+    mse, l1 = torch.nn.MSELoss(), torch.nn.L1Loss()
+    lam_F = lam_T = 10.0
+
+    def gan(pred, real_target):
+        return sum(mse(p[-1], torch.ones_like(p[-1]) if real_target else torch.zeros_like(p[-1])) for p in pred)
+
+    def fm(pf, pr):
+        return sum(0.5 * 1.0 * l1(pf[i][j], pr[i][j].detach()) * 10.0 for i in range(2) for j in range(4))
+
+    def ml1(a, b, m):
+        m = m.expand(-1, a.shape[1], -1, -1)
+        return l1(a * m, b * m)
+
+    prev0 = torch.tanh(_rand(1, 6, H, W, seed=5))
+    o1 = Gr(poses[0:1], prev0, True)
+    prev1 = torch.cat([prev0[:, 3:], o1[0].detach()], 1)
+    o2 = Gr(poses[1:2], prev1, False)
+    fake = torch.cat([o1[0], o2[0]], 0)
+    flow = torch.cat([o1[1], o2[1]], 0)
+    weight = torch.cat([o1[2], o2[2]], 0)
+    raw = torch.cat([o1[3], o2[3]], 0)
+    assert (flow.abs().max().item() < 8.0) and (flow.abs().mean().item() > 0.05)
+    A = poses[:, 6:9]
+    pred_real = Dr(torch.cat([A, real], 1))
+    pfg, pfg_r = Dr(torch.cat([A, fake], 1)), Dr(torch.cat([A, raw], 1))
+    loss_G = gan(pfg, True) + fm(pfg, pred_real) + gan(pfg_r, True) + fm(pfg_r, pred_real)
+    fake_prev = torch.cat([prev0[:, 3:], prev1[:, 3:]], 0)
+    zero_flow = torch.zeros_like(flow)
+    loss_G = loss_G + ml1(flow, zero_flow, conf) * lam_F + ml1(resample(real_prev, flow), real, conf) * lam_T \
+        + ml1(weight, torch.zeros_like(weight), conf) + ml1(fake, resample(fake_prev, zero_flow).detach(), conf) * lam_T
+    gG = torch.autograd.grad(loss_G, list(Gr.parameters()))
+    ref_gG = {k: g for (k, _), g in zip(Gr.named_parameters(), gG)}
+
+    Gh = T.TrainableGenerator(spec, sd, "cuda:0")
+    Dh = T.TrainableDiscriminator(6, dsd, 16, 3, 2, "batch", "cuda:0")
+    pz = _nhwc(poses, 12)
+    hprev0 = _nhwc(prev0, 8)
+    h1, r1, fw1 = Gh(pz[0:1], hprev0, use_raw_only=True, full=True)
+    hprev1 = torch.zeros(1, H, W, 8, device="cuda:0")
+    hprev1[..., 0:3] = hprev0[..., 3:6]
+    hprev1[..., 3:6] = h1.detach()[..., :3]
+    h2, r2, fw2 = Gh(pz[1:2], hprev1, use_raw_only=False, full=True)
+    hfake, hraw, hfw = torch.cat([h1, h2], 0), torch.cat([r1, r2], 0), torch.cat([fw1, fw2], 0)
+    assert (hfake[..., :3].permute(0, 3, 1, 2).cpu() - fake.detach()).abs().max().item() <= 2e-4
+    assert (hfw[..., :2].permute(0, 3, 1, 2).cpu() - flow.detach()).abs().max().item() <= 2e-4
+    assert (hfw[..., 2:3].permute(0, 3, 1, 2).cpu() - weight.detach()).abs().max().item() <= 1e-4
+    A8 = _nhwc(A, 3)
+    z2 = torch.zeros(2, H, W, 2, device="cuda:0")
+
+    def d_in(img4):
+        return torch.cat([A8, img4[..., :3], z2], -1).contiguous()
+
+    hp_real = Dh(d_in(_nhwc(real, 4)))
+    hpfg, hpfg_r = Dh(d_in(hfake), frozen=True), Dh(d_in(hraw), frozen=True)
+    hloss = T.gan_loss(hpfg, True) + T.feature_matching_loss(hpfg, hp_real) + T.gan_loss(hpfg_r, True) \
+        + T.feature_matching_loss(hpfg_r, hp_real)
+    hconf = conf[:, 0].cuda().contiguous()
+    hreal, hreal_prev = _nhwc(real, 4), _nhwc(real_prev, 4)
+    hfake_prev = torch.cat([hprev0, hprev1], 0)
+    zero4 = torch.zeros(2, H, W, 4, device="cuda:0")
+    from text2video_amd import ops
+    with torch.no_grad():
+        hfpw = torch.stack([ops.flow_warp(zero4[i], hfake_prev[i], 3) for i in range(2)])
+    hloss = hloss + T.masked_l1(hfw, zero4, hconf, 2, 0) * lam_F \
+        + T.masked_l1(T._Resample.apply(hfw, hreal_prev, 0), hreal, hconf, 3) * lam_T \
+        + T.masked_l1(hfw, None, hconf, 1, 2) + T.masked_l1(hfake, hfpw, hconf, 3) * lam_T
+    assert abs(hloss.item() - loss_G.item()) <= 2e-4 * max(1, abs(loss_G.item()))
+    hgG = torch.autograd.grad(hloss, list(Gh.parameters()), allow_unused=True)
+    got = {k: g for (k, _), g in zip(Gh.named_upstream_parameters().items(), hgG)}
+    errs = {}
+    for k, r in ref_gG.items():
+        assert got[k] is not None, k
+        if r.abs().max().item() <= 1e-5:
+            continue
+        errs[k] = (got[k].cpu() - r).abs().max().item() / r.abs().max().item()
+    for prefix in ("model_res_flow", "model_up_flow", "model_final_flow", "model_final_w"):
+        ks = [k for k in errs if k.startswith(prefix) and k.endswith("weight")]
+        assert ks, prefix
+        print(prefix, "max rel err %.1e over %d tensors" % (max(errs[k] for k in ks), len(ks)))
+    top = sorted(errs.items(), key=lambda kv: -kv[1])[:4]
+    print("largest relative gradient errors:", ["%s %.1e" % kv for kv in top], "median %.1e" % float(np.median(list(errs.values()))))
+    assert max(errs.values()) <= 3e-3 and float(np.median(list(errs.values()))) <= (1e-4 if size == 32 else 4e-4)
+
+
+def test_trainer_step_with_flow_branch_runs_and_is_deterministic():
+    """Vid2VidTrainer.train_step with the flow branch on (the README recipe passes no --no_flow): all loss terms
+    appear and are finite, the flow-branch parameters move, and two runs from the same state give the same losses."""
+    from text2video_amd import train as T
+    from text2video_amd.options import TrainOptions
+    opt = TrainOptions().parse(["--name", "t", "--dataset_mode", "pose", "--input_nc", "3", "--openpose_only", "--ngf", "16",
+                                "--n_downsample_G", "2", "--n_blocks", "2", "--num_D", "2", "--ndf", "16", "--no_vgg",
+                                "--max_frames_per_gpu", "2", "--n_scales_temporal", "0", "--no_first_img", "--add_face_disc"])
+    assert not opt.no_flow
+    H = W = 64
+    rng = np.random.default_rng(0)
+    pose = torch.zeros(2, H, W, 12, device="cuda:0")
+    pose[..., :9] = torch.from_numpy(rng.uniform(-1, 1, (2, H, W, 9)).astype(np.float32)).cuda()
+    real = torch.zeros(2, H, W, 4, device="cuda:0")
+    real[..., :3] = torch.tanh(torch.from_numpy(rng.standard_normal((2, H, W, 3)).astype(np.float32))).cuda()
+    real_prev = torch.cat([real[1:], real[:1]], 0).contiguous()
+    real_prev[0, :, : W // 2] = real[0, :, : W // 2]       # a region where the zero reference flow is "confident"
+    boxes = [(8, 40, 16, 48)] * 2
+    runs = []
+    for _ in range(2):
+        tr = T.Vid2VidTrainer(opt, "cuda:0", seed=5)
+        before = {k: v.detach().clone() for k, v in tr.G.named_upstream_parameters().items()}
+        l1, prev = tr.train_step(pose, real, boxes, None, real_prev=real_prev)
+        l2, _ = tr.train_step(pose, real, boxes, prev, real_prev=real_prev)
+        for name in ("G_GAN", "G_GAN_Feat", "D", "F_Flow", "F_Warp", "W", "G_Warp", "G_f_GAN", "D_f"):
+            assert name in l1 and np.isfinite(l1[name]), name
+        assert l1["W"] > 0 and l1["F_Warp"] > 0
+        moved = {k: (v.detach() - before[k]).abs().max().item() for k, v in tr.G.named_upstream_parameters().items()}
+        for prefix in ("model_res_flow", "model_up_flow", "model_final_flow", "model_final_w"):
+            assert max(v for k, v in moved.items() if k.startswith(prefix)) > 0, prefix
+        runs.append((l1, l2))
+    for a, b in zip(runs[0], runs[1]):
+        for k in a:
+            assert a[k] == b[k], (k, a[k], b[k])

@@ -6,7 +6,7 @@ expected symbols, importing/using it raises.  Build it with `python __graft_entr
 """
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_long, c_size_t, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_long, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libt2v_hip.so")
@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libt2v_hip.so")
 T2V_OK = 0
 PAD_ZERO, PAD_REFLECT = 0, 1
 ACT_NONE, ACT_TANH, ACT_FLOW_W, ACT_LRELU = 0, 1, 2, 3
-ABI_VERSION = 4
+ABI_VERSION = 5
 ALGO_DIRECT, ALGO_WINOGRAD, ALGO_WINOGRAD_F4 = 0, 1, 2
 
 
@@ -87,12 +87,18 @@ SIGNATURES = {
     "t2v_sum_abs_diff_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_long, c_void_p]),
     "t2v_sum_sq_diff_const": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_long, c_void_p, c_void_p]),
     "t2v_sum_abs_diff": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_void_p]),
-    "t2v_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_float, c_float,
-                              c_float, c_float, c_int]),
+    "t2v_sum_abs_diff_masked": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_int,
+                                        c_void_p, c_void_p]),
+    "t2v_sum_abs_diff_masked_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_long, c_int,
+                                                 c_int, c_int, c_void_p]),
+    "t2v_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_double, c_double,
+                              c_double, c_double, c_int]),
     "t2v_instance_norm_apply": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_void_p, c_long, c_int, c_int]),
     "t2v_flow_warp_composite": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
                                         c_void_p, c_int, c_int]),
+    "t2v_flow_warp_composite_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                 c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int]),
     "t2v_avgpool3x3s2": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int]),
     "t2v_maxpool2x2": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int]),
     "t2v_maxpool2x2_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int]),

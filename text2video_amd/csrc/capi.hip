@@ -683,8 +683,20 @@ int t2v_sum_abs_diff(t2v_ctx* ctx, void* stream, const float* a, const float* b,
     T2V_REQUIRE(ctx && a && b && scratch && out && n > 0, "sum_abs_diff: bad arguments");
     return launch_reduce((hipStream_t)stream, 1, a, b, 0.f, n, scratch, out);
 }
+int t2v_sum_abs_diff_masked(t2v_ctx* ctx, void* stream, const float* a, const float* b, const float* mask, long npix,
+                            int c0, int C, int cs, float* scratch, float* out) {
+    T2V_REQUIRE(ctx && a && scratch && out && npix > 0 && c0 >= 0 && C > 0 && cs >= c0 + C,
+                "sum_abs_diff_masked: bad arguments");
+    return launch_masked_l1((hipStream_t)stream, a, b, mask, npix, c0, C, cs, scratch, out);
+}
+int t2v_sum_abs_diff_masked_backward(t2v_ctx* ctx, void* stream, const float* a, const float* b, const float* mask,
+                                     float scale, long npix, int c0, int C, int cs, float* da) {
+    T2V_REQUIRE(ctx && a && da && npix > 0 && c0 >= 0 && C > 0 && cs >= c0 + C,
+                "sum_abs_diff_masked_backward: bad arguments");
+    return launch_masked_l1_backward((hipStream_t)stream, a, b, mask, scale, npix, c0, C, cs, da);
+}
 int t2v_adam_step(t2v_ctx* ctx, void* stream, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
-                  long n, float lr, float beta1, float beta2, float eps, int step) {
+                  long n, double lr, double beta1, double beta2, double eps, int step) {
     T2V_REQUIRE(ctx && param && grad && exp_avg && exp_avg_sq && n > 0 && step >= 1, "adam_step: bad arguments");
     return launch_adam((hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, step);
 }
@@ -699,9 +711,21 @@ int t2v_instance_norm_apply(t2v_ctx* ctx, void* stream, const float* x, const fl
 
 int t2v_flow_warp_composite(t2v_ctx* ctx, void* stream, const float* raw, const float* fw, const float* prev,
                             int prev_cs, int prev_c0, float* out, float* warp_out, int H, int W) {
-    T2V_REQUIRE(ctx && raw && fw && prev && out, "flow_warp_composite: null pointer");
+    T2V_REQUIRE(ctx && fw && prev && (out || warp_out), "flow_warp_composite: null pointer");
+    T2V_REQUIRE(raw == nullptr || out != nullptr, "flow_warp_composite: raw without out");
     T2V_REQUIRE(H > 1 && W > 1, "flow_warp_composite: H,W must be > 1");
+    T2V_REQUIRE(prev_c0 >= 0 && prev_c0 + 3 <= prev_cs, "flow_warp_composite: prev_c0 + 3 > prev_cs");
     return launch_warp_composite((hipStream_t)stream, raw, fw, prev, prev_cs, prev_c0, out, warp_out, H, W);
+}
+int t2v_flow_warp_composite_backward(t2v_ctx* ctx, void* stream, const float* d_out, const float* d_warp,
+                                     const float* raw, const float* fw, const float* prev, int prev_cs, int prev_c0,
+                                     float* d_raw, float* d_fw, float* d_prev, int H, int W) {
+    T2V_REQUIRE(ctx && fw && prev && d_fw && (d_out || d_warp), "flow_warp_composite_backward: null pointer");
+    T2V_REQUIRE(d_out == nullptr || raw != nullptr, "flow_warp_composite_backward: d_out needs raw (the blend's operands)");
+    T2V_REQUIRE(H > 1 && W > 1, "flow_warp_composite_backward: H,W must be > 1");
+    T2V_REQUIRE(prev_c0 >= 0 && prev_c0 + 3 <= prev_cs, "flow_warp_composite_backward: prev_c0 + 3 > prev_cs");
+    return launch_warp_composite_backward((hipStream_t)stream, d_out, d_warp, raw, fw, prev, prev_cs, prev_c0, d_raw,
+                                          d_fw, d_prev, H, W);
 }
 
 int t2v_avgpool3x3s2(t2v_ctx* ctx, void* stream, const float* x, float* y, int H, int W, int C) {

@@ -279,6 +279,53 @@ __global__ __launch_bounds__(256) void reduce_final_kernel(const float* __restri
     const float t = block_sum(s, sh);
     if (threadIdx.x == 0) out[0] = t;
 }
+// sum over pixels and the channels [c0, c0+C) of mask[pix] * |a - b|  (b == nullptr: 0; mask == nullptr: 1):
+// MaskedL1Loss of the flow / warp / weight losses, numerator only
+__global__ __launch_bounds__(256) void reduce_masked_l1_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                               const float* __restrict__ mask, long npix, int c0, int C,
+                                                               int cs, float* __restrict__ part) {
+    __shared__ float sh[4];
+    float s = 0.f;
+    const long n = npix * cs, stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const long pix = i / cs;
+        if ((unsigned)((int)(i - pix * cs) - c0) < (unsigned)C) {
+            const float d = fabsf(a[i] - (b ? b[i] : 0.f));
+            s += mask ? mask[pix] * d : d;
+        }
+    }
+    const float t = block_sum(s, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+__global__ void masked_l1_backward_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                          const float* __restrict__ mask, float scale, long npix, int c0, int C,
+                                          int cs, float* __restrict__ da) {
+    const long n = npix * cs, stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const long pix = i / cs;
+        float g = 0.f;
+        if ((unsigned)((int)(i - pix * cs) - c0) < (unsigned)C) {
+            const float d = a[i] - (b ? b[i] : 0.f);
+            g = (d > 0.f ? scale : (d < 0.f ? -scale : 0.f)) * (mask ? mask[pix] : 1.f);
+        }
+        da[i] = g;
+    }
+}
+int launch_masked_l1(hipStream_t s, const float* a, const float* b, const float* mask, long npix, int c0, int C, int cs,
+                     float* scratch, float* out) {
+    const int g = grid_for(npix * cs, 256);
+    hipLaunchKernelGGL(reduce_masked_l1_kernel, dim3(g), dim3(256), 0, s, a, b, mask, npix, c0, C, cs, scratch);
+    hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(256), 0, s, scratch, g, out);
+    T2V_HIP_CHECK(hipGetLastError());
+    return T2V_OK;
+}
+int launch_masked_l1_backward(hipStream_t s, const float* a, const float* b, const float* mask, float scale, long npix,
+                              int c0, int C, int cs, float* da) {
+    hipLaunchKernelGGL(masked_l1_backward_kernel, dim3(grid_for(npix * cs, 256)), dim3(256), 0, s, a, b, mask, scale,
+                       npix, c0, C, cs, da);
+    T2V_HIP_CHECK(hipGetLastError());
+    return T2V_OK;
+}
 int launch_reduce(hipStream_t s, int op, const float* a, const float* b, float c, long n, float* scratch, float* out) {
     const int g = grid_for(n, 256);
     if (op == 0)
@@ -292,22 +339,26 @@ int launch_reduce(hipStream_t s, int op, const float* a, const float* b, float c
 
 // torch.optim.Adam.step ($SP/torch/optim/adam.py:86-98), same operation order
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                            float* __restrict__ v, long n, float b1, float b2, float eps, float step_size) {
+                            float* __restrict__ v, long n, float b1, float b2, float omb1, float omb2, float eps,
+                            float step_size) {
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const float gi = g[i];
-        const float mi = m[i] * b1 + (1.f - b1) * gi;
-        const float vi = v[i] * b2 + (1.f - b2) * gi * gi;
+        const float mi = m[i] * b1 + omb1 * gi;
+        const float vi = v[i] * b2 + omb2 * gi * gi;
         m[i] = mi;
         v[i] = vi;
         p[i] = p[i] - step_size * (mi / (sqrtf(vi) + eps));
     }
 }
-int launch_adam(hipStream_t s, float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2,
-                float eps, int step) {
-    const double bc1 = 1.0 - pow((double)b1, step), bc2 = 1.0 - pow((double)b2, step);
-    const float step_size = (float)((double)lr * sqrt(bc2) / bc1);
-    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, p, g, m, v, n, b1, b2, eps, step_size);
+int launch_adam(hipStream_t s, float* p, const float* g, float* m, float* v, long n, double lr, double b1, double b2,
+                double eps, int step) {
+    // adam.py:86-96 evaluates 1 - beta, the bias corrections and step_size in Python doubles and hands each to a
+    // float op once: the betas arrive here as doubles for the same reason (0.999f != 0.999)
+    const double bc1 = 1.0 - pow(b1, step), bc2 = 1.0 - pow(b2, step);
+    const float step_size = (float)(lr * sqrt(bc2) / bc1);
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, p, g, m, v, n, (float)b1, (float)b2,
+                       (float)(1.0 - b1), (float)(1.0 - b2), (float)eps, step_size);
     T2V_HIP_CHECK(hipGetLastError());
     return T2V_OK;
 }
@@ -585,7 +636,7 @@ int launch_inorm_backward(hipStream_t s, const float* x, const float* dy, const 
     return T2V_OK;
 }
 
-// activation backward from the OUTPUT y: tanh' = 1-y^2 ; sigmoid' = y(1-y) ; leaky: y>0 ? 1 : slope ; scale: slope
+// activation backward from the OUTPUT y: tanh' = 1-y^2 ; sigmoid' = y(1-y) ; leaky: y>0 ? 1 : slope ; 4: flow/weight head ; scale: slope
 __global__ void act_backward_kernel(const float* __restrict__ dy, const float* __restrict__ y, int mode, float slope,
                                     long n, float* __restrict__ dpre) {
     const long stride = (long)gridDim.x * blockDim.x;
@@ -595,7 +646,10 @@ __global__ void act_backward_kernel(const float* __restrict__ dy, const float* _
         if (mode == 1) d = g * (1.f - v * v);
         else if (mode == 2) d = g * v * (1.f - v);
         else if (mode == 3) d = v > 0.f ? g : g * slope;
-        else d = g * slope;
+        else if (mode == 4) {   // T2V_ACT_FLOW_W on [.,4] storage: ch 0,1 = flow * slope, ch 2 = sigmoid, ch 3 unused
+            const int c = (int)(i & 3);
+            d = c < 2 ? g * slope : (c == 2 ? g * v * (1.f - v) : 0.f);
+        } else d = g * slope;
         dpre[i] = d;
     }
 }
@@ -881,6 +935,22 @@ int launch_to_u8(hipStream_t s, const float* x, uint8_t* y, long n) {
 // formulation (normalised grid, then un-normalise) so fp32 rounding tracks the oracle.
 // raw/out: [H,W,4]; fw: [H,W,4] = (flow_x, flow_y, weight, 0).
 // ---------------------------------------------------------------------------------------------
+// sampling position of output pixel (x, y): pixel coordinates BEFORE the border clamp
+struct WarpPos { float px, py; };
+__device__ __forceinline__ WarpPos warp_position(int x, int y, int H, int W, float flow_x, float flow_y) {
+    const float sx = (float)(W - 1) / 2.0f, sy = (float)(H - 1) / 2.0f;
+    // torch.linspace(-1,1,n): start + i*step for the lower half, end - (n-1-i)*step above
+    const float stepx = 2.0f / (float)(W - 1), stepy = 2.0f / (float)(H - 1);
+    const float gx0 = x < W / 2 ? -1.0f + stepx * (float)x : 1.0f - stepx * (float)(W - 1 - x);
+    const float gy0 = y < H / 2 ? -1.0f + stepy * (float)y : 1.0f - stepy * (float)(H - 1 - y);
+    const float gx = gx0 + flow_x / sx, gy = gy0 + flow_y / sy;
+    WarpPos p;
+    p.px = ((gx + 1.0f) / 2.0f) * (float)(W - 1);
+    p.py = ((gy + 1.0f) / 2.0f) * (float)(H - 1);
+    return p;
+}
+
+// raw == nullptr: plain resample (out, if given, receives the warped image as well)
 __global__ __launch_bounds__(256) void warp_composite_kernel(const float4* __restrict__ raw,
                                                              const float4* __restrict__ fw,
                                                              const float* __restrict__ prev, int prev_cs,
@@ -888,19 +958,12 @@ __global__ __launch_bounds__(256) void warp_composite_kernel(const float4* __res
                                                              float4* __restrict__ warp_out, int H, int W) {
     const long npix = (long)H * W;
     const long stride = (long)gridDim.x * blockDim.x;
-    const float sx = (float)(W - 1) / 2.0f, sy = (float)(H - 1) / 2.0f;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += stride) {
         const int y = (int)(i / W), x = (int)(i - (long)y * W);
         const float4 f = fw[i];
-        // torch.linspace(-1,1,n): start + i*step for the lower half, end - (n-1-i)*step above
-        const float stepx = 2.0f / (float)(W - 1), stepy = 2.0f / (float)(H - 1);
-        const float gx0 = x < W / 2 ? -1.0f + stepx * (float)x : 1.0f - stepx * (float)(W - 1 - x);
-        const float gy0 = y < H / 2 ? -1.0f + stepy * (float)y : 1.0f - stepy * (float)(H - 1 - y);
-        const float gx = gx0 + f.x / sx, gy = gy0 + f.y / sy;
-        float px = ((gx + 1.0f) / 2.0f) * (float)(W - 1);
-        float py = ((gy + 1.0f) / 2.0f) * (float)(H - 1);
-        px = fminf(fmaxf(px, 0.f), (float)(W - 1));  // padding_mode='border'
-        py = fminf(fmaxf(py, 0.f), (float)(H - 1));
+        const WarpPos wp = warp_position(x, y, H, W, f.x, f.y);
+        const float px = fminf(fmaxf(wp.px, 0.f), (float)(W - 1));  // padding_mode='border'
+        const float py = fminf(fmaxf(wp.py, 0.f), (float)(H - 1));
         const float fx0 = floorf(px), fy0 = floorf(py);
         const int x0 = (int)fx0, y0 = (int)fy0;
         const int x1 = x0 + 1, y1 = y0 + 1;
@@ -917,10 +980,14 @@ __global__ __launch_bounds__(256) void warp_composite_kernel(const float4* __res
             if (okx && oky) v += pc[((long)y1 * W + x1) * prev_cs] * w11;
             wv[c] = v;
         }
-        const float4 r = raw[i];
-        const float wt = f.z;
-        out[i] = make_float4(r.x * wt + wv[0] * (1.0f - wt), r.y * wt + wv[1] * (1.0f - wt),
-                             r.z * wt + wv[2] * (1.0f - wt), 0.f);
+        if (raw) {
+            const float4 r = raw[i];
+            const float wt = f.z;
+            out[i] = make_float4(r.x * wt + wv[0] * (1.0f - wt), r.y * wt + wv[1] * (1.0f - wt),
+                                 r.z * wt + wv[2] * (1.0f - wt), 0.f);
+        } else if (out) {
+            out[i] = make_float4(wv[0], wv[1], wv[2], 0.f);
+        }
         if (warp_out) warp_out[i] = make_float4(wv[0], wv[1], wv[2], 0.f);
     }
 }
@@ -929,6 +996,75 @@ int launch_warp_composite(hipStream_t s, const float* raw, const float* fw, cons
     hipLaunchKernelGGL(warp_composite_kernel, dim3(grid_for((long)H * W, 256)), dim3(256), 0, s,
                        reinterpret_cast<const float4*>(raw), reinterpret_cast<const float4*>(fw), prev, prev_cs,
                        prev_c0, reinterpret_cast<float4*>(out), reinterpret_cast<float4*>(warp_out), H, W);
+    T2V_HIP_CHECK(hipGetLastError());
+    return T2V_OK;
+}
+
+// Adjoint of the compositor (SpatialGridSamplerBilinear_updateGradInput, THCUNN.h:1055, fused with the blend's
+// adjoint).  With g_c = d_out_c*(1-w) + d_warp_c the gradient that reaches the warped image:
+//   d_raw_c  = d_out_c * w                       d_w = sum_c d_out_c * (raw_c - warp_c)
+//   d_flow_x = sum_c g_c * [wy0*(v10-v00) + wy1*(v11-v01)]_c      (d px / d flow_x = 1: pixel-unit flow)
+//   d_flow_y = sum_c g_c * [wx0*(v01-v00) + wx1*(v11-v10)]_c
+//   d_prev   : g_c * (w00, w10, w01, w11) scattered onto the four taps (atomicAdd; only on request)
+// Border rule of torch 0.4.1's kernel: bilinear weights from the unclipped position, the four corner INDICES clipped
+// into the image -- so outside the image (and exactly on the last row / column, where both corners clip to the
+// same pixel) the gradient with respect to that coordinate is zero.  The warp value itself is re-computed (12 taps
+// from a 3-channel image that sits in L2) rather than saved by the forward pass.
+__global__ __launch_bounds__(256) void warp_composite_backward_kernel(
+    const float4* __restrict__ d_out, const float4* __restrict__ d_warp, const float4* __restrict__ raw,
+    const float4* __restrict__ fw, const float* __restrict__ prev, int prev_cs, int prev_c0,
+    float4* __restrict__ d_raw, float4* __restrict__ d_fw, float* __restrict__ d_prev, int H, int W) {
+    const long npix = (long)H * W;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += stride) {
+        const int y = (int)(i / W), x = (int)(i - (long)y * W);
+        const float4 f = fw[i];
+        const WarpPos wp = warp_position(x, y, H, W, f.x, f.y);
+        const bool inx = wp.px >= 0.f && wp.px <= (float)(W - 1), iny = wp.py >= 0.f && wp.py <= (float)(H - 1);
+        const float px = fminf(fmaxf(wp.px, 0.f), (float)(W - 1));
+        const float py = fminf(fmaxf(wp.py, 0.f), (float)(H - 1));
+        const float fx0 = floorf(px), fy0 = floorf(py);
+        const int x0 = (int)fx0, y0 = (int)fy0;
+        const int x1 = min(x0 + 1, W - 1), y1 = min(y0 + 1, H - 1);   // clipped corner indices
+        const float wx1 = px - fx0, wy1 = py - fy0, wx0 = 1.0f - wx1, wy0 = 1.0f - wy1;
+        const float4 go = d_out ? d_out[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 gw = d_warp ? d_warp[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float wt = d_out ? f.z : 0.f;
+        const float gout[3] = {go.x, go.y, go.z};
+        const float g[3] = {go.x * (1.0f - wt) + gw.x, go.y * (1.0f - wt) + gw.y, go.z * (1.0f - wt) + gw.z};
+        float rawv[3] = {0.f, 0.f, 0.f};
+        if (raw) {
+            const float4 r = raw[i];
+            rawv[0] = r.x; rawv[1] = r.y; rawv[2] = r.z;
+        }
+        const long o00 = ((long)y0 * W + x0) * prev_cs + prev_c0, o10 = ((long)y0 * W + x1) * prev_cs + prev_c0;
+        const long o01 = ((long)y1 * W + x0) * prev_cs + prev_c0, o11 = ((long)y1 * W + x1) * prev_cs + prev_c0;
+        float gfx = 0.f, gfy = 0.f, gwt = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float v00 = prev[o00 + c], v10 = prev[o10 + c], v01 = prev[o01 + c], v11 = prev[o11 + c];
+            const float warp = v00 * (wx0 * wy0) + v10 * (wx1 * wy0) + v01 * (wx0 * wy1) + v11 * (wx1 * wy1);
+            gfx += g[c] * (wy0 * (v10 - v00) + wy1 * (v11 - v01));
+            gfy += g[c] * (wx0 * (v01 - v00) + wx1 * (v11 - v10));
+            gwt += gout[c] * (rawv[c] - warp);
+            if (d_prev) {
+                atomicAdd(d_prev + o00 + c, g[c] * (wx0 * wy0));
+                atomicAdd(d_prev + o10 + c, g[c] * (wx1 * wy0));
+                atomicAdd(d_prev + o01 + c, g[c] * (wx0 * wy1));
+                atomicAdd(d_prev + o11 + c, g[c] * (wx1 * wy1));
+            }
+        }
+        if (d_raw) d_raw[i] = make_float4(go.x * wt, go.y * wt, go.z * wt, 0.f);
+        d_fw[i] = make_float4(inx ? gfx : 0.f, iny ? gfy : 0.f, d_out ? gwt : 0.f, 0.f);
+    }
+}
+int launch_warp_composite_backward(hipStream_t s, const float* d_out, const float* d_warp, const float* raw,
+                                   const float* fw, const float* prev, int prev_cs, int prev_c0, float* d_raw,
+                                   float* d_fw, float* d_prev, int H, int W) {
+    hipLaunchKernelGGL(warp_composite_backward_kernel, dim3(grid_for((long)H * W, 256)), dim3(256), 0, s,
+                       reinterpret_cast<const float4*>(d_out), reinterpret_cast<const float4*>(d_warp),
+                       reinterpret_cast<const float4*>(raw), reinterpret_cast<const float4*>(fw), prev, prev_cs,
+                       prev_c0, reinterpret_cast<float4*>(d_raw), reinterpret_cast<float4*>(d_fw), d_prev, H, W);
     T2V_HIP_CHECK(hipGetLastError());
     return T2V_OK;
 }

@@ -187,11 +187,18 @@ void convT_phase_taps_host(int phase, int k, int pad, int* ntaps, int kh[4], int
 int launch_nchw_to_nhwc(hipStream_t s, const float* src, float* dst, int C, int H, int W, int Cs);
 int launch_nhwc_to_nchw(hipStream_t s, const float* src, float* dst, int C, int H, int W, int Cs);
 int launch_reduce(hipStream_t s, int op, const float* a, const float* b, float c, long n, float* scratch, float* out);
-int launch_adam(hipStream_t s, float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2,
-                float eps, int step);
+int launch_adam(hipStream_t s, float* p, const float* g, float* m, float* v, long n, double lr, double b1, double b2,
+                double eps, int step);
+int launch_masked_l1(hipStream_t s, const float* a, const float* b, const float* mask, long npix, int c0, int C, int cs,
+                     float* scratch, float* out);
+int launch_masked_l1_backward(hipStream_t s, const float* a, const float* b, const float* mask, float scale, long npix,
+                              int c0, int C, int cs, float* da);
 int launch_add(hipStream_t s, const float* a, const float* b, float* y, long n);
 int launch_warp_composite(hipStream_t s, const float* raw, const float* fw, const float* prev, int prev_cs,
                           int prev_c0, float* out, float* warp_out, int H, int W);
+int launch_warp_composite_backward(hipStream_t s, const float* d_out, const float* d_warp, const float* raw,
+                                   const float* fw, const float* prev, int prev_cs, int prev_c0, float* d_raw,
+                                   float* d_fw, float* d_prev, int H, int W);
 int launch_avgpool3s2(hipStream_t s, const float* x, float* y, int H, int W, int C);
 int launch_to_u8(hipStream_t s, const float* x, uint8_t* y, long n);
 int launch_u8_pose_to_f32(hipStream_t s, const uint8_t* src, float* dst, long npix, int Cs, int c0);

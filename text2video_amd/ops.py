@@ -171,15 +171,39 @@ def conv_norm_act(x, packed_w, bias, desc, gamma=None, beta=None, relu=True, res
     return instance_norm_apply(y, mr, gamma, beta, res1, res2, relu, out=y)
 
 
-def flow_warp_composite(raw, fw, prev, prev_c0, want_warp=False):
+def flow_warp_composite(raw, fw, prev, prev_c0, want_warp=False, out=None):
     """raw,fw: [H,W,4]; prev: [H,W,prev_cs] (3 channels from prev_c0).  out = raw*w + warp*(1-w)."""
     c = context()
     H, W = raw.shape[0], raw.shape[1]
-    out = torch.empty_like(raw)
+    out = torch.empty_like(raw) if out is None else out
     warp = torch.empty_like(raw) if want_warp else None
     check(c.lib.t2v_flow_warp_composite(c.handle, _stream(), _p(raw), _p(fw), _p(prev), prev.shape[-1], prev_c0,
                                         _p(out), _p(warp), H, W), "flow_warp_composite")
     return (out, warp) if want_warp else out
+
+
+def flow_warp(fw, img, c0=0, out=None):
+    """resample(img[..., c0:c0+3], flow): fw [H,W,4] (flow_x, flow_y in pixels; channel 2 ignored) -> [H,W,4]."""
+    c = context()
+    H, W = fw.shape[0], fw.shape[1]
+    out = torch.empty(H, W, 4, dtype=torch.float32, device=fw.device) if out is None else out
+    check(c.lib.t2v_flow_warp_composite(c.handle, _stream(), None, _p(fw), _p(img), img.shape[-1], c0, None, _p(out),
+                                        H, W), "flow_warp")
+    return out
+
+
+def flow_warp_composite_backward(d_out, d_warp, raw, fw, prev, prev_c0, want_d_prev=False):
+    """Adjoint of flow_warp_composite / flow_warp.  d_out, d_warp: [H,W,4] or None (not both); raw may be None when
+    d_out is.  Returns (d_raw | None, d_fw [H,W,4] = (d flow_x, d flow_y, d weight, 0), d_prev | None)."""
+    c = context()
+    H, W = fw.shape[0], fw.shape[1]
+    d_raw = torch.empty_like(fw) if d_out is not None else None
+    d_fw = torch.empty_like(fw)
+    d_prev = torch.zeros_like(prev) if want_d_prev else None
+    check(c.lib.t2v_flow_warp_composite_backward(c.handle, _stream(), _p(d_out), _p(d_warp), _p(raw), _p(fw), _p(prev),
+                                                 prev.shape[-1], prev_c0, _p(d_raw), _p(d_fw), _p(d_prev), H, W),
+          "flow_warp_composite_backward")
+    return d_raw, d_fw, d_prev
 
 
 def avgpool3x3s2(x):
@@ -280,6 +304,25 @@ def sum_abs_diff(a, b):
     check(c.lib.t2v_sum_abs_diff(c.handle, _stream(), _p(a), _p(b), a.numel(), _p(_reduce_scratch(a.device)), _p(out)),
           "sum_abs_diff")
     return out
+
+
+def sum_abs_diff_masked(a, b, mask, c0, C):
+    """sum over pixels and the channels [c0, c0+C) of mask[pix] * |a - b| ([..., cs] tensors; b / mask may be None)."""
+    c = context()
+    cs = a.shape[-1]
+    out = torch.empty(1, dtype=torch.float32, device=a.device)
+    check(c.lib.t2v_sum_abs_diff_masked(c.handle, _stream(), _p(a), _p(b), _p(mask), a.numel() // cs, c0, C, cs,
+                                        _p(_reduce_scratch(a.device)), _p(out)), "sum_abs_diff_masked")
+    return out
+
+
+def sum_abs_diff_masked_backward(a, b, mask, c0, C, scale):
+    c = context()
+    cs = a.shape[-1]
+    da = torch.empty_like(a)
+    check(c.lib.t2v_sum_abs_diff_masked_backward(c.handle, _stream(), _p(a), _p(b), _p(mask), float(scale),
+                                                 a.numel() // cs, c0, C, cs, _p(da)), "sum_abs_diff_masked_backward")
+    return da
 
 
 def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step):

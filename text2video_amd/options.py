@@ -77,10 +77,12 @@ class BaseOptions:
         opt.gpu_ids = [int(i) for i in str(opt.gpu_ids).split(",") if i.strip() != "" and int(i) >= 0]
         # CUDA_VISIBLE_DEVICES from the reference's shell is honoured by the ROCm runtime as well
         # (HIP reads CUDA_VISIBLE_DEVICES when HIP_VISIBLE_DEVICES is unset): nothing to translate.
-        # upstream very likely forces no_flow for --openpose_only (recollection): treat it as the
-        # default, but let a checkpoint that carries a flow branch override it (create_model)
+        # Inference: whether --openpose_only implies no_flow upstream is a recollection; it is the default
+        # here, and a checkpoint that carries a flow branch overrides it (create_model).  Training follows the
+        # explicit flag only: the reference's recipe (README.md:171-176) passes --openpose_only without --no_flow,
+        # and north_star names the flow-warp compositor as part of the generator.
         opt.no_flow_explicit = bool(opt.no_flow)
-        if opt.openpose_only:
+        if opt.openpose_only and not self.is_train:
             opt.no_flow = True
         if save:
             d = os.path.join(opt.checkpoints_dir, opt.name)

@@ -6,11 +6,14 @@ weight-gradient kernel, norm backward, ...).  Tensors are NHWC fp32 on the devic
 torch-layout fp32 `nn.Parameter`s (upstream state-dict names) that are re-packed for the kernels each
 step.  Channel concat / crop / detach / scalar loss arithmetic stay torch-native plumbing.
 
-Scope (what the reference's training command README.md:171-176 exercises with --openpose_only):
-generator (no flow branch), multiscale image discriminator (--num_D 2), face discriminator
-(--add_face_disc), LSGAN + feature-matching losses, Adam(lr 2e-4, beta1 0.5), data-parallel gradient
-all-reduce, and the VGG19 perceptual loss (frozen torchvision weights supplied with --vgg_weights).  Not built:
-FlowNet2-based flow losses (network and weights are not in the reference tree).
+Scope (what the reference's training command README.md:171-176 exercises): generator WITH its flow branch
+(flow / weight heads, flow-warp compositor: every loss on the blended frame back-propagates through
+raw*w + warp*(1-w) into flow, weight and raw -- `_WarpComposite`), or without it (--no_flow), multiscale image
+discriminator (--num_D 2), face discriminator (--add_face_disc), temporal discriminators, LSGAN +
+feature-matching losses, the VGG19 perceptual loss (frozen torchvision weights supplied with --vgg_weights), the
+flow / warp / weight losses against a SUPPLIED reference flow (zero flow + its confidence mask by default:
+FlowNet2, which produces it upstream, is not in the reference tree -- SURVEY 8d config 5), Adam(lr 2e-4,
+beta1 0.5), data-parallel gradient all-reduce.
 """
 import contextlib
 import os
@@ -33,6 +36,7 @@ def cached_pack(w, key, make):
     backward).  T2V_TRAIN_PACK_CACHE=0 re-packs per call (saves the memory of the transformed copies)."""
     if os.environ.get("T2V_TRAIN_PACK_CACHE", "1") == "0":
         return make()
+    w = getattr(w, "_t2v_owner", w)    # a detached view of a parameter (frozen passes) shares its parameter's cache
     ent = getattr(w, "_t2v_packs", None)
     if ent is None or ent[0] != w._version:
         ent = (w._version, {})
@@ -173,7 +177,8 @@ class _ConvBlock(torch.autograd.Function):
         B = x.shape[0]
         dgamma = dbeta = None
         if norm is None:
-            dc = ops.act_backward(dy, y_act, act, slope) if act != ops.ACT_NONE else dy
+            # (act_backward's mode 2 is a plain sigmoid; the fused flow / weight head is its mode 4)
+            dc = ops.act_backward(dy, y_act, 4 if act == ops.ACT_FLOW_W else act, slope) if act != ops.ACT_NONE else dy
         elif norm == "batch":
             dc, sums = ops.instance_norm_backward(c, dy, mrs[0], gamma, beta, relu)
             if affine:
@@ -266,15 +271,91 @@ class _L1(torch.autograd.Function):
         return ops.sum_abs_diff_backward(a.contiguous(), b.contiguous(), 1.0 / ctx.n) * g, None, None
 
 
+class _WarpComposite(torch.autograd.Function):
+    """out = raw*w + resample(prev[..., c0:c0+3], flow)*(1-w) on [B,H,W,4] tensors; fw = (flow_x, flow_y, w, 0).
+    Backward: t2v_flow_warp_composite_backward (SpatialGridSamplerBilinear_updateGradInput, THCUNN.h:1055, fused
+    with the blend's adjoint); the gradient with respect to `prev` only when autograd asks for it (the generated
+    previous frames are detached: max_frames_backpropagate 1)."""
+
+    @staticmethod
+    def forward(ctx, raw, fw, prev, c0):
+        ctx.c0 = c0
+        ctx.save_for_backward(raw, fw, prev)
+        out = torch.empty_like(raw)
+        for i in range(raw.shape[0]):
+            ops.flow_warp_composite(raw[i], fw[i], prev[i], c0, out=out[i])
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        raw, fw, prev = ctx.saved_tensors
+        dy = dy.contiguous()
+        res = [ops.flow_warp_composite_backward(dy[i], None, raw[i], fw[i], prev[i], ctx.c0, ctx.needs_input_grad[2])
+               for i in range(raw.shape[0])]
+        d_raw = torch.stack([r[0] for r in res]) if len(res) > 1 else res[0][0].unsqueeze(0)
+        d_fw = torch.stack([r[1] for r in res]) if len(res) > 1 else res[0][1].unsqueeze(0)
+        d_prev = None
+        if ctx.needs_input_grad[2]:
+            d_prev = torch.stack([r[2] for r in res])
+        return d_raw, d_fw, d_prev, None
+
+
+class _Resample(torch.autograd.Function):
+    """resample(img[..., c0:c0+3], flow) -> [B,H,W,4]: the warp losses' plain grid_sample (same kernels, no blend)."""
+
+    @staticmethod
+    def forward(ctx, fw, img, c0):
+        ctx.c0 = c0
+        ctx.save_for_backward(fw, img)
+        out = torch.empty(fw.shape[:3] + (4,), dtype=torch.float32, device=fw.device)
+        for i in range(fw.shape[0]):
+            ops.flow_warp(fw[i], img[i], c0, out=out[i])
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        fw, img = ctx.saved_tensors
+        dy = dy.contiguous()
+        res = [ops.flow_warp_composite_backward(None, dy[i], None, fw[i], img[i], ctx.c0, ctx.needs_input_grad[1])
+               for i in range(fw.shape[0])]
+        d_fw = torch.stack([r[1] for r in res])
+        d_img = torch.stack([r[2] for r in res]) if ctx.needs_input_grad[1] else None
+        return d_fw, d_img, None
+
+
+class _MaskedL1(torch.autograd.Function):
+    """vid2vid's MaskedL1Loss [RECALL upstream models/networks.py]: L1Loss(a*mask, b*mask), mean over ALL B*C*H*W
+    elements; a, b: [B,H,W,cs] (b None: zero target), mask: [B,H,W] of {0,1} or None, over the channels
+    [c0, c0+C) (the flow / weight planes of the fused head are read in place).  Gradient to `a` only."""
+
+    @staticmethod
+    def forward(ctx, a, b, mask, c0, C):
+        a = a.contiguous()
+        ctx.cw = (c0, C)
+        ctx.n = (a.numel() // a.shape[-1]) * C
+        ctx.save_for_backward(a, b, mask)
+        return ops.sum_abs_diff_masked(a, b, mask, c0, C)[0] / ctx.n
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b, mask = ctx.saved_tensors
+        return ops.sum_abs_diff_masked_backward(a, b, mask, ctx.cw[0], ctx.cw[1], 1.0 / ctx.n) * g, None, None, None, None
+
+
+def masked_l1(a, b, mask, C, c0=0):
+    return _MaskedL1.apply(a, b.detach().contiguous() if b is not None else None,
+                           mask.contiguous() if mask is not None else None, c0, C)
+
+
 # ------------------------------------------------------------------------------------------------
 # networks
 # ------------------------------------------------------------------------------------------------
 class TrainableGenerator(torch.nn.Module):
-    """CompositeGenerator without flow branch (what --openpose_only trains), upstream parameter names."""
+    """CompositeGenerator with or without its flow branch, upstream parameter names."""
 
     def __init__(self, spec, state_dict, device="cuda"):
         super().__init__()
-        assert spec.no_flow and not spec.is_local, "train step: global generator without flow branch"
+        assert not spec.is_local, "train step: the global generator (n_scales_spatial 1)"
         self.spec = spec
         self.keys = layer_keys(spec)
         self.params = torch.nn.ParameterDict()
@@ -287,8 +368,11 @@ class TrainableGenerator(torch.nn.Module):
     def named_upstream_parameters(self):
         return {k.replace("/", "."): v for k, v in self.params.items()}
 
-    def forward(self, pose, prev):
-        """pose [1,H,W,12], prev [1,H,W,8] NHWC -> fake [1,H,W,4] (tanh RGB in channels 0..2)."""
+    def forward(self, pose, prev, use_raw_only=False, full=False):
+        """pose [1,H,W,12], prev [1,H,W,8] NHWC -> fake [1,H,W,4] (RGB in channels 0..2).  full=True returns
+        (fake, raw, flow_w): raw = the tanh image before the blend, flow_w [1,H,W,4] = (flow_x, flow_y in pixels,
+        weight, 0); both None without a flow branch.  use_raw_only: the first frame of a sequence under
+        --no_first_img (fake is raw; flow and weight are still computed, the flow losses see them)."""
         s = self.spec
         n, G = s.n_downsample, s.ngf
         H, W = pose.shape[1], pose.shape[2]
@@ -316,15 +400,30 @@ class TrainableGenerator(torch.nn.Module):
                 h = cna(t, d, relu=0, res=h)
             return h
 
+        def decoder(h):
+            for i in range(n):
+                l = n - i
+                h = cna(h, ops.conv_desc(H >> l, W >> l, G << l, G << (l - 1), 3, 2, 1, ops.PAD_ZERO, True))
+            return h
+
         nb_enc, nb_res = s.n_blocks - s.n_blocks // 2, s.n_blocks // 2
         d = encoder(pose, s.input_nc, nb_enc) + encoder(prev, s.prev_nc, nb_enc)
-        h = resblocks(d, nb_res)
-        for i in range(n):
-            l = n - i
-            h = cna(h, ops.conv_desc(H >> l, W >> l, G << l, G << (l - 1), 3, 2, 1, ops.PAD_ZERO, True))
+        img_feat = decoder(resblocks(d, nb_res))
         ck, _, _ = next(it)
-        return conv_block(h, self.p(ck + ".weight"), self.p(ck + ".bias"),
-                          ops.conv_desc(H, W, G, 3, 7, 1, 3, ops.PAD_REFLECT), norm=None, relu=0, act=ops.ACT_TANH)
+        raw = conv_block(img_feat, self.p(ck + ".weight"), self.p(ck + ".bias"),
+                         ops.conv_desc(H, W, G, 3, 7, 1, 3, ops.PAD_REFLECT), norm=None, relu=0, act=ops.ACT_TANH)
+        if s.no_flow:
+            return (raw, None, None) if full else raw
+        flow_feat = decoder(resblocks(d, nb_res))
+        (kf, kw), _, _ = next(it)
+        # model_final_flow (2 outputs, x20) and model_final_w (1 output, sigmoid) read the same features: one
+        # 3-output conv, as in the inference path; autograd's cat splits the gradient back onto the two parameters
+        w3 = torch.cat([self.p(kf + ".weight"), self.p(kw + ".weight")], 0)
+        b3 = torch.cat([self.p(kf + ".bias"), self.p(kw + ".bias")], 0)
+        fw = conv_block(flow_feat, w3, b3, ops.conv_desc(H, W, G, 3, 7, 1, 3, ops.PAD_REFLECT), norm=None, relu=0,
+                        act=ops.ACT_FLOW_W, slope=20.0 * (2 ** s.scale))
+        fake = raw if use_raw_only else _WarpComposite.apply(raw, fw, prev, s.prev_nc - 3)
+        return (fake, raw, fw) if full else fake
 
 
 class TrainableDiscriminator(torch.nn.Module):
@@ -340,9 +439,15 @@ class TrainableDiscriminator(torch.nn.Module):
                 continue
             self.params[k.replace(".", "/")] = torch.nn.Parameter(v.to(device, torch.float32).contiguous())
         self.ndfs = [min(ndf * 2 ** (num_D - 1 - i), 64) for i in range(num_D)]
+        self._frozen = False
 
     def p(self, key):
-        return self.params[key.replace(".", "/")]
+        t = self.params[key.replace(".", "/")]
+        if not self._frozen:
+            return t
+        d = t.detach()
+        d._t2v_owner = t
+        return d
 
     def named_upstream_parameters(self):
         return {k.replace("/", "."): v for k, v in self.params.items()}
@@ -371,14 +476,20 @@ class TrainableDiscriminator(torch.nn.Module):
             feats.append(cur)
         return feats
 
-    def forward(self, x):
-        """x [B,H,W,cs] -> result[i] = stage outputs of the i-th finest scale."""
-        result = []
-        for i in range(self.num_D):
-            result.append(self._single(x, self.num_D - 1 - i))
-            if i != self.num_D - 1:
-                x = _AvgPool.apply(x)
-        return result
+    def forward(self, x, frozen=False):
+        """x [B,H,W,cs] -> result[i] = stage outputs of the i-th finest scale.  frozen=True: the parameters enter
+        detached (the generator-side passes: only the data gradient is wanted, so the backward nodes skip the
+        weight-gradient kernels; the packed-weight cache is keyed on the parameter either way)."""
+        self._frozen = frozen
+        try:
+            result = []
+            for i in range(self.num_D):
+                result.append(self._single(x, self.num_D - 1 - i))
+                if i != self.num_D - 1:
+                    x = _AvgPool.apply(x)
+            return result
+        finally:
+            self._frozen = False
 
 
 class _MaxPool(torch.autograd.Function):
@@ -479,24 +590,28 @@ def feature_matching_loss(pred_fake, pred_real, n_layers=3, lambda_feat=10.0):
 # optimiser + data-parallel gradient exchange
 # ------------------------------------------------------------------------------------------------
 class FusedAdam:
-    """torch-0.4.1 Adam semantics ($SP/torch/optim/adam.py:48-98), one fused HIP kernel per tensor."""
+    """torch-0.4.1 Adam semantics ($SP/torch/optim/adam.py:48-98), one fused HIP kernel per tensor.  As there,
+    `state['step']` is per parameter and only advances when that parameter has a gradient (adam.py:58-60, 82): a
+    discriminator that sits out the first iterations (temporal windows not yet full, no face box) starts its bias
+    correction at 1 when it first trains."""
 
     def __init__(self, params, lr=2e-4, betas=(0.5, 0.999), eps=1e-8):
         self.params = [p for p in params]
-        self.lr, self.betas, self.eps, self.step_no = lr, betas, eps, 0
+        self.lr, self.betas, self.eps = lr, betas, eps
         self.m = [torch.zeros_like(p) for p in self.params]
         self.v = [torch.zeros_like(p) for p in self.params]
+        self.steps = [0] * len(self.params)
 
     def zero_grad(self):
         for p in self.params:
             p.grad = None
 
     def step(self):
-        self.step_no += 1
-        for p, m, v in zip(self.params, self.m, self.v):
+        for i, (p, m, v) in enumerate(zip(self.params, self.m, self.v)):
             if p.grad is not None:
+                self.steps[i] += 1
                 ops.adam_step(p.data, p.grad.contiguous(), m, v, self.lr, self.betas[0], self.betas[1], self.eps,
-                              self.step_no)
+                              self.steps[i])
                 p._t2v_packs = None   # written through the raw pointer: no tensor version bump
 
 
@@ -607,11 +722,8 @@ class Vid2VidTrainer:
         self.opt, self.device = opt, device
         input_nc = opt.label_nc if opt.label_nc != 0 else opt.input_nc
         self.spec = GeneratorSpec(input_nc=input_nc * opt.n_frames_G, prev_nc=(opt.n_frames_G - 1) * opt.output_nc,
-                                  ngf=opt.ngf, n_downsample=opt.n_downsample_G, n_blocks=opt.n_blocks, no_flow=True,
-                                  norm=opt.norm)
-        if not opt.no_flow:
-            raise NotImplementedError("train step covers the --openpose_only / --no_flow generator; the flow branch "
-                                      "needs FlowNet2 ground truth that is not in the reference tree")
+                                  ngf=opt.ngf, n_downsample=opt.n_downsample_G, n_blocks=opt.n_blocks,
+                                  no_flow=bool(opt.no_flow), norm=opt.norm)
         self.G = TrainableGenerator(self.spec, synthetic_state_dict(self.spec, seed, "vid2vid"), device)
         d_in = input_nc + opt.output_nc
         self.D = TrainableDiscriminator(d_in, discriminator_state_dict(d_in, opt.ndf, opt.n_layers_D, opt.num_D, opt.norm,
@@ -657,38 +769,65 @@ class Vid2VidTrainer:
         z = torch.zeros(A3.shape[:-1] + (2,), dtype=torch.float32, device=A3.device)
         return torch.cat([A3, img4[..., :3], z], -1).contiguous()
 
-    def train_step(self, pose, real, face_boxes=None, prev=None):
+    def train_step(self, pose, real, face_boxes=None, prev=None, real_prev=None, flow_ref=None, conf_ref=None):
         """pose [F,H,W,12] (sliding windows), real [F,H,W,4] NHWC on the device; face_boxes: list of
-        (ys,ye,xs,xe) per frame.  Returns dict of scalar losses."""
+        (ys,ye,xs,xe) per frame; prev: the carried FIFO of generated frames (None: a new sequence starts).
+        With the flow branch: real_prev [F,H,W,4] = the real frame before each frame enables the flow / warp
+        losses against flow_ref [F,H,W,4] (flow_x, flow_y in pixels; default zero flow) and its confidence mask
+        conf_ref [F,H,W] (default: ||real - resample(real_prev, flow_ref)|| < 0.02, the rule upstream's FlowNet2
+        wrapper applies [RECALL]).  Returns (dict of scalar losses, FIFO for the next chunk)."""
         with batched_weight_gradients(self.optG.params):
-            return self._train_step(pose, real, face_boxes, prev)
+            return self._train_step(pose, real, face_boxes, prev, real_prev, flow_ref, conf_ref)
 
-    def _train_step(self, pose, real, face_boxes, prev):
+    def _train_step(self, pose, real, face_boxes, prev, real_prev=None, flow_ref=None, conf_ref=None):
         opt, dev = self.opt, pose.device
         F_, H, W = pose.shape[0], pose.shape[1], pose.shape[2]
-        if prev is None:   # a new sequence starts
+        flow_on = not self.spec.no_flow
+        first = prev is None
+        if first:   # a new sequence starts: zero previous frames, raw-only first frame (--no_first_img)
             prev = torch.zeros(1, H, W, ops.round_up(self.spec.prev_nc, 4), dtype=torch.float32, device=dev)
             self._hist_real, self._hist_fake = [], []
-        fakes = []
+        fakes, raws, fws, prevs = [], [], [], []
         for f in range(F_):
-            fk = self.G(pose[f:f + 1], prev)
+            fk, rw, fw = self.G(pose[f:f + 1], prev, use_raw_only=first and f == 0, full=True)
             fakes.append(fk)
+            raws.append(rw)
+            fws.append(fw)
+            prevs.append(prev)
             nprev = torch.zeros_like(prev)
             nprev[..., :3] = prev[..., 3:6]
             nprev[..., 3:6] = fk.detach()[..., :3]
             prev = nprev
         fake = torch.cat(fakes, 0)
         A3 = pose[..., 6:9]
+        # compute_loss_D(netD, real_A, real_B, fake) [RECALL upstream Vid2VidModelD]: real pass, fake pass on the
+        # detached frame (D's loss), fake pass for G's GAN + feature-matching loss.  The generator-side passes run
+        # with D's parameters detached: only their data gradient is wanted.
         pr = self.D(self._d_input(A3, real))
         pfd = self.D(self._d_input(A3, fake.detach()))
-        loss_D = 0.5 * (gan_loss(pfd, False) + gan_loss(pr, True))
-        pfg = self.D(self._d_input(A3, fake))
+        loss_D_real, loss_D_fake = gan_loss(pr, True), gan_loss(pfd, False)
+        pfg = self.D(self._d_input(A3, fake), frozen=True)
         loss_G_gan = gan_loss(pfg, True)
         loss_G_fm = feature_matching_loss(pfg, pr, opt.n_layers_D, opt.lambda_feat) if not opt.no_ganFeat else 0.0
+        raw = fw_all = None
+        if flow_on:
+            # with a flow branch upstream scores fake_B_raw with the same discriminator (and VGG) as well; its second
+            # real pass returns the values of the first (same weights, same batch): that term is simply added again
+            raw, fw_all = torch.cat(raws, 0), torch.cat(fws, 0)
+            pfd_r = self.D(self._d_input(A3, raw.detach()))
+            pfg_r = self.D(self._d_input(A3, raw), frozen=True)
+            loss_D_real = loss_D_real + gan_loss(pr, True)
+            loss_D_fake = loss_D_fake + gan_loss(pfd_r, False)
+            loss_G_gan = loss_G_gan + gan_loss(pfg_r, True)
+            if not opt.no_ganFeat:
+                loss_G_fm = loss_G_fm + feature_matching_loss(pfg_r, pr, opt.n_layers_D, opt.lambda_feat)
+        loss_D = 0.5 * (loss_D_fake + loss_D_real)
         loss_G = loss_G_gan + loss_G_fm
         loss_G_vgg = None
-        if self.vgg is not None:   # [RECALL upstream: criterionVGG(fake_B, real_B) * lambda_feat]
+        if self.vgg is not None:   # [RECALL upstream: criterionVGG(fake_B, real_B) * lambda_feat (+ the same on fake_B_raw)]
             loss_G_vgg = vgg_loss(self.vgg, fake, real) * opt.lambda_feat
+            if flow_on:
+                loss_G_vgg = loss_G_vgg + vgg_loss(self.vgg, raw, real) * opt.lambda_feat
             loss_G = loss_G + loss_G_vgg
         def _f(t):   # kept on the device: one host read at the end of the step instead of a sync per loss term
             return t.detach() if torch.is_tensor(t) else float(t)
@@ -696,15 +835,38 @@ class Vid2VidTrainer:
         losses = {"G_GAN": _f(loss_G_gan), "G_GAN_Feat": _f(loss_G_fm), "D": _f(loss_D)}
         if loss_G_vgg is not None:
             losses["G_VGG"] = _f(loss_G_vgg)
+        if flow_on and real_prev is not None:
+            # flow / warp / weight losses [RECALL upstream Vid2VidModelD.forward, compute_flow_losses]:
+            #   F_Flow = MaskedL1(flow, flow_ref, conf) * lambda_F      F_Warp = MaskedL1(resample(real_B_prev, flow), real_B, conf) * lambda_T
+            #   W      = MaskedL1(weight, 0, conf)  (--no_first_img)    G_Warp = MaskedL1(fake_B, resample(fake_B_prev, flow_ref), conf) * lambda_T
+            # flow_ref / conf_ref come from FlowNet2 upstream; here they are inputs (zero flow by default)
+            with torch.no_grad():
+                if flow_ref is None:
+                    flow_ref = torch.zeros(F_, H, W, 4, dtype=torch.float32, device=dev)
+                    real_prev_warp = real_prev
+                else:
+                    real_prev_warp = torch.stack([ops.flow_warp(flow_ref[i], real_prev[i], 0) for i in range(F_)])
+                if conf_ref is None:
+                    conf_ref = ((real[..., :3] - real_prev_warp[..., :3]).norm(dim=-1) < 0.02).float()
+                fake_prev = torch.cat(prevs, 0)
+                fake_prev_warp = torch.stack([ops.flow_warp(flow_ref[i], fake_prev[i], self.spec.prev_nc - 3)
+                                              for i in range(F_)])
+            loss_F_flow = masked_l1(fw_all, flow_ref, conf_ref, 2, 0) * opt.lambda_F
+            loss_F_warp = masked_l1(_Resample.apply(fw_all, real_prev.contiguous(), 0), real, conf_ref, 3) * opt.lambda_T
+            loss_W = masked_l1(fw_all, None, conf_ref, 1, 2)
+            loss_G_warp = masked_l1(fake, fake_prev_warp, conf_ref, 3) * opt.lambda_T
+            loss_G = loss_G + loss_F_flow + loss_F_warp + loss_W + loss_G_warp
+            losses.update({"F_Flow": _f(loss_F_flow), "F_Warp": _f(loss_F_warp), "W": _f(loss_W), "G_Warp": _f(loss_G_warp)})
         if self.Df is not None and face_boxes is not None:
             def crop(t):
                 return torch.stack([t[i, b[0]:b[1], b[2]:b[3]] for i, b in enumerate(face_boxes)]).contiguous()
             fr = self.Df(self._d_input(crop(A3), crop(real)))
             ffd = self.Df(self._d_input(crop(A3), crop(fake.detach())))
             loss_Df = 0.5 * (gan_loss(ffd, False) + gan_loss(fr, True))
-            ffg = self.Df(self._d_input(crop(A3), crop(fake)))
-            lg = gan_loss(ffg, True)
-            lf = feature_matching_loss(ffg, fr, opt.n_layers_D, opt.lambda_feat) if not opt.no_ganFeat else 0.0
+            ffg = self.Df(self._d_input(crop(A3), crop(fake)), frozen=True)
+            # face_weight = 2 on the generator's face terms [RECALL upstream Vid2VidModelD.forward]
+            lg = gan_loss(ffg, True) * 2.0
+            lf = feature_matching_loss(ffg, fr, opt.n_layers_D, opt.lambda_feat) * 2.0 if not opt.no_ganFeat else 0.0
             loss_G = loss_G + lg + lf
             loss_D = loss_D + loss_Df
             losses.update({"G_f_GAN": _f(lg), "G_f_GAN_Feat": _f(lf), "D_f": _f(loss_Df)})
@@ -730,7 +892,7 @@ class Vid2VidTrainer:
                 pr_t = dt(tr)
                 pfd_t = dt(tf.detach())
                 l_dt = 0.5 * (gan_loss(pfd_t, False) + gan_loss(pr_t, True))
-                pfg_t = dt(tf)
+                pfg_t = dt(tf, frozen=True)
                 lg = gan_loss(pfg_t, True)
                 lf = feature_matching_loss(pfg_t, pr_t, opt.n_layers_D, opt.lambda_feat) if not opt.no_ganFeat else 0.0
                 loss_G = loss_G + lg + lf
@@ -863,7 +1025,12 @@ def run_train(opt, steps=None):
                 real[..., :3] = torch.tanh(torch.from_numpy(rng.standard_normal((F_, H, W, 3)).astype(np.float32))).to(dev)
                 side = max(8, opt.fineSize // 32 * 8)
                 boxes = [(H // 8, H // 8 + side, (W - side) // 2, (W - side) // 2 + side)] * F_ if opt.add_face_disc else None
-                losses, _ = trainer.train_step(pose, real, boxes)
+                real_prev = None
+                if not trainer.spec.no_flow:    # the real frame before each frame (flow / warp losses)
+                    real_prev = torch.cat([torch.tanh(torch.from_numpy(rng.standard_normal((1, H, W, 4)).astype(np.float32))).to(dev),
+                                           real[:-1]], 0)
+                    real_prev[..., 3] = 0
+                losses, _ = trainer.train_step(pose, real, boxes, real_prev=real_prev)
                 what = ""
             else:
                 # one clip per rank per iteration, walked in chunks of max_frames_per_gpu frames with the generated
@@ -887,8 +1054,12 @@ def run_train(opt, steps=None):
                             ops.pose_u8_to_f32(A[t - tG + 1 + f], pose[j], 3 * f)
                     real = torch.zeros(len(fr), H, W, 4, device=dev)
                     real[..., :3] = (B[fr].float() / 255.0 - 0.5) / 0.5
+                    real_prev = None
+                    if not trainer.spec.no_flow:
+                        real_prev = torch.zeros(len(fr), H, W, 4, device=dev)
+                        real_prev[..., :3] = (B[[t - 1 for t in fr]].float() / 255.0 - 0.5) / 0.5
                     boxes = [get_face_region(clip["A"][t], min(H, W)) for t in fr] if opt.add_face_disc else None
-                    losses, prev = trainer.train_step(pose, real, boxes, prev)
+                    losses, prev = trainer.train_step(pose, real, boxes, prev, real_prev=real_prev)
                 what = ", seq %s, %d frames %dx%d step %d" % (clip["seq"], T_ - tG + 1, H, W, clip["t_step"])
             torch.cuda.synchronize()
             stats.append(time.perf_counter() - ts)
