@@ -6,19 +6,26 @@
 
 One "step" = one output frame of the hot path: pack the 3-pose-map window (uint8 maps already
 resident in HBM), run CompositeGenerator (SURVEY config 2: ngf 128, 3 down-samplings, 9 ResNet
-blocks, 512x512; --openpose_only => no flow branch, `--flow` turns the flow-warp compositor on),
-shift the 2-frame FIFO and convert the frame to uint8 (tensor2im) in HBM.  N>1: each rank runs its
-own 64-frame-style chunk (sequence-chunk sharding; weak scaling) and the chunk outputs
-are all-gathered over RCCL inside the timed region.  Weights are random-init (seeded), data is
-synthetic: there is no network for checkpoints.
+blocks, 512x512), shift the 2-frame FIFO and convert the frame to uint8 (tensor2im) in HBM.
+The HEADLINE (`value`) is the generator WITH its flow branch and flow-warp compositor -- the variant
+that contains every component north_star names (3.32 TFLOP/frame); the no-flow variant (2.57
+TFLOP/frame; what --openpose_only may select upstream) is timed in the same run over the
+same K steps and reported in config.variants (`--variant noflow` swaps the roles).  N>1: each rank
+runs its own 64-frame-style chunk (sequence-chunk sharding; weak scaling) and the chunk
+outputs are all-gathered over RCCL inside the timed region.  Weights are random-init (seeded), data
+is synthetic: there is no network for checkpoints.
 
 Prints ONE JSON line (rank 0) with the driver's contract fields plus
   "roofline":     dominant kernel (the batched-GEMM stage of the Winograd F(4x4,3x3) 1024->1024 ResnetBlock
                   conv: 19.3 GFLOP of executed fp32 MFMA work per launch at 512x512) timed with HIP events on
                   the launch stream vs the fp32 MFMA peak (157.3 TFLOP/s); "layer" = the whole conv
   "cpu_baseline": the CPU oracle (stock torch fp32) timed on this box's host cores on a bounded
-                  sample of the same workload; its frames are also compared with the timed HIP model's
-                  ("parity": max |delta| per pixel, teacher-forced, tolerance 1e-3 = north_star).
+                  sample of the same workload (3 frames with all threads, and with 8 threads: SURVEY 8d);
+                  its frames are also compared with the timed HIP model's ("parity": max |delta| per
+                  pixel, teacher-forced, tolerance 1e-3 = north_star).
+  "e2e":          the drop-in test.py frame loop (rasterise pose JSONs -> H2D -> generator -> D2H ->
+                  JPEG files, text2video_amd.model.run_test) on a dataset in the reference's layout, at
+                  512x512, 512x680 and the reference's cropped 512x320, with the rasteriser worker count.
 """
 import argparse
 import json
@@ -75,6 +82,60 @@ def synthetic_pose_u8(n, H, W, seed):
     return a
 
 
+def run_e2e(model_head, model_other, head_flow, n_frames):
+    """The drop-in test.py path end to end: a dataset in the layout the reference's L2 driver writes (OpenPose JSONs
+    + skeleton jpgs; the committed fadg0 keypoint fixtures, cycled), rasterised by the pose-dataset worker pool ->
+    uint8 H2D -> generator -> tensor2im -> pinned D2H -> JPEG files.  Full-size generator, seeded weights."""
+    import shutil
+    import tempfile
+    from PIL import Image
+    from text2video_amd.keypoints import read_keypoints
+    from text2video_amd.model import run_test
+    from text2video_amd.options import TestOptions
+    src = os.path.join(ROOT, "tests", "golden", "keypoints_fadg0")
+    files = sorted(f for f in os.listdir(src) if f.startswith("sa1_"))
+    out = []
+    models = {head_flow: model_head}
+    if model_other is not None:
+        models[not head_flow] = model_other
+    # (canvas W x H of the source frames, extra flags, geometry the generator sees, which variants)
+    cases = [((512, 512), ["--no_pose_crop"], "512x512", [True, False]),
+             ((512, 384), ["--no_pose_crop"], "512x680 (fadg0 frames, scaleHeight 512, full width)", [head_flow]),
+             ((512, 384), [], "512x320 (fadg0 frames, scaleHeight 512 + upstream's central-width crop)", [head_flow])]
+    for canvas, extra, geom, flows in cases:
+        tmp = tempfile.mkdtemp(prefix="t2v_e2e_")
+        try:
+            root = os.path.join(tmp, "datasets", "fadg0")
+            os.makedirs(os.path.join(root, "test_openpose", "tmp"))
+            os.makedirs(os.path.join(root, "test_img", "tmp"))
+            img = Image.fromarray(read_keypoints(os.path.join(src, files[0]), canvas))
+            for i in range(n_frames + 2):
+                shutil.copyfile(os.path.join(src, files[i % len(files)]),
+                                os.path.join(root, "test_openpose", "tmp", "%05d.json" % i))
+                img.save(os.path.join(root, "test_img", "tmp", "%04d.jpg" % i))
+            for flow in flows:
+                if flow not in models:
+                    continue
+                argv = ("--name fadg0 --dataroot %s --dataset_mode pose --input_nc 3 --resize_or_crop scaleHeight "
+                        "--loadSize 512 --openpose_only --how_many 1200 --no_first_img --random_drop_prob 0 "
+                        "--results_dir %s --checkpoints_dir %s"
+                        % (root, os.path.join(tmp, "results_%d" % flow), os.path.join(tmp, "ckpt"))).split() + extra
+                opt = TestOptions().parse(argv)
+                m = models[flow]
+                m.reset()
+                import contextlib
+                import io
+                with contextlib.redirect_stdout(io.StringIO()):      # the loop prints "process image..." per frame
+                    stats = run_test(opt, model=m, device="cuda:%d" % torch.cuda.current_device())
+                workers = opt.pose_workers if opt.pose_workers is not None else max(1, min(16, (os.cpu_count() or 2) - 1))
+                out.append({"geometry": geom, "flow": flow, "fps": round(stats["fps_loop"], 2), "frames": stats["frames"],
+                            "pose_workers": workers, "rasteriser": "bit-exact (curve_fit) mode"})
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    return {"path": "text2video_amd.model.run_test == vid2vid/test.py: rasterise -> H2D -> generator -> D2H -> JPEG",
+            "runs": out}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -82,10 +143,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--height", type=int, default=512)
     ap.add_argument("--width", type=int, default=512)
-    ap.add_argument("--flow", action="store_true", help="enable the flow-warp compositor branch")
+    ap.add_argument("--variant", choices=["flow", "noflow"], default="flow",
+                    help="which generator variant is the headline `value` (the other one is timed as well)")
+    ap.add_argument("--flow", action="store_true", help="(kept for old command lines) same as --variant flow")
+    ap.add_argument("--single-variant", action="store_true", help="time the headline variant only")
+    ap.add_argument("--e2e-frames", type=int, default=160, help="frames per end-to-end test.py-path run (0 = skip)")
     ap.add_argument("--scales", type=int, default=1, choices=[1, 2],
                     help="2 = config 4's two-scale generator: G0 at H/2 x W/2 + local enhancer G1 at H x W")
-    ap.add_argument("--cpu-frames", type=int, default=2, help="frames of the CPU-oracle baseline (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=3, help="frames of the CPU-oracle baseline (0 = skip)")
     ap.add_argument("--kernel-iters", type=int, default=40)
     args = ap.parse_args()
 
@@ -110,13 +175,18 @@ def main():
     from text2video_amd.generator import GeneratorSpec, HipGenerator, Vid2VidModelG, synthetic_state_dict
 
     H, W, K, Wm = args.height, args.width, args.steps, args.warmup
-    spec = GeneratorSpec(ngf=128, n_downsample=3, n_blocks=9, no_flow=not args.flow, norm="batch")
-    sd = synthetic_state_dict(spec, seed=1, flow_gain=0.1)
-    nets = [HipGenerator(spec, dev).load_state_dict(sd)]
-    if args.scales == 2:
-        spec1 = GeneratorSpec(ngf=64, n_blocks=3, no_flow=not args.flow, norm="batch", is_local=True, scale=1)
-        nets.append(HipGenerator(spec1, dev).load_state_dict(synthetic_state_dict(spec1, seed=2, flow_gain=0.1)))
-    model = Vid2VidModelG(nets)
+    head_flow = args.variant == "flow"
+
+    def build(flow):
+        spec = GeneratorSpec(ngf=128, n_downsample=3, n_blocks=9, no_flow=not flow, norm="batch")
+        sd = synthetic_state_dict(spec, seed=1, flow_gain=0.1)
+        nets, sds = [HipGenerator(spec, dev).load_state_dict(sd)], [sd]
+        if args.scales == 2:
+            spec1 = GeneratorSpec(ngf=64, n_blocks=3, no_flow=not flow, norm="batch", is_local=True, scale=1)
+            sd1 = synthetic_state_dict(spec1, seed=2, flow_gain=0.1)
+            nets.append(HipGenerator(spec1, dev).load_state_dict(sd1))
+            sds.append(sd1)
+        return Vid2VidModelG(nets), sds
 
     nposes = K + Wm + 2
     poses = torch.from_numpy(synthetic_pose_u8(nposes, H, W, seed=rank)).to(dev)   # resident in HBM
@@ -124,42 +194,60 @@ def main():
     frames = torch.empty(K, H, W, 4, dtype=torch.uint8, device=dev)
     gathered = torch.empty(world * K, H, W, 4, dtype=torch.uint8, device=dev) if dist else None
 
-    def step(t, out_slot):
-        for f in range(3):                       # sliding window of tG = 3 pose maps, oldest first
-            ops.pose_u8_to_f32(poses[t + f], window, 3 * f)
-        out = model.inference_nhwc(window)
-        u8 = ops.tensor2im_u8(out)
-        if out_slot is not None:
-            frames[out_slot].copy_(u8)
+    def timed_run(model):
+        """W untimed warm-up frames, then exactly K timed frames (+ the all-gather of the chunk's frames for N>1)
+        between barrier + synchronize on both sides; returns the MAX over ranks of the elapsed seconds."""
+        model.reset()
 
-    for t in range(Wm):
-        step(t, None)
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for t in range(K):
-        step(Wm + t, t)
-    if dist:
-        dist.all_gather_into_tensor(gathered, frames)   # RCCL over xGMI: chunk outputs to every rank
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        def step(t, out_slot):
+            for f in range(3):                       # sliding window of tG = 3 pose maps, oldest first
+                ops.pose_u8_to_f32(poses[t + f], window, 3 * f)
+            out = model.inference_nhwc(window)
+            u8 = ops.tensor2im_u8(out)
+            if out_slot is not None:
+                frames[out_slot].copy_(u8)
+
+        for t in range(Wm):
+            step(t, None)
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for t in range(K):
+            step(Wm + t, t)
+        if dist:
+            dist.all_gather_into_tensor(gathered, frames)   # RCCL over xGMI: chunk outputs to every rank
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if dist:
+            tmax = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            el = float(tmax.item())
+        return el
+
+    model, sds = build(head_flow)
+    sd = sds[0]
+    spec = model.nets[0].spec
+    elapsed = timed_run(model)                     # the headline: `value`
+    other = other_elapsed = None
+    if not args.single_variant:
+        other, _ = build(not head_flow)
+        other_elapsed = timed_run(other)
 
     result = None
     if rank == 0:
         fps = world * K / elapsed
         if args.scales == 2:   # G0 on the half-resolution pyramid level + the local enhancer (SURVEY 8d config 4)
-            gf = gflop_per_frame(H // 2, W // 2, args.flow) + local_gflop_per_frame(H, W, args.flow)
+            def gflops(flow):
+                return gflop_per_frame(H // 2, W // 2, flow) + local_gflop_per_frame(H, W, flow)
         else:
-            gf = gflop_per_frame(H, W, args.flow)
+            def gflops(flow):
+                return gflop_per_frame(H, W, flow)
+        gf = gflops(head_flow)
         # ---- dominant kernel, timed live with HIP events on the stream it is launched on ----
         # The 1024->1024 3x3 ResnetBlock conv (28 per frame, 84 % of the algorithmic FLOPs) runs as Winograd
         # F(4x4,3x3) [F(2x2,3x3)]: input transform -> 36 [16] batched GEMMs [T x 1024] x [1024 x 1024] on the
@@ -248,17 +336,19 @@ def main():
             if args.scales == 2:
                 from oracle.generator_ref import CompositeLocalGenerator
                 loc = CompositeLocalGenerator(9, 3, 6, 128, 3, 1, spec.no_flow, "batch")
-                loc.load_state_dict(synthetic_state_dict(spec1, seed=2, flow_gain=0.1), strict=False)
+                loc.load_state_dict(sds[1], strict=False)
                 ref_nets.append(loc)
             ref = Vid2VidInferenceRef(ref_nets)
-            pf = ((poses[:args.cpu_frames + 3].cpu().float() / 255.0 - 0.5) / 0.5).permute(0, 3, 1, 2)
+            nf = args.cpu_frames
+            pf = ((poses[:nf + 3].cpu().float() / 255.0 - 0.5) / 0.5).permute(0, 3, 1, 2)
             # the same frames through the measured HIP path, teacher-forced on the oracle's previous frames: the
             # timed model's output against the oracle's, reported next to the speed (outside the timed region)
             model.reset()
             wants = [ref.inference(pf[0:3].unsqueeze(0))]   # warm-up frame (thread pool, first-frame path)
             gots = [model.inference(pf[0:3].unsqueeze(0).to(dev))[0].cpu()]
+            state1 = [p.clone() for p in ref.fake_B_prev]
             csec = 0.0
-            for t in range(1, 1 + args.cpu_frames):
+            for t in range(1, 1 + nf):
                 model.load_prev(ref.fake_B_prev)
                 c0 = time.perf_counter()
                 wants.append(ref.inference(pf[t:t + 3].unsqueeze(0)))
@@ -266,10 +356,35 @@ def main():
                 gots.append(model.inference(pf[t:t + 3].unsqueeze(0).to(dev))[0].cpu())
             parity = {"max_abs_delta_vs_oracle": float("%.3g" % max((g - w).abs().max().item() for g, w in zip(gots, wants))),
                       "frames": len(wants), "tolerance": 1e-3,
-                      "how": "frames 0..%d of the sequence, previous frames taken from the oracle (teacher-forced)" % args.cpu_frames}
-            cpu = {"value": round(args.cpu_frames / csec, 4), "unit": "frames/s", "cores": cores, "kind": "port",
-                   "sample": "%d frames %dx%d after 1 warm-up frame, torch %s CPU fp32, %d threads"
-                             % (args.cpu_frames, H, W, torch.__version__, cores), "parity": parity}
+                      "how": "frames 0..%d of the sequence, previous frames taken from the oracle (teacher-forced)" % nf}
+            # the same frames again with 8 threads (comparable with an 8-vCPU host)
+            c8 = None
+            if cores > 8:
+                torch.set_num_threads(8)
+                ref.fake_B_prev = [p.clone() for p in state1]
+                ref.inference(pf[1:4].unsqueeze(0))            # warm-up at the new thread count (not timed)
+                ref.fake_B_prev = [p.clone() for p in state1]
+                c0 = time.perf_counter()
+                for t in range(1, 1 + nf):
+                    ref.inference(pf[t:t + 3].unsqueeze(0))
+                c8 = nf / (time.perf_counter() - c0)
+                torch.set_num_threads(cores)
+            cpu = {"value": round(nf / csec, 4), "unit": "frames/s", "cores": cores, "kind": "port",
+                   "sample": "%d frames %dx%d (%s) after 1 warm-up frame, torch %s CPU fp32, %d threads"
+                             % (nf, H, W, "flow branch on" if head_flow else "no flow branch", torch.__version__, cores),
+                   "value_8_threads": round(c8, 4) if c8 else None, "parity": parity}
+        # ---- end to end: the drop-in test.py frame loop on a dataset in the reference's layout ----
+        e2e = None
+        if args.e2e_frames > 0 and world == 1 and args.scales == 1:
+            e2e = run_e2e(model, other, head_flow, args.e2e_frames)
+        variants = {("flow_fps" if head_flow else "noflow_fps"): round(fps, 3)}
+        if other_elapsed is not None:
+            variants["noflow_fps" if head_flow else "flow_fps"] = round(world * K / other_elapsed, 3)
+            variants["other_ms_per_step"] = round(1e3 * other_elapsed / K, 3)
+            variants["other_algorithmic_gflop_per_frame"] = round(gflops(not head_flow), 1)
+        variants["headline"] = "flow" if head_flow else "noflow"
+        variants["note"] = ("both variants timed in this run over the same K steps and W warm-up frames; `value` is "
+                            "the headline variant")
         result = {
             "metric": "frames/sec 512x512 pose->RGB (vid2vid generator)",
             "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
@@ -279,11 +394,12 @@ def main():
                                    "generator-only inference, ngf128 n_down3 n_blocks9%s, %s"
                                    % ("configs[1]" if (H, W, args.scales) == (512, 512, 1) else "configs[3]-style", H, W, K,
                                       " + local enhancer (n_scales_spatial 2)" if args.scales == 2 else "",
-                                      "flow-warp compositor ON" if args.flow else "no flow branch (--openpose_only)"),
+                                      "flow branch + flow-warp compositor ON" if head_flow else "no flow branch"),
                        "frames_per_gpu": K, "parallelism": "sequence-chunk dp%d" % world,
                        "algorithmic_gflop_per_frame": round(gf, 1),
-                       "algorithmic_tflops": round(fps * gf / 1e3, 2)},
-            "roofline": roofline, "cpu_baseline": cpu,
+                       "algorithmic_tflops": round(fps * gf / 1e3, 2),
+                       "variants": variants},
+            "roofline": roofline, "cpu_baseline": cpu, "e2e": e2e,
         }
     if dist:
         dist.barrier()

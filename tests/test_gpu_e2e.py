@@ -219,7 +219,8 @@ def test_bench_contract_line():
     import json
     env = dict(os.environ, CUDA_VISIBLE_DEVICES="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2",
-                        "--cpu-frames", "1", "--kernel-iters", "4"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+                        "--cpu-frames", "1", "--kernel-iters", "4", "--e2e-frames", "12"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1 and r.stdout.rstrip().endswith(lines[0])
@@ -238,3 +239,12 @@ def test_bench_contract_line():
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["unit"] == "frames/s" and cb["cores"] >= 1 and 0 < cb["value"] < d["value"]
     assert cb["parity"]["frames"] == 2 and 0 < cb["parity"]["max_abs_delta_vs_oracle"] <= cb["parity"]["tolerance"] == 1e-3
+    assert cb["value_8_threads"] is None or 0 < cb["value_8_threads"] < d["value"]
+    # the headline is the generator with the flow-warp compositor; the no-flow variant is timed in the same run
+    v = d["config"]["variants"]
+    assert v["headline"] == "flow" and v["flow_fps"] == d["value"] and v["noflow_fps"] > v["flow_fps"] > 30.0
+    assert "flow-warp compositor ON" in d["config"]["workload"]
+    # end to end through the drop-in test.py frame loop (pose JSONs -> JPEG files)
+    runs = d["e2e"]["runs"]
+    assert {r["geometry"].split(" ")[0] for r in runs} == {"512x512", "512x680", "512x320"}
+    assert all(r["frames"] == 12 and r["fps"] > 0 and r["pose_workers"] >= 1 for r in runs)

@@ -9,7 +9,6 @@ the `scaleHeight` geometry, central-width crop, keep a sliding window of n_frame
 uint8 HWC: ToTensor + Normalize(.5,.5) run on the GPU (t2v_pose_u8_to_f32).
 """
 import os
-from concurrent.futures import ProcessPoolExecutor
 
 import numpy as np
 from PIL import Image
@@ -168,16 +167,19 @@ class PoseDataset:
                 if (seq, j) not in seen:
                     seen.add((seq, j))
                     need.append((seq, j))
-        with ProcessPoolExecutor(max_workers=workers) as pool:
-            futures, cache, nxt = {}, {}, 0
+        # fresh worker interpreters, not forks of this (HIP-initialised) process: raster_pool.py
+        from .raster_pool import get_pool
+        pool = get_pool(workers)
+        futures, cache, nxt = {}, {}, 0
 
-            def pump():
-                nonlocal nxt
-                while nxt < len(need) and len(futures) < ahead:
-                    futures[need[nxt]] = pool.submit(_render_job, self._job(*need[nxt]))
-                    nxt += 1
+        def pump():
+            nonlocal nxt
+            while nxt < len(need) and len(futures) < ahead:
+                futures[need[nxt]] = pool.submit(self._job(*need[nxt]))
+                nxt += 1
 
-            pump()
+        pump()
+        try:
             for idx in range(n_items):
                 seq, i = self.items[idx]
                 win = []
@@ -191,6 +193,9 @@ class PoseDataset:
                 change_seq = idx == 0 or self.items[idx - 1][0] != seq or \
                     (seq, i) in getattr(self, "_unit_starts", ())
                 yield {"A": np.stack(win), "A_path": self._name(seq, i), "seq": seq, "change_seq": change_seq}
+        finally:
+            for f in futures.values():      # an early exit (--how_many, an error): let the in-flight jobs drain
+                f.cancel()
 
     def __getitem__(self, idx):
         seq, i = self.items[idx]

@@ -1,0 +1,121 @@
+"""Pool of rasteriser worker PROCESSES for the pose dataset.
+
+The workers are fresh interpreters (`python -m text2video_amd.raster_pool`), not forks of the caller: the frame
+loop's process holds a live HIP runtime (device mappings, pinned host buffers, RCCL in multi-GPU runs), and forking
+it copies -- and at worker exit tears down -- all of those mappings per worker (measured: ~2 s per worker, 33 s for
+a 16-worker pool inside bench.py).  A worker imports numpy / scipy / PIL only, reads length-prefixed pickled jobs
+from stdin and writes the uint8 pose map back on stdout.  In the parent one thread per worker does the blocking
+pipe I/O, so `submit()` returns a concurrent.futures.Future like an executor would.  Pools are cached per worker
+count and reused by later frame loops of the same process (test_fifo.py serves many requests).
+"""
+import atexit
+import os
+import pickle
+import struct
+import subprocess
+import sys
+import threading
+from concurrent.futures import ThreadPoolExecutor
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _read_exact(f, n):
+    buf = bytearray()
+    while len(buf) < n:
+        chunk = f.read(n - len(buf))
+        if not chunk:
+            raise EOFError("rasteriser worker closed its pipe")
+        buf += chunk
+    return bytes(buf)
+
+
+def _worker_main():
+    """child side: job tuple in, (h, w, c) + bytes out; an exception travels back as text"""
+    import numpy as np  # noqa: F401
+    from text2video_amd.pose_dataset import _render_job
+    inp, out = sys.stdin.buffer, sys.stdout.buffer
+    sys.stdout = sys.stderr            # stray prints must not corrupt the result stream
+    while True:
+        head = inp.read(4)
+        if len(head) < 4:
+            return
+        job = pickle.loads(_read_exact(inp, struct.unpack("<I", head)[0]))
+        try:
+            m = _render_job(job)
+            out.write(struct.pack("<iii", *m.shape) + m.tobytes())
+        except Exception as e:        # noqa: BLE001 -- reported to the caller, which raises
+            msg = ("%s: %s" % (type(e).__name__, e)).encode()
+            out.write(struct.pack("<iii", -1, len(msg), 0) + msg)
+        out.flush()
+
+
+class RasterPool:
+    def __init__(self, workers):
+        self.workers = workers
+        self._local = threading.local()
+        self._procs = []
+        self._lock = threading.Lock()
+        self._threads = ThreadPoolExecutor(max_workers=workers, thread_name_prefix="raster")
+        env = dict(os.environ, PYTHONPATH=_ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""),
+                   OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")   # 2-point fits: no BLAS threads
+        for _ in range(workers):       # start them all now: their imports run in parallel
+            self._procs.append(subprocess.Popen([sys.executable, "-m", "text2video_amd.raster_pool"], stdin=subprocess.PIPE,
+                                                stdout=subprocess.PIPE, env=env, cwd=_ROOT))
+        self._free = list(self._procs)
+
+    def _mine(self):
+        p = getattr(self._local, "proc", None)
+        if p is None:
+            with self._lock:
+                p = self._local.proc = self._free.pop()
+        return p
+
+    def _run(self, job):
+        import numpy as np
+        p = self._mine()
+        blob = pickle.dumps(job, protocol=pickle.HIGHEST_PROTOCOL)
+        p.stdin.write(struct.pack("<I", len(blob)) + blob)
+        p.stdin.flush()
+        h, w, c = struct.unpack("<iii", _read_exact(p.stdout, 12))
+        if h < 0:
+            raise RuntimeError("rasteriser worker: " + _read_exact(p.stdout, w).decode(errors="replace"))
+        return np.frombuffer(_read_exact(p.stdout, h * w * c), dtype=np.uint8).reshape(h, w, c)
+
+    def submit(self, job):
+        return self._threads.submit(self._run, job)
+
+    def close(self):
+        self._threads.shutdown(wait=True)
+        for p in self._procs:
+            try:
+                p.stdin.close()
+            except OSError:
+                pass
+        for p in self._procs:
+            try:
+                p.wait(timeout=5)
+            except subprocess.TimeoutExpired:
+                p.kill()
+        self._procs = []
+
+
+_pools = {}
+
+
+def get_pool(workers):
+    pool = _pools.get(workers)
+    if pool is None:
+        pool = _pools[workers] = RasterPool(workers)
+    return pool
+
+
+@atexit.register
+def _close_all():
+    for pool in list(_pools.values()):
+        pool.close()
+    _pools.clear()
+
+
+if __name__ == "__main__":
+    _worker_main()
