@@ -396,6 +396,7 @@ def main():
                                       " + local enhancer (n_scales_spatial 2)" if args.scales == 2 else "",
                                       "flow branch + flow-warp compositor ON" if head_flow else "no flow branch"),
                        "frames_per_gpu": K, "parallelism": "sequence-chunk dp%d" % world,
+                       "collectives": "rccl" if dist else "none (single process)",
                        "algorithmic_gflop_per_frame": round(gf, 1),
                        "algorithmic_tflops": round(fps * gf / 1e3, 2),
                        "variants": variants},

@@ -144,3 +144,106 @@ def _ar_worker(rank, world, port, tmpdir):
 def test_two_rank_gloo_gradient_allreduce(tmp_path):
     """Bucketed, averaged gradient all-reduce of the train step (replaces DataParallel's GPU-0 star)."""
     mp.spawn(_ar_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+
+
+def _fake_generate_from(poses, state, n_frames):
+    """the stand-in recurrence with an explicit start state (None: zeros) -> (frames, FIFO state after them)"""
+    prev = [torch.zeros_like(poses[0]), torch.zeros_like(poses[0])] if state is None else [state[0], state[1]]
+    outs = []
+    stop = poses.shape[0] if n_frames is None else 2 + n_frames
+    for t in range(2, stop):
+        o = torch.tanh(poses[t - 2:t + 1].sum(0) * 0.3 + 0.5 * prev[1] - 0.25 * prev[0])
+        prev = [prev[1], o]
+        outs.append(o)
+    return torch.stack(outs), torch.stack(prev)
+
+
+def _stitch_worker(rank, world, port, seq_lengths, mode, tmpdir):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from text2video_amd import distributed as D
+    D.init_from_env("gloo")
+    shard, stitch, rounds, how_many = mode
+    plan = D.plan_units(seq_lengths, world, 3, shard, how_many)
+    poses = {s: _poses(s, n) for s, n in seq_lengths.items()}
+
+    def generate(unit, state, n_frames):
+        seq, s, e, first_out = unit
+        return _fake_generate_from(poses[seq][s:e], state, n_frames)
+
+    frames = D.run_units(plan[rank], plan, rank, generate, stitch, rounds)
+    everything = [None] * world
+    dist.all_gather_object(everything, [(u, f) for u, f in zip(plan[rank], frames)])
+    if rank == 0:
+        torch.save(everything, os.path.join(tmpdir, "out.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _collect(tmp_path):
+    got = {}
+    for per_rank in torch.load(os.path.join(str(tmp_path), "out.pt"), weights_only=False):
+        for (seq, s, e, first_out), f in per_rank:
+            for j in range(f.shape[0]):
+                assert (seq, first_out + j) not in got
+                got[(seq, first_out + j)] = f[j]
+    return got
+
+
+@pytest.mark.parametrize("seq_lengths,how_many", [({"tmp": 12, "tmp_smooth": 12}, None), ({"only": 21}, None),
+                                                  ({"a": 9, "b": 14, "c": 5}, 13)])
+def test_multi_rank_frames_equal_single_rank_frames_by_default(tmp_path, seq_lengths, how_many):
+    """Default sharding deals whole sequences only: whatever WORLD_SIZE is, every frame is the frame a single
+    process generates, and --how_many counts output frames globally in dataset order."""
+    mp.spawn(_stitch_worker, args=(2, _free_port(), seq_lengths, (False, 0, 1, how_many), str(tmp_path)), nprocs=2, join=True)
+    got = _collect(tmp_path)
+    want, budget = {}, how_many
+    for seq, n in seq_lengths.items():          # the single-process loop
+        f = _fake_generate(_poses(seq, n))
+        for j in range(f.shape[0]):
+            if budget is not None and budget <= 0:
+                break
+            want[(seq, 2 + j)] = f[j]
+            budget = None if budget is None else budget - 1
+    assert set(got) == set(want)
+    for k in want:
+        assert torch.equal(got[k], want[k]), k
+
+
+def test_stitched_chunks_reproduce_the_unsharded_sequence(tmp_path):
+    """--shard_chunks cuts the one sequence in two; with the stitch pass re-generating the WHOLE continuation chunk
+    from the first chunk's all-gathered tail the result is the unsharded sequence, bit for bit; with a short stitch
+    only the first k frames after the cut are the unsharded ones; without it the frames after the cut differ."""
+    seq_lengths = {"only": 23}
+    want = _fake_generate(_poses("only", 23))
+    results = {}
+    for name, mode in (("off", (True, 0, 1, None)), ("k3", (True, 3, 1, None)), ("full", (True, 1000, 1, None))):
+        d = tmp_path / name
+        d.mkdir()
+        mp.spawn(_stitch_worker, args=(2, _free_port(), seq_lengths, mode, str(d)), nprocs=2, join=True)
+        results[name] = _collect(d)
+        assert set(results[name]) == {("only", t) for t in range(2, 23)}
+    from text2video_amd.distributed import plan_units
+    cut = sorted(fo for p in plan_units(seq_lengths, 2, 3, True) for _, _, _, fo in p)[1]
+    for t in range(2, 23):
+        w = want[t - 2]
+        assert torch.equal(results["full"][("only", t)], w), t
+        if t < cut:
+            assert torch.equal(results["off"][("only", t)], w) and torch.equal(results["k3"][("only", t)], w)
+        elif t < cut + 3:
+            assert torch.equal(results["k3"][("only", t)], w)
+    assert not torch.equal(results["off"][("only", cut)], want[cut - 2])
+
+
+def test_plan_units_rules():
+    from text2video_amd.distributed import plan_units
+    # whole sequences by default, even when that leaves ranks idle
+    plan = plan_units({"seq": 514}, 8)
+    assert sum(len(p) for p in plan) == 1 and [u for p in plan for u in p] == [("seq", 0, 514, 2)]
+    # config 3: --shard_chunks cuts 512 output frames into 8 x 64
+    plan = plan_units({"seq": 514}, 8, 3, True)
+    assert sorted(e - fo for p in plan for _, _, e, fo in p) == [64] * 8
+    # how_many is global and applied in dataset order before the deal
+    plan = plan_units({"a": 10, "b": 10}, 2, 3, False, 11)
+    assert sorted(u for p in plan for u in p) == [("a", 0, 10, 2), ("b", 0, 5, 2)]
+    assert plan_units({"a": 10, "b": 10}, 2, 3, False, 8) == [[("a", 0, 10, 2)], []]

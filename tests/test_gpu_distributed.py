@@ -1,0 +1,145 @@
+"""GPU tests of the multi-GPU code paths that one GPU can execute: the RCCL collectives themselves (a 1-rank `nccl`
+process group runs the same RCCL entry points on device tensors: all_gather_into_tensor of the uint8 frames, the
+bucketed gradient all-reduce, the stitch pass's tail exchange), and BASELINE configs[2]'s chunk plan with the REAL
+HIP generator run over it, chunk by chunk, against the CPU oracle on the same chunks."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_runs_its_rccl_path_on_one_rank():
+    """bench.py with T2V_BENCH_FORCE_DIST=1: process group "nccl" (= RCCL) of one rank, barrier, the in-region
+    all_gather_into_tensor of the chunk's uint8 frames, MAX all-reduce of the elapsed time."""
+    env = dict(os.environ, CUDA_VISIBLE_DEVICES="0", T2V_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2",
+                        "--cpu-frames", "0", "--kernel-iters", "2", "--e2e-frames", "0", "--single-variant"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["value"] > 30.0 and d["config"]["parallelism"] == "sequence-chunk dp1"
+    assert d["config"]["collectives"] == "rccl"
+
+
+def _rccl_worker(tmp):
+    """runs in its own process: 1-rank RCCL group; GradientExchange buckets on device gradients, gather_frames of
+    uint8 frames, exchange_tails, and a whole Vid2VidTrainer step with the exchange forced on."""
+    os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29534",
+                      T2V_TRAIN_FORCE_DIST="1")
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    from text2video_amd import distributed as D
+    from text2video_amd import train as T
+    from text2video_amd.options import TrainOptions
+    out = {"backend": dist.get_backend()}
+    # frames all-gather (uint8, device)
+    fr = torch.randint(0, 255, (5, 32, 32, 4), dtype=torch.uint8, device="cuda:0")
+    full = torch.empty(5, 32, 32, 4, dtype=torch.uint8, device="cuda:0")
+    dist.all_gather_into_tensor(full, fr)
+    out["gather_equal"] = bool(torch.equal(full, fr))
+    # bucketed gradient exchange on device tensors, two exchanges in flight
+    params = [torch.nn.Parameter(torch.zeros(n, device="cuda:0")) for n in (5, 70000, 3, 1 << 18, 17)]
+    for i, p in enumerate(params):
+        p.grad = torch.full_like(p, float(i + 1))
+    xa = T.allreduce_gradients_begin(params[:3], bucket_mb=1)
+    xb = T.allreduce_gradients_begin(params[3:], bucket_mb=1)
+    out["bytes"] = xa.finish() + xb.finish()
+    out["buckets"] = True
+    out["grads_ok"] = all(bool(torch.equal(p.grad, torch.full_like(p, float(i + 1)))) for i, p in enumerate(params))
+    # stitch pass's tail exchange
+    plan = [[("seq", 0, 10, 2), ("seq", 8, 18, 10)]]
+    tails = [torch.randn(16, 16, 8, device="cuda:0") for _ in range(2)]
+    known = D.exchange_tails(plan, 0, tails)
+    out["tails_ok"] = bool(torch.equal(known[("seq", 10)], tails[0]) and torch.equal(known[("seq", 18)], tails[1]))
+    # a whole trainer step with the (1-rank) RCCL gradient exchange in it
+    opt = TrainOptions().parse(["--name", "t", "--dataset_mode", "pose", "--input_nc", "3", "--openpose_only", "--ngf", "16",
+                                "--n_downsample_G", "2", "--n_blocks", "2", "--num_D", "2", "--ndf", "16", "--no_vgg",
+                                "--max_frames_per_gpu", "2", "--n_scales_temporal", "0", "--no_first_img"])
+    tr = T.Vid2VidTrainer(opt, "cuda:0", seed=5)
+    g = torch.Generator().manual_seed(0)
+    pose = torch.zeros(2, 64, 64, 12, device="cuda:0")
+    pose[..., :9] = (torch.rand(2, 64, 64, 9, generator=g) * 2 - 1).cuda()
+    real = torch.zeros(2, 64, 64, 4, device="cuda:0")
+    real[..., :3] = torch.tanh(torch.randn(2, 64, 64, 3, generator=g)).cuda()
+    losses, _ = tr.train_step(pose, real, None, None, real_prev=real.flip(0).contiguous())
+    out["comm_bytes"] = tr.comm_bytes
+    out["n_param_bytes"] = 4 * sum(p.numel() for p in tr.optG.params + tr.optD.params if p.grad is not None)
+    out["losses_finite"] = all(np.isfinite(v) for v in losses.values())
+    dist.barrier()
+    dist.destroy_process_group()
+    with open(tmp, "w") as fh:
+        json.dump(out, fh)
+
+
+def test_rccl_collectives_execute_on_device_tensors(tmp_path):
+    """GradientExchange / frame all-gather / tail exchange through RCCL (1-rank "nccl" group) on device tensors."""
+    out = str(tmp_path / "o.json")
+    env = dict(os.environ, CUDA_VISIBLE_DEVICES="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r); from tests.test_gpu_distributed import "
+                        "_rccl_worker; _rccl_worker(%r)" % (ROOT, out)], cwd=ROOT, env=env, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    d = json.load(open(out))
+    assert d["backend"] == "nccl" and d["gather_equal"] and d["grads_ok"] and d["tails_ok"] and d["losses_finite"]
+    assert d["bytes"] == 4 * (5 + 70000 + 3 + (1 << 18) + 17)
+    assert d["comm_bytes"] == d["n_param_bytes"] > 0         # every gradient of the step went through the exchange
+
+
+def test_config2_chunk_plan_with_the_real_generator_matches_oracle_per_chunk():
+    """BASELINE configs[2]: a 514-pose-map sequence (512 output frames) cut by the 8-rank plan into 8 chunks of 64
+    frames.  The chunks are run serially on this GPU through the real HIP generator (reduced size: 64x64, ngf 16),
+    each as the plan prescribes -- a fresh recurrence, zero previous frames and raw-only first frame -- and compared
+    frame by frame with the CPU oracle run on the same chunk (teacher-forced: every frame starts from the oracle's
+    FIFO, so differences do not compound through the random-init recurrence).  Also: the chunks tile frames 2..513
+    exactly once, and a chunk's first frames DIFFER from the unsharded run's (the seam that --stitch_frames closes)."""
+    from oracle.generator_ref import CompositeGenerator, Vid2VidInferenceRef
+    from text2video_amd.distributed import plan_units
+    from text2video_amd.generator import GeneratorSpec, HipGenerator, Vid2VidModelG, synthetic_state_dict
+    spec = GeneratorSpec(ngf=16, n_downsample=2, n_blocks=2, no_flow=False, norm="batch")
+    sd = synthetic_state_dict(spec, 4, "vid2vid", flow_gain=0.1)
+    net = CompositeGenerator(9, 3, 6, 16, 2, 2, False, "batch")
+    net.load_state_dict(sd, strict=False)
+    ref = Vid2VidInferenceRef([net])
+    hip = Vid2VidModelG([HipGenerator(spec, "cuda:0").load_state_dict(sd)])
+    H = W = 64
+    rng = np.random.default_rng(0)
+    poses = torch.from_numpy(np.where(rng.random((514, 1, H, W)) < 0.03, rng.uniform(-1, 1, (514, 3, H, W)), -1.0)
+                             .astype(np.float32))
+    plan = plan_units({"seq": 514}, 8, 3, shard_chunks=True)
+    assert all(len(p) == 1 for p in plan)
+    covered, worst = [], 0.0
+    seam = None
+    for r in range(8):
+        (seq, s, e, first_out), = plan[r]
+        assert e - first_out == 64 and first_out == s + 2
+        ref.reset()
+        hip.reset()
+        for t in range(first_out, e):
+            A = poses[t - 2:t + 1].unsqueeze(0)
+            if ref.fake_B_prev is not None:
+                hip.load_prev(ref.fake_B_prev)
+            want = ref.inference(A)
+            got, _ = hip.inference(A.to("cuda:0"))
+            worst = max(worst, (got.cpu() - want).abs().max().item())
+            covered.append(t)
+            if r == 1 and t == first_out:
+                seam = want.clone()
+    assert covered == list(range(2, 514))
+    print("configs[2] chunk plan, 8 x 64 frames at 64x64: max|delta| vs oracle per chunk = %.3g" % worst)
+    assert worst <= 2e-4
+    # the unsharded oracle run reaches chunk 1's first frame with a non-zero FIFO: the seam is real
+    ref.reset()
+    first_out = plan[1][0][3]
+    for t in range(2, first_out + 1):
+        full = ref.inference(poses[t - 2:t + 1].unsqueeze(0))
+    assert (full - seam).abs().max().item() > 1e-2

@@ -1,0 +1,245 @@
+"""GPU tests at BASELINE.json's full sizes: configs[3] (1024x1024, single-scale and two-scale generator), the real fadg0
+geometries of configs[0] (512x680 / 512x320 after scaleHeight 512), and one configs[4]-sized train step (512x512, 2
+frames).  Where a CPU-oracle frame is affordable (a few seconds of host time) the frame is compared with it,
+teacher-forced; otherwise size-independent properties carry the check: bit-reproducibility, the compositor identity,
+and agreement between the two independent convolution kernel families (Winograd vs direct implicit GEMM), each of which
+is oracle-checked at small sizes in test_gpu_generator.py / test_gpu_ops.py."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-3
+
+
+def _pose_seq(n, H, W, seed=0):
+    rng = np.random.default_rng(seed)
+    a = -np.ones((n, 3, H, W), np.float32)
+    m = rng.random((n, 1, H, W)) < 0.02
+    return torch.from_numpy(np.where(m, rng.uniform(-1, 1, size=(n, 3, H, W)).astype(np.float32), a))
+
+
+def _prev_frames(H, W, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.tanh(torch.randn(2, 3, H, W, generator=g))
+
+
+def _full_nets(scales, no_flow, conv_algo=None):
+    """configs[1] / configs[3] networks: G0 = ngf 128, 3 down-samplings, 9 blocks; G1 = ngf 64, 3 local blocks."""
+    from oracle.generator_ref import CompositeGenerator, CompositeLocalGenerator
+    from text2video_amd.generator import GeneratorSpec, HipGenerator, synthetic_state_dict
+    specs = [GeneratorSpec(ngf=128, n_downsample=3, n_blocks=9, no_flow=no_flow, norm="batch")]
+    refs = [CompositeGenerator(9, 3, 6, 128, 3, 9, no_flow, "batch")]
+    if scales == 2:
+        specs.append(GeneratorSpec(ngf=64, n_blocks=3, no_flow=no_flow, norm="batch", is_local=True, scale=1))
+        refs.append(CompositeLocalGenerator(9, 3, 6, 128, 3, 1, no_flow, "batch"))
+    hips = []
+    for i, (spec, ref) in enumerate(zip(specs, refs)):
+        sd = synthetic_state_dict(spec, 1 + i, flow_gain=0.1)
+        missing, unexpected = ref.load_state_dict(sd, strict=False)
+        assert not unexpected and all(("running" in k or "num_batches" in k) for k in missing)
+        hips.append(HipGenerator(spec, "cuda:0", conv_algo=conv_algo).load_state_dict(sd))
+    return refs, hips
+
+
+@pytest.mark.parametrize("no_flow", [True, False], ids=["noflow", "flow"])
+def test_config3_two_scale_1024_frame_matches_oracle(no_flow):
+    """configs[3], two-scale: G0 at 512x512 feeds the local enhancer G1 at 1024x1024.  One frame with non-trivial
+    previous frames at both pyramid levels (teacher-forced: both sides start from the same FIFO) against the CPU
+    oracle, per-pixel |delta| <= 1e-3."""
+    from oracle.generator_ref import Vid2VidInferenceRef
+    from text2video_amd.generator import Vid2VidModelG
+    refs, hips = _full_nets(2, no_flow)
+    ref, hip = Vid2VidInferenceRef(refs), Vid2VidModelG(hips)
+    H = W = 1024
+    A = _pose_seq(3, H, W, seed=11).unsqueeze(0)
+    p1 = _prev_frames(H, W, 5)
+    ref.fake_B_prev = ref._pyr(p1)               # [fine, coarse] FIFOs (the coarse one = avg-pooled fine one)
+    hip.load_prev(ref.fake_B_prev)
+    want = ref.inference(A)
+    got, _ = hip.inference(A.to("cuda:0"))
+    err = (got.cpu() - want).abs().max().item()
+    print("two-scale 1024x1024 %s frame: max|delta| = %.3g" % ("no-flow" if no_flow else "flow", err))
+    assert err <= TOL and want.abs().max().item() > 0.05 and tuple(got.shape) == (1, 3, 1024, 1024)
+    # the FIFO the next frame would see, at both levels
+    for lvl in range(2):
+        fifo = hip.prev[lvl][..., :6].permute(2, 0, 1).cpu().reshape(2, 3, H >> lvl, W >> lvl)
+        assert (fifo - ref.fake_B_prev[lvl]).abs().max().item() <= TOL
+
+
+def test_config3_single_scale_1024_properties():
+    """configs[3], single-scale G0 at 1024x1024 (10.3 / 13.3 TFLOP per frame: a CPU-oracle frame takes minutes).
+    Properties: frames are bit-reproducible; the Winograd path (28 + 8 ResnetBlock convs on F(4x4,3x3)) and the direct
+    implicit-GEMM path (conv_algo = 1) -- two independent kernel families -- agree to <= 1e-3 per pixel on the same
+    frame, with and without flow; the compositor identity out = raw*w + warp*(1-w) holds on the returned taps."""
+    from text2video_amd import ops
+    H = W = 1024
+    poses = _pose_seq(3, H, W, seed=12)
+    pose = ops.nchw_to_nhwc(poses.reshape(9, H, W).to("cuda:0"))
+    prev = torch.zeros(H, W, 8, device="cuda:0")
+    prev[..., :6] = _prev_frames(H, W, 6).reshape(6, H, W).permute(1, 2, 0).cuda()
+    for no_flow in (True, False):
+        _, (wino,) = _full_nets(1, no_flow)
+        _, (direct,) = _full_nets(1, no_flow, conv_algo=1)
+        want = ("out",) if no_flow else ("out", "raw", "flow_w")
+        a1 = wino.forward(pose, prev, False, want=want)
+        a2 = wino.forward(pose, prev, False, want=want)
+        b = direct.forward(pose, prev, False, want=want)
+        assert torch.equal(a1["out"], a2["out"]) and torch.isfinite(a1["out"]).all()
+        err = (a1["out"] - b["out"]).abs().max().item()
+        print("single-scale 1024x1024 %s: Winograd vs direct max|delta| = %.3g" % ("no-flow" if no_flow else "flow", err))
+        assert err <= TOL and a1["out"][..., :3].abs().max().item() <= 1.0 and a1["out"][..., :3].std().item() > 0.01
+        if not no_flow:
+            out = ops.flow_warp_composite(a1["raw"], a1["flow_w"], prev, 3)
+            assert torch.equal(out, a1["out"])
+            assert (a1["flow_w"][..., :2] - b["flow_w"][..., :2]).abs().max().item() <= 5e-3   # pixels, after the x20
+        del wino, direct
+        torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("H,W", [(512, 680), (512, 320)], ids=["512x680", "512x320"])
+def test_config0_fadg0_geometries_match_oracle(H, W):
+    """The real fadg0 frames after `--resize_or_crop scaleHeight --loadSize 512`: 512x680 (bottleneck 64x85: ragged
+    Winograd tile grid) and, with upstream's central-width crop, 512x320.  Full-size network, one teacher-forced
+    frame against the CPU oracle, flow-warp compositor on."""
+    from oracle.generator_ref import Vid2VidInferenceRef
+    from text2video_amd.generator import Vid2VidModelG
+    refs, hips = _full_nets(1, False)
+    ref, hip = Vid2VidInferenceRef(refs), Vid2VidModelG(hips)
+    A = _pose_seq(3, H, W, seed=13).unsqueeze(0)
+    ref.fake_B_prev = [_prev_frames(H, W, 7)]
+    hip.load_prev(ref.fake_B_prev)
+    want = ref.inference(A)
+    got, _ = hip.inference(A.to("cuda:0"))
+    err = (got.cpu() - want).abs().max().item()
+    print("%dx%d flow frame: max|delta| = %.3g" % (H, W, err))
+    assert err <= TOL and want.abs().max().item() > 0.05
+
+
+def test_config4_train_step_512_two_frames():
+    """configs[4] per-GPU work: one train step at 512x512 with 2 frames (generator with flow branch + 2-scale
+    discriminator + face discriminator).  Losses finite; the step is reproducible (two trainers from the same seed
+    give the same losses and the same updated weights, bit for bit); every generator parameter receives a finite,
+    gradient (non-zero except for the conv biases a norm layer cancels); and the gradients of the Winograd path agree with those of the direct implicit-GEMM path
+    (T2V_CONV_ALGO=1) -- both oracle-checked at 64x64 in test_gpu_train_step.py."""
+    import os
+    from text2video_amd import train as T
+    from text2video_amd.options import TrainOptions
+    opt = TrainOptions().parse(["--name", "t", "--dataset_mode", "pose", "--input_nc", "3", "--openpose_only", "--num_D", "2",
+                                "--no_vgg", "--max_frames_per_gpu", "2", "--n_scales_temporal", "0", "--no_first_img",
+                                "--add_face_disc", "--fineSize", "512"])
+    H = W = 512
+    rng = np.random.default_rng(0)
+    pose = torch.zeros(2, H, W, 12, device="cuda:0")
+    pose[..., :9] = torch.from_numpy(np.where(rng.random((2, H, W, 1)) < 0.02, rng.uniform(-1, 1, (2, H, W, 9)), -1.0)
+                                     .astype(np.float32)).cuda()
+    real = torch.zeros(2, H, W, 4, device="cuda:0")
+    real[..., :3] = torch.tanh(torch.from_numpy(rng.standard_normal((2, H, W, 3)).astype(np.float32))).cuda()
+    real_prev = torch.cat([real[1:], real[:1]], 0).contiguous()
+    prev0 = torch.zeros(1, H, W, 8, device="cuda:0")
+    prev0[..., :6] = torch.tanh(torch.from_numpy(rng.standard_normal((1, H, W, 6)).astype(np.float32))).cuda()
+    boxes = [(64, 192, 192, 320)] * 2
+
+    def one(algo):
+        if algo:
+            os.environ["T2V_CONV_ALGO"] = algo
+        try:
+            tr = T.Vid2VidTrainer(opt, "cuda:0", seed=5)
+            before = [p.detach().clone() for p in tr.optG.params]
+            losses, _ = tr.train_step(pose, real, boxes, prev0.clone(), real_prev=real_prev)
+            grads = [p.grad.clone() if p.grad is not None else None for p in tr.optG.params]
+            after = [p.detach().clone() for p in tr.optG.params]
+            names = list(tr.G.named_upstream_parameters())
+            del tr
+            torch.cuda.empty_cache()
+            return losses, grads, before, after, names
+        finally:
+            os.environ.pop("T2V_CONV_ALGO", None)
+
+    l1, g1, b1, a1, names = one(None)
+    l2, g2, _, a2, _ = one(None)
+    for k, v in l1.items():
+        assert np.isfinite(v), k
+        assert v == l2[k], (k, v, l2[k])
+    for k in ("G_GAN", "G_GAN_Feat", "D", "F_Flow", "F_Warp", "W", "G_Warp", "G_f_GAN", "D_f"):
+        assert k in l1, k
+    for n, x, y, w0, w1 in zip(names, g1, g2, b1, a1):
+        assert x is not None and torch.isfinite(x).all(), n
+        assert torch.equal(x, y), n
+        if x.abs().max().item() > 0:      # (conv biases in front of a norm layer: exactly zero gradient, no move)
+            assert (w1 - w0).abs().max().item() > 0, n
+    for x, y in zip(a1, a2):
+        assert torch.equal(x, y)
+    # Winograd path vs direct path.  At this width (1024-channel bottleneck, instance norm after every conv) the
+    # parameter gradient is ill-conditioned in fp32 -- the CPU oracle's own fp32 gradient sits 3e-3 (median) to 4e-2
+    # (worst tensor) away from its fp64 evaluation already for the generator alone
+    # (test_fullwidth_gradient_error_is_within_the_fp32_oracles_own below) and the GAN / flow losses of this step add
+    # more cancellation -- so two correct fp32 evaluations agree only at the level measured here, not at 1e-3
+    ld, gd, _, _, _ = one("1")
+    errs = {}
+    for n, x, y in zip(names, g1, gd):
+        scale = y.norm().item()
+        if y.abs().max().item() <= 1e-7:
+            continue       # conv biases in front of a norm layer: mathematically zero gradient
+        errs[n] = (x - y).norm().item() / scale
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:3]
+    print("512x512 train step, Winograd vs direct gradients (relative L2 per tensor): worst", ["%s %.1e" % kv for kv in worst],
+          "median %.1e" % float(np.median(list(errs.values()))))
+    assert float(np.median(list(errs.values()))) <= 0.1 and max(errs.values()) <= 0.3
+    for k in l1:
+        assert abs(l1[k] - ld[k]) <= 2e-3 * max(1.0, abs(ld[k])), k
+
+
+def test_fullwidth_gradient_error_is_within_the_fp32_oracles_own():
+    """Conditioning-normalised parity of the backward pass at full width (ngf 128, 9 blocks, 256x256: the
+    ResnetBlock convs, their data gradients and weight gradients all take the Winograd F(4x4,3x3) path): the HIP
+    gradient's distance from an fp64 evaluation of the oracle, per parameter tensor, against the distance of the fp32
+    CPU oracle from the same fp64 evaluation.  The HIP path must be as good as "another fp32 implementation": within
+    a small factor of the oracle's own rounding noise (measured: 1.9x median, 2.8x at the 90th percentile)."""
+    from oracle.generator_ref import CompositeGenerator
+    from text2video_amd import ops
+    from text2video_amd import train as T
+    from text2video_amd.generator import GeneratorSpec, synthetic_state_dict
+    H = W = 256
+    assert ops.best_conv_algo(ops.conv_desc(32, 32, 1024, 1024, 3, 1, 1, ops.PAD_REFLECT), 1024) == ops.ALGO_WINOGRAD_F4
+    spec = GeneratorSpec(ngf=128, n_downsample=3, n_blocks=9, no_flow=True, norm="batch")
+    sd = synthetic_state_dict(spec, 6, "vid2vid")
+    rng = np.random.default_rng(0)
+    pose = torch.from_numpy(np.where(rng.random((1, 1, H, W)) < 0.02, rng.uniform(-1, 1, (1, 9, H, W)), -1.0).astype(np.float32))
+    prev = torch.tanh(torch.from_numpy(rng.standard_normal((1, 6, H, W)).astype(np.float32)))
+    R = torch.from_numpy(rng.standard_normal((1, 3, H, W)).astype(np.float32))
+
+    def oracle(dtype):
+        net = CompositeGenerator(9, 3, 6, 128, 3, 9, True, "batch").train()
+        net.load_state_dict(sd, strict=False)
+        net = net.to(dtype)
+        out = net(pose.to(dtype), prev.to(dtype), True)[0]
+        g = torch.autograd.grad((out * R.to(dtype)).sum() / R.numel(), list(net.parameters()))
+        return out.detach(), {k: v for (k, _), v in zip(net.named_parameters(), g)}
+
+    o64, g64 = oracle(torch.float64)
+    o32, g32 = oracle(torch.float32)
+    G = T.TrainableGenerator(spec, sd, "cuda:0")
+    p = torch.zeros(1, H, W, 12, device="cuda:0")
+    p[..., :9] = pose.permute(0, 2, 3, 1).cuda()
+    q = torch.zeros(1, H, W, 8, device="cuda:0")
+    q[..., :6] = prev.permute(0, 2, 3, 1).cuda()
+    r = torch.zeros(1, H, W, 4, device="cuda:0")
+    r[..., :3] = R.permute(0, 2, 3, 1).cuda()
+    out = G(p, q)
+    gh = torch.autograd.grad((out * r).sum() / R.numel(), list(G.parameters()), allow_unused=True)
+    gh = {k: v.cpu() for (k, _), v in zip(G.named_upstream_parameters().items(), gh)}
+    assert (out.detach()[..., :3].permute(0, 3, 1, 2).cpu().double() - o64).abs().max().item() <= 2e-4
+
+    def errs(g):
+        e = []
+        for k, ref in g64.items():
+            if ref.abs().max().item() > 1e-9:
+                e.append((g[k].double() - ref).abs().max().item() / ref.abs().max().item())
+        return np.array(e)
+
+    e32, eh = errs(g32), errs(gh)
+    print("full-width gradient vs fp64: CPU fp32 oracle median %.1e p90 %.1e max %.1e | HIP median %.1e p90 %.1e max %.1e"
+          % (np.median(e32), np.quantile(e32, 0.9), e32.max(), np.median(eh), np.quantile(eh, 0.9), eh.max()))
+    assert np.median(eh) <= 3 * np.median(e32) and np.quantile(eh, 0.9) <= 4 * np.quantile(e32, 0.9) and eh.max() <= 5 * e32.max()

@@ -2,10 +2,16 @@
 
 The frame recurrence (frame t consumes generated frames t-1, t-2) makes a sequence strictly serial,
 so the unit of independence is the reference's own: a *sequence* (sub-folder; recurrence reset on
-change_seq).  Long sequences are cut into contiguous chunks, each treated exactly like a separate
-sequence folder (zero previous frames + raw-only first frame, as --no_first_img prescribes).  One
-process per GPU; there is NO collective on the data path -- the only exchange is an all-gather of
-the finished uint8 frames (RCCL over xGMI; `gloo` in the CPU tests) to every rank / the writer.
+change_seq).  `plan_units` deals WHOLE sequences to the ranks by default -- the frames are then the
+single-GPU frames, whatever WORLD_SIZE is.  With `shard_chunks` (test.py --shard_chunks; BASELINE
+config 3) sequences are cut into contiguous chunks so that every rank has work; a chunk is treated
+exactly like a separate sequence folder (zero previous frames + raw-only first frame, as
+--no_first_img prescribes): the parity target is the oracle run on the same chunks, and the frames
+differ from the unsharded run's near the cuts.  The optional stitch pass narrows that: the ranks
+all-gather the FIFO of generated frames each chunk ended with (RCCL over xGMI: the prev-frame
+dependency, 2 frames per chunk) and every continuation chunk re-generates its first k frames from
+its predecessor's true tail.  One process per GPU; there is no other collective on the data path
+besides the optional all-gather of finished uint8 frames to every rank / the writer.
 """
 import os
 
@@ -70,6 +76,95 @@ def assign_chunks(seq_lengths, world, n_frames_G=3):
     for p in plan:
         p.sort(key=lambda u: (u[0], u[1]))
     return plan
+
+
+def plan_units(seq_lengths, world, n_frames_G=3, shard_chunks=False, how_many=None):
+    """Work units per rank: [(seq, pose_start, pose_stop, first_output_index)].
+
+    how_many caps the number of OUTPUT frames globally, in dataset order -- what the single-process frame loop's
+    `if i >= how_many: break` does -- before anything is dealt out.  Without shard_chunks only whole sequences are
+    dealt (longest first, to the least loaded rank): ranks may stay idle, but every frame equals the single-GPU
+    frame.  With shard_chunks the longest sequences are cut until every rank has work (assign_chunks)."""
+    lengths, budget = {}, how_many
+    for seq, n in seq_lengths.items():
+        n_out = n - (n_frames_G - 1)
+        if n_out <= 0:
+            continue
+        if budget is not None:
+            if budget <= 0:
+                break
+            n_out = min(n_out, budget)
+            budget -= n_out
+        lengths[seq] = n_out + (n_frames_G - 1)
+    if shard_chunks:
+        return assign_chunks(lengths, world, n_frames_G)
+    loads = [0] * world
+    plan = [[] for _ in range(world)]
+    for seq, n in sorted(lengths.items(), key=lambda kv: (-kv[1], kv[0])):
+        r = loads.index(min(loads))
+        plan[r].append((seq, 0, n, n_frames_G - 1))
+        loads[r] += n - (n_frames_G - 1)
+    for p in plan:
+        p.sort(key=lambda u: (u[0], u[1]))
+    return plan
+
+
+def exchange_tails(plan, rank, my_tails):
+    """The stitch pass's collective.  my_tails: one tensor per unit of plan[rank] (the FIFO of generated frames the
+    unit ended with; one shape everywhere).  All-gathers them (RCCL over xGMI / gloo) and returns
+    {(seq, pose_stop): tail} over the units of ALL ranks: the chunk whose first output frame is `pose_stop`
+    continues from that state."""
+    world = len(plan)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return {(u[0], u[2]): t for u, t in zip(plan[rank], my_tails)}
+    shapes = [None] * world
+    dist.all_gather_object(shapes, [tuple(t.shape) for t in my_tails])
+    kinds = {s for per_rank in shapes for s in per_rank}
+    if len(kinds) != 1:
+        raise NotImplementedError("stitching needs one frame geometry across all chunks, got %s" % sorted(kinds))
+    shape = kinds.pop()
+    umax = max(len(p) for p in plan)
+    ref = my_tails[0] if my_tails else None
+    dev = ref.device if ref is not None else (torch.device("cuda", torch.cuda.current_device())
+                                              if dist.get_backend() == "nccl" else torch.device("cpu"))
+    block = torch.zeros((umax,) + shape, dtype=torch.float32, device=dev)
+    for j, t in enumerate(my_tails):
+        block[j] = t
+    full = gather_frames(block)
+    out = {}
+    for r, p in enumerate(plan):
+        for j, (seq, s, e, fo) in enumerate(p):
+            out[(seq, e)] = full[r * umax + j]
+    return out
+
+
+def run_units(units, plan, rank, generate, stitch=0, rounds=1):
+    """Generator-agnostic driver of one rank's units.  generate(unit, start_state, n_frames) -> (frames, tail):
+    the unit's first n_frames output frames (all if None) starting from start_state (None: a fresh sequence --
+    zero previous frames, raw-only first frame) and the FIFO state after the last of them.
+    stitch = k > 0: after the chunk pass the tails are exchanged and every continuation chunk re-generates its
+    first k frames from its predecessor's tail (`rounds` times: a tail that was itself re-generated to the end of
+    its chunk is exact one round later).  With k >= chunk length and rounds >= world - 1 the result is the
+    unsharded sequence.  Returns [frames per unit]."""
+    frames, tails = [], []
+    for u in units:
+        f, t = generate(u, None, None)
+        frames.append(f)
+        tails.append(t)
+    for _ in range(rounds if stitch > 0 else 0):
+        known = exchange_tails(plan, rank, tails)
+        for j, u in enumerate(units):
+            seq, s, e, first_out = u
+            pred = known.get((seq, first_out)) if s > 0 else None
+            if pred is None:
+                continue
+            n_out = e - first_out
+            k = min(stitch, n_out)
+            f, t = generate(u, pred, k)
+            frames[j] = torch.cat([f, frames[j][k:]]) if torch.is_tensor(frames[j]) else list(f) + list(frames[j][k:])
+            if k == n_out:
+                tails[j] = t
+    return frames
 
 
 def gather_frames(local_frames):

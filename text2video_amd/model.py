@@ -78,64 +78,108 @@ def _real_A_u8(pose_map_u8):
 
 def run_test(opt, model=None, device="cuda:0", dataset=None):
     """The frame loop.  Returns a dict of counters/timings.  `dataset`: a ready PoseDataset (e.g.
-    PoseDataset.from_memory for the in-memory L2 driver) instead of the one scanned from opt.dataroot."""
+    PoseDataset.from_memory for the in-memory L2 driver) instead of the one scanned from opt.dataroot.
+
+    Under torchrun (WORLD_SIZE > 1) the sequences are dealt to the ranks (distributed.plan_units): whole
+    sequences by default, so every frame equals the single-GPU frame; --shard_chunks also cuts sequences into
+    chunks (each a fresh recurrence), and --stitch_frames K then re-generates the first K frames of every
+    continuation chunk from its predecessor's true last frames, all-gathered over RCCL.  --how_many counts
+    output frames globally, as the single-process loop does.  Every rank writes its own frames."""
     t_start = time.perf_counter()
     dataset = dataset if dataset is not None else PoseDataset(opt)
-    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
-        # one process per GPU (torchrun): sequences / sequence chunks are sharded over the ranks and
-        # every rank writes its own frames -- no collective on the data path (SURVEY 8e)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    plan = rank = None
+    limit = opt.how_many
+    if world > 1:
         from . import distributed as D
         rank, local_rank, world = D.init_from_env()
-        dataset.restrict(D.assign_chunks(dataset.seq_lengths(), world, opt.n_frames_G)[rank])
+        plan = D.plan_units(dataset.seq_lengths(), world, opt.n_frames_G, getattr(opt, "shard_chunks", False),
+                            None if opt.how_many in (None, float("inf")) else int(opt.how_many))
+        dataset.restrict(plan[rank])
+        limit = None            # already applied globally
         device = "cuda:%d" % local_rank
     if model is None:
         model = create_model(opt, device)
     vis = Visualizer(opt)
     dev = torch.device(device)
     cs = ops.round_up(3 * opt.n_frames_G, 4)
-    window = dev_maps = None
-    pending = None   # (event, pinned uint8 frame, path, real_A) of the previous frame: D2H overlaps the next frame
     pinned = {}      # shape -> ring of 3 pinned host buffers (allocating pinned memory per frame costs ~0.2 ms)
-    n = 0
-    t_data = t_loop0 = 0.0
+    counters = {"n": 0, "t_loop0": 0.0}
+    tails = {}       # unit index -> FIFO of generated frames the unit ended with (stitch pass)
 
-    def finish(p):
-        ev, host, a_path, real_a = p
-        ev.synchronize()
-        vis.save_images({"real_A": real_a, "fake_B": host.numpy()[..., :3].copy()}, a_path)
+    def frame_loop(items, tails, start_state=None):
+        window = dev_maps = None
+        pending = None   # (event, pinned uint8 frame, path, real_A) of the previous frame: D2H overlaps the next frame
+        cur_unit = None
 
-    for i, data in enumerate(dataset.iter_prefetch(opt.pose_workers, limit=opt.how_many)):
-        if n == 0:
-            t_loop0 = time.perf_counter()
-        A = data["A"]  # [tG, H, W, 3] uint8
-        H, W = A.shape[1], A.shape[2]
-        if data["change_seq"] or dev_maps is None or window.shape[:2] != (H, W):
-            model.reset()
-            window = torch.zeros(H, W, cs, dtype=torch.float32, device=dev)
-            dev_maps = [torch.from_numpy(A[f]).to(dev) for f in range(opt.n_frames_G)]
-        else:
-            dev_maps = dev_maps[1:] + [torch.from_numpy(A[-1]).to(dev, non_blocking=True)]
-        for f in range(opt.n_frames_G):
-            ops.pose_u8_to_f32(dev_maps[f], window, 3 * f)
-        out = model.inference_nhwc(window)
-        u8 = ops.tensor2im_u8(out)
-        ring = pinned.setdefault(tuple(u8.shape), [[torch.empty(u8.shape, dtype=torch.uint8, pin_memory=True) for _ in range(3)], 0])
-        host = ring[0][ring[1] % 3]     # the buffer of frame n-3: its JPEG copy was taken in finish(n-3)
-        ring[1] += 1
-        host.copy_(u8, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
+        def finish(p):
+            ev, host, a_path, real_a = p
+            ev.synchronize()
+            vis.save_images({"real_A": real_a, "fake_B": host.numpy()[..., :3].copy()}, a_path)
+
+        for data in items:
+            if counters["n"] == 0:
+                counters["t_loop0"] = time.perf_counter()
+            A = data["A"]  # [tG, H, W, 3] uint8
+            H, W = A.shape[1], A.shape[2]
+            if data["change_seq"] or dev_maps is None or window.shape[:2] != (H, W):
+                if cur_unit is not None and model.prev is not None:
+                    tails[cur_unit] = model.prev[0].clone()
+                model.reset()
+                if start_state is not None:      # stitch pass: continue from the predecessor chunk's last frames
+                    model.prev = [start_state[data["unit"]].clone()]
+                window = torch.zeros(H, W, cs, dtype=torch.float32, device=dev)
+                dev_maps = [torch.from_numpy(A[f]).to(dev) for f in range(opt.n_frames_G)]
+            else:
+                dev_maps = dev_maps[1:] + [torch.from_numpy(A[-1]).to(dev, non_blocking=True)]
+            cur_unit = data.get("unit")
+            for f in range(opt.n_frames_G):
+                ops.pose_u8_to_f32(dev_maps[f], window, 3 * f)
+            out = model.inference_nhwc(window)
+            u8 = ops.tensor2im_u8(out)
+            ring = pinned.setdefault(tuple(u8.shape), [[torch.empty(u8.shape, dtype=torch.uint8, pin_memory=True) for _ in range(3)], 0])
+            host = ring[0][ring[1] % 3]     # the buffer of frame n-3: its JPEG copy was taken in finish(n-3)
+            ring[1] += 1
+            host.copy_(u8, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            if pending is not None:
+                finish(pending)
+            pending = (ev, host, data["A_path"], _real_A_u8(A[-1]))
+            print("process image... %s" % data["A_path"])
+            counters["n"] += 1
         if pending is not None:
             finish(pending)
-        pending = (ev, host, data["A_path"], _real_A_u8(A[-1]))
-        print("process image... %s" % data["A_path"])
-        n += 1
-    if pending is not None:
-        finish(pending)
+        if cur_unit is not None and model.prev is not None:
+            tails[cur_unit] = model.prev[0].clone()
+
+    frame_loop(dataset.iter_prefetch(opt.pose_workers, limit=limit), tails)
+    n_first_pass = counters["n"]
+    stitch = int(getattr(opt, "stitch_frames", 0) or 0)
+    if plan is not None and stitch > 0:
+        # all-gather the chunk tails (2 generated frames per chunk) and re-generate the first `stitch` frames of every
+        # continuation chunk from its predecessor's; the JPEGs of those frames are overwritten
+        from . import distributed as D
+        if model.n_scales != 1:
+            raise NotImplementedError("--stitch_frames with n_scales_spatial > 1")
+        vis.flush()
+        units = plan[rank]
+        for _ in range(max(1, int(getattr(opt, "stitch_rounds", 1) or 1))):
+            known = D.exchange_tails(plan, rank, [tails[j] for j in range(len(units))])
+            redo = [(j, u) for j, u in enumerate(units) if u[1] > 0 and (u[0], u[3]) in known]
+            if redo:
+                dataset.restrict([u for _, u in redo], first_n=stitch)
+                redone = {}      # tails of the re-generated runs, under the restricted numbering
+                frame_loop(dataset.iter_prefetch(opt.pose_workers), redone,
+                           start_state={jj: known[(u[0], u[3])] for jj, (_, u) in enumerate(redo)})
+                for jj, (j, u) in enumerate(redo):
+                    if stitch >= u[2] - u[3]:      # re-generated to its end: this chunk's tail is the new one
+                        tails[j] = redone[jj]
     vis.flush()
     t_end = time.perf_counter()
-    stats = {"frames": n, "seconds_total": t_end - t_start,
-             "fps_loop": n / (t_end - t_loop0) if n else 0.0, "results_dir": vis.save_dir}
+    n = counters["n"]
+    stats = {"frames": n_first_pass, "frames_regenerated": n - n_first_pass, "seconds_total": t_end - t_start,
+             "fps_loop": n / (t_end - counters["t_loop0"]) if n else 0.0, "results_dir": vis.save_dir}
     if opt.timing_json:
         with open(opt.timing_json, "w") as fh:
             json.dump(stats, fh)

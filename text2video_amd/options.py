@@ -56,6 +56,11 @@ def _common(p):
     g("--no_hand_discs", action="store_true", help="do not draw the two radius-8 hand discs")
     g("--pose_workers", type=int, default=None, help="processes rasterising pose maps ahead of the GPU")
     g("--timing_json", type=str, default=None, help="write fps / per-stage timing to this file")
+    g("--shard_chunks", action="store_true", help="multi-GPU test.py: also cut sequences into chunks so that every rank "
+      "has work (each chunk restarts the recurrence; default: whole sequences only, frames identical to 1 GPU)")
+    g("--stitch_frames", type=int, default=0, metavar="K", help="with --shard_chunks: re-generate the first K frames of "
+      "every continuation chunk from its predecessor's last frames (all-gathered over RCCL)")
+    g("--stitch_rounds", type=int, default=1, help="repetitions of the stitch pass")
 
 
 class BaseOptions:

@@ -120,14 +120,19 @@ class PoseDataset:
         """{sequence: number of pose maps} -- input of distributed.assign_chunks"""
         return {seq: len(files) for seq, files in self.op.items()}
 
-    def restrict(self, units):
+    def restrict(self, units, first_n=None):
         """Keep only the output frames of this rank's work units [(seq, pose_start, pose_stop,
-        first_output_index)] (distributed.assign_chunks).  Every unit starts a fresh recurrence."""
+        first_output_index)] (distributed.plan_units); first_n: only the first n output frames of each (the stitch
+        pass).  Every unit starts a fresh recurrence; items report the index of their unit."""
         self.items = []
         self._unit_starts = set()
-        for seq, s, e, first_out in units:
+        self._unit_of = {}
+        for u, (seq, s, e, first_out) in enumerate(units):
             self._unit_starts.add((seq, first_out))
-            self.items += [(seq, i) for i in range(first_out, e)]
+            stop = e if first_n is None else min(e, first_out + first_n)
+            for i in range(first_out, stop):
+                self.items.append((seq, i))
+                self._unit_of[(seq, i)] = u
         self._window = self._window_key = None
 
     def _size(self, seq):
@@ -141,7 +146,10 @@ class PoseDataset:
         if seq not in self._sizes:
             self._sizes[seq] = self._size(seq)
         size = self._sizes[seq]
-        return (self.op[seq][i], size, get_img_params(opt, size), not opt.no_pose_crop, opt.remove_face_labels,
+        src = self.op[seq][i]
+        if isinstance(src, str):
+            src = os.path.abspath(src)      # the rasteriser workers do not share this process's working directory
+        return (src, size, get_img_params(opt, size), not opt.no_pose_crop, opt.remove_face_labels,
                 opt.basic_point_only, not opt.fast_pose, not opt.no_hand_discs)
 
     def _pose_map(self, seq, i):
@@ -192,7 +200,8 @@ class PoseDataset:
                     del cache[key]
                 change_seq = idx == 0 or self.items[idx - 1][0] != seq or \
                     (seq, i) in getattr(self, "_unit_starts", ())
-                yield {"A": np.stack(win), "A_path": self._name(seq, i), "seq": seq, "change_seq": change_seq}
+                yield {"A": np.stack(win), "A_path": self._name(seq, i), "seq": seq, "change_seq": change_seq,
+                       "unit": getattr(self, "_unit_of", {}).get((seq, i))}
         finally:
             for f in futures.values():      # an early exit (--how_many, an error): let the in-flight jobs drain
                 f.cancel()
@@ -205,7 +214,8 @@ class PoseDataset:
         else:
             self._window = [self._pose_map(seq, j) for j in range(i - self.tG + 1, i + 1)]
         self._window_key = (seq, i)
-        return {"A": np.stack(self._window), "A_path": self._name(seq, i), "seq": seq, "change_seq": change_seq}
+        return {"A": np.stack(self._window), "A_path": self._name(seq, i), "seq": seq, "change_seq": change_seq,
+                "unit": getattr(self, "_unit_of", {}).get((seq, i))}
 
     def __iter__(self):
         for i in range(len(self)):

@@ -625,7 +625,9 @@ class GradientExchange:
         import torch.distributed as dist
         self.pending, self.nbytes = [], 0
         self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
-        if self.world == 1:
+        # (T2V_TRAIN_FORCE_DIST=1 runs the collectives on a 1-rank group too: the RCCL path on a single GPU)
+        if self.world == 1 and not (os.environ.get("T2V_TRAIN_FORCE_DIST") == "1" and dist.is_available()
+                                    and dist.is_initialized()):
             return
         limit = bucket_mb * (1 << 20) // 4
         bucket, size = [], 0
