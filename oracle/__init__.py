@@ -11,7 +11,14 @@ restatement in generator_ref.py therefore follows SURVEY.md Appendix A (recollec
 public upstream architecture) with operator semantics pinned to the torch-0.4.1 sources that
 ARE vendored in the reference (cited per function).
 
-PINNED (host side): keypoints_ref.py restates keypoint2img.py / the L2 interpolation driver and
-is checked against golden vectors captured by importing the reference's own Python files
-(tests/golden/make_host_goldens.py).
+PINNED to outputs of the reference's own files (golden vectors under tests/golden/, each with the script that
+imported the reference file from where it lies):
+  * optim_ref.py (Adam)            <- $SP/torch/optim/adam.py                      make_adam_golden.py -> adam041.npz
+  * generator_ref.VGG19Features    <- $SP/torchvision/models/vgg.py                make_vgg_golden.py  -> vgg19_taps.npz
+  * ToTensor / Normalize / NEAREST resize, default conv init (host side of row a2, seeded weights)
+                                   <- $SP/torchvision/transforms/functional.py, $SP/torch/nn/modules/conv.py
+                                                                                   make_transforms_golden.py -> transforms.npz
+  * the pose rasteriser and both L2 interpolation drivers (product code in text2video_amd/keypoints.py, l2_driver.py,
+    which have no oracle twin: they are compared directly with captured reference outputs)
+                                   <- keypoint2img.py, interp_landmarks_motion*.py  make_host_goldens.py
 """

@@ -287,3 +287,41 @@ def test_oracle_resample_restatement_matches_modern_grid_sample():
     # identity flow returns the image (corner-aligned base grid), the anchor SURVEY 8c names
     img = torch.randn(1, 3, 12, 20)
     assert (resample(img, torch.zeros(1, 2, 12, 20)) - img).abs().max().item() <= 1e-5
+
+
+def test_transforms_and_conv_init_pinned_to_the_vendored_sources(lib_built):
+    """tests/golden/transforms.npz was produced by the reference's own vendored torchvision/transforms/functional.py
+    (to_tensor, normalize, resize NEAREST) and torch/nn/modules/conv.py (reset_parameters), imported where they lie
+    (make_transforms_golden.py).  The host side of row a2 and the seeded default init must reproduce it."""
+    import torch
+    from PIL import Image
+    from text2video_amd.generator import GeneratorSpec, default_init_bound, layer_shapes, synthetic_state_dict
+    from text2video_amd.options import TestOptions
+    from text2video_amd.pose_dataset import get_img_params
+    g = np.load(os.path.join(GOLD, "transforms.npz"))
+    # ToTensor + Normalize(.5,.5): the formula the GPU kernel and `_real_A_u8` restate, bit for bit
+    img = torch.from_numpy(g["img"])
+    want = torch.from_numpy(g["img_norm"])
+    assert torch.equal(((img.float() / 255.0 - 0.5) / 0.5).permute(2, 0, 1), want)
+    allv = torch.arange(256, dtype=torch.uint8).float()
+    assert torch.equal((allv / 255.0 - 0.5) / 0.5, torch.from_numpy(g["all_values_norm"])[0].reshape(-1))
+    # NEAREST resize as the dataset applies it: scaleHeight 512 on the L2 driver's 512x384 canvas -> 680x512
+    opt = TestOptions().parse(["--name", "x", "--resize_or_crop", "scaleHeight", "--loadSize", "512"])
+    assert get_img_params(opt, (512, 384)) == (680, 512)
+    got = np.asarray(Image.fromarray(g["sk"]).resize(get_img_params(opt, (512, 384)), Image.NEAREST))
+    assert got.shape == (512, 680, 3) and np.array_equal(got, g["sk_680x512"])
+    assert np.array_equal(np.asarray(Image.fromarray(g["small_src"]).resize((85, 64), Image.NEAREST)), g["small_85x64"])
+    assert np.array_equal(np.asarray(Image.fromarray(g["small_src"]).resize((40, 30), Image.NEAREST)), g["down_40x30"])
+    # torch-0.4.1 default conv init: stdv = 1/sqrt(in_channels*k*k), in_channels = dim 0 of a ConvTranspose2d weight
+    for transposed, cin, cout, k, s0, s1, s2, s3, stdv in g["conv_init"]:
+        assert abs(default_init_bound((int(s0), int(s1), int(s2), int(s3)), bool(transposed)) - stdv) <= 1e-15
+    spec = GeneratorSpec(ngf=16, n_downsample=2, n_blocks=2, no_flow=False, norm="batch")
+    sd = synthetic_state_dict(spec, 1, "uniform_fan_in")
+    seen_t = 0
+    for key, shape, role in layer_shapes(spec):
+        if role in ("conv_w", "convT_w") and not key.startswith("model_final_flow"):
+            b = default_init_bound(shape, role == "convT_w")
+            mx = sd[key].abs().max().item()
+            assert 0.9 * b <= mx <= b, (key, mx, b)
+            seen_t += role == "convT_w"
+    assert seen_t == 4      # the 2 + 2 transposed convs of the two decoders

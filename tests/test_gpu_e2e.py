@@ -38,7 +38,7 @@ def test_reference_command_line_end_to_end(tmp_path):
            "--dataset_mode", "pose", "--input_nc", "3", "--resize_or_crop", "scaleHeight", "--loadSize", "512",
            "--openpose_only", "--how_many", "1200", "--no_first_img", "--random_drop_prob", "0",
            # no checkpoint ships with the reference: explicit opt-in to seeded random weights, small net
-           "--synthetic_weights", "1", "--ngf", "32", "--n_blocks", "3", "--timing_json", "timing.json"]
+           "--synthetic_weights", "1", "--ngf", "32", "--n_blocks", "3", "--timing_json", "timing.json", "--write_video"]
     env = dict(os.environ, CUDA_VISIBLE_DEVICES="0")
     r = subprocess.run(cmd, cwd=work, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
@@ -51,6 +51,13 @@ def test_reference_command_line_end_to_end(tmp_path):
     im = np.asarray(Image.open(os.path.join(res, "tmp", "fake_B_0003.jpg")))
     assert im.shape == (512, 320, 3) and im.std() > 1.0          # 512 x 680 scaleHeight, central-width crop
     assert "process image..." in r.stdout
+    # --write_video: the mux stage (image2video*.py) on the frames just written, 4 JPEG samples per track
+    for seq in ("tmp", "tmp_smooth"):
+        mp4 = os.path.join(work, "results", "fadg0", "fadg0_%s.mp4" % seq)
+        blob = open(mp4, "rb").read()
+        assert blob[4:8] == b"ftyp" and b"moov" in blob and b"mp4v" in blob
+        first = open(os.path.join(res, seq, sorted(os.listdir(os.path.join(res, seq)))[0]), "rb").read()
+        assert first in blob                                      # the frame file itself is the video sample
     # without --synthetic_weights the missing checkpoint is a hard error (no silent fallback)
     r2 = subprocess.run(cmd[:cmd.index("--synthetic_weights")] + ["--ngf", "32"], cwd=work, env=env, capture_output=True,
                         text=True, timeout=600)

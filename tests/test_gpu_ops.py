@@ -201,6 +201,14 @@ def test_pose_u8_and_tensor2im_roundtrip():
     u8 = ops.tensor2im_u8(dst[..., 3:6].contiguous()).cpu()
     ref_u8 = ((ref + 1) / 2.0 * 255.0).clamp(0, 255).to(torch.uint8)
     assert (u8.int() - ref_u8.int()).abs().max().item() == 0
+    # pinned: ToTensor + Normalize(.5,.5) as the reference's vendored torchvision computes them
+    # (tests/golden/make_transforms_golden.py imports $SP/torchvision/transforms/functional.py:38-60,185-208)
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "transforms.npz"))
+    for src, want in ((g["img"], g["img_norm"]), (np.arange(256, dtype=np.uint8).reshape(16, 16, 1).repeat(3, 2), g["all_values_norm"])):
+        d = torch.zeros(src.shape[0], src.shape[1], 4, device=_dev())
+        ops.pose_u8_to_f32(torch.from_numpy(src).to(_dev()), d, 0)
+        assert torch.equal(d[..., :3].permute(2, 0, 1).cpu(), torch.from_numpy(want))
 
 
 def test_fullsize_resblock_conv_1024():

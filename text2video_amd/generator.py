@@ -86,7 +86,7 @@ def _gen_desc(spec, H, W, conv_algo=0):
 
 def layer_shapes(spec):
     """[(state-dict key, torch-layout shape, role)] for this generator; role in
-    {'conv_w','conv_b','norm_w','norm_b'}.  Shapes do not depend on H, W."""
+    {'conv_w','convT_w','conv_b','norm_w','norm_b'}.  Shapes do not depend on H, W."""
     lib = _lib.load()
     gd = _gen_desc(spec, 64, 64)
     keys = layer_keys(spec)
@@ -102,19 +102,29 @@ def layer_shapes(spec):
                     (ck[1] + ".weight", (1, cd.Cin, cd.kH, cd.kW), "conv_w"), (ck[1] + ".bias", (1,), "conv_b")]
         else:
             wshape = (cd.Cin, cd.Cout, 3, 3) if kind == "convT" else (cd.Cout, cd.Cin, cd.kH, cd.kW)
-            out += [(ck + ".weight", wshape, "conv_w"), (ck + ".bias", (cd.Cout,), "conv_b")]
+            out += [(ck + ".weight", wshape, "convT_w" if kind == "convT" else "conv_w"), (ck + ".bias", (cd.Cout,), "conv_b")]
         if nk is not None and spec.norm == "batch":
             out += [(nk + ".weight", (cd.Cout,), "norm_w"), (nk + ".bias", (cd.Cout,), "norm_b")]
     return out
 
 
+def default_init_bound(weight_shape, transposed=False):
+    """stdv of torch-0.4.1's `_ConvNd.reset_parameters` ($SP/torch/nn/modules/conv.py:40-47) for a weight of this
+    shape: 1/sqrt(in_channels * kH * kW); a ConvTranspose2d weight is [in, out, kH, kW]."""
+    cin = weight_shape[0] if transposed else weight_shape[1]
+    return 1.0 / float(np.sqrt(cin * weight_shape[2] * weight_shape[3]))
+
+
 def synthetic_state_dict(spec, seed=1, init="uniform_fan_in", flow_gain=1.0):
     """Deterministic random-init weights (numpy RNG, platform independent) in upstream key names.
 
-    init='uniform_fan_in': U(-1/sqrt(fan_in), +) for conv weight AND bias = torch-0.4.1 default
-        ($SP/torch/nn/modules/conv.py:40-47; fan_in = weight.size(1)*kH*kW) -- the BASELINE.md /
-        SURVEY 8(d) config-2 weights.
-    init='vid2vid': vid2vid's weights_init, N(0,0.02) conv weights [RECALL].
+    init='uniform_fan_in': U(-stdv, +stdv) for conv weight AND bias = torch-0.4.1 default
+        ($SP/torch/nn/modules/conv.py:40-47: stdv = 1/sqrt(in_channels*kH*kW), where in_channels is weight.size(1)
+        of a Conv2d and weight.size(0) of a ConvTranspose2d; pinned against the vendored file by
+        tests/golden/make_transforms_golden.py -> transforms.npz `conv_init`) -- the BASELINE.md / SURVEY 8(d)
+        config-2 weights.
+    init='vid2vid': vid2vid's weights_init, N(0,0.02) conv weights [RECALL]; it leaves the conv biases at the
+        default init above.
     Norm affine params (norm='batch'): gamma ~ N(1,0.02) (weights_init), beta ~ N(0,0.1) so the
     affine path is exercised.
     flow_gain scales model_final_flow's weight and bias: a random-init flow head times the x20
@@ -126,8 +136,8 @@ def synthetic_state_dict(spec, seed=1, init="uniform_fan_in", flow_gain=1.0):
     sd = {}
     bound = 1.0
     for key, shape, role in layer_shapes(spec):
-        if role == "conv_w":
-            bound = 1.0 / np.sqrt(shape[1] * shape[2] * shape[3])
+        if role in ("conv_w", "convT_w"):
+            bound = default_init_bound(shape, role == "convT_w")
             a = rng.normal(0.0, 0.02, size=shape) if init == "vid2vid" else rng.uniform(-bound, bound, size=shape)
         elif role == "conv_b":
             a = rng.uniform(-bound, bound, size=shape)

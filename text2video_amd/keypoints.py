@@ -101,8 +101,12 @@ def stamp(img, xs, ys, bw, rgb, caps):
 
 
 def filled_disc(img, cx, cy, radius, rgb):
-    """Filled circle by the midpoint algorithm with horizontal spans (OpenCV-style; unverifiable
-    here -- see module docstring)."""
+    """cv2.circle(img, (cx, cy), radius, rgb, -1) as the reference calls it (keypoint2img.py:159-160).  With
+    thickness < 0, the default LINE_8 and shift 0, cv::circle runs drawing.cpp's integer `Circle(img, center, radius,
+    color, fill = true)`: the midpoint walk err / dx / dy / plus / minus below, painting per step the horizontal spans
+    rows cy -+ dy over [cx - dx, cx + dx] and rows cy -+ dx over [cx - dy, cx + dy], clipped to the image
+    [RECALL of OpenCV's modules/imgproc/src/drawing.cpp -- OpenCV is not in this image, so the rule cannot be
+    run against the real library; the goldens were captured with the two discs stubbed out]."""
     h, w = img.shape[:2]
 
     def span(y, x0, x1):

@@ -176,10 +176,25 @@ def run_test(opt, model=None, device="cuda:0", dataset=None):
                     if stitch >= u[2] - u[3]:      # re-generated to its end: this chunk's tail is the new one
                         tails[j] = redone[jj]
     vis.flush()
+    videos = []
+    if getattr(opt, "write_video", False):
+        # the reference's next stage (image2video*.py, text2video_audio.sh:44) on the frames just written; under
+        # --shard_chunks a sequence's frames are spread over the ranks' runs of this loop: mux after all have finished
+        if plan is not None and getattr(opt, "shard_chunks", False):
+            print("note: --write_video skipped under --shard_chunks (run vid2vid/image2video.py once all ranks are done)")
+        else:
+            from . import mux
+            import glob
+            for seq_dir in sorted(glob.glob(os.path.join(vis.save_dir, "*"))):
+                frames = sorted(glob.glob(os.path.join(seq_dir, "fake_B_*.jpg")))
+                if frames and os.path.isdir(seq_dir):
+                    out = os.path.join(os.path.dirname(vis.save_dir), "%s_%s.mp4" % (opt.name, os.path.basename(seq_dir)))
+                    mux.write_mp4(frames, out, mux.FPS, getattr(opt, "video_audio", None) or None)
+                    videos.append(out)
     t_end = time.perf_counter()
     n = counters["n"]
     stats = {"frames": n_first_pass, "frames_regenerated": n - n_first_pass, "seconds_total": t_end - t_start,
-             "fps_loop": n / (t_end - counters["t_loop0"]) if n else 0.0, "results_dir": vis.save_dir}
+             "fps_loop": n / (t_end - counters["t_loop0"]) if n else 0.0, "results_dir": vis.save_dir, "videos": videos}
     if opt.timing_json:
         with open(opt.timing_json, "w") as fh:
             json.dump(stats, fh)

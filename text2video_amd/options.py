@@ -56,6 +56,9 @@ def _common(p):
     g("--no_hand_discs", action="store_true", help="do not draw the two radius-8 hand discs")
     g("--pose_workers", type=int, default=None, help="processes rasterising pose maps ahead of the GPU")
     g("--timing_json", type=str, default=None, help="write fps / per-stage timing to this file")
+    g("--write_video", action="store_true", help="after the frame loop, mux every sequence's frames into "
+      "results/<name>/<name>_<seq>.mp4 at 25 fps (the reference's image2video*.py stage; text2video_amd/mux.py)")
+    g("--video_audio", type=str, default=None, help="--write_video: .wav / .mp3 sound track")
     g("--shard_chunks", action="store_true", help="multi-GPU test.py: also cut sequences into chunks so that every rank "
       "has work (each chunk restarts the recurrence; default: whole sequences only, frames identical to 1 GPU)")
     g("--stitch_frames", type=int, default=0, metavar="K", help="with --shard_chunks: re-generate the first K frames of "
