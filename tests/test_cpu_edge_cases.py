@@ -90,3 +90,22 @@ def test_chunk_restriction_resets_recurrence(tmp_path):
         assert items[0][1] and not any(c for _, c in items[1:])      # exactly one recurrence reset per chunk
         outs += [os.path.basename(p) for p, _ in items]
     assert sorted(outs) == ["%05d.json" % i for i in range(2, 9)]    # every output frame exactly once
+
+
+def test_face_region_rule():
+    """--add_face_disc crop [RECALL upstream get_face_region]: bounding box of the nose-neck colour over ALL frames of
+    the chunk, centred on its midpoint, centre clamped into the image, None without the colour."""
+    import numpy as np
+    from text2video_amd.keypoints import NOSE_NECK_RGB
+    from text2video_amd.train import get_face_region
+    a = np.zeros((2, 512, 320, 3), np.uint8)
+    assert get_face_region(a, 512) is None
+    a[0, 100:140, 150:154] = NOSE_NECK_RGB
+    a[1, 120:180, 160:166] = NOSE_NECK_RGB
+    ys, ye, xs, xe = get_face_region(a, 512)
+    assert (ye - ys, xe - xs) == (128, 128)
+    assert (ys + ye) // 2 == (100 + 179) // 2 and (xs + xe) // 2 == (150 + 165) // 2
+    b = np.zeros((64, 64, 3), np.uint8)
+    b[0:3, 60:64] = NOSE_NECK_RGB                      # at the corner: the centre is clamped so the crop stays inside
+    ys, ye, xs, xe = get_face_region(b, 128)            # side 32
+    assert (ys, ye, xs, xe) == (0, 32, 31, 63)

@@ -563,9 +563,10 @@ class HipVGG19Features(torch.nn.Module):
 
 def vgg_loss(vgg, fake, real):
     """VGGLoss [RECALL upstream models/networks.py]: sum_i w_i * L1(vgg(fake)_i, vgg(real)_i.detach()),
-    w = 1/32, 1/16, 1/8, 1/4, 1; inputs above 1024 px wide are 2x average-pooled first."""
-    while fake.shape[2] > 1024:
-        fake, real = _AvgPool.apply(fake), _AvgPool.apply(real)
+    w = 1/32, 1/16, 1/8, 1/4, 1.  Upstream first halves inputs wider than 1024 px with AvgPool2d(2, 2); that only
+    happens in multi-scale (n_scales_spatial > 1) training, which this train step does not cover."""
+    if fake.shape[2] > 1024:
+        raise NotImplementedError("vgg_loss: inputs wider than 1024 px (upstream's AvgPool2d(2,2) pre-scaling)")
     with torch.no_grad():
         fr = vgg(real)
     ff = vgg(fake)
@@ -672,23 +673,29 @@ def allreduce_gradients(params, bucket_mb=64):
 # ------------------------------------------------------------------------------------------------
 # face discriminator crop (--add_face_disc) and the training loop
 # ------------------------------------------------------------------------------------------------
-def get_face_region(pose_map_u8, fine_size):
-    """(ys, ye, xs, xe) of the face crop: centred on the pixels of the nose-neck limb colour
-    [153,0,51] (keypoint2img.py:180) in the uint8 pose map, side fine_size//32*8 (=128 at 512)
-    [RECALL upstream Vid2VidModelD.get_face_region]."""
+def get_face_region(pose_maps_u8, fine_size):
+    """(ys, ye, xs, xe) of the face crop for a chunk of frames, or None when no frame shows the key colour.
+
+    [RECALL upstream Vid2VidModelD.get_face_region, --openpose_only branch]: the pixels of ALL frames of the chunk
+    whose colour is the nose-neck limb's [153,0,51] (keypoint2img.py:180; upstream tests the normalised map for
+    R in (0.19,0.21), G < -0.99, B in (-0.61,-0.59), which is that uint8 colour) give one bounding box; the crop is
+    centred on the box's midpoint, side fine_size//32*8 (128 at fineSize 512), the centre clamped to
+    [side/2, dim-1-side/2]; with no such pixel upstream returns an empty region -- the face terms are skipped then.
+    pose_maps_u8: [H,W,3] or [F,H,W,3]."""
     import numpy as np
     from .keypoints import NOSE_NECK_RGB
-    H, W = pose_map_u8.shape[:2]
+    a = np.asarray(pose_maps_u8)
+    if a.ndim == 3:
+        a = a[None]
+    H, W = a.shape[1:3]
     side = max(8, fine_size // 32 * 8)
-    ys, xs = np.nonzero((pose_map_u8 == np.array(NOSE_NECK_RGB, np.uint8)).all(2))
-    if ys.size:
-        # the limb runs from the nose down to the neck: the face sits around its upper end
-        cy, cx = int(ys.min()), int(xs[ys.argmin()])
-    else:
-        cy, cx = H // 4, W // 2
-    y0 = min(max(cy - side // 2, 0), H - side)
-    x0 = min(max(cx - side // 2, 0), W - side)
-    return y0, y0 + side, x0, x0 + side
+    _, ys, xs = np.nonzero((a == np.array(NOSE_NECK_RGB, np.uint8)).all(3))
+    if not ys.size:
+        return None
+    yc, xc = (int(ys.min()) + int(ys.max())) // 2, (int(xs.min()) + int(xs.max())) // 2
+    yc = max(side // 2, min(H - 1 - side // 2, yc))
+    xc = max(side // 2, min(W - 1 - side // 2, xc))
+    return yc - side // 2, yc + side // 2, xc - side // 2, xc + side // 2
 
 
 def discriminator_state_dict(input_nc, ndf, n_layers, num_D, norm, seed):
@@ -722,6 +729,18 @@ class Vid2VidTrainer:
 
     def __init__(self, opt, device="cuda:0", seed=1):
         self.opt, self.device = opt, device
+        # flags of upstream's train.py that would train a DIFFERENT configuration here: refuse instead of ignoring
+        for flag, bad, why in (("no_lsgan", bool(getattr(opt, "no_lsgan", False)), "only the LSGAN (MSE) objective is built"),
+                               ("n_scales_spatial", getattr(opt, "n_scales_spatial", 1) > 1, "the train step covers the global generator"),
+                               ("max_frames_backpropagate", getattr(opt, "max_frames_backpropagate", 1) > 1,
+                                "generated previous frames are always detached (the recipe's default, 1)"),
+                               ("use_single_G", bool(getattr(opt, "use_single_G", False)), "no first-frame generator"),
+                               ("fg", bool(getattr(opt, "fg", False)), "no foreground / background generators")):
+            if bad:
+                raise NotImplementedError("--%s: %s" % (flag, why))
+        for flag, on in (("pool_size", getattr(opt, "pool_size", 1) > 1), ("niter_fix_global", getattr(opt, "niter_fix_global", 0) > 0)):
+            if on:
+                print("warning: --%s has no effect here (single-scale training, no image pool)" % flag, flush=True)
         input_nc = opt.label_nc if opt.label_nc != 0 else opt.input_nc
         self.spec = GeneratorSpec(input_nc=input_nc * opt.n_frames_G, prev_nc=(opt.n_frames_G - 1) * opt.output_nc,
                                   ngf=opt.ngf, n_downsample=opt.n_downsample_G, n_blocks=opt.n_blocks,
@@ -762,8 +781,15 @@ class Vid2VidTrainer:
             else:
                 print("VGG loss off: no --vgg_weights <torchvision vgg19 .pth> given (the file is not in the reference "
                       "tree; --no_vgg silences this)", flush=True)
-        self.optG = FusedAdam(self.G.parameters(), opt.lr, (opt.beta1, 0.999))
-        self.optD = FusedAdam(d_params, opt.lr, (opt.beta1, 0.999))
+        lr_g = lr_d = opt.lr
+        betas = (opt.beta1, 0.999)
+        if getattr(opt, "TTUR", False):    # [RECALL upstream: two time-scale update rule]
+            betas, lr_g, lr_d = (0.0, 0.9), opt.lr / 2.0, opt.lr * 2.0
+        self.lr_scale = (lr_g / opt.lr, lr_d / opt.lr)
+        self.optG = FusedAdam(self.G.parameters(), lr_g, betas)
+        self.optD = FusedAdam(d_params, lr_d, betas)
+        if getattr(opt, "load_pretrain", ""):
+            self.load(opt.which_epoch, opt.load_pretrain)
         self.comm_bytes, self.comm_ms = 0, 0.0
         self.time_comm = os.environ.get("T2V_TRAIN_COMM_TIMING", "0") == "1"
 
@@ -929,13 +955,14 @@ class Vid2VidTrainer:
     def update_learning_rate(self, epoch):
         """linear decay to zero over the niter_decay epochs after `niter` [RECALL upstream update_learning_rate]"""
         lr = self.opt.lr * max(0.0, 1.0 - (epoch - self.opt.niter) / float(max(1, self.opt.niter_decay)))
-        print("update learning rate: %f -> %f" % (self.optG.lr, lr), flush=True)
-        self.optG.lr = self.optD.lr = lr
+        print("update learning rate: %f -> %f" % (self.optG.lr / self.lr_scale[0], lr), flush=True)
+        self.optG.lr, self.optD.lr = lr * self.lr_scale[0], lr * self.lr_scale[1]
 
-    def load(self, epoch_label):
-        """--continue_train: the nets saved by save() (upstream file names); missing files keep their initialisation"""
+    def load(self, epoch_label, directory=None):
+        """--continue_train / --load_pretrain DIR: the nets saved by save() (upstream file names); missing files keep
+        their initialisation"""
         import os
-        d = os.path.join(self.opt.checkpoints_dir, self.opt.name)
+        d = directory or os.path.join(self.opt.checkpoints_dir, self.opt.name)
         nets = [("G0", self.G), ("D", self.D)] + ([("D_f", self.Df)] if self.Df is not None else []) + \
                [("D_T%d" % sc, dt) for sc, dt in enumerate(self.DT)]
         for tag, net in nets:
@@ -944,15 +971,24 @@ class Vid2VidTrainer:
                 print("continue_train: %s not found, keeping the initial weights" % path, flush=True)
                 continue
             sd = torch.load(path, map_location="cpu")
+            sd = {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}    # saved from nn.DataParallel
             with torch.no_grad():
                 for k, p in net.named_upstream_parameters().items():
+                    if k not in sd:
+                        print("continue_train: %s has no %s, keeping its initial value" % (path, k), flush=True)
+                        continue
                     p.copy_(sd[k].to(p.device, torch.float32))
                     p._t2v_packs = None
 
-    def save(self, epoch_label):
+    def save(self, epoch_label, progress=None):
+        """progress = (epoch, samples done in it): written to iter.txt beside the nets every time `latest` is saved, so
+        that --continue_train never pairs newer weights with an older position."""
         import os
         d = os.path.join(self.opt.checkpoints_dir, self.opt.name)
         os.makedirs(d, exist_ok=True)
+        if progress is not None and epoch_label == "latest":
+            with open(os.path.join(d, "iter.txt"), "w") as fh:
+                fh.write("%d\n%d\n" % (int(progress[0]), int(progress[1])))
         torch.save({k: v.detach().cpu() for k, v in self.G.named_upstream_parameters().items()},
                    os.path.join(d, "%s_net_G0.pth" % epoch_label))
         torch.save({k: v.detach().cpu() for k, v in self.D.named_upstream_parameters().items()},
@@ -982,6 +1018,9 @@ def run_train(opt, steps=None):
     dev = "cuda:%d" % local_rank
     torch.cuda.set_device(local_rank)
     trainer = Vid2VidTrainer(opt, dev)
+    if rank == 0 and getattr(opt, "batchSize", world) not in (1, world):
+        print("warning: --batchSize %d, but the batch is one clip per rank: %d (launch with torchrun --nproc-per-node %d)"
+              % (opt.batchSize, world, opt.batchSize), flush=True)
     F_ = opt.max_frames_per_gpu
     synthetic = getattr(opt, "synthetic_data", False)
     ds = None
@@ -1006,11 +1045,11 @@ def run_train(opt, steps=None):
 
     def checkpoint(label, epoch, done):
         if rank == 0:
-            trainer.save(label)
-            np.savetxt(iter_path, (epoch, done), delimiter=",", fmt="%d")
+            trainer.save(label, (epoch, done))
 
     rng = np.random.default_rng(100 + rank)          # synthetic data: every rank has its own sequence
     tG = opt.n_frames_G
+    last_pos = (start_epoch, epoch_iter)
     stats, it, total_samples = [], 0, (start_epoch - 1) * per_epoch * world + epoch_iter
     last_epoch = opt.niter + opt.niter_decay
     for epoch in range(start_epoch, last_epoch + 1):
@@ -1060,7 +1099,10 @@ def run_train(opt, steps=None):
                     if not trainer.spec.no_flow:
                         real_prev = torch.zeros(len(fr), H, W, 4, device=dev)
                         real_prev[..., :3] = (B[[t - 1 for t in fr]].float() / 255.0 - 0.5) / 0.5
-                    boxes = [get_face_region(clip["A"][t], min(H, W)) for t in fr] if opt.add_face_disc else None
+                    boxes = None
+                    if opt.add_face_disc:      # one region for the chunk (upstream boxes the whole batch of frames)
+                        box = get_face_region(clip["A"][fr], opt.fineSize)
+                        boxes = [box] * len(fr) if box is not None else None
                     losses, prev = trainer.train_step(pose, real, boxes, prev, real_prev=real_prev)
                 what = ", seq %s, %d frames %dx%d step %d" % (clip["seq"], T_ - tG + 1, H, W, clip["t_step"])
             torch.cuda.synchronize()
@@ -1072,10 +1114,12 @@ def run_train(opt, steps=None):
                       % (it - 1, epoch, what, 1e3 * stats[-1], trainer.comm_bytes / 2**20,
                          ", %.1f ms exposed" % trainer.comm_ms if trainer.time_comm else "",
                          " ".join("%s: %.3f" % kv for kv in losses.items())), flush=True)
+            last_pos = (epoch, (k + 1) * world)
             if total_samples % max(1, opt.save_latest_freq) < world:
                 checkpoint("latest", epoch, (k + 1) * world)
         else:
             epoch_iter = 0
+            last_pos = (epoch + 1, 0)
             if epoch % max(1, opt.save_epoch_freq) == 0:
                 checkpoint("latest", epoch + 1, 0)
                 checkpoint(str(epoch), epoch + 1, 0)
@@ -1085,6 +1129,6 @@ def run_train(opt, steps=None):
                 ds.update_training_batch(epoch // max(1, opt.niter_step))
             continue
         break   # the step cap was reached
-    if rank == 0:
-        trainer.save("latest")
+    if rank == 0:      # the final (or step-capped) save carries its position too
+        trainer.save("latest", last_pos)
     return {"ms_per_step": 1e3 * float(np.median(stats)) if stats else 0.0, "steps": it, "world": world}
