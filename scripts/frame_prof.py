@@ -1,0 +1,28 @@
+"""N frames of the config-2 generator (flow on unless --noflow) for rocprofv3: nothing but the frame loop.
+Usage: [T2V_STREAMS=1] frame_prof.py [--frames 40] [--noflow] [--size 512]"""
+import argparse, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from text2video_amd import ops
+from text2video_amd.generator import GeneratorSpec, HipGenerator, Vid2VidModelG, synthetic_state_dict
+ap = argparse.ArgumentParser()
+ap.add_argument("--frames", type=int, default=40)
+ap.add_argument("--noflow", action="store_true")
+ap.add_argument("--size", type=int, default=512)
+a = ap.parse_args()
+dev = torch.device("cuda:0")
+spec = GeneratorSpec(ngf=128, n_downsample=3, n_blocks=9, no_flow=a.noflow, norm="batch")
+model = Vid2VidModelG([HipGenerator(spec, dev).load_state_dict(synthetic_state_dict(spec, 1, flow_gain=0.1))])
+H = W = a.size
+rng = np.random.default_rng(0)
+win = torch.zeros(H, W, 12, device=dev)
+win[..., :9] = torch.from_numpy(np.where(rng.random((H, W, 1)) < 0.02, rng.uniform(-1, 1, (H, W, 9)), -1.0).astype(np.float32)).to(dev)
+for _ in range(10):
+    model.inference_nhwc(win)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(a.frames):
+    model.inference_nhwc(win)
+torch.cuda.synchronize()
+print("FRAMES %d  %.3f ms/frame" % (a.frames + 10, 1e3 * (time.perf_counter() - t0) / a.frames))

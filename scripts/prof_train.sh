@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out/prof_train
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_train -o train -- python scripts/train_bench.py --iters 3 "$@" > gpurun_out/prof_train/log.txt 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_train -o train -- python scripts/train_bench.py --iters 2 "$@" > gpurun_out/prof_train/log.txt 2>&1
 tail -1 gpurun_out/prof_train/log.txt
 python - <<'PY'
 import csv, glob

@@ -1,61 +1,53 @@
-"""Time one train iteration pieces at config-5 size on one GPU: generator forward+backward for
-`frames` frames (1 sequence per GPU, max_frames_per_gpu 2), discriminator losses, Adam."""
+"""Time Vid2VidTrainer.train_step at config-5 size on one GPU (1 sequence per GPU, max_frames_per_gpu 2): generator
+(with the flow branch unless --no_flow) forward + backward, 2-scale discriminator (+ face discriminator), all losses,
+Adam.  Usage: train_bench.py [--size 512] [--iters 3] [--no_flow] [--vgg] [--no_face]"""
 import argparse, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
 import torch
 from text2video_amd import train as T
-from text2video_amd.generator import GeneratorSpec, synthetic_state_dict
-from oracle.generator_ref import MultiscaleDiscriminator, weights_init
+from text2video_amd.options import TrainOptions
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--size", type=int, default=512)
-ap.add_argument("--ngf", type=int, default=128)
 ap.add_argument("--frames", type=int, default=2)
 ap.add_argument("--iters", type=int, default=3)
+ap.add_argument("--no_flow", action="store_true")
+ap.add_argument("--no_face", action="store_true")
 ap.add_argument("--vgg", action="store_true", help="add the VGG19 perceptual loss (seeded random weights)")
 args = ap.parse_args()
+argv = ["--name", "b", "--dataset_mode", "pose", "--input_nc", "3", "--openpose_only", "--num_D", "2", "--max_frames_per_gpu",
+        str(args.frames), "--n_scales_temporal", "0", "--no_first_img", "--fineSize", str(args.size)]
+argv += ["--vgg_random_init"] if args.vgg else ["--no_vgg"]
+argv += ["--no_flow"] if args.no_flow else []
+argv += [] if args.no_face else ["--add_face_disc"]
+opt = TrainOptions().parse(argv)
 dev = "cuda:0"
 H = W = args.size
-spec = GeneratorSpec(ngf=args.ngf, n_downsample=3, n_blocks=9, no_flow=True, norm="batch")
-G = T.TrainableGenerator(spec, synthetic_state_dict(spec, 1, "vid2vid"), dev)
-Dr = MultiscaleDiscriminator(6, 64, 3, 2, "batch")
-gen = torch.Generator().manual_seed(1); Dr.apply(lambda m: weights_init(m, gen))
-D = T.TrainableDiscriminator(6, Dr.state_dict(), 64, 3, 2, "batch", dev)
-optG, optD = T.FusedAdam(G.parameters()), T.FusedAdam(D.parameters())
-vgg = T.HipVGG19Features(T.vgg19_random_state_dict(5), dev) if args.vgg else None
 F = args.frames
-pose = torch.randn(F, H, W, 12, device=dev).clamp(-1, 1); pose[..., 9:] = 0
-real = torch.tanh(torch.randn(F, H, W, 4, device=dev)); real[..., 3] = 0
-A = pose[..., 6:9]
-z2 = torch.zeros(F, H, W, 2, device=dev)
-def d_in(img): return torch.cat([A, img[..., :3], z2], -1).contiguous()
+tr = T.Vid2VidTrainer(opt, dev, seed=1)
+rng = np.random.default_rng(0)
+pose = torch.zeros(F, H, W, 12, device=dev)
+pose[..., :9] = torch.from_numpy(np.where(rng.random((F, H, W, 1)) < 0.02, rng.uniform(-1, 1, (F, H, W, 9)), -1.0).astype(np.float32)).to(dev)
+real = torch.zeros(F, H, W, 4, device=dev)
+real[..., :3] = torch.tanh(torch.from_numpy(rng.standard_normal((F, H, W, 3)).astype(np.float32))).to(dev)
+real_prev = torch.cat([real[1:], real[:1]], 0).contiguous() if not args.no_flow else None
+side = max(8, args.size // 32 * 8)
+boxes = None if args.no_face else [(H // 8, H // 8 + side, (W - side) // 2, (W - side) // 2 + side)] * F
+prev = torch.zeros(1, H, W, 8, device=dev)
+prev[..., :6] = torch.tanh(torch.from_numpy(rng.standard_normal((1, H, W, 6)).astype(np.float32))).to(dev)
+
+
 def step():
-    with T.batched_weight_gradients(optG.params):
-        return _step()
-def _step():
-    prev = torch.tanh(torch.randn(1, H, W, 8, device=dev)); prev[..., 6:] = 0
-    fakes = []
-    for f in range(F):
-        fk = G(pose[f:f + 1], prev); fakes.append(fk)
-        nprev = torch.zeros_like(prev); nprev[..., :3] = prev[..., 3:6]; nprev[..., 3:6] = fk.detach()[..., :3]; prev = nprev
-    fake = torch.cat(fakes, 0)
-    pr = D(d_in(real)); pfd = D(d_in(fake.detach()))
-    loss_D = 0.5 * (T.gan_loss(pfd, False) + T.gan_loss(pr, True))
-    pfg = D(d_in(fake))
-    loss_G = T.gan_loss(pfg, True) + T.feature_matching_loss(pfg, pr)
-    if vgg is not None:
-        loss_G = loss_G + T.vgg_loss(vgg, fake, real) * 10.0
-    optG.zero_grad(); optD.zero_grad()
-    gG = torch.autograd.grad(loss_G, list(G.parameters()), retain_graph=True)
-    gD = torch.autograd.grad(loss_D, list(D.parameters()))
-    for p, g in zip(G.parameters(), gG): p.grad = g
-    for p, g in zip(D.parameters(), gD): p.grad = g
-    optG.step(); optD.step()
-    return loss_G.item(), loss_D.item()
-step(); torch.cuda.synchronize()
+    return tr.train_step(pose, real, boxes, prev.clone(), real_prev=real_prev)[0]
+
+
+step(); step(); torch.cuda.synchronize()
 t0 = time.perf_counter()
-for _ in range(args.iters): lg, ld = step()
+for _ in range(args.iters):
+    losses = step()
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / args.iters
-print("train iteration %dx%d ngf%d, %d frames: %.1f ms/step (loss_G %.3f loss_D %.3f), peak mem %.1f GB"
-      % (H, W, args.ngf, F, dt * 1e3, lg, ld, torch.cuda.max_memory_allocated() / 2**30))
+print("train step %dx%d, %d frames, %s%s%s: %.1f ms/step, peak mem %.1f GB | %s"
+      % (H, W, F, "no flow" if args.no_flow else "flow branch on", "" if args.no_face else " + face D", " + VGG" if args.vgg else "",
+         dt * 1e3, torch.cuda.max_memory_allocated() / 2**30, " ".join("%s %.3f" % kv for kv in losses.items())))

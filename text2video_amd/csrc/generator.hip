@@ -174,15 +174,27 @@ struct Runner {
         if (is_winograd(L.cd.algo)) {
             const int M = L.cd.H * L.cd.W;
             T2V_TRY(winograd_forward(ctx, s, &L.cd, x, w.w, w.bias, y, b.stats[sc], b.wino[sc], 7));
-            T2V_TRY(launch_inorm_finalize_winograd(s, b.stats[sc], wino_m(L.cd.algo), L.cd.H, L.cd.W, Cout, g.eps,
-                                                   b.mean_rstd[sc], 1, b.fin[sc]));
             const float* gam = g.norm_affine ? w.gamma : nullptr;
             const float* bet = g.norm_affine ? w.beta : nullptr;
             if (g.norm_affine) T2V_REQUIRE(gam && bet, "layer %d: norm_affine=1 but gamma/beta missing", li - 1);
+            const int wm = wino_m(L.cd.algo);
+            const int nparts = wino_tiles_padded(&L.cd, L.cd.algo) / (128 / (wm * wm));
+            if (inorm_fused_ok(nparts, Cout))   // the apply pass pools the (few) partials itself: no finalize launch
+                return launch_inorm_apply_partials(s, y, b.stats[sc], nparts, nparts, 0, M, wm, L.cd.H, L.cd.W, Cout, g.eps,
+                                                   gam, bet, res1, res2, y, (long)M, relu);
+            T2V_TRY(launch_inorm_finalize_winograd(s, b.stats[sc], wm, L.cd.H, L.cd.W, Cout, g.eps, b.mean_rstd[sc], 1,
+                                                   b.fin[sc]));
             return launch_inorm_apply(s, y, b.mean_rstd[sc], gam, bet, res1, res2, y, (long)M, Cout, relu);
         }
         T2V_TRY(build_conv_plan(&L.cd, L.x_cs, true, &pl));
         T2V_TRY(run_conv(ctx, s, pl, x, w.w, w.bias, y, Cout, b.stats[sc]));
+        if (pl.tile != kTileStem && inorm_fused_ok(pl.nparts, Cout)) {
+            const float* gam = g.norm_affine ? w.gamma : nullptr;
+            const float* bet = g.norm_affine ? w.beta : nullptr;
+            if (g.norm_affine) T2V_REQUIRE(gam && bet, "layer %d: norm_affine=1 but gamma/beta missing", li - 1);
+            return launch_inorm_apply_partials(s, y, b.stats[sc], pl.nparts, pl.kp.mtiles, pl.BM, pl.kp.M, 0, 0, 0, Cout, g.eps,
+                                               gam, bet, res1, res2, y, (long)pl.Hout * pl.Wout, relu);
+        }
         if (pl.tile == kTileStem)
             T2V_TRY(launch_inorm_finalize_tiles(s, b.stats[sc], 16, L.cd.H, L.cd.W, Cout, g.eps, b.mean_rstd[sc], 1, b.fin[sc]));
         else

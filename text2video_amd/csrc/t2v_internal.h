@@ -174,6 +174,12 @@ int launch_inorm_finalize_tiles(hipStream_t s, const float* stats, int edge, int
                                 float* mean_rstd, int batch, double* scratch = nullptr);
 int launch_inorm_finalize(hipStream_t s, const float* stats, int nparts, int mtiles, int BM, int M, int C,
                           float eps, float* mean_rstd, double* scratch = nullptr);
+// finalize folded into the apply pass (layers with <= 128 partials per channel); geometry arguments as the finalize
+// launchers derive them: conv partials (nparts, mtiles, BM, M, wm = 0), stem tiles (wm = -edge), Winograd (wm = 2 | 4)
+bool inorm_fused_ok(int nparts, int C);
+int launch_inorm_apply_partials(hipStream_t s, const float* x, const float* stats, int nparts, int mtiles, int BM, int M,
+                                int wm, int H, int W, int C, float eps, const float* gamma, const float* beta,
+                                const float* res1, const float* res2, float* y, long npix, int relu);
 int launch_inorm_apply(hipStream_t s, const float* x, const float* mean_rstd, const float* gamma,
                        const float* beta, const float* res1, const float* res2, float* y, long npix, int C,
                        int relu);
