@@ -9,13 +9,18 @@
 // conflict-free ds_read_b32 -- no transposes, no swizzle.
 //
 //   block tile : 128 output channels (n) x 128 input channels (c) of ONE tap, 64 accumulator VGPRs/wave
-//   K loop     : 32 pixels per LDS stage (2 x 16 KiB), 2-slot ring (two blocks per CU), loader waves with buffer-addressed
-//                LDS-DMA (same wave-specialised structure as conv_igemm.hip); padding / tails = OOB lanes
+//   K loop     : 16 pixels per LDS stage (2 x 8 KiB), 4-slot ring = 64 KiB (two blocks per CU), loader waves with
+//                buffer-addressed LDS-DMA (same wave-specialised structure as conv_igemm.hip); padding / tails = OOB lanes.
+//                (Round 1 ran 32-pixel stages on a 2-slot ring; halving the stage is worth +3-4.5 % on every layer
+//                shape -- rb1024 0.735 -> 0.706 ms, stride-2 / transposed layers 106 -> 110 TF -- whatever the ring
+//                depth, 3 / 4 / 5 slots measure alike: T2V_WGRAD_PIX / T2V_WGRAD_RING select the variants)
 //   grid       : (Cout/128) x (Cin_s/128) x taps  [x phases for transposed convs]
 //   output     : written straight into the PACKED weight layout [Cout_p][Kp] (K = tap*Cin_s + c), so the
 //                optimiser can run on packed parameters; t2v_conv_unpack_weight converts back.
 // Transposed convolutions are the same reduction per sub-pixel phase: dY is sampled at the phase's
 // strided output positions (ostride / toy / tox), X at the phase taps (t2v_conv2d_backward_weight).
+#include <stdlib.h>
+
 #include "t2v_internal.h"
 
 namespace t2v {
@@ -29,13 +34,16 @@ __device__ __forceinline__ void wg_dma16(const float* base, int nbytes, char* ld
 #endif
 }
 
-constexpr int kWgPix = 32;                       // pixels per stage
-constexpr int kWgStage = 2 * kWgPix * 128 * 4;   // dY tile + X tile, 128 channels each
-constexpr int kWgRing = 2;
-
+// PIX pixels per stage (dY tile + X tile, 128 channels each = PIX KiB), RING slots: 32 x 2 (a stage = 4096 MFMA cycles
+// per wave, its DMA has < 1 stage time to land) or 16 x 4 (2048-cycle stages, DMA three stages ahead); both 64 KiB,
+// i.e. two blocks per CU
 // REFLECT: the forward conv used reflection padding (taps never fall outside; indices mirror)
-template <bool REFLECT>
+template <bool REFLECT, int PIX, int RING>
 __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradParams p) {
+    constexpr int kWgPix = PIX, kWgRing = RING;
+    constexpr int kWgStage = 2 * kWgPix * 128 * 4;
+    constexpr int RW = PIX / 4;    // pixel rows of a stage per loader wave
+    constexpr int NI = PIX / 8;    // DMA instructions per loader wave, stage and operand (2 pixel rows each)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int kOOB = 0x7fff0000;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -59,7 +67,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradParams p) {
     const int nk = max(0, min(per, nk_all - kt0));
 
     if (is_loader) {
-        // each loader wave: 4 dY instructions + 4 X instructions per stage; one instruction = 2 pixel rows
+        // each loader wave: NI dY instructions + NI X instructions per stage; one instruction = 2 pixel rows
         const int prow = lane >> 5;           // pixel row inside the instruction's pair
         const int chunk = lane & 31;          // 16-byte chunk inside the 512-byte channel row
         bool n_ok = n0 + chunk * 4 < p.Cout_s;
@@ -87,10 +95,10 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradParams p) {
         // (image, row, column) of this lane's four pixels in the stage being issued: set up once with divisions,
         // then stepped by kWgPix pixels per stage (stages are issued in increasing order)
         const int Hm = p.M / p.Wm;
-        int pb[4], py[4], px[4];
+        int pb[NI], py[NI], px[NI];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int pidx = kt0 * kWgPix + wid * 8 + i * 2 + prow;   // global pixel (image-major)
+        for (int i = 0; i < NI; ++i) {
+            const int pidx = kt0 * kWgPix + wid * RW + i * 2 + prow;   // global pixel (image-major)
             pb[i] = pidx / p.M;
             const int m = pidx - pb[i] * p.M;
             py[i] = m / p.Wm;
@@ -103,14 +111,14 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradParams p) {
             if (kt > cur) {   // kt == cur + 1
                 cur = kt;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int i = 0; i < NI; ++i) {
                     px[i] += kWgPix;
                     while (px[i] >= p.Wm) { px[i] -= p.Wm; ++py[i]; }
                     while (py[i] >= Hm) { py[i] -= Hm; ++pb[i]; }
                 }
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < NI; ++i) {
                 const int b = pb[i], my = py[i], mx = px[i];
                 const bool ok = b < p.batch;
                 // dY: output pixel of GEMM pixel m (strided for the sub-pixel phases of a transposed conv)
@@ -122,7 +130,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradParams p) {
                     opix = (b * p.Hout + oy) * p.Wout + ox;
                 }
                 const int vy = oky ? (opix * p.Cout_s + (fold_n ? ln : n0 + chunk * 4)) * 4 : kOOB;
-                wg_dma16(p.dy, dy_bytes, sY + (wid * 8 + i * 2) * 512, vy, 0);
+                wg_dma16(p.dy, dy_bytes, sY + (wid * RW + i * 2) * 512, vy, 0);
                 // X: gathered through the tap
                 int iy = my * p.stride + ldy, ix = mx * p.stride + ldx;
                 bool okx = ok && c_ok;
@@ -135,10 +143,10 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradParams p) {
                     okx = okx && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
                 }
                 const int vx = okx ? (((b * p.Hin + iy) * p.Win + ix) * p.Cin_s + lc) * 4 : kOOB;
-                wg_dma16(p.x, x_bytes, sX + (wid * 8 + i * 2) * 512, vx, 0);
+                wg_dma16(p.x, x_bytes, sX + (wid * RW + i * 2) * 512, vx, 0);
             }
         };
-        constexpr int LD = 8;               // DMA instructions per loader wave and stage
+        constexpr int LD = 2 * NI;          // DMA instructions per loader wave and stage
         constexpr int AHEAD = kWgRing - 1;  // stages in flight beyond the one being computed
 #pragma unroll
         for (int st = 0; st < AHEAD; ++st) issue_stage(max(0, min(st, nk - 1)), st);
@@ -171,6 +179,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradParams p) {
     // (issue order MFMA, ds_read, MFMA, ds_read, ...); the stage barrier sits before the last group's reads,
     // which are the first of the next stage.
     constexpr int NQ = kWgPix / 8;
+    static_assert(NQ % 2 == 0, "operand register sets alternate per group");
     float av[2][4][2], bv[2][4][2];
     auto load_group = [&](int buf, int q, int set) {
         const float* sY = reinterpret_cast<const float*>(smem + buf * kWgStage);
@@ -265,27 +274,33 @@ int launch_wgrad_reduce(hipStream_t s, const float* partial, int splits, long n,
     return T2V_OK;
 }
 
-int launch_conv_wgrad(hipStream_t s, const WgradParams& p) {
-    static bool attr_done[2] = {false, false};
-    const int lds = kWgRing * kWgStage;
-    const int nblocks = p.ntaps * p.ntiles * p.ctiles * p.splits;
-    if (p.reflect) {
-        if (!attr_done[1]) {
-            T2V_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<true>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-            attr_done[1] = true;
-        }
-        hipLaunchKernelGGL(conv_wgrad_kernel<true>, dim3(nblocks), dim3(512), lds, s, p);
-    } else {
-        if (!attr_done[0]) {
-            T2V_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<false>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-            attr_done[0] = true;
-        }
-        hipLaunchKernelGGL(conv_wgrad_kernel<false>, dim3(nblocks), dim3(512), lds, s, p);
+template <bool REFLECT, int PIX, int RING>
+static int launch_wgrad_variant(hipStream_t s, const WgradParams& p) {
+    auto kern = conv_wgrad_kernel<REFLECT, PIX, RING>;
+    constexpr int lds = RING * 2 * PIX * 128 * 4;
+    static bool attr_done = false;   // per instantiation
+    if (!attr_done) {
+        T2V_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_done = true;
     }
+    const int nblocks = p.ntaps * p.ntiles * p.ctiles * p.splits;
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(512), lds, s, p);
     T2V_HIP_CHECK(hipGetLastError());
     return T2V_OK;
+}
+
+int launch_conv_wgrad(hipStream_t s, const WgradParams& p) {
+    static const int pix = getenv("T2V_WGRAD_PIX") ? atoi(getenv("T2V_WGRAD_PIX")) : 16;
+    static const int ring = getenv("T2V_WGRAD_RING") ? atoi(getenv("T2V_WGRAD_RING")) : 4;
+    if (pix == 16 && ring == 5)
+        return p.reflect ? launch_wgrad_variant<true, 16, 5>(s, p) : launch_wgrad_variant<false, 16, 5>(s, p);
+    if (pix == 16 && ring == 3)
+        return p.reflect ? launch_wgrad_variant<true, 16, 3>(s, p) : launch_wgrad_variant<false, 16, 3>(s, p);
+    if (pix == 16)
+        return p.reflect ? launch_wgrad_variant<true, 16, 4>(s, p) : launch_wgrad_variant<false, 16, 4>(s, p);
+    if (ring == 3)
+        return p.reflect ? launch_wgrad_variant<true, 32, 3>(s, p) : launch_wgrad_variant<false, 32, 3>(s, p);
+    return p.reflect ? launch_wgrad_variant<true, 32, 2>(s, p) : launch_wgrad_variant<false, 32, 2>(s, p);
 }
 
 }  // namespace t2v
