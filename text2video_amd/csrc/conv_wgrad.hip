@@ -179,7 +179,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradParams p) {
     // (issue order MFMA, ds_read, MFMA, ds_read, ...); the stage barrier sits before the last group's reads,
     // which are the first of the next stage.
     constexpr int NQ = kWgPix / 8;
-    static_assert(NQ % 2 == 0, "operand register sets alternate per group");
+    constexpr int U = (NQ % 2) ? 2 : 1;   // stages per unrolled iteration: keeps the operand register set of a group static
     float av[2][4][2], bv[2][4][2];
     auto load_group = [&](int buf, int q, int set) {
         const float* sY = reinterpret_cast<const float*>(smem + buf * kWgStage);
@@ -196,34 +196,38 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradParams p) {
     __syncthreads();  // B0
     load_group(0, 0, 0);
     int buf = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int nbuf = buf == kWgRing - 1 ? 0 : buf + 1;
+    for (int kt0u = 0; kt0u < nk; kt0u += U) {
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const int cur = q & 1;
-            __builtin_amdgcn_sched_barrier(0);
-            if (q + 1 == NQ) {
-                __syncthreads();  // barrier(kt): slot `buf` fully read, stage kt+1 visible
+        for (int u = 0; u < U; ++u) {
+            if (kt0u + u >= nk) break;   // wave-uniform
+            const int nbuf = buf == kWgRing - 1 ? 0 : buf + 1;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int cur = (u * NQ + q) & 1;
                 __builtin_amdgcn_sched_barrier(0);
-                load_group(nbuf, 0, cur ^ 1);
-            } else {
-                load_group(buf, q + 1, cur ^ 1);
+                if (q + 1 == NQ) {
+                    __syncthreads();  // barrier(kt): slot `buf` fully read, stage kt+1 visible
+                    __builtin_amdgcn_sched_barrier(0);
+                    load_group(nbuf, 0, cur ^ 1);
+                } else {
+                    load_group(buf, q + 1, cur ^ 1);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][e][i], bv[cur][e][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
             }
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][e][i], bv[cur][e][j], acc[i][j], 0, 0, 0);
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read
-            }
-            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+            buf = nbuf;
         }
-        buf = nbuf;
     }
 
     // ---- epilogue: D[row n][col c] -> packed dW[n][koff + c]  (koff: position of this tap in K) ----
@@ -292,6 +296,10 @@ static int launch_wgrad_variant(hipStream_t s, const WgradParams& p) {
 int launch_conv_wgrad(hipStream_t s, const WgradParams& p) {
     static const int pix = getenv("T2V_WGRAD_PIX") ? atoi(getenv("T2V_WGRAD_PIX")) : 16;
     static const int ring = getenv("T2V_WGRAD_RING") ? atoi(getenv("T2V_WGRAD_RING")) : 4;
+    if (pix == 8 && ring == 4)
+        return p.reflect ? launch_wgrad_variant<true, 8, 4>(s, p) : launch_wgrad_variant<false, 8, 4>(s, p);
+    if (pix == 8)
+        return p.reflect ? launch_wgrad_variant<true, 8, 8>(s, p) : launch_wgrad_variant<false, 8, 8>(s, p);
     if (pix == 16 && ring == 5)
         return p.reflect ? launch_wgrad_variant<true, 16, 5>(s, p) : launch_wgrad_variant<false, 16, 5>(s, p);
     if (pix == 16 && ring == 3)
