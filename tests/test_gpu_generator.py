@@ -288,7 +288,7 @@ def test_fused_norm_pass_matches_the_two_kernel_form():
             "m = Vid2VidModelG([HipGenerator(spec, 'cuda:0').load_state_dict(synthetic_state_dict(spec, 9, flow_gain=0.1))]);"
             "g = torch.Generator().manual_seed(0);"
             "outs = [];\n"
-            "for H, W in ((256, 256), (128, 340)):\n"
+            "for H, W in ((256, 256), (128, 344)):\n"
             "    m.reset()\n"
             "    for t in range(3):\n"
             "        w = torch.zeros(H, W, 12, device='cuda:0'); w[..., :9] = (torch.rand(H, W, 9, generator=g) * 2 - 1).cuda()\n"
