@@ -127,6 +127,9 @@ def test_readme_train_command_parses():
            "--add_face_disc --openpose_only")   # README.md:171-176
     opt = TrainOptions().parse(cmd.split())
     assert opt.gpu_ids == list(range(8)) and opt.batchSize == 8 and opt.max_frames_per_gpu == 2 and opt.add_face_disc
+    # the recipe passes --openpose_only and no --no_flow: training keeps the flow branch (inference lets the checkpoint decide)
+    assert opt.openpose_only and not opt.no_flow
+    assert TrainOptions().parse(cmd.split() + ["--no_flow"]).no_flow
 
 
 def test_scale_height_geometry_and_central_crop():
@@ -325,3 +328,23 @@ def test_transforms_and_conv_init_pinned_to_the_vendored_sources(lib_built):
             assert 0.9 * b <= mx <= b, (key, mx, b)
             seen_t += role == "convT_w"
     assert seen_t == 4      # the 2 + 2 transposed convs of the two decoders
+
+
+def test_checkpoint_loading_rules(tmp_path):
+    """`load_checkpoint` takes an upstream `latest_net_G0.pth` as is: `module.` prefixes of a DataParallel save are
+    stripped, BatchNorm running statistics are dropped (the generator runs its norm layers on batch statistics at test
+    time) -- which is also what torch 0.4.1's InstanceNorm does with pre-0.4 running stats on load
+    ($SP/torch/nn/modules/instancenorm.py:15-38 removes `running_mean` / `running_var` when track_running_stats=False) --
+    and a wrapped {'state_dict': ...} file is unwrapped."""
+    import torch
+    from text2video_amd.model import load_checkpoint
+    sd = {"module.model_down_seg.1.weight": torch.randn(4, 3, 7, 7), "module.model_down_seg.2.running_mean": torch.zeros(4),
+          "module.model_down_seg.2.running_var": torch.ones(4), "module.model_down_seg.2.num_batches_tracked": torch.tensor(5),
+          "module.model_down_seg.2.weight": torch.ones(4).double()}
+    p = str(tmp_path / "latest_net_G0.pth")
+    torch.save(sd, p)
+    out = load_checkpoint(p)
+    assert sorted(out) == ["model_down_seg.1.weight", "model_down_seg.2.weight"]
+    assert out["model_down_seg.2.weight"].dtype == torch.float32
+    torch.save({"state_dict": {"a.weight": torch.ones(2)}}, p)
+    assert list(load_checkpoint(p)) == ["a.weight"]
