@@ -483,6 +483,11 @@ static int launch_pad(hipStream_t s, const ConvKParams& p) {
     static const int force = getenv("T2V_CONV_RING") ? atoi(getenv("T2V_CONV_RING")) : 0;
     // (swept per layer shape with scripts/kernel_bench.py: single-phase launches like two co-resident blocks from 512
     // blocks on; 64x64 tiles of a multi-phase launch prefer the deeper ring)
+    // T2V_GEMM_RING: ring depth of the single-phase 64x64-tile launches only (the Winograd GEMM stages)
+    static const int gemm_ring = getenv("T2V_GEMM_RING") ? atoi(getenv("T2V_GEMM_RING")) : 0;
+    if (gemm_ring && Cfg::MF == 32 && Cfg::BM == 64 && p.nphases == 1)
+        return gemm_ring == 2 ? launch_ring<Cfg, MODE, STATS, REFLECT, 2>(s, p)
+               : gemm_ring == 4 ? launch_ring<Cfg, MODE, STATS, REFLECT, 4>(s, p) : launch_ring<Cfg, MODE, STATS, REFLECT, 3>(s, p);
     const bool two = force ? force == 2
                            : (Cfg::MF == 32 && (Cfg::BM == 64 ? (p.nphases == 1 || nblocks >= 4096)
                                                               : (nblocks >= 1024 || (p.nphases == 1 && nblocks >= 512))));
