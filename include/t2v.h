@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define T2V_ABI_VERSION 5
+#define T2V_ABI_VERSION 6
 
 typedef enum {
     T2V_OK = 0,
@@ -249,6 +249,14 @@ int t2v_sum_abs_diff_masked_backward(t2v_ctx* ctx, void* stream, const float* a,
  * in double and rounded to fp32 once (adam.py:86-96 does the same through Python floats). */
 int t2v_adam_step(t2v_ctx* ctx, void* stream, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
                   long n, double lr, double beta1, double beta2, double eps, int step);
+
+/* The same update for many tensors in ONE launch (all tables are DEVICE arrays): ptrs[t] = {param, grad, exp_avg,
+ * exp_avg_sq} addresses of tensor t (grad 0: the tensor is skipped, as Adam skips parameters without gradient),
+ * nelem[t] its length, step_size[t] = lr*sqrt(1-beta2^k)/(1-beta1^k) with that tensor's own step count k; the work is
+ * cut into `nchunks` chunks of `chunk` elements: chunk c covers [chunk_off[c], chunk_off[c]+chunk) of tensor chunk_tensor[c]. */
+int t2v_adam_step_multi(t2v_ctx* ctx, void* stream, const int64_t* ptrs, const int64_t* nelem, const float* step_size,
+                        const int32_t* chunk_tensor, const int64_t* chunk_off, int nchunks, int chunk, double beta1,
+                        double beta2, double eps);
 
 /* layout / dtype plumbing on the device */
 int t2v_nchw_to_nhwc(t2v_ctx* ctx, void* stream, const float* src, float* dst, int C, int H, int W, int dst_cs);

@@ -313,3 +313,29 @@ def test_trainer_adds_the_vgg_term(tmp_path):
     assert "G_VGG" in losses and np.isfinite(losses["G_VGG"]) and losses["G_VGG"] > 0
     tr2 = T.Vid2VidTrainer(TrainOptions().parse(args[:-1]), "cuda:0")       # no weights given: the term is off (with a notice)
     assert tr2.vgg is None
+
+
+def test_multi_tensor_adam_equals_the_per_tensor_kernel(monkeypatch):
+    """FusedAdam.step as ONE launch over all parameter tensors (chunk table on the device) against one launch per tensor:
+    identical bits -- tensors longer than a chunk, shorter than a wave, and one that has no gradient in some steps."""
+    from text2video_amd import train as T
+    sizes = [5, 70001, 3 * (1 << 16), 64, (1 << 16) + 1]
+    g = torch.Generator().manual_seed(3)
+    init = [torch.randn(n, generator=g) for n in sizes]
+    grads = [[torch.randn(n, generator=g) * 0.1 for n in sizes] for _ in range(3)]
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("T2V_ADAM_MULTI", mode)
+        ps = [torch.nn.Parameter(t.clone().cuda()) for t in init]
+        opt = T.FusedAdam(ps, lr=1e-2)
+        for s in range(3):
+            for i, p in enumerate(ps):
+                p.grad = None if (i == 3 and s != 1) else grads[s][i].cuda()
+            opt.step()
+        torch.cuda.synchronize()
+        outs[mode] = ([p.detach().cpu() for p in ps], [m.cpu() for m in opt.m], [v.cpu() for v in opt.v], list(opt.steps))
+    assert outs["1"][3] == outs["0"][3] == [3, 3, 3, 1, 3]
+    for k in range(3):
+        for a, b in zip(outs["1"][k], outs["0"][k]):
+            assert torch.equal(a, b)
+    assert not torch.equal(outs["1"][0][0], init[0])

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libt2v_hip.so")
 T2V_OK = 0
 PAD_ZERO, PAD_REFLECT = 0, 1
 ACT_NONE, ACT_TANH, ACT_FLOW_W, ACT_LRELU = 0, 1, 2, 3
-ABI_VERSION = 5
+ABI_VERSION = 6
 ALGO_DIRECT, ALGO_WINOGRAD, ALGO_WINOGRAD_F4 = 0, 1, 2
 
 
@@ -93,6 +93,8 @@ SIGNATURES = {
                                                  c_int, c_int, c_void_p]),
     "t2v_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_double, c_double,
                               c_double, c_double, c_int]),
+    "t2v_adam_step_multi": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                    c_double, c_double, c_double]),
     "t2v_instance_norm_apply": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_void_p, c_long, c_int, c_int]),
     "t2v_flow_warp_composite": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,

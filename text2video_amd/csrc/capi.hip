@@ -701,6 +701,16 @@ int t2v_adam_step(t2v_ctx* ctx, void* stream, float* param, const float* grad, f
     return launch_adam((hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, step);
 }
 
+int t2v_adam_step_multi(t2v_ctx* ctx, void* stream, const int64_t* ptrs, const int64_t* nelem, const float* step_size,
+                        const int32_t* chunk_tensor, const int64_t* chunk_off, int nchunks, int chunk, double beta1,
+                        double beta2, double eps) {
+    T2V_REQUIRE(ctx && ptrs && nelem && step_size && chunk_tensor && chunk_off && nchunks > 0 && chunk > 0,
+                "adam_step_multi: bad arguments");
+    return launch_adam_multi((hipStream_t)stream, reinterpret_cast<const long long*>(ptrs),
+                             reinterpret_cast<const long long*>(nelem), step_size, chunk_tensor,
+                             reinterpret_cast<const long long*>(chunk_off), nchunks, chunk, beta1, beta2, eps);
+}
+
 int t2v_instance_norm_apply(t2v_ctx* ctx, void* stream, const float* x, const float* mean_rstd, const float* gamma,
                             const float* beta, const float* res1, const float* res2, float* y, long npix, int C,
                             int relu) {

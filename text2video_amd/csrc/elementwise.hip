@@ -500,6 +500,42 @@ int launch_adam(hipStream_t s, float* p, const float* g, float* m, float* v, lon
     return T2V_OK;
 }
 
+// The same update for MANY tensors in one launch (a generator has ~250 parameter tensors: one launch each costs more
+// than the arithmetic).  Block b works on chunk b: `chunk` consecutive elements at chunk_off[b] of tensor
+// chunk_tensor[b]; ptrs[t] = (param, grad, exp_avg, exp_avg_sq) device addresses; step_size per tensor (every
+// parameter keeps its own step count).
+__global__ __launch_bounds__(256) void adam_multi_kernel(const long long* __restrict__ ptrs, const long long* __restrict__ nelem,
+                                                         const float* __restrict__ step_size,
+                                                         const int* __restrict__ chunk_tensor,
+                                                         const long long* __restrict__ chunk_off, int chunk, float b1,
+                                                         float b2, float omb1, float omb2, float eps) {
+    const int t = chunk_tensor[blockIdx.x];
+    const long long off = chunk_off[blockIdx.x];
+    float* __restrict__ p = reinterpret_cast<float*>(ptrs[4 * t]);
+    const float* __restrict__ g = reinterpret_cast<const float*>(ptrs[4 * t + 1]);
+    if (g == nullptr) return;          // no gradient this step: parameter and moments stay as they are
+    float* __restrict__ m = reinterpret_cast<float*>(ptrs[4 * t + 2]);
+    float* __restrict__ v = reinterpret_cast<float*>(ptrs[4 * t + 3]);
+    const float ss = step_size[t];
+    const long long end = min(nelem[t], off + (long long)chunk);
+    for (long long i = off + threadIdx.x; i < end; i += blockDim.x) {
+        const float gi = g[i];
+        const float mi = m[i] * b1 + omb1 * gi;
+        const float vi = v[i] * b2 + omb2 * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] = p[i] - ss * (mi / (sqrtf(vi) + eps));
+    }
+}
+int launch_adam_multi(hipStream_t s, const long long* ptrs, const long long* nelem, const float* step_size,
+                      const int* chunk_tensor, const long long* chunk_off, int nchunks, int chunk, double b1, double b2,
+                      double eps) {
+    hipLaunchKernelGGL(adam_multi_kernel, dim3(nchunks), dim3(256), 0, s, ptrs, nelem, step_size, chunk_tensor, chunk_off,
+                       chunk, (float)b1, (float)b2, (float)(1.0 - b1), (float)(1.0 - b2), (float)eps);
+    T2V_HIP_CHECK(hipGetLastError());
+    return T2V_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // weight repacking: torch layouts ($SP/torch/nn/modules/conv.py:28-33) -> [Cout_p][Kp], K =
 // tap*Cin_s + c, zero padded.  One-time, at checkpoint load.

@@ -195,6 +195,9 @@ int launch_nhwc_to_nchw(hipStream_t s, const float* src, float* dst, int C, int 
 int launch_reduce(hipStream_t s, int op, const float* a, const float* b, float c, long n, float* scratch, float* out);
 int launch_adam(hipStream_t s, float* p, const float* g, float* m, float* v, long n, double lr, double b1, double b2,
                 double eps, int step);
+int launch_adam_multi(hipStream_t s, const long long* ptrs, const long long* nelem, const float* step_size,
+                      const int* chunk_tensor, const long long* chunk_off, int nchunks, int chunk, double b1, double b2,
+                      double eps);
 int launch_masked_l1(hipStream_t s, const float* a, const float* b, const float* mask, long npix, int c0, int C, int cs,
                      float* scratch, float* out);
 int launch_masked_l1_backward(hipStream_t s, const float* a, const float* b, const float* mask, float scale, long npix,

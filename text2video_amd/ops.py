@@ -333,6 +333,14 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step):
     return param
 
 
+def adam_step_multi(ptrs, nelem, step_size, chunk_tensor, chunk_off, chunk, beta1, beta2, eps):
+    """One launch over many tensors (tables are device tensors: ptrs int64 [T,4], nelem int64 [T], step_size float32
+    [T], chunk_tensor int32 [NC], chunk_off int64 [NC])."""
+    c = context()
+    check(c.lib.t2v_adam_step_multi(c.handle, _stream(), _p(ptrs), _p(nelem), _p(step_size), _p(chunk_tensor), _p(chunk_off),
+                                    chunk_tensor.numel(), int(chunk), beta1, beta2, eps), "adam_step_multi")
+
+
 def conv2d_backward_weight(x, dy, desc, accumulate_into=None):
     """Weight gradient in the PACKED layout.  x: [B,H,W,x_cs], dy: [B,Hout,Wout,dy_cs] (or 3-D, B=1)."""
     c = context()

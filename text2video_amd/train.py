@@ -607,13 +607,65 @@ class FusedAdam:
         for p in self.params:
             p.grad = None
 
+    CHUNK = 1 << 16
+
+    def _tables(self):
+        """static device tables of the multi-tensor launch (parameter / moment addresses, lengths, chunk map)"""
+        if getattr(self, "_tab", None) is None:
+            dev = self.params[0].device
+            import math
+            ct, co = [], []
+            for t, p in enumerate(self.params):
+                for c in range(math.ceil(p.numel() / self.CHUNK)):
+                    ct.append(t)
+                    co.append(c * self.CHUNK)
+            self._tab = {
+                "nelem": torch.tensor([p.numel() for p in self.params], dtype=torch.int64, device=dev),
+                "chunk_tensor": torch.tensor(ct, dtype=torch.int32, device=dev),
+                "chunk_off": torch.tensor(co, dtype=torch.int64, device=dev),
+                "ptrs_host": torch.zeros(len(self.params), 4, dtype=torch.int64).pin_memory(),
+                "ss_host": torch.zeros(len(self.params), dtype=torch.float32).pin_memory(),
+                "ptrs": torch.zeros(len(self.params), 4, dtype=torch.int64, device=dev),
+                "ss": torch.zeros(len(self.params), dtype=torch.float32, device=dev),
+            }
+        return self._tab
+
     def step(self):
+        """One launch for all tensors (T2V_ADAM_MULTI=0: one launch per tensor).  Every parameter keeps its own step
+        count; a parameter without gradient is skipped, moments included."""
+        import math
+        if os.environ.get("T2V_ADAM_MULTI", "1") == "0" or not self.params:
+            for i, (p, m, v) in enumerate(zip(self.params, self.m, self.v)):
+                if p.grad is not None:
+                    self.steps[i] += 1
+                    ops.adam_step(p.data, p.grad.contiguous(), m, v, self.lr, self.betas[0], self.betas[1], self.eps,
+                                  self.steps[i])
+                    p._t2v_packs = None   # written through the raw pointer: no tensor version bump
+            return
+        tab = self._tables()
+        if getattr(self, "_pending", None) is not None:
+            self._pending[1].synchronize()    # the previous step's table copies have left the pinned staging buffers
+        grads = []        # kept alive until the launch is enqueued
+        ph, sh = tab["ptrs_host"], tab["ss_host"]
+        b1, b2 = self.betas
         for i, (p, m, v) in enumerate(zip(self.params, self.m, self.v)):
-            if p.grad is not None:
-                self.steps[i] += 1
-                ops.adam_step(p.data, p.grad.contiguous(), m, v, self.lr, self.betas[0], self.betas[1], self.eps,
-                              self.steps[i])
-                p._t2v_packs = None   # written through the raw pointer: no tensor version bump
+            g = p.grad
+            if g is None:
+                ph[i, 1] = 0
+                continue
+            g = g.contiguous()
+            grads.append(g)
+            self.steps[i] += 1
+            k = self.steps[i]
+            ph[i, 0], ph[i, 1], ph[i, 2], ph[i, 3] = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr()
+            sh[i] = self.lr * math.sqrt(1.0 - b2 ** k) / (1.0 - b1 ** k)
+            p._t2v_packs = None
+        tab["ptrs"].copy_(ph, non_blocking=True)
+        tab["ss"].copy_(sh, non_blocking=True)
+        ops.adam_step_multi(tab["ptrs"], tab["nelem"], tab["ss"], tab["chunk_tensor"], tab["chunk_off"], self.CHUNK, b1, b2,
+                            self.eps)
+        # the pinned staging tables are reused by the next step: make sure this step's copies have been issued from them
+        self._pending = (grads, torch.cuda.current_stream().record_event())
 
 
 class GradientExchange:
