@@ -209,6 +209,8 @@ def main():
 
         for t in range(Wm):
             step(t, None)
+        if dist:    # untimed: RCCL sets up its channels / registers the buffers on the first collective of a shape
+            dist.all_gather_into_tensor(gathered, frames)
         torch.cuda.synchronize()
         if dist:
             dist.barrier()
