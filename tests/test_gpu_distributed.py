@@ -143,3 +143,74 @@ def test_config2_chunk_plan_with_the_real_generator_matches_oracle_per_chunk():
     for t in range(2, first_out + 1):
         full = ref.inference(poses[t - 2:t + 1].unsqueeze(0))
     assert (full - seam).abs().max().item() > 1e-2
+
+
+def _run_test_py(work, extra, env, nproc=1, port=29541):
+    cmd = [sys.executable]
+    if nproc > 1:
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+                "--master-port", str(port)]
+    cmd += [os.path.join(ROOT, "vid2vid", "test.py"), "--name", "fadg0", "--dataroot", "datasets/fadg0", "--dataset_mode", "pose",
+            "--input_nc", "3", "--resize_or_crop", "scaleHeight", "--loadSize", "128", "--openpose_only", "--how_many", "1200",
+            "--no_first_img", "--random_drop_prob", "0", "--synthetic_weights", "1", "--ngf", "16", "--n_blocks", "2",
+            "--n_downsample_G", "2", "--pose_workers", "2"] + extra
+    r = subprocess.run(cmd, cwd=work, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    return r
+
+
+def test_two_rank_frame_loop_whole_sequences_chunks_and_stitch(tmp_path):
+    """The drop-in frame loop (vid2vid/test.py) under torchrun with TWO ranks, both on this GPU (gloo transport,
+    T2V_DIST_BACKEND=gloo: RCCL refuses two ranks per device), against the single-process run:
+      * default sharding (whole sequences): identical JPEG files, every frame written exactly once;
+      * --shard_chunks: the one long sequence is cut in two -- same files, but frames after the cut differ;
+      * --shard_chunks --stitch_frames <chunk length>: the tail exchange + re-generation reproduces the single-process
+        files bit for bit."""
+    import glob
+    import shutil
+    from PIL import Image
+    from text2video_amd.keypoints import read_keypoints
+    src = os.path.join(ROOT, "tests", "golden", "keypoints_fadg0")
+    files = sorted(f for f in os.listdir(src) if f.startswith("sa1_"))
+    env = dict(os.environ, CUDA_VISIBLE_DEVICES="0", T2V_DIST_BACKEND="gloo")
+
+    def dataset(work, seqs):
+        root = os.path.join(work, "datasets", "fadg0")
+        for seq, n in seqs.items():
+            os.makedirs(os.path.join(root, "test_openpose", seq))
+            os.makedirs(os.path.join(root, "test_img", seq))
+            img = Image.fromarray(read_keypoints(os.path.join(src, files[0]), (128, 96)))
+            for i in range(n):
+                shutil.copyfile(os.path.join(src, files[(i * 5 + len(seq)) % len(files)]),
+                                os.path.join(root, "test_openpose", seq, "%05d.json" % i))
+                img.save(os.path.join(root, "test_img", seq, "%04d.jpg" % i))
+
+    def frames(work):
+        out = {}
+        for p in sorted(glob.glob(os.path.join(work, "results", "fadg0", "test_latest", "*", "fake_B_*.jpg"))):
+            out[os.path.relpath(p, work)] = open(p, "rb").read()
+        return out
+
+    # (1) two sequences, whole-sequence sharding
+    w1, w2 = str(tmp_path / "one"), str(tmp_path / "two")
+    for w in (w1, w2):
+        os.makedirs(w)
+        dataset(w, {"tmp": 9, "tmp_smooth": 7})
+    _run_test_py(w1, [], env)
+    _run_test_py(w2, [], env, nproc=2)
+    a, b = frames(w1), frames(w2)
+    assert len(a) == (9 - 2) + (7 - 2) and a.keys() == b.keys() and all(a[k] == b[k] for k in a)
+    # (2) one sequence of 14 pose maps -> 12 frames, cut in two chunks of 6
+    ws = {k: str(tmp_path / k) for k in ("single", "chunks", "stitched")}
+    for w in ws.values():
+        os.makedirs(w)
+        dataset(w, {"tmp": 14})
+    _run_test_py(ws["single"], [], env)
+    _run_test_py(ws["chunks"], ["--shard_chunks"], env, nproc=2, port=29542)
+    r = _run_test_py(ws["stitched"], ["--shard_chunks", "--stitch_frames", "100"], env, nproc=2, port=29543)
+    one, ch, st = frames(ws["single"]), frames(ws["chunks"]), frames(ws["stitched"])
+    assert len(one) == 12 and one.keys() == ch.keys() == st.keys()
+    names = sorted(one)
+    assert all(one[k] == ch[k] for k in names[:6])            # the first chunk is the sequence's start
+    assert any(one[k] != ch[k] for k in names[6:])            # the second restarts the recurrence: a seam
+    assert all(one[k] == st[k] for k in names), [k for k in names if one[k] != st[k]]

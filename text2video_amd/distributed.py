@@ -24,11 +24,15 @@ def init_from_env(backend=None):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if torch.cuda.is_available() and os.environ.get("T2V_DIST_BACKEND") == "gloo":
+        local_rank %= torch.cuda.device_count()     # more ranks than GPUs (single-GPU tests): ranks share devices
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"   # "nccl" is RCCL on ROCm
+            # "nccl" is RCCL on ROCm.  T2V_DIST_BACKEND=gloo: several ranks on ONE GPU (tests of the multi-rank frame loop
+            # on a single-GPU box; RCCL refuses two ranks per device) -- the collectives then stage through host memory
+            backend = os.environ.get("T2V_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         kw = {}
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
@@ -172,6 +176,11 @@ def gather_frames(local_frames):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return local_frames
     world = dist.get_world_size()
+    if local_frames.is_cuda and dist.get_backend() == "gloo":     # gloo moves host memory
+        host = local_frames.contiguous().cpu()
+        out = torch.empty((world * host.shape[0],) + tuple(host.shape[1:]), dtype=host.dtype)
+        dist.all_gather_into_tensor(out, host)
+        return out.to(local_frames.device)
     out = torch.empty((world * local_frames.shape[0],) + tuple(local_frames.shape[1:]), dtype=local_frames.dtype,
                       device=local_frames.device)
     dist.all_gather_into_tensor(out, local_frames.contiguous())
