@@ -1181,6 +1181,18 @@ def run_train(opt, steps=None):
                 ds.update_training_batch(epoch // max(1, opt.niter_step))
             continue
         break   # the step cap was reached
+    if world > 1:
+        # the replicas started from the same seed and applied the same averaged gradients: their weights must still be
+        # equal -- a cheap end-of-run check that the exchange reached every parameter on every rank
+        import torch.distributed as dist
+        chk = torch.stack([p.detach().double().sum() for p in trainer.optG.params + trainer.optD.params]).sum().reshape(1)
+        allc = [torch.zeros_like(chk) for _ in range(world)]
+        dist.all_gather(allc, chk)
+        if any(float(c) != float(allc[0]) for c in allc):
+            raise RuntimeError("data-parallel replicas diverged: parameter checksums %s" % [float(c) for c in allc])
+        if rank == 0:
+            print("replicas in sync after %d steps (parameter checksum %.9g on all %d ranks)" % (it, float(allc[0]), world),
+                  flush=True)
     if rank == 0:      # the final (or step-capped) save carries its position too
         trainer.save("latest", last_pos)
     return {"ms_per_step": 1e3 * float(np.median(stats)) if stats else 0.0, "steps": it, "world": world}
