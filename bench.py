@@ -162,6 +162,9 @@ def main():
               % (args.gpus, world), file=sys.stderr)
         sys.exit(2)
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    backend = os.environ.get("T2V_DIST_BACKEND", "nccl")   # "nccl" = RCCL; "gloo": several ranks on one GPU (tests only)
+    if backend == "gloo":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -169,7 +172,10 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from text2video_amd import ops
     from text2video_amd.generator import GeneratorSpec, HipGenerator, Vid2VidModelG, synthetic_state_dict
@@ -194,6 +200,15 @@ def main():
     frames = torch.empty(K, H, W, 4, dtype=torch.uint8, device=dev)
     gathered = torch.empty(world * K, H, W, 4, dtype=torch.uint8, device=dev) if dist else None
 
+    def all_gather_frames():
+        """chunk outputs to every rank: RCCL all-gather over xGMI (gloo in single-GPU tests: staged through the host)"""
+        if backend == "nccl":
+            dist.all_gather_into_tensor(gathered, frames)
+        else:
+            host = torch.empty(gathered.shape, dtype=torch.uint8)
+            dist.all_gather_into_tensor(host, frames.cpu())
+            gathered.copy_(host)
+
     def timed_run(model):
         """W untimed warm-up frames, then exactly K timed frames (+ the all-gather of the chunk's frames for N>1)
         between barrier + synchronize on both sides; returns the MAX over ranks of the elapsed seconds."""
@@ -210,7 +225,7 @@ def main():
         for t in range(Wm):
             step(t, None)
         if dist:    # untimed: RCCL sets up its channels / registers the buffers on the first collective of a shape
-            dist.all_gather_into_tensor(gathered, frames)
+            all_gather_frames()
         torch.cuda.synchronize()
         if dist:
             dist.barrier()
@@ -219,7 +234,7 @@ def main():
         for t in range(K):
             step(Wm + t, t)
         if dist:
-            dist.all_gather_into_tensor(gathered, frames)   # RCCL over xGMI: chunk outputs to every rank
+            all_gather_frames()
         torch.cuda.synchronize()
         if dist:
             dist.barrier()
@@ -398,7 +413,7 @@ def main():
                                       " + local enhancer (n_scales_spatial 2)" if args.scales == 2 else "",
                                       "flow branch + flow-warp compositor ON" if head_flow else "no flow branch"),
                        "frames_per_gpu": K, "parallelism": "sequence-chunk dp%d" % world,
-                       "collectives": "rccl" if dist else "none (single process)",
+                       "collectives": ("rccl" if backend == "nccl" else backend) if dist else "none (single process)",
                        "algorithmic_gflop_per_frame": round(gf, 1),
                        "algorithmic_tflops": round(fps * gf / 1e3, 2),
                        "variants": variants},

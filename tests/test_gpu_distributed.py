@@ -233,3 +233,22 @@ def test_two_rank_train_py_keeps_replicas_in_sync(tmp_path):
     mb = float(line.split("all-reduce")[1].split("MB")[0])
     assert mb > 1.0, line                                        # the gradients of G and the discriminators went through it
     assert os.path.exists(tmp_path / "ck" / "dp" / "latest_net_G0.pth")
+
+
+def test_bench_two_ranks_on_one_gpu_contract():
+    """bench.py as the driver launches it for N = 2 (torch.distributed.run, one rank per "GPU"), here with both ranks on this
+    GPU over gloo: ONE JSON line from rank 0, n_gpus = 2, value = the frames of BOTH ranks over the slowest rank's time,
+    weak scaling, no cpu_baseline / e2e legs (those are N = 1 only)."""
+    env = dict(os.environ, CUDA_VISIBLE_DEVICES="0", T2V_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29561", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
+           "--kernel-iters", "2", "--single-variant"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["scaling"] == "weak" and d["cpu_baseline"] is None and d["e2e"] is None
+    assert d["config"]["parallelism"] == "sequence-chunk dp2" and d["config"]["collectives"] == "gloo"
+    assert abs(d["value"] - 2 * 1e3 / d["ms_per_step"]) <= 0.01 * d["value"]      # 2 ranks x K frames / max-over-ranks time
+    assert d["value"] > 30.0
