@@ -348,3 +348,27 @@ def test_checkpoint_loading_rules(tmp_path):
     assert out["model_down_seg.2.weight"].dtype == torch.float32
     torch.save({"state_dict": {"a.weight": torch.ones(2)}}, p)
     assert list(load_checkpoint(p)) == ["a.weight"]
+
+
+def test_direct_minpack_fit_equals_curve_fit_bit_for_bit():
+    """The bit-exact rasteriser mode calls MINPACK's lmdif directly instead of going through scipy.optimize.curve_fit:
+    same routine, same defaults, so the same bits -- on random two-point segments, incl. horizontal ones."""
+    import warnings
+    from scipy.optimize import curve_fit
+    from text2video_amd import keypoints as K
+    assert K._MINPACK is not None
+    rng = np.random.default_rng(0)
+    n = 0
+    for i in range(400):
+        u, v = rng.uniform(0, 512, 2), rng.uniform(0, 384, 2)
+        if i % 7 == 0:
+            v[1] = v[0]
+        if abs(u[0] - u[1]) < 1:
+            continue
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            (a, b), _ = curve_fit(K._affine, u, v)
+        a2, b2 = K._fit_line(u, v, True)
+        assert a == a2 and b == b2, (u, v)
+        n += 1
+    assert n > 300

@@ -48,8 +48,27 @@ def _affine(x, a, b):
     return a * x + b
 
 
+try:    # MINPACK's lmdif, the routine scipy.optimize.curve_fit(method='lm') ends up in
+    from scipy.optimize import _minpack as _MINPACK
+    _EPS = float(np.finfo(np.float64).eps)
+except ImportError:      # pragma: no cover -- SciPy layouts without the private module: curve_fit itself
+    _MINPACK = None
+
+
 def _fit_line(u, v, exact_fit):
     if exact_fit:
+        if _MINPACK is not None:
+            # curve_fit(_affine, u, v) = leastsq(p -> _affine(u, *p) - v, p0 = ones(2)) with leastsq's defaults
+            # (ftol = xtol = 1.49012e-8, gtol = 0, maxfev = 200*(n+1), epsfcn = eps, factor = 100, no scaling), which
+            # calls _minpack._lmdif; calling it directly returns the SAME bits (tests/test_cpu_oracle_and_host.py
+            # compares both on the golden frames and on random segments) without curve_fit's argument checking,
+            # memoiser and covariance estimate: 0.04 ms instead of 0.28 ms per fit, 66 fits per frame
+            try:
+                r = _MINPACK._lmdif(lambda p: (p[0] * u + p[1]) - v, np.ones(2), (), 1, 1.49012e-8, 1.49012e-8, 0.0, 600,
+                                    _EPS, 100, None)
+                return r[0][0], r[0][1]
+            except (AttributeError, TypeError):      # private signature changed: fall back to the public routine
+                pass
         from scipy.optimize import curve_fit
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
