@@ -127,7 +127,8 @@ def run_e2e(model_head, model_other, head_flow, n_frames):
                 import io
                 with contextlib.redirect_stdout(io.StringIO()):      # the loop prints "process image..." per frame
                     stats = run_test(opt, model=m, device="cuda:%d" % torch.cuda.current_device())
-                workers = opt.pose_workers if opt.pose_workers is not None else max(1, min(16, (os.cpu_count() or 2) - 1))
+                from text2video_amd.pose_dataset import default_pose_workers
+                workers = opt.pose_workers if opt.pose_workers is not None else default_pose_workers()
                 out.append({"geometry": geom, "flow": flow, "fps": round(stats["fps_loop"], 2), "frames": stats["frames"],
                             "pose_workers": workers, "rasteriser": "bit-exact (curve_fit) mode"})
         finally:

@@ -372,3 +372,28 @@ def test_direct_minpack_fit_equals_curve_fit_bit_for_bit():
         assert a == a2 and b == b2, (u, v)
         n += 1
     assert n > 300
+
+
+def test_c_stamping_loops_equal_the_numpy_form(lib_built, monkeypatch):
+    """csrc/raster_host.c (lib/libt2v_host.so) against keypoints.stamp's numpy form: random segments that overlap each
+    other, run off the image (clamped coordinates -> repeated pixels), long and short, with and without end caps."""
+    import importlib
+    from text2video_amd import keypoints as K
+    assert K._host_lib(), "libt2v_host.so not built (make -C text2video_amd/csrc)"
+    rng = np.random.default_rng(5)
+    segs = []
+    for i in range(60):
+        x = rng.uniform(-30, 230, 2)
+        y = rng.uniform(-30, 180, 2)
+        if i % 9 == 0:
+            x = np.array([5.0, 195.0 + 900 * (i % 2)])      # a long one (1100 points: beyond the stack buffer)
+        xs, ys = K.trace_segment(x, y, exact_fit=False)
+        segs.append((xs, ys, int(rng.integers(1, 4)), tuple(int(v) for v in rng.integers(0, 256, 3)), bool(i % 2)))
+    a = np.zeros((150, 200, 3), np.uint8)
+    for xs, ys, bw, rgb, caps in segs:
+        K.stamp(a, xs, ys, bw, rgb, caps)
+    monkeypatch.setattr(K, "_HOST", False)                      # the numpy form
+    b = np.zeros((150, 200, 3), np.uint8)
+    for xs, ys, bw, rgb, caps in segs:
+        K.stamp(b, xs, ys, bw, rgb, caps)
+    assert a.any() and np.array_equal(a, b)

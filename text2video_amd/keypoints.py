@@ -102,11 +102,42 @@ def _blend(img, yy, xx, rgb):
         img[yy, xx] = ((cur.astype(float) + rgb) / 2).astype(np.uint8)
 
 
+_HOST = None
+
+
+def _host_lib():
+    """lib/libt2v_host.so (csrc/raster_host.c, built by `make -C text2video_amd/csrc`): the stamping loops in C.
+    False when it is not there -- the numpy form below is the same arithmetic."""
+    global _HOST
+    if _HOST is None:
+        import ctypes
+        import os
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libt2v_host.so")
+        _HOST = False
+        if os.path.exists(path) and os.environ.get("T2V_RASTER_NUMPY", "0") != "1":
+            try:
+                lib = ctypes.CDLL(path)
+                lib.t2v_raster_stamp.restype = None
+                lib.t2v_raster_stamp.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                                 ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+                if lib.t2v_raster_abi() == 1:
+                    _HOST = lib
+            except (OSError, AttributeError):
+                _HOST = False
+    return _HOST
+
+
 def stamp(img, xs, ys, bw, rgb, caps):
     if xs.size == 0:
         return
     h, w = img.shape[:2]
     rgb = np.asarray(rgb, float)
+    lib = _host_lib()
+    if lib and img.flags.c_contiguous and img.dtype == np.uint8:
+        xs64, ys64 = np.ascontiguousarray(xs, np.int64), np.ascontiguousarray(ys, np.int64)
+        lib.t2v_raster_stamp(img.ctypes.data, h, w, xs64.ctypes.data, ys64.ctypes.data, int(xs64.size), int(bw),
+                             np.ascontiguousarray(rgb, np.float64).ctypes.data, int(bool(caps)))
+        return
     for oy in range(-bw, bw):
         yy = np.clip(ys + oy, 0, h - 1)
         for ox in range(-bw, bw):
