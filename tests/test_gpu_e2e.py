@@ -78,6 +78,14 @@ def test_train_py_then_test_py_roundtrip(tmp_path):
     assert "G_GAN" in r.stdout and "D_f" in r.stdout
     for f in ("latest_net_G0.pth", "latest_net_D.pth", "latest_net_D_f.pth"):
         assert os.path.exists(os.path.join(work, "checkpoints", "fadg0", f))
+    # the files load STRICTLY into the reference-architecture modules (the oracle's stock torch.nn restatement):
+    # parameters + BatchNorm buffers under upstream's key names
+    import torch
+    from oracle.generator_ref import CompositeGenerator, MultiscaleDiscriminator
+    sd = torch.load(os.path.join(work, "checkpoints", "fadg0", "latest_net_G0.pth"), map_location="cpu")
+    CompositeGenerator(9, 3, 6, 32, 3, 3, False, "batch").load_state_dict(sd, strict=True)
+    sd = torch.load(os.path.join(work, "checkpoints", "fadg0", "latest_net_D.pth"), map_location="cpu")
+    MultiscaleDiscriminator(6, 64, 3, 2, "batch").load_state_dict(sd, strict=True)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "vid2vid", "test.py")] + common +
                        ["--dataroot", "datasets/fadg0", "--resize_or_crop", "scaleHeight", "--loadSize", "512",
                         "--how_many", "3", "--random_drop_prob", "0"], cwd=work, env=env, capture_output=True, text=True,

@@ -1041,16 +1041,29 @@ class Vid2VidTrainer:
         if progress is not None and epoch_label == "latest":
             with open(os.path.join(d, "iter.txt"), "w") as fh:
                 fh.write("%d\n%d\n" % (int(progress[0]), int(progress[1])))
-        torch.save({k: v.detach().cpu() for k, v in self.G.named_upstream_parameters().items()},
-                   os.path.join(d, "%s_net_G0.pth" % epoch_label))
-        torch.save({k: v.detach().cpu() for k, v in self.D.named_upstream_parameters().items()},
-                   os.path.join(d, "%s_net_D.pth" % epoch_label))
+        def state_dict(net):
+            """upstream's file layout: the parameters plus, for every BatchNorm2d (a 1-D `.weight`), the buffers torch
+            0.4.1's module carries ($SP/torch/nn/modules/batchnorm.py: running_mean, running_var, num_batches_tracked)
+            so that the file also loads strictly into the reference's own modules.  The norm layers run on batch
+            statistics in training AND at test time, so the running statistics are never read: they are
+            written at their initial values, with the step count."""
+            sd = {}
+            steps = max(self.optG.steps + self.optD.steps + [0])
+            for k, v in net.named_upstream_parameters().items():
+                sd[k] = v.detach().cpu()
+                if k.endswith(".weight") and v.dim() == 1 and self.opt.norm == "batch":
+                    base = k[:-len("weight")]
+                    sd[base + "running_mean"] = torch.zeros(v.numel())
+                    sd[base + "running_var"] = torch.ones(v.numel())
+                    sd[base + "num_batches_tracked"] = torch.tensor(steps, dtype=torch.long)
+            return sd
+
+        torch.save(state_dict(self.G), os.path.join(d, "%s_net_G0.pth" % epoch_label))
+        torch.save(state_dict(self.D), os.path.join(d, "%s_net_D.pth" % epoch_label))
         if self.Df is not None:
-            torch.save({k: v.detach().cpu() for k, v in self.Df.named_upstream_parameters().items()},
-                       os.path.join(d, "%s_net_D_f.pth" % epoch_label))
+            torch.save(state_dict(self.Df), os.path.join(d, "%s_net_D_f.pth" % epoch_label))
         for sc, dt in enumerate(self.DT):
-            torch.save({k: v.detach().cpu() for k, v in dt.named_upstream_parameters().items()},
-                       os.path.join(d, "%s_net_D_T%d.pth" % (epoch_label, sc)))
+            torch.save(state_dict(dt), os.path.join(d, "%s_net_D_T%d.pth" % (epoch_label, sc)))
 
 
 def run_train(opt, steps=None):
