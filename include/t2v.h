@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define T2V_ABI_VERSION 6
+#define T2V_ABI_VERSION 7
 
 typedef enum {
     T2V_OK = 0,
@@ -87,6 +87,11 @@ size_t t2v_conv_packed_weight_floats(const t2v_conv_desc* d, int x_cs);
  * 28-33) that already lives on the device into the kernel's K-contiguous layout. */
 int t2v_conv_pack_weight(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, int x_cs,
                          const float* w_torch_dev, float* packed_dev);
+/* The same for the DATA-GRADIENT conv `d` of a stride-1 forward layer, given that layer's own torch weight
+ * [Cout_f = d->Cin][Cin_f = d->Cout][k][k]: the 180-degree flip and the in/out transpose of updateGradInput's filter are
+ * folded into the gather (no flipped / transposed copy of the weight is ever made). */
+int t2v_conv_pack_weight_adjoint(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, int x_cs,
+                                 const float* w_forward_torch_dev, float* packed_dev);
 /* number of floats of the per-tile instance-norm partial-statistics buffer for this conv */
 size_t t2v_conv_stats_floats(const t2v_conv_desc* d);
 /* y = act(conv(x) + bias).  If stats_partial != NULL the epilogue also emits per-(tile,channel)

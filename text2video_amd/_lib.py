@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libt2v_hip.so")
 T2V_OK = 0
 PAD_ZERO, PAD_REFLECT = 0, 1
 ACT_NONE, ACT_TANH, ACT_FLOW_W, ACT_LRELU = 0, 1, 2, 3
-ABI_VERSION = 6
+ABI_VERSION = 7
 ALGO_DIRECT, ALGO_WINOGRAD, ALGO_WINOGRAD_F4 = 0, 1, 2
 
 
@@ -54,6 +54,7 @@ SIGNATURES = {
     "t2v_conv_out_dims": (c_int, [POINTER(ConvDesc), POINTER(c_int), POINTER(c_int)]),
     "t2v_conv_packed_weight_floats": (c_size_t, [POINTER(ConvDesc), c_int]),
     "t2v_conv_pack_weight": (c_int, [c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_void_p, c_void_p]),
+    "t2v_conv_pack_weight_adjoint": (c_int, [c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_void_p, c_void_p]),
     "t2v_conv_stats_floats": (c_size_t, [POINTER(ConvDesc)]),
     "t2v_conv2d_forward": (c_int, [c_void_p, c_void_p, POINTER(ConvDesc), c_void_p, c_int, c_void_p, c_void_p,
                                    c_void_p, c_int, c_void_p]),

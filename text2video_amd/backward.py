@@ -55,10 +55,9 @@ class ConvDataGrad:
 
     def refresh(self, weight):
         """weight: the forward layer's torch-layout weight on the device."""
-        w = weight
-        if self.kind == "flip":
-            w = weight.flip(2, 3).transpose(0, 1).contiguous()   # layout plumbing: [Cin][Cout][k][k] flipped
-        self.packed = ops.pack_conv_weight(w.contiguous(), self.desc, ops.round_up(self.desc.Cin, 4))
+        # kind "flip": the gradient's filter is the forward one flipped and transposed -- gathered that way by the packer
+        self.packed = ops.pack_conv_weight(weight.contiguous(), self.desc, ops.round_up(self.desc.Cin, 4),
+                                           adjoint=self.kind == "flip")
         return self
 
     def __call__(self, dy, out=None):

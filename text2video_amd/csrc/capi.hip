@@ -352,8 +352,8 @@ int t2v_conv2d_forward_winograd(t2v_ctx* ctx, void* stream, const t2v_conv_desc*
     return t2v_conv2d_forward_winograd_stages(ctx, stream, d, x, x_cs, w_packed, bias, y, y_cs, stats_partial, workspace, 7);
 }
 
-int t2v_conv_pack_weight(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, int x_cs, const float* w_torch_dev,
-                         float* packed_dev) {
+static int pack_weight(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, int x_cs, const float* w_torch_dev,
+                       float* packed_dev, int adjoint) {
     T2V_REQUIRE(ctx && w_torch_dev && packed_dev, "pack_weight: null pointer");
     ConvPlan pl;
     T2V_TRY(build_conv_plan(d, x_cs, false, &pl));
@@ -361,12 +361,22 @@ int t2v_conv_pack_weight(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, int
     if (is_winograd(d->algo)) {
         T2V_REQUIRE(winograd_supported(d, x_cs, d->algo), "pack_weight: Winograd not supported for this shape");
         return (d->algo == T2V_ALGO_WINOGRAD_F4 ? launch_winograd4_weight : launch_winograd_weight)(
-            s, w_torch_dev, packed_dev, d->Cout, d->Cin, pl.Cout_p, x_cs);
+            s, w_torch_dev, packed_dev, d->Cout, d->Cin, pl.Cout_p, x_cs, adjoint);
     }
     if (!d->transposed)
         return launch_pack_conv_weight(s, w_torch_dev, packed_dev, d->Cout, d->Cin, d->kH, d->kW, x_cs, pl.kp.ph[0].Kp,
-                                       pl.Cout_p);
+                                       pl.Cout_p, adjoint);
+    T2V_REQUIRE(!adjoint, "pack_weight_adjoint: stride-1 convolutions only (a transposed conv's data gradient reuses its weight)");
     return launch_pack_convT_weight(s, w_torch_dev, packed_dev, d->Cin, d->Cout, x_cs, pl.Cout_p, d->kH, d->pad);
+}
+int t2v_conv_pack_weight(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, int x_cs, const float* w_torch_dev,
+                         float* packed_dev) {
+    return pack_weight(ctx, stream, d, x_cs, w_torch_dev, packed_dev, 0);
+}
+int t2v_conv_pack_weight_adjoint(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, int x_cs, const float* w_forward_dev,
+                                 float* packed_dev) {
+    T2V_REQUIRE(d && !d->transposed && d->stride == 1, "pack_weight_adjoint: `d` must be a stride-1 (data-gradient) conv");
+    return pack_weight(ctx, stream, d, x_cs, w_forward_dev, packed_dev, 1);
 }
 
 size_t t2v_conv_stats_floats(const t2v_conv_desc* d) {

@@ -540,8 +540,10 @@ int launch_adam_multi(hipStream_t s, const long long* ptrs, const long long* nel
 // weight repacking: torch layouts ($SP/torch/nn/modules/conv.py:28-33) -> [Cout_p][Kp], K =
 // tap*Cin_s + c, zero padded.  One-time, at checkpoint load.
 // ---------------------------------------------------------------------------------------------
+// adjoint != 0: `w` is the FORWARD layer's weight [Cin][Cout][KH][KW] as seen from the data-gradient conv being packed
+// (its Cout = the forward Cin): element (n, c, kh, kw) = w[c][n][KH-1-kh][KW-1-kw] -- flip + transpose folded into the gather
 __global__ void pack_conv_weight_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin,
-                                        int KH, int KW, int Cin_s, int Kp, long total) {
+                                        int KH, int KW, int Cin_s, int Kp, long total, int adjoint) {
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
         const int n = (int)(i / Kp), k = (int)(i - (long)n * Kp);
@@ -549,16 +551,17 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ w, float* __re
         float v = 0.f;
         if (n < Cout && tap < KH * KW && c < Cin) {
             const int kh = tap / KW, kw = tap - kh * KW;
-            v = w[(((size_t)n * Cin + c) * KH + kh) * KW + kw];
+            v = adjoint ? w[(((size_t)c * Cout + n) * KH + (KH - 1 - kh)) * KW + (KW - 1 - kw)]
+                        : w[(((size_t)n * Cin + c) * KH + kh) * KW + kw];
         }
         out[i] = v;
     }
 }
 int launch_pack_conv_weight(hipStream_t s, const float* w, float* packed, int Cout, int Cin, int KH, int KW,
-                            int Cin_s, int Kp, int Cout_p) {
+                            int Cin_s, int Kp, int Cout_p, int adjoint) {
     const long total = (long)Cout_p * Kp;
     hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, w, packed, Cout, Cin,
-                       KH, KW, Cin_s, Kp, total);
+                       KH, KW, Cin_s, Kp, total, adjoint);
     T2V_HIP_CHECK(hipGetLastError());
     return T2V_OK;
 }

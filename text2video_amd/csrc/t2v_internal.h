@@ -125,10 +125,10 @@ inline int wino_pad_tiles(int T) {
     const int a = (T + 63) / 64 * 64, b = (T + 127) / 128 * 128;
     return (b - a) * 8 >= b ? a : b;
 }
-int launch_winograd_weight(hipStream_t s, const float* w, float* U, int Cout, int Cin, int Cout_p, int Cin_s);
+int launch_winograd_weight(hipStream_t s, const float* w, float* U, int Cout, int Cin, int Cout_p, int Cin_s, int adjoint = 0);
 int launch_winograd_input(hipStream_t s, const float* x, float* V, int H, int W, int C, int pad, int reflect);
 int launch_winograd_output(hipStream_t s, const float* Mm, const float* bias, float* y, float* stats, int H, int W, int N);
-int launch_winograd4_weight(hipStream_t s, const float* w, float* U, int Cout, int Cin, int Cout_p, int Cin_s);
+int launch_winograd4_weight(hipStream_t s, const float* w, float* U, int Cout, int Cin, int Cout_p, int Cin_s, int adjoint = 0);
 int launch_winograd4_input(hipStream_t s, const float* x, float* V, int H, int W, int C, int pad, int reflect, int batch = 1,
                            int image = 0);
 int launch_winograd4_dy(hipStream_t s, const float* dy, float* Md, int Ho, int Wo, int N, int dy_cs, int batch, int image);
@@ -184,7 +184,7 @@ int launch_inorm_apply(hipStream_t s, const float* x, const float* mean_rstd, co
                        const float* beta, const float* res1, const float* res2, float* y, long npix, int C,
                        int relu);
 int launch_pack_conv_weight(hipStream_t s, const float* w, float* packed, int Cout, int Cin, int KH, int KW,
-                            int Cin_s, int Kp, int Cout_p);
+                            int Cin_s, int Kp, int Cout_p, int adjoint = 0);
 int launch_pack_convT_weight(hipStream_t s, const float* w, float* packed, int Cin, int Cout, int Cin_s, int Cout_p,
                              int K, int pad);
 // taps of sub-pixel phase `phase` of ConvTranspose2d(k3,s2,p1,op1); shared by packer and launcher

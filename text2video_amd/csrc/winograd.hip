@@ -29,8 +29,9 @@ static inline int wg_grid(long n, int block) {
 }
 
 // U[xi][n][c] = (G g G^T)[xi],  G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
+// adjoint: w is the forward layer's weight [Cin][Cout][3][3]; the tap read is w[c][n][2-a][2-b] (the data gradient's filter)
 __global__ void winograd_weight_kernel(const float* __restrict__ w, float* __restrict__ U, int Cout, int Cin, int Cout_p,
-                                       int Cin_s) {
+                                       int Cin_s, int adjoint) {
     const long total = (long)Cout_p * Cin_s;
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
@@ -39,7 +40,9 @@ __global__ void winograd_weight_kernel(const float* __restrict__ w, float* __res
 #pragma unroll
         for (int a = 0; a < 3; ++a)
 #pragma unroll
-            for (int b = 0; b < 3; ++b) g[a][b] = (n < Cout && c < Cin) ? w[(((size_t)n * Cin + c) * 3 + a) * 3 + b] : 0.f;
+            for (int b = 0; b < 3; ++b)
+                g[a][b] = (n < Cout && c < Cin) ? (adjoint ? w[(((size_t)c * Cout + n) * 3 + (2 - a)) * 3 + (2 - b)]
+                                                           : w[(((size_t)n * Cin + c) * 3 + a) * 3 + b]) : 0.f;
         float t[4][3];
 #pragma unroll
         for (int b = 0; b < 3; ++b) {
@@ -59,9 +62,9 @@ __global__ void winograd_weight_kernel(const float* __restrict__ w, float* __res
         }
     }
 }
-int launch_winograd_weight(hipStream_t s, const float* w, float* U, int Cout, int Cin, int Cout_p, int Cin_s) {
+int launch_winograd_weight(hipStream_t s, const float* w, float* U, int Cout, int Cin, int Cout_p, int Cin_s, int adjoint) {
     hipLaunchKernelGGL(winograd_weight_kernel, dim3(wg_grid((long)Cout_p * Cin_s, 256)), dim3(256), 0, s, w, U, Cout, Cin,
-                       Cout_p, Cin_s);
+                       Cout_p, Cin_s, adjoint);
     T2V_HIP_CHECK(hipGetLastError());
     return T2V_OK;
 }
@@ -246,7 +249,7 @@ __device__ __forceinline__ float cdot(const double (&row)[K], const float (&v)[K
 }
 
 __global__ void winograd4_weight_kernel(const float* __restrict__ w, float* __restrict__ U, int Cout, int Cin, int Cout_p,
-                                        int Cin_s) {
+                                        int Cin_s, int adjoint) {
     const long total = (long)Cout_p * Cin_s;
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
@@ -255,7 +258,9 @@ __global__ void winograd4_weight_kernel(const float* __restrict__ w, float* __re
 #pragma unroll
         for (int a = 0; a < 3; ++a)
 #pragma unroll
-            for (int b = 0; b < 3; ++b) g[a][b] = (n < Cout && c < Cin) ? (double)w[(((size_t)n * Cin + c) * 3 + a) * 3 + b] : 0.0;
+            for (int b = 0; b < 3; ++b)
+                g[a][b] = (n < Cout && c < Cin) ? (double)(adjoint ? w[(((size_t)c * Cout + n) * 3 + (2 - a)) * 3 + (2 - b)]
+                                                                   : w[(((size_t)n * Cin + c) * 3 + a) * 3 + b]) : 0.0;
 #pragma unroll
         for (int a = 0; a < 6; ++a)
 #pragma unroll
@@ -269,9 +274,9 @@ __global__ void winograd4_weight_kernel(const float* __restrict__ w, float* __re
             }
     }
 }
-int launch_winograd4_weight(hipStream_t s, const float* w, float* U, int Cout, int Cin, int Cout_p, int Cin_s) {
+int launch_winograd4_weight(hipStream_t s, const float* w, float* U, int Cout, int Cin, int Cout_p, int Cin_s, int adjoint) {
     hipLaunchKernelGGL(winograd4_weight_kernel, dim3(wg_grid((long)Cout_p * Cin_s, 256)), dim3(256), 0, s, w, U, Cout, Cin,
-                       Cout_p, Cin_s);
+                       Cout_p, Cin_s, adjoint);
     T2V_HIP_CHECK(hipGetLastError());
     return T2V_OK;
 }

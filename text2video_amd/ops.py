@@ -111,8 +111,10 @@ def conv_out_dims(desc):
     return h.value, w.value
 
 
-def pack_conv_weight(weight, desc, x_cs=None):
-    """weight: torch layout ([Cout,Cin,kH,kW], or [Cin,Cout,3,3] if desc.transposed) on the device."""
+def pack_conv_weight(weight, desc, x_cs=None, adjoint=False):
+    """weight: torch layout ([Cout,Cin,kH,kW], or [Cin,Cout,3,3] if desc.transposed) on the device.
+    adjoint=True: `desc` is the data-gradient conv of a stride-1 layer and `weight` that layer's FORWARD weight
+    ([desc.Cin, desc.Cout, k, k]); flip and transpose happen inside the packing kernel."""
     c = context()
     _chk(weight, "weight")
     x_cs = round_up(desc.Cin, 4) if x_cs is None else x_cs
@@ -120,8 +122,8 @@ def pack_conv_weight(weight, desc, x_cs=None):
     if n == 0:
         raise RuntimeError("pack_conv_weight: %s" % c.lib.t2v_last_error().decode())
     packed = torch.empty(n, dtype=torch.float32, device=weight.device)
-    check(c.lib.t2v_conv_pack_weight(c.handle, _stream(), ctypes.byref(desc), x_cs, _p(weight), _p(packed)),
-          "conv_pack_weight")
+    fn = c.lib.t2v_conv_pack_weight_adjoint if adjoint else c.lib.t2v_conv_pack_weight
+    check(fn(c.handle, _stream(), ctypes.byref(desc), x_cs, _p(weight), _p(packed)), "conv_pack_weight")
     return packed
 
 
