@@ -20,7 +20,8 @@ Prints ONE JSON line (rank 0) with the driver's contract fields plus
                   conv: 19.3 GFLOP of executed fp32 MFMA work per launch at 512x512) timed with HIP events on
                   the launch stream vs the fp32 MFMA peak (157.3 TFLOP/s); "layer" = the whole conv
   "cpu_baseline": the CPU oracle (stock torch fp32) timed on this box's host cores on a bounded
-                  sample of the same workload (3 frames with all threads, and with 8 threads: SURVEY 8d);
+                  sample of the same workload (3 frames each with all, 32 and 8 threads -- the fastest is `value`,
+                  with its thread count in `cores`; SURVEY 8d asks for the 8-thread figure);
                   its frames are also compared with the timed HIP model's ("parity": max |delta| per
                   pixel, teacher-forced, tolerance 1e-3 = north_star).
   "e2e":          the drop-in test.py frame loop (rasterise pose JSONs -> H2D -> generator -> D2H ->
@@ -375,22 +376,28 @@ def main():
             parity = {"max_abs_delta_vs_oracle": float("%.3g" % max((g - w).abs().max().item() for g, w in zip(gots, wants))),
                       "frames": len(wants), "tolerance": 1e-3,
                       "how": "frames 0..%d of the sequence, previous frames taken from the oracle (teacher-forced)" % nf}
-            # the same frames again with 8 threads (comparable with an 8-vCPU host)
-            c8 = None
-            if cores > 8:
-                torch.set_num_threads(8)
+            # the same frames again with fewer threads (SURVEY 8d asks for an 8-thread figure; torch's CPU convolutions do
+            # not scale to all 128 hardware threads of this host -- the fastest setting is the baseline `value`)
+            by_threads = {cores: nf / csec}
+            for nt in (32, 8):
+                if nt >= cores:
+                    continue
+                torch.set_num_threads(nt)
                 ref.fake_B_prev = [p.clone() for p in state1]
                 ref.inference(pf[1:4].unsqueeze(0))            # warm-up at the new thread count (not timed)
                 ref.fake_B_prev = [p.clone() for p in state1]
                 c0 = time.perf_counter()
                 for t in range(1, 1 + nf):
                     ref.inference(pf[t:t + 3].unsqueeze(0))
-                c8 = nf / (time.perf_counter() - c0)
-                torch.set_num_threads(cores)
-            cpu = {"value": round(nf / csec, 4), "unit": "frames/s", "cores": cores, "kind": "port",
-                   "sample": "%d frames %dx%d (%s) after 1 warm-up frame, torch %s CPU fp32, %d threads"
-                             % (nf, H, W, "flow branch on" if head_flow else "no flow branch", torch.__version__, cores),
-                   "value_8_threads": round(c8, 4) if c8 else None, "parity": parity}
+                by_threads[nt] = nf / (time.perf_counter() - c0)
+            torch.set_num_threads(cores)
+            best = max(by_threads, key=lambda k: by_threads[k])
+            cpu = {"value": round(by_threads[best], 4), "unit": "frames/s", "cores": best, "kind": "port",
+                   "sample": "%d frames %dx%d (%s) after 1 warm-up frame, torch %s CPU fp32; fastest of %s threads"
+                             % (nf, H, W, "flow branch on" if head_flow else "no flow branch", torch.__version__,
+                                "/".join(str(k) for k in sorted(by_threads, reverse=True))),
+                   "by_threads": {str(k): round(v, 4) for k, v in sorted(by_threads.items(), reverse=True)},
+                   "value_8_threads": round(by_threads[8], 4) if 8 in by_threads else None, "parity": parity}
         # ---- end to end: the drop-in test.py frame loop on a dataset in the reference's layout ----
         e2e = None
         if args.e2e_frames > 0 and world == 1 and args.scales == 1:

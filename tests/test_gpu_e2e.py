@@ -257,6 +257,7 @@ def test_bench_contract_line():
     assert cb["kind"] == "port" and cb["unit"] == "frames/s" and cb["cores"] >= 1 and 0 < cb["value"] < d["value"]
     assert cb["parity"]["frames"] == 2 and 0 < cb["parity"]["max_abs_delta_vs_oracle"] <= cb["parity"]["tolerance"] == 1e-3
     assert cb["value_8_threads"] is None or 0 < cb["value_8_threads"] < d["value"]
+    assert cb["value"] == max(cb["by_threads"].values()) and str(cb["cores"]) in cb["by_threads"]
     # the headline is the generator with the flow-warp compositor; the no-flow variant is timed in the same run
     v = d["config"]["variants"]
     assert v["headline"] == "flow" and v["flow_fps"] == d["value"] and v["noflow_fps"] > v["flow_fps"] > 30.0
