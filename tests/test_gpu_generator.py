@@ -305,3 +305,36 @@ def test_fused_norm_pass_matches_the_two_kernel_form():
             res[mode] = np.load(out)
     assert np.isfinite(res["1"]).all() and np.abs(res["1"]).max() > 0.05
     assert np.abs(res["0"] - res["1"]).max() <= 2e-5
+
+
+def test_lazy_resblock_chain_is_bit_identical_to_the_apply_form():
+    """The ResnetBlock chains run with every norm applied inside the next conv's Winograd input transform (default);
+    T2V_CHAIN_LAZY=0 keeps the separate apply passes.  Same arithmetic in the same order => the same bits, for square and
+    ragged tile grids, instance norm and batch norm (affine), with and without the flow branch."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    code = ("import sys, torch, numpy as np; sys.path.insert(0, %r);"
+            "from text2video_amd.generator import GeneratorSpec, HipGenerator, Vid2VidModelG, synthetic_state_dict;"
+            "outs = [];\n"
+            "g = torch.Generator().manual_seed(0)\n"
+            "for norm, no_flow, nb in (('batch', False, 4), ('instance', True, 9), ('batch', False, 2)):\n"
+            "    spec = GeneratorSpec(ngf=32, n_downsample=3, n_blocks=nb, no_flow=no_flow, norm=norm)\n"
+            "    m = Vid2VidModelG([HipGenerator(spec, 'cuda:0').load_state_dict(synthetic_state_dict(spec, 9, flow_gain=0.1))])\n"
+            "    for H, W in ((256, 256), (128, 344), (72, 40)):\n"
+            "        m.reset()\n"
+            "        for t in range(3):\n"
+            "            w = torch.zeros(H, W, 12, device='cuda:0'); w[..., :9] = (torch.rand(H, W, 9, generator=g) * 2 - 1).cuda()\n"
+            "            outs.append(m.inference_nhwc(w).cpu().numpy())\n"
+            "np.save(sys.argv[1], np.concatenate([o.reshape(-1) for o in outs]))\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    with tempfile.TemporaryDirectory() as d:
+        for mode in ("0", "1"):
+            out = os.path.join(d, "o%s.npy" % mode)
+            r = subprocess.run([sys.executable, "-c", code, out], env=dict(os.environ, T2V_CHAIN_LAZY=mode), capture_output=True,
+                               text=True, timeout=600)
+            assert r.returncode == 0, r.stderr[-2000:]
+            res[mode] = np.load(out)
+    assert np.isfinite(res["1"]).all() and np.abs(res["1"]).max() > 0.05
+    assert np.array_equal(res["0"], res["1"])

@@ -95,7 +95,7 @@ int check_desc(const t2v_gen_desc* g) {
 struct Buffers {
     float *encA[8], *encB[8];  // encoder activations per level (A: pose/seg, B: prev-image)
     float* bt[4];              // bottleneck temporaries (resnet chains)
-    float* bt2[3];             // ... of the branch that runs on the side stream
+    float* bt2[4];             // ... of the branch that runs on the side stream
     float* d;                  // encoder sum
     float *dimg, *dflow;       // local generator: d + coarse features
     float *decI[8], *decF[8];  // decoder activations per level
@@ -115,7 +115,7 @@ void plan_buffers(const t2v_gen_desc& g, const std::vector<LayerSpec>& layers, A
         b.encB[l] = a.alloc(lvl(l));
     }
     for (int i = 0; i < 4; ++i) b.bt[i] = a.alloc(lvl(n));
-    for (int i = 0; i < 3; ++i) b.bt2[i] = a.alloc(lvl(n));
+    for (int i = 0; i < 4; ++i) b.bt2[i] = a.alloc(lvl(n));
     b.d = a.alloc(lvl(n));
     b.dimg = a.alloc(lvl(n));
     b.dflow = a.alloc(lvl(n));
@@ -221,9 +221,62 @@ struct Runner {
         return conv_norm(t, y, 0, x, extra);
     }
 
+    // One F(4x4) Winograd conv of a chain, up to and including the finalize of its norm statistics; the norm itself
+    // is left to the consumer.  `lz` (or null for a plain input map) describes the norm layer the INPUT still has to
+    // go through: the previous conv's, whose (mean, rstd) are in mean_rstd[sc] until this conv's finalize replaces them.
+    struct LazyIn {
+        const t2v_layer* norm;
+        int relu;
+        const float* res;
+        float* xout;
+    };
+    int wino4_conv_stats(const float* x, const LazyIn* lz, float* y_raw) {
+        const LayerSpec& L = specs[li];
+        const t2v_layer& w = layers[li];
+        ++li;
+        const t2v_conv_desc& cd = L.cd;
+        if (g.norm_affine) T2V_REQUIRE(w.gamma && w.beta, "layer %d: norm_affine=1 but gamma/beta missing", li - 1);
+        if (lz)
+            T2V_TRY(launch_winograd4_input_lazy(s, x, b.wino[sc], cd.H, cd.W, cd.Cin, cd.pad, cd.pad_mode == T2V_PAD_REFLECT,
+                                                b.mean_rstd[sc], g.norm_affine ? lz->norm->gamma : nullptr,
+                                                g.norm_affine ? lz->norm->beta : nullptr, lz->relu, lz->res, lz->xout));
+        T2V_TRY(winograd_forward(ctx, s, &cd, x, w.w, w.bias, y_raw, b.stats[sc], b.wino[sc], lz ? 6 : 7));
+        return launch_inorm_finalize_winograd(s, b.stats[sc], 4, cd.H, cd.W, cd.Cout, g.eps, b.mean_rstd[sc], 1, b.fin[sc]);
+    }
+
+    // The same chain with every norm applied by its consumer: the next conv's input transform normalises (and adds
+    // the residual) on the fly, and writes the block output the following block needs as ITS residual on the side.
+    // Only the last norm of the chain runs as an apply pass.  Per block: 8 launches instead of 10, and one read +
+    // one write of the map less per conv.  tmp: raw conv1 / conv2 outputs, block outputs (alternating).
+    int res_chain_lazy(const float* x, int count, float* tmp[4], const float* extra, const float** out) {
+        const float* cur = x;
+        const t2v_layer* pend = nullptr;   // norm layer of the conv output waiting in tmp[1]
+        for (int i = 0; i < count; ++i) {
+            if (i == 0) {
+                T2V_TRY(wino4_conv_stats(x, nullptr, tmp[0]));
+            } else {
+                float* xi = tmp[2 + (i & 1)];
+                const LazyIn in{pend, 0, cur, xi};
+                T2V_TRY(wino4_conv_stats(tmp[1], &in, tmp[0]));
+                cur = xi;
+            }
+            const LazyIn mid{&layers[li - 1], 1, nullptr, nullptr};
+            T2V_TRY(wino4_conv_stats(tmp[0], &mid, tmp[1]));
+            pend = &layers[li - 1];
+        }
+        const LayerSpec& L = specs[li - 1];
+        T2V_TRY(launch_inorm_apply(s, tmp[1], b.mean_rstd[sc], g.norm_affine ? pend->gamma : nullptr,
+                                   g.norm_affine ? pend->beta : nullptr, cur, extra, tmp[1], (long)L.cd.H * L.cd.W,
+                                   L.cd.Cout, 0));
+        *out = tmp[1];
+        return T2V_OK;
+    }
+
     // chain of `count` resblocks starting from x (never written); result pointer in *out.
-    // `extra` is added to the output of the LAST block.  tmp: 3 distinct buffers != x.
-    int res_chain(const float* x, int count, float* tmp[3], const float* extra, const float** out) {
+    // `extra` is added to the output of the LAST block.  tmp: 4 distinct buffers != x.
+    int res_chain(const float* x, int count, float* tmp[4], const float* extra, const float** out) {
+        static const bool lazy = !(getenv("T2V_CHAIN_LAZY") && atoi(getenv("T2V_CHAIN_LAZY")) == 0);
+        if (lazy && count > 0 && specs[li].cd.algo == T2V_ALGO_WINOGRAD_F4) return res_chain_lazy(x, count, tmp, extra, out);
         const float* cur = x;
         for (int i = 0; i < count; ++i) {
             float* t = tmp[0];
@@ -236,7 +289,7 @@ struct Runner {
     }
 
     // c7,N,R, (d,N,R) x n, RB x nb ; `extra` added to the final output
-    int encoder(const float* x, float** act, int nb, float* tmp[3], const float* extra, const float** out) {
+    int encoder(const float* x, float** act, int nb, float* tmp[4], const float* extra, const float** out) {
         const int n = g.is_local ? 1 : g.n_downsample;
         T2V_TRY(conv_norm(x, act[0], 1, nullptr, nullptr));
         for (int i = 0; i < n; ++i) {
@@ -351,8 +404,8 @@ int t2v_generator_forward(t2v_ctx* ctx, void* stream, const t2v_gen_desc* d, con
     r2.sc = two_streams ? 1 : 0;
 
     // d = model_down_seg(x) + model_down_img(prev)
-    float* tmpA[3] = {b.bt[0], b.bt[1], b.bt[2]};
-    float* tmpB[3] = {b.bt2[0], b.bt2[1], b.bt2[2]};
+    float* tmpA[4] = {b.bt[0], b.bt[1], b.bt[2], b.bt[3]};
+    float* tmpB[4] = {b.bt2[0], b.bt2[1], b.bt2[2], b.bt2[3]};
     const float *segout, *imgout;
     T2V_TRY(fork());
     r2.li = enc_layers;

@@ -131,6 +131,10 @@ int launch_winograd_output(hipStream_t s, const float* Mm, const float* bias, fl
 int launch_winograd4_weight(hipStream_t s, const float* w, float* U, int Cout, int Cin, int Cout_p, int Cin_s, int adjoint = 0);
 int launch_winograd4_input(hipStream_t s, const float* x, float* V, int H, int W, int C, int pad, int reflect, int batch = 1,
                            int image = 0);
+// input transform of a conv output that still has to go through its norm layer (winograd4_input_kernel<1|2>)
+int launch_winograd4_input_lazy(hipStream_t s, const float* x, float* V, int H, int W, int C, int pad, int reflect,
+                                const float* mean_rstd, const float* gamma, const float* beta, int relu_only,
+                                const float* res, float* xout);
 int launch_winograd4_dy(hipStream_t s, const float* dy, float* Md, int Ho, int Wo, int N, int dy_cs, int batch, int image);
 int launch_winograd4_dw(hipStream_t s, const float* dU, float* dw, int Cout, int Cin, int Cout_p, int Kp, int accumulate);
 int launch_winograd4_output(hipStream_t s, const float* Mm, const float* bias, float* y, float* stats, int H, int W, int N,

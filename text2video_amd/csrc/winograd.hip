@@ -283,9 +283,20 @@ int launch_winograd4_weight(hipStream_t s, const float* w, float* U, int Cout, i
 
 // V[a*6+b][tile][c] = (B^T d B)[a][b]; one thread = one tile x 2 channels (float2; 36 live values each)
 // Tt / t0: V is [36][Tt][C] and this image's tiles start at row t0 (a batch of images shares one matrix)
+//
+// MODE 1 / 2: x is a conv output that has not been normalised yet.  The transform applies the consumer side of the
+// norm layer on the fly -- d = [relu]((x - mean) * rstd [* gamma + beta]) [+ res], the arithmetic of
+// inorm_apply_kernel in the same order, so the result is bit-identical to apply-then-transform.  MODE 1: with ReLU
+// (a ResnetBlock's first norm).  MODE 2: plus the residual, and the tile's own 4x4 pixels of d are written to `xout`
+// as well (every pixel belongs to exactly one tile): a ResnetBlock's output, which the next block needs again as
+// its residual.  All pointers are distinct buffers (restrict: the side stores must not fence the patch loads).
+template <int MODE>
 __global__ __launch_bounds__(256) void winograd4_input_kernel(const float2* __restrict__ x, float2* __restrict__ V, int H,
                                                               int W, int C2, int TW, int T, int Tp, int pad, int reflect,
-                                                              int Tt, int t0) {
+                                                              int Tt, int t0, const float2* __restrict__ mean_rstd,
+                                                              const float2* __restrict__ gamma,
+                                                              const float2* __restrict__ beta,
+                                                              const float2* __restrict__ res, float2* __restrict__ xout) {
     const long total = (long)Tp * C2;
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
@@ -309,16 +320,51 @@ __global__ __launch_bounds__(256) void winograd4_input_kernel(const float2* __re
             ry[k] = max(min(yy, 2 * H - 2 - yy), 0);   // past the reflected border: ragged tile, outputs masked
             rx[k] = max(min(xx, 2 * W - 2 - xx), 0);
         }
+        float2 mr0, mr1, gm = make_float2(1.f, 1.f), bt = make_float2(0.f, 0.f);
+        if (MODE) {
+            mr0 = mean_rstd[2 * c2];
+            mr1 = mean_rstd[2 * c2 + 1];
+            if (gamma) {
+                gm = gamma[c2];
+                bt = beta[c2];
+            }
+        }
         // rows first: r[a][j] = sum_b B^T[j][b] d[a][b]
         float rxv[6][6], ryv[6][6];
 #pragma unroll
         for (int a = 0; a < 6; ++a) {
+            float2 d[6], r[6];
+#pragma unroll
+            for (int b = 0; b < 6; ++b) {
+                const long at = ((long)ry[a] * W + rx[b]) * C2 + c2;
+                d[b] = (oky[a] && okx[b]) ? x[at] : make_float2(0.f, 0.f);
+                if (MODE == 2) r[b] = (oky[a] && okx[b]) ? res[at] : make_float2(0.f, 0.f);
+            }
             float dx[6], dy[6];
 #pragma unroll
             for (int b = 0; b < 6; ++b) {
-                const float2 d = (oky[a] && okx[b]) ? x[((long)ry[a] * W + rx[b]) * C2 + c2] : make_float2(0.f, 0.f);
-                dx[b] = d.x;
-                dy[b] = d.y;
+                float2 v = d[b];
+                if (MODE && oky[a] && okx[b]) {
+                    v.x = (v.x - mr0.x) * mr0.y;
+                    v.y = (v.y - mr1.x) * mr1.y;
+                    if (gamma) {
+                        v.x = v.x * gm.x + bt.x;
+                        v.y = v.y * gm.y + bt.y;
+                    }
+                    if (MODE == 1) {
+                        v.x = fmaxf(v.x, 0.f);
+                        v.y = fmaxf(v.y, 0.f);
+                    }
+                    if (MODE == 2) {
+                        v.x += r[b].x;
+                        v.y += r[b].y;
+                        // the tile's own pixels: rows / columns pad .. pad+3 of the patch, inside the map
+                        if (a >= pad && a < pad + 4 && b >= pad && b < pad + 4 && 4 * ty - pad + a < H && 4 * tx - pad + b < W)
+                            xout[((long)ry[a] * W + rx[b]) * C2 + c2] = v;
+                    }
+                }
+                dx[b] = v.x;
+                dy[b] = v.y;
             }
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
@@ -345,9 +391,28 @@ int launch_winograd4_input(hipStream_t s, const float* x, float* V, int H, int W
                            int image) {
     const int Ho = H + 2 * pad - 2, Wo = W + 2 * pad - 2;
     const int TW = (Wo + 3) / 4, T = ((Ho + 3) / 4) * TW, Tp = wino_pad_tiles(T);
-    hipLaunchKernelGGL(winograd4_input_kernel, dim3(wg_grid((long)Tp * (C / 2), 256)), dim3(256), 0, s,
+    hipLaunchKernelGGL(winograd4_input_kernel<0>, dim3(wg_grid((long)Tp * (C / 2), 256)), dim3(256), 0, s,
                        reinterpret_cast<const float2*>(x), reinterpret_cast<float2*>(V), H, W, C / 2, TW, T, Tp, pad,
-                       reflect, batch * Tp, image * Tp);
+                       reflect, batch * Tp, image * Tp, nullptr, nullptr, nullptr, nullptr, nullptr);
+    T2V_HIP_CHECK(hipGetLastError());
+    return T2V_OK;
+}
+// relu_only: 1 = [ReLU](norm(x)); 0 = norm(x) + res with the result also written to xout (both required)
+int launch_winograd4_input_lazy(hipStream_t s, const float* x, float* V, int H, int W, int C, int pad, int reflect,
+                                const float* mean_rstd, const float* gamma, const float* beta, int relu_only,
+                                const float* res, float* xout) {
+    T2V_REQUIRE(mean_rstd && (gamma == nullptr) == (beta == nullptr), "winograd4_input_lazy: bad norm arguments");
+    T2V_REQUIRE(relu_only ? (!res && !xout) : (res && xout), "winograd4_input_lazy: residual and side output go together");
+    // with another padding a tile's own 4x4 block would not tile the input map
+    T2V_REQUIRE(relu_only || pad == 1, "winograd4_input_lazy: the side output needs pad == 1");
+    const int Ho = H + 2 * pad - 2, Wo = W + 2 * pad - 2;
+    const int TW = (Wo + 3) / 4, T = ((Ho + 3) / 4) * TW, Tp = wino_pad_tiles(T);
+    auto kern = relu_only ? winograd4_input_kernel<1> : winograd4_input_kernel<2>;
+    hipLaunchKernelGGL(kern, dim3(wg_grid((long)Tp * (C / 2), 256)), dim3(256), 0, s, reinterpret_cast<const float2*>(x),
+                       reinterpret_cast<float2*>(V), H, W, C / 2, TW, T, Tp, pad, reflect, Tp, 0,
+                       reinterpret_cast<const float2*>(mean_rstd), reinterpret_cast<const float2*>(gamma),
+                       reinterpret_cast<const float2*>(beta), reinterpret_cast<const float2*>(res),
+                       reinterpret_cast<float2*>(xout));
     T2V_HIP_CHECK(hipGetLastError());
     return T2V_OK;
 }
