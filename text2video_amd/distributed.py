@@ -124,6 +124,8 @@ def exchange_tails(plan, rank, my_tails):
     shapes = [None] * world
     dist.all_gather_object(shapes, [tuple(t.shape) for t in my_tails])
     kinds = {s for per_rank in shapes for s in per_rank}
+    if not kinds:      # no rank generated anything
+        return {}
     if len(kinds) != 1:
         raise NotImplementedError("stitching needs one frame geometry across all chunks, got %s" % sorted(kinds))
     shape = kinds.pop()

@@ -185,7 +185,10 @@ def run_test(opt, model=None, device="cuda:0", dataset=None):
         else:
             from . import mux
             import glob
+            own = None if plan is None else {u[0] for u in plan[rank]}    # the ranks share results_dir: mux only what this one wrote
             for seq_dir in sorted(glob.glob(os.path.join(vis.save_dir, "*"))):
+                if own is not None and os.path.basename(seq_dir) not in own:
+                    continue
                 frames = sorted(glob.glob(os.path.join(seq_dir, "fake_B_*.jpg")))
                 if frames and os.path.isdir(seq_dir):
                     out = os.path.join(os.path.dirname(vis.save_dir), "%s_%s.mp4" % (opt.name, os.path.basename(seq_dir)))
