@@ -666,14 +666,15 @@ int launch_pad_copy(hipStream_t s, const float* x, float* xp, int batch, int H, 
 }
 
 // adjoint of ReflectionPad2d(p): dx[i][j] = sum of dxp over every padded position that mirrors to (i,j)
-__global__ void reflect_pad_backward_kernel(const float* __restrict__ dxp, float* __restrict__ dx, int H, int W, int C,
-                                            int p) {
+// VT = float4 when C % 4 == 0 (every layer of the generator), float otherwise; same order of additions either way
+template <class VT>
+__global__ void reflect_pad_backward_kernel(const VT* __restrict__ dxp, VT* __restrict__ dx, int H, int W, int Cv, int p) {
     const int Wp = W + 2 * p;
-    const long total = (long)H * W * C;
+    const long total = (long)H * W * Cv;
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-        const int c = (int)(i % C);
-        const long pix = i / C;
+        const int c = (int)(i % Cv);
+        const long pix = i / Cv;
         const int x = (int)(pix % W), y = (int)(pix / W);
         int ys[3], xs[3], ny = 0, nx = 0;
         ys[ny++] = y + p;
@@ -682,15 +683,19 @@ __global__ void reflect_pad_backward_kernel(const float* __restrict__ dxp, float
         xs[nx++] = x + p;
         if (x >= 1 && x <= p) xs[nx++] = p - x;
         if (x >= W - 1 - p && x <= W - 2) xs[nx++] = 2 * (W - 1) + p - x;
-        float s = 0.f;
+        VT s = dxp[((long)ys[0] * Wp + xs[0]) * Cv + c];   // 0 + v == v: the first term starts the sum
         for (int a = 0; a < ny; ++a)
-            for (int b = 0; b < nx; ++b) s += dxp[((long)ys[a] * Wp + xs[b]) * C + c];
+            for (int b = (a == 0 ? 1 : 0); b < nx; ++b) s += dxp[((long)ys[a] * Wp + xs[b]) * Cv + c];
         dx[i] = s;
     }
 }
 int launch_reflect_pad_backward(hipStream_t s, const float* dxp, float* dx, int H, int W, int C, int p) {
-    hipLaunchKernelGGL(reflect_pad_backward_kernel, dim3(grid_for((long)H * W * C, 256)), dim3(256), 0, s, dxp, dx, H, W,
-                       C, p);
+    if (C % 4 == 0)
+        hipLaunchKernelGGL(reflect_pad_backward_kernel<float4>, dim3(grid_for((long)H * W * (C / 4), 256)), dim3(256), 0, s,
+                           reinterpret_cast<const float4*>(dxp), reinterpret_cast<float4*>(dx), H, W, C / 4, p);
+    else
+        hipLaunchKernelGGL(reflect_pad_backward_kernel<float>, dim3(grid_for((long)H * W * C, 256)), dim3(256), 0, s, dxp, dx,
+                           H, W, C, p);
     T2V_HIP_CHECK(hipGetLastError());
     return T2V_OK;
 }
