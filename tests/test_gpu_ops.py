@@ -112,6 +112,30 @@ def test_head_conv_small_cout(act):
     assert y[..., 3].abs().max().item() == 0.0
 
 
+@pytest.mark.parametrize("geom", [(66, 66, 512, 1), (34, 35, 512, 1), (9, 13, 256, 1), (3, 3, 512, 1), (18, 14, 256, 2)],
+                         ids=lambda g: "%dx%dx%d_s%d" % g)
+@pytest.mark.parametrize("lrelu", [False, True], ids=["linear", "lrelu"])
+def test_single_output_channel_conv(geom, lrelu):
+    """Conv2d(C, 1, 4, padding=2): the PatchGAN discriminators' last layer runs on the wave-per-pixel kernel
+    (conv_cout1_kernel) instead of the implicit GEMM; every tap position relative to the zero border is covered."""
+    from text2video_amd import ops
+    H, W, Cin, stride = geom
+    x = _rand(Cin, H, W, seed=11)
+    w = _rand(1, Cin, 4, 4, seed=12, scale=0.02)
+    b = _rand(1, seed=13, scale=0.1)
+    ref = _ref_conv(x, w, b, 4, stride, 2, 0, False)
+    act, slope = (ops.ACT_LRELU, 0.2) if lrelu else (ops.ACT_NONE, 1.0)
+    if lrelu:
+        ref = F.leaky_relu(ref, 0.2)
+    desc = ops.conv_desc(H, W, Cin, 1, 4, stride, 2, ops.PAD_ZERO, False, act, slope)
+    xs = _to_nhwc(x)
+    pw = ops.pack_conv_weight(w.to(_dev()), desc, Cin)
+    y = torch.full(tuple(ref.shape[1:]) + (4,), float("nan"), device=_dev())
+    ops.conv2d(xs, pw, b.to(_dev()), desc, y_cs=4, out=y)
+    assert (_from_nhwc(y, 1) - ref).abs().max().item() <= TOL * max(1.0, ref.abs().max().item())
+    assert y[..., 1:].abs().max().item() == 0.0
+
+
 def test_instance_norm_affine_residual_matches_trainmode_batchnorm():
     """BN(train, N=1) == IN + affine; apply adds two residuals after the ReLU-less norm."""
     from text2video_amd import ops

@@ -221,6 +221,20 @@ int run_conv(t2v_ctx* ctx, hipStream_t s, const ConvPlan& pl, const float* x, co
             return launch_conv_head7x7(s, h);
         }
     }
+    {
+        // one output channel, long K (the discriminators' last layer): a wave per output pixel (conv_head.hip)
+        static const int use_c1 = getenv("T2V_CONV_COUT1") ? atoi(getenv("T2V_CONV_COUT1")) : 1;
+        const ConvKParams& q = pl.kp;
+        if (use_c1 && !stats && q.nphases == 1 && q.Cout == 1 && q.pad_mode == T2V_PAD_ZERO && q.ostride == 1 &&
+            q.ph[0].ntaps == q.KW * q.KW && conv_cout1_supported(q.KW, q.Cin_s) &&
+            (q.act == T2V_ACT_NONE || q.act == T2V_ACT_LRELU)) {
+            Cout1Params c;
+            c.x = x; c.w = w; c.bias = bias; c.y = y;
+            c.H = q.Hin; c.W = q.Win; c.Cin_s = q.Cin_s; c.ksize = q.KW; c.stride = q.stride; c.pad = q.pad;
+            c.Hout = pl.Hout; c.Wout = pl.Wout; c.Cout_s = y_cs; c.act = q.act; c.act_scale = q.act_scale;
+            return launch_conv_cout1(s, c);
+        }
+    }
     if (pl.tile == kTileStem && stats) {
         StemParams sp;
         sp.x = x; sp.w = w; sp.bias = bias; sp.y = y; sp.stats = stats;

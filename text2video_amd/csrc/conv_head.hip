@@ -164,4 +164,75 @@ int launch_conv_head7x7(hipStream_t s, const HeadParams& p) {
     return wide ? launch_head<32>(s, p) : launch_head<16>(s, p);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Conv2d(C, 1, k, zero padding): the last layer of every PatchGAN discriminator (C = 8 * ndf = 512, k = 4: one
+// 8192-long dot product per output pixel, 67 x 67 pixels at 512 x 512).  On the implicit-GEMM kernel that is 18
+// blocks of 256 K stages each -- 130 us of latency for 37 MFLOP.  Here a wave owns an output pixel: the weight
+// vector lives in registers (k*k*C/64 floats per lane, loaded once per wave), each tap is one coalesced 1-2 KiB
+// row of the NHWC input, and the 64 partial sums meet in a cross-lane reduction.  Consecutive pixels of a wave
+// share 3/4 of their taps through L1.  Bound: L2 reads of the taps (k*k x the input), ~10 us at 67 x 67 x 512.
+constexpr int kC1Pix = 4;   // output pixels per wave
+template <int KS, int CPL>  // CPL = float4 chunks per lane and tap = Cin_s / 256
+__global__ __launch_bounds__(256) void conv_cout1_kernel(const Cout1Params p) {
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int C4 = p.Cin_s >> 2;
+    const float4* __restrict__ x4 = reinterpret_cast<const float4*>(p.x);
+    const float4* __restrict__ w4 = reinterpret_cast<const float4*>(p.w);
+    float4 wv[KS * KS][CPL];
+#pragma unroll
+    for (int t = 0; t < KS * KS; ++t)
+#pragma unroll
+        for (int h = 0; h < CPL; ++h) wv[t][h] = w4[t * C4 + h * 64 + lane];
+    const float bv = p.bias ? p.bias[0] : 0.f;
+    const int P = p.Hout * p.Wout;
+    for (int i = 0; i < kC1Pix; ++i) {
+        const int pix = wave * kC1Pix + i;   // wave-uniform
+        if (pix >= P) return;
+        const int oy = pix / p.Wout, ox = pix - oy * p.Wout;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int kh = 0; kh < KS; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < KS; ++kw) {
+                const int iy = oy * p.stride - p.pad + kh, ix = ox * p.stride - p.pad + kw;
+                const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                // taps in the zero padding read pixel 0 and are masked: no branch between the loads
+                const long base = ok ? ((long)iy * p.W + ix) * C4 : 0;
+#pragma unroll
+                for (int h = 0; h < CPL; ++h) {
+                    float4 xv = x4[base + h * 64 + lane];
+                    if (!ok) xv = make_float4(0.f, 0.f, 0.f, 0.f);
+                    const float4 wq = wv[kh * KS + kw][h];
+                    acc.x = fmaf(xv.x, wq.x, acc.x);
+                    acc.y = fmaf(xv.y, wq.y, acc.y);
+                    acc.z = fmaf(xv.z, wq.z, acc.z);
+                    acc.w = fmaf(xv.w, wq.w, acc.w);
+                }
+            }
+        float s = (acc.x + acc.y) + (acc.z + acc.w);
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+        if (lane == 0) {
+            float v = s + bv;
+            if (p.act == T2V_ACT_LRELU) v = v > 0.f ? v : v * p.act_scale;
+            float* dst = p.y + (size_t)pix * p.Cout_s;
+            dst[0] = v;
+            for (int c = 1; c < p.Cout_s; ++c) dst[c] = 0.f;
+        }
+    }
+}
+bool conv_cout1_supported(int ksize, int Cin_s) { return ksize == 4 && (Cin_s == 256 || Cin_s == 512); }
+int launch_conv_cout1(hipStream_t s, const Cout1Params& p) {
+    T2V_REQUIRE(conv_cout1_supported(p.ksize, p.Cin_s), "conv_cout1: k=%d Cin_s=%d not supported", p.ksize, p.Cin_s);
+    const int P = p.Hout * p.Wout;
+    const int blocks = (P + 4 * kC1Pix - 1) / (4 * kC1Pix);
+    if (p.Cin_s == 512)
+        hipLaunchKernelGGL((conv_cout1_kernel<4, 2>), dim3(blocks), dim3(256), 0, s, p);
+    else
+        hipLaunchKernelGGL((conv_cout1_kernel<4, 1>), dim3(blocks), dim3(256), 0, s, p);
+    T2V_HIP_CHECK(hipGetLastError());
+    return T2V_OK;
+}
+
 }  // namespace t2v

@@ -152,6 +152,18 @@ struct HeadParams {
 };
 int launch_conv_head7x7(hipStream_t s, const HeadParams& p);
 
+// single-output-channel convolution (the PatchGAN discriminators' last layer; conv_head.hip)
+struct Cout1Params {
+    const float* x;
+    const float* w;      // row 0 of the packed [Cout_p][Kp] weight: K = tap * Cin_s + c
+    const float* bias;
+    float* y;
+    int H, W, Cin_s, ksize, stride, pad, Hout, Wout, Cout_s, act;
+    float act_scale;
+};
+bool conv_cout1_supported(int ksize, int Cin_s);
+int launch_conv_cout1(hipStream_t s, const Cout1Params& p);
+
 struct StemParams {
     const float* x;
     const float* w;      // the packed [Cout_p][Kp] weight of the implicit-GEMM kernels
