@@ -518,13 +518,39 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const long long* __rest
     float* __restrict__ v = reinterpret_cast<float*>(ptrs[4 * t + 3]);
     const float ss = step_size[t];
     const long long end = min(nelem[t], off + (long long)chunk);
-    for (long long i = off + threadIdx.x; i < end; i += blockDim.x) {
-        const float gi = g[i];
-        const float mi = m[i] * b1 + omb1 * gi;
-        const float vi = v[i] * b2 + omb2 * gi * gi;
+    auto upd = [&](float gi, float& mi, float& vi, float& pi) {
+        mi = mi * b1 + omb1 * gi;
+        vi = vi * b2 + omb2 * gi * gi;
+        pi = pi - ss * (mi / (sqrtf(vi) + eps));
+    };
+    // 16-byte lanes over the aligned body (torch allocations are 256-byte aligned and the chunk size is a multiple of
+    // 4: only a view with an odd storage offset falls back to scalars), scalars for the tail
+    long long body = off;
+    if ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0 && (off & 3) == 0) {
+        const long long n4 = (end - off) >> 2;
+        float4* p4 = reinterpret_cast<float4*>(p + off);
+        const float4* g4 = reinterpret_cast<const float4*>(g + off);
+        float4* m4 = reinterpret_cast<float4*>(m + off);
+        float4* v4 = reinterpret_cast<float4*>(v + off);
+        for (long long i = threadIdx.x; i < n4; i += blockDim.x) {
+            const float4 gv = g4[i];
+            float4 mv = m4[i], vv = v4[i], pv = p4[i];
+            upd(gv.x, mv.x, vv.x, pv.x);
+            upd(gv.y, mv.y, vv.y, pv.y);
+            upd(gv.z, mv.z, vv.z, pv.z);
+            upd(gv.w, mv.w, vv.w, pv.w);
+            m4[i] = mv;
+            v4[i] = vv;
+            p4[i] = pv;
+        }
+        body = off + (n4 << 2);
+    }
+    for (long long i = body + threadIdx.x; i < end; i += blockDim.x) {
+        float mi = m[i], vi = v[i], pi = p[i];
+        upd(g[i], mi, vi, pi);
         m[i] = mi;
         v[i] = vi;
-        p[i] = p[i] - ss * (mi / (sqrtf(vi) + eps));
+        p[i] = pi;
     }
 }
 int launch_adam_multi(hipStream_t s, const long long* ptrs, const long long* nelem, const float* step_size,

@@ -248,35 +248,66 @@ __device__ __forceinline__ float cdot(const double (&row)[K], const float (&v)[K
     return acc;
 }
 
+__device__ __forceinline__ void winograd4_weight_store(const double (&g)[3][3], float* __restrict__ U, size_t at,
+                                                        size_t pos_stride) {
+    double t[6][3];
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) t[a][b] = f4::kG[a][0] * g[0][b] + f4::kG[a][1] * g[1][b] + f4::kG[a][2] * g[2][b];
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+            const double u = t[a][0] * f4::kG[b][0] + t[a][1] * f4::kG[b][1] + t[a][2] * f4::kG[b][2];
+            U[(size_t)(a * 6 + b) * pos_stride + at] = (float)u;   // transformed in fp64, rounded once
+        }
+}
 __global__ void winograd4_weight_kernel(const float* __restrict__ w, float* __restrict__ U, int Cout, int Cin, int Cout_p,
-                                        int Cin_s, int adjoint) {
+                                        int Cin_s) {
     const long total = (long)Cout_p * Cin_s;
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
         const int n = (int)(i / Cin_s), c = (int)(i - (long)n * Cin_s);
-        double g[3][3], t[6][3];
+        double g[3][3];
 #pragma unroll
         for (int a = 0; a < 3; ++a)
 #pragma unroll
-            for (int b = 0; b < 3; ++b)
-                g[a][b] = (n < Cout && c < Cin) ? (double)(adjoint ? w[(((size_t)c * Cout + n) * 3 + (2 - a)) * 3 + (2 - b)]
-                                                                   : w[(((size_t)n * Cin + c) * 3 + a) * 3 + b]) : 0.0;
-#pragma unroll
-        for (int a = 0; a < 6; ++a)
-#pragma unroll
-            for (int b = 0; b < 3; ++b) t[a][b] = f4::kG[a][0] * g[0][b] + f4::kG[a][1] * g[1][b] + f4::kG[a][2] * g[2][b];
-#pragma unroll
-        for (int a = 0; a < 6; ++a)
-#pragma unroll
-            for (int b = 0; b < 6; ++b) {
-                const double u = t[a][0] * f4::kG[b][0] + t[a][1] * f4::kG[b][1] + t[a][2] * f4::kG[b][2];
-                U[((size_t)(a * 6 + b) * Cout_p + n) * Cin_s + c] = (float)u;   // transformed in fp64, rounded once
-            }
+            for (int b = 0; b < 3; ++b) g[a][b] = (n < Cout && c < Cin) ? (double)w[(((size_t)n * Cin + c) * 3 + a) * 3 + b] : 0.0;
+        winograd4_weight_store(g, U, (size_t)n * Cin_s + c, (size_t)Cout_p * Cin_s);
     }
 }
+// The data-gradient conv's weights from the FORWARD layer's tensor: element (n, c, a, b) = w[c][n][2-a][2-b], w laid out
+// [Cin of this conv = forward Cout][Cout of this conv = forward Cin][3][3].  A thread per (n, c) with c fastest would
+// gather 36-byte pieces 36 KB apart; instead a block stages the 8 (n) x 32 (c) tile through LDS: per c a contiguous
+// run of 8 x 9 floats is read, and the transformed values leave in 128-byte rows.
+__global__ __launch_bounds__(256) void winograd4_weight_adjoint_kernel(const float* __restrict__ w, float* __restrict__ U,
+                                                                       int Cout, int Cin, int Cout_p, int Cin_s) {
+    __shared__ float sh[32][8 * 9 + 1];
+    const int n0 = blockIdx.y * 8, c0 = blockIdx.x * 32;
+    for (int i = threadIdx.x; i < 32 * 72; i += 256) {
+        const int cl = i / 72, r = i - cl * 72;        // r = nl * 9 + tap
+        const int c = c0 + cl, n = n0 + r / 9;
+        sh[cl][r] = (c < Cin && n < Cout) ? w[((size_t)c * Cout + n0) * 9 + r] : 0.f;
+    }
+    __syncthreads();
+    const int cl = threadIdx.x & 31, nl = threadIdx.x >> 5;
+    const int n = n0 + nl, c = c0 + cl;
+    if (n >= Cout_p || c >= Cin_s) return;
+    double g[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) g[a][b] = (double)sh[cl][nl * 9 + (2 - a) * 3 + (2 - b)];
+    winograd4_weight_store(g, U, (size_t)n * Cin_s + c, (size_t)Cout_p * Cin_s);
+}
 int launch_winograd4_weight(hipStream_t s, const float* w, float* U, int Cout, int Cin, int Cout_p, int Cin_s, int adjoint) {
-    hipLaunchKernelGGL(winograd4_weight_kernel, dim3(wg_grid((long)Cout_p * Cin_s, 256)), dim3(256), 0, s, w, U, Cout, Cin,
-                       Cout_p, Cin_s, adjoint);
+    if (adjoint)
+        hipLaunchKernelGGL(winograd4_weight_adjoint_kernel, dim3((Cin_s + 31) / 32, (Cout_p + 7) / 8), dim3(256), 0, s, w, U,
+                           Cout, Cin, Cout_p, Cin_s);
+    else
+        hipLaunchKernelGGL(winograd4_weight_kernel, dim3(wg_grid((long)Cout_p * Cin_s, 256)), dim3(256), 0, s, w, U, Cout, Cin,
+                           Cout_p, Cin_s);
     T2V_HIP_CHECK(hipGetLastError());
     return T2V_OK;
 }
