@@ -29,7 +29,7 @@ __device__ __forceinline__ void dma16(const void* base, unsigned nbytes, char* l
 #endif
 }
 
-template <int NPL, int RING>
+template <int NPL, int RING, int ABL = 0>   // ABL (ablations): 1 = no DMA inside the K loop, 2 = no MFMAs
 __global__ __launch_bounds__(512) void gemm_split_kernel(const u16* __restrict__ A, const u16* __restrict__ B, float* __restrict__ C) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int STAGE = NPL * 2 * 64 * 128;   // [plane][A|B][64 LDS rows][128 B]
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(512) void gemm_split_kernel(const u16* __restrict__
         __builtin_amdgcn_s_barrier();
         int slot = AHEAD % RING;
         for (int kt = 0; kt < nk; ++kt) {
-            issue_stage(kt + AHEAD < nk ? kt + AHEAD : nk - 1, slot);
+            if (ABL != 1) issue_stage(kt + AHEAD < nk ? kt + AHEAD : nk - 1, slot);
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * LD) : "memory");
             __builtin_amdgcn_s_barrier();
             slot = slot == RING - 1 ? 0 : slot + 1;
@@ -135,12 +135,12 @@ __global__ __launch_bounds__(512) void gemm_split_kernel(const u16* __restrict__
         const int nbuf = buf == RING - 1 ? 0 : buf + 1;
         __builtin_amdgcn_sched_barrier(0);
         load_frags(buf, 1, 1);
-        mfmas(0);
+        if (ABL != 2) mfmas(0);
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();   // barrier(kt): slot `buf` fully read, stage kt+1 visible
         __builtin_amdgcn_sched_barrier(0);
         load_frags(nbuf, 0, 0);
-        mfmas(1);
+        if (ABL != 2) mfmas(1);
         buf = nbuf;
     }
 
@@ -183,9 +183,9 @@ __global__ void split_kernel(const float* x, u16* planes, size_t n) {
     }
 }
 
-template <int NPL, int RING>
+template <int NPL, int RING, int ABL = 0>
 static float run(const u16* A, const u16* B, float* C, int iters) {
-    auto kern = gemm_split_kernel<NPL, RING>;
+    auto kern = gemm_split_kernel<NPL, RING, ABL>;
     const int lds = RING * NPL * 2 * 64 * 128;
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     const int blocks = P * (M / BM) * (N / BN);
@@ -250,5 +250,9 @@ int main(int argc, char** argv) {
     ms = run<2, 3>(pA, pB, dC, iters);
     printf("3 products, ring 3: %.1f us  (%.0f TF executed bf16)\n", ms * 1e3, 3 * gf / ms);
     check(hA.data(), hB.data(), dC, "3 products");
+    ms = run<3, 3, 1>(pA, pB, dC, iters);
+    printf("ablation, 6 products, no DMA in the K loop: %.1f us\n", ms * 1e3);
+    ms = run<3, 3, 2>(pA, pB, dC, iters);
+    printf("ablation, 6 products, no MFMAs (DMA + LDS reads + barriers): %.1f us\n", ms * 1e3);
     return 0;
 }
