@@ -397,3 +397,59 @@ def test_c_stamping_loops_equal_the_numpy_form(lib_built, monkeypatch):
     for xs, ys, bw, rgb, caps in segs:
         K.stamp(b, xs, ys, bw, rgb, caps)
     assert a.any() and np.array_equal(a, b)
+
+
+def test_host_rasteriser_loops_are_clean_under_the_sanitizers(tmp_path):
+    """SURVEY section 5 (race detection / sanitizers): the host-side C of the frame path (csrc/raster_host.c) built with
+    -fsanitize=address,undefined and driven over segments that hang over every border, pens wider than the image,
+    key points far outside it and point counts past the stack buffer."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    src = os.path.join(ROOT, "text2video_amd", "csrc", "raster_host.c")
+    drv = tmp_path / "drive.c"
+    drv.write_text(r'''
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+void t2v_raster_stamp(uint8_t* img, int h, int w, const long* xs, const long* ys, int n, int bw, const double* rgb, int caps);
+int main(void) {
+    const int dims[4][2] = {{1, 1}, {7, 5}, {64, 48}, {33, 130}};
+    unsigned s = 12345u;
+    for (int d = 0; d < 4; ++d) {
+        const int h = dims[d][0], w = dims[d][1];
+        uint8_t* img = (uint8_t*)calloc((size_t)h * w * 3, 1);
+        for (int rep = 0; rep < 40; ++rep) {
+            const int n = rep % 5 == 4 ? 3000 : 1 + (int)(s % 97u);
+            long* xs = (long*)malloc(sizeof(long) * n);
+            long* ys = (long*)malloc(sizeof(long) * n);
+            for (int i = 0; i < n; ++i) {
+                s = s * 1664525u + 1013904223u;
+                xs[i] = (long)(s >> 8) % (3 * w + 1) - w;
+                s = s * 1664525u + 1013904223u;
+                ys[i] = (long)(s >> 8) % (3 * h + 1) - h;
+            }
+            if (rep % 7 == 0) { xs[0] = 4000000000000L; ys[n - 1] = -4000000000000L; }
+            const double rgb[3] = {(double)(s & 255u), 170.0, 0.0};
+            t2v_raster_stamp(img, h, w, xs, ys, n, 1 + rep % 4, rgb, rep & 1);
+            free(xs);
+            free(ys);
+        }
+        unsigned long sum = 0;
+        for (long i = 0; i < (long)h * w * 3; ++i) sum += img[i];
+        printf("%d x %d: %lu\n", h, w, sum);
+        free(img);
+    }
+    return 0;
+}
+''')
+    exe = tmp_path / "drive"
+    r = subprocess.run(["gcc", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", str(drv), src, "-o", str(exe)],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120,
+                       env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", LD_PRELOAD=""))
+    assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
+    assert r.stdout.count("\n") == 4

@@ -14,19 +14,20 @@
 #include <stdint.h>
 #include <stdlib.h>
 
-static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+/* coordinates stay 64-bit until they are clamped (numpy clips int64 values): a far-off key point cannot overflow */
+static inline long clampl(long v, long lo, long hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 /* one pen offset over n points: all-black test, then paint or average */
 static void blend_points(uint8_t* img, int h, int w, const long* xs, const long* ys, int n, int ox, int oy,
                          const double rgb[3]) {
     int all_zero = 1;
     for (int i = 0; i < n && all_zero; ++i) {
-        const uint8_t* p = img + ((long)clampi((int)ys[i] + oy, 0, h - 1) * w + clampi((int)xs[i] + ox, 0, w - 1)) * 3;
+        const uint8_t* p = img + (clampl(ys[i] + oy, 0, h - 1) * w + clampl(xs[i] + ox, 0, w - 1)) * 3;
         all_zero = (p[0] | p[1] | p[2]) == 0;
     }
     if (all_zero) {
         for (int i = 0; i < n; ++i) {
-            uint8_t* p = img + ((long)clampi((int)ys[i] + oy, 0, h - 1) * w + clampi((int)xs[i] + ox, 0, w - 1)) * 3;
+            uint8_t* p = img + (clampl(ys[i] + oy, 0, h - 1) * w + clampl(xs[i] + ox, 0, w - 1)) * 3;
             p[0] = (uint8_t)rgb[0]; p[1] = (uint8_t)rgb[1]; p[2] = (uint8_t)rgb[2];
         }
         return;
@@ -38,11 +39,11 @@ static void blend_points(uint8_t* img, int h, int w, const long* xs, const long*
     uint8_t* tmp = n <= CH ? stack_tmp : (uint8_t*)malloc((size_t)n * 3);
     if (!tmp) return;
     for (int i = 0; i < n; ++i) {
-        const uint8_t* p = img + ((long)clampi((int)ys[i] + oy, 0, h - 1) * w + clampi((int)xs[i] + ox, 0, w - 1)) * 3;
+        const uint8_t* p = img + (clampl(ys[i] + oy, 0, h - 1) * w + clampl(xs[i] + ox, 0, w - 1)) * 3;
         for (int c = 0; c < 3; ++c) tmp[i * 3 + c] = (uint8_t)(((double)p[c] + rgb[c]) / 2.0);
     }
     for (int i = 0; i < n; ++i) {
-        uint8_t* p = img + ((long)clampi((int)ys[i] + oy, 0, h - 1) * w + clampi((int)xs[i] + ox, 0, w - 1)) * 3;
+        uint8_t* p = img + (clampl(ys[i] + oy, 0, h - 1) * w + clampl(xs[i] + ox, 0, w - 1)) * 3;
         p[0] = tmp[i * 3]; p[1] = tmp[i * 3 + 1]; p[2] = tmp[i * 3 + 2];
     }
     if (tmp != stack_tmp) free(tmp);
