@@ -190,6 +190,16 @@ int build_winograd_gemm_plan(const t2v_conv_desc* d, ConvPlan* pl) {
     g.H = wino_pos(d->algo); g.W = T; g.Cin = d->Cin; g.Cout = d->Cout; g.kH = g.kW = 1; g.stride = 1; g.pad = 0;
     g.pad_mode = T2V_PAD_ZERO; g.act = T2V_ACT_NONE; g.act_scale = 1.f;
     T2V_TRY(build_conv_plan(&g, d->Cin, /*need_stats: 128- or 64-row tiles only*/ true, pl));
+    // T2V_WINO_GEMM_TILE=0: 128x128 tiles wherever the tile count allows (half the LDS-DMA traffic of the 64x64 tiles the
+    // fill heuristic picks for 2.25-round grids; measured slower alone, and in two-stream frames -- DESIGN 4.3)
+    static const int force_l = getenv("T2V_WINO_GEMM_TILE") ? atoi(getenv("T2V_WINO_GEMM_TILE")) == 0 : 0;
+    if (force_l && pl->tile == kTileQ && T % 128 == 0 && d->Cout > 64) {
+        pl->tile = kTileL;
+        conv_tile_dims(pl->tile, &pl->BM, &pl->BN);
+        pl->kp.ntiles = (g.Cout + pl->BN - 1) / pl->BN;
+        pl->kp.mtiles = (pl->kp.M + pl->BM - 1) / pl->BM;
+        pl->nparts = pl->kp.nphases * pl->kp.mtiles;
+    }
     if (T % pl->BM != 0 && pl->tile == kTileL) {   // tile count padded to 64 only: the 64x64 tile config
         pl->tile = kTileQ;
         conv_tile_dims(pl->tile, &pl->BM, &pl->BN);
