@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- frames/sec of the vid2vid pose->RGB generator on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W            (N > 1: spawns one rank per GPU itself, text2video_amd/launch.py)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One "step" = one output frame of the hot path: pack the 3-pose-map window (uint8 maps already
@@ -156,17 +156,19 @@ def main():
     ap.add_argument("--kernel-iters", type=int, default=40)
     args = ap.parse_args()
 
+    from text2video_amd import launch
+    # plain `python bench.py --gpus N` (no torchrun environment): run the N ranks ourselves, one per GPU
+    launch.fan_out_if_needed(args.gpus)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        print("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N>1)"
+        print("bench.py: --gpus %d but WORLD_SIZE=%d (the launcher's world size and --gpus must agree)"
               % (args.gpus, world), file=sys.stderr)
         sys.exit(2)
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     backend = os.environ.get("T2V_DIST_BACKEND", "nccl")   # "nccl" = RCCL; "gloo": several ranks on one GPU (tests only)
-    if backend == "gloo":
-        local_rank %= torch.cuda.device_count()
+    local_rank = launch.local_device_index(local_rank)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None

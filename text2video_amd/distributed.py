@@ -24,8 +24,11 @@ def init_from_env(backend=None):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if torch.cuda.is_available() and os.environ.get("T2V_DIST_BACKEND") == "gloo":
-        local_rank %= torch.cuda.device_count()     # more ranks than GPUs (single-GPU tests): ranks share devices
+    if torch.cuda.is_available():
+        # --gpu_ids[local_rank] when the self-launcher passed the list on; with T2V_DIST_BACKEND=gloo more ranks than
+        # GPUs are allowed (single-GPU tests): ranks then share devices
+        from .launch import local_device_index
+        local_rank = local_device_index(local_rank)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")

@@ -1,0 +1,107 @@
+"""One command -> one rank per GPU.
+
+The reference fans out inside one process from one command line: `python train.py ... --gpu_ids 0,1,2,3,4,5,6,7
+--batchSize 8` (/root/reference/README.md:171-176) wraps the model in nn.DataParallel, which scatters the batch,
+replicates the module and runs one Python thread per listed device
+(/root/reference/venv_vid2vid/lib/python3.7/site-packages/torch/nn/parallel/data_parallel.py:116-137).  Here the
+fan-out is one PROCESS per device with persistent replicas: when an entry point (vid2vid/train.py, vid2vid/test.py,
+bench.py) is started plainly -- no RANK / WORLD_SIZE in the environment -- and asks for more than one device, it
+re-executes its own command line once per device with the torchrun-style environment (RANK, LOCAL_RANK,
+WORLD_SIZE, LOCAL_WORLD_SIZE, MASTER_ADDR=127.0.0.1, MASTER_PORT=<free port>) and waits.  Under
+`python -m torch.distributed.run` the environment is already there and nothing is spawned.
+
+T2V_DEVICE_IDS carries the `--gpu_ids` list to the ranks: rank r computes on device ids[r] (as DataParallel's
+device_ids[r]).  With T2V_DIST_BACKEND=gloo several ranks may share a device (single-GPU tests), ids wrap around.
+"""
+import os
+import signal
+import socket
+import subprocess
+import sys
+import time
+
+
+def under_launcher():
+    """True inside a rank that torchrun (or self_launch) started."""
+    return "RANK" in os.environ and "WORLD_SIZE" in os.environ
+
+
+def free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def local_device_index(local_rank):
+    """Device ordinal this rank computes on: --gpu_ids[local_rank] when the launcher passed the list on, else
+    local_rank; wrapped to the visible devices when ranks share GPUs over gloo (tests)."""
+    ids = [int(v) for v in os.environ.get("T2V_DEVICE_IDS", "").split(",") if v.strip() != ""]
+    idx = ids[local_rank % len(ids)] if ids else local_rank
+    if os.environ.get("T2V_DIST_BACKEND") == "gloo":
+        import torch
+        if torch.cuda.is_available():
+            idx %= torch.cuda.device_count()
+    return idx
+
+
+def self_launch(nranks, device_ids=None, argv=None, poll_s=0.05):
+    """Run `sys.executable argv` (default: this process's own command line) as `nranks` ranks and return the job's
+    exit status: 0 when every rank returned 0, else the first failing rank's status (the remaining ranks are
+    terminated by PID -- a rank blocked in a collective whose peer died would otherwise wait for its timeout).
+    Ranks inherit stdout / stderr, so rank 0's single JSON / summary line is the job's."""
+    argv = list(sys.argv if argv is None else argv)
+    port = free_port()
+    procs = []
+    for r in range(nranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(nranks), LOCAL_WORLD_SIZE=str(nranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), T2V_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # the host driver only supports dmabuf IPC (RCCL needs it)
+        if device_ids:
+            env["T2V_DEVICE_IDS"] = ",".join(str(d) for d in device_ids)
+        procs.append(subprocess.Popen([sys.executable] + argv, env=env))
+
+    def stop_all(sig=signal.SIGTERM):
+        for p in procs:
+            if p.poll() is None:
+                try:
+                    p.send_signal(sig)
+                except OSError:
+                    pass
+
+    old = {}
+    for s in (signal.SIGINT, signal.SIGTERM):
+        try:
+            old[s] = signal.signal(s, lambda signum, frame: (stop_all(signum), sys.exit(128 + signum)))
+        except ValueError:      # not the main thread
+            pass
+    rc = 0
+    try:
+        live = set(range(nranks))
+        while live:
+            for r in sorted(live):
+                st = procs[r].poll()
+                if st is None:
+                    continue
+                live.discard(r)
+                if st != 0 and rc == 0:
+                    rc = st if st > 0 else 128 - st
+                    print("launch: rank %d exited with status %d -- stopping the other ranks" % (r, st), file=sys.stderr,
+                          flush=True)
+                    stop_all()
+                    t_kill = time.time() + 10.0
+                    while any(p.poll() is None for p in procs) and time.time() < t_kill:
+                        time.sleep(poll_s)
+                    stop_all(signal.SIGKILL)
+            if live:
+                time.sleep(poll_s)
+    finally:
+        for s, h in old.items():
+            signal.signal(s, h)
+    return rc
+
+
+def fan_out_if_needed(nranks, device_ids=None):
+    """Entry-point helper: if this process was started plainly and wants `nranks` > 1, run the ranks and exit with
+    the job's status; otherwise return (the caller is a rank, or a single-device run)."""
+    if nranks > 1 and not under_launcher():
+        sys.exit(self_launch(nranks, device_ids))

@@ -76,7 +76,7 @@ def _real_A_u8(pose_map_u8):
     return np.clip((x + 1) / 2.0 * 255.0, 0, 255).astype(np.uint8)
 
 
-def run_test(opt, model=None, device="cuda:0", dataset=None):
+def run_test(opt, model=None, device=None, dataset=None):
     """The frame loop.  Returns a dict of counters/timings.  `dataset`: a ready PoseDataset (e.g.
     PoseDataset.from_memory for the in-memory L2 driver) instead of the one scanned from opt.dataroot.
 
@@ -86,6 +86,9 @@ def run_test(opt, model=None, device="cuda:0", dataset=None):
     continuation chunk from its predecessor's true last frames, all-gathered over RCCL.  --how_many counts
     output frames globally, as the single-process loop does.  Every rank writes its own frames."""
     t_start = time.perf_counter()
+    if device is None:      # a plain single-device run computes on --gpu_ids[0]
+        ids = getattr(opt, "gpu_ids", None)
+        device = "cuda:%d" % (ids[0] if ids else 0)
     dataset = dataset if dataset is not None else PoseDataset(opt)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     plan = rank = None

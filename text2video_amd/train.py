@@ -1079,12 +1079,15 @@ def run_train(opt, steps=None):
     import time
     import numpy as np
     from . import distributed as Dm
-    rank, local_rank, world = Dm.init_from_env() if "WORLD_SIZE" in os.environ else (0, 0, 1)
+    if "WORLD_SIZE" in os.environ:
+        rank, local_rank, world = Dm.init_from_env()
+    else:       # a plain single-device run computes on --gpu_ids[0], as the reference's single-GPU recipes do
+        rank, local_rank, world = 0, (opt.gpu_ids[0] if getattr(opt, "gpu_ids", None) else 0), 1
     dev = "cuda:%d" % local_rank
     torch.cuda.set_device(local_rank)
     trainer = Vid2VidTrainer(opt, dev)
     if rank == 0 and getattr(opt, "batchSize", world) not in (1, world):
-        print("warning: --batchSize %d, but the batch is one clip per rank: %d (launch with torchrun --nproc-per-node %d)"
+        print("warning: --batchSize %d, but the batch is one clip per rank = %d (list %d devices in --gpu_ids)"
               % (opt.batchSize, world, opt.batchSize), flush=True)
     F_ = opt.max_frames_per_gpu
     synthetic = getattr(opt, "synthetic_data", False)

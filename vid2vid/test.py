@@ -7,7 +7,8 @@
 
 Reads datasets/<name>/test_openpose/<seq>/*.json (+ test_img/<seq>/*.jpg for size and names), writes
 results/<name>/test_latest/<seq>/{real_A,fake_B}_*.jpg.  The generator runs on the MI355X through
-libt2v_hip.so; there is no CPU fallback.
+libt2v_hip.so; there is no CPU fallback.  `--gpu_ids a,b,...` with more than one device runs one rank per device
+(whole sequences per rank; --shard_chunks also cuts sequences), started by this script itself or by torchrun.
 """
 import os
 import sys
@@ -19,6 +20,10 @@ from text2video_amd.options import TestOptions  # noqa: E402
 
 if __name__ == "__main__":
     opt = TestOptions().parse()
+    # more than one device in --gpu_ids and no torchrun environment: one rank per listed device (text2video_amd/launch.py);
+    # the sequences are dealt to the ranks (run_test), every rank writes its own frames
+    from text2video_amd import launch          # noqa: E402
+    launch.fan_out_if_needed(len(opt.gpu_ids), opt.gpu_ids)
     stats = run_test(opt)
     print("done: %d frames, %.2f fps in the frame loop -> %s" % (stats["frames"], stats["fps_loop"],
                                                                 stats["results_dir"]))
