@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define T2V_ABI_VERSION 7
+#define T2V_ABI_VERSION 8
 
 typedef enum {
     T2V_OK = 0,
@@ -335,6 +335,19 @@ int t2v_generator_layer_desc(const t2v_gen_desc* d, int i, t2v_conv_desc* out, i
 size_t t2v_generator_workspace_bytes(const t2v_gen_desc* d);
 int t2v_generator_forward(t2v_ctx* ctx, void* stream, const t2v_gen_desc* d, const t2v_layer* layers,
                           int n_layers, const t2v_gen_io* io, void* workspace, size_t ws_bytes);
+
+/* `batch` INDEPENDENT recurrences advanced in lock-step on one GPU: the frames of `batch` sequences (the reference
+ * always generates two per utterance -- tmp and tmp_smooth, text2video_audio.sh:24-31 -- and BASELINE configs[2] has
+ * more chunks than GPUs on 1-4 GPUs) through ONE pass of the layer list.  ios[i] is image i's io block (every image
+ * its own pose window, previous frames, use_raw_only and outputs).  The ResnetBlock chains (Winograd F(4x4,3x3)) run
+ * batched: the transforms carry the image index in their grid, and the 36 GEMMs see batch x T tile rows per weight
+ * matrix instead of T -- the skinny M = 256 of one 64x64 bottleneck becomes 512 at batch 2; norm statistics stay
+ * per image (instance norm), so each image's frame is the frame t2v_generator_forward computes for it.  The
+ * remaining layers are launched image by image.  Workspace from ..._workspace_bytes_batch(d, batch). */
+#define T2V_MAX_BATCH 8
+size_t t2v_generator_workspace_bytes_batch(const t2v_gen_desc* d, int batch);
+int t2v_generator_forward_batch(t2v_ctx* ctx, void* stream, const t2v_gen_desc* d, const t2v_layer* layers,
+                                int n_layers, const t2v_gen_io* ios, int batch, void* workspace, size_t ws_bytes);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,39 @@
+"""Golden maps for the training-time options of the reference rasteriser (random_drop_prob > 0, remove_face_labels):
+/root/reference/keypoint2img.py:113-123 jitters the head key points and the face and drops limbs / hands / the face
+with draws from the GLOBAL np.random stream.  Runs only in the build container (imports the reference from where it
+lies, cv2.circle stubbed as in make_host_goldens.py); the committed fixture holds inputs' names, seeds and the
+expected uint8 maps.
+
+Usage: python tests/golden/make_jitter_golden.py
+"""
+import glob
+import os
+import sys
+import types
+
+import numpy as np
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+cv2 = types.ModuleType("cv2")
+cv2.circle = lambda *a, **k: None
+cv2.imwrite = lambda *a, **k: True
+sys.modules["cv2"] = cv2
+sys.path.insert(0, REF)
+import keypoint2img  # noqa: E402
+
+cases, maps = [], []
+for frame in (0, 17):
+    name = "sa1_%03d_keypoints.json" % frame
+    src = os.path.join(HERE, "keypoints_fadg0", name)
+    assert os.path.exists(src), src
+    for seed in (1, 2):
+        for prob, remove in ((0.3, True), (0.3, False), (0.0, True)):
+            np.random.seed(seed)
+            maps.append(keypoint2img.read_keypoints(src, (512, 384), prob, remove))
+            cases.append((name, seed, prob, int(remove)))
+np.savez_compressed(os.path.join(HERE, "pose_maps_jitter.npz"), maps=np.stack(maps),
+                    names=np.array([c[0] for c in cases]), seeds=np.array([c[1] for c in cases]),
+                    probs=np.array([c[2] for c in cases]), remove=np.array([c[3] for c in cases]))
+print("jitter goldens:", np.stack(maps).shape, [int((m != 0).any(2).sum()) for m in maps])

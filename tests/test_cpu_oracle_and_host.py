@@ -89,6 +89,29 @@ def test_rasteriser_matches_reference_golden_maps():
         assert (fast != want).any(2).sum() <= 25     # closed form flips <= 25 px per frame
 
 
+def test_rasteriser_training_jitter_and_drops_match_reference_golden_maps():
+    """random_drop_prob > 0 (limb / hand / face drops) and remove_face_labels (head and face jitter,
+    /root/reference/keypoint2img.py:113-123): a RandomState seeded like the reference's global np.random stream
+    reproduces the reference's maps bit for bit (tests/golden/make_jitter_golden.py); with random_drop_prob == 0 the
+    jitter is off, as there."""
+    from text2video_amd.keypoints import read_keypoints
+    g = np.load(os.path.join(GOLD, "pose_maps_jitter.npz"))
+    plain = {}
+    for name, seed, prob, remove, want in zip(g["names"], g["seeds"], g["probs"], g["remove"], g["maps"]):
+        path = os.path.join(GOLD, "keypoints_fadg0", str(name))
+        got = read_keypoints(path, (512, 384), float(prob), bool(remove), hand_discs=False,
+                             rng=np.random.RandomState(int(seed)))
+        assert np.array_equal(got, want), (name, seed, prob, remove)
+        if prob == 0:
+            plain[str(name)] = want
+        else:
+            assert str(name) not in plain or not np.array_equal(want, plain[str(name)])
+    # the jitter really moves something: same seed, same drops, with and without remove_face_labels
+    a = read_keypoints(path, (512, 384), 0.3, True, hand_discs=False, rng=np.random.RandomState(5))
+    b = read_keypoints(path, (512, 384), 0.3, False, hand_discs=False, rng=np.random.RandomState(5))
+    assert not np.array_equal(a, b)
+
+
 def test_rasteriser_hand_discs_and_colour_key():
     from text2video_amd.keypoints import NOSE_NECK_RGB, read_keypoints
     p = os.path.join(GOLD, "keypoints_fadg0", "sa1_000_keypoints.json")

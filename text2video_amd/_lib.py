@@ -14,7 +14,8 @@ LIB_PATH = os.path.join(_HERE, "lib", "libt2v_hip.so")
 T2V_OK = 0
 PAD_ZERO, PAD_REFLECT = 0, 1
 ACT_NONE, ACT_TANH, ACT_FLOW_W, ACT_LRELU = 0, 1, 2, 3
-ABI_VERSION = 7
+ABI_VERSION = 8
+MAX_BATCH = 8     # T2V_MAX_BATCH
 ALGO_DIRECT, ALGO_WINOGRAD, ALGO_WINOGRAD_F4 = 0, 1, 2
 
 
@@ -116,6 +117,9 @@ SIGNATURES = {
     "t2v_generator_workspace_bytes": (c_size_t, [POINTER(GenDesc)]),
     "t2v_generator_forward": (c_int, [c_void_p, c_void_p, POINTER(GenDesc), POINTER(Layer), c_int, POINTER(GenIO),
                                       c_void_p, c_size_t]),
+    "t2v_generator_workspace_bytes_batch": (c_size_t, [POINTER(GenDesc), c_int]),
+    "t2v_generator_forward_batch": (c_int, [c_void_p, c_void_p, POINTER(GenDesc), POINTER(Layer), c_int, POINTER(GenIO),
+                                            c_int, c_void_p, c_size_t]),
 }
 
 _lib = None

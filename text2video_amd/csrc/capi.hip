@@ -183,8 +183,8 @@ int best_conv_algo(const t2v_conv_desc* d, int x_cs, int cap) {
 }
 
 // the batched GEMM of a Winograd conv as a plan of the implicit-GEMM kernel: a 1x1 conv over a 16|36 x T image
-int build_winograd_gemm_plan(const t2v_conv_desc* d, ConvPlan* pl) {
-    const int T = wino_tiles_padded(d, d->algo);
+int build_winograd_gemm_plan(const t2v_conv_desc* d, ConvPlan* pl, int nimg) {
+    const int T = nimg * wino_tiles_padded(d, d->algo);   // GEMM rows per transform position: all images' tiles
     t2v_conv_desc g;
     memset(&g, 0, sizeof(g));
     g.H = wino_pos(d->algo); g.W = T; g.Cin = d->Cin; g.Cout = d->Cout; g.kH = g.kW = 1; g.stride = 1; g.pad = 0;
@@ -265,26 +265,31 @@ int run_conv(t2v_ctx* ctx, hipStream_t s, const ConvPlan& pl, const float* x, co
 // all of a Winograd conv (shared with the generator orchestrator): stages bit 1 = input transform,
 // 2 = batched GEMM, 4 = output transform
 int winograd_forward(t2v_ctx* ctx, hipStream_t s, const t2v_conv_desc* d, const float* x, const float* w_packed,
-                     const float* bias, float* y, float* stats_partial, float* workspace, int stages) {
-    const size_t T = (size_t)wino_tiles_padded(d, d->algo);
+                     const float* bias, float* y, float* stats_partial, float* workspace, int stages,
+                     const WinoBatch* batch) {
+    const WinoBatch one;
+    const WinoBatch& wb = batch ? *batch : one;
+    const int nimg = wb.nimg;
+    const bool f4 = d->algo == T2V_ALGO_WINOGRAD_F4;
+    T2V_REQUIRE(nimg >= 1 && (f4 || (nimg == 1 && !wb.tickets)), "winograd: batches and in-kernel finalize are F(4x4,3x3) only");
+    const size_t T = (size_t)nimg * wino_tiles_padded(d, d->algo);
     float* V = workspace;
     float* Mm = workspace + wino_pos(d->algo) * T * d->Cin;
-    const bool f4 = d->algo == T2V_ALGO_WINOGRAD_F4;
     if (stages & 1) {
         const int reflect = d->pad_mode == T2V_PAD_REFLECT;
-        T2V_TRY(f4 ? launch_winograd4_input(s, x, V, d->H, d->W, d->Cin, d->pad, reflect)
+        T2V_TRY(f4 ? launch_winograd4_input(s, x, V, d->H, d->W, d->Cin, d->pad, reflect, nimg, 0, nimg, wb.img_stride_x)
                    : launch_winograd_input(s, x, V, d->H, d->W, d->Cin, d->pad, reflect));
     }
     if (stages & 2) {
         ConvPlan pl;
-        T2V_TRY(build_winograd_gemm_plan(d, &pl));
+        T2V_TRY(build_winograd_gemm_plan(d, &pl, nimg));
         T2V_TRY(run_conv(ctx, s, pl, V, w_packed, nullptr, Mm, d->Cout, nullptr));
     }
     if (stages & 4) {
         T2V_REQUIRE(d->act == T2V_ACT_NONE || !stats_partial, "winograd: an activation and norm statistics do not combine");
         if (f4)
             T2V_TRY(launch_winograd4_output(s, Mm, bias, y, stats_partial, wino_out_h(d), wino_out_w(d), d->Cout,
-                                            d->act == T2V_ACT_LRELU, d->act_scale));
+                                            d->act == T2V_ACT_LRELU, d->act_scale, nimg, wb.tickets, wb.mean_rstd, wb.eps));
         else
             T2V_TRY(launch_winograd_output(s, Mm, bias, y, stats_partial, wino_out_h(d), wino_out_w(d), d->Cout));
     }

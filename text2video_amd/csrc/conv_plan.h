@@ -26,16 +26,29 @@ inline int wino_tiles_padded(const t2v_conv_desc* d, int algo) {
     const int T = ((wino_out_h(d) + m - 1) / m) * ((wino_out_w(d) + m - 1) / m);
     return wino_pad_tiles(T);
 }
-inline size_t winograd_workspace_floats(const t2v_conv_desc* d) {                    // V + M
-    return (size_t)wino_pos(d->algo) * wino_tiles_padded(d, d->algo) * ((size_t)d->Cin + d->Cout);
+inline size_t winograd_workspace_floats(const t2v_conv_desc* d, int nimg = 1) {      // V + M of `nimg` images
+    return (size_t)nimg * wino_pos(d->algo) * wino_tiles_padded(d, d->algo) * ((size_t)d->Cin + d->Cout);
 }
 // GEMM rows of the whole conv (all positions): what the algorithm choice compares
 inline long wino_gemm_rows(const t2v_conv_desc* d, int algo) { return (long)wino_pos(algo) * wino_tiles_padded(d, algo); }
 bool winograd_supported(const t2v_conv_desc* d, int x_cs, int algo);
 int best_conv_algo(const t2v_conv_desc* d, int x_cs, int cap);
-int build_winograd_gemm_plan(const t2v_conv_desc* d, ConvPlan* pl);
+int build_winograd_gemm_plan(const t2v_conv_desc* d, ConvPlan* pl, int nimg = 1);
+// A batch of images through one Winograd conv (F(4x4,3x3) only when nimg > 1): the images' maps x / y are
+// `img_stride_x` / H*W*Cout floats apart, V and M hold nimg*Tp tile rows per transform position (one GEMM with
+// M = nimg*Tp rows per position), the statistics partials follow each other image by image.
+// tickets != nullptr: the output transform also finalizes the norm statistics into mean_rstd (nimg tables of
+// [Cout][2]); see launch_winograd4_output.
+struct WinoBatch {
+    int nimg = 1;
+    long img_stride_x = 0;     // floats between the input maps
+    int* tickets = nullptr;
+    float* mean_rstd = nullptr;
+    float eps = 1e-5f;
+};
 int winograd_forward(t2v_ctx* ctx, hipStream_t s, const t2v_conv_desc* d, const float* x, const float* w_packed,
-                     const float* bias, float* y, float* stats_partial, float* workspace, int stages);
+                     const float* bias, float* y, float* stats_partial, float* workspace, int stages,
+                     const WinoBatch* batch = nullptr);
 int run_conv(t2v_ctx* ctx, hipStream_t s, const ConvPlan& pl, const float* x, const float* w, const float* bias,
              float* y, int y_cs, float* stats);
 

@@ -6,6 +6,7 @@
 #include <stdlib.h>
 
 #include "t2v_internal.h"
+#include "norm_pool.h"
 
 namespace t2v {
 
@@ -32,28 +33,6 @@ static inline int grid_for(long n, int block) {
 // Pixel count of partial `part`: conv-kernel partials cover BM consecutive GEMM rows of a phase; the Winograd
 // output transform's partials (wm = 2 | 4 > 0) cover 128/wm^2 consecutive wm x wm tiles of the ceil(H/wm) x
 // ceil(W/wm) tile grid, ragged at the bottom / right edge and padded with empty tiles at the end.
-constexpr int kFinSlices = 64;
-// pixels the partial `part` was computed over (see the geometry notes above)
-__device__ __forceinline__ int partial_pixels(int part, int mtiles, int BM, int M, int wm, int H, int W) {
-    if (wm < 0) {   // square pixel tiles of edge -wm (conv_stem.hip), ragged at the right / bottom
-        const int e = -wm, TW = (W + e - 1) / e;
-        const int pi = part % mtiles, ty = pi / TW, tx = pi - ty * TW;
-        return min(e, H - e * ty) * min(e, W - e * tx);
-    }
-    if (wm == 0) {
-        const int mt = part % mtiles;
-        return min(BM, M - mt * BM);
-    }
-    const int TW = (W + wm - 1) / wm, T = ((H + wm - 1) / wm) * TW, tpb = 128 / (wm * wm);
-    const int pi = part % mtiles;   // partial index inside its image (mtiles = partials per image)
-    int nb = 0;
-    for (int t = pi * tpb; t < min((pi + 1) * tpb, T); ++t) {
-        const int ty = t / TW, tx = t - ty * TW;
-        nb += min(wm, H - wm * ty) * min(wm, W - wm * tx);
-    }
-    return nb;
-}
-
 __global__ __launch_bounds__(16 * kFinSlices) void inorm_finalize_kernel(const float2* __restrict__ stats, int nparts, int mtiles,
                                                              int BM, int M, int C, float eps,
                                                              float2* __restrict__ mean_rstd, int wm, int H, int W,
@@ -173,6 +152,14 @@ __global__ __launch_bounds__(256) void inorm_apply_kernel(const float4* __restri
                                                           const float4* __restrict__ res1,
                                                           const float4* __restrict__ res2, float4* __restrict__ y,
                                                           long n4, int C4, int relu) {
+    {   // blockIdx.y = image of a batch: maps n4 float4 apart, (mean, rstd) tables 2*C4 float4 apart
+        const long im = blockIdx.y;
+        x += im * n4;
+        y += im * n4;
+        mean_rstd += im * 2 * C4;
+        if (res1) res1 += im * n4;
+        if (res2) res2 += im * n4;
+    }
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
         const int c4 = (int)(i % C4);
@@ -212,12 +199,13 @@ __global__ __launch_bounds__(256) void inorm_apply_kernel(const float4* __restri
     }
 }
 
+// nimg > 1: a batch of images back to back (x, res1, res2, y npix*C floats apart, mean_rstd 2*C apart), one launch
 int launch_inorm_apply(hipStream_t s, const float* x, const float* mean_rstd, const float* gamma,
                        const float* beta, const float* res1, const float* res2, float* y, long npix, int C,
-                       int relu) {
+                       int relu, int nimg) {
     T2V_REQUIRE(C % 4 == 0, "inorm_apply: C=%d must be a multiple of 4", C);
     const long n4 = npix * (C / 4);
-    hipLaunchKernelGGL(inorm_apply_kernel, dim3(grid_for(n4, 256)), dim3(256), 0, s,
+    hipLaunchKernelGGL(inorm_apply_kernel, dim3(grid_for(n4, 256), nimg), dim3(256), 0, s,
                        reinterpret_cast<const float4*>(x), reinterpret_cast<const float4*>(mean_rstd),
                        reinterpret_cast<const float4*>(gamma), reinterpret_cast<const float4*>(beta),
                        reinterpret_cast<const float4*>(res1), reinterpret_cast<const float4*>(res2),

@@ -92,6 +92,11 @@ int check_desc(const t2v_gen_desc* g) {
     return T2V_OK;
 }
 
+constexpr int kMaxBatch = T2V_MAX_BATCH;
+
+// Every buffer holds the `nimg` images of a batch back to back (image stride = the single-image size), so the
+// batched kernels of the ResnetBlock chains address image i at base + i*stride and the per-image launches of the
+// other layers do the same.
 struct Buffers {
     float *encA[8], *encB[8];  // encoder activations per level (A: pose/seg, B: prev-image)
     float* bt[4];              // bottleneck temporaries (resnet chains)
@@ -100,31 +105,39 @@ struct Buffers {
     float *dimg, *dflow;       // local generator: d + coarse features
     float *decI[8], *decF[8];  // decoder activations per level
     float *raw, *fw;
-    // per-stream scratch [0]: caller's stream, [1]: side stream
+    size_t lvl[8];             // floats of one image at level l
+    size_t bott;               // = lvl[n]
+    // per-stream scratch [0]: caller's stream, [1]: side stream; one slot per image
     float* stats[2];
     float* mean_rstd[2];
-    float* wino[2];   // Winograd scratch: transformed input V + transformed output M
+    float* wino[2];   // Winograd scratch: transformed input V + transformed output M of the whole batch
     double* fin[2];   // norm finalize scratch (pooled moments per group of partials)
+    int* tickets[2];  // arrival counters of the producers that finalize their own statistics
+    size_t stats_stride, mr_stride, fin_stride;   // floats (doubles for fin) between the images' slots
+    size_t ticket_ints;                           // per stream
 };
 
-void plan_buffers(const t2v_gen_desc& g, const std::vector<LayerSpec>& layers, Arena& a, Buffers& b) {
+void plan_buffers(const t2v_gen_desc& g, const std::vector<LayerSpec>& layers, int nimg, Arena& a, Buffers& b) {
     const int G = g.ngf, n = g.is_local ? 1 : g.n_downsample;
     auto lvl = [&](int l) { return (size_t)(g.H >> l) * (g.W >> l) * (G << l); };
+    const size_t N = (size_t)nimg;
     for (int l = 0; l <= n; ++l) {
-        b.encA[l] = a.alloc(lvl(l));
-        b.encB[l] = a.alloc(lvl(l));
+        b.lvl[l] = lvl(l);
+        b.encA[l] = a.alloc(N * lvl(l));
+        b.encB[l] = a.alloc(N * lvl(l));
     }
-    for (int i = 0; i < 4; ++i) b.bt[i] = a.alloc(lvl(n));
-    for (int i = 0; i < 4; ++i) b.bt2[i] = a.alloc(lvl(n));
-    b.d = a.alloc(lvl(n));
-    b.dimg = a.alloc(lvl(n));
-    b.dflow = a.alloc(lvl(n));
+    b.bott = lvl(n);
+    for (int i = 0; i < 4; ++i) b.bt[i] = a.alloc(N * lvl(n));
+    for (int i = 0; i < 4; ++i) b.bt2[i] = a.alloc(N * lvl(n));
+    b.d = a.alloc(N * lvl(n));
+    b.dimg = a.alloc(N * lvl(n));
+    b.dflow = a.alloc(N * lvl(n));
     for (int l = 0; l < n; ++l) {
-        b.decI[l] = a.alloc(lvl(l));
-        b.decF[l] = g.no_flow ? nullptr : a.alloc(lvl(l));
+        b.decI[l] = a.alloc(N * lvl(l));
+        b.decF[l] = g.no_flow ? nullptr : a.alloc(N * lvl(l));
     }
-    b.raw = a.alloc((size_t)g.H * g.W * 4);
-    b.fw = a.alloc((size_t)g.H * g.W * 4);
+    b.raw = a.alloc(N * g.H * g.W * 4);
+    b.fw = a.alloc(N * g.H * g.W * 4);
     size_t max_stats = 0;
     int max_c = 4;
     for (const LayerSpec& L : layers) {
@@ -139,19 +152,39 @@ void plan_buffers(const t2v_gen_desc& g, const std::vector<LayerSpec>& layers, A
         }
         if (L.cd.Cout > max_c) max_c = L.cd.Cout;
     }
+    b.stats_stride = (max_stats + 63) / 64 * 64;
+    b.mr_stride = (size_t)max_c * 2;
+    b.fin_stride = (size_t)kFinalizeMaxGroups * max_c * 4;
+    b.ticket_ints = (size_t)kMaxBatch * ((max_c + 63) / 64);
     for (int k = 0; k < 2; ++k) {
-        b.stats[k] = a.alloc(max_stats);
-        b.mean_rstd[k] = a.alloc((size_t)max_c * 2);
-        b.fin[k] = reinterpret_cast<double*>(a.alloc((size_t)kFinalizeMaxGroups * max_c * 4 * 2));
+        b.stats[k] = a.alloc(N * b.stats_stride);
+        b.mean_rstd[k] = a.alloc(N * b.mr_stride);
+        b.fin[k] = reinterpret_cast<double*>(a.alloc(N * b.fin_stride * 2));
     }
+    // both streams' counters in one block: one memset per frame clears them
+    b.tickets[0] = reinterpret_cast<int*>(a.alloc(2 * b.ticket_ints));
+    b.tickets[1] = b.tickets[0] + b.ticket_ints;
     size_t max_wino = 0;
     for (const LayerSpec& L : layers)
         if (is_winograd(L.cd.algo)) {
-            const size_t w = winograd_workspace_floats(&L.cd);
+            const size_t w = winograd_workspace_floats(&L.cd, L.cd.algo == T2V_ALGO_WINOGRAD_F4 ? nimg : 1);
             if (w > max_wino) max_wino = w;
         }
     for (int k = 0; k < 2; ++k) b.wino[k] = max_wino ? a.alloc(max_wino) : nullptr;
 }
+
+// the images of a batch as pointers (maps that are not laid out back to back: the caller's inputs and outputs)
+struct Ptrs {
+    const float* p[kMaxBatch];
+};
+struct MutPtrs {
+    float* p[kMaxBatch];
+    operator Ptrs() const {
+        Ptrs q;
+        for (int i = 0; i < kMaxBatch; ++i) q.p[i] = p[i];
+        return q;
+    }
+};
 
 struct Runner {
     t2v_ctx* ctx;
@@ -160,70 +193,101 @@ struct Runner {
     const std::vector<LayerSpec>& specs;
     const t2v_layer* layers;
     Buffers& b;
+    int nimg;
     int li = 0;
     int sc = 0;   // which per-stream scratch set this runner uses
 
-    // conv (+ fused stats) -> finalize -> apply.  y receives the conv output and is normalised in
-    // place: y = [relu](norm(conv(x))) + res1 + res2
-    int conv_norm(const float* x, float* y, int relu, const float* res1, const float* res2) {
-        const LayerSpec& L = specs[li];
-        const t2v_layer& w = layers[li];
-        ++li;
-        ConvPlan pl;
-        const int Cout = L.cd.Cout;
-        if (is_winograd(L.cd.algo)) {
-            const int M = L.cd.H * L.cd.W;
-            T2V_TRY(winograd_forward(ctx, s, &L.cd, x, w.w, w.bias, y, b.stats[sc], b.wino[sc], 7));
-            const float* gam = g.norm_affine ? w.gamma : nullptr;
-            const float* bet = g.norm_affine ? w.beta : nullptr;
-            if (g.norm_affine) T2V_REQUIRE(gam && bet, "layer %d: norm_affine=1 but gamma/beta missing", li - 1);
-            const int wm = wino_m(L.cd.algo);
-            const int nparts = wino_tiles_padded(&L.cd, L.cd.algo) / (128 / (wm * wm));
-            if (inorm_fused_ok(nparts, Cout))   // the apply pass pools the (few) partials itself: no finalize launch
-                return launch_inorm_apply_partials(s, y, b.stats[sc], nparts, nparts, 0, M, wm, L.cd.H, L.cd.W, Cout, g.eps,
-                                                   gam, bet, res1, res2, y, (long)M, relu);
-            T2V_TRY(launch_inorm_finalize_winograd(s, b.stats[sc], wm, L.cd.H, L.cd.W, Cout, g.eps, b.mean_rstd[sc], 1,
-                                                   b.fin[sc]));
-            return launch_inorm_apply(s, y, b.mean_rstd[sc], gam, bet, res1, res2, y, (long)M, Cout, relu);
-        }
-        T2V_TRY(build_conv_plan(&L.cd, L.x_cs, true, &pl));
-        T2V_TRY(run_conv(ctx, s, pl, x, w.w, w.bias, y, Cout, b.stats[sc]));
-        if (pl.tile != kTileStem && inorm_fused_ok(pl.nparts, Cout)) {
-            const float* gam = g.norm_affine ? w.gamma : nullptr;
-            const float* bet = g.norm_affine ? w.beta : nullptr;
-            if (g.norm_affine) T2V_REQUIRE(gam && bet, "layer %d: norm_affine=1 but gamma/beta missing", li - 1);
-            return launch_inorm_apply_partials(s, y, b.stats[sc], pl.nparts, pl.kp.mtiles, pl.BM, pl.kp.M, 0, 0, 0, Cout, g.eps,
-                                               gam, bet, res1, res2, y, (long)pl.Hout * pl.Wout, relu);
-        }
-        if (pl.tile == kTileStem)
-            T2V_TRY(launch_inorm_finalize_tiles(s, b.stats[sc], 16, L.cd.H, L.cd.W, Cout, g.eps, b.mean_rstd[sc], 1, b.fin[sc]));
-        else
-            T2V_TRY(launch_inorm_finalize(s, b.stats[sc], pl.nparts, pl.kp.mtiles, pl.BM, pl.kp.M, Cout, g.eps, b.mean_rstd[sc],
-                                          b.fin[sc]));
-        const float* gamma = g.norm_affine ? w.gamma : nullptr;
-        const float* beta = g.norm_affine ? w.beta : nullptr;
-        if (g.norm_affine) T2V_REQUIRE(gamma && beta, "layer %d: norm_affine=1 but gamma/beta missing", li - 1);
-        return launch_inorm_apply(s, y, b.mean_rstd[sc], gamma, beta, res1, res2, y, (long)pl.Hout * pl.Wout, Cout, relu);
+    Ptrs at(const float* base, size_t stride) const {
+        Ptrs q{};
+        for (int i = 0; i < nimg; ++i) q.p[i] = base ? base + (size_t)i * stride : nullptr;
+        return q;
+    }
+    MutPtrs at(float* base, size_t stride) const {
+        MutPtrs q{};
+        for (int i = 0; i < nimg; ++i) q.p[i] = base ? base + (size_t)i * stride : nullptr;
+        return q;
+    }
+    float* stats_of(int im) const { return b.stats[sc] + (size_t)im * b.stats_stride; }
+    float* mr_of(int im) const { return b.mean_rstd[sc] + (size_t)im * b.mr_stride; }
+    double* fin_of(int im) const { return b.fin[sc] + (size_t)im * b.fin_stride; }
+    // T2V_NORM_TICKET=0: every norm layer's statistics are finalized by a launch of their own (read per call, so one
+    // process can compare the two forms)
+    static bool ticket_on() {
+        const char* e = getenv("T2V_NORM_TICKET");
+        return !(e && atoi(e) == 0);
     }
 
-    int head(const float* x, float* y) {
+    // conv (+ fused stats) -> finalize -> apply of layer `l` for ONE image.  y receives the conv output and is
+    // normalised in place: y = [relu](norm(conv(x))) + res1 + res2
+    int conv_norm_one(int l, int im, const float* x, float* y, int relu, const float* res1, const float* res2) {
+        const LayerSpec& L = specs[l];
+        const t2v_layer& w = layers[l];
+        ConvPlan pl;
+        const int Cout = L.cd.Cout;
+        float* stats = stats_of(im);
+        float* mr = mr_of(im);
+        const float* gam = g.norm_affine ? w.gamma : nullptr;
+        const float* bet = g.norm_affine ? w.beta : nullptr;
+        if (g.norm_affine) T2V_REQUIRE(gam && bet, "layer %d: norm_affine=1 but gamma/beta missing", l);
+        if (is_winograd(L.cd.algo)) {
+            const int M = L.cd.H * L.cd.W;
+            const int wm = wino_m(L.cd.algo);
+            const int nparts = wino_tiles_padded(&L.cd, L.cd.algo) / (128 / (wm * wm));
+            const bool fused = inorm_fused_ok(nparts, Cout);
+            // the output transform's last block per channel group finalizes the statistics itself
+            const bool ticket = !fused && ticket_on() && wm == 4 && winograd4_ticket_ok(L.cd.H, L.cd.W);
+            WinoBatch wb;
+            if (ticket) {
+                wb.tickets = b.tickets[sc];
+                wb.mean_rstd = mr;
+                wb.eps = g.eps;
+            }
+            T2V_TRY(winograd_forward(ctx, s, &L.cd, x, w.w, w.bias, y, stats, b.wino[sc], 7, &wb));
+            if (fused)   // the apply pass pools the (few) partials itself: no finalize launch
+                return launch_inorm_apply_partials(s, y, stats, nparts, nparts, 0, M, wm, L.cd.H, L.cd.W, Cout, g.eps,
+                                                   gam, bet, res1, res2, y, (long)M, relu);
+            if (!ticket)
+                T2V_TRY(launch_inorm_finalize_winograd(s, stats, wm, L.cd.H, L.cd.W, Cout, g.eps, mr, 1, fin_of(im)));
+            return launch_inorm_apply(s, y, mr, gam, bet, res1, res2, y, (long)M, Cout, relu);
+        }
+        T2V_TRY(build_conv_plan(&L.cd, L.x_cs, true, &pl));
+        T2V_TRY(run_conv(ctx, s, pl, x, w.w, w.bias, y, Cout, stats));
+        if (pl.tile != kTileStem && inorm_fused_ok(pl.nparts, Cout))
+            return launch_inorm_apply_partials(s, y, stats, pl.nparts, pl.kp.mtiles, pl.BM, pl.kp.M, 0, 0, 0, Cout, g.eps,
+                                               gam, bet, res1, res2, y, (long)pl.Hout * pl.Wout, relu);
+        if (pl.tile == kTileStem)
+            T2V_TRY(launch_inorm_finalize_tiles(s, stats, 16, L.cd.H, L.cd.W, Cout, g.eps, mr, 1, fin_of(im)));
+        else
+            T2V_TRY(launch_inorm_finalize(s, stats, pl.nparts, pl.kp.mtiles, pl.BM, pl.kp.M, Cout, g.eps, mr, fin_of(im)));
+        return launch_inorm_apply(s, y, mr, gam, bet, res1, res2, y, (long)pl.Hout * pl.Wout, Cout, relu);
+    }
+    // the next layer for every image of the batch (one launch sequence per image)
+    int conv_norm(const Ptrs& x, const MutPtrs& y, int relu, const Ptrs& res1) {
+        for (int im = 0; im < nimg; ++im) T2V_TRY(conv_norm_one(li, im, x.p[im], y.p[im], relu, res1.p[im], nullptr));
+        ++li;
+        return T2V_OK;
+    }
+
+    int head(const Ptrs& x, const MutPtrs& y) {
         const LayerSpec& L = specs[li];
         const t2v_layer& w = layers[li];
         ++li;
         ConvPlan pl;
         T2V_TRY(build_conv_plan(&L.cd, L.x_cs, false, &pl));
-        return run_conv(ctx, s, pl, x, w.w, w.bias, y, 4, nullptr);
+        for (int im = 0; im < nimg; ++im) T2V_TRY(run_conv(ctx, s, pl, x.p[im], w.w, w.bias, y.p[im], 4, nullptr));
+        return T2V_OK;
     }
 
-    // x + [pad1,conv3,N,ReLU,pad1,conv3,N](x) (+ extra)
-    int resblock(const float* x, float* t, float* y, const float* extra) {
-        T2V_TRY(conv_norm(x, t, 1, nullptr, nullptr));
-        return conv_norm(t, y, 0, x, extra);
+    // x + [pad1,conv3,N,ReLU,pad1,conv3,N](x), image by image
+    int resblock(const Ptrs& x, const MutPtrs& t, const MutPtrs& y) {
+        T2V_TRY(conv_norm(x, t, 1, Ptrs{}));
+        return conv_norm(t, y, 0, x);
     }
 
-    // One F(4x4) Winograd conv of a chain, up to and including the finalize of its norm statistics; the norm itself
-    // is left to the consumer.  `lz` (or null for a plain input map) describes the norm layer the INPUT still has to
-    // go through: the previous conv's, whose (mean, rstd) are in mean_rstd[sc] until this conv's finalize replaces them.
+    // One F(4x4) Winograd conv of a chain over the whole batch (maps `bott` floats apart), up to and including the
+    // finalize of its norm statistics; the norm itself is left to the consumer.  `lz` (or null for a plain input map)
+    // describes the norm layer the INPUT still has to go through: the previous conv's, whose (mean, rstd) tables are in
+    // mean_rstd[sc] until this conv's finalize replaces them.
     struct LazyIn {
         const t2v_layer* norm;
         int relu;
@@ -236,19 +300,37 @@ struct Runner {
         ++li;
         const t2v_conv_desc& cd = L.cd;
         if (g.norm_affine) T2V_REQUIRE(w.gamma && w.beta, "layer %d: norm_affine=1 but gamma/beta missing", li - 1);
+        T2V_REQUIRE(b.mr_stride == (size_t)2 * cd.Cout, "internal: chain scratch layout");
         if (lz)
             T2V_TRY(launch_winograd4_input_lazy(s, x, b.wino[sc], cd.H, cd.W, cd.Cin, cd.pad, cd.pad_mode == T2V_PAD_REFLECT,
                                                 b.mean_rstd[sc], g.norm_affine ? lz->norm->gamma : nullptr,
-                                                g.norm_affine ? lz->norm->beta : nullptr, lz->relu, lz->res, lz->xout));
-        T2V_TRY(winograd_forward(ctx, s, &cd, x, w.w, w.bias, y_raw, b.stats[sc], b.wino[sc], lz ? 6 : 7));
-        return launch_inorm_finalize_winograd(s, b.stats[sc], 4, cd.H, cd.W, cd.Cout, g.eps, b.mean_rstd[sc], 1, b.fin[sc]);
+                                                g.norm_affine ? lz->norm->beta : nullptr, lz->relu, lz->res, lz->xout, nimg,
+                                                (long)b.bott));
+        const bool ticket = ticket_on() && winograd4_ticket_ok(cd.H, cd.W);
+        WinoBatch wb;
+        wb.nimg = nimg;
+        wb.img_stride_x = (long)b.bott;
+        if (ticket) {
+            wb.tickets = b.tickets[sc];
+            wb.mean_rstd = b.mean_rstd[sc];
+            wb.eps = g.eps;
+        }
+        // the images' partials are packed back to back by the batched output transform: nparts*Cout*2 floats each
+        T2V_TRY(winograd_forward(ctx, s, &cd, x, w.w, w.bias, y_raw, b.stats[sc], b.wino[sc], lz ? 6 : 7, &wb));
+        if (ticket) return T2V_OK;
+        const size_t per_img = (size_t)(wino_tiles_padded(&cd, cd.algo) / 8) * cd.Cout * 2;
+        for (int im = 0; im < nimg; ++im)
+            T2V_TRY(launch_inorm_finalize_winograd(s, b.stats[sc] + im * per_img, 4, cd.H, cd.W, cd.Cout, g.eps, mr_of(im), 1,
+                                                   fin_of(im)));
+        return T2V_OK;
     }
 
     // The same chain with every norm applied by its consumer: the next conv's input transform normalises (and adds
     // the residual) on the fly, and writes the block output the following block needs as ITS residual on the side.
-    // Only the last norm of the chain runs as an apply pass.  Per block: 8 launches instead of 10, and one read +
-    // one write of the map less per conv.  tmp: raw conv1 / conv2 outputs, block outputs (alternating).
-    int res_chain_lazy(const float* x, int count, float* tmp[4], const float* extra, const float** out) {
+    // Only the last norm of the chain runs as an apply pass.  Per block: 8 launches instead of 10 (6 when the output
+    // transforms finalize the statistics themselves) for the WHOLE batch, and one read + one write of the map less
+    // per conv.  tmp: raw conv1 / conv2 outputs, block outputs (alternating); all hold the batch back to back.
+    int res_chain_lazy(const float* x, int count, float* tmp[4], const float** out) {
         const float* cur = x;
         const t2v_layer* pend = nullptr;   // norm layer of the conv output waiting in tmp[1]
         for (int i = 0; i < count; ++i) {
@@ -266,50 +348,51 @@ struct Runner {
         }
         const LayerSpec& L = specs[li - 1];
         T2V_TRY(launch_inorm_apply(s, tmp[1], b.mean_rstd[sc], g.norm_affine ? pend->gamma : nullptr,
-                                   g.norm_affine ? pend->beta : nullptr, cur, extra, tmp[1], (long)L.cd.H * L.cd.W,
-                                   L.cd.Cout, 0));
+                                   g.norm_affine ? pend->beta : nullptr, cur, nullptr, tmp[1], (long)L.cd.H * L.cd.W,
+                                   L.cd.Cout, 0, nimg));
         *out = tmp[1];
         return T2V_OK;
     }
 
-    // chain of `count` resblocks starting from x (never written); result pointer in *out.
-    // `extra` is added to the output of the LAST block.  tmp: 4 distinct buffers != x.
-    int res_chain(const float* x, int count, float* tmp[4], const float* extra, const float** out) {
+    // chain of `count` resblocks starting from x (never written; the batch back to back, `bott` floats apart); result
+    // pointer in *out.  tmp: 4 distinct buffers != x.
+    int res_chain(const float* x, int count, float* tmp[4], const float** out) {
         static const bool lazy = !(getenv("T2V_CHAIN_LAZY") && atoi(getenv("T2V_CHAIN_LAZY")) == 0);
-        if (lazy && count > 0 && specs[li].cd.algo == T2V_ALGO_WINOGRAD_F4) return res_chain_lazy(x, count, tmp, extra, out);
+        if (lazy && count > 0 && specs[li].cd.algo == T2V_ALGO_WINOGRAD_F4 && b.mr_stride == (size_t)2 * specs[li].cd.Cout)
+            return res_chain_lazy(x, count, tmp, out);
         const float* cur = x;
         for (int i = 0; i < count; ++i) {
             float* t = tmp[0];
             float* y = (cur == tmp[1]) ? tmp[2] : tmp[1];
-            T2V_TRY(resblock(cur, t, y, i == count - 1 ? extra : nullptr));
+            T2V_TRY(resblock(at(cur, b.bott), at(t, b.bott), at(y, b.bott)));
             cur = y;
         }
         *out = cur;
         return T2V_OK;
     }
 
-    // c7,N,R, (d,N,R) x n, RB x nb ; `extra` added to the final output
-    int encoder(const float* x, float** act, int nb, float* tmp[4], const float* extra, const float** out) {
+    // c7,N,R, (d,N,R) x n, RB x nb
+    int encoder(const Ptrs& x, float** act, int nb, float* tmp[4], const float** out) {
         const int n = g.is_local ? 1 : g.n_downsample;
-        T2V_TRY(conv_norm(x, act[0], 1, nullptr, nullptr));
-        for (int i = 0; i < n; ++i) {
-            const bool last = (i == n - 1) && nb == 0;
-            T2V_TRY(conv_norm(act[i], act[i + 1], 1, last ? extra : nullptr, nullptr));
-        }
+        T2V_TRY(conv_norm(x, at(act[0], b.lvl[0]), 1, Ptrs{}));
+        for (int i = 0; i < n; ++i) T2V_TRY(conv_norm(at(act[i], b.lvl[i]), at(act[i + 1], b.lvl[i + 1]), 1, Ptrs{}));
         if (nb == 0) {
             *out = act[n];
             return T2V_OK;
         }
-        return res_chain(act[n], nb, tmp, extra, out);
+        return res_chain(act[n], nb, tmp, out);
     }
 
     int decoder(const float* x, float** dec, const float** out) {
         const int n = g.is_local ? 1 : g.n_downsample;
         const float* cur = x;
+        size_t cur_stride = b.bott;
         for (int i = 0; i < n; ++i) {
-            float* y = dec[n - 1 - i];
-            T2V_TRY(conv_norm(cur, y, 1, nullptr, nullptr));
+            const int l = n - 1 - i;
+            float* y = dec[l];
+            T2V_TRY(conv_norm(at(cur, cur_stride), at(y, b.lvl[l]), 1, Ptrs{}));
             cur = y;
+            cur_stride = b.lvl[l];
         }
         *out = cur;
         return T2V_OK;
@@ -340,35 +423,40 @@ int t2v_generator_layer_desc(const t2v_gen_desc* d, int i, t2v_conv_desc* out, i
     return T2V_OK;
 }
 
-size_t t2v_generator_workspace_bytes(const t2v_gen_desc* d) {
-    if (check_desc(d) != T2V_OK) return 0;
+size_t t2v_generator_workspace_bytes_batch(const t2v_gen_desc* d, int batch) {
+    if (check_desc(d) != T2V_OK || batch < 1 || batch > kMaxBatch) return 0;
     std::vector<LayerSpec> L;
     enumerate_layers(*d, L);
     Arena a{nullptr, 0};
     Buffers b;
-    plan_buffers(*d, L, a, b);
+    plan_buffers(*d, L, batch, a, b);
     return a.off;
 }
+size_t t2v_generator_workspace_bytes(const t2v_gen_desc* d) { return t2v_generator_workspace_bytes_batch(d, 1); }
 
-int t2v_generator_forward(t2v_ctx* ctx, void* stream, const t2v_gen_desc* d, const t2v_layer* layers, int n_layers,
-                          const t2v_gen_io* io, void* workspace, size_t ws_bytes) {
-    T2V_REQUIRE(ctx && layers && io && workspace, "generator_forward: null pointer");
+int t2v_generator_forward_batch(t2v_ctx* ctx, void* stream, const t2v_gen_desc* d, const t2v_layer* layers, int n_layers,
+                                const t2v_gen_io* ios, int batch, void* workspace, size_t ws_bytes) {
+    T2V_REQUIRE(ctx && layers && ios && workspace, "generator_forward: null pointer");
+    T2V_REQUIRE(batch >= 1 && batch <= kMaxBatch, "generator_forward: batch %d out of range [1,%d]", batch, kMaxBatch);
     T2V_TRY(check_desc(d));
     std::vector<LayerSpec> specs;
     enumerate_layers(*d, specs);
     T2V_REQUIRE(n_layers == (int)specs.size(), "generator_forward: expected %d layers, got %d", (int)specs.size(),
                 n_layers);
-    T2V_REQUIRE(io->pose && io->prev && io->out, "generator_forward: pose/prev/out must be set");
     T2V_REQUIRE(((uintptr_t)workspace & 255) == 0, "workspace must be 256-byte aligned");
-    if (d->is_local) {
-        T2V_REQUIRE(io->coarse_img_feat, "local generator needs coarse_img_feat");
-        T2V_REQUIRE(d->no_flow || io->coarse_flow_feat, "local generator with flow needs coarse_flow_feat");
+    for (int im = 0; im < batch; ++im) {
+        const t2v_gen_io* io = ios + im;
+        T2V_REQUIRE(io->pose && io->prev && io->out, "generator_forward: pose/prev/out must be set (image %d)", im);
+        if (d->is_local) {
+            T2V_REQUIRE(io->coarse_img_feat, "local generator needs coarse_img_feat");
+            T2V_REQUIRE(d->no_flow || io->coarse_flow_feat, "local generator with flow needs coarse_flow_feat");
+        }
     }
     for (int i = 0; i < n_layers; ++i)
         T2V_REQUIRE(layers[i].w && layers[i].bias, "layer %d: weight/bias pointer missing", i);
     Arena a{reinterpret_cast<char*>(workspace), ws_bytes};
     Buffers b;
-    plan_buffers(*d, specs, a, b);
+    plan_buffers(*d, specs, batch, a, b);
     if (a.overflow) {
         set_error("generator_forward: workspace %zu bytes < required %zu", ws_bytes, a.off);
         return T2V_ERR_WORKSPACE;
@@ -394,75 +482,96 @@ int t2v_generator_forward(t2v_ctx* ctx, void* stream, const t2v_gen_desc* d, con
     };
     const int n = d->is_local ? 1 : d->n_downsample;
     const int G = d->ngf;
-    const size_t bott = (size_t)(d->H >> n) * (d->W >> n) * (G << n);
+    const size_t bott = b.bott;
     const int nb_enc = d->is_local ? 0 : d->n_blocks - d->n_blocks / 2;
     const int nb_res = d->is_local ? d->n_blocks : d->n_blocks / 2;
     const int enc_layers = 1 + n + 2 * nb_enc;                 // layers of one encoder
     const int branch_layers = 2 * nb_res + n + 1;              // res trunk + decoder + head of one branch
-    Runner r{ctx, s, *d, specs, layers, b};
-    Runner r2{ctx, s2, *d, specs, layers, b};
+    Runner r{ctx, s, *d, specs, layers, b, batch};
+    Runner r2{ctx, s2, *d, specs, layers, b, batch};
     r2.sc = two_streams ? 1 : 0;
+    // arrival counters of the producers that finalize their own norm statistics (they leave them zeroed; this
+    // clears whatever an aborted frame, or the allocator, left behind)
+    T2V_HIP_CHECK(hipMemsetAsync(b.tickets[0], 0, 2 * b.ticket_ints * sizeof(int), s));
 
+    Ptrs pose{}, prevp{};
+    for (int im = 0; im < batch; ++im) {
+        pose.p[im] = ios[im].pose;
+        prevp.p[im] = ios[im].prev;
+    }
     // d = model_down_seg(x) + model_down_img(prev)
     float* tmpA[4] = {b.bt[0], b.bt[1], b.bt[2], b.bt[3]};
     float* tmpB[4] = {b.bt2[0], b.bt2[1], b.bt2[2], b.bt2[3]};
     const float *segout, *imgout;
     T2V_TRY(fork());
     r2.li = enc_layers;
-    T2V_TRY(r2.encoder(io->prev, b.encB, nb_enc, tmpB, nullptr, &imgout));
-    T2V_TRY(r.encoder(io->pose, b.encA, nb_enc, tmpA, nullptr, &segout));
+    T2V_TRY(r2.encoder(prevp, b.encB, nb_enc, tmpB, &imgout));
+    T2V_TRY(r.encoder(pose, b.encA, nb_enc, tmpA, &segout));
     T2V_TRY(join());
-    T2V_TRY(launch_add(s, imgout, segout, b.d, (long)bott));   // (norm + x) + seg: the order the fused form summed in
+    T2V_TRY(launch_add(s, imgout, segout, b.d, (long)(batch * bott)));   // (norm + x) + seg: the order the fused form summed in
     const float* dsum = b.d;
     r.li = 2 * enc_layers;
 
     const float* img_in = dsum;
     const float* flow_in = dsum;
     if (d->is_local) {
-        T2V_TRY(launch_add(s, dsum, io->coarse_img_feat, b.dimg, (long)bott));
-        img_in = b.dimg;
-        if (!d->no_flow) {
-            T2V_TRY(launch_add(s, dsum, io->coarse_flow_feat, b.dflow, (long)bott));
-            flow_in = b.dflow;
+        for (int im = 0; im < batch; ++im) {
+            T2V_TRY(launch_add(s, dsum + im * bott, ios[im].coarse_img_feat, b.dimg + im * bott, (long)bott));
+            if (!d->no_flow)
+                T2V_TRY(launch_add(s, dsum + im * bott, ios[im].coarse_flow_feat, b.dflow + im * bott, (long)bott));
         }
+        img_in = b.dimg;
+        if (!d->no_flow) flow_in = b.dflow;
     }
-    const bool blend = !(d->no_flow || io->use_raw_only);
-    float* raw = io->raw ? io->raw : (blend ? b.raw : io->out);
-    float* fw = io->flow_w ? io->flow_w : b.fw;
+    const size_t px4 = (size_t)d->H * d->W * 4, feat = (size_t)d->H * d->W * G;
+    MutPtrs raw{}, fw{};
+    bool blend[kMaxBatch];
+    for (int im = 0; im < batch; ++im) {
+        blend[im] = !(d->no_flow || ios[im].use_raw_only);
+        raw.p[im] = ios[im].raw ? ios[im].raw : (blend[im] ? b.raw + im * px4 : ios[im].out);
+        fw.p[im] = ios[im].flow_w ? ios[im].flow_w : b.fw + im * px4;
+    }
     if (!d->no_flow) {
         // flow branch on the side stream (temporaries bt2: the encoders are done with them)
         T2V_TRY(fork());
         r2.li = 2 * enc_layers + branch_layers;
         const float *res_flow, *flow_feat;
-        T2V_TRY(r2.res_chain(flow_in, nb_res, tmpB, nullptr, &res_flow));
+        T2V_TRY(r2.res_chain(flow_in, nb_res, tmpB, &res_flow));
         T2V_TRY(r2.decoder(res_flow, b.decF, &flow_feat));
-        T2V_TRY(r2.head(flow_feat, fw));
-        if (io->flow_feat)
-            T2V_HIP_CHECK(hipMemcpyAsync(io->flow_feat, flow_feat, (size_t)d->H * d->W * G * sizeof(float),
-                                         hipMemcpyDeviceToDevice, s2));
+        T2V_TRY(r2.head(r2.at(flow_feat, feat), fw));
+        for (int im = 0; im < batch; ++im)
+            if (ios[im].flow_feat)
+                T2V_HIP_CHECK(hipMemcpyAsync(ios[im].flow_feat, flow_feat + im * feat, feat * sizeof(float),
+                                             hipMemcpyDeviceToDevice, s2));
     }
     const float *res_img, *img_feat;
-    T2V_TRY(r.res_chain(img_in, nb_res, tmpA, nullptr, &res_img));
+    T2V_TRY(r.res_chain(img_in, nb_res, tmpA, &res_img));
     T2V_TRY(r.decoder(res_img, b.decI, &img_feat));
-    T2V_TRY(r.head(img_feat, raw));
-    if (io->img_feat)
-        T2V_HIP_CHECK(hipMemcpyAsync(io->img_feat, img_feat, (size_t)d->H * d->W * G * sizeof(float),
-                                     hipMemcpyDeviceToDevice, s));
+    T2V_TRY(r.head(r.at(img_feat, feat), raw));
+    for (int im = 0; im < batch; ++im)
+        if (ios[im].img_feat)
+            T2V_HIP_CHECK(hipMemcpyAsync(ios[im].img_feat, img_feat + im * feat, feat * sizeof(float), hipMemcpyDeviceToDevice,
+                                         s));
     if (!d->no_flow) {
         T2V_TRY(join());
         r.li += branch_layers;
         T2V_REQUIRE(r2.li == n_layers, "internal: flow branch consumed up to layer %d of %d", r2.li, n_layers);
-        if (blend) {
-            const int prev_cs = round_up(d->prev_nc, 4);
-            T2V_TRY(launch_warp_composite(s, raw, fw, io->prev, prev_cs, d->prev_nc - 3, io->out, nullptr, d->H,
-                                          d->W));
-        }
+        const int prev_cs = round_up(d->prev_nc, 4);
+        for (int im = 0; im < batch; ++im)
+            if (blend[im])
+                T2V_TRY(launch_warp_composite(s, raw.p[im], fw.p[im], ios[im].prev, prev_cs, d->prev_nc - 3, ios[im].out,
+                                              nullptr, d->H, d->W));
     }
-    if (!blend && raw != io->out)
-        T2V_HIP_CHECK(hipMemcpyAsync(io->out, raw, (size_t)d->H * d->W * 4 * sizeof(float), hipMemcpyDeviceToDevice,
-                                     s));
+    for (int im = 0; im < batch; ++im)
+        if (!blend[im] && raw.p[im] != ios[im].out)
+            T2V_HIP_CHECK(hipMemcpyAsync(ios[im].out, raw.p[im], px4 * sizeof(float), hipMemcpyDeviceToDevice, s));
     T2V_REQUIRE(r.li == n_layers, "internal: consumed %d of %d layers", r.li, n_layers);
     return T2V_OK;
+}
+
+int t2v_generator_forward(t2v_ctx* ctx, void* stream, const t2v_gen_desc* d, const t2v_layer* layers, int n_layers,
+                          const t2v_gen_io* io, void* workspace, size_t ws_bytes) {
+    return t2v_generator_forward_batch(ctx, stream, d, layers, n_layers, io, 1, workspace, ws_bytes);
 }
 
 }  // extern "C"

@@ -130,15 +130,17 @@ int launch_winograd_input(hipStream_t s, const float* x, float* V, int H, int W,
 int launch_winograd_output(hipStream_t s, const float* Mm, const float* bias, float* y, float* stats, int H, int W, int N);
 int launch_winograd4_weight(hipStream_t s, const float* w, float* U, int Cout, int Cin, int Cout_p, int Cin_s, int adjoint = 0);
 int launch_winograd4_input(hipStream_t s, const float* x, float* V, int H, int W, int C, int pad, int reflect, int batch = 1,
-                           int image = 0);
+                           int image = 0, int nimg = 1, long img_stride = 0);
 // input transform of a conv output that still has to go through its norm layer (winograd4_input_kernel<1|2>)
 int launch_winograd4_input_lazy(hipStream_t s, const float* x, float* V, int H, int W, int C, int pad, int reflect,
                                 const float* mean_rstd, const float* gamma, const float* beta, int relu_only,
-                                const float* res, float* xout);
+                                const float* res, float* xout, int nimg = 1, long img_stride = 0);
 int launch_winograd4_dy(hipStream_t s, const float* dy, float* Md, int Ho, int Wo, int N, int dy_cs, int batch, int image);
 int launch_winograd4_dw(hipStream_t s, const float* dU, float* dw, int Cout, int Cin, int Cout_p, int Kp, int accumulate);
 int launch_winograd4_output(hipStream_t s, const float* Mm, const float* bias, float* y, float* stats, int H, int W, int N,
-                            int lrelu, float slope);
+                            int lrelu, float slope, int nimg = 1, int* tickets = nullptr, float* mean_rstd = nullptr,
+                            float eps = 1e-5f);
+bool winograd4_ticket_ok(int H, int W);
 int launch_channel_sum(hipStream_t s, const float* x, long npix, int C, int cs, float* scratch, float* out);
 
 // 7x7 reflect-padded head convolution with <= 3 output channels (conv_head.hip)
@@ -198,7 +200,7 @@ int launch_inorm_apply_partials(hipStream_t s, const float* x, const float* stat
                                 const float* res1, const float* res2, float* y, long npix, int relu);
 int launch_inorm_apply(hipStream_t s, const float* x, const float* mean_rstd, const float* gamma,
                        const float* beta, const float* res1, const float* res2, float* y, long npix, int C,
-                       int relu);
+                       int relu, int nimg = 1);
 int launch_pack_conv_weight(hipStream_t s, const float* w, float* packed, int Cout, int Cin, int KH, int KW,
                             int Cin_s, int Kp, int Cout_p, int adjoint = 0);
 int launch_pack_convT_weight(hipStream_t s, const float* w, float* packed, int Cin, int Cout, int Cin_s, int Cout_p,

@@ -18,6 +18,7 @@
 // (ragged last row / column: the transforms read clamped indices and mask their writes), padded with zero tiles to
 // Tp = a multiple of 128 so that every transform position owns whole GEMM tiles.
 #include "t2v_internal.h"
+#include "norm_pool.h"
 #include "winograd_f4_consts.h"
 
 namespace t2v {
@@ -145,6 +146,7 @@ int launch_winograd_input(hipStream_t s, const float* x, float* V, int H, int W,
 // slots, `mask` marks the ones inside the image (all of them except in ragged / padding tiles).  Two passes,
 // tree-summed (exact for constant maps over power-of-two counts), written as the partial inorm_finalize
 // merges; the partial's pixel count is recomputed there from the geometry.
+template <bool PUBLISH = false>
 __device__ __forceinline__ void block_stats_128(const float (&val)[32], unsigned mask, float (*sh)[64], int tl, int cl,
                                                 bool ok, float2* __restrict__ stats, int N, int n) {
     if (stats == nullptr) return;
@@ -173,7 +175,10 @@ __device__ __forceinline__ void block_stats_128(const float (&val)[32], unsigned
         if (pass == 0) {
             mean_b = tot * inv_cnt;
         } else if (tl == 0 && ok) {
-            stats[(size_t)blockIdx.x * N + n] = make_float2(mean_b, tot);
+            if (PUBLISH)   // read back inside this launch by the block that finalizes the layer's statistics
+                publish_partial(stats + (size_t)blockIdx.x * N + n, make_float2(mean_b, tot));
+            else
+                stats[(size_t)blockIdx.x * N + n] = make_float2(mean_b, tot);
         }
     }
 }
@@ -327,7 +332,21 @@ __global__ __launch_bounds__(256) void winograd4_input_kernel(const float2* __re
                                                               int Tt, int t0, const float2* __restrict__ mean_rstd,
                                                               const float2* __restrict__ gamma,
                                                               const float2* __restrict__ beta,
-                                                              const float2* __restrict__ res, float2* __restrict__ xout) {
+                                                              const float2* __restrict__ res, float2* __restrict__ xout,
+                                                              long img_stride) {
+    // blockIdx.y = image of a batch (independent sequences advanced in lock-step): its map, residual and side output
+    // sit img_stride float2 after the previous image's, its (mean, rstd) table 2*C2 float2 after, and its tiles
+    // occupy rows [t0 + image*Tp, ...) of the batch-wide V
+    {
+        const long im = blockIdx.y;
+        x += im * img_stride;
+        t0 += (int)im * Tp;
+        if (MODE) mean_rstd += im * 2 * C2;
+        if (MODE == 2) {
+            res += im * img_stride;
+            xout += im * img_stride;
+        }
+    }
     const long total = (long)Tp * C2;
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
@@ -418,20 +437,21 @@ __global__ __launch_bounds__(256) void winograd4_input_kernel(const float2* __re
         }
     }
 }
+// the `nimg` images starting at `x` (img_stride floats apart) go to slots [image, image + nimg) of a V sized for `batch`
 int launch_winograd4_input(hipStream_t s, const float* x, float* V, int H, int W, int C, int pad, int reflect, int batch,
-                           int image) {
+                           int image, int nimg, long img_stride) {
     const int Ho = H + 2 * pad - 2, Wo = W + 2 * pad - 2;
     const int TW = (Wo + 3) / 4, T = ((Ho + 3) / 4) * TW, Tp = wino_pad_tiles(T);
-    hipLaunchKernelGGL(winograd4_input_kernel<0>, dim3(wg_grid((long)Tp * (C / 2), 256)), dim3(256), 0, s,
+    hipLaunchKernelGGL(winograd4_input_kernel<0>, dim3(wg_grid((long)Tp * (C / 2), 256), nimg), dim3(256), 0, s,
                        reinterpret_cast<const float2*>(x), reinterpret_cast<float2*>(V), H, W, C / 2, TW, T, Tp, pad,
-                       reflect, batch * Tp, image * Tp, nullptr, nullptr, nullptr, nullptr, nullptr);
+                       reflect, batch * Tp, image * Tp, nullptr, nullptr, nullptr, nullptr, nullptr, img_stride / 2);
     T2V_HIP_CHECK(hipGetLastError());
     return T2V_OK;
 }
 // relu_only: 1 = [ReLU](norm(x)); 0 = norm(x) + res with the result also written to xout (both required)
 int launch_winograd4_input_lazy(hipStream_t s, const float* x, float* V, int H, int W, int C, int pad, int reflect,
                                 const float* mean_rstd, const float* gamma, const float* beta, int relu_only,
-                                const float* res, float* xout) {
+                                const float* res, float* xout, int nimg, long img_stride) {
     T2V_REQUIRE(mean_rstd && (gamma == nullptr) == (beta == nullptr), "winograd4_input_lazy: bad norm arguments");
     T2V_REQUIRE(relu_only ? (!res && !xout) : (res && xout), "winograd4_input_lazy: residual and side output go together");
     // with another padding a tile's own 4x4 block would not tile the input map
@@ -439,21 +459,38 @@ int launch_winograd4_input_lazy(hipStream_t s, const float* x, float* V, int H, 
     const int Ho = H + 2 * pad - 2, Wo = W + 2 * pad - 2;
     const int TW = (Wo + 3) / 4, T = ((Ho + 3) / 4) * TW, Tp = wino_pad_tiles(T);
     auto kern = relu_only ? winograd4_input_kernel<1> : winograd4_input_kernel<2>;
-    hipLaunchKernelGGL(kern, dim3(wg_grid((long)Tp * (C / 2), 256)), dim3(256), 0, s, reinterpret_cast<const float2*>(x),
-                       reinterpret_cast<float2*>(V), H, W, C / 2, TW, T, Tp, pad, reflect, Tp, 0,
+    hipLaunchKernelGGL(kern, dim3(wg_grid((long)Tp * (C / 2), 256), nimg), dim3(256), 0, s, reinterpret_cast<const float2*>(x),
+                       reinterpret_cast<float2*>(V), H, W, C / 2, TW, T, Tp, pad, reflect, nimg * Tp, 0,
                        reinterpret_cast<const float2*>(mean_rstd), reinterpret_cast<const float2*>(gamma),
                        reinterpret_cast<const float2*>(beta), reinterpret_cast<const float2*>(res),
-                       reinterpret_cast<float2*>(xout));
+                       reinterpret_cast<float2*>(xout), img_stride / 2);
     T2V_HIP_CHECK(hipGetLastError());
     return T2V_OK;
 }
 
 // y = A^T M A + bias; block = 64 channels x 4 tile lanes, 8 tiles (2 per thread) = 128 output pixels
+// blockIdx.z = image of a batch: its tiles are rows [image*Tp, ...) of the batch-wide M ([36][Tt][N]), its map /
+// statistics partials / (mean, rstd) table follow the previous image's.
+// TICKET: the last block to finish a (image, 64-channel group) -- an atomic ticket per group -- pools that group's
+// partials itself, in inorm_finalize_kernel's summation order, and writes (mean, rstd): the norm layer's finalize
+// without a launch of its own (partials published write-through, read back with sc1 loads: norm_pool.h).
+template <bool TICKET>
 __global__ __launch_bounds__(256) void winograd4_output_kernel(const float* __restrict__ Mm, const float* __restrict__ bias,
                                                                float* __restrict__ y, float2* __restrict__ stats, int H,
                                                                int W, int N, int TW, int T, int Tp, int lrelu,
-                                                               float slope) {
+                                                               float slope, int Tt, int* __restrict__ tickets,
+                                                               float2* __restrict__ mean_rstd, float eps) {
     __shared__ float sh[4][64];
+    {
+        const long im = blockIdx.z;
+        Mm += im * Tp * N;                       // row offset image*Tp inside every position's [Tt][N] matrix
+        y += im * H * W * N;
+        if (stats) stats += im * (Tp / 8) * N;
+        if (TICKET) {
+            tickets += im * gridDim.y;
+            mean_rstd += im * N;
+        }
+    }
     const int cl = threadIdx.x & 63, tl = threadIdx.x >> 6;
     const int n = blockIdx.y * 64 + cl;
     const bool ok = n < N;
@@ -469,7 +506,7 @@ __global__ __launch_bounds__(256) void winograd4_output_kernel(const float* __re
         for (int b = 0; b < 6; ++b) {
             float m[6];
 #pragma unroll
-            for (int a = 0; a < 6; ++a) m[a] = (ok && tv) ? Mm[((long)(a * 6 + b) * Tp + tile) * N + n] : 0.f;
+            for (int a = 0; a < 6; ++a) m[a] = (ok && tv) ? Mm[((long)(a * 6 + b) * Tt + tile) * N + n] : 0.f;
 #pragma unroll
             for (int i2 = 0; i2 < 4; ++i2) r[i2][b] = cdot<6>(f4::kAT[i2], m);
         }
@@ -488,13 +525,32 @@ __global__ __launch_bounds__(256) void winograd4_output_kernel(const float* __re
                 }
             }
     }
-    block_stats_128(out, mask, sh, tl, cl, ok, stats, N, n);
+    block_stats_128<TICKET>(out, mask, sh, tl, cl, ok, stats, N, n);
+    if (TICKET) {
+        if (!last_arriver(tickets + blockIdx.y, gridDim.x, reinterpret_cast<int*>(&sh[0][0]))) return;
+        if (tl == 0 && ok) mean_rstd[n] = pool_partials_ordered(stats, gridDim.x, N, n, gridDim.x, 0, H * W, 4, H, W, eps);
+    }
+}
+// nimg images: M is [36][nimg*Tp][N]; y, stats, mean_rstd hold the images back to back.  tickets != nullptr (with
+// stats and mean_rstd): the kernel also finalizes the norm statistics (needs Tp/8 <= kTicketMaxParts partials per
+// channel -- winograd4_ticket_ok -- and zeroed tickets: nimg * ceil(N/64) ints, left zeroed again).
+bool winograd4_ticket_ok(int H, int W) {
+    const int TW = (W + 3) / 4, T = ((H + 3) / 4) * TW, Tp = wino_pad_tiles(T);
+    return Tp / 8 <= kTicketMaxParts;
 }
 int launch_winograd4_output(hipStream_t s, const float* Mm, const float* bias, float* y, float* stats, int H, int W, int N,
-                            int lrelu, float slope) {
+                            int lrelu, float slope, int nimg, int* tickets, float* mean_rstd, float eps) {
     const int TW = (W + 3) / 4, T = ((H + 3) / 4) * TW, Tp = wino_pad_tiles(T);
-    hipLaunchKernelGGL(winograd4_output_kernel, dim3(Tp / 8, (N + 63) / 64), dim3(256), 0, s, Mm, bias, y,
-                       reinterpret_cast<float2*>(stats), H, W, N, TW, T, Tp, lrelu, slope);
+    const dim3 grid(Tp / 8, (N + 63) / 64, nimg);
+    if (tickets) {
+        T2V_REQUIRE(stats && mean_rstd && Tp / 8 <= kTicketMaxParts, "winograd4_output: ticket finalize needs statistics and "
+                    "<= %d partials per channel", kTicketMaxParts);
+        hipLaunchKernelGGL(winograd4_output_kernel<true>, grid, dim3(256), 0, s, Mm, bias, y, reinterpret_cast<float2*>(stats),
+                           H, W, N, TW, T, Tp, lrelu, slope, nimg * Tp, tickets, reinterpret_cast<float2*>(mean_rstd), eps);
+    } else {
+        hipLaunchKernelGGL(winograd4_output_kernel<false>, grid, dim3(256), 0, s, Mm, bias, y,
+                           reinterpret_cast<float2*>(stats), H, W, N, TW, T, Tp, lrelu, slope, nimg * Tp, nullptr, nullptr, eps);
+    }
     T2V_HIP_CHECK(hipGetLastError());
     return T2V_OK;
 }

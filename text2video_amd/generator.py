@@ -170,6 +170,7 @@ class HipGenerator:
         self._layers = None
         self._ws = None
         self._ws_hw = None
+        self._ws_batch = 0
 
     # -- weights ---------------------------------------------------------------------------------
     def load_state_dict(self, sd):
@@ -211,55 +212,92 @@ class HipGenerator:
         self._packed, self._layers = keep, arr
 
     # -- forward ---------------------------------------------------------------------------------
-    def _workspace(self, H, W):
+    def _workspace(self, H, W, batch=1):
         if self._ws_hw != (H, W):
             gd = _gen_desc(self.spec, H, W, self.conv_algo)
-            nbytes = self.lib.t2v_generator_workspace_bytes(ctypes.byref(gd))
-            if nbytes == 0:
+            if self.lib.t2v_generator_workspace_bytes(ctypes.byref(gd)) == 0:
                 raise RuntimeError("generator: %s" % self.lib.t2v_last_error().decode())
             self._pack(gd)
-            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            self._ws, self._ws_batch = None, 0
             self._ws_hw = (H, W)
             self._gd = gd
+        if self._ws is None or self._ws_batch < batch:     # one arena, sized for the largest batch seen
+            nbytes = self.lib.t2v_generator_workspace_bytes_batch(ctypes.byref(self._gd), batch)
+            if nbytes == 0:
+                raise RuntimeError("generator: %s" % self.lib.t2v_last_error().decode())
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            self._ws_batch = batch
         return self._ws
 
     def forward(self, pose, prev, use_raw_only=False, coarse_img_feat=None, coarse_flow_feat=None,
                 want=("out",)):
         """pose [H,W,round_up4(input_nc)], prev [H,W,round_up4(prev_nc)] NHWC fp32 on the device.
         Returns dict of NHWC tensors for the names in `want` ⊆ {out, raw, flow_w, img_feat, flow_feat}."""
+        return self.forward_batch([pose], [prev], [use_raw_only], [coarse_img_feat], [coarse_flow_feat], want)[0]
+
+    def forward_batch(self, poses, prevs, use_raw_only, coarse_img_feat=None, coarse_flow_feat=None, want=("out",)):
+        """N independent images (one frame each of N sequences advanced in lock-step) through one pass of the layer
+        list: t2v_generator_forward_batch.  All arguments are lists of length N (same geometry); returns a list of N
+        dicts as forward() does.  N = 1 is t2v_generator_forward."""
         if self._raw is None:
             raise RuntimeError("HipGenerator.forward before load_state_dict")
-        H, W = pose.shape[0], pose.shape[1]
-        ws = self._workspace(H, W)
-        res = {}
+        N = len(poses)
+        if not 1 <= N <= _lib.MAX_BATCH:
+            raise ValueError("forward_batch: %d images (1..%d)" % (N, _lib.MAX_BATCH))
+        H, W = poses[0].shape[0], poses[0].shape[1]
+        if any(tuple(p.shape[:2]) != (H, W) for p in poses):
+            raise ValueError("forward_batch: one frame geometry per batch")
+        coarse_img_feat = coarse_img_feat or [None] * N
+        coarse_flow_feat = coarse_flow_feat or [None] * N
+        ws = self._workspace(H, W, N)
+        ios = (GenIO * N)()
+        results = []
+        for i in range(N):
+            res = {}
 
-        def buf(name, c):
-            if name in want:
-                res[name] = torch.empty(H, W, c, dtype=torch.float32, device=self.device)
-                return res[name].data_ptr()
-            return None
+            def buf(name, c, res=res):
+                if name in want:
+                    res[name] = torch.empty(H, W, c, dtype=torch.float32, device=self.device)
+                    return res[name].data_ptr()
+                return None
 
-        io = GenIO()
-        io.pose, io.prev = pose.data_ptr(), prev.data_ptr()
-        io.coarse_img_feat = coarse_img_feat.data_ptr() if coarse_img_feat is not None else None
-        io.coarse_flow_feat = coarse_flow_feat.data_ptr() if coarse_flow_feat is not None else None
-        io.use_raw_only = int(use_raw_only)
-        res["out"] = torch.empty(H, W, 4, dtype=torch.float32, device=self.device)
-        io.out = res["out"].data_ptr()
-        io.raw = buf("raw", 4)
-        io.flow_w = buf("flow_w", 4) if not self.spec.no_flow else None
-        io.img_feat = buf("img_feat", self.spec.ngf)
-        io.flow_feat = buf("flow_feat", self.spec.ngf) if not self.spec.no_flow else None
-        check(self.lib.t2v_generator_forward(self.ctx.handle, ops._stream(), ctypes.byref(self._gd), self._layers,
-                                             len(self.keys), ctypes.byref(io), ctypes.c_void_p(ws.data_ptr()),
-                                             ws.numel()), "generator_forward")
-        return res
+            io = ios[i]
+            io.pose, io.prev = poses[i].data_ptr(), prevs[i].data_ptr()
+            io.coarse_img_feat = coarse_img_feat[i].data_ptr() if coarse_img_feat[i] is not None else None
+            io.coarse_flow_feat = coarse_flow_feat[i].data_ptr() if coarse_flow_feat[i] is not None else None
+            io.use_raw_only = int(use_raw_only[i])
+            res["out"] = torch.empty(H, W, 4, dtype=torch.float32, device=self.device)
+            io.out = res["out"].data_ptr()
+            io.raw = buf("raw", 4)
+            io.flow_w = buf("flow_w", 4) if not self.spec.no_flow else None
+            io.img_feat = buf("img_feat", self.spec.ngf)
+            io.flow_feat = buf("flow_feat", self.spec.ngf) if not self.spec.no_flow else None
+            results.append(res)
+        check(self.lib.t2v_generator_forward_batch(self.ctx.handle, ops._stream(), ctypes.byref(self._gd), self._layers,
+                                                   len(self.keys), ios, N, ctypes.c_void_p(ws.data_ptr()), ws.numel()),
+              "generator_forward")
+        return results
+
+
+class Recurrence:
+    """The state one sequence carries from frame to frame: per spatial scale (finest first) the NHWC [H,W,8] FIFO of
+    the tG-1 previous generated frames (`fake_B_prev` upstream), None before the first frame."""
+
+    def __init__(self):
+        self.prev = None
+        self._spare = None     # ping-pong partner of every FIFO buffer (channels >= prev_nc stay zero)
+
+    def reset(self):
+        self.prev = None
+        self._spare = None
 
 
 class Vid2VidModelG:
     """`Vid2VidModelG.inference` on the HIP path.
 
     nets: [HipGenerator scale 0 (coarsest, global), scale 1 (local), ...]
+    One model can advance several independent sequences in lock-step (`inference_nhwc_batch`): each has its own
+    Recurrence; `self.state` is the one the single-sequence entry points use.
     """
 
     def __init__(self, nets, n_frames_G=3, output_nc=3, no_first_img=True):
@@ -269,51 +307,77 @@ class Vid2VidModelG:
         self.output_nc = output_nc
         self.no_first_img = no_first_img
         self.device = nets[0].device
-        self.prev = None  # per scale: NHWC [H,W,8] FIFO of the tG-1 previous outputs
+        self.state = Recurrence()
+
+    @property
+    def prev(self):
+        """per scale: NHWC [H,W,8] FIFO of the tG-1 previous outputs (None before the first frame)"""
+        return self.state.prev
+
+    @prev.setter
+    def prev(self, value):
+        self.state.prev = value
+        self.state._spare = None
 
     def reset(self):
         """`model.fake_B_prev = None` on data['change_seq']."""
-        self.prev = None
+        self.state.reset()
 
-    def load_prev(self, fake_B_prev):
+    def load_prev(self, fake_B_prev, state=None):
         """Set the FIFO from reference-layout tensors: list (finest first) of [tG-1, 3, h, w]."""
         pcs = ops.round_up(self.nets[0].spec.prev_nc, 4)
-        self.prev = [ops.nchw_to_nhwc(p.reshape(-1, p.shape[-2], p.shape[-1]).to(self.device).contiguous(), pcs)
-                     for p in fake_B_prev]
+        st = state or self.state
+        st.prev = [ops.nchw_to_nhwc(p.reshape(-1, p.shape[-2], p.shape[-1]).to(self.device).contiguous(), pcs)
+                   for p in fake_B_prev]
+        st._spare = None
 
     @torch.no_grad()
-    def inference_nhwc(self, pose):
-        """pose: [H,W,round_up4(3*tG)] fp32 NHWC window (oldest frame first).  Returns [H,W,4] (RGB0)."""
-        first = self.prev is None
-        if first and not self.no_first_img:
+    def inference_nhwc_batch(self, poses, states):
+        """One frame of each of N independent sequences: poses[i] is sequence i's [H,W,round_up4(3*tG)] fp32 NHWC window
+        (oldest frame first), states[i] its Recurrence (updated in place).  Returns the N [H,W,4] frames (RGB0).
+        Frame i is the frame inference_nhwc computes for sequence i alone."""
+        N = len(poses)
+        firsts = [st.prev is None for st in states]
+        if any(firsts) and not self.no_first_img:
             raise NotImplementedError("first-frame generator: the reference always passes --no_first_img")
-        # spatial pyramid: index 0 = finest
-        poses = [pose]
-        for _ in range(1, self.n_scales):
-            poses.append(ops.avgpool3x3s2(poses[-1]))
         pcs = ops.round_up(self.nets[0].spec.prev_nc, 4)
-        if first:
-            self.prev = [torch.zeros(p.shape[0], p.shape[1], pcs, dtype=torch.float32, device=self.device)
-                         for p in poses]
-        use_raw_only = self.no_first_img and first
-        img_feat = flow_feat = None
-        out = None
+        pyr = []        # per sequence: spatial pyramid, index 0 = finest
+        for i in range(N):
+            ps = [poses[i]]
+            for _ in range(1, self.n_scales):
+                ps.append(ops.avgpool3x3s2(ps[-1]))
+            pyr.append(ps)
+            if firsts[i]:
+                states[i].prev = [torch.zeros(p.shape[0], p.shape[1], pcs, dtype=torch.float32, device=self.device)
+                                  for p in ps]
+            if states[i]._spare is None:
+                states[i]._spare = [torch.zeros_like(p) for p in states[i].prev]
+        raw_only = [self.no_first_img and f for f in firsts]
+        img_feat, flow_feat = [None] * N, [None] * N
+        outs = None
         for s in range(self.n_scales):
             si = self.n_scales - 1 - s
             net = self.nets[s]
             want = ("out",) if s == self.n_scales - 1 else \
                 (("out", "img_feat") if net.spec.no_flow else ("out", "img_feat", "flow_feat"))
-            r = net.forward(poses[si], self.prev[si], use_raw_only, img_feat, flow_feat, want)
-            out = r["out"]
-            img_feat, flow_feat = r.get("img_feat"), r.get("flow_feat")
-            # fake_B_prev = cat(fake_B_prev[1:], fake_B): shift the FIFO (ping-pong buffer)
+            rs = net.forward_batch([pyr[i][si] for i in range(N)], [states[i].prev[si] for i in range(N)], raw_only,
+                                   img_feat, flow_feat, want)
+            outs = [r["out"] for r in rs]
+            img_feat, flow_feat = [r.get("img_feat") for r in rs], [r.get("flow_feat") for r in rs]
+            # fake_B_prev = cat(fake_B_prev[1:], fake_B): shift the FIFO into its ping-pong partner
             nc = self.output_nc
-            newp = torch.zeros_like(self.prev[si])
-            for f in range(self.tG - 2):
-                ops.copy_channels(self.prev[si], (f + 1) * nc, newp, f * nc, nc)
-            ops.copy_channels(out, 0, newp, (self.tG - 2) * nc, nc)
-            self.prev[si] = newp
-        return out
+            for i in range(N):
+                st = states[i]
+                newp = st._spare[si]
+                for f in range(self.tG - 2):
+                    ops.copy_channels(st.prev[si], (f + 1) * nc, newp, f * nc, nc)
+                ops.copy_channels(outs[i], 0, newp, (self.tG - 2) * nc, nc)
+                st.prev[si], st._spare[si] = newp, st.prev[si]
+        return outs
+
+    def inference_nhwc(self, pose):
+        """pose: [H,W,round_up4(3*tG)] fp32 NHWC window (oldest frame first).  Returns [H,W,4] (RGB0)."""
+        return self.inference_nhwc_batch([pose], [self.state])[0]
 
     @torch.no_grad()
     def inference(self, A, B=None, inst=None):

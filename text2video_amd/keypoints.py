@@ -210,7 +210,8 @@ def _draw_chain(img, pts, idx, bw, rgb, caps, exact_fit):
             stamp(img, xs, ys, bw, rgb, caps)
 
 
-def render_person(person, size, basic_point_only=False, exact_fit=True, hand_discs=True, drop_prob=0.0, rng=None):
+def render_person(person, size, basic_point_only=False, exact_fit=True, hand_discs=True, drop_prob=0.0, rng=None,
+                  remove_face_labels=False):
     w, h = size
     img = np.zeros((h, w, 3), np.uint8)
     pose = _valid_xy(np.asarray(person["pose_keypoints_2d"], float).reshape(25, 3), "pose")
@@ -220,6 +221,14 @@ def render_person(person, size, basic_point_only=False, exact_fit=True, hand_dis
     else:
         hands = [_valid_xy(np.asarray(person[k], float).reshape(21, 3), "hand")
                  for k in ("hand_left_keypoints_2d", "hand_right_keypoints_2d")]
+
+    if drop_prob > 0 and remove_face_labels:
+        # training-time jitter of the head key points and of the whole face (/root/reference/keypoint2img.py:119-123):
+        # same draws in the same order -- randn(5,2), randn(), randn() -- so a RandomState seeded like the reference's
+        # global np.random reproduces its maps.  Invalid points sit at (0,0) and are moved like the others, as there.
+        pose[[0, 15, 16, 17, 18], :] += 5 * rng.standard_normal((5, 2))
+        face[:, 0] += 2 * rng.standard_normal()
+        face[:, 1] += 2 * rng.standard_normal()
 
     def keep():
         return drop_prob <= 0 or rng.random() > drop_prob
@@ -256,5 +265,6 @@ def read_keypoints(json_input, size, random_drop_prob=0, remove_face_labels=Fals
     if random_drop_prob > 0 and rng is None:
         rng = np.random.default_rng()
     for person in people:
-        canvas += render_person(person, size, basic_point_only, exact_fit, hand_discs, random_drop_prob, rng)
+        canvas += render_person(person, size, basic_point_only, exact_fit, hand_discs, random_drop_prob, rng,
+                                remove_face_labels)
     return canvas

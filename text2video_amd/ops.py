@@ -409,6 +409,16 @@ def conv2d_backward_weight_winograd_stages(x, dy, desc, ws, batch, b0, reduce):
     return dw
 
 
+def conv2d_backward_weight_winograd_reduce(desc, ws, batch, x_cs, dy_cs):
+    """Reduction stage alone over the `batch` slots already transformed into `ws` -> dW in torch layout."""
+    c = context()
+    dw = torch.empty(desc.Cout, desc.Cin, 3, 3, dtype=torch.float32, device=ws.device)
+    check(c.lib.t2v_conv2d_backward_weight_winograd_stages(c.handle, _stream(), ctypes.byref(desc), batch, 0, 0, None, x_cs,
+                                                           None, dy_cs, _p(dw), 0, _p(ws), 2),
+          "conv2d_backward_weight_winograd_stages")
+    return dw
+
+
 def maxpool2x2(x):
     """MaxPool2d(2,2) on [H,W,C] or [B,H,W,C] (H even for a batch: the images are pooled as one tall image)."""
     c = context()

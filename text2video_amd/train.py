@@ -73,7 +73,8 @@ def _batched_winograd_wgrad(w, x, dc, fdesc):
         return ops.conv2d_backward_weight_winograd(x, dc, fdesc)
     st = getattr(w, "_t2v_wg_state", None)
     if st is None:
-        st = [ops.backward_weight_winograd_workspace(fdesc, x.shape[-1], total, x.device), 0, _desc_key(fdesc, x.shape[-1])]
+        st = [ops.backward_weight_winograd_workspace(fdesc, x.shape[-1], total, x.device), 0, _desc_key(fdesc, x.shape[-1]),
+              fdesc, x.shape[-1], dc.shape[-1]]
         w._t2v_wg_state = st
     assert st[2] == _desc_key(fdesc, x.shape[-1]), "one layer, two geometries in one step: set T2V_WGRAD_BATCH=0"
     ws, done = st[0], st[1]
@@ -84,6 +85,29 @@ def _batched_winograd_wgrad(w, x, dc, fdesc):
     else:
         st[1] = done + x.shape[0]
     return dw
+
+
+def flush_pending_weight_gradients(params, grads):
+    """After the backward pass: a layer whose forward counted more images than its backward nodes delivered (part of
+    the graph fed no loss -- e.g. the flow head of a raw-only first frame when no flow loss is on) has transformed
+    slots waiting for a reduction that no node will run.  Reduce what is there: the slots that were never filled are
+    zeroed (a zero image contributes nothing) and the reduction runs over the whole workspace.  Returns `grads` with
+    those gradients filled in."""
+    out = list(grads)
+    for i, p in enumerate(params):
+        st = getattr(p, "_t2v_wg_state", None)
+        if st is None:
+            continue
+        ws, done, _, fdesc, xcs, dycs = st
+        total = p._t2v_wg_images
+        if done > 0:
+            cout_p, kp = ops.round_up(fdesc.Cout, 128), ops.round_up(xcs, 32)
+            tp = (ws.numel() - 36 * cout_p * kp) // (36 * total * (xcs + fdesc.Cout))
+            ws[:36 * total * tp * xcs].view(36, total, tp * xcs)[:, done:].zero_()
+            dw = ops.conv2d_backward_weight_winograd_reduce(fdesc, ws, total, xcs, dycs)
+            out[i] = dw if out[i] is None else out[i] + dw
+        p._t2v_wg_state, p._t2v_wg_images = None, 0
+    return out
 
 
 _ZEROS = {}
@@ -368,7 +392,7 @@ class TrainableGenerator(torch.nn.Module):
     def named_upstream_parameters(self):
         return {k.replace("/", "."): v for k, v in self.params.items()}
 
-    def forward(self, pose, prev, use_raw_only=False, full=False):
+    def forward(self, pose, prev, use_raw_only=False, full=False, need_flow=True):
         """pose [1,H,W,12], prev [1,H,W,8] NHWC -> fake [1,H,W,4] (RGB in channels 0..2).  full=True returns
         (fake, raw, flow_w): raw = the tanh image before the blend, flow_w [1,H,W,4] = (flow_x, flow_y in pixels,
         weight, 0); both None without a flow branch.  use_raw_only: the first frame of a sequence under
@@ -414,6 +438,10 @@ class TrainableGenerator(torch.nn.Module):
                          ops.conv_desc(H, W, G, 3, 7, 1, 3, ops.PAD_REFLECT), norm=None, relu=0, act=ops.ACT_TANH)
         if s.no_flow:
             return (raw, None, None) if full else raw
+        if use_raw_only and not need_flow:
+            # raw-only first frame and no loss reads its flow / weight maps: the flow branch would be a dead part of
+            # the graph (its batched weight-gradient slots would never be reduced) -- do not run it
+            return (raw, raw, None) if full else raw
         flow_feat = decoder(resblocks(d, nb_res))
         (kf, kw), _, _ = next(it)
         # model_final_flow (2 outputs, x20) and model_final_w (1 output, sigmoid) read the same features: one
@@ -869,7 +897,8 @@ class Vid2VidTrainer:
             self._hist_real, self._hist_fake = [], []
         fakes, raws, fws, prevs = [], [], [], []
         for f in range(F_):
-            fk, rw, fw = self.G(pose[f:f + 1], prev, use_raw_only=first and f == 0, full=True)
+            fk, rw, fw = self.G(pose[f:f + 1], prev, use_raw_only=first and f == 0, full=True,
+                                need_flow=real_prev is not None)
             fakes.append(fk)
             raws.append(rw)
             fws.append(fw)
@@ -893,7 +922,8 @@ class Vid2VidTrainer:
         if flow_on:
             # with a flow branch upstream scores fake_B_raw with the same discriminator (and VGG) as well; its second
             # real pass returns the values of the first (same weights, same batch): that term is simply added again
-            raw, fw_all = torch.cat(raws, 0), torch.cat(fws, 0)
+            raw = torch.cat(raws, 0)
+            fw_all = torch.cat(fws, 0) if real_prev is not None else None
             pfd_r = self.D(self._d_input(A3, raw.detach()))
             pfg_r = self.D(self._d_input(A3, raw), frozen=True)
             loss_D_real = loss_D_real + gan_loss(pr, True)
@@ -922,6 +952,11 @@ class Vid2VidTrainer:
             # flow_ref / conf_ref come from FlowNet2 upstream; here they are inputs (zero flow by default)
             with torch.no_grad():
                 if flow_ref is None:
+                    if not getattr(self, "_warned_zero_flow", False):
+                        self._warned_zero_flow = True
+                        print("warning: flow / warp / weight losses run against a synthetic ZERO reference flow (FlowNet2 is not "
+                              "in the reference tree; pass flow_ref / conf_ref, or --no_flow to train without the flow branch)",
+                              flush=True)
                     flow_ref = torch.zeros(F_, H, W, 4, dtype=torch.float32, device=dev)
                     real_prev_warp = real_prev
                 else:
@@ -931,9 +966,15 @@ class Vid2VidTrainer:
                 fake_prev = torch.cat(prevs, 0)
                 fake_prev_warp = torch.stack([ops.flow_warp(flow_ref[i], fake_prev[i], self.spec.prev_nc - 3)
                                               for i in range(F_)])
+                if first:
+                    # no generated previous frame exists for a sequence's first frame: upstream warps the REAL previous
+                    # frame there (fake_B_prev = real_B_prev[:, 0:1] when there is no previous chunk [RECALL
+                    # compute_fake_B_prev]); the all-zero FIFO stays the generator's INPUT only
+                    fake_prev_warp[0] = real_prev_warp[0]
             loss_F_flow = masked_l1(fw_all, flow_ref, conf_ref, 2, 0) * opt.lambda_F
             loss_F_warp = masked_l1(_Resample.apply(fw_all, real_prev.contiguous(), 0), real, conf_ref, 3) * opt.lambda_T
-            loss_W = masked_l1(fw_all, None, conf_ref, 1, 2)
+            # the weight-map loss exists only under --no_first_img upstream (zero otherwise) [RECALL]
+            loss_W = masked_l1(fw_all, None, conf_ref, 1, 2) if getattr(opt, "no_first_img", False) else 0.0
             loss_G_warp = masked_l1(fake, fake_prev_warp, conf_ref, 3) * opt.lambda_T
             loss_G = loss_G + loss_F_flow + loss_F_warp + loss_W + loss_G_warp
             losses.update({"F_Flow": _f(loss_F_flow), "F_Warp": _f(loss_F_warp), "W": _f(loss_W), "G_Warp": _f(loss_G_warp)})
@@ -984,6 +1025,7 @@ class Vid2VidTrainer:
         g_params = list(self.G.parameters())
         d_params = self.optD.params
         gG = torch.autograd.grad(loss_G, g_params, retain_graph=True, allow_unused=True)
+        gG = flush_pending_weight_gradients(g_params, gG)
         for p, g in zip(g_params, gG):
             p.grad = g
         xg = allreduce_gradients_begin(g_params)     # in flight under the discriminators' backward pass
@@ -1170,6 +1212,15 @@ def run_train(opt, steps=None):
                     boxes = None
                     if opt.add_face_disc:      # one region for the chunk (upstream boxes the whole batch of frames)
                         box = get_face_region(clip["A"][fr], opt.fineSize)
+                        if world > 1:
+                            # the face terms decide which parameters (D_f) have gradients: every rank must take the same
+                            # branch, or the ranks' gradient buckets would differ in size and order -- the face
+                            # discriminator trains on a chunk only when EVERY rank's chunk shows a face
+                            import torch.distributed as dist
+                            has = torch.tensor([1 if box is not None else 0], device=dev if dist.get_backend() == "nccl" else "cpu")
+                            dist.all_reduce(has, op=dist.ReduceOp.MIN)
+                            if int(has.item()) == 0:
+                                box = None
                         boxes = [box] * len(fr) if box is not None else None
                     losses, prev = trainer.train_step(pose, real, boxes, prev, real_prev=real_prev)
                 what = ", seq %s, %d frames %dx%d step %d" % (clip["seq"], T_ - tG + 1, H, W, clip["t_step"])
