@@ -10,6 +10,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--frames", type=int, default=40)
 ap.add_argument("--noflow", action="store_true")
 ap.add_argument("--size", type=int, default=512)
+ap.add_argument("--batch", type=int, default=1, help="independent sequences advanced in lock-step")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 spec = GeneratorSpec(ngf=128, n_downsample=3, n_blocks=9, no_flow=a.noflow, norm="batch")
@@ -18,11 +19,15 @@ H = W = a.size
 rng = np.random.default_rng(0)
 win = torch.zeros(H, W, 12, device=dev)
 win[..., :9] = torch.from_numpy(np.where(rng.random((H, W, 1)) < 0.02, rng.uniform(-1, 1, (H, W, 9)), -1.0).astype(np.float32)).to(dev)
+from text2video_amd.generator import Recurrence
+wins = [win] + [win.clone() for _ in range(a.batch - 1)]
+states = [Recurrence() for _ in range(a.batch)]
 for _ in range(10):
-    model.inference_nhwc(win)
+    model.inference_nhwc_batch(wins, states)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(a.frames):
-    model.inference_nhwc(win)
+    model.inference_nhwc_batch(wins, states)
 torch.cuda.synchronize()
-print("FRAMES %d  %.3f ms/frame" % (a.frames + 10, 1e3 * (time.perf_counter() - t0) / a.frames))
+# FRAMES counts generated frames (steps x batch): the per-frame table divides by it
+print("FRAMES %d  %.3f ms/frame (batch %d)" % ((a.frames + 10) * a.batch, 1e3 * (time.perf_counter() - t0) / a.frames / a.batch, a.batch))

@@ -2,7 +2,7 @@
 must be the frames the single-sequence path generates for it -- the batch only changes how the ResnetBlock chains'
 kernels are launched (image index in the transforms' grids, N x T tile rows per Winograd GEMM), never a value that
 depends on another sequence; norm statistics stay per image.  Also: the norm statistics finalized by the producing
-kernel's last block (T2V_NORM_TICKET, default) against the separate finalize launch -- bit-identical frames."""
+kernel's last block (T2V_NORM_TICKET=1) against the separate finalize launch (the default) -- bit-identical frames."""
 import os
 
 import numpy as np
@@ -97,7 +97,7 @@ def test_batch2_frame_matches_the_oracle():
 @pytest.mark.parametrize("name,spec_kw,scales,H,W", BATCH_CASES[:3], ids=[c[0] for c in BATCH_CASES[:3]])
 def test_producer_side_norm_finalize_is_bit_identical_to_the_finalize_launch(name, spec_kw, scales, H, W):
     """The F(4x4) output transform's last block per (image, 64-channel group) pools the partial statistics in the
-    finalize kernel's summation order: frames with T2V_NORM_TICKET=1 (default) and =0 (separate finalize launches)
+    finalize kernel's summation order: frames with T2V_NORM_TICKET=1 and =0 (separate finalize launches, the default)
     must be bit-identical, at batch 1 and batch 2, over a free-running sequence."""
     from text2video_amd.generator import Recurrence
     _, hip = _build(spec_kw, scales)

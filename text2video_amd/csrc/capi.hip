@@ -200,7 +200,12 @@ int build_winograd_gemm_plan(const t2v_conv_desc* d, ConvPlan* pl, int nimg) {
         pl->kp.mtiles = (pl->kp.M + pl->BM - 1) / pl->BM;
         pl->nparts = pl->kp.nphases * pl->kp.mtiles;
     }
-    if (T % pl->BM != 0 && pl->tile == kTileL) {   // tile count padded to 64 only: the 64x64 tile config
+    // A batch (nimg >= 2: T = 512, 1024, ... rows per position) keeps the 128x128 tiles build_conv_plan's fill rule
+    // leaves it with: alone the 64x64 tiles are faster at T = 512 (315 vs 335 us per batch-2 launch), inside two-stream
+    // frames they lose (11.80 vs 11.41 ms per frame) -- the big tiles leave wave slots to the other stream's kernels.
+    // T2V_WINO_GEMM_TILE=2 forces the 64x64 tiles.
+    static const int force_q = getenv("T2V_WINO_GEMM_TILE") ? atoi(getenv("T2V_WINO_GEMM_TILE")) == 2 : 0;
+    if ((T % pl->BM != 0 || force_q) && pl->tile == kTileL) {   // tile count padded to 64 only: the 64x64 tile config
         pl->tile = kTileQ;
         conv_tile_dims(pl->tile, &pl->BM, &pl->BN);
         pl->kp.ntiles = (g.Cout + pl->BN - 1) / pl->BN;

@@ -210,11 +210,13 @@ struct Runner {
     float* stats_of(int im) const { return b.stats[sc] + (size_t)im * b.stats_stride; }
     float* mr_of(int im) const { return b.mean_rstd[sc] + (size_t)im * b.mr_stride; }
     double* fin_of(int im) const { return b.fin[sc] + (size_t)im * b.fin_stride; }
-    // T2V_NORM_TICKET=0: every norm layer's statistics are finalized by a launch of their own (read per call, so one
-    // process can compare the two forms)
+    // T2V_NORM_TICKET=1: the F(4x4) output transforms finalize their norm statistics in their own last block per
+    // channel group instead of a finalize launch (bit-identical frames, 36 launches per flow frame fewer).  OFF by
+    // default: measured slower (DESIGN 4.3 -- every block drains its stores and takes a ticket, and the last one pools
+    // serially: 57 vs 22 + 2 x 6.6 us per batch-2 conv).  Read per call, so one process can compare the two forms.
     static bool ticket_on() {
         const char* e = getenv("T2V_NORM_TICKET");
-        return !(e && atoi(e) == 0);
+        return e && atoi(e) == 1;
     }
 
     // conv (+ fused stats) -> finalize -> apply of layer `l` for ONE image.  y receives the conv output and is

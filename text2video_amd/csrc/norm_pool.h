@@ -24,6 +24,8 @@ __device__ __forceinline__ int partial_pixels(int part, int mtiles, int BM, int 
     }
     const int TW = (W + wm - 1) / wm, T = ((H + wm - 1) / wm) * TW, tpb = 128 / (wm * wm);
     const int pi = part % mtiles;   // partial index inside its image (mtiles = partials per image)
+    if (H % wm == 0 && W % wm == 0)   // no ragged tiles: every tile of the grid is whole
+        return wm * wm * max(0, min(tpb, T - pi * tpb));
     int nb = 0;
     for (int t = pi * tpb; t < min((pi + 1) * tpb, T); ++t) {
         const int ty = t / TW, tx = t - ty * TW;
