@@ -83,6 +83,67 @@ def synthetic_pose_u8(n, H, W, seed):
     return a
 
 
+class ClockSampler:
+    """GPU core clock of THIS rank's device sampled from sysfs (pp_dpm_sclk: the active DPM level carries a '*') every
+    50 ms by a background thread while a timed region runs; plus the box / device identity.  Best effort: fields are
+    None where the files are missing."""
+
+    def __init__(self, device_index):
+        import glob
+        import socket
+        self.path, self.samples, self._stop, self._thr = None, [], None, None
+        self.ident = {"host": socket.gethostname(), "gpu": None, "unique_id": None, "pci_bus_id": None}
+        try:
+            props = torch.cuda.get_device_properties(device_index)
+            self.ident["gpu"] = props.name
+            bus = "%04x:%02x:%02x" % (getattr(props, "pci_domain_id", 0), props.pci_bus_id, props.pci_device_id)
+            self.ident["pci_bus_id"] = bus
+            cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/pp_dpm_sclk"))
+            pick = [c for c in cards if bus in os.path.realpath(os.path.dirname(c))] or cards
+            if pick:
+                self.path = pick[0]
+                uid = os.path.join(os.path.dirname(self.path), "unique_id")
+                if os.path.exists(uid):
+                    self.ident["unique_id"] = open(uid).read().strip()
+        except Exception:
+            pass
+
+    def _read(self):
+        try:
+            for line in open(self.path):
+                if "*" in line:
+                    return int("".join(ch for ch in line.split(":")[1] if ch.isdigit()))
+        except Exception:
+            return None
+        return None
+
+    def __enter__(self):
+        if self.path is not None:
+            import threading
+            self._stop = threading.Event()
+
+            def loop():
+                while not self._stop.is_set():
+                    v = self._read()
+                    if v:
+                        self.samples.append(v)
+                    self._stop.wait(0.05)
+            self._thr = threading.Thread(target=loop, daemon=True)
+            self._thr.start()
+        return self
+
+    def __exit__(self, *exc):
+        if self._thr is not None:
+            self._stop.set()
+            self._thr.join()
+
+    def summary(self):
+        s = self.samples
+        return dict(self.ident, sclk_mhz_mean=round(sum(s) / len(s), 1) if s else None, sclk_mhz_min=min(s) if s else None,
+                    sclk_mhz_max=max(s) if s else None, sclk_samples=len(s),
+                    source="sysfs pp_dpm_sclk, 50 ms period, during the headline timed region")
+
+
 def run_e2e(model_head, model_other, head_flow, n_frames):
     """The drop-in test.py path end to end: a dataset in the layout the reference's L2 driver writes (OpenPose JSONs
     + skeleton jpgs; the committed fadg0 keypoint fixtures, cycled), rasterised by the pose-dataset worker pool ->
@@ -99,21 +160,31 @@ def run_e2e(model_head, model_other, head_flow, n_frames):
     models = {head_flow: model_head}
     if model_other is not None:
         models[not head_flow] = model_other
-    # (canvas W x H of the source frames, extra flags, geometry the generator sees, which variants)
-    cases = [((512, 512), ["--no_pose_crop"], "512x512", [True, False]),
-             ((512, 384), ["--no_pose_crop"], "512x680 (fadg0 frames, scaleHeight 512, full width)", [head_flow]),
-             ((512, 384), [], "512x320 (fadg0 frames, scaleHeight 512 + upstream's central-width crop)", [head_flow])]
-    for canvas, extra, geom, flows in cases:
+    # (canvas W x H of the source frames, extra flags, geometry the generator sees, which variants, sequence folders)
+    one = ["tmp"]
+    two = ["tmp", "tmp_smooth"]       # what the reference's L2 driver writes per utterance (text2video_audio.sh:24-31)
+    cases = [((512, 512), ["--no_pose_crop", "--batch_sequences", "1"], "512x512", [True, False], one),
+             ((512, 384), ["--no_pose_crop", "--batch_sequences", "1"], "512x680 (fadg0 frames, scaleHeight 512, full width)",
+              [head_flow], one),
+             ((512, 384), ["--batch_sequences", "1"], "512x320 (fadg0 frames, scaleHeight 512 + upstream's central-width crop)",
+              [head_flow], one),
+             ((512, 512), ["--no_pose_crop", "--batch_sequences", "1"], "512x512, two sequences one after the other",
+              [head_flow], two),
+             ((512, 512), ["--no_pose_crop", "--batch_sequences", "2"], "512x512, two sequences in lock-step (batch 2)",
+              [head_flow], two)]
+    for canvas, extra, geom, flows, seqs in cases:
         tmp = tempfile.mkdtemp(prefix="t2v_e2e_")
         try:
             root = os.path.join(tmp, "datasets", "fadg0")
-            os.makedirs(os.path.join(root, "test_openpose", "tmp"))
-            os.makedirs(os.path.join(root, "test_img", "tmp"))
             img = Image.fromarray(read_keypoints(os.path.join(src, files[0]), canvas))
-            for i in range(n_frames + 2):
-                shutil.copyfile(os.path.join(src, files[i % len(files)]),
-                                os.path.join(root, "test_openpose", "tmp", "%05d.json" % i))
-                img.save(os.path.join(root, "test_img", "tmp", "%04d.jpg" % i))
+            per_seq = n_frames // len(seqs)
+            for q, seq in enumerate(seqs):
+                os.makedirs(os.path.join(root, "test_openpose", seq))
+                os.makedirs(os.path.join(root, "test_img", seq))
+                for i in range(per_seq + 2):
+                    shutil.copyfile(os.path.join(src, files[(i + 7 * q) % len(files)]),
+                                    os.path.join(root, "test_openpose", seq, "%05d.json" % i))
+                    img.save(os.path.join(root, "test_img", seq, "%04d.jpg" % i))
             for flow in flows:
                 if flow not in models:
                     continue
@@ -131,6 +202,7 @@ def run_e2e(model_head, model_other, head_flow, n_frames):
                 from text2video_amd.pose_dataset import default_pose_workers
                 workers = opt.pose_workers if opt.pose_workers is not None else default_pose_workers()
                 out.append({"geometry": geom, "flow": flow, "fps": round(stats["fps_loop"], 2), "frames": stats["frames"],
+                            "sequences": len(seqs), "batch_sequences": opt.batch_sequences,
                             "pose_workers": workers, "rasteriser": "bit-exact (curve_fit) mode"})
         finally:
             shutil.rmtree(tmp, ignore_errors=True)
@@ -154,6 +226,8 @@ def main():
                     help="2 = config 4's two-scale generator: G0 at H/2 x W/2 + local enhancer G1 at H x W")
     ap.add_argument("--cpu-frames", type=int, default=3, help="frames of the CPU-oracle baseline (0 = skip)")
     ap.add_argument("--kernel-iters", type=int, default=40)
+    ap.add_argument("--batch-variants", type=lambda v: [int(x) for x in v.split(",") if x], default=[2, 4],
+                    help="lock-step batch sizes timed in addition to the headline (config.variants.batch<N>_fps)")
     args = ap.parse_args()
 
     from text2video_amd import launch
@@ -213,18 +287,25 @@ def main():
             dist.all_gather_into_tensor(host, frames.cpu())
             gathered.copy_(host)
 
-    def timed_run(model):
-        """W untimed warm-up frames, then exactly K timed frames (+ the all-gather of the chunk's frames for N>1)
-        between barrier + synchronize on both sides; returns the MAX over ranks of the elapsed seconds."""
-        model.reset()
+    def timed_run(model, sampler=None, nseq=1):
+        """W untimed warm-up frames, then exactly K timed steps (+ the all-gather of the chunk's frames for N>1)
+        between barrier + synchronize on both sides; returns the MAX over ranks of the elapsed seconds.
+        nseq > 1: every step advances `nseq` independent sequences by one frame each (lock-step batch); the frames of
+        sequence 0 are the ones gathered."""
+        from text2video_amd.generator import Recurrence
+        states = [Recurrence() for _ in range(nseq)]
+        windows = [window] + [torch.zeros_like(window) for _ in range(nseq - 1)]
+        seq_poses = [poses] + [torch.from_numpy(synthetic_pose_u8(nposes, H, W, seed=1000 * (q + 1) + rank)).to(dev)
+                               for q in range(nseq - 1)]
 
         def step(t, out_slot):
-            for f in range(3):                       # sliding window of tG = 3 pose maps, oldest first
-                ops.pose_u8_to_f32(poses[t + f], window, 3 * f)
-            out = model.inference_nhwc(window)
-            u8 = ops.tensor2im_u8(out)
+            for q in range(nseq):
+                for f in range(3):                       # sliding window of tG = 3 pose maps, oldest first
+                    ops.pose_u8_to_f32(seq_poses[q][t + f], windows[q], 3 * f)
+            outs = model.inference_nhwc_batch(windows, states)
+            u8s = [ops.tensor2im_u8(o) for o in outs]
             if out_slot is not None:
-                frames[out_slot].copy_(u8)
+                frames[out_slot].copy_(u8s[0])
 
         for t in range(Wm):
             step(t, None)
@@ -234,16 +315,18 @@ def main():
         if dist:
             dist.barrier()
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for t in range(K):
-            step(Wm + t, t)
-        if dist:
-            all_gather_frames()
-        torch.cuda.synchronize()
-        if dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-        el = time.perf_counter() - t0
+        import contextlib
+        with (sampler if sampler is not None else contextlib.nullcontext()):
+            t0 = time.perf_counter()
+            for t in range(K):
+                step(Wm + t, t)
+            if dist:
+                all_gather_frames()
+            torch.cuda.synchronize()
+            if dist:
+                dist.barrier()
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
         if dist:
             tmax = torch.tensor([el], dtype=torch.float64, device=dev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -253,9 +336,15 @@ def main():
     model, sds = build(head_flow)
     sd = sds[0]
     spec = model.nets[0].spec
-    elapsed = timed_run(model)                     # the headline: `value`
+    sampler = ClockSampler(local_rank)
+    elapsed = timed_run(model, sampler)            # the headline: `value`
     other = other_elapsed = None
+    batch_elapsed = {}
     if not args.single_variant:
+        # the same model advancing 2 / 4 independent sequences in lock-step (t2v_generator_forward_batch): aggregate rate
+        # over all sequences, reported in config.variants -- `value` stays the single-sequence figure
+        for nb in args.batch_variants:
+            batch_elapsed[nb] = timed_run(model, None, nb)
         other, _ = build(not head_flow)
         other_elapsed = timed_run(other)
 
@@ -341,6 +430,9 @@ def main():
         roofline = {"bound": "mfma", "kernel": kname,
                     "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+                    "traffic_source": ("profiles/pmc_summary.json (separate rocprofv3 --pmc passes of this launch: "
+                                       "2*FETCH_SIZE + WRITE_SIZE, bytes per launch; not measured by this run)"
+                                       if traffic is not None else None),
                     "ms_per_launch": round(k_ms, 4), "gflop_per_launch": round(k_flop / 1e9, 2),
                     "flops_counted": "executed MFMA FLOPs of the launch" if use_wino else "algorithmic conv FLOPs",
                     "layer": {"algo": "winograd_f%dx%d_3x3" % (wm, wm) if use_wino else "direct", "ms_per_conv": round(conv_ms, 4),
@@ -409,6 +501,12 @@ def main():
             variants["noflow_fps" if head_flow else "flow_fps"] = round(world * K / other_elapsed, 3)
             variants["other_ms_per_step"] = round(1e3 * other_elapsed / K, 3)
             variants["other_algorithmic_gflop_per_frame"] = round(gflops(not head_flow), 1)
+        for nb, el in batch_elapsed.items():
+            variants["batch%d_fps" % nb] = round(world * nb * K / el, 3)
+        if batch_elapsed:
+            variants["batch_note"] = ("batch<N>_fps: N independent sequences per GPU advanced in lock-step through "
+                                      "t2v_generator_forward_batch (headline variant), aggregate frames/s over all N; every "
+                                      "sequence's frames equal the single-sequence frames")
         variants["headline"] = "flow" if head_flow else "noflow"
         variants["note"] = ("both variants timed in this run over the same K steps and W warm-up frames; `value` is "
                             "the headline variant")
@@ -427,7 +525,7 @@ def main():
                        "algorithmic_gflop_per_frame": round(gf, 1),
                        "algorithmic_tflops": round(fps * gf / 1e3, 2),
                        "variants": variants},
-            "roofline": roofline, "cpu_baseline": cpu, "e2e": e2e,
+            "roofline": roofline, "cpu_baseline": cpu, "e2e": e2e, "box": sampler.summary(),
         }
     if dist:
         dist.barrier()

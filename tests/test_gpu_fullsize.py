@@ -25,7 +25,7 @@ def _prev_frames(H, W, seed):
     return torch.tanh(torch.randn(2, 3, H, W, generator=g))
 
 
-def _full_nets(scales, no_flow, conv_algo=None):
+def _full_nets(scales, no_flow, conv_algo=None, flow_gain=0.1):
     """configs[1] / configs[3] networks: G0 = ngf 128, 3 down-samplings, 9 blocks; G1 = ngf 64, 3 local blocks."""
     from oracle.generator_ref import CompositeGenerator, CompositeLocalGenerator
     from text2video_amd.generator import GeneratorSpec, HipGenerator, synthetic_state_dict
@@ -36,7 +36,7 @@ def _full_nets(scales, no_flow, conv_algo=None):
         refs.append(CompositeLocalGenerator(9, 3, 6, 128, 3, 1, no_flow, "batch"))
     hips = []
     for i, (spec, ref) in enumerate(zip(specs, refs)):
-        sd = synthetic_state_dict(spec, 1 + i, flow_gain=0.1)
+        sd = synthetic_state_dict(spec, 1 + i, flow_gain=flow_gain)
         missing, unexpected = ref.load_state_dict(sd, strict=False)
         assert not unexpected and all(("running" in k or "num_batches" in k) for k in missing)
         hips.append(HipGenerator(spec, "cuda:0", conv_algo=conv_algo).load_state_dict(sd))
@@ -115,6 +115,64 @@ def test_config0_fadg0_geometries_match_oracle(H, W):
     err = (got.cpu() - want).abs().max().item()
     print("%dx%d flow frame: max|delta| = %.3g" % (H, W, err))
     assert err <= TOL and want.abs().max().item() > 0.05
+
+
+def _smooth_prev_frames(H, W, seed):
+    """two previous frames with image-like spectra (low-pass filtered noise): what a trained generator feeds back"""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(2, 3, H // 8, W // 8, generator=g)
+    x = torch.nn.functional.interpolate(x, size=(H, W), mode="bicubic", align_corners=False)
+    return torch.tanh(x)
+
+
+@pytest.mark.parametrize("prev_kind", ["smooth", "noise"])
+def test_config1_512_flow_frame_at_full_flow_gain_matches_oracle(prev_kind):
+    """BASELINE configs[1] WITH the flow branch at flow_gain = 1.0: the x20 flow multiplier on an undamped random-init
+    flow head (flows of tens of pixels, the multiplier amplifying every rounding difference of the flow branch's 11 convs
+    twenty-fold before the bilinear taps are chosen).  One teacher-forced 512x512 frame of the full-size network against
+    the CPU oracle, per-pixel |delta| <= 1e-3, on image-like previous frames and on white-noise ones (the worst case
+    for a warp: unit gradient everywhere)."""
+    from oracle.generator_ref import Vid2VidInferenceRef
+    from text2video_amd.generator import Vid2VidModelG
+    refs, hips = _full_nets(1, False, flow_gain=1.0)
+    ref, hip = Vid2VidInferenceRef(refs), Vid2VidModelG(hips)
+    H = W = 512
+    A = _pose_seq(3, H, W, seed=21).unsqueeze(0)
+    ref.fake_B_prev = [_smooth_prev_frames(H, W, 8) if prev_kind == "smooth" else _prev_frames(H, W, 8)]
+    hip.load_prev(ref.fake_B_prev)
+    want = ref.inference(A)
+    got, _ = hip.inference(A.to("cuda:0"))
+    err = (got.cpu() - want).abs().max().item()
+    # how large the flows are: re-run the net for its taps on the same inputs
+    from text2video_amd import ops
+    hip.load_prev([_smooth_prev_frames(H, W, 8) if prev_kind == "smooth" else _prev_frames(H, W, 8)])
+    taps = hips[0].forward(ops.nchw_to_nhwc(A[0].reshape(9, H, W).contiguous().cuda()), hip.prev[0], False,
+                           want=("out", "flow_w"))
+    fl = taps["flow_w"][..., :2].abs()
+    print("512x512 flow frame, flow_gain 1.0, %s previous frames: max|delta| = %.3g (|flow| mean %.2f px, max %.1f px)"
+          % (prev_kind, err, fl.mean().item(), fl.max().item()))
+    assert fl.max().item() > 5.0            # the flows are not the damped ones of the other tests
+    assert err <= TOL and want.abs().max().item() > 0.05
+
+
+@pytest.mark.parametrize("H,W", [(512, 912), (512, 448)], ids=["512x912", "512x448"])
+def test_chinese_speaker_16x9_geometries_match_oracle(H, W):
+    """The 16:9 speakers of text2video_tts_chinese.sh (/root/reference/interp_landmarks_motion.py:63-68: 1280x720 and
+    1920x1080 sources): `--resize_or_crop scaleHeight --loadSize 512` makes them 512x912 (bottleneck 64x114), and
+    upstream's central-width crop 512x448 (64x56).  Full-size network, one teacher-forced frame against the CPU oracle,
+    flow-warp compositor on."""
+    from oracle.generator_ref import Vid2VidInferenceRef
+    from text2video_amd.generator import Vid2VidModelG
+    refs, hips = _full_nets(1, False)
+    ref, hip = Vid2VidInferenceRef(refs), Vid2VidModelG(hips)
+    A = _pose_seq(3, H, W, seed=14).unsqueeze(0)
+    ref.fake_B_prev = [_prev_frames(H, W, 9)]
+    hip.load_prev(ref.fake_B_prev)
+    want = ref.inference(A)
+    got, _ = hip.inference(A.to("cuda:0"))
+    err = (got.cpu() - want).abs().max().item()
+    print("%dx%d flow frame: max|delta| = %.3g" % (H, W, err))
+    assert err <= TOL and want.abs().max().item() > 0.05 and tuple(got.shape) == (1, 3, H, W)
 
 
 def test_config4_train_step_512_two_frames():

@@ -176,6 +176,35 @@ def test_free_running_sequence_vs_fp64_conditioning():
             assert ehip <= TOL
 
 
+def test_free_running_64_pose_maps_vs_fp64_conditioning():
+    """BASELINE configs[1]'s sequence LENGTH (64 pose maps -> 62 frames) free-running at reduced width: every path feeds
+    on its own previous outputs for the whole sequence.  Yardstick as above -- an fp64 evaluation of the same network:
+    the HIP path stays as close to fp64 as the fp32 CPU oracle does (x10 slack + 1e-4) on every one of the 62 frames,
+    and within 1e-3 wherever the fp32 oracle itself is within 1e-4."""
+    import copy
+    name, kw, scales, H, W = CASES[0]
+    ref, hip = _build(kw, scales)
+    ref64 = copy.deepcopy(ref)
+    for n in ref64.nets:
+        n.double()
+    poses = _pose_seq(64, H, W, seed=17)
+    worst32 = worsthip = 0.0
+    tight = 0
+    for t in range(2, 64):
+        A = poses[t - 2:t + 1].unsqueeze(0)
+        truth = ref64.inference(A.double())
+        e32 = (ref.inference(A).double() - truth).abs().max().item()
+        ehip = (hip.inference(A.to("cuda:0"))[0].cpu().double() - truth).abs().max().item()
+        worst32, worsthip = max(worst32, e32), max(worsthip, ehip)
+        assert ehip <= 10 * e32 + 1e-4, "frame %d: |hip-fp64| = %g, |oracle32-fp64| = %g" % (t, ehip, e32)
+        if e32 <= 1e-4:
+            tight += 1
+            assert ehip <= TOL
+    print("62 free-running frames: max |oracle32-fp64| = %.2e, max |hip-fp64| = %.2e, %d frames with the fp32 oracle within 1e-4"
+          % (worst32, worsthip, tight))
+    assert tight >= 1
+
+
 def test_fullsize_frame_512_noflow_matches_oracle():
     """BASELINE config 2 geometry (ngf 128, 3 down, 9 blocks, 512x512, openpose_only => no flow):
     the first frame (zero prev) and a teacher-forced second frame through the real-size network."""

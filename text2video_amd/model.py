@@ -70,6 +70,11 @@ def create_model(opt, device="cuda:0"):
     return Vid2VidModelG(nets, opt.n_frames_G, opt.output_nc, opt.no_first_img)
 
 
+def _lib_max_batch():
+    from ._lib import MAX_BATCH
+    return MAX_BATCH
+
+
 def _real_A_u8(pose_map_u8):
     """what util.tensor2im(real_A) writes: the pose map after the Normalize / de-normalize round trip"""
     x = (pose_map_u8.astype(np.float32) / 255.0 - 0.5) / 0.5
@@ -84,7 +89,11 @@ def run_test(opt, model=None, device=None, dataset=None):
     sequences by default, so every frame equals the single-GPU frame; --shard_chunks also cuts sequences into
     chunks (each a fresh recurrence), and --stitch_frames K then re-generates the first K frames of every
     continuation chunk from its predecessor's true last frames, all-gathered over RCCL.  --how_many counts
-    output frames globally, as the single-process loop does.  Every rank writes its own frames."""
+    output frames globally, as the single-process loop does.  Every rank writes its own frames.
+
+    --batch_sequences N (default 2): a rank with several independent recurrences to generate (the reference always has
+    two per utterance: tmp and tmp_smooth) advances N of them in lock-step, one batched generator call per frame
+    (t2v_generator_forward_batch); the frames are those of the one-at-a-time loop, only their order of production differs."""
     t_start = time.perf_counter()
     if device is None:      # a plain single-device run computes on --gpu_ids[0]
         ids = getattr(opt, "gpu_ids", None)
@@ -110,53 +119,74 @@ def run_test(opt, model=None, device=None, dataset=None):
     counters = {"n": 0, "t_loop0": 0.0}
     tails = {}       # unit index -> FIFO of generated frames the unit ended with (stitch pass)
 
-    def frame_loop(items, tails, start_state=None):
-        window = dev_maps = None
-        pending = None   # (event, pinned uint8 frame, path, real_A) of the previous frame: D2H overlaps the next frame
-        cur_unit = None
+    n_lanes = max(1, min(int(getattr(opt, "batch_sequences", 2) or 1), _lib_max_batch()))
+
+    class Lane:
+        """one recurrence being advanced: its FIFO of generated frames, pose window and resident pose maps"""
+        def __init__(self):
+            from .generator import Recurrence
+            self.rec, self.window, self.dev_maps, self.unit = Recurrence(), None, None, None
+
+    def frame_loop(steps, tails, start_state=None):
+        """steps: iterable of [(lane, item), ...] (PoseDataset.iter_lanes): the items of one step belong to independent
+        recurrences and go through the generator in ONE batched call per frame geometry."""
+        lanes = {}
+        pending = []   # (event, pinned uint8 frame, path, real_A) of the previous step: D2H overlaps the next step
 
         def finish(p):
             ev, host, a_path, real_a = p
             ev.synchronize()
             vis.save_images({"real_A": real_a, "fake_B": host.numpy()[..., :3].copy()}, a_path)
 
-        for data in items:
-            if counters["n"] == 0:
-                counters["t_loop0"] = time.perf_counter()
-            A = data["A"]  # [tG, H, W, 3] uint8
-            H, W = A.shape[1], A.shape[2]
-            if data["change_seq"] or dev_maps is None or window.shape[:2] != (H, W):
-                if cur_unit is not None and model.prev is not None:
-                    tails[cur_unit] = model.prev[0].clone()
-                model.reset()
-                if start_state is not None:      # stitch pass: continue from the predecessor chunk's last frames
-                    model.prev = [start_state[data["unit"]].clone()]
-                window = torch.zeros(H, W, cs, dtype=torch.float32, device=dev)
-                dev_maps = [torch.from_numpy(A[f]).to(dev) for f in range(opt.n_frames_G)]
-            else:
-                dev_maps = dev_maps[1:] + [torch.from_numpy(A[-1]).to(dev, non_blocking=True)]
-            cur_unit = data.get("unit")
-            for f in range(opt.n_frames_G):
-                ops.pose_u8_to_f32(dev_maps[f], window, 3 * f)
-            out = model.inference_nhwc(window)
-            u8 = ops.tensor2im_u8(out)
-            ring = pinned.setdefault(tuple(u8.shape), [[torch.empty(u8.shape, dtype=torch.uint8, pin_memory=True) for _ in range(3)], 0])
-            host = ring[0][ring[1] % 3]     # the buffer of frame n-3: its JPEG copy was taken in finish(n-3)
-            ring[1] += 1
-            host.copy_(u8, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record()
-            if pending is not None:
-                finish(pending)
-            pending = (ev, host, data["A_path"], _real_A_u8(A[-1]))
-            print("process image... %s" % data["A_path"])
-            counters["n"] += 1
-        if pending is not None:
-            finish(pending)
-        if cur_unit is not None and model.prev is not None:
-            tails[cur_unit] = model.prev[0].clone()
+        def close_unit(L):
+            if L.unit is not None and L.rec.prev is not None:
+                tails[L.unit] = L.rec.prev[0].clone()
 
-    frame_loop(dataset.iter_prefetch(opt.pose_workers, limit=limit), tails)
+        for step in steps:
+            groups = {}      # frame geometry -> [(lane object, item)]
+            for k, data in step:
+                if counters["n"] == 0 and not groups:
+                    counters["t_loop0"] = time.perf_counter()
+                L = lanes.setdefault(k, Lane())
+                A = data["A"]  # [tG, H, W, 3] uint8
+                H, W = A.shape[1], A.shape[2]
+                if data["change_seq"] or L.dev_maps is None or L.window.shape[:2] != (H, W):
+                    close_unit(L)
+                    L.rec.reset()
+                    if start_state is not None:      # stitch pass: continue from the predecessor chunk's last frames
+                        L.rec.prev = [start_state[data["unit"]].clone()]
+                    L.window = torch.zeros(H, W, cs, dtype=torch.float32, device=dev)
+                    L.dev_maps = [torch.from_numpy(A[f]).to(dev) for f in range(opt.n_frames_G)]
+                else:
+                    L.dev_maps = L.dev_maps[1:] + [torch.from_numpy(A[-1]).to(dev, non_blocking=True)]
+                L.unit = data.get("unit")
+                for f in range(opt.n_frames_G):
+                    ops.pose_u8_to_f32(L.dev_maps[f], L.window, 3 * f)
+                groups.setdefault((H, W), []).append((k, L, data))
+            now = []
+            for members in groups.values():
+                outs = model.inference_nhwc_batch([L.window for _, L, _ in members], [L.rec for _, L, _ in members])
+                for (k, L, data), out in zip(members, outs):
+                    u8 = ops.tensor2im_u8(out)
+                    ring = pinned.setdefault((k,) + tuple(u8.shape),
+                                             [[torch.empty(u8.shape, dtype=torch.uint8, pin_memory=True) for _ in range(3)], 0])
+                    host = ring[0][ring[1] % 3]     # the buffer of this lane's frame n-3: its JPEG copy was taken in finish(n-3)
+                    ring[1] += 1
+                    host.copy_(u8, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    now.append((ev, host, data["A_path"], _real_A_u8(data["A"][-1])))
+                    print("process image... %s" % data["A_path"])
+                    counters["n"] += 1
+            for p in pending:
+                finish(p)
+            pending = now
+        for p in pending:
+            finish(p)
+        for L in lanes.values():
+            close_unit(L)
+
+    frame_loop(dataset.iter_lanes(n_lanes, opt.pose_workers, limit=limit), tails)
     n_first_pass = counters["n"]
     stitch = int(getattr(opt, "stitch_frames", 0) or 0)
     if plan is not None and stitch > 0:
@@ -173,7 +203,7 @@ def run_test(opt, model=None, device=None, dataset=None):
             if redo:
                 dataset.restrict([u for _, u in redo], first_n=stitch)
                 redone = {}      # tails of the re-generated runs, under the restricted numbering
-                frame_loop(dataset.iter_prefetch(opt.pose_workers), redone,
+                frame_loop(dataset.iter_lanes(n_lanes, opt.pose_workers), redone,
                            start_state={jj: known[(u[0], u[3])] for jj, (_, u) in enumerate(redo)})
                 for jj, (j, u) in enumerate(redo):
                     if stitch >= u[2] - u[3]:      # re-generated to its end: this chunk's tail is the new one

@@ -59,6 +59,8 @@ def _common(p):
     g("--write_video", action="store_true", help="after the frame loop, mux every sequence's frames into "
       "results/<name>/<name>_<seq>.mp4 at 25 fps (the reference's image2video*.py stage; text2video_amd/mux.py)")
     g("--video_audio", type=str, default=None, help="--write_video: .wav / .mp3 sound track")
+    g("--batch_sequences", type=int, default=2, metavar="N", help="advance up to N independent sequences (or chunks) of this "
+      "rank in lock-step, one batched generator call per frame; frames are identical to N=1")
     g("--shard_chunks", action="store_true", help="multi-GPU test.py: also cut sequences into chunks so that every rank "
       "has work (each chunk restarts the recurrence; default: whole sequences only, frames identical to 1 GPU)")
     g("--stitch_frames", type=int, default=0, metavar="K", help="with --shard_chunks: re-generate the first K frames of "

@@ -213,6 +213,92 @@ class PoseDataset:
             for f in futures.values():      # an early exit (--how_many, an error): let the in-flight jobs drain
                 f.cancel()
 
+    def lane_plan(self, n_lanes, limit=None):
+        """The items cut into recurrences (maximal runs of consecutive frames of one unit / sequence) and the
+        recurrences dealt to `n_lanes` lanes that advance in lock-step: longest first to the least loaded lane,
+        dataset order kept inside a lane.  Returns [[item index, ...] per lane].  `limit` keeps the first `limit` items
+        in dataset order (what the single-lane loop's --how_many does) before anything is dealt."""
+        n_items = len(self.items) if limit is None else min(limit, len(self.items))
+        runs = []
+        for idx in range(n_items):
+            seq, i = self.items[idx]
+            new = idx == 0 or self.items[idx - 1] != (seq, i - 1) or (seq, i) in getattr(self, "_unit_starts", ())
+            if new:
+                runs.append([])
+            runs[-1].append(idx)
+        n_lanes = max(1, min(n_lanes, len(runs)))
+        loads, lanes = [0] * n_lanes, [[] for _ in range(n_lanes)]
+        for r in sorted(range(len(runs)), key=lambda r: (-len(runs[r]), r)):
+            k = loads.index(min(loads))
+            lanes[k].append(r)
+            loads[k] += len(runs[r])
+        return [[idx for r in sorted(lane) for idx in runs[r]] for lane in lanes]
+
+    def iter_lanes(self, n_lanes, workers=None, ahead=None, limit=None):
+        """Lock-step iteration for N independent recurrences per step (t2v_generator_forward_batch): yields, per step, a
+        list of (lane, item) with at most one item per lane -- the same items, windows and names as iter_prefetch,
+        only their order differs.  change_seq marks the first frame of every recurrence."""
+        plan = self.lane_plan(n_lanes, limit)
+        if workers is None:
+            workers = default_pose_workers()
+        steps = max((len(p) for p in plan), default=0)
+        order = [(k, plan[k][t]) for t in range(steps) for k in range(len(plan)) if t < len(plan[k])]
+        first_of_run = set()
+        for lane in plan:
+            for j, idx in enumerate(lane):
+                seq, i = self.items[idx]
+                if j == 0 or self.items[lane[j - 1]] != (seq, i - 1) or (seq, i) in getattr(self, "_unit_starts", ()):
+                    first_of_run.add(idx)
+        pool = futures = None
+        need, nxt = [], 0
+        if workers > 1 and order:
+            ahead = ahead or 4 * workers
+            seen = set()
+            for k, idx in order:        # pose maps in first-use order, per lane (chunks of one sequence overlap by tG-1 maps)
+                seq, i = self.items[idx]
+                for j in range(i - self.tG + 1, i + 1):
+                    if (k, seq, j) not in seen:
+                        seen.add((k, seq, j))
+                        need.append((k, seq, j))
+            from .raster_pool import get_pool
+            pool, futures = get_pool(workers), {}
+
+        def pump():
+            nonlocal nxt
+            while pool is not None and nxt < len(need) and len(futures) < ahead:
+                futures[need[nxt]] = pool.submit(self._job(*need[nxt][1:]))
+                nxt += 1
+
+        caches = [dict() for _ in plan]
+        pump()
+        try:
+            for t in range(steps):
+                out = []
+                for k in range(len(plan)):
+                    if t >= len(plan[k]):
+                        continue
+                    idx = plan[k][t]
+                    seq, i = self.items[idx]
+                    cache, win = caches[k], []
+                    for j in range(i - self.tG + 1, i + 1):
+                        if (seq, j) not in cache:
+                            if pool is not None:
+                                cache[(seq, j)] = futures.pop((k, seq, j)).result()
+                                pump()
+                            else:
+                                cache[(seq, j)] = self._pose_map(seq, j)
+                        win.append(cache[(seq, j)])
+                    for key in [q for q in cache if q[0] != seq or q[1] < i - self.tG + 2]:
+                        del cache[key]
+                    out.append((k, {"A": np.stack(win), "A_path": self._name(seq, i), "seq": seq,
+                                    "change_seq": idx in first_of_run,
+                                    "unit": getattr(self, "_unit_of", {}).get((seq, i))}))
+                yield out
+        finally:
+            if futures:
+                for f in futures.values():      # an early exit: let the in-flight jobs drain
+                    f.cancel()
+
     def __getitem__(self, idx):
         seq, i = self.items[idx]
         change_seq = idx == 0 or self.items[idx - 1][0] != seq or (seq, i) in getattr(self, "_unit_starts", ())
