@@ -264,8 +264,16 @@ def test_bench_contract_line():
     assert "flow-warp compositor ON" in d["config"]["workload"]
     # end to end through the drop-in test.py frame loop (pose JSONs -> JPEG files)
     runs = d["e2e"]["runs"]
-    assert {r["geometry"].split(" ")[0] for r in runs} == {"512x512", "512x680", "512x320"}
+    assert {r["geometry"].split(" ")[0].rstrip(",") for r in runs} == {"512x512", "512x680", "512x320"}
     assert all(r["frames"] == 12 and r["fps"] > 0 and r["pose_workers"] >= 1 for r in runs)
+    # the two-sequence dataset (tmp + tmp_smooth, as the reference's L2 driver writes it), one at a time and in lock-step
+    assert sorted(r["batch_sequences"] for r in runs if r["sequences"] == 2) == [1, 2]
+    # N independent sequences per GPU in lock-step: aggregate rates beside the single-sequence headline
+    assert v["batch2_fps"] > 30.0 and v["batch4_fps"] > 30.0 and d["value"] == v["flow_fps"]
+    # the box the line was measured on and the core clock during the timed region (None where sysfs has no such file)
+    box = d["box"]
+    assert box["host"] and "sclk_mhz_mean" in box and (box["sclk_mhz_mean"] is None or 500 < box["sclk_mhz_mean"] < 3500)
+    assert rf["traffic"] is None or "pmc_summary.json" in rf["traffic_source"]
 
 
 def test_lockstep_sequences_write_the_same_files_as_one_at_a_time(tmp_path):
