@@ -136,6 +136,13 @@ int t2v_instance_norm_finalize(t2v_ctx* ctx, void* stream, const t2v_conv_desc* 
                                const float* stats_partial, float eps, float* mean_rstd);
 int t2v_batch_norm_finalize(t2v_ctx* ctx, void* stream, const t2v_conv_desc* producer, int batch,
                             const float* stats_partial, float eps, float* mean_rstd);
+/* BatchNorm2d's running statistics (training mode; $SP/torch/nn/modules/batchnorm.py:27-29,57-64; the momentum
+ * argument of BatchNormalization_updateOutput, THCUNN.h:33-45): running_mean / running_var [C] are updated in place
+ * from the (mean, rstd) table a finalize call produced over n values per channel:
+ *   running_mean = (1-momentum)*running_mean + momentum*mean
+ *   running_var  = (1-momentum)*running_var  + momentum*var*n/(n-1)      (unbiased; var = 1/rstd^2 - eps) */
+int t2v_batch_norm_update_running(t2v_ctx* ctx, void* stream, const float* mean_rstd, float* running_mean,
+                                  float* running_var, long n, int C, float momentum, float eps);
 int t2v_instance_norm_apply(t2v_ctx* ctx, void* stream, const float* x, const float* mean_rstd,
                             const float* gamma, const float* beta, const float* res1,
                             const float* res2, float* y, long npix, int C, int relu);

@@ -130,3 +130,13 @@ def test_algorithm_choice_and_winograd_bookkeeping(lib_built):
     big = desc(2048, 2048, C=128)
     assert lib_built.t2v_conv_stats_floats(ctypes.byref(big)) == 0 and b"too large" in lib_built.t2v_last_error()
     assert lib_built.t2v_conv_stats_floats(ctypes.byref(desc(1024, 1024, C=128))) > 0
+
+
+def test_makefile_rebuilds_objects_when_the_winograd_constants_change():
+    """csrc/Makefile: every object depends on winograd_f4_consts.h (generated by scripts/gen_winograd_consts.py); an
+    incremental `make` -- what __graft_entry__.build() runs -- must rebuild after the header is regenerated."""
+    import os
+    import re
+    mk = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "text2video_amd", "csrc", "Makefile")).read()
+    rule = re.search(r"^%\.o: %\.hip (.*)$", mk, re.M).group(1).split()
+    assert "winograd_f4_consts.h" in rule and "t2v_internal.h" in rule and "../../include/t2v.h" in rule

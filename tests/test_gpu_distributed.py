@@ -325,3 +325,38 @@ def test_plain_test_py_with_two_gpu_ids_equals_the_single_device_run(tmp_path):
                 for p in sorted(glob.glob(os.path.join(work, "results", "fadg0", "test_latest", "*", "fake_B_*.jpg")))}
     a, b = frames(works["one"]), frames(works["two"])
     assert len(a) == (8 - 2) + (6 - 2) and a.keys() == b.keys() and all(a[k] == b[k] for k in a)
+
+
+def test_two_ranks_agree_on_the_face_terms_when_one_clip_shows_no_face(tmp_path):
+    """--add_face_disc with two ranks whose clips differ: clipA shows the nose-neck limb (a face region exists), clipB has
+    the nose key point at confidence 0 (no face region -> that rank alone would skip D_f's terms, leave D_f without
+    gradients and put a different parameter list into its gradient buckets).  The ranks settle it with a MIN all-reduce of
+    the has-face flag per chunk: the face terms are skipped on both, the exchange stays aligned, replicas stay in sync."""
+    import json as js
+    import shutil
+    from PIL import Image
+    from text2video_amd.keypoints import read_keypoints
+    root = tmp_path / "datasets" / "fadg0"
+    src = os.path.join(ROOT, "tests", "golden", "keypoints_fadg0")
+    files = sorted(f for f in os.listdir(src) if f.startswith("sa1_"))
+    for seq in ("clipA", "clipB"):
+        os.makedirs(root / "train_openpose" / seq)
+        os.makedirs(root / "train_img" / seq)
+        for i, f in enumerate(files + files[::-1]):
+            d = js.load(open(os.path.join(src, f)))
+            if seq == "clipB":
+                d["people"][0]["pose_keypoints_2d"][2] = 0.0          # nose confidence 0: the nose-neck limb is not drawn
+            dst = root / "train_openpose" / seq / ("%04d_keypoints.json" % i)
+            js.dump(d, open(dst, "w"))
+            Image.fromarray(read_keypoints(str(dst), (256, 192))).save(root / "train_img" / seq / ("%04d.jpg" % i))
+    cmd = [sys.executable, os.path.join(ROOT, "vid2vid", "train.py"), "--name", "fadg0", "--dataroot", "datasets/fadg0",
+           "--dataset_mode", "pose", "--input_nc", "3", "--openpose_only", "--num_D", "2", "--resize_or_crop",
+           "randomScaleHeight_and_scaledCrop", "--loadSize", "136", "--fineSize", "128", "--gpu_ids", "0,1", "--batchSize", "2",
+           "--max_frames_per_gpu", "2", "--no_first_img", "--n_frames_total", "5", "--max_t_step", "2", "--niter_step", "100",
+           "--add_face_disc", "--random_drop_prob", "0", "--ngf", "16", "--n_blocks", "2", "--n_downsample_G", "2",
+           "--ndf", "16", "--no_vgg", "--niter", "2", "--niter_decay", "0", "--checkpoints_dir", str(tmp_path / "ck")]
+    r = subprocess.run(cmd, cwd=str(tmp_path), env=_plain_env(), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    assert "replicas in sync after 2 steps" in r.stdout and "on all 2 ranks" in r.stdout
+    lines = [l for l in r.stdout.splitlines() if l.startswith("(iter")]
+    assert lines and not any("D_f" in l for l in lines), lines      # rank 0's clip HAS a face: skipped together all the same

@@ -339,3 +339,70 @@ def test_multi_tensor_adam_equals_the_per_tensor_kernel(monkeypatch):
         for a, b in zip(outs["1"][k], outs["0"][k]):
             assert torch.equal(a, b)
     assert not torch.equal(outs["1"][0][0], init[0])
+
+
+def test_batchnorm_running_statistics_follow_torch_and_reach_the_checkpoint(tmp_path):
+    """Training-mode BatchNorm2d also moves running_mean / running_var (momentum 0.1, UNBIASED variance;
+    /root/reference/venv_vid2vid/lib/python3.7/site-packages/torch/nn/modules/batchnorm.py:57-64).  The discriminator
+    (statistics over the batch) and the generator (a batch of one per call) against torch.nn.BatchNorm2d inside the CPU
+    oracle after two forwards each; then the saved checkpoint carries them and loads strictly into the oracle's modules."""
+    from oracle.generator_ref import CompositeGenerator, MultiscaleDiscriminator
+    from text2video_amd import train as T
+    from text2video_amd.generator import GeneratorSpec, synthetic_state_dict
+    from text2video_amd.options import TrainOptions
+    # discriminator: batch statistics over B = 2 images
+    ref = _init(MultiscaleDiscriminator(6, 16, 3, 2, "batch"), 5)
+    dsd = {k: v.clone() for k, v in ref.state_dict().items() if "running" not in k and "num_batches" not in k}
+    Dh = T.TrainableDiscriminator(6, dsd, 16, 3, 2, "batch", "cuda:0")
+    for seed in (1, 2):
+        x = _rand(2, 6, 64, 96, seed=seed)
+        ref(x)
+        Dh(torch.cat([_nhwc_batch(x, 8)], 0))
+    checked = 0
+    for k, p in Dh.named_upstream_parameters().items():
+        if k.endswith(".weight") and p.dim() == 1:
+            rs = T.running_stats(p, create=False)
+            assert rs is not None and rs[2] == 2, k
+            base = k[:-len("weight")]
+            want_m, want_v = ref.state_dict()[base + "running_mean"], ref.state_dict()[base + "running_var"]
+            assert (rs[0].cpu() - want_m).abs().max().item() <= 1e-5 + 1e-4 * want_m.abs().max().item(), k
+            assert ((rs[1].cpu() - want_v).abs() / want_v.abs()).max().item() <= 1e-4, k
+            assert int(ref.state_dict()[base + "num_batches_tracked"]) == rs[2]
+            checked += 1
+    assert checked >= 4
+    # generator: BatchNorm2d(train) on a batch of ONE per frame; through the trainer, then its checkpoint
+    opt = TrainOptions().parse(["--name", "bn", "--dataset_mode", "pose", "--input_nc", "3", "--openpose_only", "--no_flow",
+                                "--ngf", "16", "--n_downsample_G", "2", "--n_blocks", "2", "--num_D", "1", "--ndf", "16",
+                                "--no_vgg", "--max_frames_per_gpu", "2", "--n_scales_temporal", "0", "--no_first_img",
+                                "--checkpoints_dir", str(tmp_path)])
+    tr = T.Vid2VidTrainer(opt, "cuda:0", seed=3)
+    spec = tr.spec
+    Gr = CompositeGenerator(9, 3, 6, 16, 2, 2, True, "batch").train()
+    sd0 = {k: v.detach().cpu().clone() for k, v in tr.G.named_upstream_parameters().items()}
+    Gr.load_state_dict(sd0, strict=False)
+    poses = _rand(2, 9, 64, 64, seed=4).clamp(-1, 1)
+    real = torch.tanh(_rand(2, 3, 64, 64, seed=5))
+    # the oracle's two frames with the SAME previous frames the trainer builds (zero FIFO, then its own detached output)
+    with torch.no_grad():
+        prev0 = torch.zeros(1, 6, 64, 64)
+        o1 = Gr(poses[0:1], prev0, True)
+        Gr(poses[1:2], torch.cat([prev0[:, 3:], o1[0]], 1), False)
+    pz = torch.zeros(2, 64, 64, 12, device="cuda:0")
+    pz[..., :9] = poses.permute(0, 2, 3, 1).cuda()
+    rz = torch.zeros(2, 64, 64, 4, device="cuda:0")
+    rz[..., :3] = real.permute(0, 2, 3, 1).cuda()
+    tr.train_step(pz, rz, None, None)
+    tr.save("latest", (1, 1))
+    ck = torch.load(str(tmp_path / "bn" / "latest_net_G0.pth"), map_location="cpu")
+    want = Gr.state_dict()
+    n = 0
+    for k in want:
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            assert k in ck, k
+            tol = 1e-5 + 2e-4 * want[k].abs().max().item()
+            assert (ck[k] - want[k]).abs().max().item() <= tol, (k, (ck[k] - want[k]).abs().max().item())
+            n += 1
+        elif k.endswith("num_batches_tracked"):
+            assert int(ck[k]) == int(want[k]) == 2, k
+    assert n >= 10
+    assert not Gr.load_state_dict(ck, strict=True).missing_keys       # the file is a complete torch state dict

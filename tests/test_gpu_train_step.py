@@ -283,3 +283,97 @@ def test_trainer_step_with_flow_branch_runs_and_is_deterministic():
     for a, b in zip(runs[0], runs[1]):
         for k in a:
             assert a[k] == b[k], (k, a[k], b[k])
+
+
+def test_first_frame_g_warp_target_is_the_warped_real_previous_frame():
+    """No generated previous frame exists for a sequence's first frame: G_Warp there compares the fake with the REAL
+    previous frame warped by the reference flow (upstream: fake_B_prev = real_B_prev[:, 0:1] without a previous chunk
+    [RECALL compute_fake_B_prev]), not with the generator's all-zero FIFO.  One-frame first chunk, zero reference flow,
+    explicit confidence mask: G_Warp == MaskedL1(fake0, real_prev0, conf) * lambda_T."""
+    from text2video_amd import train as T
+    from text2video_amd.options import TrainOptions
+    opt = TrainOptions().parse(["--name", "t", "--dataset_mode", "pose", "--input_nc", "3", "--openpose_only", "--ngf", "16",
+                                "--n_downsample_G", "2", "--n_blocks", "2", "--num_D", "1", "--ndf", "16", "--no_vgg",
+                                "--max_frames_per_gpu", "1", "--n_scales_temporal", "0", "--no_first_img"])
+    H = W = 64
+    rng = np.random.default_rng(3)
+    pose = torch.zeros(1, H, W, 12, device="cuda:0")
+    pose[..., :9] = torch.from_numpy(rng.uniform(-1, 1, (1, H, W, 9)).astype(np.float32)).cuda()
+    real = torch.zeros(1, H, W, 4, device="cuda:0")
+    real[..., :3] = torch.tanh(torch.from_numpy(rng.standard_normal((1, H, W, 3)).astype(np.float32))).cuda()
+    real_prev = torch.zeros(1, H, W, 4, device="cuda:0")
+    real_prev[..., :3] = torch.tanh(torch.from_numpy(rng.standard_normal((1, H, W, 3)).astype(np.float32))).cuda()
+    conf = (torch.from_numpy(rng.random((1, H, W))) < 0.6).float().cuda()
+    tr = T.Vid2VidTrainer(opt, "cuda:0", seed=7)
+    losses, prev = tr.train_step(pose, real, None, None, real_prev=real_prev, conf_ref=conf)
+    fake0 = prev[0, ..., 3:6]                                   # the FIFO's newest frame = the (detached) first fake
+    m = conf[0].unsqueeze(-1)
+    want = ((fake0 * m) - (real_prev[0, ..., :3] * m)).abs().mean().item() * opt.lambda_T
+    zero_target = (fake0 * m).abs().mean().item() * opt.lambda_T          # what the all-zero FIFO would have given
+    assert abs(losses["G_Warp"] - want) <= 1e-5 * max(1.0, want), (losses["G_Warp"], want)
+    assert abs(want - zero_target) > 1e-3
+    # the weight-map loss only exists under --no_first_img
+    opt2 = TrainOptions().parse(["--name", "t", "--dataset_mode", "pose", "--input_nc", "3", "--openpose_only", "--ngf", "16",
+                                 "--n_downsample_G", "2", "--n_blocks", "2", "--num_D", "1", "--ndf", "16", "--no_vgg",
+                                 "--max_frames_per_gpu", "1", "--n_scales_temporal", "0"])
+    tr2 = T.Vid2VidTrainer(opt2, "cuda:0", seed=7)
+    prev_in = torch.zeros(1, H, W, 8, device="cuda:0")
+    l2, _ = tr2.train_step(pose, real, None, prev_in, real_prev=real_prev, conf_ref=conf)
+    assert l2["W"] == 0.0 and losses["W"] > 0.0
+
+
+def test_flow_branch_gets_its_weight_gradients_when_a_new_sequence_has_no_flow_losses():
+    """train_step on a NEW sequence (prev=None) with the flow branch but without real_prev: frame 0 is raw-only and no
+    loss reads its flow / weight maps.  Its flow branch is not run (it would be a dead part of the graph whose batched
+    Winograd weight-gradient slots nobody reduces), frame 1's is: every flow-branch 3x3 weight must move.  And the
+    general safety net: a graph built WITH the dead branch is flushed after the backward pass and yields the gradients of
+    the one-by-one reduction."""
+    from text2video_amd import ops
+    from text2video_amd import train as T
+    from text2video_amd.generator import GeneratorSpec, synthetic_state_dict
+    from text2video_amd.options import TrainOptions
+    opt = TrainOptions().parse(["--name", "t", "--dataset_mode", "pose", "--input_nc", "3", "--openpose_only", "--ngf", "16",
+                                "--n_downsample_G", "2", "--n_blocks", "2", "--num_D", "1", "--ndf", "16", "--no_vgg",
+                                "--max_frames_per_gpu", "2", "--n_scales_temporal", "0", "--no_first_img"])
+    H, W = 128, 256       # bottleneck 32x64: the ResnetBlock convs run (and differentiate) in the Winograd domain
+    rng = np.random.default_rng(5)
+    pose = torch.zeros(2, H, W, 12, device="cuda:0")
+    pose[..., :9] = torch.from_numpy(rng.uniform(-1, 1, (2, H, W, 9)).astype(np.float32)).cuda()
+    real = torch.zeros(2, H, W, 4, device="cuda:0")
+    real[..., :3] = torch.tanh(torch.from_numpy(rng.standard_normal((2, H, W, 3)).astype(np.float32))).cuda()
+    tr = T.Vid2VidTrainer(opt, "cuda:0", seed=9)
+    before = {k: v.detach().clone() for k, v in tr.G.named_upstream_parameters().items()}
+    tr.train_step(pose, real, None, None)
+    moved = {k: (v.detach() - before[k]).abs().max().item() for k, v in tr.G.named_upstream_parameters().items()}
+    for k, d in moved.items():
+        if k.startswith(("model_res_flow", "model_up_flow")) and k.endswith("weight") and before[k].dim() == 4:
+            assert d > 0, k
+    # the flush: build the graph with frame 0's flow branch in it but unused, batched reduction on
+    spec = GeneratorSpec(ngf=16, n_downsample=2, n_blocks=2, no_flow=False, norm="batch")
+    sd = synthetic_state_dict(spec, 3, "vid2vid", flow_gain=0.1)
+
+    def grads(batched, flush):
+        G = T.TrainableGenerator(spec, sd, "cuda:0")
+        params = list(G.parameters())
+        prev0 = torch.zeros(1, H, W, 8, device="cuda:0")
+        ctx = T.batched_weight_gradients(params) if batched else __import__("contextlib").nullcontext()
+        with ctx:
+            f0, _, _ = G(pose[0:1], prev0, use_raw_only=True, full=True, need_flow=True)     # flow branch built, never used
+            prev1 = torch.zeros_like(prev0)
+            prev1[..., 3:6] = f0.detach()[..., :3]
+            f1, _, _ = G(pose[1:2], prev1, use_raw_only=False, full=True)
+            loss = (f0[..., :3] * real[0:1, ..., :3]).sum() + (f1[..., :3] * real[1:2, ..., :3]).sum()
+            g = torch.autograd.grad(loss, params, allow_unused=True)
+            if flush:
+                g = T.flush_pending_weight_gradients(params, g)
+        return {k: gi for (k, _), gi in zip(G.named_upstream_parameters().items(), g)}
+
+    ref = grads(False, False)
+    lost = grads(True, False)
+    got = grads(True, True)
+    flow3x3 = [k for k in ref if k.startswith("model_res_flow") and k.endswith("weight") and ref[k] is not None and ref[k].dim() == 4]
+    assert flow3x3 and any(lost[k] is None for k in flow3x3)              # the failure mode the flush exists for
+    for k in flow3x3:
+        assert got[k] is not None, k
+        err = (got[k] - ref[k]).abs().max().item() / max(ref[k].abs().max().item(), 1e-12)
+        assert err <= 2e-3, (k, err)

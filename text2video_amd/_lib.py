@@ -97,6 +97,8 @@ SIGNATURES = {
                               c_double, c_double, c_int]),
     "t2v_adam_step_multi": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                     c_double, c_double, c_double]),
+    "t2v_batch_norm_update_running": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_float,
+                                              c_float]),
     "t2v_instance_norm_apply": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_void_p, c_long, c_int, c_int]),
     "t2v_flow_warp_composite": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,

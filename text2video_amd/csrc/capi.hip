@@ -755,6 +755,13 @@ int t2v_adam_step_multi(t2v_ctx* ctx, void* stream, const int64_t* ptrs, const i
                              reinterpret_cast<const long long*>(chunk_off), nchunks, chunk, beta1, beta2, eps);
 }
 
+int t2v_batch_norm_update_running(t2v_ctx* ctx, void* stream, const float* mean_rstd, float* running_mean,
+                                  float* running_var, long n, int C, float momentum, float eps) {
+    T2V_REQUIRE(ctx && mean_rstd && running_mean && running_var && C > 0 && n > 1,
+                "batch_norm_update_running: bad arguments (needs more than one value per channel)");
+    return launch_bn_running_update((hipStream_t)stream, mean_rstd, running_mean, running_var, n, momentum, eps, C);
+}
+
 int t2v_instance_norm_apply(t2v_ctx* ctx, void* stream, const float* x, const float* mean_rstd, const float* gamma,
                             const float* beta, const float* res1, const float* res2, float* y, long npix, int C,
                             int relu) {

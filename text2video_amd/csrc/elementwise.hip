@@ -144,6 +144,28 @@ int launch_inorm_finalize_winograd(hipStream_t s, const float* stats, int wm, in
     return run_finalize(s, stats, batch * nparts, nparts, 0, H * W, C, eps, mean_rstd, wm, H, W, scratch);
 }
 
+// BatchNorm2d's running statistics in training mode ($SP/torch/nn/modules/batchnorm.py:57-64 -> BatchNormalization_
+// updateOutput(train, momentum), THCUNN.h:33-45): running = (1 - momentum) * running + momentum * batch statistic,
+// the variance entering with the UNBIASED estimate n/(n-1) * var.  The batch statistics are the (mean, rstd) table the
+// norm layer was applied with (biased variance: var = 1/rstd^2 - eps).
+__global__ void bn_running_update_kernel(const float2* __restrict__ mean_rstd, float* __restrict__ running_mean,
+                                         float* __restrict__ running_var, float n, float momentum, float eps, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float2 mr = mean_rstd[c];
+    const float var = fmaxf(1.0f / (mr.y * mr.y) - eps, 0.f);
+    const float unbiased = var * (n / (n - 1.0f));
+    running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * mr.x;
+    running_var[c] = (1.0f - momentum) * running_var[c] + momentum * unbiased;
+}
+int launch_bn_running_update(hipStream_t s, const float* mean_rstd, float* running_mean, float* running_var, long n,
+                             float momentum, float eps, int C) {
+    hipLaunchKernelGGL(bn_running_update_kernel, dim3((C + 255) / 256), dim3(256), 0, s,
+                       reinterpret_cast<const float2*>(mean_rstd), running_mean, running_var, (float)n, momentum, eps, C);
+    T2V_HIP_CHECK(hipGetLastError());
+    return T2V_OK;
+}
+
 // y = [relu]((x-mean)*rstd*gamma+beta) + res1 + res2 ; float4 over NHWC, C % 4 == 0
 __global__ __launch_bounds__(256) void inorm_apply_kernel(const float4* __restrict__ x,
                                                           const float4* __restrict__ mean_rstd,

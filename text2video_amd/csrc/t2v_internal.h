@@ -201,6 +201,8 @@ int launch_inorm_apply_partials(hipStream_t s, const float* x, const float* stat
 int launch_inorm_apply(hipStream_t s, const float* x, const float* mean_rstd, const float* gamma,
                        const float* beta, const float* res1, const float* res2, float* y, long npix, int C,
                        int relu, int nimg = 1);
+int launch_bn_running_update(hipStream_t s, const float* mean_rstd, float* running_mean, float* running_var, long n,
+                             float momentum, float eps, int C);
 int launch_pack_conv_weight(hipStream_t s, const float* w, float* packed, int Cout, int Cin, int KH, int KW,
                             int Cin_s, int Kp, int Cout_p, int adjoint = 0);
 int launch_pack_convT_weight(hipStream_t s, const float* w, float* packed, int Cin, int Cout, int Cin_s, int Cout_p,

@@ -279,6 +279,14 @@ def batch_norm_finalize(stats, desc, batch, eps=1e-5):
     return mr
 
 
+def batch_norm_update_running(mean_rstd, running_mean, running_var, n, momentum=0.1, eps=1e-5):
+    """BatchNorm2d's running statistics, updated in place from a finalize call's (mean, rstd) table over n values per
+    channel ($SP/torch/nn/modules/batchnorm.py:57-64: exponential average with `momentum`, unbiased variance)."""
+    c = context()
+    check(c.lib.t2v_batch_norm_update_running(c.handle, _stream(), _p(mean_rstd), _p(running_mean), _p(running_var), int(n),
+                                              running_mean.numel(), momentum, eps), "batch_norm_update_running")
+
+
 _scratch = {}
 
 

@@ -110,6 +110,32 @@ def flush_pending_weight_gradients(params, grads):
     return out
 
 
+BN_MOMENTUM = 0.1     # nn.BatchNorm2d default ($SP/torch/nn/modules/batchnorm.py:16)
+
+
+def running_stats(gamma, create=True):
+    """[running_mean, running_var, num_batches_tracked] of the BatchNorm2d whose weight is `gamma` (kept on the parameter
+    object; created at torch's initial values 0 / 1 / 0)."""
+    owner = getattr(gamma, "_t2v_owner", gamma)
+    rs = getattr(owner, "_t2v_running", None)
+    if rs is None and create:
+        rs = [torch.zeros(owner.numel(), dtype=torch.float32, device=owner.device),
+              torch.ones(owner.numel(), dtype=torch.float32, device=owner.device), 0]
+        owner._t2v_running = rs
+    return rs
+
+
+def track_running_stats(gamma, mean_rstd, n):
+    """Every training-mode forward of a BatchNorm2d also moves its running statistics
+    ($SP/torch/nn/modules/batchnorm.py:57-64, momentum 0.1, unbiased variance) -- never read on this path (upstream
+    keeps the generator in train mode at test time) but part of a faithful checkpoint.  T2V_BN_RUNNING=0: off."""
+    if gamma is None or n < 2 or os.environ.get("T2V_BN_RUNNING", "1") == "0":
+        return
+    rs = running_stats(gamma)
+    ops.batch_norm_update_running(mean_rstd, rs[0], rs[1], n, BN_MOMENTUM)
+    rs[2] += 1
+
+
 _ZEROS = {}
 
 
@@ -172,11 +198,13 @@ class _ConvBlock(torch.autograd.Function):
             if norm == "batch":
                 mrs = [ops.batch_norm_finalize(stats, fdesc, B)]
                 ops.instance_norm_apply(c, mrs[0], g, bt, res1=rs, relu=relu, out=y)
+                track_running_stats(gamma, mrs[0], B * ho * wo)
             else:
                 mrs = []
                 for i in range(B):
                     mrs.append(ops.instance_norm_finalize(stats[i * n:(i + 1) * n], fdesc))
                     ops.instance_norm_apply(c[i], mrs[i], g, bt, res1=rs[i] if rs is not None else None, relu=relu, out=y[i])
+                    track_running_stats(gamma, mrs[i], ho * wo)      # BatchNorm2d(train) on a batch of one
             if rs is not None:
                 res = None
         if res is not None:
@@ -1073,6 +1101,12 @@ class Vid2VidTrainer:
                         continue
                     p.copy_(sd[k].to(p.device, torch.float32))
                     p._t2v_packs = None
+                    if k.endswith(".weight") and p.dim() == 1 and k[:-len("weight")] + "running_mean" in sd:
+                        base = k[:-len("weight")]
+                        nbt = sd.get(base + "num_batches_tracked")
+                        p._t2v_running = [sd[base + "running_mean"].to(p.device, torch.float32).clone(),
+                                          sd[base + "running_var"].to(p.device, torch.float32).clone(),
+                                          int(nbt) if nbt is not None else 0]
 
     def save(self, epoch_label, progress=None):
         """progress = (epoch, samples done in it): written to iter.txt beside the nets every time `latest` is saved, so
@@ -1088,16 +1122,17 @@ class Vid2VidTrainer:
             0.4.1's module carries ($SP/torch/nn/modules/batchnorm.py: running_mean, running_var, num_batches_tracked)
             so that the file also loads strictly into the reference's own modules.  The norm layers run on batch
             statistics in training AND at test time, so the running statistics are never read: they are
-            written at their initial values, with the step count."""
+            tracked all the same (track_running_stats: momentum 0.1, unbiased variance, one update per forward) and
+            written as they stand."""
             sd = {}
-            steps = max(self.optG.steps + self.optD.steps + [0])
             for k, v in net.named_upstream_parameters().items():
                 sd[k] = v.detach().cpu()
                 if k.endswith(".weight") and v.dim() == 1 and self.opt.norm == "batch":
                     base = k[:-len("weight")]
-                    sd[base + "running_mean"] = torch.zeros(v.numel())
-                    sd[base + "running_var"] = torch.ones(v.numel())
-                    sd[base + "num_batches_tracked"] = torch.tensor(steps, dtype=torch.long)
+                    rs = running_stats(v)
+                    sd[base + "running_mean"] = rs[0].detach().cpu()
+                    sd[base + "running_var"] = rs[1].detach().cpu()
+                    sd[base + "num_batches_tracked"] = torch.tensor(rs[2], dtype=torch.long)
             return sd
 
         torch.save(state_dict(self.G), os.path.join(d, "%s_net_G0.pth" % epoch_label))
