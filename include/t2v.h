@@ -213,6 +213,19 @@ int t2v_conv2d_backward_weight_winograd_stages(t2v_ctx* ctx, void* stream, const
 
 int t2v_conv_unpack_weight(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, int x_cs, const float* packed_dev,
                            float* w_torch_dev);
+/* unpack_weight with a destination that may already hold a gradient: accumulate != 0 adds (w_torch += unpacked).  The
+ * backward nodes of a layer used several times per step deliver straight into the parameter's slice of a flat
+ * exchange bucket: the first writes, the later ones add -- what autograd's AccumulateGrad would do with an extra pass. */
+int t2v_conv_unpack_weight_into(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, int x_cs, const float* packed_dev,
+                                float* w_torch_dev, int accumulate);
+/* dst = src (overwrite != 0) or dst += src; x *= s; zero-fill: the small-tensor ends of the gradient path (bias / affine
+ * gradients into their bucket slice, averaging a summed bucket where the collective cannot, clearing the slice of a
+ * parameter no backward node reached).  Replace ATen's add / mul / fill on the product path. */
+int t2v_accumulate(t2v_ctx* ctx, void* stream, float* dst, const float* src, long n, int overwrite);
+int t2v_scale(t2v_ctx* ctx, void* stream, float* x, long n, float s);
+int t2v_zero(t2v_ctx* ctx, void* stream, void* ptr, size_t bytes);
+/* src [C][2] (t2v_instance_norm_backward's dbeta_dgamma) -> dst0[c] (+)= src[c][0], dst1[c] (+)= src[c][1] */
+int t2v_unzip2(t2v_ctx* ctx, void* stream, const float* src, float* dst0, float* dst1, int C, int overwrite);
 int t2v_channel_sum(t2v_ctx* ctx, void* stream, const float* x, long npix, int C, int cs,
                     float* scratch /* >= 256*C floats */, float* out);
 /* adjoint of ReflectionPad2d(pad): dxp [H+2pad][W+2pad][C] -> dx [H][W][C]  (SpatialReflectionPadding_updateGradInput) */

@@ -247,3 +247,67 @@ def test_plan_units_rules():
     plan = plan_units({"a": 10, "b": 10}, 2, 3, False, 11)
     assert sorted(u for p in plan for u in p) == [("a", 0, 10, 2), ("b", 0, 5, 2)]
     assert plan_units({"a": 10, "b": 10}, 2, 3, False, 8) == [[("a", 0, 10, 2)], []]
+
+
+def _buckets_worker(rank, world, port, tmpdir, rs_ag):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), T2V_GRAD_RS_AG="1" if rs_ag else "0")
+    from text2video_amd import distributed as D
+    from text2video_amd import train as T
+    D.init_from_env("gloo")
+    params = [torch.nn.Parameter(torch.zeros(n)) for n in (6, 70000, 3, 1 << 18, 17, 40)]
+    gb = T.GradBuckets(params, bucket_mb=0.5)
+    assert len(gb.bounds) >= 3 and all((hi - lo) % (256 * world) == 0 for lo, hi in gb.bounds)
+    # static layout: reverse parameter order, every slot a view of the one flat buffer
+    assert gb.members[0][0] == len(params) - 1
+    for p, sl in zip(params, gb.slots):
+        assert sl.view.shape == p.shape and sl.view.untyped_storage().data_ptr() == gb.flat.untyped_storage().data_ptr()
+    for step in range(2):          # the buffers persist across steps
+        gb.begin_step()
+        uses = [1, 2, 1, 3, 1, 0]  # backward nodes per parameter this step (the last one: never reached)
+        for p, u in zip(params, uses):
+            for _ in range(u):
+                T.expect_gradient(p)
+        gb.seal()                  # forward over: parameters without a pending node do not hold their bucket back
+        launched_before = gb._launched
+        # "backward": last parameters first; a bucket goes out as soon as all of its parameters are complete
+        for i in reversed(range(len(params))):
+            for k in range(uses[i]):
+                T.deliver(T.grad_slot(params[i]), torch.full_like(params[i], float(rank + 1) * (i + 1) + k + step))
+        assert launched_before == 0 and gb._launched >= 1          # collectives started from inside the "backward pass"
+        gb.absorb([None] * len(params))
+        nbytes = gb.finish()
+        assert nbytes == 4 * sum(p.numel() for p in params)
+        for i, p in enumerate(params):
+            if uses[i] == 0:
+                assert p.grad is None
+                continue
+            want = sum(1.5 * (i + 1) + k + step for k in range(uses[i]))      # mean over ranks of the node sum
+            assert p.grad.data_ptr() == gb.slots[i].view.data_ptr()            # the gradient IS the bucket slice
+            assert torch.allclose(p.grad, torch.full_like(p, want)), (i, float(p.grad.view(-1)[0]), want)
+        T.check_presence_across_ranks([gb], "cpu")
+    # ranks that disagree on which parameters have gradients are caught
+    gb.begin_step()
+    for i, p in enumerate(params[:2 + rank]):
+        T.expect_gradient(p)
+    gb.seal()
+    for i, p in enumerate(params[:2 + rank]):
+        T.deliver(T.grad_slot(p), torch.ones_like(p))
+    gb.absorb([None] * len(params))
+    gb.finish()
+    try:
+        T.check_presence_across_ranks([gb], "cpu")
+        raised = False
+    except RuntimeError as e:
+        raised = "disagree" in str(e)
+    assert raised
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("rs_ag", [False, True], ids=["all_reduce", "reduce_scatter_all_gather"])
+def test_two_rank_gloo_grad_buckets_deliver_launch_in_order_and_average(tmp_path, rs_ag):
+    """GradBuckets: persistent flat buckets, gradients delivered in place by the backward nodes, a bucket's collective
+    launched when its last gradient lands (in bucket order), all-reduce or reduce-scatter + all-gather, the result
+    averaged over the ranks and handed to the optimiser as views; and the guard against ranks whose gradient sets differ."""
+    mp.spawn(_buckets_worker, args=(2, _free_port(), str(tmp_path), rs_ag), nprocs=2, join=True)

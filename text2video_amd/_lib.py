@@ -79,6 +79,11 @@ SIGNATURES = {
     "t2v_conv2d_backward_weight": (c_int, [c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_void_p, c_int, c_void_p,
                                            c_int, c_void_p, c_int, c_void_p]),
     "t2v_conv_unpack_weight": (c_int, [c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_void_p, c_void_p]),
+    "t2v_conv_unpack_weight_into": (c_int, [c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_void_p, c_void_p, c_int]),
+    "t2v_accumulate": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int]),
+    "t2v_scale": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_float]),
+    "t2v_zero": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),
+    "t2v_unzip2": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int]),
     "t2v_channel_sum": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_void_p, c_void_p]),
     "t2v_reflect_pad_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int]),
     "t2v_instance_norm_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,

@@ -664,16 +664,37 @@ int t2v_conv2d_backward_weight_winograd(t2v_ctx* ctx, void* stream, const t2v_co
                                                       accumulate, workspace, 3);
 }
 
-int t2v_conv_unpack_weight(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, int x_cs, const float* packed_dev,
-                           float* w_torch_dev) {
+int t2v_conv_unpack_weight_into(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, int x_cs, const float* packed_dev,
+                                float* w_torch_dev, int accumulate) {
     T2V_REQUIRE(ctx && packed_dev && w_torch_dev, "unpack_weight: null pointer");
     ConvPlan pl;
     T2V_TRY(build_conv_plan(d, x_cs, false, &pl));
     if (!d->transposed)
         return launch_unpack_conv_weight((hipStream_t)stream, packed_dev, w_torch_dev, d->Cout, d->Cin, d->kH, d->kW, x_cs,
-                                         pl.kp.ph[0].Kp);
+                                         pl.kp.ph[0].Kp, accumulate);
     return launch_unpack_convT_weight((hipStream_t)stream, packed_dev, w_torch_dev, d->Cin, d->Cout, x_cs, pl.Cout_p,
-                                      d->kH, d->pad);
+                                      d->kH, d->pad, accumulate);
+}
+int t2v_conv_unpack_weight(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, int x_cs, const float* packed_dev,
+                           float* w_torch_dev) {
+    return t2v_conv_unpack_weight_into(ctx, stream, d, x_cs, packed_dev, w_torch_dev, 0);
+}
+int t2v_accumulate(t2v_ctx* ctx, void* stream, float* dst, const float* src, long n, int overwrite) {
+    T2V_REQUIRE(ctx && dst && src && n > 0, "accumulate: bad arguments");
+    return launch_accumulate((hipStream_t)stream, dst, src, n, overwrite);
+}
+int t2v_scale(t2v_ctx* ctx, void* stream, float* x, long n, float s) {
+    T2V_REQUIRE(ctx && x && n > 0, "scale: bad arguments");
+    return launch_scale((hipStream_t)stream, x, n, s);
+}
+int t2v_unzip2(t2v_ctx* ctx, void* stream, const float* src, float* dst0, float* dst1, int C, int overwrite) {
+    T2V_REQUIRE(ctx && src && dst0 && dst1 && C > 0, "unzip2: bad arguments");
+    return launch_unzip2((hipStream_t)stream, src, dst0, dst1, C, overwrite);
+}
+int t2v_zero(t2v_ctx* ctx, void* stream, void* ptr, size_t bytes) {
+    T2V_REQUIRE(ctx && ptr, "zero: null pointer");
+    T2V_HIP_CHECK(hipMemsetAsync(ptr, 0, bytes, (hipStream_t)stream));
+    return T2V_OK;
 }
 
 int t2v_channel_sum(t2v_ctx* ctx, void* stream, const float* x, long npix, int C, int cs, float* scratch, float* out) {

@@ -978,7 +978,7 @@ int launch_loss_backward(hipStream_t s, int op, const float* a, const float* b, 
 
 // inverse of the packers (checkpoint save, gradient export): packed -> torch layout
 __global__ void unpack_conv_weight_kernel(const float* __restrict__ packed, float* __restrict__ w, int Cout, int Cin,
-                                          int KH, int KW, int Cin_s, int Kp, long total) {
+                                          int KH, int KW, int Cin_s, int Kp, long total, int accumulate) {
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
         long t = i;
@@ -986,19 +986,20 @@ __global__ void unpack_conv_weight_kernel(const float* __restrict__ packed, floa
         const int kh = (int)(t % KH); t /= KH;
         const int c = (int)(t % Cin); t /= Cin;
         const int n = (int)t;
-        w[i] = packed[(size_t)n * Kp + (kh * KW + kw) * Cin_s + c];
+        const float v = packed[(size_t)n * Kp + (kh * KW + kw) * Cin_s + c];
+        w[i] = accumulate ? w[i] + v : v;
     }
 }
 int launch_unpack_conv_weight(hipStream_t s, const float* packed, float* w, int Cout, int Cin, int KH, int KW, int Cin_s,
-                              int Kp) {
+                              int Kp, int accumulate) {
     const long total = (long)Cout * Cin * KH * KW;
     hipLaunchKernelGGL(unpack_conv_weight_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, packed, w, Cout, Cin, KH,
-                       KW, Cin_s, Kp, total);
+                       KW, Cin_s, Kp, total, accumulate);
     T2V_HIP_CHECK(hipGetLastError());
     return T2V_OK;
 }
 __global__ void unpack_convT_weight_kernel(const float* __restrict__ packed, float* __restrict__ w, int Cin, int Cout,
-                                           int Cout_p, int Cin_s, int K, int pad, long total) {
+                                           int Cout_p, int Cin_s, int K, int pad, long total, int accumulate) {
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
         long t = i;
@@ -1017,14 +1018,51 @@ __global__ void unpack_convT_weight_kernel(const float* __restrict__ packed, flo
                 if (pkh[q] == kh && pkw[q] == kw) v = packed[off + (size_t)n * Kq + q * Cin_s + c];
             off += (long)Cout_p * Kq;
         }
-        w[i] = v;
+        w[i] = accumulate ? w[i] + v : v;
     }
 }
 int launch_unpack_convT_weight(hipStream_t s, const float* packed, float* w, int Cin, int Cout, int Cin_s, int Cout_p,
-                               int K, int pad) {
+                               int K, int pad, int accumulate) {
     const long total = (long)Cin * Cout * K * K;
     hipLaunchKernelGGL(unpack_convT_weight_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, packed, w, Cin, Cout,
-                       Cout_p, Cin_s, K, pad, total);
+                       Cout_p, Cin_s, K, pad, total, accumulate);
+    T2V_HIP_CHECK(hipGetLastError());
+    return T2V_OK;
+}
+
+// dst = src (overwrite) or dst += src; x *= s -- the small-tensor ends of the gradient path (bias / affine gradients
+// landing in their slice of a flat exchange bucket, averaging a summed bucket)
+__global__ void accumulate_kernel(float* __restrict__ dst, const float* __restrict__ src, long n, int overwrite) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = overwrite ? src[i] : dst[i] + src[i];
+}
+int launch_accumulate(hipStream_t s, float* dst, const float* src, long n, int overwrite) {
+    hipLaunchKernelGGL(accumulate_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, dst, src, n, overwrite);
+    T2V_HIP_CHECK(hipGetLastError());
+    return T2V_OK;
+}
+// src [C][2] -> dst0[c] (+)= src[c][0], dst1[c] (+)= src[c][1]: the (sum g, sum g*xhat) pairs of the norm backward into
+// the bias / weight gradient slots of the affine parameters
+__global__ void unzip2_kernel(const float2* __restrict__ src, float* __restrict__ dst0, float* __restrict__ dst1, int C,
+                              int overwrite) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float2 v = src[c];
+    dst0[c] = overwrite ? v.x : dst0[c] + v.x;
+    dst1[c] = overwrite ? v.y : dst1[c] + v.y;
+}
+int launch_unzip2(hipStream_t s, const float* src, float* dst0, float* dst1, int C, int overwrite) {
+    hipLaunchKernelGGL(unzip2_kernel, dim3((C + 255) / 256), dim3(256), 0, s, reinterpret_cast<const float2*>(src), dst0, dst1,
+                       C, overwrite);
+    T2V_HIP_CHECK(hipGetLastError());
+    return T2V_OK;
+}
+__global__ void scale_kernel(float* __restrict__ x, long n, float sc) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) x[i] *= sc;
+}
+int launch_scale(hipStream_t s, float* x, long n, float sc) {
+    hipLaunchKernelGGL(scale_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, x, n, sc);
     T2V_HIP_CHECK(hipGetLastError());
     return T2V_OK;
 }

@@ -106,9 +106,12 @@ struct WgradParams {
 int launch_conv_wgrad(hipStream_t s, const WgradParams& p);
 int launch_wgrad_reduce(hipStream_t s, const float* partial, int splits, long n, float* dw, int accumulate);
 int launch_unpack_conv_weight(hipStream_t s, const float* packed, float* w, int Cout, int Cin, int KH, int KW, int Cin_s,
-                              int Kp);
+                              int Kp, int accumulate = 0);
 int launch_unpack_convT_weight(hipStream_t s, const float* packed, float* w, int Cin, int Cout, int Cin_s, int Cout_p,
-                               int K, int pad);
+                               int K, int pad, int accumulate = 0);
+int launch_accumulate(hipStream_t s, float* dst, const float* src, long n, int overwrite);
+int launch_scale(hipStream_t s, float* x, long n, float sc);
+int launch_unzip2(hipStream_t s, const float* src, float* dst0, float* dst1, int C, int overwrite);
 int launch_pad_copy(hipStream_t s, const float* x, float* xp, int batch, int H, int W, int C, int pad, int reflect);
 int launch_reflect_pad_backward(hipStream_t s, const float* dxp, float* dx, int H, int W, int C, int p);
 int launch_inorm_backward(hipStream_t s, const float* x, const float* dy, const float* mean_rstd, const float* gamma,

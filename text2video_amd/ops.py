@@ -372,7 +372,7 @@ def backward_weight_winograd_supported(desc, x_cs, dy_cs):
     return bool(_lib.load().t2v_conv_backward_weight_winograd_supported(ctypes.byref(desc), x_cs, dy_cs))
 
 
-def conv2d_backward_weight_winograd(x, dy, desc, accumulate_into=None):
+def conv2d_backward_weight_winograd(x, dy, desc, accumulate_into=None, out=None):
     """Weight gradient of a 3x3 stride-1 conv through the Winograd domain (F(4x4,3x3)), TORCH layout
     [Cout,Cin,3,3].  x: [B,H,W,Cin], dy: [B,Ho,Wo,Cout] (or 3-D, B=1)."""
     c = context()
@@ -381,7 +381,7 @@ def conv2d_backward_weight_winograd(x, dy, desc, accumulate_into=None):
     _chk(x, "x")
     _chk(dy, "dy")
     B, x_cs, dy_cs = x.shape[0], x.shape[-1], dy.shape[-1]
-    dw = accumulate_into if accumulate_into is not None else \
+    dw = accumulate_into if accumulate_into is not None else out if out is not None else \
         torch.empty(desc.Cout, desc.Cin, 3, 3, dtype=torch.float32, device=x.device)
     nws = c.lib.t2v_conv_backward_weight_winograd_workspace_floats(ctypes.byref(desc), x_cs, B)
     if nws == 0:
@@ -400,7 +400,7 @@ def backward_weight_winograd_workspace(desc, x_cs, batch, device):
     return torch.empty(n, dtype=torch.float32, device=device)
 
 
-def conv2d_backward_weight_winograd_stages(x, dy, desc, ws, batch, b0, reduce):
+def conv2d_backward_weight_winograd_stages(x, dy, desc, ws, batch, b0, reduce, out=None, accumulate=False):
     """Staged form: transform the images x, dy ([nb,H,W,C] / [nb,Ho,Wo,Cout]) into slots [b0, b0+nb) of `ws`
     (backward_weight_winograd_workspace(desc, x_cs, batch)); with reduce=True also run the reduction over all
     `batch` slots and return dW in torch layout, else return None."""
@@ -409,20 +409,23 @@ def conv2d_backward_weight_winograd_stages(x, dy, desc, ws, batch, b0, reduce):
         x, dy = x.unsqueeze(0), dy.unsqueeze(0)
     _chk(x, "x")
     _chk(dy, "dy")
-    dw = torch.empty(desc.Cout, desc.Cin, 3, 3, dtype=torch.float32, device=x.device) if reduce else None
+    dw = (out if out is not None else torch.empty(desc.Cout, desc.Cin, 3, 3, dtype=torch.float32, device=x.device)) \
+        if reduce else None
     check(c.lib.t2v_conv2d_backward_weight_winograd_stages(c.handle, _stream(), ctypes.byref(desc), batch, b0, x.shape[0],
-                                                           _p(x), x.shape[-1], _p(dy), dy.shape[-1], _p(dw), 0, _p(ws),
+                                                           _p(x), x.shape[-1], _p(dy), dy.shape[-1], _p(dw),
+                                                           int(bool(accumulate and out is not None)), _p(ws),
                                                            3 if reduce else 1),
           "conv2d_backward_weight_winograd_stages")
     return dw
 
 
-def conv2d_backward_weight_winograd_reduce(desc, ws, batch, x_cs, dy_cs):
+def conv2d_backward_weight_winograd_reduce(desc, ws, batch, x_cs, dy_cs, out=None, accumulate=False):
     """Reduction stage alone over the `batch` slots already transformed into `ws` -> dW in torch layout."""
     c = context()
-    dw = torch.empty(desc.Cout, desc.Cin, 3, 3, dtype=torch.float32, device=ws.device)
+    dw = out if out is not None else torch.empty(desc.Cout, desc.Cin, 3, 3, dtype=torch.float32, device=ws.device)
     check(c.lib.t2v_conv2d_backward_weight_winograd_stages(c.handle, _stream(), ctypes.byref(desc), batch, 0, 0, None, x_cs,
-                                                           None, dy_cs, _p(dw), 0, _p(ws), 2),
+                                                           None, dy_cs, _p(dw), int(bool(accumulate and out is not None)),
+                                                           _p(ws), 2),
           "conv2d_backward_weight_winograd_stages")
     return dw
 
@@ -465,13 +468,50 @@ def unpack_conv_weight(packed, desc, x_cs=None):
     return w
 
 
-def channel_sum(x, C=None):
+def unpack_conv_weight_into(packed, desc, x_cs, out, accumulate):
+    """packed layout -> torch layout written (or added, accumulate=True) into `out`: a contiguous tensor of the weight's
+    torch shape, e.g. the parameter's slice of a flat gradient bucket."""
+    c = context()
+    check(c.lib.t2v_conv_unpack_weight_into(c.handle, _stream(), ctypes.byref(desc), x_cs, _p(packed), _p(out), int(accumulate)),
+          "conv_unpack_weight_into")
+    return out
+
+
+def accumulate_(dst, src, overwrite=False):
+    """dst = src (overwrite) or dst += src, in place on contiguous fp32 tensors of equal size."""
+    c = context()
+    assert dst.numel() == src.numel() and dst.is_contiguous() and src.is_contiguous()
+    check(c.lib.t2v_accumulate(c.handle, _stream(), _p(dst), _p(src), dst.numel(), int(overwrite)), "accumulate")
+    return dst
+
+
+def unzip2_(src, dst0, dst1, overwrite=False):
+    """src [C,2] -> dst0 (+)= src[:,0], dst1 (+)= src[:,1]"""
+    c = context()
+    check(c.lib.t2v_unzip2(c.handle, _stream(), _p(src), _p(dst0), _p(dst1), dst0.numel(), int(overwrite)), "unzip2")
+
+
+def scale_(x, s):
+    c = context()
+    assert x.is_contiguous()
+    check(c.lib.t2v_scale(c.handle, _stream(), _p(x), x.numel(), float(s)), "scale")
+    return x
+
+
+def zero_(x):
+    c = context()
+    assert x.is_contiguous()
+    check(c.lib.t2v_zero(c.handle, _stream(), _p(x), x.numel() * x.element_size()), "zero")
+    return x
+
+
+def channel_sum(x, C=None, out=None):
     """sum over all pixels per channel of an NHWC tensor (bias gradient)."""
     c = context()
     _chk(x, "x")
     cs = x.shape[-1]
     C = cs if C is None else C
-    out = torch.empty(C, dtype=torch.float32, device=x.device)
+    out = torch.empty(C, dtype=torch.float32, device=x.device) if out is None else out
     scratch = torch.empty(256 * C, dtype=torch.float32, device=x.device)
     check(c.lib.t2v_channel_sum(c.handle, _stream(), _p(x), x.numel() // cs, C, cs, _p(scratch), _p(out)),
           "channel_sum")

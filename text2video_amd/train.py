@@ -46,6 +46,46 @@ def cached_pack(w, key, make):
     return ent[1][key]
 
 
+# ------------------------------------------------------------------------------------------------
+# gradient slots: every trainable parameter owns a slice ("slot") of a persistent flat exchange bucket
+# (GradBuckets below).  Inside a train step the backward nodes DELIVER their weight / bias / affine gradients
+# straight into the slot -- the first node of a step writes, later nodes of the same parameter add (kernels with
+# an accumulate flag) -- and return None to autograd: no AccumulateGrad adds, no torch.cat / copy-back around the
+# collective, and a bucket's all-reduce starts the moment its last gradient has landed.
+# ------------------------------------------------------------------------------------------------
+class GradSlot:
+    __slots__ = ("owner", "bucket", "idx", "view", "expect", "got", "filled")
+
+    def __init__(self, owner, bucket, idx, view):
+        self.owner, self.bucket, self.idx, self.view = owner, bucket, idx, view
+        self.expect = self.got = 0
+        self.filled = False       # the slot holds this step's (partial) gradient
+
+
+def grad_slot(p):
+    """the slot of parameter `p` if its buckets are collecting (inside a train step), else None"""
+    sl = getattr(p, "_t2v_gslot", None)
+    return sl if (sl is not None and sl.owner.collecting) else None
+
+
+def expect_gradient(p):
+    """forward side: one more backward node will deliver a gradient for `p` in this step"""
+    sl = grad_slot(p) if p is not None and p.requires_grad else None
+    if sl is not None:
+        sl.expect += 1
+
+
+def deliver(sl, tensor=None, zero=False):
+    """backward side: add `tensor` (or nothing / an exact zero) to slot `sl` and count the node as done"""
+    if tensor is not None:
+        _acc(sl.view, tensor, not sl.filled)
+        sl.filled = True
+    elif zero and not sl.filled:
+        _zero(sl.view)
+        sl.filled = True
+    sl.owner.node_done(sl)
+
+
 _WG_BATCH = [False]
 
 
@@ -63,13 +103,19 @@ def batched_weight_gradients(params):
         _WG_BATCH[0] = False
 
 
-def _batched_winograd_wgrad(w, x, dc, fdesc):
+def _batched_winograd_wgrad(w, x, dc, fdesc, slot=None):
     """Weight gradient of one use of a layer whose forward counted `w._t2v_wg_images` images in this graph: the
     images are transformed into their slots of a workspace kept on the weight; the node that brings the last ones
     runs the single reduction over all of them and returns dW, the earlier ones return None (a zero gradient --
     autograd sums the nodes' results).  One K = images x tiles reduction instead of one short one per frame."""
     total = getattr(w, "_t2v_wg_images", 0)
     if total < x.shape[0]:     # no count on this object: reduce on the spot
+        if slot is not None:
+            ops.conv2d_backward_weight_winograd(x, dc, fdesc, accumulate_into=slot.view if slot.filled else None,
+                                                out=slot.view)
+            slot.filled = True
+            slot.owner.node_done(slot)
+            return None
         return ops.conv2d_backward_weight_winograd(x, dc, fdesc)
     st = getattr(w, "_t2v_wg_state", None)
     if st is None:
@@ -79,11 +125,19 @@ def _batched_winograd_wgrad(w, x, dc, fdesc):
     assert st[2] == _desc_key(fdesc, x.shape[-1]), "one layer, two geometries in one step: set T2V_WGRAD_BATCH=0"
     ws, done = st[0], st[1]
     last = done + x.shape[0] == total
-    dw = ops.conv2d_backward_weight_winograd_stages(x, dc, fdesc, ws, total, done, last)
+    if slot is not None:     # the reduction writes (adds to) the parameter's bucket slot; every node counts as delivered
+        ops.conv2d_backward_weight_winograd_stages(x, dc, fdesc, ws, total, done, last, out=slot.view, accumulate=slot.filled)
+        dw = None
+        if last:
+            slot.filled = True
+    else:
+        dw = ops.conv2d_backward_weight_winograd_stages(x, dc, fdesc, ws, total, done, last)
     if last:
         w._t2v_wg_state, w._t2v_wg_images = None, 0
     else:
         st[1] = done + x.shape[0]
+    if slot is not None:
+        slot.owner.node_done(slot)
     return dw
 
 
@@ -104,8 +158,13 @@ def flush_pending_weight_gradients(params, grads):
             cout_p, kp = ops.round_up(fdesc.Cout, 128), ops.round_up(xcs, 32)
             tp = (ws.numel() - 36 * cout_p * kp) // (36 * total * (xcs + fdesc.Cout))
             ws[:36 * total * tp * xcs].view(36, total, tp * xcs)[:, done:].zero_()
-            dw = ops.conv2d_backward_weight_winograd_reduce(fdesc, ws, total, xcs, dycs)
-            out[i] = dw if out[i] is None else out[i] + dw
+            sl = grad_slot(p)
+            if sl is not None:
+                ops.conv2d_backward_weight_winograd_reduce(fdesc, ws, total, xcs, dycs, out=sl.view, accumulate=sl.filled)
+                sl.filled = True
+            else:
+                dw = ops.conv2d_backward_weight_winograd_reduce(fdesc, ws, total, xcs, dycs)
+                out[i] = dw if out[i] is None else out[i] + dw
         p._t2v_wg_state, p._t2v_wg_images = None, 0
     return out
 
@@ -217,6 +276,8 @@ class _ConvBlock(torch.autograd.Function):
         if wino_wgrad and w.requires_grad and _WG_BATCH[0]:
             w._t2v_wg_images = getattr(w, "_t2v_wg_images", 0) + B
             wino_wgrad = 2
+        for prm in (w, b, gamma, beta):
+            expect_gradient(prm)
         ctx.meta = (desc, ddesc, norm, relu, act, need_dx, mrs, gamma is not None, wino_wgrad, slope)
         ctx.save_for_backward(x, w, c, gamma, beta, y if (norm is None and act != ops.ACT_NONE) else None)
         return y
@@ -228,34 +289,76 @@ class _ConvBlock(torch.autograd.Function):
         dy = dy.contiguous()
         B = x.shape[0]
         dgamma = dbeta = None
+        # parameters with a bucket slot get their gradients delivered in place (and None goes back to autograd)
+        sl_w = grad_slot(w) if ctx.needs_input_grad[1] else None
+        sl_b = grad_slot(b) if ctx.needs_input_grad[2] else None
+        sl_g = grad_slot(gamma) if (affine and ctx.needs_input_grad[3]) else None
+        sl_bt = grad_slot(beta) if (affine and ctx.needs_input_grad[4]) else None
+        both = sl_g is not None and sl_bt is not None
+
+        def affine_sums(sums):       # [C,2] = (sum g, sum g*xhat) -> d beta, d gamma
+            nonlocal dbeta, dgamma
+            if both:
+                ops.unzip2_(sums, sl_bt.view, sl_g.view, overwrite=not sl_g.filled)
+                sl_g.filled = sl_bt.filled = True
+            else:
+                db_, dg_ = sums.t().contiguous().unbind(0)
+                dbeta = db_ if dbeta is None else dbeta + db_
+                dgamma = dg_ if dgamma is None else dgamma + dg_
+
         if norm is None:
             # (act_backward's mode 2 is a plain sigmoid; the fused flow / weight head is its mode 4)
             dc = ops.act_backward(dy, y_act, 4 if act == ops.ACT_FLOW_W else act, slope) if act != ops.ACT_NONE else dy
         elif norm == "batch":
             dc, sums = ops.instance_norm_backward(c, dy, mrs[0], gamma, beta, relu)
             if affine:
-                dbeta, dgamma = sums.t().contiguous().unbind(0)
+                affine_sums(sums)
         else:
             dc = torch.empty_like(c)
-            tot = None
             for i in range(B):
                 _, s_i = ops.instance_norm_backward(c[i], dy[i], mrs[i], gamma, beta, relu, out=dc[i])
-                tot = s_i if tot is None else tot + s_i
-            if affine:
-                dbeta, dgamma = tot.t().contiguous().unbind(0)
+                if affine:
+                    affine_sums(s_i)
+        if both:
+            sl_g.owner.node_done(sl_g)
+            sl_bt.owner.node_done(sl_bt)
         # a bias in front of a norm layer has an exactly zero gradient (the norm removes the channel mean)
         db = None
         if ctx.needs_input_grad[2]:
-            db = ops.channel_sum(dc, desc.Cout) if norm is None else _zeros(desc.Cout, x.device)
+            if sl_b is not None:
+                if norm is None:
+                    if sl_b.filled:
+                        deliver(sl_b, ops.channel_sum(dc, desc.Cout))
+                    else:
+                        ops.channel_sum(dc, desc.Cout, out=sl_b.view)
+                        sl_b.filled = True
+                        sl_b.owner.node_done(sl_b)
+                else:
+                    deliver(sl_b, zero=True)
+            else:
+                db = ops.channel_sum(dc, desc.Cout) if norm is None else _zeros(desc.Cout, x.device)
         if not ctx.needs_input_grad[1]:      # frozen weights (the VGG19 feature extractor): data gradient only
             dw = None
         elif wino_wgrad == 2:
-            dw = _batched_winograd_wgrad(w, x, dc, fdesc)
+            dw = _batched_winograd_wgrad(w, x, dc, fdesc, sl_w)
         elif wino_wgrad:
-            dw = ops.conv2d_backward_weight_winograd(x, dc, fdesc)
+            if sl_w is not None:
+                ops.conv2d_backward_weight_winograd(x, dc, fdesc, accumulate_into=sl_w.view if sl_w.filled else None,
+                                                    out=sl_w.view)
+                sl_w.filled = True
+                sl_w.owner.node_done(sl_w)
+                dw = None
+            else:
+                dw = ops.conv2d_backward_weight_winograd(x, dc, fdesc)
         else:
             dwp = ops.conv2d_backward_weight(x, dc, fdesc)
-            dw = ops.unpack_conv_weight(dwp, fdesc, x.shape[-1])
+            if sl_w is not None:
+                ops.unpack_conv_weight_into(dwp, fdesc, x.shape[-1], sl_w.view, sl_w.filled)
+                sl_w.filled = True
+                sl_w.owner.node_done(sl_w)
+                dw = None
+            else:
+                dw = ops.unpack_conv_weight(dwp, fdesc, x.shape[-1])
         dx = None
         if need_dx:
             dg = ConvDataGrad(fdesc)
@@ -268,6 +371,34 @@ class _ConvBlock(torch.autograd.Function):
                 dx = torch.zeros_like(x)
                 dx[..., :ops.round_up(fdesc.Cin, 4)] = torch.stack([dg(dc[i]) for i in range(B)])
         return dx, dw, db, dgamma, dbeta, (dy if ctx.needs_input_grad[5] else None), None, None, None, None, None, None
+
+
+class _CatParams(torch.autograd.Function):
+    """torch.cat([a, b], 0) of two parameters (the flow head and the weight head read the same features: one
+    3-output conv).  Backward splits the gradient and delivers the halves into the parameters' bucket slots, like
+    every other node that owns a parameter gradient."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.n = a.shape[0]
+        ctx.save_for_backward(a, b)
+        expect_gradient(a)
+        expect_gradient(b)
+        return torch.cat([a, b], 0)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        ga, gb = g[:ctx.n].contiguous(), g[ctx.n:].contiguous()
+        out = []
+        for p, gp, need in ((a, ga, ctx.needs_input_grad[0]), (b, gb, ctx.needs_input_grad[1])):
+            sl = grad_slot(p) if need else None
+            if sl is not None:
+                deliver(sl, gp)
+                out.append(None)
+            else:
+                out.append(gp if need else None)
+        return tuple(out)
 
 
 def conv_block(x, w, b, desc, gamma=None, beta=None, res=None, norm="instance", relu=1, act=ops.ACT_NONE,
@@ -474,8 +605,8 @@ class TrainableGenerator(torch.nn.Module):
         (kf, kw), _, _ = next(it)
         # model_final_flow (2 outputs, x20) and model_final_w (1 output, sigmoid) read the same features: one
         # 3-output conv, as in the inference path; autograd's cat splits the gradient back onto the two parameters
-        w3 = torch.cat([self.p(kf + ".weight"), self.p(kw + ".weight")], 0)
-        b3 = torch.cat([self.p(kf + ".bias"), self.p(kw + ".bias")], 0)
+        w3 = _CatParams.apply(self.p(kf + ".weight"), self.p(kw + ".weight"))
+        b3 = _CatParams.apply(self.p(kf + ".bias"), self.p(kw + ".bias"))
         fw = conv_block(flow_feat, w3, b3, ops.conv_desc(H, W, G, 3, 7, 1, 3, ops.PAD_REFLECT), norm=None, relu=0,
                         act=ops.ACT_FLOW_W, slope=20.0 * (2 ** s.scale))
         fake = raw if use_raw_only else _WarpComposite.apply(raw, fw, prev, s.prev_nc - 3)
@@ -724,47 +855,219 @@ class FusedAdam:
         self._pending = (grads, torch.cuda.current_stream().record_event())
 
 
-class GradientExchange:
-    """Bucketed gradient all-reduce in flight (`allreduce_gradients_begin`).  Every bucket is one asynchronous
-    collective on the process group's own stream (RCCL over xGMI; gloo on CPU), so the exchange of the
-    generator's gradients (1.13 GB at ngf 128) runs under the discriminators' backward pass; `finish()` waits,
-    averages over the ranks and scatters the buckets back into the .grad tensors."""
+def _acc(dst, src, overwrite):
+    """dst (+)= src on flat views: HIP kernel on device tensors; host tensors only occur in the gloo CPU tests of the
+    bucket bookkeeping (the trainer itself cannot exist without the GPU)"""
+    if dst.is_cuda:
+        ops.accumulate_(dst, src.contiguous().view(-1), overwrite=overwrite)
+    elif overwrite:
+        dst.view(-1).copy_(src.reshape(-1))
+    else:
+        dst.view(-1).add_(src.reshape(-1))
 
-    def __init__(self, params, bucket_mb=64):
+
+def _zero(x):
+    ops.zero_(x) if x.is_cuda else x.zero_()
+
+
+def _scale(x, f):
+    ops.scale_(x, f) if x.is_cuda else x.mul_(f)
+
+
+class GradBuckets:
+    """Persistent flat gradient buckets of one optimiser's parameters + their data-parallel exchange.
+
+    Layout (static, identical on every rank): the parameters in REVERSE order -- backward reaches the last layers
+    first -- packed into buckets of <= bucket_mb; every parameter's gradient lives at a fixed slice of its bucket
+    (`GradSlot.view`, handed to Adam as p.grad).  During a train step the backward nodes deliver into the slots
+    (`deliver` / the accumulate flags of the weight-gradient kernels); when the last expected node of the last
+    parameter of a bucket has delivered, the bucket's collective is launched from inside the backward pass --
+    asynchronously on the process group's stream (RCCL over xGMI; gloo in the single-GPU tests), buckets strictly in
+    index order so that every rank issues the same sequence.  Replaces DataParallel's gradient reduce onto GPU 0 through
+    10 MiB coalesced copies + re-broadcast of the weights ($SP/torch/cuda/comm.py:24,76-86; nn/parallel/_functions.py)
+    and round 2's cat -> all_reduce -> divide -> copy-back (three extra passes over 1.1-1.5 GB per step): the bytes
+    on the wire are the gradients themselves, in place.
+
+    T2V_GRAD_RS_AG=1: reduce-scatter + all-gather per bucket instead of one all-reduce (what a ring all-reduce does
+    internally; lets a sharded optimiser step sit between the two halves later).  T2V_GRAD_BUCKET_MB overrides 64."""
+
+    def __init__(self, params, bucket_mb=None, name=""):
         import torch.distributed as dist
-        self.pending, self.nbytes = [], 0
+        self.params = list(params)
+        self.name = name
+        self.collecting = False
         self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
         # (T2V_TRAIN_FORCE_DIST=1 runs the collectives on a 1-rank group too: the RCCL path on a single GPU)
-        if self.world == 1 and not (os.environ.get("T2V_TRAIN_FORCE_DIST") == "1" and dist.is_available()
-                                    and dist.is_initialized()):
-            return
-        limit = bucket_mb * (1 << 20) // 4
-        bucket, size = [], 0
-        for g in [p.grad for p in params if p.grad is not None]:
-            if size + g.numel() > limit and bucket:
-                self._launch(bucket)
-                bucket, size = [], 0
-            bucket.append(g)
-            size += g.numel()
-        if bucket:
-            self._launch(bucket)
+        self.exchange = self.world > 1 or (os.environ.get("T2V_TRAIN_FORCE_DIST") == "1" and dist.is_available()
+                                            and dist.is_initialized())
+        self.rs_ag = os.environ.get("T2V_GRAD_RS_AG", "0") == "1"
+        if bucket_mb is None:
+            bucket_mb = float(os.environ.get("T2V_GRAD_BUCKET_MB", "64"))
+        limit = max(1, int(bucket_mb * (1 << 20) // 4))
+        pad = 256 * max(1, self.world)     # bucket sizes divisible by the world size (reduce-scatter shards) and 1 KiB
+        order = list(range(len(self.params)))[::-1]
+        bounds, members, off, cur, cur_n = [], [], 0, [], 0
+        for i in order:
+            n = self.params[i].numel()
+            if cur and cur_n + n > limit:
+                size = (cur_n + pad - 1) // pad * pad
+                bounds.append((off, off + size))
+                members.append(cur)
+                off += size
+                cur, cur_n = [], 0
+            cur.append((i, cur_n))
+            cur_n += n
+        if cur:
+            size = (cur_n + pad - 1) // pad * pad
+            bounds.append((off, off + size))
+            members.append(cur)
+            off += size
+        dev = self.params[0].device if self.params else "cpu"
+        self.flat = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.bounds = bounds
+        self.slots = [None] * len(self.params)
+        self.bucket_of = [None] * len(self.params)
+        for bi, mem in enumerate(members):
+            for i, rel in mem:
+                p = self.params[i]
+                view = self.flat[bounds[bi][0] + rel: bounds[bi][0] + rel + p.numel()].view(p.shape)
+                self.slots[i] = GradSlot(self, bi, i, view)
+                p._t2v_gslot = self.slots[i]
+                self.bucket_of[i] = bi
+        self.members = [[i for i, _ in mem] for mem in members]
+        self.nbytes = 0
+        self._works, self._open, self._launched = [], [], 0
 
-    def _launch(self, bucket):
+    # -- one train step -----------------------------------------------------------------------------
+    def begin_step(self):
+        for sl in self.slots:
+            sl.expect = sl.got = 0
+            sl.filled = False
+        self._open = [len(m) for m in self.members]      # parameters of each bucket still waiting for nodes
+        self._done = [False] * len(self.params)
+        self._works, self._launched, self.nbytes = [], 0, 0
+        # T2V_GRAD_DIRECT=0: the backward nodes hand their gradients to autograd as before and absorb() copies the sums
+        # into the slots afterwards (one extra pass, no launch from inside the backward pass): the A/B baseline
+        self.collecting = os.environ.get("T2V_GRAD_DIRECT", "1") != "0"
+
+    def seal(self):
+        """The forward pass is over: parameters no node will deliver to (unused in this step) no longer hold their
+        bucket back."""
+        if not self.collecting:
+            return
+        for sl in self.slots:
+            if sl.expect == 0 and not self._done[sl.idx]:
+                self._done[sl.idx] = True
+                self._open[sl.bucket] -= 1
+        # (nothing is launched here: a launch from the first delivering node keeps the bucket order intact)
+
+    def node_done(self, sl):
+        sl.got += 1
+        if sl.got == sl.expect and not self._done[sl.idx]:
+            self._done[sl.idx] = True
+            self._open[sl.bucket] -= 1
+            self._launch_ready()
+
+    def _launch_ready(self):
+        """launch, in bucket order, every bucket whose parameters have all received their last expected gradient"""
+        while self._launched < len(self.bounds) and self._open[self._launched] == 0:
+            self._launch(self._launched)
+            self._launched += 1
+
+    def _launch(self, b):
+        # parameters no backward node reached contribute exact zeros (and get no optimiser step: see finish)
+        for i in self.members[b]:
+            if not self.slots[i].filled:
+                _zero(self.slots[i].view)
+        if not self.exchange:
+            return
         import torch.distributed as dist
-        flat = torch.cat([g.reshape(-1) for g in bucket])
-        self.pending.append((dist.all_reduce(flat, async_op=True), flat, bucket))
-        self.nbytes += flat.numel() * 4
+        lo, hi = self.bounds[b]
+        buf = self.flat[lo:hi]
+        avg = dist.get_backend() == "nccl"       # RCCL averages in the collective; gloo sums (scaled in finish)
+        op = dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM
+        if self.rs_ag and self.world > 1:
+            shard = (hi - lo) // self.world
+            r = dist.get_rank()
+            mine = buf[r * shard:(r + 1) * shard]
+            if avg:     # RCCL: in-place reduce-scatter (output = this rank's shard of the input), then the all-gather,
+                w1 = dist.reduce_scatter_tensor(mine, buf, op=op, async_op=True)      # both stream-ordered
+                self._works.append((w1, None, None, None))
+                w2 = dist.all_gather_into_tensor(buf, mine, async_op=True)
+                self._works.append((w2, buf, avg, None))
+            else:       # gloo (tests): works are not ordered among themselves -- the all-gather is issued in finish()
+                out = torch.empty_like(mine)
+                w1 = dist.reduce_scatter_tensor(out, buf, op=op, async_op=True)
+                self._works.append((w1, buf, avg, (mine, out)))
+        else:
+            self._works.append((dist.all_reduce(buf, op=op, async_op=True), buf, avg, None))
+        self.nbytes += 4 * sum(self.params[i].numel() for i in self.members[b])     # payload (the padding travels too)
+
+    def absorb(self, grads):
+        """After autograd.grad: gradients that came back as tensors (parameters reached through torch-native plumbing,
+        e.g. the cat of the two flow-head convs; a flushed Winograd reduction) are added into their slots; then every
+        bucket not yet launched goes out, in order."""
+        for i, g in enumerate(grads):
+            if g is not None:
+                sl = self.slots[i]
+                _acc(sl.view, g, not sl.filled)
+                sl.filled = True
+        for b in range(self._launched, len(self.bounds)):
+            self._launch(b)
+        self._launched = len(self.bounds)
+        self.collecting = False
 
     def finish(self):
-        for work, flat, bucket in self.pending:
+        """Wait for the collectives; p.grad = the slot (None where no rank-local node delivered: Adam then skips the
+        parameter, as torch 0.4.1's does).  Returns the bytes exchanged."""
+        import torch.distributed as dist
+        for work, buf, avg, shard in self._works:
             work.wait()
-            flat /= self.world
-            off = 0
-            for g in bucket:
-                g.copy_(flat[off:off + g.numel()].view_as(g))
-                off += g.numel()
-        self.pending = []
+            if shard is not None:
+                shard[0].copy_(shard[1])
+                dist.all_gather_into_tensor(buf, shard[0].clone())
+            if buf is not None and not avg and self.world > 1:
+                _scale(buf, 1.0 / self.world)
+        self._works = []
+        for p, sl in zip(self.params, self.slots):
+            p.grad = sl.view if sl.filled else None
         return self.nbytes
+
+    def presence(self):
+        """a checksum of WHICH parameters received gradients on this rank: must agree across ranks, or the replicas'
+        optimiser steps differ (Adam skips parameters without gradient)"""
+        return float(sum((k + 1) * (k + 7) for k, sl in enumerate(self.slots) if sl.filled) % 1000003)
+
+
+def check_presence_across_ranks(buckets, device):
+    """Every rank must have delivered gradients to the same parameters.  One tiny MAX / MIN all-reduce per step."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    v = [b.presence() for b in buckets]
+    dev = device if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor(v + [-x for x in v], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    t = t.cpu().tolist()
+    n = len(v)
+    if any(t[k] != -t[n + k] for k in range(n)):
+        raise RuntimeError("data-parallel ranks disagree on which parameters received gradients this step (checksums "
+                           "max %s / min %s): their optimiser steps would diverge" % (t[:n], [-x for x in t[n:]]))
+
+
+class GradientExchange:
+    """Stand-alone form for gradients that already sit in p.grad (tests, callers outside the trainer): the gradients
+    are moved into a temporary GradBuckets (one pass), exchanged bucket by bucket, and p.grad ends as the averaged slot."""
+
+    def __init__(self, params, bucket_mb=64):
+        ps = [p for p in params if p.grad is not None]
+        self.b = GradBuckets(ps, bucket_mb) if ps else None
+        if self.b is not None:
+            self.b.begin_step()
+            self.b.absorb([p.grad for p in ps])
+
+    def finish(self):
+        return self.b.finish() if self.b is not None else 0
 
 
 def allreduce_gradients_begin(params, bucket_mb=64):
@@ -772,9 +1075,9 @@ def allreduce_gradients_begin(params, bucket_mb=64):
 
 
 def allreduce_gradients(params, bucket_mb=64):
-    """Data-parallel gradient exchange: bucketed all-reduce, averaged over ranks; returns the bytes exchanged.
-    Replaces DataParallel's reduce-to-GPU-0 + re-broadcast: replicas are persistent, so one
-    all-reduce per bucket is all the communication a step needs."""
+    """Data-parallel gradient exchange of gradients already in p.grad: bucketed, averaged over ranks; returns the bytes
+    exchanged.  Replaces DataParallel's reduce-to-GPU-0 + re-broadcast: replicas are persistent, so
+    one collective per bucket is all the communication a step needs."""
     return GradientExchange(params, bucket_mb).finish()
 
 
@@ -896,6 +1199,9 @@ class Vid2VidTrainer:
         self.lr_scale = (lr_g / opt.lr, lr_d / opt.lr)
         self.optG = FusedAdam(self.G.parameters(), lr_g, betas)
         self.optD = FusedAdam(d_params, lr_d, betas)
+        # persistent flat gradient buckets (the backward nodes write into them; exchanged in place)
+        self.bucketsG = GradBuckets(self.optG.params, name="G")
+        self.bucketsD = GradBuckets(self.optD.params, name="D")
         if getattr(opt, "load_pretrain", ""):
             self.load(opt.which_epoch, opt.load_pretrain)
         self.comm_bytes, self.comm_ms = 0, 0.0
@@ -918,6 +1224,8 @@ class Vid2VidTrainer:
     def _train_step(self, pose, real, face_boxes, prev, real_prev=None, flow_ref=None, conf_ref=None):
         opt, dev = self.opt, pose.device
         F_, H, W = pose.shape[0], pose.shape[1], pose.shape[2]
+        self.bucketsG.begin_step()
+        self.bucketsD.begin_step()
         flow_on = not self.spec.no_flow
         first = prev is None
         if first:   # a new sequence starts: zero previous frames, raw-only first frame (--no_first_img)
@@ -1050,22 +1358,25 @@ class Vid2VidTrainer:
             keep = (self.tD - 1) * self.tD ** (len(self.DT) - 1)
             self._hist_real = [r.detach() for r in reals][-keep:]
             self._hist_fake = [f.detach() for f in fks][-keep:]
-        g_params = list(self.G.parameters())
+        g_params = self.optG.params
         d_params = self.optD.params
+        # G's backward: the nodes deliver into bucketsG and launch its buckets' collectives as they complete; what is
+        # left goes out in absorb() -- all of it in flight under the discriminators' backward pass
+        self.bucketsG.seal()
+        self.bucketsD.seal()
         gG = torch.autograd.grad(loss_G, g_params, retain_graph=True, allow_unused=True)
         gG = flush_pending_weight_gradients(g_params, gG)
-        for p, g in zip(g_params, gG):
-            p.grad = g
-        xg = allreduce_gradients_begin(g_params)     # in flight under the discriminators' backward pass
+        self.bucketsG.absorb(gG)
         gD = torch.autograd.grad(loss_D, d_params, allow_unused=True)
-        for p, g in zip(d_params, gD):
-            p.grad = g
-        xd = allreduce_gradients_begin(d_params)
+        self.bucketsD.absorb(gD)
+        if self.time_comm:       # T2V_TRAIN_COMM_TIMING=1: what of the exchange is still running once the backward kernels
+            torch.cuda.synchronize()      # have drained = its exposed (not hidden) part
         t0 = time.perf_counter()
-        self.comm_bytes = xg.finish() + xd.finish()
-        if self.time_comm and self.comm_bytes:       # exposed (not hidden) part of the exchange
+        self.comm_bytes = self.bucketsG.finish() + self.bucketsD.finish()
+        if self.time_comm and self.comm_bytes:
             torch.cuda.synchronize()
             self.comm_ms = 1e3 * (time.perf_counter() - t0)
+        check_presence_across_ranks([self.bucketsG, self.bucketsD], dev)
         self.optG.step()
         self.optD.step()
         keys = [k for k, v in losses.items() if torch.is_tensor(v)]
