@@ -377,3 +377,63 @@ def test_flow_branch_gets_its_weight_gradients_when_a_new_sequence_has_no_flow_l
         assert got[k] is not None, k
         err = (got[k] - ref[k]).abs().max().item() / max(ref[k].abs().max().item(), 1e-12)
         assert err <= 2e-3, (k, err)
+
+
+def test_direct_gradient_delivery_equals_autograd_accumulation_and_launches_no_aten_adds():
+    """The backward nodes write their parameter gradients straight into the persistent flat buckets (first node writes,
+    later nodes add through the kernels' accumulate flags) and hand None to autograd.  Against T2V_GRAD_DIRECT=0 --
+    autograd's own accumulation, the sums copied into the buckets afterwards -- the gradients must be bit-equal (same
+    node order, same fp32 additions), every gradient must BE a slice of its bucket, and the ATen elementwise-add launches
+    of the parameter-gradient accumulation must be gone."""
+    import os
+    from text2video_amd import train as T
+    from text2video_amd.options import TrainOptions
+    opt = TrainOptions().parse(["--name", "t", "--dataset_mode", "pose", "--input_nc", "3", "--openpose_only", "--ngf", "16",
+                                "--n_downsample_G", "2", "--n_blocks", "2", "--num_D", "2", "--ndf", "16", "--no_vgg",
+                                "--max_frames_per_gpu", "2", "--n_scales_temporal", "1", "--no_first_img", "--add_face_disc"])
+    H, W = 128, 256
+    rng = np.random.default_rng(11)
+    pose = torch.zeros(2, H, W, 12, device="cuda:0")
+    pose[..., :9] = torch.from_numpy(rng.uniform(-1, 1, (2, H, W, 9)).astype(np.float32)).cuda()
+    real = torch.zeros(2, H, W, 4, device="cuda:0")
+    real[..., :3] = torch.tanh(torch.from_numpy(rng.standard_normal((2, H, W, 3)).astype(np.float32))).cuda()
+    real_prev = torch.cat([real[1:], real[:1]], 0).contiguous()
+    boxes = [(16, 48, 100, 132)] * 2
+    grads, adds = {}, {}
+    old = os.environ.get("T2V_GRAD_DIRECT")
+    try:
+        for mode in ("1", "0"):
+            os.environ["T2V_GRAD_DIRECT"] = mode
+            tr = T.Vid2VidTrainer(opt, "cuda:0", seed=13)
+            _, prev = tr.train_step(pose, real, boxes, None, real_prev=real_prev)        # fills the temporal history
+            # capture the gradients of the second step before Adam consumes them: patch the optimiser steps away
+            tr.optG.step = lambda: None
+            tr.optD.step = lambda: None
+            with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CUDA]) as prof:
+                tr.train_step(pose, real, boxes, prev, real_prev=real_prev)
+                torch.cuda.synchronize()
+            names = [e.key for e in prof.key_averages()]
+            adds[mode] = sum(e.count for e in prof.key_averages() if "CUDAFunctor_add" in e.key)
+            grads[mode] = {k: (None if p.grad is None else p.grad.clone()) for k, p in
+                           list(tr.G.named_upstream_parameters().items()) + [("D." + k, p) for k, p in tr.D.named_upstream_parameters().items()]}
+            if mode == "1":
+                for p, sl in zip(tr.optG.params, tr.bucketsG.slots):
+                    assert p.grad is None or p.grad.data_ptr() == sl.view.data_ptr()
+                lo = tr.bucketsG.flat.data_ptr()
+                assert all(lo <= p.grad.data_ptr() < lo + 4 * tr.bucketsG.flat.numel() for p in tr.optG.params if p.grad is not None)
+                assert any("accumulate_kernel" in n or "unzip2_kernel" in n for n in names)
+    finally:
+        if old is None:
+            os.environ.pop("T2V_GRAD_DIRECT", None)
+        else:
+            os.environ["T2V_GRAD_DIRECT"] = old
+    assert grads["1"].keys() == grads["0"].keys()
+    for k in grads["1"]:
+        a, b = grads["1"][k], grads["0"][k]
+        assert (a is None) == (b is None), k
+        if a is not None:
+            assert torch.equal(a, b), (k, (a - b).abs().max().item())
+    print("ATen add launches per step: direct delivery %d, autograd accumulation %d" % (adds["1"], adds["0"]))
+    # what is left are the scalar loss sums and autograd's accumulation of ACTIVATION gradients (a frame read by several
+    # losses), not parameter gradients
+    assert adds["0"] > 50 and adds["1"] <= adds["0"] // 2

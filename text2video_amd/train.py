@@ -279,13 +279,13 @@ class _ConvBlock(torch.autograd.Function):
         for prm in (w, b, gamma, beta):
             expect_gradient(prm)
         ctx.meta = (desc, ddesc, norm, relu, act, need_dx, mrs, gamma is not None, wino_wgrad, slope)
-        ctx.save_for_backward(x, w, c, gamma, beta, y if (norm is None and act != ops.ACT_NONE) else None)
+        ctx.save_for_backward(x, w, c, gamma, beta, y if (norm is None and act != ops.ACT_NONE) else None, b)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         desc, fdesc, norm, relu, act, need_dx, mrs, affine, wino_wgrad, slope = ctx.meta
-        x, w, c, gamma, beta, y_act = ctx.saved_tensors
+        x, w, c, gamma, beta, y_act, b = ctx.saved_tensors
         dy = dy.contiguous()
         B = x.shape[0]
         dgamma = dbeta = None
