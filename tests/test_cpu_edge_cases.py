@@ -109,3 +109,64 @@ def test_face_region_rule():
     b[0:3, 60:64] = NOSE_NECK_RGB                      # at the corner: the centre is clamped so the crop stays inside
     ys, ye, xs, xe = get_face_region(b, 128)            # side 32
     assert (ys, ye, xs, xe) == (0, 32, 31, 63)
+
+
+def test_raster_pool_respawns_a_dead_worker_and_returns_writable_maps():
+    """The pool is cached per process (test_fifo.py serves many requests): a worker that died must not fail every later
+    job of its I/O thread -- the job is retried once on a fresh worker.  Maps come back writable."""
+    import os
+    import numpy as np
+    from text2video_amd.raster_pool import RasterPool
+    from text2video_amd.keypoints import read_keypoints
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "keypoints_fadg0")
+    src = os.path.join(gold, sorted(f for f in os.listdir(gold) if f.startswith("sa1_"))[0])
+    job = (src, (128, 96), (128, 96), False, False, False, True, False)
+    pool = RasterPool(1)
+    try:
+        want = read_keypoints(src, (128, 96), hand_discs=False)
+        a = pool.submit(job).result(timeout=120)
+        assert np.array_equal(a, want) and a.flags.writeable
+        pool._procs[0].kill()                      # the worker dies between two requests
+        pool._procs[0].wait()
+        b = pool.submit(job).result(timeout=120)
+        assert np.array_equal(b, want)
+        c = pool.submit(job).result(timeout=120)   # and the replacement keeps serving
+        assert np.array_equal(c, want)
+    finally:
+        pool.close()
+
+
+def test_lane_plan_and_lockstep_iteration_cover_the_same_items():
+    """PoseDataset.iter_lanes (N recurrences per step for t2v_generator_forward_batch): the same windows, names and
+    change_seq flags as the one-at-a-time iteration, every item exactly once, at most one item per lane and step,
+    --how_many applied in dataset order before the recurrences are dealt to the lanes."""
+    import json
+    import os
+    import numpy as np
+    from text2video_amd.options import TestOptions
+    from text2video_amd.pose_dataset import PoseDataset
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "keypoints_fadg0")
+    files = sorted(f for f in os.listdir(gold) if f.startswith("sa1_"))
+    frames = [json.load(open(os.path.join(gold, f))) for f in files]
+    opt = TestOptions().parse(["--name", "x", "--dataroot", "x", "--dataset_mode", "pose", "--loadSize", "64", "--no_first_img",
+                               "--random_drop_prob", "0"])
+    ds = PoseDataset.from_memory(opt, {"tmp": [frames[i % len(frames)] for i in range(7)],
+                                       "tmp_smooth": [frames[(2 * i) % len(frames)] for i in range(5)],
+                                       "third": [frames[(3 * i) % len(frames)] for i in range(4)]})
+    ref = {d["A_path"]: (d["A"], d["change_seq"]) for d in ds.iter_prefetch(1)}
+    assert ds.lane_plan(2) == [[0, 1, 2, 3, 4], [5, 6, 7, 8, 9]]          # longest first, then least loaded; dataset order inside
+    assert ds.lane_plan(1) == [list(range(10))] and ds.lane_plan(8) == [[0, 1, 2, 3, 4], [5, 6, 7], [8, 9]]
+    assert ds.lane_plan(2, limit=6) == [[0, 1, 2, 3, 4], [5]]
+    for workers in (1, 2):
+        for lanes in (1, 2, 3):
+            got = {}
+            for step in ds.iter_lanes(lanes, workers):
+                assert 1 <= len(step) <= lanes and len({k for k, _ in step}) == len(step)
+                for k, d in step:
+                    assert d["A_path"] not in got
+                    got[d["A_path"]] = (d["A"], d["change_seq"])
+            assert got.keys() == ref.keys()
+            for name in ref:
+                assert np.array_equal(ref[name][0], got[name][0]) and ref[name][1] == got[name][1], name
+    cut = [d["A_path"] for step in ds.iter_lanes(2, 1, limit=6) for _, d in step]
+    assert sorted(cut) == sorted(list(ref)[:6])

@@ -59,10 +59,14 @@ class RasterPool:
         self._threads = ThreadPoolExecutor(max_workers=workers, thread_name_prefix="raster")
         env = dict(os.environ, PYTHONPATH=_ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""),
                    OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")   # 2-point fits: no BLAS threads
+        self._env = env
         for _ in range(workers):       # start them all now: their imports run in parallel
-            self._procs.append(subprocess.Popen([sys.executable, "-m", "text2video_amd.raster_pool"], stdin=subprocess.PIPE,
-                                                stdout=subprocess.PIPE, env=env, cwd=_ROOT))
+            self._procs.append(self._spawn())
         self._free = list(self._procs)
+
+    def _spawn(self):
+        return subprocess.Popen([sys.executable, "-m", "text2video_amd.raster_pool"], stdin=subprocess.PIPE,
+                                stdout=subprocess.PIPE, env=self._env, cwd=_ROOT)
 
     def _mine(self):
         p = getattr(self._local, "proc", None)
@@ -71,16 +75,36 @@ class RasterPool:
                 p = self._local.proc = self._free.pop()
         return p
 
-    def _run(self, job):
+    def _replace(self, dead):
+        """the I/O thread's worker died or its pipe lost framing: start a fresh one in its place (the pool is cached per
+        process -- test_fifo.py serves many requests -- so a dead worker would otherwise fail every later job of its thread)"""
+        try:
+            dead.kill()
+        except OSError:
+            pass
+        fresh = self._spawn()
+        with self._lock:
+            self._procs = [fresh if q is dead else q for q in self._procs]
+        self._local.proc = fresh
+        return fresh
+
+    def _exchange(self, p, blob):
         import numpy as np
-        p = self._mine()
-        blob = pickle.dumps(job, protocol=pickle.HIGHEST_PROTOCOL)
         p.stdin.write(struct.pack("<I", len(blob)) + blob)
         p.stdin.flush()
         h, w, c = struct.unpack("<iii", _read_exact(p.stdout, 12))
         if h < 0:
             raise RuntimeError("rasteriser worker: " + _read_exact(p.stdout, w).decode(errors="replace"))
-        return np.frombuffer(_read_exact(p.stdout, h * w * c), dtype=np.uint8).reshape(h, w, c)
+        # (a writable copy: np.frombuffer on bytes is read-only)
+        return np.frombuffer(bytearray(_read_exact(p.stdout, h * w * c)), dtype=np.uint8).reshape(h, w, c)
+
+    def _run(self, job):
+        p = self._mine()
+        blob = pickle.dumps(job, protocol=pickle.HIGHEST_PROTOCOL)
+        try:
+            return self._exchange(p, blob)
+        except (EOFError, BrokenPipeError, OSError, struct.error):
+            return self._exchange(self._replace(p), blob)      # one retry on a fresh worker; a second failure raises
 
     def submit(self, job):
         return self._threads.submit(self._run, job)
