@@ -271,3 +271,30 @@ def test_masked_l1_and_flow_head_activation_backward():
     d = ops.act_backward(dy, y, 4, 20.0)
     want = torch.stack([20 * dy[..., 0], 20 * dy[..., 1], dy[..., 2] * y[..., 2] * (1 - y[..., 2]), torch.zeros_like(z[..., 3])], -1)
     assert (d - want).abs().max().item() <= 1e-6
+
+
+def test_in_kernel_combine_of_split_weight_gradients_equals_the_reduce_launch(monkeypatch):
+    """Direct weight gradients whose pixel reduction is cut into a few ranges: the block that draws the last arrival
+    ticket of a (tap, n, c) tile sums the published partials in split order inside the launch (default, <= 4 partials)
+    -- bit for bit what the separate reduce launch over zero-filled slabs produces (T2V_WGRAD_COMBINE=0), run after
+    run, with and without accumulation into an existing gradient."""
+    from text2video_amd import ops
+    torch.manual_seed(0)
+    for (B, H, W, Cin, Cout, stride, tr) in [(2, 16, 16, 64, 128, 1, False), (1, 64, 64, 256, 256, 1, False),
+                                              (1, 32, 32, 256, 512, 2, False), (1, 16, 16, 512, 256, 2, True)]:
+        desc = ops.conv_desc(H, W, Cin, Cout, 3, stride, 1, ops.PAD_ZERO if stride == 2 else ops.PAD_REFLECT, tr)
+        ho, wo = ops.conv_out_dims(desc)
+        x = torch.randn(B, H, W, Cin, device="cuda:0")
+        dy = torch.randn(B, ho, wo, Cout, device="cuda:0")
+        outs = {}
+        for mode in ("1", "0"):
+            monkeypatch.setenv("T2V_WGRAD_COMBINE", mode)
+            monkeypatch.setenv("T2V_WGRAD_COMBINE_MAX", "64")       # also the many-partial shapes the default leaves to the reduce launch
+            for rep in range(2):
+                dwp = ops.conv2d_backward_weight(x, dy, desc)
+                acc = ops.conv2d_backward_weight(x, dy, desc, accumulate_into=dwp.clone())
+                outs[(mode, rep)] = (dwp.clone(), acc.clone())
+        for rep in range(2):
+            assert torch.equal(outs[("1", rep)][0], outs[("0", 0)][0]), (B, H, W, Cin, Cout, stride, tr)
+            assert torch.equal(outs[("1", rep)][1], outs[("0", 0)][1])
+        assert outs[("0", 0)][0].abs().max().item() > 1.0

@@ -504,6 +504,24 @@ static int wgrad_splits(const t2v_conv_desc* d, int x_cs, int batch, const ConvP
     return s < 1 ? 1 : (int)s;
 }
 
+// arrival counters of the in-kernel combine: one int per (tap, n tile, c tile), rounded up to 256 floats
+static size_t wgrad_ticket_floats(const t2v_conv_desc* d, int x_cs, const ConvPlan& pl) {
+    int ntaps = 0;
+    for (int ph = 0; ph < pl.kp.nphases; ++ph) ntaps += pl.kp.ph[ph].ntaps;
+    const size_t tiles = wgrad_fold(d, x_cs) ? (size_t)((d->Cout + 127) / 128) * ((ntaps * x_cs + 127) / 128)
+                                            : (size_t)ntaps * ((d->Cout + 127) / 128) * ((x_cs + 127) / 128);
+    return (tiles + 255) / 256 * 256;
+}
+static int wgrad_combine_max_splits() {
+    const char* e = getenv("T2V_WGRAD_COMBINE_MAX");
+    return e ? atoi(e) : 4;
+}
+// T2V_WGRAD_COMBINE=0: split partials zero-filled, written and summed by a reduce launch (the round-1 form)
+static bool wgrad_combine_on() {
+    const char* e = getenv("T2V_WGRAD_COMBINE");
+    return !(e && atoi(e) == 0);
+}
+
 size_t t2v_conv_backward_weight_workspace_floats(const t2v_conv_desc* d, int x_cs, int batch) {
     ConvPlan pl;
     if (!d || build_conv_plan(d, x_cs, true, &pl) != T2V_OK) return 0;
@@ -516,7 +534,7 @@ size_t t2v_conv_backward_weight_workspace_floats(const t2v_conv_desc* d, int x_c
         return wgrad_padded_floats(d, x_cs, batch) + (size_t)s * d->Cout * pl.kp.ph[0].Kp;   // partials: the Cout real rows
     }
     const int s = wgrad_splits(d, x_cs, batch, pl);
-    return s > 1 ? (size_t)s * pl.wfloats : 0;
+    return s > 1 ? (size_t)s * pl.wfloats + wgrad_ticket_floats(d, x_cs, pl) : 0;
 }
 
 int t2v_conv2d_backward_weight(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, int batch, const float* x,
@@ -568,8 +586,9 @@ int t2v_conv2d_backward_weight(t2v_ctx* ctx, void* stream, const t2v_conv_desc* 
         // only the first Cout rows of the packed [Cout_p][Kp] matrix are ever written: partials hold just those
         const long part = (long)d->Cout * k.ph[0].Kp;
         w.dw_floats = part;
-        T2V_HIP_CHECK(hipMemsetAsync(partial, 0, (size_t)w.splits * part * sizeof(float), st));
         w.dw = partial;
+        // (taps folded onto the dY side: tile rows are (tap, channel) pairs -- this shape keeps the reduce launch)
+        T2V_HIP_CHECK(hipMemsetAsync(partial, 0, (size_t)w.splits * part * sizeof(float), st));
         w.accumulate = 0;
         T2V_TRY(launch_conv_wgrad(st, w));
         return launch_wgrad_reduce(st, partial, w.splits, part, dw_packed, accumulate);
@@ -586,8 +605,18 @@ int t2v_conv2d_backward_weight(t2v_ctx* ctx, void* stream, const t2v_conv_desc* 
     if (w.splits == 1) return launch_conv_wgrad((hipStream_t)stream, w);
     T2V_REQUIRE(workspace, "backward_weight: this shape needs a workspace of "
                            "t2v_conv_backward_weight_workspace_floats() floats");
-    T2V_HIP_CHECK(hipMemsetAsync(workspace, 0, (size_t)w.splits * pl.wfloats * sizeof(float), (hipStream_t)stream));
     w.dw = workspace;
+    if (wgrad_combine_on() && w.splits <= wgrad_combine_max_splits()) {
+        // in-kernel combine: no zero-fill of the partial slabs, no reduce launch -- only the arrival counters are cleared.
+        // For few partials only: the last arriver of a tile reads them one after the other (T2V_WGRAD_COMBINE_MAX).
+        int* tickets = reinterpret_cast<int*>(workspace + (size_t)w.splits * pl.wfloats);
+        T2V_HIP_CHECK(hipMemsetAsync(tickets, 0, (size_t)w.ntaps * w.ntiles * w.ctiles * sizeof(int), (hipStream_t)stream));
+        w.tickets = tickets;
+        w.dw_final = dw_packed;
+        w.accumulate = accumulate;
+        return launch_conv_wgrad((hipStream_t)stream, w);
+    }
+    T2V_HIP_CHECK(hipMemsetAsync(workspace, 0, (size_t)w.splits * pl.wfloats * sizeof(float), (hipStream_t)stream));
     w.accumulate = 0;
     T2V_TRY(launch_conv_wgrad((hipStream_t)stream, w));
     return launch_wgrad_reduce((hipStream_t)stream, workspace, w.splits, (long)pl.wfloats, dw_packed, accumulate);

@@ -22,6 +22,7 @@
 #include <stdlib.h>
 
 #include "t2v_internal.h"
+#include "norm_pool.h"
 
 namespace t2v {
 
@@ -231,34 +232,78 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradParams p) {
     }
 
     // ---- epilogue: D[row n][col c] -> packed dW[n][koff + c]  (koff: position of this tap in K) ----
+    const bool combine = p.tickets != nullptr;   // splits > 1: this block's tile is a partial to be summed in-kernel
     float* out = p.dw + (size_t)split * p.dw_floats + p.tap_woff[tap];
     const int Kp = p.tap_Kp[tap];
     const int kbase = p.fold == 1 ? c0 : p.tap_kidx[tap] * p.Cin_s + c0;
     const int klimit = p.fold == 1 ? p.fold_taps * p.Cin_s - c0 : p.Cin_s - c0;   // valid columns of this tile
+    // element (i, r, j) of this lane -> offset in the packed matrix, or -1 outside the valid rows / columns
+    auto elem_off = [&](int i, int r, int j) -> long {
+        int n = n0 + wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+        int koff = kbase;
+        bool row_ok = n < p.Cout;
+        if (fold_n) {   // row n' = tap*Cout_s + n
+            const int ltap = n / p.Cout_s;
+            n -= ltap * p.Cout_s;
+            row_ok = ltap < p.fold_taps && n < p.Cout;
+            koff = ltap * p.Cin_s + c0;
+        }
+        const int c = wc * 64 + j * 32 + fi;
+        return (row_ok && c < klimit) ? (long)n * Kp + koff + c : -1L;
+    };
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            int n = n0 + wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
-            int koff = kbase;
-            bool row_ok = n < p.Cout;
-            if (fold_n) {   // row n' = tap*Cout_s + n
-                const int ltap = n / p.Cout_s;
-                n -= ltap * p.Cout_s;
-                row_ok = ltap < p.fold_taps && n < p.Cout;
-                koff = ltap * p.Cin_s + c0;
-            }
-            if (row_ok) {
+        for (int r = 0; r < 16; ++r)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int c = wc * 64 + j * 32 + fi;
-                    if (c < klimit) {
-                        float* dst = out + (size_t)n * Kp + koff + c;
-                        *dst = p.accumulate ? *dst + acc[i][j][r] : acc[i][j][r];
-                    }
-                }
+            for (int j = 0; j < 2; ++j) {
+                const long off = elem_off(i, r, j);
+                if (off < 0) continue;
+                float* dst = out + off;
+                if (combine)   // published for the block that will sum this tile's partials inside this launch
+                    __hip_atomic_store(dst, acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else
+                    *dst = p.accumulate ? *dst + acc[i][j][r] : acc[i][j][r];
             }
+    if (!combine) return;
+    // Arrival ticket of the (tap, n tile, c tile): the loader waves have left (the hardware barrier counts the live
+    // waves only); the flag lives behind the LDS ring, which their last DMA may still be filling.
+    const int tiles = p.ntaps * p.ntiles * p.ctiles;
+    int* flag = reinterpret_cast<int*>(smem + kWgRing * kWgStage);
+    if (!last_arriver(p.tickets + (blockIdx.x - split * tiles), p.splits, flag)) return;
+    // The last arriver sums the tile's partials in split order -- the order launch_wgrad_reduce uses -- its own included
+    // (read back like the others: the accumulators are dead after the publish).  The 128 x 128 tile is walked as 4096
+    // float4 pieces, 16 per thread of the four live waves; sc1 (L1-bypassing) 16-byte buffer loads.
+    float* fin = p.dw_final + p.tap_woff[tap];
+    const int tw = threadIdx.x;         // 0..255: the MFMA waves
+    int off[16];
+    float4 sum[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int idx = q * 256 + tw, rr = idx >> 5, c4 = (idx & 31) * 4;
+        const int n = n0 + rr;
+        off[q] = (n < p.Cout && c4 < klimit) ? n * Kp + kbase + c4 : -1;
+        sum[q] = (p.accumulate && off[q] >= 0) ? *reinterpret_cast<const float4*>(fin + off[q]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int k = 0; k < p.splits; ++k) {
+        const float* pk = p.dw + (size_t)k * p.dw_floats + p.tap_woff[tap];
+        const __amdgpu_buffer_rsrc_t srd =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pk), 0, (int)((p.dw_floats - p.tap_woff[tap]) * 4), 0x00020000);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            if (off[q] < 0) continue;
+            const auto raw = __builtin_amdgcn_raw_buffer_load_b128(srd, off[q] * 4, 0, /*sc1*/ 16);
+            float4 v;
+            __builtin_memcpy(&v, &raw, 16);
+            sum[q].x += v.x;
+            sum[q].y += v.y;
+            sum[q].z += v.z;
+            sum[q].w += v.w;
         }
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+        if (off[q] >= 0) *reinterpret_cast<float4*>(fin + off[q]) = sum[q];
 }
 
 __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int splits, long n, float* __restrict__ dw,
@@ -281,7 +326,7 @@ int launch_wgrad_reduce(hipStream_t s, const float* partial, int splits, long n,
 template <bool REFLECT, int PIX, int RING>
 static int launch_wgrad_variant(hipStream_t s, const WgradParams& p) {
     auto kern = conv_wgrad_kernel<REFLECT, PIX, RING>;
-    constexpr int lds = RING * 2 * PIX * 128 * 4;
+    constexpr int lds = RING * 2 * PIX * 128 * 4 + 16;   // + the arrival flag of the in-kernel combine
     static bool attr_done = false;   // per instantiation
     if (!attr_done) {
         T2V_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));

@@ -97,6 +97,12 @@ struct WgradParams {
     // taps are folded into the 128-wide dY side instead: row n' = tap*Cout_s + n reads dY at pixel q - (kh, kw)
     int splits;        // the pixel reduction is cut into `splits` ranges (blockIdx major), each writing its own
     long dw_floats;    // partial gradient at dw + split*dw_floats (deterministic; summed by wgrad_reduce)
+    // in-kernel combine (tickets != nullptr, splits > 1): the partials are published write-through, every (tap, n, c)
+    // tile has an arrival counter, and the block that draws the last ticket of a tile adds the `splits` partials up in
+    // split order -- the order wgrad_reduce uses -- and writes (accumulates into) dw_final: no zero-fill of the
+    // partial slabs, no reduce launch
+    float* dw_final;
+    int* tickets;      // ntaps * ntiles * ctiles zeroed ints (left zeroed)
     int tdy[kMaxTaps], tdx[kMaxTaps];   // input offset of every tap (all phases concatenated)
     int toy[kMaxTaps], tox[kMaxTaps];   // output offset (sub-pixel phase) of the tap's phase
     long tap_woff[kMaxTaps];            // float offset of the tap's phase matrix in dw
