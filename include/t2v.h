@@ -181,7 +181,9 @@ int t2v_avgpool3x3s2(t2v_ctx* ctx, void* stream, const float* x, float* y, int H
  *   backward_weight: dW (packed layout, same as the packed forward weight) = sum over the batch and
  *       all pixels of dy (x) x through every filter tap; accumulate != 0 adds to dw_packed.
  *       Narrow high-resolution layers cut the pixel reduction into ranges (deterministic partials in
- *       `workspace`, summed in a fixed order).
+ *       `workspace`, summed in a fixed order: up to 4 partials by the last-arriving block of each (tap, n, c)
+ *       tile inside the launch -- arrival tickets, write-through partials -- more by a reduce pass; the same
+ *       bits either way).
  *       x: [batch][H][W][x_cs], dy: [batch][Hout][Wout][dy_cs].
  *   unpack_weight:   packed -> torch layout (inverse of t2v_conv_pack_weight).
  *   channel_sum:     out[c] = sum over pixels of x[.][c]  (bias gradient).
