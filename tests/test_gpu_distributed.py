@@ -75,6 +75,14 @@ def _rccl_worker(tmp):
     out["comm_bytes"] = tr.comm_bytes
     out["n_param_bytes"] = 4 * sum(p.numel() for p in tr.optG.params + tr.optD.params if p.grad is not None)
     out["losses_finite"] = all(np.isfinite(v) for v in losses.values())
+    # the same step with the reduce-scatter + all-gather form of the exchange (in place on the flat buckets)
+    os.environ["T2V_GRAD_RS_AG"] = "1"
+    tr2 = T.Vid2VidTrainer(opt, "cuda:0", seed=5)
+    losses2, _ = tr2.train_step(pose, real, None, None, real_prev=real.flip(0).contiguous())
+    os.environ["T2V_GRAD_RS_AG"] = "0"
+    out["rs_ag_bytes"] = tr2.comm_bytes
+    out["rs_ag_same_losses"] = all(losses[k] == losses2[k] for k in losses)
+    out["rs_ag_same_weights"] = all(bool(torch.equal(a, b)) for a, b in zip(tr.optG.params, tr2.optG.params))
     dist.barrier()
     dist.destroy_process_group()
     with open(tmp, "w") as fh:
@@ -93,6 +101,7 @@ def test_rccl_collectives_execute_on_device_tensors(tmp_path):
     assert d["backend"] == "nccl" and d["gather_equal"] and d["grads_ok"] and d["tails_ok"] and d["losses_finite"]
     assert d["bytes"] == 4 * (5 + 70000 + 3 + (1 << 18) + 17)
     assert d["comm_bytes"] == d["n_param_bytes"] > 0         # every gradient of the step went through the exchange
+    assert d["rs_ag_bytes"] == d["comm_bytes"] and d["rs_ag_same_losses"] and d["rs_ag_same_weights"]
 
 
 def test_config2_chunk_plan_with_the_real_generator_matches_oracle_per_chunk():

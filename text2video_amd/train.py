@@ -986,7 +986,7 @@ class GradBuckets:
         buf = self.flat[lo:hi]
         avg = dist.get_backend() == "nccl"       # RCCL averages in the collective; gloo sums (scaled in finish)
         op = dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM
-        if self.rs_ag and self.world > 1:
+        if self.rs_ag:      # (also on a forced 1-rank group: the RCCL entry points run on device tensors)
             shard = (hi - lo) // self.world
             r = dist.get_rank()
             mine = buf[r * shard:(r + 1) * shard]
