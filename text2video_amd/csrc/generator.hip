@@ -494,7 +494,7 @@ int t2v_generator_forward_batch(t2v_ctx* ctx, void* stream, const t2v_gen_desc* 
     r2.sc = two_streams ? 1 : 0;
     // arrival counters of the producers that finalize their own norm statistics (they leave them zeroed; this
     // clears whatever an aborted frame, or the allocator, left behind)
-    T2V_HIP_CHECK(hipMemsetAsync(b.tickets[0], 0, 2 * b.ticket_ints * sizeof(int), s));
+    if (Runner::ticket_on()) T2V_HIP_CHECK(hipMemsetAsync(b.tickets[0], 0, 2 * b.ticket_ints * sizeof(int), s));
 
     Ptrs pose{}, prevp{};
     for (int im = 0; im < batch; ++im) {
