@@ -301,3 +301,34 @@ def test_fullwidth_gradient_error_is_within_the_fp32_oracles_own():
     print("full-width gradient vs fp64: CPU fp32 oracle median %.1e p90 %.1e max %.1e | HIP median %.1e p90 %.1e max %.1e"
           % (np.median(e32), np.quantile(e32, 0.9), e32.max(), np.median(eh), np.quantile(eh, 0.9), eh.max()))
     assert np.median(eh) <= 3 * np.median(e32) and np.quantile(eh, 0.9) <= 4 * np.quantile(e32, 0.9) and eh.max() <= 5 * e32.max()
+
+
+def test_config1_512_batch_of_two_sequences_equals_single_sequence_frames():
+    """Full-size network, 512x512, flow on: two sequences advanced in lock-step (the batched ResnetBlock chains run their
+    36 Winograd GEMMs as [512 x 1024] x [1024 x 1024] on 128x128 tiles, the single-sequence path as [256 x 1024] on 64x64
+    tiles) against each sequence generated alone, three free-running frames each.  Reported: bit-equality; asserted:
+    <= 2e-4 per pixel (and the frames are not trivial)."""
+    from text2video_amd import ops
+    from text2video_amd.generator import Recurrence, Vid2VidModelG
+    _, hips = _full_nets(1, False)
+    hip = Vid2VidModelG(hips)
+    H = W = 512
+    seqs = [_pose_seq(5, H, W, seed=31 + i) for i in range(2)]
+
+    def window(i, t):
+        return ops.nchw_to_nhwc(seqs[i][t - 2:t + 1].reshape(9, H, W).contiguous().cuda())
+
+    alone = []
+    for i in range(2):
+        st = Recurrence()
+        alone.append([hip.inference_nhwc_batch([window(i, t)], [st])[0].clone() for t in range(2, 5)])
+    states = [Recurrence(), Recurrence()]
+    worst, equal = 0.0, True
+    for k, t in enumerate(range(2, 5)):
+        outs = hip.inference_nhwc_batch([window(0, t), window(1, t)], states)
+        for i in range(2):
+            d = (outs[i] - alone[i][k]).abs().max().item()
+            worst, equal = max(worst, d), equal and d == 0.0
+            assert outs[i][..., :3].std().item() > 0.01
+    print("512x512 flow, batch 2 vs single sequence: max|delta| = %.3g (%s)" % (worst, "bit-equal" if equal else "not bit-equal"))
+    assert worst <= 2e-4
