@@ -311,3 +311,22 @@ def test_two_rank_gloo_grad_buckets_deliver_launch_in_order_and_average(tmp_path
     launched when its last gradient lands (in bucket order), all-reduce or reduce-scatter + all-gather, the result
     averaged over the ranks and handed to the optimiser as views; and the guard against ranks whose gradient sets differ."""
     mp.spawn(_buckets_worker, args=(2, _free_port(), str(tmp_path), rs_ag), nprocs=2, join=True)
+
+
+def test_chunks_per_rank_reproduces_the_finer_plan_on_fewer_ranks():
+    """--shard_chunks --chunks_per_rank C: the chunks are those of the world * C rank plan (BASELINE configs[2]: 8 x 64
+    frames), every rank holding C consecutive ones -- 1 GPU x 8, 2 x 4, 4 x 2 -- so the frames do not depend on how many
+    GPUs the plan runs on."""
+    from text2video_amd.distributed import plan_units
+    p8 = plan_units({"seq": 514}, 8, 3, shard_chunks=True)
+    flat8 = sorted(u for r in p8 for u in r)
+    for world, c in ((1, 8), (2, 4), (4, 2)):
+        p = plan_units({"seq": 514}, world, 3, shard_chunks=True, chunks_per_rank=c)
+        assert len(p) == world and all(len(r) == c for r in p)
+        assert sorted(u for r in p for u in r) == flat8
+        for r in p:                                   # consecutive chunks per rank
+            assert all(r[i][3] + 64 == r[i + 1][3] for i in range(c - 1))
+    # two sequences, two ranks, two chunks each: every sequence stays on one rank
+    p = plan_units({"a": 10, "b": 8}, 2, 3, shard_chunks=True, chunks_per_rank=2)
+    assert [sorted({u[0] for u in r}) for r in p] == [["a"], ["b"]]
+    assert plan_units({"a": 10}, 1, 3, shard_chunks=False, chunks_per_rank=4) == [[("a", 0, 10, 2)]]     # only with --shard_chunks

@@ -369,3 +369,42 @@ def test_two_ranks_agree_on_the_face_terms_when_one_clip_shows_no_face(tmp_path)
     assert "replicas in sync after 2 steps" in r.stdout and "on all 2 ranks" in r.stdout
     lines = [l for l in r.stdout.splitlines() if l.startswith("(iter")]
     assert lines and not any("D_f" in l for l in lines), lines      # rank 0's clip HAS a face: skipped together all the same
+
+
+def test_chunk_plan_on_one_gpu_equals_the_two_rank_chunk_plan(tmp_path):
+    """BASELINE configs[2] on fewer GPUs than chunks: `test.py --shard_chunks --chunks_per_rank 2` in ONE process cuts the
+    sequence exactly as two ranks would and advances the two chunks in lock-step (batch 2) -- the JPEG files equal the
+    two-rank `--shard_chunks` run's; with the stitch pass over the whole chunk length they equal the unsharded run's."""
+    import glob
+    import shutil
+    from PIL import Image
+    from text2video_amd.keypoints import read_keypoints
+    src = os.path.join(ROOT, "tests", "golden", "keypoints_fadg0")
+    files = sorted(f for f in os.listdir(src) if f.startswith("sa1_"))
+    env = _plain_env()
+
+    def work(name):
+        w = str(tmp_path / name)
+        root = os.path.join(w, "datasets", "fadg0")
+        os.makedirs(os.path.join(root, "test_openpose", "tmp"))
+        os.makedirs(os.path.join(root, "test_img", "tmp"))
+        img = Image.fromarray(read_keypoints(os.path.join(src, files[0]), (128, 96)))
+        for i in range(14):
+            shutil.copyfile(os.path.join(src, files[(i * 5 + 3) % len(files)]), os.path.join(root, "test_openpose", "tmp", "%05d.json" % i))
+            img.save(os.path.join(root, "test_img", "tmp", "%04d.jpg" % i))
+        return w
+
+    def frames(w):
+        return {os.path.relpath(p, w): open(p, "rb").read()
+                for p in sorted(glob.glob(os.path.join(w, "results", "fadg0", "test_latest", "*", "fake_B_*.jpg")))}
+
+    ws = {k: work(k) for k in ("single", "two_ranks", "one_rank_two_chunks", "one_rank_stitched")}
+    _run_test_py(ws["single"], [], env)
+    _run_test_py(ws["two_ranks"], ["--shard_chunks", "--gpu_ids", "0,1"], env)
+    _run_test_py(ws["one_rank_two_chunks"], ["--shard_chunks", "--chunks_per_rank", "2"], env)
+    _run_test_py(ws["one_rank_stitched"], ["--shard_chunks", "--chunks_per_rank", "2", "--stitch_frames", "100"], env)
+    one, two, cpr, st = (frames(ws[k]) for k in ("single", "two_ranks", "one_rank_two_chunks", "one_rank_stitched"))
+    assert len(one) == 12 and one.keys() == two.keys() == cpr.keys() == st.keys()
+    assert all(two[k] == cpr[k] for k in two)                       # the same chunks, the same frames
+    assert any(one[k] != cpr[k] for k in one)                       # ... which restart the recurrence at the cut
+    assert all(one[k] == st[k] for k in one)                        # stitched over the whole chunk: the unsharded sequence

@@ -85,8 +85,13 @@ def assign_chunks(seq_lengths, world, n_frames_G=3):
     return plan
 
 
-def plan_units(seq_lengths, world, n_frames_G=3, shard_chunks=False, how_many=None):
+def plan_units(seq_lengths, world, n_frames_G=3, shard_chunks=False, how_many=None, chunks_per_rank=1):
     """Work units per rank: [(seq, pose_start, pose_stop, first_output_index)].
+
+    chunks_per_rank C > 1 (with shard_chunks): sequences are cut as for world * C ranks and every rank takes C
+    consecutive shares -- BASELINE configs[2]'s 8 x 64-frame plan on fewer than 8 GPUs (C = 8 / world), the chunks of a
+    rank advancing in lock-step on its GPU (test.py --batch_sequences).  The chunks, and so the frames, are those of the
+    world * C rank plan.
 
     how_many caps the number of OUTPUT frames globally, in dataset order -- what the single-process frame loop's
     `if i >= how_many: break` does -- before anything is dealt out.  Without shard_chunks only whole sequences are
@@ -104,7 +109,16 @@ def plan_units(seq_lengths, world, n_frames_G=3, shard_chunks=False, how_many=No
             budget -= n_out
         lengths[seq] = n_out + (n_frames_G - 1)
     if shard_chunks:
-        return assign_chunks(lengths, world, n_frames_G)
+        C = max(1, int(chunks_per_rank))
+        fine = assign_chunks(lengths, world * C, n_frames_G)
+        if C == 1:
+            return fine
+        plan = [[] for _ in range(world)]
+        for v, units in enumerate(fine):          # virtual rank v -> real rank v // C (contiguous shares)
+            plan[v // C] += units
+        for p in plan:
+            p.sort(key=lambda u: (u[0], u[1]))
+        return plan
     loads = [0] * world
     plan = [[] for _ in range(world)]
     for seq, n in sorted(lengths.items(), key=lambda kv: (-kv[1], kv[0])):

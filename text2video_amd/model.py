@@ -102,14 +102,18 @@ def run_test(opt, model=None, device=None, dataset=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     plan = rank = None
     limit = opt.how_many
-    if world > 1:
+    cpr = int(getattr(opt, "chunks_per_rank", 1) or 1)
+    if world > 1 or (getattr(opt, "shard_chunks", False) and cpr > 1):
         from . import distributed as D
-        rank, local_rank, world = D.init_from_env()
+        rank, local_rank = 0, None
+        if world > 1:
+            rank, local_rank, world = D.init_from_env()
         plan = D.plan_units(dataset.seq_lengths(), world, opt.n_frames_G, getattr(opt, "shard_chunks", False),
-                            None if opt.how_many in (None, float("inf")) else int(opt.how_many))
+                            None if opt.how_many in (None, float("inf")) else int(opt.how_many), cpr)
         dataset.restrict(plan[rank])
         limit = None            # already applied globally
-        device = "cuda:%d" % local_rank
+        if local_rank is not None:
+            device = "cuda:%d" % local_rank
     if model is None:
         model = create_model(opt, device)
     vis = Visualizer(opt)

@@ -63,6 +63,9 @@ def _common(p):
       "rank in lock-step, one batched generator call per frame; frames are identical to N=1")
     g("--shard_chunks", action="store_true", help="multi-GPU test.py: also cut sequences into chunks so that every rank "
       "has work (each chunk restarts the recurrence; default: whole sequences only, frames identical to 1 GPU)")
+    g("--chunks_per_rank", type=int, default=1, metavar="C", help="with --shard_chunks: cut as for C x the number of ranks "
+      "and give every rank C chunks (BASELINE configs[2]'s 8 x 64 plan on fewer than 8 GPUs); a rank advances its chunks in "
+      "lock-step (--batch_sequences)")
     g("--stitch_frames", type=int, default=0, metavar="K", help="with --shard_chunks: re-generate the first K frames of "
       "every continuation chunk from its predecessor's last frames (all-gathered over RCCL)")
     g("--stitch_rounds", type=int, default=1, help="repetitions of the stitch pass")
