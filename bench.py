@@ -171,7 +171,10 @@ def run_e2e(model_head, model_other, head_flow, n_frames):
              ((512, 512), ["--no_pose_crop", "--batch_sequences", "1"], "512x512, two sequences one after the other",
               [head_flow], two),
              ((512, 512), ["--no_pose_crop", "--batch_sequences", "2"], "512x512, two sequences in lock-step (batch 2)",
-              [head_flow], two)]
+              [head_flow], two),
+             # the reference's own run: fadg0 frames, scaleHeight 512 + central-width crop, tmp and tmp_smooth
+             ((512, 384), ["--batch_sequences", "1"], "512x320, two sequences one after the other", [head_flow], two),
+             ((512, 384), ["--batch_sequences", "2"], "512x320, two sequences in lock-step (batch 2)", [head_flow], two)]
     for canvas, extra, geom, flows, seqs in cases:
         tmp = tempfile.mkdtemp(prefix="t2v_e2e_")
         try:

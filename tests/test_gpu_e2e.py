@@ -267,7 +267,7 @@ def test_bench_contract_line():
     assert {r["geometry"].split(" ")[0].rstrip(",") for r in runs} == {"512x512", "512x680", "512x320"}
     assert all(r["frames"] == 12 and r["fps"] > 0 and r["pose_workers"] >= 1 for r in runs)
     # the two-sequence dataset (tmp + tmp_smooth, as the reference's L2 driver writes it), one at a time and in lock-step
-    assert sorted(r["batch_sequences"] for r in runs if r["sequences"] == 2) == [1, 2]
+    assert sorted(r["batch_sequences"] for r in runs if r["sequences"] == 2) == [1, 1, 2, 2]      # at 512x512 and at the reference's 512x320
     # N independent sequences per GPU in lock-step: aggregate rates beside the single-sequence headline
     assert v["batch2_fps"] > 30.0 and v["batch4_fps"] > 30.0 and d["value"] == v["flow_fps"]
     # the box the line was measured on and the core clock during the timed region (None where sysfs has no such file)
