@@ -184,7 +184,7 @@ int best_conv_algo(const t2v_conv_desc* d, int x_cs, int cap) {
 
 // the batched GEMM of a Winograd conv as a plan of the implicit-GEMM kernel: a 1x1 conv over a 16|36 x T image
 int build_winograd_gemm_plan(const t2v_conv_desc* d, ConvPlan* pl, int nimg) {
-    const int T = nimg * wino_tiles_padded(d, d->algo);   // GEMM rows per transform position: all images' tiles
+    const int T = wino_rows_batch(d, d->algo, nimg);   // GEMM rows per transform position: all images' tiles, packed
     t2v_conv_desc g;
     memset(&g, 0, sizeof(g));
     g.H = wino_pos(d->algo); g.W = T; g.Cin = d->Cin; g.Cout = d->Cout; g.kH = g.kW = 1; g.stride = 1; g.pad = 0;
@@ -277,7 +277,7 @@ int winograd_forward(t2v_ctx* ctx, hipStream_t s, const t2v_conv_desc* d, const 
     const int nimg = wb.nimg;
     const bool f4 = d->algo == T2V_ALGO_WINOGRAD_F4;
     T2V_REQUIRE(nimg >= 1 && (f4 || (nimg == 1 && !wb.tickets)), "winograd: batches and in-kernel finalize are F(4x4,3x3) only");
-    const size_t T = (size_t)nimg * wino_tiles_padded(d, d->algo);
+    const size_t T = (size_t)wino_rows_batch(d, d->algo, nimg);
     float* V = workspace;
     float* Mm = workspace + wino_pos(d->algo) * T * d->Cin;
     if (stages & 1) {

@@ -26,8 +26,16 @@ inline int wino_tiles_padded(const t2v_conv_desc* d, int algo) {
     const int T = ((wino_out_h(d) + m - 1) / m) * ((wino_out_w(d) + m - 1) / m);
     return wino_pad_tiles(T);
 }
+// GEMM rows per transform position for a batch of nimg images: F(4x4) packs the images' tiles and pads the total
+inline int wino_tiles_real(const t2v_conv_desc* d, int algo) {
+    const int m = wino_m(algo);
+    return ((wino_out_h(d) + m - 1) / m) * ((wino_out_w(d) + m - 1) / m);
+}
+inline int wino_rows_batch(const t2v_conv_desc* d, int algo, int nimg) {
+    return (nimg > 1 && algo == T2V_ALGO_WINOGRAD_F4) ? wino_pad_tiles(nimg * wino_tiles_real(d, algo)) : wino_tiles_padded(d, algo);
+}
 inline size_t winograd_workspace_floats(const t2v_conv_desc* d, int nimg = 1) {      // V + M of `nimg` images
-    return (size_t)nimg * wino_pos(d->algo) * wino_tiles_padded(d, d->algo) * ((size_t)d->Cin + d->Cout);
+    return (size_t)wino_pos(d->algo) * wino_rows_batch(d, d->algo, nimg) * ((size_t)d->Cin + d->Cout);
 }
 // GEMM rows of the whole conv (all positions): what the algorithm choice compares
 inline long wino_gemm_rows(const t2v_conv_desc* d, int algo) { return (long)wino_pos(algo) * wino_tiles_padded(d, algo); }

@@ -138,8 +138,9 @@ int launch_winograd_weight(hipStream_t s, const float* w, float* U, int Cout, in
 int launch_winograd_input(hipStream_t s, const float* x, float* V, int H, int W, int C, int pad, int reflect);
 int launch_winograd_output(hipStream_t s, const float* Mm, const float* bias, float* y, float* stats, int H, int W, int N);
 int launch_winograd4_weight(hipStream_t s, const float* w, float* U, int Cout, int Cin, int Cout_p, int Cin_s, int adjoint = 0);
+// nimg == 0: slot layout (image -> slot `image` of `batch` slots of Tp rows); nimg > 0: packed batch of nimg images
 int launch_winograd4_input(hipStream_t s, const float* x, float* V, int H, int W, int C, int pad, int reflect, int batch = 1,
-                           int image = 0, int nimg = 1, long img_stride = 0);
+                           int image = 0, int nimg = 0, long img_stride = 0);
 // input transform of a conv output that still has to go through its norm layer (winograd4_input_kernel<1|2>)
 int launch_winograd4_input_lazy(hipStream_t s, const float* x, float* V, int H, int W, int C, int pad, int reflect,
                                 const float* mean_rstd, const float* gamma, const float* beta, int relu_only,

@@ -326,28 +326,32 @@ int launch_winograd4_weight(hipStream_t s, const float* w, float* U, int Cout, i
 // (a ResnetBlock's first norm).  MODE 2: plus the residual, and the tile's own 4x4 pixels of d are written to `xout`
 // as well (every pixel belongs to exactly one tile): a ResnetBlock's output, which the next block needs again as
 // its residual.  All pointers are distinct buffers (restrict: the side stores must not fence the patch loads).
+// img_tiles / last_tiles: rows of V between consecutive images of the launch, and the tiles the LAST image walks
+// (its own T plus the zero rows that pad the whole matrix up to Tt).  Two layouts: slots of Tp rows per image (the weight
+// gradient's batch workspace: img_tiles = last_tiles = Tp) and packed (a forward batch: image i owns rows [i*T, (i+1)*T), only
+// the total is padded -- two 160-tile images are 320 GEMM rows per position, not 2 x 192).
 template <int MODE>
 __global__ __launch_bounds__(256) void winograd4_input_kernel(const float2* __restrict__ x, float2* __restrict__ V, int H,
-                                                              int W, int C2, int TW, int T, int Tp, int pad, int reflect,
+                                                              int W, int C2, int TW, int T, int img_tiles, int pad, int reflect,
                                                               int Tt, int t0, const float2* __restrict__ mean_rstd,
                                                               const float2* __restrict__ gamma,
                                                               const float2* __restrict__ beta,
                                                               const float2* __restrict__ res, float2* __restrict__ xout,
-                                                              long img_stride) {
+                                                              long img_stride, int last_tiles) {
     // blockIdx.y = image of a batch (independent sequences advanced in lock-step): its map, residual and side output
     // sit img_stride float2 after the previous image's, its (mean, rstd) table 2*C2 float2 after, and its tiles
     // occupy rows [t0 + image*Tp, ...) of the batch-wide V
     {
         const long im = blockIdx.y;
         x += im * img_stride;
-        t0 += (int)im * Tp;
+        t0 += (int)im * img_tiles;
         if (MODE) mean_rstd += im * 2 * C2;
         if (MODE == 2) {
             res += im * img_stride;
             xout += im * img_stride;
         }
     }
-    const long total = (long)Tp * C2;
+    const long total = (long)(blockIdx.y == gridDim.y - 1 ? last_tiles : img_tiles) * C2;
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
         const long tile = i / C2;
@@ -437,14 +441,20 @@ __global__ __launch_bounds__(256) void winograd4_input_kernel(const float2* __re
         }
     }
 }
-// the `nimg` images starting at `x` (img_stride floats apart) go to slots [image, image + nimg) of a V sized for `batch`
+// Slot layout (the weight gradient's batch workspace): the image at `x` goes to slot `image` of a V sized for `batch`
+// slots of Tp rows.  Packed layout (nimg > 0: a forward batch): the nimg images starting at `x` (img_stride floats apart)
+// own T rows each, the total padded to wino_pad_tiles(nimg * T).
 int launch_winograd4_input(hipStream_t s, const float* x, float* V, int H, int W, int C, int pad, int reflect, int batch,
                            int image, int nimg, long img_stride) {
     const int Ho = H + 2 * pad - 2, Wo = W + 2 * pad - 2;
     const int TW = (Wo + 3) / 4, T = ((Ho + 3) / 4) * TW, Tp = wino_pad_tiles(T);
-    hipLaunchKernelGGL(winograd4_input_kernel<0>, dim3(wg_grid((long)Tp * (C / 2), 256), nimg), dim3(256), 0, s,
-                       reinterpret_cast<const float2*>(x), reinterpret_cast<float2*>(V), H, W, C / 2, TW, T, Tp, pad,
-                       reflect, batch * Tp, image * Tp, nullptr, nullptr, nullptr, nullptr, nullptr, img_stride / 2);
+    const bool packed = nimg > 0;
+    const int n = packed ? nimg : 1;
+    const int Tt = packed ? wino_pad_tiles(n * T) : batch * Tp;
+    const int img_tiles = packed ? T : Tp, last_tiles = packed ? Tt - (n - 1) * T : Tp, t0 = packed ? 0 : image * Tp;
+    hipLaunchKernelGGL(winograd4_input_kernel<0>, dim3(wg_grid((long)(last_tiles > img_tiles ? last_tiles : img_tiles) * (C / 2), 256), n),
+                       dim3(256), 0, s, reinterpret_cast<const float2*>(x), reinterpret_cast<float2*>(V), H, W, C / 2, TW, T,
+                       img_tiles, pad, reflect, Tt, t0, nullptr, nullptr, nullptr, nullptr, nullptr, img_stride / 2, last_tiles);
     T2V_HIP_CHECK(hipGetLastError());
     return T2V_OK;
 }
@@ -457,20 +467,21 @@ int launch_winograd4_input_lazy(hipStream_t s, const float* x, float* V, int H, 
     // with another padding a tile's own 4x4 block would not tile the input map
     T2V_REQUIRE(relu_only || pad == 1, "winograd4_input_lazy: the side output needs pad == 1");
     const int Ho = H + 2 * pad - 2, Wo = W + 2 * pad - 2;
-    const int TW = (Wo + 3) / 4, T = ((Ho + 3) / 4) * TW, Tp = wino_pad_tiles(T);
+    const int TW = (Wo + 3) / 4, T = ((Ho + 3) / 4) * TW;
+    const int Tt = wino_pad_tiles(nimg * T), last_tiles = Tt - (nimg - 1) * T;      // packed layout
     auto kern = relu_only ? winograd4_input_kernel<1> : winograd4_input_kernel<2>;
-    hipLaunchKernelGGL(kern, dim3(wg_grid((long)Tp * (C / 2), 256), nimg), dim3(256), 0, s, reinterpret_cast<const float2*>(x),
-                       reinterpret_cast<float2*>(V), H, W, C / 2, TW, T, Tp, pad, reflect, nimg * Tp, 0,
+    hipLaunchKernelGGL(kern, dim3(wg_grid((long)last_tiles * (C / 2), 256), nimg), dim3(256), 0, s,
+                       reinterpret_cast<const float2*>(x), reinterpret_cast<float2*>(V), H, W, C / 2, TW, T, T, pad, reflect, Tt, 0,
                        reinterpret_cast<const float2*>(mean_rstd), reinterpret_cast<const float2*>(gamma),
                        reinterpret_cast<const float2*>(beta), reinterpret_cast<const float2*>(res),
-                       reinterpret_cast<float2*>(xout), img_stride / 2);
+                       reinterpret_cast<float2*>(xout), img_stride / 2, last_tiles);
     T2V_HIP_CHECK(hipGetLastError());
     return T2V_OK;
 }
 
 // y = A^T M A + bias; block = 64 channels x 4 tile lanes, 8 tiles (2 per thread) = 128 output pixels
-// blockIdx.z = image of a batch: its tiles are rows [image*Tp, ...) of the batch-wide M ([36][Tt][N]), its map /
-// statistics partials / (mean, rstd) table follow the previous image's.
+// blockIdx.z = image of a batch: its tiles are rows [image*T, (image+1)*T) of the batch-wide M ([36][Tt][N], packed: only
+// the total is padded), its map / statistics partials (Tp/8 per image) / (mean, rstd) table follow the previous image's.
 // TICKET: the last block to finish a (image, 64-channel group) -- an atomic ticket per group -- pools that group's
 // partials itself, in inorm_finalize_kernel's summation order, and writes (mean, rstd): the norm layer's finalize
 // without a launch of its own (partials published write-through, read back with sc1 loads: norm_pool.h).
@@ -483,7 +494,7 @@ __global__ __launch_bounds__(256) void winograd4_output_kernel(const float* __re
     __shared__ float sh[4][64];
     {
         const long im = blockIdx.z;
-        Mm += im * Tp * N;                       // row offset image*Tp inside every position's [Tt][N] matrix
+        Mm += im * T * N;                        // packed layout: image i owns rows [i*T, (i+1)*T) of every position's [Tt][N] matrix
         y += im * H * W * N;
         if (stats) stats += im * (Tp / 8) * N;
         if (TICKET) {
@@ -546,10 +557,12 @@ int launch_winograd4_output(hipStream_t s, const float* Mm, const float* bias, f
         T2V_REQUIRE(stats && mean_rstd && Tp / 8 <= kTicketMaxParts, "winograd4_output: ticket finalize needs statistics and "
                     "<= %d partials per channel", kTicketMaxParts);
         hipLaunchKernelGGL(winograd4_output_kernel<true>, grid, dim3(256), 0, s, Mm, bias, y, reinterpret_cast<float2*>(stats),
-                           H, W, N, TW, T, Tp, lrelu, slope, nimg * Tp, tickets, reinterpret_cast<float2*>(mean_rstd), eps);
+                           H, W, N, TW, T, Tp, lrelu, slope, wino_pad_tiles(nimg * T), tickets,
+                           reinterpret_cast<float2*>(mean_rstd), eps);
     } else {
         hipLaunchKernelGGL(winograd4_output_kernel<false>, grid, dim3(256), 0, s, Mm, bias, y,
-                           reinterpret_cast<float2*>(stats), H, W, N, TW, T, Tp, lrelu, slope, nimg * Tp, nullptr, nullptr, eps);
+                           reinterpret_cast<float2*>(stats), H, W, N, TW, T, Tp, lrelu, slope, wino_pad_tiles(nimg * T), nullptr,
+                           nullptr, eps);
     }
     T2V_HIP_CHECK(hipGetLastError());
     return T2V_OK;
