@@ -33,7 +33,7 @@ def _rccl_worker(tmp):
     """runs in its own process: 1-rank RCCL group; GradientExchange buckets on device gradients, gather_frames of
     uint8 frames, exchange_tails, and a whole Vid2VidTrainer step with the exchange forced on."""
     os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29534",
-                      T2V_TRAIN_FORCE_DIST="1")
+                      T2V_TRAIN_FORCE_DIST="1", T2V_TRAIN_COMM_TIMING="1")
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     torch.cuda.set_device(0)
@@ -73,6 +73,8 @@ def _rccl_worker(tmp):
     real[..., :3] = torch.tanh(torch.randn(2, 64, 64, 3, generator=g)).cuda()
     losses, _ = tr.train_step(pose, real, None, None, real_prev=real.flip(0).contiguous())
     out["comm_bytes"] = tr.comm_bytes
+    out["comm_ms_exposed"] = tr.comm_ms         # what of the exchange was still running when the backward kernels had drained
+    out["buckets"] = [len(tr.bucketsG.bounds), len(tr.bucketsD.bounds)]
     out["n_param_bytes"] = 4 * sum(p.numel() for p in tr.optG.params + tr.optD.params if p.grad is not None)
     out["losses_finite"] = all(np.isfinite(v) for v in losses.values())
     # the same step with the reduce-scatter + all-gather form of the exchange (in place on the flat buckets)
@@ -102,6 +104,9 @@ def test_rccl_collectives_execute_on_device_tensors(tmp_path):
     assert d["bytes"] == 4 * (5 + 70000 + 3 + (1 << 18) + 17)
     assert d["comm_bytes"] == d["n_param_bytes"] > 0         # every gradient of the step went through the exchange
     assert d["rs_ag_bytes"] == d["comm_bytes"] and d["rs_ag_same_losses"] and d["rs_ag_same_weights"]
+    print("1-rank RCCL gradient exchange: %.1f MB in %s buckets, %.3f ms exposed after the backward pass"
+          % (d["comm_bytes"] / 2**20, d["buckets"], d["comm_ms_exposed"]))
+    assert 0.0 <= d["comm_ms_exposed"] < 1000.0
 
 
 def test_config2_chunk_plan_with_the_real_generator_matches_oracle_per_chunk():
