@@ -15,7 +15,16 @@ ap.add_argument("--iters", type=int, default=3)
 ap.add_argument("--no_flow", action="store_true")
 ap.add_argument("--no_face", action="store_true")
 ap.add_argument("--vgg", action="store_true", help="add the VGG19 perceptual loss (seeded random weights)")
+ap.add_argument("--force_dist", action="store_true", help="run the gradient exchange on a 1-rank RCCL group and report its "
+                "bytes, buckets and the part still running after the backward pass")
 args = ap.parse_args()
+if args.force_dist:
+    import torch.distributed as dist
+    os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", T2V_TRAIN_FORCE_DIST="1",
+                      T2V_TRAIN_COMM_TIMING="1")
+    os.environ.setdefault("MASTER_PORT", "29577")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
 argv = ["--name", "b", "--dataset_mode", "pose", "--input_nc", "3", "--openpose_only", "--num_D", "2", "--max_frames_per_gpu",
         str(args.frames), "--n_scales_temporal", "0", "--no_first_img", "--fineSize", str(args.size)]
 argv += ["--vgg_random_init"] if args.vgg else ["--no_vgg"]
@@ -51,3 +60,8 @@ dt = (time.perf_counter() - t0) / args.iters
 print("train step %dx%d, %d frames, %s%s%s: %.1f ms/step, peak mem %.1f GB | %s"
       % (H, W, F, "no flow" if args.no_flow else "flow branch on", "" if args.no_face else " + face D", " + VGG" if args.vgg else "",
          dt * 1e3, torch.cuda.max_memory_allocated() / 2**30, " ".join("%s %.3f" % kv for kv in losses.items())))
+if args.force_dist:
+    print("gradient exchange (1-rank RCCL%s): %.1f MB per step in %d + %d buckets, %.2f ms still running after the backward pass"
+          % (", reduce-scatter + all-gather" if os.environ.get("T2V_GRAD_RS_AG") == "1" else ", all-reduce", tr.comm_bytes / 2**20,
+             len(tr.bucketsG.bounds), len(tr.bucketsD.bounds), tr.comm_ms))
+    dist.destroy_process_group()
