@@ -437,3 +437,42 @@ def test_direct_gradient_delivery_equals_autograd_accumulation_and_launches_no_a
     # what is left are the scalar loss sums and autograd's accumulation of ACTIVATION gradients (a frame read by several
     # losses), not parameter gradients
     assert adds["0"] > 50 and adds["1"] <= adds["0"] // 2
+
+
+def test_shared_discriminator_forward_equals_the_two_forward_form(monkeypatch):
+    """One discriminator forward on the fake frames serves D's loss (through D's parameters) and G's loss (through the
+    frames, D's parameter gradients switched off for that backward pass).  Against the two-forward form upstream runs
+    (T2V_D_SHARED_FWD=0: D(fake.detach()) and D(fake) with frozen parameters): the same losses, the same updated weights,
+    the same BatchNorm running statistics -- bit for bit -- with the image, face and temporal discriminators on."""
+    from text2video_amd import train as T
+    from text2video_amd.options import TrainOptions
+    opt = TrainOptions().parse(["--name", "t", "--dataset_mode", "pose", "--input_nc", "3", "--openpose_only", "--ngf", "16",
+                                "--n_downsample_G", "2", "--n_blocks", "2", "--num_D", "2", "--ndf", "16", "--no_vgg",
+                                "--max_frames_per_gpu", "2", "--n_scales_temporal", "1", "--no_first_img", "--add_face_disc"])
+    H, W = 64, 128
+    rng = np.random.default_rng(21)
+    pose = torch.zeros(2, H, W, 12, device="cuda:0")
+    pose[..., :9] = torch.from_numpy(rng.uniform(-1, 1, (2, H, W, 9)).astype(np.float32)).cuda()
+    real = torch.zeros(2, H, W, 4, device="cuda:0")
+    real[..., :3] = torch.tanh(torch.from_numpy(rng.standard_normal((2, H, W, 3)).astype(np.float32))).cuda()
+    real_prev = torch.cat([real[1:], real[:1]], 0).contiguous()
+    boxes = [(8, 40, 40, 72)] * 2
+    runs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("T2V_D_SHARED_FWD", mode)
+        tr = T.Vid2VidTrainer(opt, "cuda:0", seed=17)
+        l1, prev = tr.train_step(pose, real, boxes, None, real_prev=real_prev)
+        l2, _ = tr.train_step(pose, real, boxes, prev, real_prev=real_prev)          # temporal windows full from here on
+        nets = [tr.G, tr.D, tr.Df] + tr.DT
+        weights = [p.detach().clone() for n in nets for p in n.parameters()]
+        stats = [T.running_stats(p, create=False) for n in nets for k, p in n.named_upstream_parameters().items()
+                 if k.endswith(".weight") and p.dim() == 1]
+        runs[mode] = (l1, l2, weights, [(s[0].clone(), s[1].clone(), s[2]) for s in stats if s is not None])
+    a, b = runs["1"], runs["0"]
+    for la, lb in ((a[0], b[0]), (a[1], b[1])):
+        assert la.keys() == lb.keys() and all(la[k] == lb[k] for k in la), [(k, la[k], lb[k]) for k in la if la[k] != lb[k]]
+    assert "D_T0" in a[1] and "D_f" in a[1]
+    assert all(torch.equal(x, y) for x, y in zip(a[2], b[2]))
+    assert len(a[3]) == len(b[3]) > 4
+    for (m1, v1, n1), (m2, v2, n2) in zip(a[3], b[3]):
+        assert n1 == n2 and torch.equal(m1, m2) and torch.equal(v1, v2)

@@ -170,6 +170,30 @@ def flush_pending_weight_gradients(params, grads):
 
 
 BN_MOMENTUM = 0.1     # nn.BatchNorm2d default ($SP/torch/nn/modules/batchnorm.py:16)
+_BN_UPDATES = [1]     # running-statistics updates per forward (a forward that stands for two upstream forwards: 2)
+_NO_PARAM_GRAD = set()   # ids of parameters whose gradients the backward pass under way must not produce
+
+
+@contextlib.contextmanager
+def param_gradients_off(params):
+    """Scope of a backward pass that runs THROUGH layers whose parameters belong to another loss: their nodes only
+    propagate the data gradient (no weight-gradient kernels, nothing delivered to their gradient slots)."""
+    ids = {id(getattr(p, "_t2v_owner", p)) for p in params}
+    _NO_PARAM_GRAD.update(ids)
+    try:
+        yield
+    finally:
+        _NO_PARAM_GRAD.difference_update(ids)
+
+
+@contextlib.contextmanager
+def bn_updates(n):
+    old = _BN_UPDATES[0]
+    _BN_UPDATES[0] = n
+    try:
+        yield
+    finally:
+        _BN_UPDATES[0] = old
 
 
 def running_stats(gamma, create=True):
@@ -191,8 +215,9 @@ def track_running_stats(gamma, mean_rstd, n):
     if gamma is None or n < 2 or os.environ.get("T2V_BN_RUNNING", "1") == "0":
         return
     rs = running_stats(gamma)
-    ops.batch_norm_update_running(mean_rstd, rs[0], rs[1], n, BN_MOMENTUM)
-    rs[2] += 1
+    for _ in range(_BN_UPDATES[0]):
+        ops.batch_norm_update_running(mean_rstd, rs[0], rs[1], n, BN_MOMENTUM)
+        rs[2] += 1
 
 
 _ZEROS = {}
@@ -289,11 +314,15 @@ class _ConvBlock(torch.autograd.Function):
         dy = dy.contiguous()
         B = x.shape[0]
         dgamma = dbeta = None
+        # a backward pass that only passes THROUGH this layer (param_gradients_off): data gradient only
+        want = [bool(v) for v in ctx.needs_input_grad]
+        if _NO_PARAM_GRAD and id(getattr(w, "_t2v_owner", w)) in _NO_PARAM_GRAD:
+            want[1] = want[2] = want[3] = want[4] = False
         # parameters with a bucket slot get their gradients delivered in place (and None goes back to autograd)
-        sl_w = grad_slot(w) if ctx.needs_input_grad[1] else None
-        sl_b = grad_slot(b) if ctx.needs_input_grad[2] else None
-        sl_g = grad_slot(gamma) if (affine and ctx.needs_input_grad[3]) else None
-        sl_bt = grad_slot(beta) if (affine and ctx.needs_input_grad[4]) else None
+        sl_w = grad_slot(w) if want[1] else None
+        sl_b = grad_slot(b) if want[2] else None
+        sl_g = grad_slot(gamma) if (affine and want[3]) else None
+        sl_bt = grad_slot(beta) if (affine and want[4]) else None
         both = sl_g is not None and sl_bt is not None
 
         def affine_sums(sums):       # [C,2] = (sum g, sum g*xhat) -> d beta, d gamma
@@ -311,20 +340,20 @@ class _ConvBlock(torch.autograd.Function):
             dc = ops.act_backward(dy, y_act, 4 if act == ops.ACT_FLOW_W else act, slope) if act != ops.ACT_NONE else dy
         elif norm == "batch":
             dc, sums = ops.instance_norm_backward(c, dy, mrs[0], gamma, beta, relu)
-            if affine:
+            if affine and (want[3] or want[4]):
                 affine_sums(sums)
         else:
             dc = torch.empty_like(c)
             for i in range(B):
                 _, s_i = ops.instance_norm_backward(c[i], dy[i], mrs[i], gamma, beta, relu, out=dc[i])
-                if affine:
+                if affine and (want[3] or want[4]):
                     affine_sums(s_i)
         if both:
             sl_g.owner.node_done(sl_g)
             sl_bt.owner.node_done(sl_bt)
         # a bias in front of a norm layer has an exactly zero gradient (the norm removes the channel mean)
         db = None
-        if ctx.needs_input_grad[2]:
+        if want[2]:
             if sl_b is not None:
                 if norm is None:
                     if sl_b.filled:
@@ -337,7 +366,7 @@ class _ConvBlock(torch.autograd.Function):
                     deliver(sl_b, zero=True)
             else:
                 db = ops.channel_sum(dc, desc.Cout) if norm is None else _zeros(desc.Cout, x.device)
-        if not ctx.needs_input_grad[1]:      # frozen weights (the VGG19 feature extractor): data gradient only
+        if not want[1]:      # frozen weights (the VGG19 feature extractor) / a pass-through backward: data gradient only
             dw = None
         elif wino_wgrad == 2:
             dw = _batched_winograd_wgrad(w, x, dc, fdesc, sl_w)
@@ -748,14 +777,16 @@ class HipVGG19Features(torch.nn.Module):
         return taps
 
 
-def vgg_loss(vgg, fake, real):
+def vgg_loss(vgg, fake, real, real_feats=None):
     """VGGLoss [RECALL upstream models/networks.py]: sum_i w_i * L1(vgg(fake)_i, vgg(real)_i.detach()),
     w = 1/32, 1/16, 1/8, 1/4, 1.  Upstream first halves inputs wider than 1024 px with AvgPool2d(2, 2); that only
     happens in multi-scale (n_scales_spatial > 1) training, which this train step does not cover."""
     if fake.shape[2] > 1024:
         raise NotImplementedError("vgg_loss: inputs wider than 1024 px (upstream's AvgPool2d(2,2) pre-scaling)")
-    with torch.no_grad():
-        fr = vgg(real)
+    fr = real_feats          # the real frames' taps, when the caller already has them (two fake inputs, one real)
+    if fr is None:
+        with torch.no_grad():
+            fr = vgg(real)
     ff = vgg(fake)
     return sum(wi * _L1.apply(a, b, a.numel()) for wi, a, b in zip(VGG_WEIGHTS, ff, fr))
 
@@ -1248,10 +1279,24 @@ class Vid2VidTrainer:
         # compute_loss_D(netD, real_A, real_B, fake) [RECALL upstream Vid2VidModelD]: real pass, fake pass on the
         # detached frame (D's loss), fake pass for G's GAN + feature-matching loss.  The generator-side passes run
         # with D's parameters detached: only their data gradient is wanted.
+        # One forward on the fake frames serves both losses (T2V_D_SHARED_FWD=0: two forwards, as upstream runs them): D's
+        # loss reaches D's parameters through it, G's loss reaches the frames through it with D's parameter gradients
+        # switched off for that backward pass (param_gradients_off) -- the same values either way, a D forward less per
+        # fake input.  The running statistics still move twice (upstream's two forwards).
+        shared = os.environ.get("T2V_D_SHARED_FWD", "1") != "0"
+        self._shared_d = shared
+
+        def d_fake(net, x_attached):
+            """-> (prediction for D's loss, prediction for G's loss)"""
+            if shared:
+                with bn_updates(2):
+                    pf = net(x_attached)
+                return pf, pf
+            return net(x_attached.detach()), net(x_attached, frozen=True)
+
         pr = self.D(self._d_input(A3, real))
-        pfd = self.D(self._d_input(A3, fake.detach()))
+        pfd, pfg = d_fake(self.D, self._d_input(A3, fake))
         loss_D_real, loss_D_fake = gan_loss(pr, True), gan_loss(pfd, False)
-        pfg = self.D(self._d_input(A3, fake), frozen=True)
         loss_G_gan = gan_loss(pfg, True)
         loss_G_fm = feature_matching_loss(pfg, pr, opt.n_layers_D, opt.lambda_feat) if not opt.no_ganFeat else 0.0
         raw = fw_all = None
@@ -1260,8 +1305,7 @@ class Vid2VidTrainer:
             # real pass returns the values of the first (same weights, same batch): that term is simply added again
             raw = torch.cat(raws, 0)
             fw_all = torch.cat(fws, 0) if real_prev is not None else None
-            pfd_r = self.D(self._d_input(A3, raw.detach()))
-            pfg_r = self.D(self._d_input(A3, raw), frozen=True)
+            pfd_r, pfg_r = d_fake(self.D, self._d_input(A3, raw))
             loss_D_real = loss_D_real + gan_loss(pr, True)
             loss_D_fake = loss_D_fake + gan_loss(pfd_r, False)
             loss_G_gan = loss_G_gan + gan_loss(pfg_r, True)
@@ -1271,9 +1315,11 @@ class Vid2VidTrainer:
         loss_G = loss_G_gan + loss_G_fm
         loss_G_vgg = None
         if self.vgg is not None:   # [RECALL upstream: criterionVGG(fake_B, real_B) * lambda_feat (+ the same on fake_B_raw)]
-            loss_G_vgg = vgg_loss(self.vgg, fake, real) * opt.lambda_feat
+            with torch.no_grad():
+                real_taps = self.vgg(real)
+            loss_G_vgg = vgg_loss(self.vgg, fake, real, real_taps) * opt.lambda_feat
             if flow_on:
-                loss_G_vgg = loss_G_vgg + vgg_loss(self.vgg, raw, real) * opt.lambda_feat
+                loss_G_vgg = loss_G_vgg + vgg_loss(self.vgg, raw, real, real_taps) * opt.lambda_feat
             loss_G = loss_G + loss_G_vgg
         def _f(t):   # kept on the device: one host read at the end of the step instead of a sync per loss term
             return t.detach() if torch.is_tensor(t) else float(t)
@@ -1318,9 +1364,8 @@ class Vid2VidTrainer:
             def crop(t):
                 return torch.stack([t[i, b[0]:b[1], b[2]:b[3]] for i, b in enumerate(face_boxes)]).contiguous()
             fr = self.Df(self._d_input(crop(A3), crop(real)))
-            ffd = self.Df(self._d_input(crop(A3), crop(fake.detach())))
+            ffd, ffg = d_fake(self.Df, self._d_input(crop(A3), crop(fake)))
             loss_Df = 0.5 * (gan_loss(ffd, False) + gan_loss(fr, True))
-            ffg = self.Df(self._d_input(crop(A3), crop(fake)), frozen=True)
             # face_weight = 2 on the generator's face terms [RECALL upstream Vid2VidModelD.forward]
             lg = gan_loss(ffg, True) * 2.0
             lf = feature_matching_loss(ffg, fr, opt.n_layers_D, opt.lambda_feat) * 2.0 if not opt.no_ganFeat else 0.0
@@ -1347,9 +1392,8 @@ class Vid2VidTrainer:
                     return torch.stack(rows).contiguous()
                 tr, tf = stack(reals), stack(fks)
                 pr_t = dt(tr)
-                pfd_t = dt(tf.detach())
+                pfd_t, pfg_t = d_fake(dt, tf)
                 l_dt = 0.5 * (gan_loss(pfd_t, False) + gan_loss(pr_t, True))
-                pfg_t = dt(tf, frozen=True)
                 lg = gan_loss(pfg_t, True)
                 lf = feature_matching_loss(pfg_t, pr_t, opt.n_layers_D, opt.lambda_feat) if not opt.no_ganFeat else 0.0
                 loss_G = loss_G + lg + lf
@@ -1364,7 +1408,8 @@ class Vid2VidTrainer:
         # left goes out in absorb() -- all of it in flight under the discriminators' backward pass
         self.bucketsG.seal()
         self.bucketsD.seal()
-        gG = torch.autograd.grad(loss_G, g_params, retain_graph=True, allow_unused=True)
+        with param_gradients_off(d_params if getattr(self, "_shared_d", False) else []):
+            gG = torch.autograd.grad(loss_G, g_params, retain_graph=True, allow_unused=True)
         gG = flush_pending_weight_gradients(g_params, gG)
         self.bucketsG.absorb(gG)
         gD = torch.autograd.grad(loss_D, d_params, allow_unused=True)
