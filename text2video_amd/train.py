@@ -303,6 +303,8 @@ class _ConvBlock(torch.autograd.Function):
             wino_wgrad = 2
         for prm in (w, b, gamma, beta):
             expect_gradient(prm)
+        # (an input nobody differentiates -- the discriminators' real pass -- needs no data-gradient conv)
+        need_dx = bool(need_dx and ctx.needs_input_grad[0])
         ctx.meta = (desc, ddesc, norm, relu, act, need_dx, mrs, gamma is not None, wino_wgrad, slope)
         ctx.save_for_backward(x, w, c, gamma, beta, y if (norm is None and act != ops.ACT_NONE) else None, b)
         return y
