@@ -37,3 +37,16 @@ np.savez_compressed(os.path.join(HERE, "pose_maps_jitter.npz"), maps=np.stack(ma
                     names=np.array([c[0] for c in cases]), seeds=np.array([c[1] for c in cases]),
                     probs=np.array([c[2] for c in cases]), remove=np.array([c[3] for c in cases]))
 print("jitter goldens:", np.stack(maps).shape, [int((m != 0).any(2).sum()) for m in maps])
+
+# the remaining options of read_keypoints: basic_point_only (no hands / face), other canvas sizes (key points are NOT
+# rescaled: a smaller canvas clips the skeleton, a larger one leaves it in the corner -- keypoint2img.py:70-90)
+opt_maps, opt_cases = [], []
+for frame, size, bpo in ((17, (512, 384), True), (0, (512, 384), True), (17, (256, 192), False), (17, (1280, 720), False),
+                         (0, (320, 512), False)):
+    name = "sa1_%03d_keypoints.json" % frame
+    opt_maps.append(keypoint2img.read_keypoints(os.path.join(HERE, "keypoints_fadg0", name), size, 0, False, bpo))
+    opt_cases.append((name, size[0], size[1], int(bpo)))
+np.savez_compressed(os.path.join(HERE, "pose_maps_options.npz"), names=np.array([c[0] for c in opt_cases]),
+                    sizes=np.array([[c[1], c[2]] for c in opt_cases]), basic=np.array([c[3] for c in opt_cases]),
+                    **{"map%d" % i: m for i, m in enumerate(opt_maps)})
+print("option goldens:", [(c, int((m != 0).any(2).sum())) for c, m in zip(opt_cases, opt_maps)])

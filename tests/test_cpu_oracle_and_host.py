@@ -112,6 +112,21 @@ def test_rasteriser_training_jitter_and_drops_match_reference_golden_maps():
     assert not np.array_equal(a, b)
 
 
+def test_rasteriser_options_match_reference_golden_maps():
+    """basic_point_only (pose limbs only) and canvas sizes other than the L2 driver's 512x384 -- key points are not
+    rescaled, the canvas clips or leaves room (/root/reference/keypoint2img.py:70-90) -- bit-exact against maps captured
+    from the reference (tests/golden/make_jitter_golden.py)."""
+    from text2video_amd.keypoints import read_keypoints
+    g = np.load(os.path.join(GOLD, "pose_maps_options.npz"))
+    for i, (name, size, basic) in enumerate(zip(g["names"], g["sizes"], g["basic"])):
+        want = g["map%d" % i]
+        got = read_keypoints(os.path.join(GOLD, "keypoints_fadg0", str(name)), (int(size[0]), int(size[1])), 0, False, bool(basic),
+                             hand_discs=False)
+        assert got.shape == want.shape == (int(size[1]), int(size[0]), 3)
+        assert np.array_equal(got, want), (name, tuple(size), basic)
+        assert (want != 0).any(2).sum() > 500
+
+
 def test_rasteriser_hand_discs_and_colour_key():
     from text2video_amd.keypoints import NOSE_NECK_RGB, read_keypoints
     p = os.path.join(GOLD, "keypoints_fadg0", "sa1_000_keypoints.json")
