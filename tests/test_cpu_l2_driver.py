@@ -11,17 +11,21 @@ from text2video_amd import l2_driver as L
 HERE = os.path.dirname(os.path.abspath(__file__))
 INPUTS = os.path.join(HERE, "golden", "l2_inputs")
 CASES = [("She had your dark suit in greasy wash water all year.", "fadg0", L.PHONEME, "l2_driver_Shehadyour.npz", 87),
-         ("你好啊", "henan", L.PINYIN, "l2_driver_pinyin_nihaoa.npz", 16)]
+         ("你好啊", "henan", L.PINYIN, "l2_driver_pinyin_nihaoa.npz", 16),
+         # a second utterance per driver (tests/golden/make_host_goldens_more.py): other key poses, long gaps, skips
+         ("she slipped on the floor", "fadg0", L.PHONEME, "l2_driver_sheslipped.npz", None),
+         ("今天天气好极了不冷不", "henan", L.PINYIN, "l2_driver_pinyin_jintiantianqi.npz", 150)]
 
 
-@pytest.mark.parametrize("case", CASES, ids=["phoneme_fadg0", "pinyin_henan"])
+@pytest.mark.parametrize("case", CASES, ids=["phoneme_fadg0", "pinyin_henan", "phoneme_fadg0_sheslipped", "pinyin_henan_weather"])
 def test_sequences_match_reference_bit_for_bit(case):
     text, person, spec, gold, n = case
     g = np.load(os.path.join(HERE, "golden", gold))
     raw, smooth = L.synthesize(text, person, INPUTS, spec)
     a = np.stack([L.pose_vector(j) for j in raw])
     b = np.stack([L.pose_vector(j) for j in smooth])
-    assert a.shape == b.shape == (n, 285)
+    n = g["tmp"].shape[0] if n is None else n
+    assert a.shape == b.shape == (n, 285) and n >= 16
     assert np.array_equal(a, g["tmp"]), np.abs(a - g["tmp"]).max()
     assert np.array_equal(b, g["tmp_smooth"]), np.abs(b - g["tmp_smooth"]).max()
 
