@@ -213,6 +213,21 @@ int t2v_conv2d_backward_weight_winograd_stages(t2v_ctx* ctx, void* stream, const
                                                int nb, const float* x, int x_cs, const float* dy, int dy_cs,
                                                float* dw_torch, int accumulate, float* workspace, int stages);
 
+/* Data gradient of a 3x3 stride-1 ReflectionPad(1) conv by the TRANSPOSED Winograd algorithm (updateGradInput of
+ * SpatialConvolutionMM + SpatialReflectionPadding_updateGradInput, THCUNN.h:664,952): forward is V = B^T d B, M = U V,
+ * Y = A^T M A; its transpose is dM = A dy A^T -- the tensor the Winograd-domain weight gradient builds anyway, read here
+ * out of ITS workspace (slot `slot` of `batch`, after t2v_conv2d_backward_weight_winograd_stages(stages & 1)) -- then
+ * dV = U^T dM (36 GEMMs over the layer's own T tiles, against (H+2)(W+2)/16 for the full-correlation form), the 6x6 patches
+ * B dV B^T overlap-added into the padded gradient and folded by the reflect-pad adjoint.  `d` is the FORWARD descriptor;
+ * H, W multiples of 4; ut_packed from t2v_conv_pack_weight_transposed (the forward weight's transform, transposed, no flip). */
+int t2v_conv_backward_data_winograd_supported(const t2v_conv_desc* d, int x_cs, int dy_cs);
+size_t t2v_conv_backward_data_winograd_weight_floats(const t2v_conv_desc* d, int x_cs);
+size_t t2v_conv_backward_data_winograd_scratch_floats(const t2v_conv_desc* d, int x_cs);
+int t2v_conv_pack_weight_transposed(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, int x_cs, const float* w_forward_dev,
+                                    float* packed_dev);
+int t2v_conv2d_backward_data_winograd(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, int batch, int slot,
+                                      const float* wgrad_workspace, int x_cs, const float* ut_packed, float* scratch, float* dx);
+
 int t2v_conv_unpack_weight(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, int x_cs, const float* packed_dev,
                            float* w_torch_dev);
 /* unpack_weight with a destination that may already hold a gradient: accumulate != 0 adds (w_torch += unpacked).  The

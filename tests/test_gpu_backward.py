@@ -298,3 +298,38 @@ def test_in_kernel_combine_of_split_weight_gradients_equals_the_reduce_launch(mo
             assert torch.equal(outs[("1", rep)][0], outs[("0", 0)][0]), (B, H, W, Cin, Cout, stride, tr)
             assert torch.equal(outs[("1", rep)][1], outs[("0", 0)][1])
         assert outs[("0", 0)][0].abs().max().item() > 1.0
+
+
+@pytest.mark.parametrize("H,W,Cin,Cout", [(32, 32, 64, 64), (16, 32, 128, 64), (64, 64, 128, 128)], ids=["32x32", "16x32", "64x64"])
+def test_transposed_winograd_data_gradient_matches_autograd(H, W, Cin, Cout):
+    """Data gradient of the ResnetBlock conv (3x3, ReflectionPad 1) by the transposed Winograd algorithm: A dy A^T is read out
+    of the weight gradient's batch workspace (two images, both slots), dV = U^T dM on the layer's own tiles, patches
+    overlap-added and folded.  Against torch autograd on the CPU (fp64) and against the full-correlation form."""
+    from text2video_amd import ops
+    from text2video_amd.backward import ConvDataGrad
+    g = torch.Generator().manual_seed(3)
+    B = 2
+    x = torch.randn(B, Cin, H, W, generator=g, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g, dtype=torch.float64) * 0.1
+    dy = torch.randn(B, Cout, H, W, generator=g, dtype=torch.float64)
+    y = torch.nn.functional.conv2d(torch.nn.functional.pad(x, (1, 1, 1, 1), mode="reflect"), w)
+    (want,) = torch.autograd.grad(y, x, dy)
+    desc = ops.with_algo(ops.conv_desc(H, W, Cin, Cout, 3, 1, 1, ops.PAD_REFLECT), ops.ALGO_WINOGRAD_F4)
+    assert ops.backward_data_winograd_supported(desc, Cin, Cout)
+    xs = x.detach().float().permute(0, 2, 3, 1).contiguous().cuda()
+    dys = dy.float().permute(0, 2, 3, 1).contiguous().cuda()
+    wd = w.float().cuda()
+    ws = ops.backward_weight_winograd_workspace(desc, Cin, B, "cuda:0")
+    ops.conv2d_backward_weight_winograd_stages(xs[0:1], dys[0:1], desc, ws, B, 0, False)      # slot 0
+    ops.conv2d_backward_weight_winograd_stages(xs[1:2], dys[1:2], desc, ws, B, 1, False)      # slot 1
+    ut = ops.pack_conv_weight_transposed(wd, desc, Cin)
+    full = ConvDataGrad(desc).refresh(wd)
+    scale = want.abs().max().item()
+    for b in range(B):
+        got = ops.conv2d_backward_data_winograd(desc, B, b, ws, Cin, ut).permute(2, 0, 1).cpu().double()
+        err = (got - want[b]).abs().max().item() / scale
+        ref = full(dys[b]).permute(2, 0, 1).cpu().double()
+        err_full = (ref - want[b]).abs().max().item() / scale
+        print("%dx%d C%d->%d image %d: transposed algorithm %.2e, full-correlation form %.2e (relative to max|dx|)"
+              % (H, W, Cin, Cout, b, err, err_full))
+        assert err <= 2e-5 and err <= 4 * err_full + 1e-6

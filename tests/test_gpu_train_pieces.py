@@ -210,7 +210,7 @@ def test_trainer_batches_the_frames_winograd_weight_gradients(tmp_path, monkeypa
     prev[..., :6] = torch.tanh(torch.randn(1, S, S, 6, generator=g)).cuda()
     calls, grads = [], {}
     orig = T._batched_winograd_wgrad
-    monkeypatch.setattr(T, "_batched_winograd_wgrad", lambda w, x, dc, d, slot=None: (calls.append(x.shape[0]), orig(w, x, dc, d, slot))[1])
+    monkeypatch.setattr(T, "_batched_winograd_wgrad", lambda w, x, dc, d, *rest: (calls.append(x.shape[0]), orig(w, x, dc, d, *rest))[1])
     for mode in ("1", "0"):
         monkeypatch.setenv("T2V_WGRAD_BATCH", mode)
         tr = T.Vid2VidTrainer(TrainOptions().parse(args), "cuda:0")

@@ -79,6 +79,12 @@ SIGNATURES = {
     "t2v_conv2d_backward_weight": (c_int, [c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_void_p, c_int, c_void_p,
                                            c_int, c_void_p, c_int, c_void_p]),
     "t2v_conv_unpack_weight": (c_int, [c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_void_p, c_void_p]),
+    "t2v_conv_backward_data_winograd_supported": (c_int, [POINTER(ConvDesc), c_int, c_int]),
+    "t2v_conv_backward_data_winograd_weight_floats": (c_size_t, [POINTER(ConvDesc), c_int]),
+    "t2v_conv_backward_data_winograd_scratch_floats": (c_size_t, [POINTER(ConvDesc), c_int]),
+    "t2v_conv_pack_weight_transposed": (c_int, [c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_void_p, c_void_p]),
+    "t2v_conv2d_backward_data_winograd": (c_int, [c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_int, c_void_p, c_int, c_void_p,
+                                                  c_void_p, c_void_p]),
     "t2v_conv_unpack_weight_into": (c_int, [c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_void_p, c_void_p, c_int]),
     "t2v_accumulate": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int]),
     "t2v_scale": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_float]),

@@ -693,6 +693,57 @@ int t2v_conv2d_backward_weight_winograd(t2v_ctx* ctx, void* stream, const t2v_co
                                                       accumulate, workspace, 3);
 }
 
+// ---- data gradient by the transposed Winograd algorithm (winograd.hip: winograd4_dgrad_output_kernel) -------------------
+static bool dgrad_winograd_ok(const t2v_conv_desc* d, int x_cs, int dy_cs) {
+    return wgrad_winograd_ok(d, x_cs, dy_cs) && d->pad_mode == T2V_PAD_REFLECT && d->pad == 1 && d->H % 4 == 0 && d->W % 4 == 0 &&
+           d->Cout % kBK == 0;
+}
+int t2v_conv_backward_data_winograd_supported(const t2v_conv_desc* d, int x_cs, int dy_cs) {
+    return d && dgrad_winograd_ok(d, x_cs, dy_cs) ? 1 : 0;
+}
+size_t t2v_conv_backward_data_winograd_weight_floats(const t2v_conv_desc* d, int x_cs) {
+    if (!d) return 0;
+    return (size_t)36 * round_up(x_cs, 128) * round_up(d->Cout, kBK);
+}
+size_t t2v_conv_backward_data_winograd_scratch_floats(const t2v_conv_desc* d, int x_cs) {
+    if (!d) return 0;
+    return (size_t)36 * wino_tiles_padded(d, T2V_ALGO_WINOGRAD_F4) * x_cs + (size_t)(d->H + 2) * (d->W + 2) * x_cs;
+}
+int t2v_conv_pack_weight_transposed(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, int x_cs, const float* w_forward_dev,
+                                    float* packed_dev) {
+    T2V_REQUIRE(ctx && d && w_forward_dev && packed_dev, "pack_weight_transposed: null pointer");
+    T2V_REQUIRE(dgrad_winograd_ok(d, x_cs, d->Cout), "pack_weight_transposed: shape not supported "
+                                                     "(t2v_conv_backward_data_winograd_supported)");
+    // U^T[xi][c][n]: the rows are the forward layer's INPUT channels, K runs over its OUTPUT channels
+    return launch_winograd4_weight((hipStream_t)stream, w_forward_dev, packed_dev, /*rows*/ d->Cin, /*K*/ d->Cout,
+                                   round_up(x_cs, 128), round_up(d->Cout, kBK), /*transpose, no flip*/ 2);
+}
+int t2v_conv2d_backward_data_winograd(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, int batch, int slot,
+                                      const float* wgrad_workspace, int x_cs, const float* ut_packed, float* scratch, float* dx) {
+    T2V_REQUIRE(ctx && d && wgrad_workspace && ut_packed && scratch && dx && batch >= 1 && slot >= 0 && slot < batch,
+                "backward_data_winograd: bad arguments");
+    T2V_REQUIRE(dgrad_winograd_ok(d, x_cs, d->Cout), "backward_data_winograd: shape not supported");
+    hipStream_t s = (hipStream_t)stream;
+    const int Tp = wino_tiles_padded(d, T2V_ALGO_WINOGRAD_F4), Tt = batch * Tp;
+    // M_dy = A dy A^T of all `batch` images sits behind V in the weight gradient's workspace ([36][Tt][Cout] each)
+    const float* Md = wgrad_workspace + (size_t)36 * Tt * x_cs;
+    float* dV = scratch;
+    float* dxp = scratch + (size_t)36 * Tp * x_cs;
+    // dV[xi][t][c] = sum_n M_dy[xi][slot*Tp + t][n] * U[xi][n][c]: the batched GEMM of a conv with the channel roles swapped,
+    // reading its rows out of the batch-wide matrix (input row pitch Tt, Tp rows per position)
+    t2v_conv_desc da = *d;
+    da.Cin = d->Cout;
+    da.Cout = d->Cin;
+    da.algo = T2V_ALGO_WINOGRAD_F4;
+    ConvPlan pl;
+    T2V_TRY(build_winograd_gemm_plan(&da, &pl));
+    T2V_REQUIRE((long)36 * Tt * d->Cout * 4 < 0x7fff0000L, "backward_data_winograd: M_dy too large for 32-bit buffer offsets");
+    pl.kp.Win = Tt;
+    T2V_TRY(run_conv(ctx, s, pl, Md + (size_t)slot * Tp * d->Cout, ut_packed, nullptr, dV, x_cs, nullptr));
+    T2V_TRY(launch_winograd4_dgrad_output(s, dV, dxp, d->H, d->W, x_cs));
+    return launch_reflect_pad_backward(s, dxp, dx, d->H, d->W, x_cs, 1);
+}
+
 int t2v_conv_unpack_weight_into(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, int x_cs, const float* packed_dev,
                                 float* w_torch_dev, int accumulate) {
     T2V_REQUIRE(ctx && packed_dev && w_torch_dev, "unpack_weight: null pointer");

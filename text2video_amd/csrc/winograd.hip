@@ -286,6 +286,9 @@ __global__ void winograd4_weight_kernel(const float* __restrict__ w, float* __re
 // [Cin of this conv = forward Cout][Cout of this conv = forward Cin][3][3].  A thread per (n, c) with c fastest would
 // gather 36-byte pieces 36 KB apart; instead a block stages the 8 (n) x 32 (c) tile through LDS: per c a contiguous
 // run of 8 x 9 floats is read, and the transformed values leave in 128-byte rows.
+// FLIP = false: transposition only -- U^T of the forward layer, [36][Cin_f as rows][Cout_f as K], for the data gradient by the
+// TRANSPOSED Winograd algorithm (winograd4_dgrad_output_kernel below)
+template <bool FLIP>
 __global__ __launch_bounds__(256) void winograd4_weight_adjoint_kernel(const float* __restrict__ w, float* __restrict__ U,
                                                                        int Cout, int Cin, int Cout_p, int Cin_s) {
     __shared__ float sh[32][8 * 9 + 1];
@@ -303,12 +306,15 @@ __global__ __launch_bounds__(256) void winograd4_weight_adjoint_kernel(const flo
 #pragma unroll
     for (int a = 0; a < 3; ++a)
 #pragma unroll
-        for (int b = 0; b < 3; ++b) g[a][b] = (double)sh[cl][nl * 9 + (2 - a) * 3 + (2 - b)];
+        for (int b = 0; b < 3; ++b) g[a][b] = (double)sh[cl][nl * 9 + (FLIP ? (2 - a) * 3 + (2 - b) : a * 3 + b)];
     winograd4_weight_store(g, U, (size_t)n * Cin_s + c, (size_t)Cout_p * Cin_s);
 }
 int launch_winograd4_weight(hipStream_t s, const float* w, float* U, int Cout, int Cin, int Cout_p, int Cin_s, int adjoint) {
-    if (adjoint)
-        hipLaunchKernelGGL(winograd4_weight_adjoint_kernel, dim3((Cin_s + 31) / 32, (Cout_p + 7) / 8), dim3(256), 0, s, w, U,
+    if (adjoint == 2)
+        hipLaunchKernelGGL(winograd4_weight_adjoint_kernel<false>, dim3((Cin_s + 31) / 32, (Cout_p + 7) / 8), dim3(256), 0, s, w,
+                           U, Cout, Cin, Cout_p, Cin_s);
+    else if (adjoint)
+        hipLaunchKernelGGL(winograd4_weight_adjoint_kernel<true>, dim3((Cin_s + 31) / 32, (Cout_p + 7) / 8), dim3(256), 0, s, w, U,
                            Cout, Cin, Cout_p, Cin_s);
     else
         hipLaunchKernelGGL(winograd4_weight_kernel, dim3(wg_grid((long)Cout_p * Cin_s, 256)), dim3(256), 0, s, w, U, Cout, Cin,
@@ -564,6 +570,95 @@ int launch_winograd4_output(hipStream_t s, const float* Mm, const float* bias, f
                            reinterpret_cast<float2*>(stats), H, W, N, TW, T, Tp, lrelu, slope, wino_pad_tiles(nimg * T), nullptr,
                            nullptr, eps);
     }
+    T2V_HIP_CHECK(hipGetLastError());
+    return T2V_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Data gradient by the TRANSPOSED algorithm.  Forward: V = B^T d B, M = U V, Y = A^T M A per 6x6 patch d of the padded input.
+// Its transpose: dM = A dY A^T (winograd4_dy_kernel -- the tensor the weight gradient needs as well), dV = U^T dM (a batched
+// GEMM over the layer's OWN T tiles: the "full correlation" form works on (H+2) x (W+2) outputs, 289 -> 320 tiles for a 64 x 64
+// map), dd = B dV B^T, and the 6x6 patches dd -- stride 4, two rows / columns of overlap -- are added up into the gradient of
+// the PADDED input, dxp [(H+2)][(W+2)][C] (the reflect-pad adjoint folds it afterwards).  One thread = one 4x4 block of padded
+// pixels x 2 channels: it gathers its 16 values from the (up to) four patches that cover them, each patch element computed
+// exactly once chip-wide, contributions added in a fixed order (own tile, left, top, top-left).  H % 4 == 0 == W % 4.
+struct F4B {   // B = (B^T)^T as a constexpr table: row i = the coefficients of patch row / column i
+    double m[6][6];
+    constexpr F4B() : m{} {
+        for (int r = 0; r < 6; ++r)
+            for (int c = 0; c < 6; ++c) m[c][r] = f4::kBT[r][c];
+    }
+};
+constexpr F4B kF4B{};
+
+template <int DY, int DX>   // source tile = (by - DY, bx - DX); it contributes its patch rows 4*DY.., columns 4*DX..
+__device__ __forceinline__ void dgrad_gather_tile(const float2* __restrict__ dV, long tile, int Tp, int C2, int c2,
+                                                  float (&ox)[4][4], float (&oy)[4][4]) {
+    constexpr int NR = DY ? 2 : 4, NS = DX ? 2 : 4;
+    float tx[6][NS], ty[6][NS];      // stage 1: columns of the patch, per transform row a2
+#pragma unroll
+    for (int a2 = 0; a2 < 6; ++a2) {
+        float vx[6], vy[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const float2 v = dV[((long)(a2 * 6 + j) * Tp + tile) * C2 + c2];
+            vx[j] = v.x;
+            vy[j] = v.y;
+        }
+#pragma unroll
+        for (int sidx = 0; sidx < NS; ++sidx) {
+            tx[a2][sidx] = cdot<6>(kF4B.m[4 * DX + sidx], vx);
+            ty[a2][sidx] = cdot<6>(kF4B.m[4 * DX + sidx], vy);
+        }
+    }
+#pragma unroll
+    for (int sidx = 0; sidx < NS; ++sidx) {
+        float cx[6], cy[6];
+#pragma unroll
+        for (int a2 = 0; a2 < 6; ++a2) {
+            cx[a2] = tx[a2][sidx];
+            cy[a2] = ty[a2][sidx];
+        }
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            ox[r][sidx] += cdot<6>(kF4B.m[4 * DY + r], cx);
+            oy[r][sidx] += cdot<6>(kF4B.m[4 * DY + r], cy);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void winograd4_dgrad_output_kernel(const float2* __restrict__ dV, float2* __restrict__ dxp,
+                                                                     int H, int W, int C2, int TH, int TW, int Tp) {
+    const long total = (long)(TH + 1) * (TW + 1) * C2;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const long blk = i / C2;
+        const int c2 = (int)(i - blk * C2);
+        const int by = (int)(blk / (TW + 1)), bx = (int)(blk - (long)by * (TW + 1));
+        float ox[4][4], oy[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ox[r][q] = oy[r][q] = 0.f;
+        if (by < TH && bx < TW) dgrad_gather_tile<0, 0>(dV, (long)by * TW + bx, Tp, C2, c2, ox, oy);
+        if (by < TH && bx >= 1) dgrad_gather_tile<0, 1>(dV, (long)by * TW + bx - 1, Tp, C2, c2, ox, oy);
+        if (by >= 1 && bx < TW) dgrad_gather_tile<1, 0>(dV, (long)(by - 1) * TW + bx, Tp, C2, c2, ox, oy);
+        if (by >= 1 && bx >= 1) dgrad_gather_tile<1, 1>(dV, (long)(by - 1) * TW + bx - 1, Tp, C2, c2, ox, oy);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int py = 4 * by + r, px = 4 * bx + q;
+                if (py < H + 2 && px < W + 2) dxp[((long)py * (W + 2) + px) * C2 + c2] = make_float2(ox[r][q], oy[r][q]);
+            }
+    }
+}
+// dV [36][Tp][C] of an H x W map (H, W multiples of 4, pad 1) -> dxp [(H+2)][(W+2)][C]
+int launch_winograd4_dgrad_output(hipStream_t s, const float* dV, float* dxp, int H, int W, int C) {
+    T2V_REQUIRE(H % 4 == 0 && W % 4 == 0 && C % 2 == 0, "winograd4_dgrad_output: H, W must be multiples of 4");
+    const int TH = H / 4, TW = W / 4, Tp = wino_pad_tiles(TH * TW);
+    hipLaunchKernelGGL(winograd4_dgrad_output_kernel, dim3(wg_grid((long)(TH + 1) * (TW + 1) * (C / 2), 256)), dim3(256), 0, s,
+                       reinterpret_cast<const float2*>(dV), reinterpret_cast<float2*>(dxp), H, W, C / 2, TH, TW, Tp);
     T2V_HIP_CHECK(hipGetLastError());
     return T2V_OK;
 }

@@ -430,6 +430,32 @@ def conv2d_backward_weight_winograd_reduce(desc, ws, batch, x_cs, dy_cs, out=Non
     return dw
 
 
+def backward_data_winograd_supported(desc, x_cs, dy_cs):
+    return bool(_lib.load().t2v_conv_backward_data_winograd_supported(ctypes.byref(desc), x_cs, dy_cs))
+
+
+def pack_conv_weight_transposed(w, desc, x_cs):
+    """U^T of a forward 3x3 layer (torch weight [Cout,Cin,3,3] on the device) for conv2d_backward_data_winograd."""
+    c = context()
+    n = c.lib.t2v_conv_backward_data_winograd_weight_floats(ctypes.byref(desc), x_cs)
+    out = torch.empty(n, dtype=torch.float32, device=w.device)
+    check(c.lib.t2v_conv_pack_weight_transposed(c.handle, _stream(), ctypes.byref(desc), x_cs, _p(w.contiguous()), _p(out)),
+          "conv_pack_weight_transposed")
+    return out
+
+
+def conv2d_backward_data_winograd(desc, batch, slot, wgrad_ws, x_cs, ut, out=None):
+    """dx [H,W,x_cs] of image `slot` of a batch whose A dy A^T already sits in the weight gradient's workspace `wgrad_ws`
+    (conv2d_backward_weight_winograd_stages): the transposed Winograd algorithm (include/t2v.h)."""
+    c = context()
+    dx = torch.empty(desc.H, desc.W, x_cs, dtype=torch.float32, device=wgrad_ws.device) if out is None else out
+    n = c.lib.t2v_conv_backward_data_winograd_scratch_floats(ctypes.byref(desc), x_cs)
+    scratch = torch.empty(n, dtype=torch.float32, device=wgrad_ws.device)
+    check(c.lib.t2v_conv2d_backward_data_winograd(c.handle, _stream(), ctypes.byref(desc), batch, slot, _p(wgrad_ws), x_cs, _p(ut),
+                                                  _p(scratch), _p(dx)), "conv2d_backward_data_winograd")
+    return dx
+
+
 def maxpool2x2(x):
     """MaxPool2d(2,2) on [H,W,C] or [B,H,W,C] (H even for a batch: the images are pooled as one tall image)."""
     c = context()

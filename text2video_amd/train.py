@@ -103,7 +103,7 @@ def batched_weight_gradients(params):
         _WG_BATCH[0] = False
 
 
-def _batched_winograd_wgrad(w, x, dc, fdesc, slot=None):
+def _batched_winograd_wgrad(w, x, dc, fdesc, slot=None, info=None):
     """Weight gradient of one use of a layer whose forward counted `w._t2v_wg_images` images in this graph: the
     images are transformed into their slots of a workspace kept on the weight; the node that brings the last ones
     runs the single reduction over all of them and returns dW, the earlier ones return None (a zero gradient --
@@ -124,6 +124,8 @@ def _batched_winograd_wgrad(w, x, dc, fdesc, slot=None):
         w._t2v_wg_state = st
     assert st[2] == _desc_key(fdesc, x.shape[-1]), "one layer, two geometries in one step: set T2V_WGRAD_BATCH=0"
     ws, done = st[0], st[1]
+    if info is not None:      # where this node's A dy A^T sits: the data gradient reads it too (transposed algorithm)
+        info[:] = [ws, total, done]
     last = done + x.shape[0] == total
     if slot is not None:     # the reduction writes (adds to) the parameter's bucket slot; every node counts as delivered
         ops.conv2d_backward_weight_winograd_stages(x, dc, fdesc, ws, total, done, last, out=slot.view, accumulate=slot.filled)
@@ -371,7 +373,8 @@ class _ConvBlock(torch.autograd.Function):
         if not want[1]:      # frozen weights (the VGG19 feature extractor) / a pass-through backward: data gradient only
             dw = None
         elif wino_wgrad == 2:
-            dw = _batched_winograd_wgrad(w, x, dc, fdesc, sl_w)
+            wg_info = []
+            dw = _batched_winograd_wgrad(w, x, dc, fdesc, sl_w, wg_info)
         elif wino_wgrad:
             if sl_w is not None:
                 ops.conv2d_backward_weight_winograd(x, dc, fdesc, accumulate_into=sl_w.view if sl_w.filled else None,
@@ -391,7 +394,18 @@ class _ConvBlock(torch.autograd.Function):
             else:
                 dw = ops.unpack_conv_weight(dwp, fdesc, x.shape[-1])
         dx = None
-        if need_dx:
+        xcs_ = x.shape[-1]
+        if need_dx and wino_wgrad == 2 and want[1] and len(wg_info) == 3 and os.environ.get("T2V_DGRAD_TRANSPOSED", "1") != "0" \
+                and ops.backward_data_winograd_supported(fdesc, xcs_, dc.shape[-1]):
+            # The weight gradient has just put A dy A^T of these images into its workspace: the data gradient by the
+            # TRANSPOSED Winograd algorithm reads it from there -- U^T dM on the layer's own 256 tiles instead of the
+            # full-correlation form's 289 -> 320, no second transform of dy, no flipped filter transform
+            ws_, total_, done_ = wg_info
+            ut = cached_pack(w, ("dgradT",) + _desc_key(fdesc, xcs_), lambda: ops.pack_conv_weight_transposed(w.detach(), fdesc, xcs_))
+            dx = torch.empty_like(x)
+            for i in range(B):
+                ops.conv2d_backward_data_winograd(fdesc, total_, done_ + i, ws_, xcs_, ut, out=dx[i])
+        elif need_dx:
             dg = ConvDataGrad(fdesc)
             dg.packed = cached_pack(w, ("dgrad",) + _desc_key(fdesc, x.shape[-1]), lambda: dg.refresh(w.detach()).packed)
             if ops.round_up(fdesc.Cin, 4) == x.shape[-1]:
