@@ -387,3 +387,32 @@ def test_winograd_f4_output_transform_applies_the_activation(slope):
     assert (_from_nhwc(y, Cout) - ref).abs().max().item() <= 2e-4 * max(1.0, ref.abs().max().item())
     with pytest.raises(RuntimeError):
         ops.conv2d_auto(_to_nhwc(x), U, b.to(_dev()), desc, stats=ops.conv_stats_buffer(desc, _dev()))
+
+
+@pytest.mark.parametrize("geom", [(64, 64, 1024, 1024), (64, 88, 640, 640), (128, 128, 256, 256), (64, 128, 512, 1024),
+                                  (128, 128, 512, 256)])
+def test_fixed_grid_winograd_gemm_equals_tile_per_block(geom, monkeypatch):
+    """The batched Winograd GEMM on a fixed grid (conv_igemm.hip: wino_gemm_sk_kernel; tiles cut between two blocks are
+    finished from the first block's accumulators) against one block per tile: the same K-ordered MFMA chain per output,
+    so the conv must be BIT-identical -- also launch after launch on one workspace (a stale hand-over flag or a stale L2
+    line of an earlier launch would show as a differing frame).  Tile counts not divisible by the 8 XCDs included."""
+    from text2video_amd import ops
+    H, W, Cin, Cout = geom
+    dev = _dev()
+    desc = ops.conv_desc(H, W, Cin, Cout, 3, 1, 1, ops.PAD_REFLECT, algo=ops.ALGO_WINOGRAD_F4)
+    w = _rand(Cout, Cin, 3, 3, seed=2, scale=0.03).to(dev)
+    b = _rand(Cout, seed=3).to(dev)
+    pu = ops.pack_conv_weight(w, desc, Cin)
+    ws = ops.winograd_workspace(desc, Cin, dev)
+    xs = [_rand(H, W, Cin, seed=10 + i).to(dev) for i in range(3)]
+    monkeypatch.setenv("T2V_WINO_GEMM_SK", "0")
+    want = [ops.conv2d_winograd(x, pu, b, desc, workspace=ws).clone() for x in xs]
+    monkeypatch.setenv("T2V_WINO_GEMM_SK", "2")      # wherever the shape allows, not only where it is faster
+    ws.fill_(float("nan"))
+    for rep in range(12):
+        x, y0 = xs[rep % 3], want[rep % 3]
+        y = ops.conv2d_winograd(x, pu, b, desc, workspace=ws)
+        assert torch.equal(y, y0), "launch %d: %d of %d outputs differ" % (rep, int((y != y0).sum()), y.numel())
+    # and against the fp32 reference of the conv (the tolerance of the other Winograd tests)
+    ref = _ref_conv(xs[0].cpu().permute(2, 0, 1), w.cpu(), b.cpu(), 3, 1, 1, 1, False)
+    assert float((_from_nhwc(want[0], Cout) - ref).abs().max()) < 2e-3 * max(1.0, float(ref.abs().max()))

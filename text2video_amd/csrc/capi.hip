@@ -286,9 +286,17 @@ int winograd_forward(t2v_ctx* ctx, hipStream_t s, const t2v_conv_desc* d, const 
                    : launch_winograd_input(s, x, V, d->H, d->W, d->Cin, d->pad, reflect));
     }
     if (stages & 2) {
-        ConvPlan pl;
-        T2V_TRY(build_winograd_gemm_plan(d, &pl, nimg));
-        T2V_TRY(run_conv(ctx, s, pl, V, w_packed, nullptr, Mm, d->Cout, nullptr));
+        if (f4 && wino_gemm_sk_ok(36, (int)T, d->Cin, d->Cout, d->Cout)) {
+            SkGemm g;
+            g.a = V; g.b = w_packed; g.c = Mm; g.scratch = workspace + winograd_vm_floats(d, nimg);
+            g.a_group_stride = (long)T * d->Cin;
+            g.groups = 36; g.T = (int)T; g.K = d->Cin; g.N = d->Cout; g.c_cs = d->Cout;
+            T2V_TRY(launch_wino_gemm_sk(s, g));
+        } else {
+            ConvPlan pl;
+            T2V_TRY(build_winograd_gemm_plan(d, &pl, nimg));
+            T2V_TRY(run_conv(ctx, s, pl, V, w_packed, nullptr, Mm, d->Cout, nullptr));
+        }
     }
     if (stages & 4) {
         T2V_REQUIRE(d->act == T2V_ACT_NONE || !stats_partial, "winograd: an activation and norm statistics do not combine");
@@ -707,7 +715,8 @@ size_t t2v_conv_backward_data_winograd_weight_floats(const t2v_conv_desc* d, int
 }
 size_t t2v_conv_backward_data_winograd_scratch_floats(const t2v_conv_desc* d, int x_cs) {
     if (!d) return 0;
-    return (size_t)36 * wino_tiles_padded(d, T2V_ALGO_WINOGRAD_F4) * x_cs + (size_t)(d->H + 2) * (d->W + 2) * x_cs;
+    return (size_t)36 * wino_tiles_padded(d, T2V_ALGO_WINOGRAD_F4) * x_cs + (size_t)(d->H + 2) * (d->W + 2) * x_cs +
+           wino_gemm_sk_scratch_floats();
 }
 int t2v_conv_pack_weight_transposed(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, int x_cs, const float* w_forward_dev,
                                     float* packed_dev) {
@@ -731,15 +740,24 @@ int t2v_conv2d_backward_data_winograd(t2v_ctx* ctx, void* stream, const t2v_conv
     float* dxp = scratch + (size_t)36 * Tp * x_cs;
     // dV[xi][t][c] = sum_n M_dy[xi][slot*Tp + t][n] * U[xi][n][c]: the batched GEMM of a conv with the channel roles swapped,
     // reading its rows out of the batch-wide matrix (input row pitch Tt, Tp rows per position)
-    t2v_conv_desc da = *d;
-    da.Cin = d->Cout;
-    da.Cout = d->Cin;
-    da.algo = T2V_ALGO_WINOGRAD_F4;
-    ConvPlan pl;
-    T2V_TRY(build_winograd_gemm_plan(&da, &pl));
-    T2V_REQUIRE((long)36 * Tt * d->Cout * 4 < 0x7fff0000L, "backward_data_winograd: M_dy too large for 32-bit buffer offsets");
-    pl.kp.Win = Tt;
-    T2V_TRY(run_conv(ctx, s, pl, Md + (size_t)slot * Tp * d->Cout, ut_packed, nullptr, dV, x_cs, nullptr));
+    if (wino_gemm_sk_ok(36, Tp, d->Cout, x_cs, x_cs) && round_up(x_cs, 128) == x_cs) {
+        SkGemm g;
+        g.a = Md + (size_t)slot * Tp * d->Cout; g.b = ut_packed; g.c = dV;
+        g.scratch = dxp + (size_t)(d->H + 2) * (d->W + 2) * x_cs;
+        g.a_group_stride = (long)Tt * d->Cout;
+        g.groups = 36; g.T = Tp; g.K = d->Cout; g.N = x_cs; g.c_cs = x_cs;
+        T2V_TRY(launch_wino_gemm_sk(s, g));
+    } else {
+        t2v_conv_desc da = *d;
+        da.Cin = d->Cout;
+        da.Cout = d->Cin;
+        da.algo = T2V_ALGO_WINOGRAD_F4;
+        ConvPlan pl;
+        T2V_TRY(build_winograd_gemm_plan(&da, &pl));
+        T2V_REQUIRE((long)36 * Tt * d->Cout * 4 < 0x7fff0000L, "backward_data_winograd: M_dy too large for 32-bit buffer offsets");
+        pl.kp.Win = Tt;
+        T2V_TRY(run_conv(ctx, s, pl, Md + (size_t)slot * Tp * d->Cout, ut_packed, nullptr, dV, x_cs, nullptr));
+    }
     T2V_TRY(launch_winograd4_dgrad_output(s, dV, dxp, d->H, d->W, x_cs));
     return launch_reflect_pad_backward(s, dxp, dx, d->H, d->W, x_cs, 1);
 }

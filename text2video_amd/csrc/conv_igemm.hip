@@ -24,7 +24,11 @@
 //     norm never re-reads the activation to compute statistics.
 //   * blockIdx -> tile mapping is XCD-aware: each XCD's L2 sees a contiguous band of tiles that
 //     share A rows / all B columns.
+#include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
+
+#include <atomic>
 
 #include "t2v_internal.h"
 
@@ -32,6 +36,7 @@ namespace t2v {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int v4u __attribute__((__vector_size__(16)));
 
 template <int MF> struct Mfma;
 template <> struct Mfma<32> {
@@ -443,6 +448,310 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(const ConvKParams p) {
                 }
             }
         }
+}
+
+// ---- the batched Winograd GEMM on a fixed grid ("stream-K") ------------------------------------------------------------
+// conv_igemm_kernel gives every 128x128 tile its own block: the 576 tiles of a 512x512 frame's F(4x4) GEMM stage
+// (36 positions x 2 x 8) are 1.125 rounds of the 512 resident blocks (two per CU), and the 2304 64x64 tiles used instead
+// pay twice the LDS-DMA traffic per FLOP.  Here the grid IS the 512 resident blocks: the (tile, K stage) units are laid
+// out tile-major and every block takes an equal run of them -- 36 of 18432 stages for that frame, i.e. the tail of one
+// tile, (whole tiles,) and the head of the next.  The head goes FIRST: its accumulators are written (write-through) to
+// the block's slot of `partial` and a per-wave tag is raised; the block that owns the rest of that tile gets to it LAST
+// and starts its K loop from those accumulators instead of zeros.  Every output is therefore the same K-ordered chain
+// of MFMAs as in conv_igemm_kernel (bit-identical), nobody waits on a block that started after it (the producer of a
+// block's hand-over is block b - 8, dispatched earlier), and whole tiles never touch the scratch.
+// Blocks b, b + 8, ... (one XCD under round-robin dispatch) share a run of whole tiles, m tile fastest: the two blocks
+// on one U column tile run side by side in one L2.
+struct SkKParams {
+    const float* a;
+    const float* b;
+    float* c;
+    float* partial;               // [grid][4 waves][64 regs][64 lanes]
+    unsigned long long* flags;    // [grid][4 waves]
+    unsigned long long tag;       // unique per launch: stale flags of earlier launches never match
+    long a_group_stride;
+    int T, K, N, c_cs;
+    int mtiles_g, ntiles, nk, tiles, tiles_per_xcd, blocks_per_xcd;
+};
+
+template <int RING>
+__global__ __launch_bounds__(512) void wino_gemm_sk_kernel(const SkKParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using Cfg = CfgL;
+    using MM = Mfma<32>;
+    using acc_t = MM::acc_t;
+    constexpr int BM = Cfg::BM, BN = Cfg::BN, MF = 32;
+    constexpr int A_ITERS = BM / 32, B_PER_WAVE = BN / 32, LD_PER_WAVE = A_ITERS + B_PER_WAVE;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool is_loader = wave >= 4;
+    const int wid = wave & 3;
+
+    // ---- this block's run of units (relative to its XCD's first tile) ----
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int t0 = xcd * p.tiles_per_xcd, t1 = min(t0 + p.tiles_per_xcd, p.tiles);
+    if (t0 >= t1) return;
+    const int nk = p.nk;
+    const int ux = (t1 - t0) * nk;
+    const int S = max(nk, (ux + p.blocks_per_xcd - 1) / p.blocks_per_xcd);   // >= one tile: a run never lies inside a tile
+    const int u0 = j * S, u1 = min(u0 + S, ux);
+    if (u0 >= u1) return;
+    const int tf = u0 / nk, tl = (u1 - 1) / nk;
+    const int kf = u0 - tf * nk, kl = u1 - tl * nk;
+    const int has_tail = kf > 0, has_head = kl < nk;
+    const int nf = tl - tf + 1, nmid = nf - has_head - has_tail;
+
+    // ---- loader lane geometry (the same for every tile: only the SRD bases move) ----
+    const int lrow = lane >> 3, lslot = lane & 7;
+    const int tile_bytes = 128 * p.K * 4;
+    int a_voff[A_ITERS], b_voff[B_PER_WAVE];
+#pragma unroll
+    for (int i = 0; i < A_ITERS; ++i) {
+        const int r = wid * (BM / 4) + i * 8 + lrow;
+        a_voff[i] = (r * p.K + (lslot ^ ((r >> 1) & 7)) * 4) * 4;
+    }
+#pragma unroll
+    for (int i = 0; i < B_PER_WAVE; ++i) {
+        const int r = (wid * B_PER_WAVE + i) * 8 + lrow;
+        b_voff[i] = (r * p.K + (lslot ^ ((r >> 1) & 7)) * 4) * 4;
+    }
+
+    // ---- MFMA fragment geometry ----
+    const int wm = wid / Cfg::WAVES_N, wn = wid - wm * Cfg::WAVES_N;
+    const int fr = lane & (MF - 1);
+    const int g = lane / MF;
+    const int fsw = (fr >> 1) & 7;
+    const int a_row0 = wm * (Cfg::TM * MF) + fr;
+    const int b_row0 = wn * (Cfg::TN * MF) + fr;
+    f32x4 af[2][Cfg::TM], bf[2][Cfg::TN];
+    auto load_frags = [&](int buf, int q, int set) {
+        const char* sA = smem + buf * Cfg::STAGE_BYTES;
+        const char* sB = sA + BM * 128;
+        const int slot = ((q * Cfg::NG + g) ^ fsw) * 16;
+#pragma unroll
+        for (int i = 0; i < Cfg::TM; ++i)
+            af[set][i] = *reinterpret_cast<const f32x4*>(sA + (a_row0 + i * MF) * 128 + slot);
+#pragma unroll
+        for (int jj = 0; jj < Cfg::TN; ++jj)
+            bf[set][jj] = *reinterpret_cast<const f32x4*>(sB + (b_row0 + jj * MF) * 128 + slot);
+    };
+
+    bool flag_due = false;   // this wave's hand-over stores are in flight; its tag is raised at the next wait point
+    for (int f = 0; f < nf; ++f) {
+        // processing order: the head handed on to block j+1, the whole tiles, the tail begun by block j-1
+        int tr;
+        if (has_head && f == 0) tr = tl;
+        else if (f - has_head < nmid) tr = tf + has_tail + (f - has_head);
+        else tr = tf;
+        const int kb = tr == tf ? kf : 0, ke = tr == tl ? kl : nk;
+        const bool init = kb > 0, publish = ke < nk;
+        const int tile = t0 + tr;
+        const int tpg = p.mtiles_g * p.ntiles;
+        const int pg = tile / tpg, rem = tile - pg * tpg;
+        const int nt = rem / p.mtiles_g, mt = rem - nt * p.mtiles_g;
+
+        if (is_loader) {
+            const float* abase = p.a + pg * p.a_group_stride + (long)mt * BM * p.K;
+            const float* bbase = p.b + ((long)pg * p.N + nt * BN) * p.K;
+            auto issue_stage = [&](int kt, int buf) {
+                char* dstA = smem + buf * Cfg::STAGE_BYTES + wid * (BM / 4) * 128;
+                char* dstB = smem + buf * Cfg::STAGE_BYTES + BM * 128 + wid * B_PER_WAVE * 8 * 128;
+#pragma unroll
+                for (int i = 0; i < A_ITERS; ++i) dma16(abase, tile_bytes, dstA + i * 8 * 128, a_voff[i], kt * (kBK * 4));
+#pragma unroll
+                for (int i = 0; i < B_PER_WAVE; ++i) dma16(bbase, tile_bytes, dstB + i * 8 * 128, b_voff[i], kt * (kBK * 4));
+            };
+            constexpr int AHEAD = RING - 1;
+#pragma unroll
+            for (int st = 0; st < AHEAD; ++st) issue_stage(min(kb + st, ke - 1), st);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * LD_PER_WAVE) : "memory");
+            __builtin_amdgcn_s_barrier();  // B0
+            int slot = AHEAD;
+            for (int kt = kb; kt < ke; ++kt) {
+                issue_stage(min(kt + AHEAD, ke - 1), slot);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * LD_PER_WAVE) : "memory");
+                __builtin_amdgcn_s_barrier();
+                slot = slot >= RING - 1 ? 0 : slot + 1;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();   // MFMA waves have read their last fragments: the next tile's prologue may overwrite the ring
+            continue;
+        }
+
+        // ---- MFMA waves ----
+        acc_t acc[Cfg::TM][Cfg::TN];
+        if (init) {
+            // the accumulators block j-1 (blockIdx - 8) left for this tile; its wave `wid` wrote what this wave reads
+            const int src = blockIdx.x - 8;
+            const unsigned long long* fl = p.flags + src * 4 + wid;
+            while (__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.tag) __builtin_amdgcn_s_sleep(4);
+            // write-through (sc1) stores on the producer's side, sc1 loads here: the pair that is coherent across the
+            // XCDs' L2s inside one launch; 16 x 16 bytes per lane at scalar offsets off one SRD
+            const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(p.partial) + (size_t)(src * 4 + wid) * 4096, 0, 16384, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+                for (int jj = 0; jj < Cfg::TN; ++jj)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        auto raw = __builtin_amdgcn_raw_buffer_load_b128(srd, lane * 16, ((i * Cfg::TN + jj) * 4 + q) * 1024, 16);
+                        float v[4];
+                        __builtin_memcpy(v, &raw, 16);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[i][jj][q * 4 + e] = v[e];
+                    }
+        } else {
+#pragma unroll
+            for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+                for (int jj = 0; jj < Cfg::TN; ++jj)
+#pragma unroll
+                    for (int r = 0; r < MM::NREG; ++r) acc[i][jj][r] = 0.f;
+        }
+        if (flag_due) {
+            // (the head went first: its stores drain while the loaders fetch this tile's first stage)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the write-through stores have left for memory
+            if (lane == 0)
+                __hip_atomic_store(p.flags + blockIdx.x * 4 + wid, p.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            flag_due = false;
+        }
+        __syncthreads();  // B0
+        load_frags(0, 0, 0);
+        int buf = 0;
+        for (int kt = kb; kt < ke; ++kt) {
+            const int nbuf = buf == RING - 1 ? 0 : buf + 1;
+#pragma unroll
+            for (int q = 0; q < Cfg::RQ; ++q) {
+                const int cur = q & 1;
+                __builtin_amdgcn_sched_barrier(0);
+                if (q + 1 == Cfg::RQ) {
+                    __syncthreads();
+                    __builtin_amdgcn_sched_barrier(0);
+                    load_frags(nbuf, 0, cur ^ 1);
+                } else {
+                    load_frags(buf, q + 1, cur ^ 1);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+                        for (int jj = 0; jj < Cfg::TN; ++jj)
+                            acc[i][jj] = MM::run(af[cur][i][e], bf[cur][jj][e], acc[i][jj]);
+#pragma unroll
+                for (int r = 0; r < Cfg::TM + Cfg::TN; ++r) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 4 * Cfg::TM * Cfg::TN - (Cfg::TM + Cfg::TN), 0);
+            }
+            buf = nbuf;
+        }
+        __syncthreads();   // pairs with the loaders' closing barrier
+
+        if (publish) {
+            const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(
+                p.partial + (size_t)(blockIdx.x * 4 + wid) * 4096, 0, 16384, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+                for (int jj = 0; jj < Cfg::TN; ++jj)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = acc[i][jj][q * 4 + e];
+                        v4u raw;
+                        __builtin_memcpy(&raw, v, 16);
+                        __builtin_amdgcn_raw_buffer_store_b128(raw, srd, lane * 16, ((i * Cfg::TN + jj) * 4 + q) * 1024, 16);
+                    }
+            flag_due = true;
+        } else {
+            // one SRD on the tile's first output row, one per-lane offset (its row group and column), the rest scalar
+            const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(
+                p.c + ((size_t)pg * p.T + (size_t)mt * BM) * p.c_cs + nt * BN, 0, 0x7ffffffc, 0x00020000);
+            const int voff = ((wm * (Cfg::TM * MF) + 4 * g) * p.c_cs + wn * (Cfg::TN * MF) + fr) * 4;
+#pragma unroll
+            for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+                for (int r = 0; r < MM::NREG; ++r) {
+                    const int soff = (i * MF + (r & 3) + 8 * (r >> 2)) * p.c_cs * 4;
+#pragma unroll
+                    for (int jj = 0; jj < Cfg::TN; ++jj) {
+                        const float v = acc[i][jj][r];
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), srd, voff + jj * MF * 4, soff, 0);
+                    }
+                }
+        }
+    }
+    if (flag_due) {   // a run that was nothing but a head
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_store(p.flags + blockIdx.x * 4 + wid, p.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+static int sk_grid_blocks() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+            cus = 256;
+        n = max(8, min(1024, 2 * cus) / 8 * 8);   // two 64-KiB-ring blocks per CU, whole XCD groups
+    }
+    return n;
+}
+constexpr int kSkMaxGrid = 1024;
+size_t wino_gemm_sk_scratch_floats() { return (size_t)kSkMaxGrid * (4 * 64 * 64 + 4 * 2); }
+
+bool wino_gemm_sk_ok(int groups, int T, int K, int N, int c_cs) {
+    const char* e = getenv("T2V_WINO_GEMM_SK");   // read per call: tests and A/B runs flip it inside one process
+    if ((e && atoi(e) == 0) || T % 128 || N % 128 || K % kBK || c_cs != N || (long)128 * K * 4 >= 0x7fff0000L) return false;
+    // fewer tiles than resident blocks: one tile per block is already less than one round.  Beyond that the fixed grid
+    // pays where whole tiles fill their last round badly -- measured on MI355X (scripts/sk_probe.py, K = N = 1024):
+    // 1.125 rounds 189 -> 144 us, 1.69 rounds 241 -> 210 us, 2.25 rounds 352 -> 294 us, 4.5 rounds 583 -> 611 us
+    const long tiles = (long)groups * (T / 128) * (N / 128), grid = sk_grid_blocks();
+    if (tiles < grid) return false;
+    if (e && atoi(e) == 2) return true;   // T2V_WINO_GEMM_SK=2: wherever the shape allows
+    const long rounds = (tiles + grid - 1) / grid;
+    return tiles * 100 <= rounds * grid * 85;
+}
+
+int launch_wino_gemm_sk(hipStream_t s, const SkGemm& g) {
+    T2V_REQUIRE(wino_gemm_sk_ok(g.groups, g.T, g.K, g.N, g.c_cs), "stream-K gemm: shape not supported");
+    static std::atomic<unsigned long long> tag_counter{0};
+    if (tag_counter.load() == 0) {
+        unsigned long long seed = 0;
+        FILE* f = fopen("/dev/urandom", "rb");
+        if (!f || fread(&seed, sizeof(seed), 1, f) != 1) seed = 0x9e3779b97f4a7c15ull * (unsigned long long)(uintptr_t)&seed;
+        if (f) fclose(f);
+        unsigned long long zero = 0;
+        tag_counter.compare_exchange_strong(zero, (seed >> 1) | 1ull);
+    }
+    SkKParams k;
+    k.a = g.a; k.b = g.b; k.c = g.c;
+    k.partial = g.scratch;
+    k.flags = reinterpret_cast<unsigned long long*>(g.scratch + (size_t)kSkMaxGrid * 4 * 64 * 64);
+    k.tag = ++tag_counter;
+    k.a_group_stride = g.a_group_stride;
+    k.T = g.T; k.K = g.K; k.N = g.N; k.c_cs = g.c_cs;
+    k.mtiles_g = g.T / 128; k.ntiles = g.N / 128; k.nk = g.K / kBK;
+    k.tiles = g.groups * k.mtiles_g * k.ntiles;
+    const int grid = sk_grid_blocks();
+    k.blocks_per_xcd = grid / 8;
+    k.tiles_per_xcd = (k.tiles + 7) / 8;
+    auto kern = wino_gemm_sk_kernel<2>;
+    constexpr int LDS_BYTES = 2 * CfgL::STAGE_BYTES;
+    static bool attr_done = false;
+    if (!attr_done) {
+        T2V_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS_BYTES, s, k);
+    T2V_HIP_CHECK(hipGetLastError());
+    return T2V_OK;
 }
 
 int conv_tile_for(int Cout) { return Cout <= 16 ? kTileS : kTileL; }

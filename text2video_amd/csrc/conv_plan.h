@@ -34,8 +34,12 @@ inline int wino_tiles_real(const t2v_conv_desc* d, int algo) {
 inline int wino_rows_batch(const t2v_conv_desc* d, int algo, int nimg) {
     return (nimg > 1 && algo == T2V_ALGO_WINOGRAD_F4) ? wino_pad_tiles(nimg * wino_tiles_real(d, algo)) : wino_tiles_padded(d, algo);
 }
-inline size_t winograd_workspace_floats(const t2v_conv_desc* d, int nimg = 1) {      // V + M of `nimg` images
+inline size_t winograd_vm_floats(const t2v_conv_desc* d, int nimg = 1) {             // V + M of `nimg` images
     return (size_t)wino_pos(d->algo) * wino_rows_batch(d, d->algo, nimg) * ((size_t)d->Cin + d->Cout);
+}
+// ... followed, for F(4x4,3x3), by the hand-over scratch of the fixed-grid GEMM (conv_igemm.hip: wino_gemm_sk_kernel)
+inline size_t winograd_workspace_floats(const t2v_conv_desc* d, int nimg = 1) {
+    return winograd_vm_floats(d, nimg) + (d->algo == T2V_ALGO_WINOGRAD_F4 ? wino_gemm_sk_scratch_floats() : 0);
 }
 // GEMM rows of the whole conv (all positions): what the algorithm choice compares
 inline long wino_gemm_rows(const t2v_conv_desc* d, int algo) { return (long)wino_pos(algo) * wino_tiles_padded(d, algo); }

@@ -194,6 +194,23 @@ int conv_tile_for(int Cout);
 void conv_tile_dims(int tile, int* BM, int* BN);
 int launch_conv_igemm(hipStream_t s, const ConvKParams& p, int tile);
 
+// The batched Winograd GEMM (36 groups x [T x K] x [K x N]) on a fixed grid of two blocks per CU, each block taking an
+// equal run of K stages out of the tile-major list of (128x128 tile, stage) units: 576 tiles of a 512x512 frame are
+// 2.25 rounds of whole tiles on 256 CUs, but exactly 36 stages per block.  A tile cut between two blocks is finished
+// by the second one STARTING from the first one's accumulators (handed over through `scratch`), so every output is
+// the same K-ordered sum as in conv_igemm_kernel: bit-identical results.
+struct SkGemm {
+    const float* a;        // [groups][a_group_rows][K], the first T rows of each group are used
+    const float* b;        // [groups][N][K]
+    float* c;              // [groups][T][c_cs]
+    float* scratch;        // wino_gemm_sk_scratch_floats() floats, any content
+    long a_group_stride;   // floats between the groups of a
+    int groups, T, K, N, c_cs;
+};
+size_t wino_gemm_sk_scratch_floats();
+bool wino_gemm_sk_ok(int groups, int T, int K, int N, int c_cs);
+int launch_wino_gemm_sk(hipStream_t s, const SkGemm& g);
+
 // elementwise.hip
 // scratch (optional): kFinalizeMaxGroups * C * 4 doubles -- lets big layers pool their partials on many CUs
 constexpr int kFinalizeMaxGroups = 64;
