@@ -110,7 +110,9 @@ int t2v_conv_winograd_supported(const t2v_conv_desc* d, int x_cs);
  * direct (9 per output pixel), F(2x2,3x3) and F(4x4,3x3) (16 | 36 per tile, tile count padded to 128).
  * cap: 0 = any, 1 = direct only, 2 = at most F(2x2,3x3).  Returns a T2V_ALGO_* value. */
 int t2v_conv_best_algo(const t2v_conv_desc* d, int x_cs, int cap);
-/* floats of scratch (transformed input V + transformed output M) a Winograd forward needs */
+/* floats of scratch a Winograd forward needs: transformed input V + transformed output M, and for F(4x4,3x3) the
+ * hand-over area of the fixed-grid GEMM stage (blocks that share a 128x128 tile pass accumulators through it; any
+ * content on entry, one workspace per conv in flight) */
 size_t t2v_conv_winograd_workspace_floats(const t2v_conv_desc* d, int x_cs);
 /* forward with d->algo == T2V_ALGO_WINOGRAD | T2V_ALGO_WINOGRAD_F4; same contract as t2v_conv2d_forward plus the workspace */
 int t2v_conv2d_forward_winograd(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, const float* x, int x_cs,

@@ -15,6 +15,8 @@ ap.add_argument("--iters", type=int, default=3)
 ap.add_argument("--no_flow", action="store_true")
 ap.add_argument("--no_face", action="store_true")
 ap.add_argument("--vgg", action="store_true", help="add the VGG19 perceptual loss (seeded random weights)")
+ap.add_argument("--aten_stacks", action="store_true", help="one step under torch.profiler: where the ATen fills / adds / "
+                "copies of the step come from (python call sites, by count)")
 ap.add_argument("--force_dist", action="store_true", help="run the gradient exchange on a 1-rank RCCL group and report its "
                 "bytes, buckets and the part still running after the backward pass")
 args = ap.parse_args()
@@ -60,6 +62,27 @@ dt = (time.perf_counter() - t0) / args.iters
 print("train step %dx%d, %d frames, %s%s%s: %.1f ms/step, peak mem %.1f GB | %s"
       % (H, W, F, "no flow" if args.no_flow else "flow branch on", "" if args.no_face else " + face D", " + VGG" if args.vgg else "",
          dt * 1e3, torch.cuda.max_memory_allocated() / 2**30, " ".join("%s %.3f" % kv for kv in losses.items())))
+if args.aten_stacks:
+    import collections, traceback
+    sites = collections.Counter()
+
+    def spy(owner, name):
+        orig = getattr(owner, name)
+
+        def wrapped(*a, **k):
+            st = [f for f in traceback.extract_stack(limit=8)[:-1] if "text2video_amd" in f.filename]
+            sites[(name, " <- ".join("%s:%d" % (os.path.basename(f.filename), f.lineno) for f in st[-2:][::-1]))] += 1
+            return orig(*a, **k)
+        setattr(owner, name, wrapped)
+    for owner, name in [(torch, "zeros"), (torch, "zeros_like"), (torch, "cat"), (torch, "ones_like"), (torch, "full"),
+                        (torch.Tensor, "zero_"), (torch.Tensor, "fill_"), (torch.Tensor, "clone"), (torch.Tensor, "contiguous"),
+                        (torch.Tensor, "add_"), (torch.Tensor, "__add__"), (torch.Tensor, "__mul__"), (torch.Tensor, "mul_"),
+                        (torch.Tensor, "copy_"), (torch.Tensor, "sum"), (torch.Tensor, "mean")]:
+        spy(owner, name)
+    step()
+    torch.cuda.synchronize()
+    for (name, where), n in sites.most_common(70):
+        print("%4d  %-12s %s" % (n, name, where))
 if args.force_dist:
     print("gradient exchange (1-rank RCCL%s): %.1f MB per step in %d + %d buckets, %.2f ms still running after the backward pass"
           % (", reduce-scatter + all-gather" if os.environ.get("T2V_GRAD_RS_AG") == "1" else ", all-reduce", tr.comm_bytes / 2**20,

@@ -119,10 +119,11 @@ def test_algorithm_choice_and_winograd_bookkeeping(lib_built):
     f4 = desc(64, 64, algo=_lib.ALGO_WINOGRAD_F4)
     assert lib_built.t2v_conv_winograd_supported(ctypes.byref(f4), 1024) == 3
     assert lib_built.t2v_conv_packed_weight_floats(ctypes.byref(f4), 1024) == 36 * 1024 * 1024
-    assert lib_built.t2v_conv_winograd_workspace_floats(ctypes.byref(f4), 1024) == 36 * 256 * 2048
+    # V + M of the 256 tiles, then the hand-over scratch of the fixed-grid GEMM (1024 blocks x 4 waves x (64 x 64 + 2))
+    assert lib_built.t2v_conv_winograd_workspace_floats(ctypes.byref(f4), 1024) == 36 * 256 * 2048 + 1024 * 4 * (64 * 64 + 2)
     assert lib_built.t2v_conv_stats_floats(ctypes.byref(f4)) == 32 * 1024 * 2      # one partial per 128 output pixels
     r = desc(64, 40, algo=_lib.ALGO_WINOGRAD_F4)
-    assert lib_built.t2v_conv_winograd_workspace_floats(ctypes.byref(r), 1024) == 36 * 192 * 2048   # 160 tiles -> 192
+    assert lib_built.t2v_conv_winograd_workspace_floats(ctypes.byref(r), 1024) == 36 * 192 * 2048 + 1024 * 4 * (64 * 64 + 2)   # 160 tiles -> 192
     assert lib_built.t2v_conv_backward_weight_winograd_supported(ctypes.byref(f4), 1024, 1024) == 1
     assert lib_built.t2v_conv_backward_weight_winograd_workspace_floats(ctypes.byref(f4), 1024, 2) == \
         36 * 2 * 256 * 2048 + 36 * 1024 * 1024

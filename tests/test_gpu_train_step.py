@@ -476,3 +476,39 @@ def test_shared_discriminator_forward_equals_the_two_forward_form(monkeypatch):
     assert len(a[3]) == len(b[3]) > 4
     for (m1, v1, n1), (m2, v2, n2) in zip(a[3], b[3]):
         assert n1 == n2 and torch.equal(m1, m2) and torch.equal(v1, v2)
+
+
+def test_weight_gradients_on_the_side_stream_leave_the_step_unchanged(monkeypatch):
+    """The weight-gradient kernels of the backward nodes run on a second stream next to the following layers' data
+    gradients (train.py: wgrad_fork / wgrad_join).  Against everything on one stream (T2V_WGRAD_STREAM=0): the same
+    losses and the same updated weights, bit for bit, over three steps on one trainer each (a slot read before its
+    side-stream kernels finished, or a buffer handed back to the allocator too early, would show here) -- at a size
+    where the ResnetBlock convs take the Winograd-domain path and the others the direct one."""
+    from text2video_amd import train as T
+    from text2video_amd.options import TrainOptions
+    opt = TrainOptions().parse(["--name", "t", "--dataset_mode", "pose", "--input_nc", "3", "--openpose_only", "--ngf", "32",
+                                "--n_downsample_G", "2", "--n_blocks", "3", "--num_D", "2", "--ndf", "16", "--no_vgg",
+                                "--max_frames_per_gpu", "2", "--n_scales_temporal", "0", "--no_first_img", "--add_face_disc"])
+    H, W = 128, 128
+    rng = np.random.default_rng(33)
+    pose = torch.zeros(2, H, W, 12, device="cuda:0")
+    pose[..., :9] = torch.from_numpy(rng.uniform(-1, 1, (2, H, W, 9)).astype(np.float32)).cuda()
+    real = torch.zeros(2, H, W, 4, device="cuda:0")
+    real[..., :3] = torch.tanh(torch.from_numpy(rng.standard_normal((2, H, W, 3)).astype(np.float32))).cuda()
+    real_prev = torch.cat([real[1:], real[:1]], 0).contiguous()
+    boxes = [(16, 80, 32, 96)] * 2
+    runs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("T2V_WGRAD_STREAM", mode)
+        tr = T.Vid2VidTrainer(opt, "cuda:0", seed=5)
+        prev, ls = None, []
+        for _ in range(3):
+            l, prev = tr.train_step(pose, real, boxes, prev, real_prev=real_prev)
+            ls.append(l)
+        nets = [tr.G, tr.D, tr.Df]
+        runs[mode] = (ls, [p.detach().clone() for n in nets for p in n.parameters()])
+        if mode == "1":
+            assert T._WG_SIDE["stream"] is not None and not T._WG_SIDE["pending"]
+    for la, lb in zip(runs["1"][0], runs["0"][0]):
+        assert la.keys() == lb.keys() and all(la[k] == lb[k] for k in la), [(k, la[k], lb[k]) for k in la if la[k] != lb[k]]
+    assert all(torch.equal(x, y) for x, y in zip(runs["1"][1], runs["0"][1]))

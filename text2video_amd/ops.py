@@ -360,7 +360,8 @@ def conv2d_backward_weight(x, dy, desc, accumulate_into=None):
     _chk(dy, "dy")
     B, x_cs, dy_cs = x.shape[0], x.shape[-1], dy.shape[-1]
     n = c.lib.t2v_conv_packed_weight_floats(ctypes.byref(desc), x_cs)
-    dw = accumulate_into if accumulate_into is not None else torch.zeros(n, dtype=torch.float32, device=x.device)
+    # (every real entry of the packed gradient is written -- by the kernel, its in-kernel combine or the reduce pass)
+    dw = accumulate_into if accumulate_into is not None else torch.empty(n, dtype=torch.float32, device=x.device)
     nws = c.lib.t2v_conv_backward_weight_workspace_floats(ctypes.byref(desc), x_cs, B)
     ws = torch.empty(nws, dtype=torch.float32, device=x.device) if nws else None
     check(c.lib.t2v_conv2d_backward_weight(c.handle, _stream(), ctypes.byref(desc), B, _p(x), x_cs, _p(dy), dy_cs,

@@ -103,6 +103,44 @@ def batched_weight_gradients(params):
         _WG_BATCH[0] = False
 
 
+# ---- weight gradients on a second stream ---------------------------------------------------------------------------
+# Nothing in the backward pass waits for a weight gradient: the chain that has to run in order is dy -> norm backward ->
+# data gradient -> the next layer's dy.  With gradients delivered straight into bucket slots (GradBuckets) the weight-
+# gradient kernels of a node can therefore run on a side stream, next to the data-gradient kernels of the following
+# layers: the tails of one launch (4.5-round grids, split-K partial combines, transforms of 36 small matrices) are
+# filled by the other stream's blocks, as in the two-stream inference frames.  The side stream waits for the node's dc;
+# the main stream waits for the side stream before anything reads a slot (bucket collectives, absorb, finish).
+# T2V_WGRAD_STREAM=0: everything on one stream.
+_WG_SIDE = {"stream": None, "pending": False}
+
+
+def wgrad_stream_on(t):
+    return t.is_cuda and os.environ.get("T2V_WGRAD_STREAM", "1") != "0"
+
+
+@contextlib.contextmanager
+def wgrad_fork(*tensors):
+    """kernels launched in this scope run on the side stream, after everything the current stream holds so far; the
+    tensors named (inputs allocated on the current stream) stay allocated until the side stream is done with them"""
+    if _WG_SIDE["stream"] is None:
+        _WG_SIDE["stream"] = torch.cuda.Stream()
+    side = _WG_SIDE["stream"]
+    side.wait_stream(torch.cuda.current_stream())
+    for t in tensors:
+        if t is not None:
+            t.record_stream(side)
+    _WG_SIDE["pending"] = True
+    with torch.cuda.stream(side):
+        yield
+
+
+def wgrad_join():
+    """the current stream waits for the weight gradients in flight on the side stream"""
+    if _WG_SIDE["pending"]:
+        torch.cuda.current_stream().wait_stream(_WG_SIDE["stream"])
+        _WG_SIDE["pending"] = False
+
+
 def _batched_winograd_wgrad(w, x, dc, fdesc, slot=None, info=None):
     """Weight gradient of one use of a layer whose forward counted `w._t2v_wg_images` images in this graph: the
     images are transformed into their slots of a workspace kept on the weight; the node that brings the last ones
@@ -111,8 +149,9 @@ def _batched_winograd_wgrad(w, x, dc, fdesc, slot=None, info=None):
     total = getattr(w, "_t2v_wg_images", 0)
     if total < x.shape[0]:     # no count on this object: reduce on the spot
         if slot is not None:
-            ops.conv2d_backward_weight_winograd(x, dc, fdesc, accumulate_into=slot.view if slot.filled else None,
-                                                out=slot.view)
+            with (wgrad_fork(x, dc) if wgrad_stream_on(x) else contextlib.nullcontext()):
+                ops.conv2d_backward_weight_winograd(x, dc, fdesc, accumulate_into=slot.view if slot.filled else None,
+                                                    out=slot.view)
             slot.filled = True
             slot.owner.node_done(slot)
             return None
@@ -128,7 +167,16 @@ def _batched_winograd_wgrad(w, x, dc, fdesc, slot=None, info=None):
         info[:] = [ws, total, done]
     last = done + x.shape[0] == total
     if slot is not None:     # the reduction writes (adds to) the parameter's bucket slot; every node counts as delivered
-        ops.conv2d_backward_weight_winograd_stages(x, dc, fdesc, ws, total, done, last, out=slot.view, accumulate=slot.filled)
+        if wgrad_stream_on(x):
+            # transforms here (the data gradient of this node reads A dy A^T), the reduction over all slots on the side
+            ops.conv2d_backward_weight_winograd_stages(x, dc, fdesc, ws, total, done, False)
+            if last:
+                with wgrad_fork(ws):
+                    ops.conv2d_backward_weight_winograd_reduce(fdesc, ws, total, x.shape[-1], dc.shape[-1], out=slot.view,
+                                                               accumulate=slot.filled)
+        else:
+            ops.conv2d_backward_weight_winograd_stages(x, dc, fdesc, ws, total, done, last, out=slot.view,
+                                                       accumulate=slot.filled)
         dw = None
         if last:
             slot.filled = True
@@ -150,6 +198,7 @@ def flush_pending_weight_gradients(params, grads):
     zeroed (a zero image contributes nothing) and the reduction runs over the whole workspace.  Returns `grads` with
     those gradients filled in."""
     out = list(grads)
+    wgrad_join()
     for i, p in enumerate(params):
         st = getattr(p, "_t2v_wg_state", None)
         if st is None:
@@ -159,7 +208,10 @@ def flush_pending_weight_gradients(params, grads):
         if done > 0:
             cout_p, kp = ops.round_up(fdesc.Cout, 128), ops.round_up(xcs, 32)
             tp = (ws.numel() - 36 * cout_p * kp) // (36 * total * (xcs + fdesc.Cout))
-            ws[:36 * total * tp * xcs].view(36, total, tp * xcs)[:, done:].zero_()
+            nv = 36 * total * tp * xcs
+            ws[:nv].view(36, total, tp * xcs)[:, done:].zero_()
+            # (their A dy A^T slots too: 0 x whatever the allocation held is not 0 for a NaN / Inf bit pattern)
+            ws[nv:nv + 36 * total * tp * fdesc.Cout].view(36, total, tp * fdesc.Cout)[:, done:].zero_()
             sl = grad_slot(p)
             if sl is not None:
                 ops.conv2d_backward_weight_winograd_reduce(fdesc, ws, total, xcs, dycs, out=sl.view, accumulate=sl.filled)
@@ -377,22 +429,24 @@ class _ConvBlock(torch.autograd.Function):
             dw = _batched_winograd_wgrad(w, x, dc, fdesc, sl_w, wg_info)
         elif wino_wgrad:
             if sl_w is not None:
-                ops.conv2d_backward_weight_winograd(x, dc, fdesc, accumulate_into=sl_w.view if sl_w.filled else None,
-                                                    out=sl_w.view)
+                with (wgrad_fork(x, dc) if wgrad_stream_on(x) else contextlib.nullcontext()):
+                    ops.conv2d_backward_weight_winograd(x, dc, fdesc, accumulate_into=sl_w.view if sl_w.filled else None,
+                                                        out=sl_w.view)
                 sl_w.filled = True
                 sl_w.owner.node_done(sl_w)
                 dw = None
             else:
                 dw = ops.conv2d_backward_weight_winograd(x, dc, fdesc)
         else:
-            dwp = ops.conv2d_backward_weight(x, dc, fdesc)
             if sl_w is not None:
-                ops.unpack_conv_weight_into(dwp, fdesc, x.shape[-1], sl_w.view, sl_w.filled)
+                with (wgrad_fork(x, dc) if wgrad_stream_on(x) else contextlib.nullcontext()):
+                    dwp = ops.conv2d_backward_weight(x, dc, fdesc)
+                    ops.unpack_conv_weight_into(dwp, fdesc, x.shape[-1], sl_w.view, sl_w.filled)
                 sl_w.filled = True
                 sl_w.owner.node_done(sl_w)
                 dw = None
             else:
-                dw = ops.unpack_conv_weight(dwp, fdesc, x.shape[-1])
+                dw = ops.unpack_conv_weight(ops.conv2d_backward_weight(x, dc, fdesc), fdesc, x.shape[-1])
         dx = None
         xcs_ = x.shape[-1]
         if need_dx and wino_wgrad == 2 and want[1] and len(wg_info) == 3 and os.environ.get("T2V_DGRAD_TRANSPOSED", "1") != "0" \
@@ -1029,6 +1083,7 @@ class GradBuckets:
         if not self.exchange:
             return
         import torch.distributed as dist
+        wgrad_join()      # the collective is ordered behind the current stream: let that include the side stream's gradients
         lo, hi = self.bounds[b]
         buf = self.flat[lo:hi]
         avg = dist.get_backend() == "nccl"       # RCCL averages in the collective; gloo sums (scaled in finish)
@@ -1054,6 +1109,7 @@ class GradBuckets:
         """After autograd.grad: gradients that came back as tensors (parameters reached through torch-native plumbing,
         e.g. the cat of the two flow-head convs; a flushed Winograd reduction) are added into their slots; then every
         bucket not yet launched goes out, in order."""
+        wgrad_join()
         for i, g in enumerate(grads):
             if g is not None:
                 sl = self.slots[i]
@@ -1068,6 +1124,7 @@ class GradBuckets:
         """Wait for the collectives; p.grad = the slot (None where no rank-local node delivered: Adam then skips the
         parameter, as torch 0.4.1's does).  Returns the bytes exchanged."""
         import torch.distributed as dist
+        wgrad_join()
         for work, buf, avg, shard in self._works:
             work.wait()
             if shard is not None:
