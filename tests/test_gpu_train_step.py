@@ -480,7 +480,8 @@ def test_shared_discriminator_forward_equals_the_two_forward_form(monkeypatch):
 
 def test_weight_gradients_on_the_side_stream_leave_the_step_unchanged(monkeypatch):
     """The weight-gradient kernels of the backward nodes run on a second stream next to the following layers' data
-    gradients (train.py: wgrad_fork / wgrad_join).  Against everything on one stream (T2V_WGRAD_STREAM=0): the same
+    gradients (train.py: wgrad_fork / wgrad_join), and so do the packed / transformed weight copies of the NEXT step
+    right after the optimiser step (prefetch_packs).  Against everything on one stream (both switched off): the same
     losses and the same updated weights, bit for bit, over three steps on one trainer each (a slot read before its
     side-stream kernels finished, or a buffer handed back to the allocator too early, would show here) -- at a size
     where the ResnetBlock convs take the Winograd-domain path and the others the direct one."""
@@ -500,6 +501,7 @@ def test_weight_gradients_on_the_side_stream_leave_the_step_unchanged(monkeypatc
     runs = {}
     for mode in ("1", "0"):
         monkeypatch.setenv("T2V_WGRAD_STREAM", mode)
+        monkeypatch.setenv("T2V_PACK_PREFETCH", mode)     # (the packed weights of the next step, made on the same side stream)
         tr = T.Vid2VidTrainer(opt, "cuda:0", seed=5)
         prev, ls = None, []
         for _ in range(3):
@@ -508,7 +510,9 @@ def test_weight_gradients_on_the_side_stream_leave_the_step_unchanged(monkeypatc
         nets = [tr.G, tr.D, tr.Df]
         runs[mode] = (ls, [p.detach().clone() for n in nets for p in n.parameters()])
         if mode == "1":
-            assert T._WG_SIDE["stream"] is not None and not T._WG_SIDE["pending"]
+            assert T._WG_SIDE["stream"] is not None
+            ahead = [p for p in tr.G.parameters() if getattr(p, "_t2v_pack_event", None) is not None]
+            assert len(ahead) > 10            # the generator's packed weights for the next step are already under way
     for la, lb in zip(runs["1"][0], runs["0"][0]):
         assert la.keys() == lb.keys() and all(la[k] == lb[k] for k in la), [(k, la[k], lb[k]) for k in la if la[k] != lb[k]]
     assert all(torch.equal(x, y) for x, y in zip(runs["1"][1], runs["0"][1]))

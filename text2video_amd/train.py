@@ -39,11 +39,45 @@ def cached_pack(w, key, make):
     w = getattr(w, "_t2v_owner", w)    # a detached view of a parameter (frozen passes) shares its parameter's cache
     ent = getattr(w, "_t2v_packs", None)
     if ent is None or ent[0] != w._version:
-        ent = (w._version, {})
+        ent = (w._version, {}, {})
         w._t2v_packs = ent
+        w._t2v_pack_event = None
+    elif getattr(w, "_t2v_pack_event", None) is not None:
+        # packed ahead on the side stream (prefetch_packs): the first use in the step waits for that batch
+        torch.cuda.current_stream().wait_event(w._t2v_pack_event)
+        w._t2v_pack_event = None
     if key not in ent[1]:
         ent[1][key] = make()
+        ent[2][key] = make
     return ent[1][key]
+
+
+def invalidate_packs(p):
+    """the optimiser has written `p` (through its raw pointer: no version bump): drop the packed copies, remember how
+    they were made"""
+    ent = getattr(p, "_t2v_packs", None)
+    p._t2v_repack = ent[2] if (ent is not None and len(ent) > 2 and ent[2]) else None
+    p._t2v_packs = None
+    p._t2v_pack_event = None
+
+
+def prefetch_packs(params):
+    """After the optimiser step: every packed / Winograd-transformed / transposed copy the last step used is made again
+    from the new weights NOW, on the side stream -- ~150 small memory-bound kernels per step (36 filter transforms of
+    151 MB each among them) that depend on nothing but the weights and would otherwise sit in front of each layer's
+    first use on the critical path; here they run under the next step's first convs.  T2V_PACK_PREFETCH=0: lazily."""
+    todo = [(p, p._t2v_repack) for p in params if getattr(p, "_t2v_repack", None)]
+    if not todo or os.environ.get("T2V_PACK_PREFETCH", "1") == "0" or not todo[0][0].is_cuda:
+        for p, _ in todo:
+            p._t2v_repack = None
+        return
+    with wgrad_fork():
+        for p, makers in todo:
+            p._t2v_packs = (p._version, {k: mk() for k, mk in makers.items()}, dict(makers))
+            p._t2v_repack = None
+        ev = torch.cuda.current_stream().record_event()
+    for p, _ in todo:
+        p._t2v_pack_event = ev
 
 
 # ------------------------------------------------------------------------------------------------
@@ -412,12 +446,13 @@ class _ConvBlock(torch.autograd.Function):
         if want[2]:
             if sl_b is not None:
                 if norm is None:
-                    if sl_b.filled:
-                        deliver(sl_b, ops.channel_sum(dc, desc.Cout))
-                    else:
-                        ops.channel_sum(dc, desc.Cout, out=sl_b.view)
-                        sl_b.filled = True
-                        sl_b.owner.node_done(sl_b)
+                    with (wgrad_fork(dc) if wgrad_stream_on(dc) else contextlib.nullcontext()):   # (off the dy -> dx chain too)
+                        if sl_b.filled:
+                            _acc(sl_b.view, ops.channel_sum(dc, desc.Cout), False)
+                        else:
+                            ops.channel_sum(dc, desc.Cout, out=sl_b.view)
+                    sl_b.filled = True
+                    sl_b.owner.node_done(sl_b)      # (outside the scope: a bucket launch must see the MAIN stream as current)
                 else:
                     deliver(sl_b, zero=True)
             else:
@@ -928,7 +963,8 @@ class FusedAdam:
                     self.steps[i] += 1
                     ops.adam_step(p.data, p.grad.contiguous(), m, v, self.lr, self.betas[0], self.betas[1], self.eps,
                                   self.steps[i])
-                    p._t2v_packs = None   # written through the raw pointer: no tensor version bump
+                    invalidate_packs(p)   # written through the raw pointer: no tensor version bump
+            prefetch_packs(self.params)
             return
         tab = self._tables()
         if getattr(self, "_pending", None) is not None:
@@ -947,13 +983,14 @@ class FusedAdam:
             k = self.steps[i]
             ph[i, 0], ph[i, 1], ph[i, 2], ph[i, 3] = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr()
             sh[i] = self.lr * math.sqrt(1.0 - b2 ** k) / (1.0 - b1 ** k)
-            p._t2v_packs = None
+            invalidate_packs(p)
         tab["ptrs"].copy_(ph, non_blocking=True)
         tab["ss"].copy_(sh, non_blocking=True)
         ops.adam_step_multi(tab["ptrs"], tab["nelem"], tab["ss"], tab["chunk_tensor"], tab["chunk_off"], self.CHUNK, b1, b2,
                             self.eps)
         # the pinned staging tables are reused by the next step: make sure this step's copies have been issued from them
         self._pending = (grads, torch.cuda.current_stream().record_event())
+        prefetch_packs(self.params)
 
 
 def _acc(dst, src, overwrite):
@@ -1529,7 +1566,7 @@ class Vid2VidTrainer:
                         print("continue_train: %s has no %s, keeping its initial value" % (path, k), flush=True)
                         continue
                     p.copy_(sd[k].to(p.device, torch.float32))
-                    p._t2v_packs = None
+                    p._t2v_packs = p._t2v_repack = p._t2v_pack_event = None
                     if k.endswith(".weight") and p.dim() == 1 and k[:-len("weight")] + "running_mean" in sd:
                         base = k[:-len("weight")]
                         nbt = sd.get(base + "num_batches_tracked")
