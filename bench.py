@@ -415,19 +415,26 @@ def main():
         k_flop = 2.0 * npos * ntile * C * C if use_wino else conv_flop
         achieved = k_flop / (k_ms * 1e-3) / 1e12
         traffic = None
+        # the fixed-grid form of the F(4x4) GEMM stage (conv_igemm.hip: wino_gemm_sk_ok -- same rule restated here for the
+        # label only): whole 128-row tiles, at least one round of the 512 resident blocks, a badly filled last round
+        sk_tiles = npos * (ntile // 128) * (C // 128) if (algo == ops.ALGO_WINOGRAD_F4 and ntile % 128 == 0) else 0
+        fixed_grid = bool(sk_tiles >= 512 and sk_tiles * 100 <= -(-sk_tiles // 512) * 512 * 85
+                          and os.environ.get("T2V_WINO_GEMM_SK", "1") != "0")
         prof = os.path.join(ROOT, "profiles", "pmc_summary.json")
         if os.path.exists(prof):
             try:
                 traffic = json.load(open(prof)).get({0: "conv_igemm_rb_hbm_bytes_per_launch",
                                                      1: "winograd_f2_gemm_hbm_bytes_per_launch",
-                                                     2: "winograd_f4_gemm_hbm_bytes_per_launch"}[algo]
+                                                     2: ("winograd_f4_gemm_sk_hbm_bytes_per_launch" if fixed_grid else
+                                                         "winograd_f4_gemm_hbm_bytes_per_launch")}[algo]
                                                     if (hb, wb) == (64, 64) else "-")
             except Exception:
                 traffic = None
-        kname = ("conv_igemm_kernel<%s,fp32 32x32x2> as %d batched GEMMs [%d x 1024]x[1024 x 1024]: Winograd "
-                 "F(%dx%d,3x3) stage of the 1024->1024 3x3 ResnetBlock conv @%dx%d"
-                 % ("128x128" if npos * ntile // 128 * 8 >= 0.8 * 256 * -(-(npos * ntile // 128 * 8) // 256) else "64x64",
-                    npos, ntile, wm, wm, hb, wb)
+        kname = (("wino_gemm_sk_kernel<128x128 tiles on a fixed grid of 2 blocks per CU,fp32 32x32x2>"
+                  if fixed_grid else "conv_igemm_kernel<%s,fp32 32x32x2>"
+                  % ("128x128" if npos * ntile // 128 * 8 >= 0.8 * 256 * -(-(npos * ntile // 128 * 8) // 256) else "64x64"))
+                 + " as %d batched GEMMs [%d x 1024]x[1024 x 1024]: Winograd F(%dx%d,3x3) stage of the 1024->1024 3x3 "
+                   "ResnetBlock conv @%dx%d" % (npos, ntile, wm, wm, hb, wb)
                  if use_wino else
                  "conv_igemm_kernel<128x128,fp32 32x32x2,reflect,stats> 1024->1024 3x3 @%dx%d" % (hb, wb))
         roofline = {"bound": "mfma", "kernel": kname,

@@ -12,24 +12,35 @@ for nb in 1 2 4; do
   T2V_STREAMS=1 bash scripts/prof_frames.sh r03b$nb --frames $((40 / nb)) --batch $nb > $O/frames_flow_batch${nb}_1stream.txt 2>&1
 done
 T2V_STREAMS=1 T2V_NORM_TICKET=1 bash scripts/prof_frames.sh r03t --frames 20 --batch 2 > $O/frames_flow_batch2_ticket_1stream.txt 2>&1
-# 3. PMC on the batched Winograd GEMM stage inside frames (batch 2 and 4): one counter group per run
-for nb in 2 4; do
+# 3. PMC on the batched Winograd GEMM stage inside frames (1 / 2 sequences: the fixed-grid kernel; 4: one block per tile):
+#    one counter group per run
+for nb in 1 2 4; do
   i=0
+  pat="wino_gemm_sk"; [ $nb = 4 ] && pat="false, false, 2"
   for grp in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES" "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"; do
     i=$((i+1)); out=$O/pmc_gemm_b$nb/p$i; mkdir -p $out
     T2V_STREAMS=1 timeout 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $out -o pmc -- python scripts/frame_prof.py --frames 6 --batch $nb > $out/log.txt 2>&1
     f=$(find $out -name "*counter_collection.csv" | head -1)
-    python scripts/pmc_summary.py ${f%_counter_collection.csv} "false, false, 2" > $O/pmc_wino4_gemm_batch${nb}_p$i.txt 2>&1
+    python scripts/pmc_summary.py ${f%_counter_collection.csv} "$pat" > $O/pmc_wino4_gemm_batch${nb}_p$i.txt 2>&1
   done
 done
 # 4. two-stream A/B of the knobs tried this round (alternating runs on this one box)
 for i in 1 2; do
   python scripts/batch_probe.py --flow 1 --batches 1,2,4
+  T2V_WINO_GEMM_SK=0 python scripts/batch_probe.py --flow 1 --batches 1,2,4
   T2V_NORM_TICKET=1 python scripts/batch_probe.py --flow 1 --batches 1,2
-  T2V_WINO_GEMM_TILE=2 python scripts/batch_probe.py --flow 1 --batches 2,4
+  T2V_WINO_GEMM_SK=0 T2V_WINO_GEMM_TILE=2 python scripts/batch_probe.py --flow 1 --batches 2,4
 done > $O/ab_batch_ticket_tile.txt 2>&1
-# 5. train step
-( python scripts/train_bench.py --iters 5; T2V_GRAD_DIRECT=0 python scripts/train_bench.py --iters 5; python scripts/train_bench.py --iters 5 --no_flow; python scripts/train_bench.py --iters 5 --no_flow --no_face; python scripts/train_bench.py --iters 5 --vgg ) 2>&1 | grep -v "amdgpu.ids\|^warning" > $O/train_bench.txt
+python scripts/sk_probe.py > $O/sk_probe.txt 2>&1
+# 5. train step: everything on, then the round's changes switched off one after the other
+( python scripts/train_bench.py --iters 5
+  T2V_PACK_PREFETCH=0 python scripts/train_bench.py --iters 5
+  T2V_PACK_PREFETCH=0 T2V_WGRAD_STREAM=0 python scripts/train_bench.py --iters 5
+  T2V_PACK_PREFETCH=0 T2V_WGRAD_STREAM=0 T2V_WINO_GEMM_SK=0 python scripts/train_bench.py --iters 5
+  T2V_PACK_PREFETCH=0 T2V_WGRAD_STREAM=0 T2V_WINO_GEMM_SK=0 T2V_DGRAD_TRANSPOSED=0 python scripts/train_bench.py --iters 5
+  T2V_PACK_PREFETCH=0 T2V_WGRAD_STREAM=0 T2V_WINO_GEMM_SK=0 T2V_DGRAD_TRANSPOSED=0 T2V_D_SHARED_FWD=0 python scripts/train_bench.py --iters 5
+  T2V_PACK_PREFETCH=0 T2V_WGRAD_STREAM=0 T2V_WINO_GEMM_SK=0 T2V_DGRAD_TRANSPOSED=0 T2V_D_SHARED_FWD=0 T2V_GRAD_DIRECT=0 T2V_WGRAD_COMBINE=0 python scripts/train_bench.py --iters 5
+  python scripts/train_bench.py --iters 5 --no_flow; python scripts/train_bench.py --iters 5 --no_flow --no_face; python scripts/train_bench.py --iters 5 --vgg ) 2>&1 | grep -v "amdgpu.ids\|^warning" > $O/train_bench.txt
 bash scripts/prof_train.sh > $O/train_step_kernel_summary.txt 2>&1
 cp gpurun_out/prof_train/train_kernel_stats.csv $O/train_step_kernel_stats.csv
 # the raw traces are tens of MB each: keep the summaries only (gpurun merges at most 64 MiB back)
