@@ -586,7 +586,10 @@ __global__ __launch_bounds__(512) void wino_gemm_sk_kernel(const SkKParams p) {
             // the accumulators block j-1 (blockIdx - 8) left for this tile; its wave `wid` wrote what this wave reads
             const int src = blockIdx.x - 8;
             const unsigned long long* fl = p.flags + src * 4 + wid;
-            while (__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.tag) __builtin_amdgcn_s_sleep(4);
+            // (bounded: ~1 s of polling.  The producer ran before this block was even dispatched; if its tag is still
+            // missing something is broken, and a wrong tile is a better failure than a hung GPU)
+            for (int spin = 0; spin < (1 << 23) && __hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.tag; ++spin)
+                __builtin_amdgcn_s_sleep(4);
             // write-through (sc1) stores on the producer's side, sc1 loads here: the pair that is coherent across the
             // XCDs' L2s inside one launch; 16 x 16 bytes per lane at scalar offsets off one SRD
             const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(
