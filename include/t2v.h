@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define T2V_ABI_VERSION 8
+#define T2V_ABI_VERSION 9
 
 typedef enum {
     T2V_OK = 0,
@@ -114,6 +114,9 @@ int t2v_conv_best_algo(const t2v_conv_desc* d, int x_cs, int cap);
  * hand-over area of the fixed-grid GEMM stage (blocks that share a 128x128 tile pass accumulators through it; any
  * content on entry, one workspace per conv in flight) */
 size_t t2v_conv_winograd_workspace_floats(const t2v_conv_desc* d, int x_cs);
+/* GEMM rows one image contributes per F(4x4,3x3) transform position: its ceil(H/4) x ceil(W/4) tiles padded to the
+ * 64 / 128-row granule (the slot pitch of the batch-wide tile lists in the weight-gradient workspace) */
+int t2v_conv_winograd_tile_rows(const t2v_conv_desc* d);
 /* forward with d->algo == T2V_ALGO_WINOGRAD | T2V_ALGO_WINOGRAD_F4; same contract as t2v_conv2d_forward plus the workspace */
 int t2v_conv2d_forward_winograd(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, const float* x, int x_cs,
                                 const float* w_packed, const float* bias, float* y, int y_cs, float* stats_partial,

@@ -126,7 +126,8 @@ def test_algorithm_choice_and_winograd_bookkeeping(lib_built):
     assert lib_built.t2v_conv_winograd_workspace_floats(ctypes.byref(r), 1024) == 36 * 192 * 2048 + 1024 * 4 * (64 * 64 + 2)   # 160 tiles -> 192
     assert lib_built.t2v_conv_backward_weight_winograd_supported(ctypes.byref(f4), 1024, 1024) == 1
     assert lib_built.t2v_conv_backward_weight_winograd_workspace_floats(ctypes.byref(f4), 1024, 2) == \
-        36 * 2 * 256 * 2048 + 36 * 1024 * 1024
+        36 * 2 * 256 * 2048 + 36 * 1024 * 1024 + 1024 * 4 * (64 * 64 + 2)     # V + M_dy, dU, the fixed grid's hand-over area
+    assert lib_built.t2v_conv_winograd_tile_rows(ctypes.byref(f4)) == 256 and lib_built.t2v_conv_winograd_tile_rows(ctypes.byref(r)) == 192
     # activations of 2 GiB and more do not fit the kernels' 32-bit buffer offsets: the plan refuses them (no wrap)
     big = desc(2048, 2048, C=128)
     assert lib_built.t2v_conv_stats_floats(ctypes.byref(big)) == 0 and b"too large" in lib_built.t2v_last_error()

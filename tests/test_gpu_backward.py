@@ -300,6 +300,34 @@ def test_in_kernel_combine_of_split_weight_gradients_equals_the_reduce_launch(mo
         assert outs[("0", 0)][0].abs().max().item() > 1.0
 
 
+@pytest.mark.parametrize("geom", [(64, 64, 1024, 1024, 2), (64, 88, 640, 896, 2), (32, 32, 512, 488, 3)], ids=["rb1024x2", "ragged", "cout488"])
+def test_fixed_grid_winograd_domain_weight_gradient_equals_tile_per_block(geom, monkeypatch):
+    """The 36 Winograd-domain reductions dU[xi] = M_dy[xi]^T V[xi] on a fixed grid (conv_wgrad.hip: wino_wgrad_sk_kernel;
+    a tile cut between two blocks is finished from the first block's accumulators) against one block per tile
+    (T2V_WGRAD_SK=0): the same t-ordered MFMA chain per element, so dW is BIT-identical -- launch after launch on one
+    workspace, with channel counts that are not multiples of the 128-wide tiles, and with accumulation."""
+    from text2video_amd import ops
+    H, W, Cin, Cout, B = geom
+    torch.manual_seed(4)
+    desc = ops.conv_desc(H, W, Cin, Cout, 3, 1, 1, ops.PAD_REFLECT)
+    x = torch.randn(B, H, W, Cin, device="cuda:0")
+    dy = torch.randn(B, H, W, Cout, device="cuda:0")
+    ws = ops.backward_weight_winograd_workspace(desc, Cin, B, x.device)
+    ws.fill_(float("nan"))
+    ops.conv2d_backward_weight_winograd_stages(x, dy, desc, ws, B, 0, False)
+    monkeypatch.setenv("T2V_WGRAD_SK", "0")
+    want = ops.conv2d_backward_weight_winograd_reduce(desc, ws, B, Cin, Cout).clone()
+    base = torch.randn_like(want)
+    want_acc = ops.conv2d_backward_weight_winograd_reduce(desc, ws, B, Cin, Cout, out=base.clone(), accumulate=True).clone()
+    monkeypatch.setenv("T2V_WGRAD_SK", "1")
+    for rep in range(6):
+        got = ops.conv2d_backward_weight_winograd_reduce(desc, ws, B, Cin, Cout)
+        assert torch.equal(got, want), "launch %d: %d of %d differ" % (rep, int((got != want).sum()), got.numel())
+    got_acc = ops.conv2d_backward_weight_winograd_reduce(desc, ws, B, Cin, Cout, out=base.clone(), accumulate=True)
+    assert torch.equal(got_acc, want_acc)
+    assert bool(torch.isfinite(want).all()) and want.abs().max().item() > 1.0
+
+
 @pytest.mark.parametrize("H,W,Cin,Cout", [(32, 32, 64, 64), (16, 32, 128, 64), (64, 64, 128, 128)], ids=["32x32", "16x32", "64x64"])
 def test_transposed_winograd_data_gradient_matches_autograd(H, W, Cin, Cout):
     """Data gradient of the ResnetBlock conv (3x3, ReflectionPad 1) by the transposed Winograd algorithm: A dy A^T is read out

@@ -641,7 +641,11 @@ size_t t2v_conv_backward_weight_winograd_workspace_floats(const t2v_conv_desc* d
     if (!d || batch < 1 || !winograd_supported(d, x_cs, T2V_ALGO_WINOGRAD_F4)) return 0;
     const size_t Tp = (size_t)wino_tiles_padded(d, T2V_ALGO_WINOGRAD_F4);
     const size_t Cout_p = (size_t)round_up(d->Cout, 128), Kp = (size_t)round_up(x_cs, kBK);
-    return 36 * batch * Tp * ((size_t)x_cs + d->Cout) + 36 * Cout_p * Kp;
+    // V, M_dy, dU, then the hand-over area of the fixed-grid reduction (conv_wgrad.hip: wino_wgrad_sk_kernel)
+    return 36 * batch * Tp * ((size_t)x_cs + d->Cout) + 36 * Cout_p * Kp + wino_gemm_sk_scratch_floats();
+}
+int t2v_conv_winograd_tile_rows(const t2v_conv_desc* d) {
+    return d ? wino_tiles_padded(d, T2V_ALGO_WINOGRAD_F4) : 0;
 }
 int t2v_conv2d_backward_weight_winograd_stages(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, int batch, int b0,
                                                int nb, const float* x, int x_cs, const float* dy, int dy_cs,
@@ -689,7 +693,10 @@ int t2v_conv2d_backward_weight_winograd_stages(t2v_ctx* ctx, void* stream, const
     w.ntaps = 36;
     w.splits = 1;
     w.dw_floats = (long)36 * Cout_p * Kp;
-    T2V_TRY(launch_conv_wgrad(s, w));
+    if (wino_wgrad_sk_ok(Tt, x_cs, d->Cout))
+        T2V_TRY(launch_wino_wgrad_sk(s, V, Md, dU, dU + (size_t)36 * Cout_p * Kp, Tt, x_cs, d->Cout, Cout_p, Kp));
+    else
+        T2V_TRY(launch_conv_wgrad(s, w));
     return launch_winograd4_dw(s, dU, dw_torch, d->Cout, d->Cin, Cout_p, Kp, accumulate);
 }
 

@@ -696,7 +696,7 @@ __global__ __launch_bounds__(512) void wino_gemm_sk_kernel(const SkKParams p) {
     }
 }
 
-static int sk_grid_blocks() {
+int wino_gemm_sk_grid_blocks() {
     static int n = 0;
     if (!n) {
         int dev = 0, cus = 0;
@@ -715,15 +715,14 @@ bool wino_gemm_sk_ok(int groups, int T, int K, int N, int c_cs) {
     // fewer tiles than resident blocks: one tile per block is already less than one round.  Beyond that the fixed grid
     // pays where whole tiles fill their last round badly -- measured on MI355X (scripts/sk_probe.py, K = N = 1024):
     // 1.125 rounds 189 -> 144 us, 1.69 rounds 241 -> 210 us, 2.25 rounds 352 -> 294 us, 4.5 rounds 583 -> 611 us
-    const long tiles = (long)groups * (T / 128) * (N / 128), grid = sk_grid_blocks();
+    const long tiles = (long)groups * (T / 128) * (N / 128), grid = wino_gemm_sk_grid_blocks();
     if (tiles < grid) return false;
     if (e && atoi(e) == 2) return true;   // T2V_WINO_GEMM_SK=2: wherever the shape allows
     const long rounds = (tiles + grid - 1) / grid;
     return tiles * 100 <= rounds * grid * 85;
 }
 
-int launch_wino_gemm_sk(hipStream_t s, const SkGemm& g) {
-    T2V_REQUIRE(wino_gemm_sk_ok(g.groups, g.T, g.K, g.N, g.c_cs), "stream-K gemm: shape not supported");
+unsigned long long wino_gemm_sk_next_tag() {
     static std::atomic<unsigned long long> tag_counter{0};
     if (tag_counter.load() == 0) {
         unsigned long long seed = 0;
@@ -733,16 +732,21 @@ int launch_wino_gemm_sk(hipStream_t s, const SkGemm& g) {
         unsigned long long zero = 0;
         tag_counter.compare_exchange_strong(zero, (seed >> 1) | 1ull);
     }
+    return ++tag_counter;
+}
+
+int launch_wino_gemm_sk(hipStream_t s, const SkGemm& g) {
+    T2V_REQUIRE(wino_gemm_sk_ok(g.groups, g.T, g.K, g.N, g.c_cs), "stream-K gemm: shape not supported");
     SkKParams k;
     k.a = g.a; k.b = g.b; k.c = g.c;
     k.partial = g.scratch;
     k.flags = reinterpret_cast<unsigned long long*>(g.scratch + (size_t)kSkMaxGrid * 4 * 64 * 64);
-    k.tag = ++tag_counter;
+    k.tag = wino_gemm_sk_next_tag();
     k.a_group_stride = g.a_group_stride;
     k.T = g.T; k.K = g.K; k.N = g.N; k.c_cs = g.c_cs;
     k.mtiles_g = g.T / 128; k.ntiles = g.N / 128; k.nk = g.K / kBK;
     k.tiles = g.groups * k.mtiles_g * k.ntiles;
-    const int grid = sk_grid_blocks();
+    const int grid = wino_gemm_sk_grid_blocks();
     k.blocks_per_xcd = grid / 8;
     k.tiles_per_xcd = (k.tiles + 7) / 8;
     auto kern = wino_gemm_sk_kernel<2>;

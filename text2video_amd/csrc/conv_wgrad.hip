@@ -306,6 +306,270 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradParams p) {
         if (off[q] >= 0) *reinterpret_cast<float4*>(fin + off[q]) = sum[q];
 }
 
+// ---- the Winograd-domain weight gradient on a fixed grid --------------------------------------------------------------------
+// dU[xi][n][c] = sum_t M_dy[xi][t][n] * V[xi][t][c] for the 36 transform positions: 36 x (Cout/128) x (Cin/128) output tiles,
+// each a reduction over the Tt tile rows of all frames (512 for two 512x512 frames = 32 stages of 16 rows).  One block per
+// tile (conv_wgrad_kernel with 36 "taps") is 2304 short blocks = 4.5 rounds of the 512 resident ones, each paying its own
+// pipeline fill and 64 KiB epilogue.  Here, as in conv_igemm.hip's wino_gemm_sk_kernel: a grid of the resident blocks, every
+// block an equal run of the tile-major (tile, stage) list; a tile cut between two blocks is FINISHED by the second one from
+// the first one's accumulators (head first, tail last: nobody waits for a block dispatched after it), so every dU element is
+// the same t-ordered MFMA chain as with one block per tile -- bit-identical.  Both operands are plain row-major matrices:
+// the loaders' per-lane offsets are fixed for the whole block and a stage is one scalar offset (no address VALU per stage),
+// and they fetch the next tile's first stages while the MFMA waves store the previous tile.
+struct WinoWgradSkParams {
+    const float* v;               // [36][Tt][Cin]
+    const float* m;               // [36][Tt][Cout]
+    float* du;                    // [36][Cout_p][Kp]
+    float* partial;               // [grid][4 waves][64 regs][64 lanes]
+    unsigned long long* flags;    // [grid][4 waves]
+    unsigned long long tag;
+    int Tt, Cin, Cout, Cout_p, Kp;
+    int ntiles, ctiles, nk, tiles, tiles_per_xcd, blocks_per_xcd;
+};
+typedef unsigned int wg_v4u __attribute__((__vector_size__(16)));
+
+template <int PIX, int RING>
+__global__ __launch_bounds__(512) void wino_wgrad_sk_kernel(const WinoWgradSkParams p) {
+    constexpr int kStage = 2 * PIX * 128 * 4;
+    constexpr int RW = PIX / 4, NI = PIX / 8, LD = 2 * NI, AHEAD = RING - 1;
+    constexpr int kOOB = 0x7fff0000;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool is_loader = wave >= 4;
+    const int wid = wave & 3;
+
+    // ---- this block's run of (tile, stage) units, relative to its XCD's first tile (see wino_gemm_sk_kernel) ----
+    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int t0 = xcd * p.tiles_per_xcd, t1 = min(t0 + p.tiles_per_xcd, p.tiles);
+    if (t0 >= t1) return;
+    const int nk = p.nk;
+    const int ux = (t1 - t0) * nk;
+    const int S = max(nk, (ux + p.blocks_per_xcd - 1) / p.blocks_per_xcd);
+    const int u0 = jb * S, u1 = min(u0 + S, ux);
+    if (u0 >= u1) return;
+    const int tf = u0 / nk, tl = (u1 - 1) / nk;
+    const int kf = u0 - tf * nk, kl = u1 - tl * nk;
+    const int has_tail = kf > 0, has_head = kl < nk;
+    const int nf = tl - tf + 1, nmid = nf - has_head - has_tail;
+
+    // loader lanes: an instruction moves 2 tile rows x 512 B; lane -> (row of the pair, 16-byte chunk of the channel slice)
+    const int prow = lane >> 5, chunk = lane & 31;
+    int vm[NI], vx[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int r = wid * RW + i * 2 + prow;
+        vm[i] = (r * p.Cout + chunk * 4) * 4;
+        vx[i] = (r * p.Cin + chunk * 4) * 4;
+    }
+    // MFMA waves: 2 x 2 waves, each 64 (n) x 64 (c)
+    const int wn = wid >> 1, wc = wid & 1;
+    const int fi = lane & 31, kk = lane >> 5;
+    constexpr int NQ = PIX / 8;
+    static_assert(NQ % 2 == 0, "operand register sets alternate per group");
+    float av[2][4][2], bv[2][4][2];
+    auto load_group = [&](int buf, int q, int set) {
+        const float* sY = reinterpret_cast<const float*>(smem + buf * kStage);
+        const float* sX = sY + PIX * 128;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int px = 8 * q + 2 * e + kk;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) av[set][e][i] = sY[px * 128 + wn * 64 + i * 32 + fi];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bv[set][e][j] = sX[px * 128 + wc * 64 + j * 32 + fi];
+        }
+    };
+
+    bool flag_due = false;
+    for (int f = 0; f < nf; ++f) {
+        int tr;
+        if (has_head && f == 0) tr = tl;
+        else if (f - has_head < nmid) tr = tf + has_tail + (f - has_head);
+        else tr = tf;
+        const int kb = tr == tf ? kf : 0, ke = tr == tl ? kl : nk;
+        const bool init = kb > 0, publish = ke < nk;
+        const int tile = t0 + tr;
+        const int tpp = p.ntiles * p.ctiles;
+        const int xi = tile / tpp, rem = tile - xi * tpp;
+        const int nt = rem / p.ctiles, ct = rem - nt * p.ctiles;   // c tile fastest: neighbours share the M_dy tile
+        const int n0 = nt * 128, c0 = ct * 128;
+
+        if (is_loader) {
+            const float* mbase = p.m + ((long)xi * p.Tt + (long)kb * PIX) * p.Cout + n0;
+            const float* xbase = p.v + ((long)xi * p.Tt + (long)kb * PIX) * p.Cin + c0;
+            const bool n_ok = n0 + chunk * 4 < p.Cout, c_ok = c0 + chunk * 4 < p.Cin;
+            auto issue_stage = [&](int kt, int slot) {
+                char* sY = smem + slot * kStage + wid * RW * 512;
+                char* sX = sY + PIX * 512;
+                const int so_m = (kt - kb) * PIX * p.Cout * 4, so_x = (kt - kb) * PIX * p.Cin * 4;
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    wg_dma16(mbase, kOOB, sY + i * 2 * 512, n_ok ? vm[i] : kOOB, so_m);
+                    wg_dma16(xbase, kOOB, sX + i * 2 * 512, c_ok ? vx[i] : kOOB, so_x);
+                }
+            };
+#pragma unroll
+            for (int st = 0; st < AHEAD; ++st) issue_stage(min(kb + st, ke - 1), st);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * LD) : "memory");
+            __builtin_amdgcn_s_barrier();   // B0
+            int slot = AHEAD % RING;
+            for (int kt = kb; kt < ke; ++kt) {
+                issue_stage(min(kt + AHEAD, ke - 1), slot);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * LD) : "memory");
+                __builtin_amdgcn_s_barrier();
+                slot = slot == RING - 1 ? 0 : slot + 1;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();   // the MFMA waves have read their last operands: the next tile's prologue may refill the ring
+            continue;
+        }
+
+        // ---- MFMA waves ----
+        f32x16 acc[2][2];
+        if (init) {
+            const int src = blockIdx.x - 8;
+            const unsigned long long* fl = p.flags + src * 4 + wid;
+            for (int spin = 0; spin < (1 << 23) && __hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.tag; ++spin)
+                __builtin_amdgcn_s_sleep(4);
+            const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(p.partial) + (size_t)(src * 4 + wid) * 4096, 0, 16384, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        auto raw = __builtin_amdgcn_raw_buffer_load_b128(srd, lane * 16, ((i * 2 + j) * 4 + q) * 1024, /*sc1*/ 16);
+                        float v[4];
+                        __builtin_memcpy(v, &raw, 16);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[i][j][q * 4 + e] = v[e];
+                    }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        }
+        if (flag_due) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0)
+                __hip_atomic_store(p.flags + blockIdx.x * 4 + wid, p.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            flag_due = false;
+        }
+        __syncthreads();   // B0
+        load_group(0, 0, 0);
+        int buf = 0;
+        for (int kt = kb; kt < ke; ++kt) {
+            const int nbuf = buf == RING - 1 ? 0 : buf + 1;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int cur = q & 1;
+                __builtin_amdgcn_sched_barrier(0);
+                if (q + 1 == NQ) {
+                    __syncthreads();
+                    __builtin_amdgcn_sched_barrier(0);
+                    load_group(nbuf, 0, cur ^ 1);
+                } else {
+                    load_group(buf, q + 1, cur ^ 1);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][e][i], bv[cur][e][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+            }
+            buf = nbuf;
+        }
+        __syncthreads();   // pairs with the loaders' closing barrier
+
+        if (publish) {
+            const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(
+                p.partial + (size_t)(blockIdx.x * 4 + wid) * 4096, 0, 16384, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][q * 4 + e];
+                        wg_v4u raw;
+                        __builtin_memcpy(&raw, v, 16);
+                        __builtin_amdgcn_raw_buffer_store_b128(raw, srd, lane * 16, ((i * 2 + j) * 4 + q) * 1024, /*sc1*/ 16);
+                    }
+            flag_due = true;
+        } else {
+            // D[row n][col c] -> dU[xi][n][c]: one SRD on the tile's first element, one per-lane offset, scalar row steps
+            const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(
+                p.du + ((size_t)xi * p.Cout_p + n0) * p.Kp + c0, 0, 0x7ffffffc, 0x00020000);
+            const int voff = ((wn * 64 + 4 * kk) * p.Kp + wc * 64 + fi) * 4;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = i * 32 + (r & 3) + 8 * (r >> 2);
+                    const bool row_ok = n0 + wn * 64 + 4 * kk + row < p.Cout;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const float v = acc[i][j][r];
+                        if (row_ok && c0 + wc * 64 + j * 32 + fi < p.Cin)
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), srd, voff + j * 32 * 4, row * p.Kp * 4, 0);
+                    }
+                }
+        }
+    }
+    if (flag_due) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_store(p.flags + blockIdx.x * 4 + wid, p.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+bool wino_wgrad_sk_ok(int Tt, int Cin, int Cout) {
+    const char* e = getenv("T2V_WGRAD_SK");
+    if ((e && atoi(e) == 0) || Tt % 16 || Cin % 4 || Cout % 4) return false;
+    const long tiles = 36L * ((Cout + 127) / 128) * ((Cin + 127) / 128);
+    return tiles >= wino_gemm_sk_grid_blocks();
+}
+
+int launch_wino_wgrad_sk(hipStream_t s, const float* V, const float* Md, float* dU, float* scratch, int Tt, int Cin, int Cout,
+                         int Cout_p, int Kp) {
+    T2V_REQUIRE(wino_wgrad_sk_ok(Tt, Cin, Cout), "fixed-grid weight gradient: shape not supported");
+    WinoWgradSkParams k;
+    k.v = V; k.m = Md; k.du = dU;
+    k.partial = scratch;
+    k.flags = reinterpret_cast<unsigned long long*>(scratch + wino_gemm_sk_scratch_floats() - 1024 * 4 * 2);
+    k.tag = wino_gemm_sk_next_tag();
+    k.Tt = Tt; k.Cin = Cin; k.Cout = Cout; k.Cout_p = Cout_p; k.Kp = Kp;
+    k.ntiles = (Cout + 127) / 128; k.ctiles = (Cin + 127) / 128; k.nk = Tt / 16;
+    k.tiles = 36 * k.ntiles * k.ctiles;
+    const int grid = wino_gemm_sk_grid_blocks();
+    k.blocks_per_xcd = grid / 8;
+    k.tiles_per_xcd = (k.tiles + 7) / 8;
+    auto kern = wino_wgrad_sk_kernel<16, 4>;
+    constexpr int lds = 4 * 2 * 16 * 128 * 4;
+    static bool attr_done = false;
+    if (!attr_done) {
+        T2V_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, k);
+    T2V_HIP_CHECK(hipGetLastError());
+    return T2V_OK;
+}
+
 __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int splits, long n, float* __restrict__ dw,
                                     int accumulate) {
     const long stride = (long)gridDim.x * blockDim.x;

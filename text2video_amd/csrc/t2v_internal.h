@@ -210,6 +210,12 @@ struct SkGemm {
 size_t wino_gemm_sk_scratch_floats();
 bool wino_gemm_sk_ok(int groups, int T, int K, int N, int c_cs);
 int launch_wino_gemm_sk(hipStream_t s, const SkGemm& g);
+int wino_gemm_sk_grid_blocks();                 // two blocks per CU, a multiple of 8
+unsigned long long wino_gemm_sk_next_tag();     // hand-over tags: unique per launch, process-wide
+// the same scheme for the Winograd-domain weight gradient dU[xi] = M_dy[xi]^T V[xi] (conv_wgrad.hip); scratch as above
+bool wino_wgrad_sk_ok(int Tt, int Cin, int Cout);
+int launch_wino_wgrad_sk(hipStream_t s, const float* V, const float* Md, float* dU, float* scratch, int Tt, int Cin, int Cout,
+                         int Cout_p, int Kp);
 
 // elementwise.hip
 // scratch (optional): kFinalizeMaxGroups * C * 4 doubles -- lets big layers pool their partials on many CUs

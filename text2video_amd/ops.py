@@ -83,6 +83,11 @@ def with_algo(desc, algo):
                     desc.transposed, desc.act, desc.act_scale, desc.output_padding, algo)
 
 
+def winograd_tile_rows(desc):
+    """GEMM rows one image contributes per F(4x4,3x3) transform position (tile count, padded)"""
+    return _lib.load().t2v_conv_winograd_tile_rows(ctypes.byref(desc))
+
+
 def winograd_workspace(desc, x_cs, device):
     n = _lib.load().t2v_conv_winograd_workspace_floats(ctypes.byref(desc), x_cs)
     if n == 0:

@@ -240,8 +240,7 @@ def flush_pending_weight_gradients(params, grads):
         ws, done, _, fdesc, xcs, dycs = st
         total = p._t2v_wg_images
         if done > 0:
-            cout_p, kp = ops.round_up(fdesc.Cout, 128), ops.round_up(xcs, 32)
-            tp = (ws.numel() - 36 * cout_p * kp) // (36 * total * (xcs + fdesc.Cout))
+            tp = ops.winograd_tile_rows(fdesc)      # slot pitch of the batch-wide tile lists
             nv = 36 * total * tp * xcs
             ws[:nv].view(36, total, tp * xcs)[:, done:].zero_()
             # (their A dy A^T slots too: 0 x whatever the allocation held is not 0 for a NaN / Inf bit pattern)
