@@ -32,17 +32,8 @@ for i in 1 2; do
   T2V_WINO_GEMM_SK=0 T2V_WINO_GEMM_TILE=2 python scripts/batch_probe.py --flow 1 --batches 2,4
 done > $O/ab_batch_ticket_tile.txt 2>&1
 python scripts/sk_probe.py > $O/sk_probe.txt 2>&1
-# 5. train step: everything on, then the round's changes switched off one after the other
-( python scripts/train_bench.py --iters 5
-  T2V_PACK_PREFETCH=0 python scripts/train_bench.py --iters 5
-  T2V_PACK_PREFETCH=0 T2V_WGRAD_STREAM=0 python scripts/train_bench.py --iters 5
-  T2V_PACK_PREFETCH=0 T2V_WGRAD_STREAM=0 T2V_WINO_GEMM_SK=0 python scripts/train_bench.py --iters 5
-  T2V_PACK_PREFETCH=0 T2V_WGRAD_STREAM=0 T2V_WINO_GEMM_SK=0 T2V_DGRAD_TRANSPOSED=0 python scripts/train_bench.py --iters 5
-  T2V_PACK_PREFETCH=0 T2V_WGRAD_STREAM=0 T2V_WINO_GEMM_SK=0 T2V_DGRAD_TRANSPOSED=0 T2V_D_SHARED_FWD=0 python scripts/train_bench.py --iters 5
-  T2V_PACK_PREFETCH=0 T2V_WGRAD_STREAM=0 T2V_WINO_GEMM_SK=0 T2V_DGRAD_TRANSPOSED=0 T2V_D_SHARED_FWD=0 T2V_GRAD_DIRECT=0 T2V_WGRAD_COMBINE=0 python scripts/train_bench.py --iters 5
-  python scripts/train_bench.py --iters 5 --no_flow; python scripts/train_bench.py --iters 5 --no_flow --no_face; python scripts/train_bench.py --iters 5 --vgg ) 2>&1 | grep -v "amdgpu.ids\|^warning" > $O/train_bench.txt
-bash scripts/prof_train.sh > $O/train_step_kernel_summary.txt 2>&1
-cp gpurun_out/prof_train/train_kernel_stats.csv $O/train_step_kernel_stats.csv
+# 5. train step
+bash scripts/r03_train_profiles.sh $O
 # the raw traces are tens of MB each: keep the summaries only (gpurun merges at most 64 MiB back)
 rm -rf $O/bench_prof $O/pmc_gemm_b2 $O/pmc_gemm_b4 gpurun_out/prof_frames_r03* gpurun_out/prof_train
 ls -la $O
