@@ -17,6 +17,8 @@ ap.add_argument("--no_face", action="store_true")
 ap.add_argument("--vgg", action="store_true", help="add the VGG19 perceptual loss (seeded random weights)")
 ap.add_argument("--aten_stacks", action="store_true", help="one step under torch.profiler: where the ATen fills / adds / "
                 "copies of the step come from (python call sites, by count)")
+ap.add_argument("--host_time", action="store_true", help="also report when the host has finished ENQUEUEING a step (return of "
+                "the last optimiser step, before the losses are read back): host-bound or GPU-bound?")
 ap.add_argument("--force_dist", action="store_true", help="run the gradient exchange on a 1-rank RCCL group and report its "
                 "bytes, buckets and the part still running after the backward pass")
 args = ap.parse_args()
@@ -54,11 +56,24 @@ def step():
 
 
 step(); step(); torch.cuda.synchronize()
+host_marks = []
+if args.host_time:
+    _optD_step = tr.optD.step
+
+    def _marked():
+        _optD_step()
+        host_marks.append(time.perf_counter())
+    tr.optD.step = _marked
 t0 = time.perf_counter()
+starts = []
 for _ in range(args.iters):
+    starts.append(time.perf_counter())
     losses = step()
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / args.iters
+if args.host_time:
+    print("host has enqueued the step after %.1f ms on average (of %.1f ms per step)"
+          % (1e3 * sum(m - s0 for m, s0 in zip(host_marks, starts)) / len(starts), dt * 1e3))
 print("train step %dx%d, %d frames, %s%s%s: %.1f ms/step, peak mem %.1f GB | %s"
       % (H, W, F, "no flow" if args.no_flow else "flow branch on", "" if args.no_face else " + face D", " + VGG" if args.vgg else "",
          dt * 1e3, torch.cuda.max_memory_allocated() / 2**30, " ".join("%s %.3f" % kv for kv in losses.items())))

@@ -416,3 +416,35 @@ def test_fixed_grid_winograd_gemm_equals_tile_per_block(geom, monkeypatch):
     # and against the fp32 reference of the conv (the tolerance of the other Winograd tests)
     ref = _ref_conv(xs[0].cpu().permute(2, 0, 1), w.cpu(), b.cpu(), 3, 1, 1, 1, False)
     assert float((_from_nhwc(want[0], Cout) - ref).abs().max()) < 2e-3 * max(1.0, float(ref.abs().max()))
+
+
+def test_fixed_grid_gemm_survives_graph_replay(monkeypatch):
+    """A captured launch is re-issued with the SAME kernel arguments, hand-over tag included: the consumer clears a tag it has
+    taken, so a replay does not mistake the previous replay's accumulators for this one's.  Capture one Winograd conv
+    (fixed-grid GEMM stage) in a HIP graph, replay it on three different inputs, compare with the eager results."""
+    from text2video_amd import ops
+    H, W, C = 64, 64, 1024
+    dev = _dev()
+    monkeypatch.setenv("T2V_WINO_GEMM_SK", "2")
+    desc = ops.conv_desc(H, W, C, C, 3, 1, 1, ops.PAD_REFLECT, algo=ops.ALGO_WINOGRAD_F4)
+    w = _rand(C, C, 3, 3, seed=5, scale=0.03).to(dev)
+    b = _rand(C, seed=6).to(dev)
+    pu = ops.pack_conv_weight(w, desc, C)
+    ws = ops.winograd_workspace(desc, C, dev)
+    xs = [_rand(H, W, C, seed=20 + i).to(dev) for i in range(3)]
+    want = [ops.conv2d_winograd(x, pu, b, desc, workspace=ws).clone() for x in xs]
+    x_static, y_static = xs[0].clone(), torch.empty_like(want[0])
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ops.conv2d_winograd(x_static, pu, b, desc, workspace=ws, out=y_static)
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        ops.conv2d_winograd(x_static, pu, b, desc, workspace=ws, out=y_static)
+    for rep in range(6):
+        x_static.copy_(xs[rep % 3])
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(y_static, want[rep % 3]), "replay %d: %d outputs differ" % (rep, int((y_static != want[rep % 3]).sum()))

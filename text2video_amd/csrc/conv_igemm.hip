@@ -590,6 +590,8 @@ __global__ __launch_bounds__(512) void wino_gemm_sk_kernel(const SkKParams p) {
             // missing something is broken, and a wrong tile is a better failure than a hung GPU)
             for (int spin = 0; spin < (1 << 23) && __hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.tag; ++spin)
                 __builtin_amdgcn_s_sleep(4);
+            // taken: clear it, so that a replay of this very launch (a captured graph re-issues the same tag) starts clean
+            if (lane == 0) __hip_atomic_store(const_cast<unsigned long long*>(fl), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             // write-through (sc1) stores on the producer's side, sc1 loads here: the pair that is coherent across the
             // XCDs' L2s inside one launch; 16 x 16 bytes per lane at scalar offsets off one SRD
             const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(

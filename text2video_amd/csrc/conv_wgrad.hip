@@ -432,6 +432,8 @@ __global__ __launch_bounds__(512) void wino_wgrad_sk_kernel(const WinoWgradSkPar
             const unsigned long long* fl = p.flags + src * 4 + wid;
             for (int spin = 0; spin < (1 << 23) && __hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.tag; ++spin)
                 __builtin_amdgcn_s_sleep(4);
+            // taken: clear it, so that a replay of this very launch (a captured graph re-issues the same tag) starts clean
+            if (lane == 0) __hip_atomic_store(const_cast<unsigned long long*>(fl), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<float*>(p.partial) + (size_t)(src * 4 + wid) * 4096, 0, 16384, 0x00020000);
 #pragma unroll
