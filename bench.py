@@ -417,7 +417,8 @@ def main():
         traffic = None
         # the fixed-grid form of the F(4x4) GEMM stage (conv_igemm.hip: wino_gemm_sk_ok -- same rule restated here for the
         # label only): whole 128-row tiles, at least one round of the 512 resident blocks, a badly filled last round
-        sk_tiles = npos * (ntile // 128) * (C // 128) if (algo == ops.ALGO_WINOGRAD_F4 and ntile % 128 == 0) else 0
+        trows = ops.winograd_tile_rows(desc) if algo == ops.ALGO_WINOGRAD_F4 else 0     # tile rows per position, padded
+        sk_tiles = npos * (trows // 128) * (C // 128) if (trows and trows % 128 == 0) else 0
         fixed_grid = bool(sk_tiles >= 512 and sk_tiles * 100 <= -(-sk_tiles // 512) * 512 * 85
                           and os.environ.get("T2V_WINO_GEMM_SK", "1") != "0")
         prof = os.path.join(ROOT, "profiles", "pmc_summary.json")
