@@ -516,3 +516,34 @@ def test_weight_gradients_on_the_side_stream_leave_the_step_unchanged(monkeypatc
     for la, lb in zip(runs["1"][0], runs["0"][0]):
         assert la.keys() == lb.keys() and all(la[k] == lb[k] for k in la), [(k, la[k], lb[k]) for k in la if la[k] != lb[k]]
     assert all(torch.equal(x, y) for x, y in zip(runs["1"][1], runs["0"][1]))
+
+
+def test_train_step_with_the_fixed_grid_kernels_forced_is_bit_identical(monkeypatch):
+    """Both fixed-grid kernels (Winograd GEMM stage in the forward convs and the transposed data gradient; Winograd-domain
+    weight-gradient reduction) forced on at a size whose tile counts are far below the grid -- short runs, many blocks idle,
+    every tile whole or cut once -- against one block per tile: losses and updated weights bit for bit."""
+    from text2video_amd import train as T
+    from text2video_amd.options import TrainOptions
+    opt = TrainOptions().parse(["--name", "t", "--dataset_mode", "pose", "--input_nc", "3", "--openpose_only", "--ngf", "64",
+                                "--n_downsample_G", "1", "--n_blocks", "2", "--num_D", "1", "--ndf", "16", "--no_vgg",
+                                "--max_frames_per_gpu", "2", "--n_scales_temporal", "0", "--no_first_img"])
+    H, W = 128, 128      # bottleneck 64 x 64 x 128 channels (ngf 64, one downsampling): 256 tile rows, one 128-wide channel tile
+    rng = np.random.default_rng(8)
+    pose = torch.zeros(2, H, W, 12, device="cuda:0")
+    pose[..., :9] = torch.from_numpy(rng.uniform(-1, 1, (2, H, W, 9)).astype(np.float32)).cuda()
+    real = torch.zeros(2, H, W, 4, device="cuda:0")
+    real[..., :3] = torch.tanh(torch.from_numpy(rng.standard_normal((2, H, W, 3)).astype(np.float32))).cuda()
+    real_prev = torch.cat([real[1:], real[:1]], 0).contiguous()
+    runs = {}
+    for mode in ("2", "0"):
+        monkeypatch.setenv("T2V_WINO_GEMM_SK", mode)
+        monkeypatch.setenv("T2V_WGRAD_SK", mode)
+        tr = T.Vid2VidTrainer(opt, "cuda:0", seed=9)
+        prev, ls = None, []
+        for _ in range(2):
+            l, prev = tr.train_step(pose, real, None, prev, real_prev=real_prev)
+            ls.append(l)
+        runs[mode] = (ls, [p.detach().clone() for n in (tr.G, tr.D) for p in n.parameters()])
+    for la, lb in zip(runs["2"][0], runs["0"][0]):
+        assert la.keys() == lb.keys() and all(la[k] == lb[k] for k in la), [(k, la[k], lb[k]) for k in la if la[k] != lb[k]]
+    assert all(torch.equal(x, y) for x, y in zip(runs["2"][1], runs["0"][1]))
