@@ -17,6 +17,8 @@ ap.add_argument("--no_face", action="store_true")
 ap.add_argument("--vgg", action="store_true", help="add the VGG19 perceptual loss (seeded random weights)")
 ap.add_argument("--aten_stacks", action="store_true", help="one step under torch.profiler: where the ATen fills / adds / "
                 "copies of the step come from (python call sites, by count)")
+ap.add_argument("--high_priority", action="store_true", help="run the steps on a high-priority stream (the weight-gradient side "
+                "stream keeps the default priority)")
 ap.add_argument("--host_time", action="store_true", help="also report when the host has finished ENQUEUEING a step (return of "
                 "the last optimiser step, before the losses are read back): host-bound or GPU-bound?")
 ap.add_argument("--force_dist", action="store_true", help="run the gradient exchange on a 1-rank RCCL group and report its "
@@ -51,8 +53,17 @@ prev = torch.zeros(1, H, W, 8, device=dev)
 prev[..., :6] = torch.tanh(torch.from_numpy(rng.standard_normal((1, H, W, 6)).astype(np.float32))).to(dev)
 
 
+_hp = torch.cuda.Stream(priority=-1) if args.high_priority else None
+
+
 def step():
-    return tr.train_step(pose, real, boxes, prev.clone(), real_prev=real_prev)[0]
+    if _hp is None:
+        return tr.train_step(pose, real, boxes, prev.clone(), real_prev=real_prev)[0]
+    _hp.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(_hp):
+        out = tr.train_step(pose, real, boxes, prev.clone(), real_prev=real_prev)[0]
+    torch.cuda.current_stream().wait_stream(_hp)
+    return out
 
 
 step(); step(); torch.cuda.synchronize()

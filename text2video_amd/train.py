@@ -39,7 +39,7 @@ def cached_pack(w, key, make):
     w = getattr(w, "_t2v_owner", w)    # a detached view of a parameter (frozen passes) shares its parameter's cache
     ent = getattr(w, "_t2v_packs", None)
     if ent is None or ent[0] != w._version:
-        ent = (w._version, {}, {})
+        ent = (w._version, {}, {}, set())       # version, copies, how each was made, which were used since the last write
         w._t2v_packs = ent
         w._t2v_pack_event = None
     elif getattr(w, "_t2v_pack_event", None) is not None:
@@ -49,6 +49,7 @@ def cached_pack(w, key, make):
     if key not in ent[1]:
         ent[1][key] = make()
         ent[2][key] = make
+    ent[3].add(key)
     return ent[1][key]
 
 
@@ -56,7 +57,8 @@ def invalidate_packs(p):
     """the optimiser has written `p` (through its raw pointer: no version bump): drop the packed copies, remember how
     they were made"""
     ent = getattr(p, "_t2v_packs", None)
-    p._t2v_repack = ent[2] if (ent is not None and len(ent) > 2 and ent[2]) else None
+    # (only the copies the last step actually used: a geometry or mode that is gone is not made again for ever)
+    p._t2v_repack = {k: ent[2][k] for k in ent[3]} if (ent is not None and ent[3]) else None
     p._t2v_packs = None
     p._t2v_pack_event = None
 
@@ -73,7 +75,7 @@ def prefetch_packs(params):
         return
     with wgrad_fork():
         for p, makers in todo:
-            p._t2v_packs = (p._version, {k: mk() for k, mk in makers.items()}, dict(makers))
+            p._t2v_packs = (p._version, {k: mk() for k, mk in makers.items()}, dict(makers), set())
             p._t2v_repack = None
         ev = torch.cuda.current_stream().record_event()
     for p, _ in todo:
