@@ -31,6 +31,7 @@
 #include <atomic>
 
 #include "t2v_internal.h"
+#include "k_loops.h"
 
 namespace t2v {
 
@@ -84,6 +85,73 @@ __device__ __forceinline__ void dma16(const float* base, int nbytes, char* lds_d
     const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, nbytes, 0x00020000);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (__attribute__((address_space(3))) void*)lds_dst, 16, voff, soff, 0, 0);
 #endif
+}
+
+// ---- the MFMA waves' K loop, shared by conv_igemm_kernel and wino_gemm_sk_kernel -------------------------------------------
+// One K stage = RQ groups of 4*TM*TN MFMAs, software-pipelined by hand (one wave per SIMD has nobody else to hide its
+// latencies):
+//   * fragments are double-buffered in registers: group q's MFMAs run while the ds_read_b128s of group q+1 are in flight
+//     (LDS latency always covered by >= 1000 MFMA cycles);
+//   * the DMA of stage kt+1 is issued by the loader waves right after barrier(kt-1);
+//   * ONE barrier per stage, placed before the last group's MFMAs: by then every wave has read its last fragments of the
+//     current slot (slot reusable) and the DMA issued >= 1 group ago has landed (vmcnt(0) folded into the barrier), so
+//     group 0 of the next stage can be prefetched from the other slot under the last group's MFMAs.
+// Runs `nstages` stages out of ring slots 0, 1, ... (the loaders start every run at slot 0) and begins with the B0 barrier
+// (stage 0 has landed); the caller closes with its own barrier.
+template <class Cfg, int RING>
+__device__ __forceinline__ void mfma_k_loop(const char* smem, int nstages, int a_row0, int b_row0, int g, int fsw,
+                                            typename Mfma<Cfg::MF>::acc_t (&acc)[Cfg::TM][Cfg::TN]) {
+    using MM = Mfma<Cfg::MF>;
+    constexpr int MF = Cfg::MF, BM = Cfg::BM;
+    static_assert(Cfg::RQ % 2 == 0, "fragment register sets alternate per group");
+    f32x4 af[2][Cfg::TM], bf[2][Cfg::TN];
+    auto load_frags = [&](int buf, int q, int set) {
+        const char* sA = smem + buf * Cfg::STAGE_BYTES;
+        const char* sB = sA + BM * 128;
+        const int slot = ((q * Cfg::NG + g) ^ fsw) * 16;
+#pragma unroll
+        for (int i = 0; i < Cfg::TM; ++i)
+            af[set][i] = *reinterpret_cast<const f32x4*>(sA + (a_row0 + i * MF) * 128 + slot);
+#pragma unroll
+        for (int j = 0; j < Cfg::TN; ++j)
+            bf[set][j] = *reinterpret_cast<const f32x4*>(sB + (b_row0 + j * MF) * 128 + slot);
+    };
+    __syncthreads();  // B0
+    load_frags(0, 0, 0);
+    int buf = 0;
+    for (int kt = 0; kt < nstages; ++kt) {
+        const int nbuf = buf == RING - 1 ? 0 : buf + 1;
+#pragma unroll
+        for (int q = 0; q < Cfg::RQ; ++q) {
+            const int cur = q & 1;
+            __builtin_amdgcn_sched_barrier(0);
+            if (q + 1 == Cfg::RQ) {
+                // barrier(kt): every wave has read its last fragments of slot `buf` (issued during the previous group)
+                // -> slot released to the loaders; stage kt+1 is visible
+                __syncthreads();
+                __builtin_amdgcn_sched_barrier(0);
+                load_frags(nbuf, 0, cur ^ 1);
+            } else {
+                load_frags(buf, q + 1, cur ^ 1);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < Cfg::TN; ++j)
+                        acc[i][j] = MM::run(af[cur][i][e], bf[cur][j][e], acc[i][j]);
+            // issue order inside the group: MFMA, ds_read, MFMA, ds_read, ... so that every fragment read of the NEXT
+            // group issues in the shadow of an executing MFMA
+#pragma unroll
+            for (int r = 0; r < Cfg::TM + Cfg::TN; ++r) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 4 * Cfg::TM * Cfg::TN - (Cfg::TM + Cfg::TN), 0);
+        }
+        buf = nbuf;
+    }
 }
 
 // MODE 0: Cin_s % 32 == 0 (a stage lies inside one tap; tap offsets read with scalar loads)
@@ -260,89 +328,12 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(const ConvKParams p) {
 #pragma unroll
             for (int r = 0; r < MM::NREG; ++r) acc[i][j][r] = 0.f;
 
-    // ---- main loop ------------------------------------------------------------------------------
-    // One K stage = RQ groups of 4*TM*TN MFMAs, software-pipelined by hand (one wave per SIMD has
-    // nobody else to hide its latencies):
-    //   * fragments are double-buffered in registers: group q's MFMAs run while the ds_read_b128s
-    //     of group q+1 are in flight (LDS latency always covered by >= 1000 MFMA cycles);
-    //   * the DMA of stage kt+1 is issued by the loader waves right after barrier(kt-1);
-    //   * ONE barrier per stage, placed before the last group's MFMAs: by then every wave has read
-    //     its last fragments of the current slot (slot reusable) and the DMA issued >= 1 group ago
-    //     has landed (vmcnt(0) folded into the barrier), so group 0 of the next stage can be
-    //     prefetched from the other slot under the last group's MFMAs.
-    static_assert(Cfg::RQ % 2 == 0, "fragment register sets alternate per group");
-    f32x4 af[2][Cfg::TM], bf[2][Cfg::TN];
-    auto load_frags = [&](int buf, int q, int set) {
-        const char* sA = smem + buf * Cfg::STAGE_BYTES;
-        const char* sB = sA + BM * 128;
-        const int slot = ((q * Cfg::NG + g) ^ fsw) * 16;
-#pragma unroll
-        for (int i = 0; i < Cfg::TM; ++i)
-            af[set][i] = *reinterpret_cast<const f32x4*>(sA + (a_row0 + i * MF) * 128 + slot);
-#pragma unroll
-        for (int j = 0; j < Cfg::TN; ++j)
-            bf[set][j] = *reinterpret_cast<const f32x4*>(sB + (b_row0 + j * MF) * 128 + slot);
-    };
-
+    // ---- main loop (mfma_k_loop / loader_k_loop above) ----
     const int nk = ph.nk;
-    if (is_loader) {
-        // ---- loader waves ----
-        // Stage kt+2 is issued into the slot that barrier(kt-1) released; before barrier(kt) the
-        // loader only waits (counted vmcnt) for stage kt+1, so every DMA has two stage times to
-        // land and is never on the critical path.  Raw s_barrier + asm waits: __syncthreads()
-        // would drain vmcnt to 0.  Stages past the end re-fetch the last stage (no branches).
-        constexpr int AHEAD = RING - 1;  // stages in flight beyond the one being computed
-#pragma unroll
-        for (int st = 0; st < AHEAD; ++st) issue_stage(min(st, nk - 1), st);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * LD_PER_WAVE) : "memory");
-        __builtin_amdgcn_s_barrier();  // B0: stage 0 has landed
-        int slot = AHEAD;              // slot of stage kt+AHEAD (== slot released by barrier(kt-1))
-        for (int kt = 0; kt < nk; ++kt) {
-            issue_stage(min(kt + AHEAD, nk - 1), slot);
-            // stage kt+1 landed; the younger stage (RING 3) stays in flight across the barrier
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * LD_PER_WAVE) : "memory");
-            __builtin_amdgcn_s_barrier();  // barrier(kt)
-            slot = slot >= RING - 1 ? 0 : slot + 1;
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else {
-        __syncthreads();  // B0
-        load_frags(0, 0, 0);
-        int buf = 0;
-        for (int kt = 0; kt < nk; ++kt) {
-            const int nbuf = buf == RING - 1 ? 0 : buf + 1;
-#pragma unroll
-            for (int q = 0; q < Cfg::RQ; ++q) {
-                const int cur = q & 1;
-                __builtin_amdgcn_sched_barrier(0);
-                if (q + 1 == Cfg::RQ) {
-                    // barrier(kt): every wave has read its last fragments of slot `buf` (issued during
-                    // the previous group) -> slot released to the loaders; stage kt+1 is visible
-                    __syncthreads();
-                    __builtin_amdgcn_sched_barrier(0);
-                    load_frags(nbuf, 0, cur ^ 1);
-                } else {
-                    load_frags(buf, q + 1, cur ^ 1);
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-#pragma unroll
-                    for (int i = 0; i < Cfg::TM; ++i)
-#pragma unroll
-                        for (int j = 0; j < Cfg::TN; ++j)
-                            acc[i][j] = MM::run(af[cur][i][e], bf[cur][j][e], acc[i][j]);
-                // issue order inside the group: MFMA, ds_read, MFMA, ds_read, ... so that every
-                // fragment read of the NEXT group issues in the shadow of an executing MFMA
-#pragma unroll
-                for (int r = 0; r < Cfg::TM + Cfg::TN; ++r) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read
-                }
-                __builtin_amdgcn_sched_group_barrier(0x008, 4 * Cfg::TM * Cfg::TN - (Cfg::TM + Cfg::TN), 0);
-            }
-            buf = nbuf;
-        }
-    }
+    if (is_loader)
+        loader_k_loop<RING, LD_PER_WAVE>(0, nk, issue_stage);
+    else
+        mfma_k_loop<Cfg, RING>(smem, nk, a_row0, b_row0, g, fsw, acc);
     __syncthreads();  // the epilogue reuses the LDS ring
     if (is_loader) {
         // loader waves only keep the barrier count of the statistics reduction below in step
@@ -525,19 +516,6 @@ __global__ __launch_bounds__(512) void wino_gemm_sk_kernel(const SkKParams p) {
     const int fsw = (fr >> 1) & 7;
     const int a_row0 = wm * (Cfg::TM * MF) + fr;
     const int b_row0 = wn * (Cfg::TN * MF) + fr;
-    f32x4 af[2][Cfg::TM], bf[2][Cfg::TN];
-    auto load_frags = [&](int buf, int q, int set) {
-        const char* sA = smem + buf * Cfg::STAGE_BYTES;
-        const char* sB = sA + BM * 128;
-        const int slot = ((q * Cfg::NG + g) ^ fsw) * 16;
-#pragma unroll
-        for (int i = 0; i < Cfg::TM; ++i)
-            af[set][i] = *reinterpret_cast<const f32x4*>(sA + (a_row0 + i * MF) * 128 + slot);
-#pragma unroll
-        for (int jj = 0; jj < Cfg::TN; ++jj)
-            bf[set][jj] = *reinterpret_cast<const f32x4*>(sB + (b_row0 + jj * MF) * 128 + slot);
-    };
-
     bool flag_due = false;   // this wave's hand-over stores are in flight; its tag is raised at the next wait point
     for (int f = 0; f < nf; ++f) {
         // processing order: the head handed on to block j+1, the whole tiles, the tail begun by block j-1
@@ -563,19 +541,7 @@ __global__ __launch_bounds__(512) void wino_gemm_sk_kernel(const SkKParams p) {
 #pragma unroll
                 for (int i = 0; i < B_PER_WAVE; ++i) dma16(bbase, tile_bytes, dstB + i * 8 * 128, b_voff[i], kt * (kBK * 4));
             };
-            constexpr int AHEAD = RING - 1;
-#pragma unroll
-            for (int st = 0; st < AHEAD; ++st) issue_stage(min(kb + st, ke - 1), st);
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * LD_PER_WAVE) : "memory");
-            __builtin_amdgcn_s_barrier();  // B0
-            int slot = AHEAD;
-            for (int kt = kb; kt < ke; ++kt) {
-                issue_stage(min(kt + AHEAD, ke - 1), slot);
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * LD_PER_WAVE) : "memory");
-                __builtin_amdgcn_s_barrier();
-                slot = slot >= RING - 1 ? 0 : slot + 1;
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            loader_k_loop<RING, LD_PER_WAVE>(kb, ke, issue_stage);
             __syncthreads();   // MFMA waves have read their last fragments: the next tile's prologue may overwrite the ring
             continue;
         }
@@ -623,38 +589,7 @@ __global__ __launch_bounds__(512) void wino_gemm_sk_kernel(const SkKParams p) {
                 __hip_atomic_store(p.flags + blockIdx.x * 4 + wid, p.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             flag_due = false;
         }
-        __syncthreads();  // B0
-        load_frags(0, 0, 0);
-        int buf = 0;
-        for (int kt = kb; kt < ke; ++kt) {
-            const int nbuf = buf == RING - 1 ? 0 : buf + 1;
-#pragma unroll
-            for (int q = 0; q < Cfg::RQ; ++q) {
-                const int cur = q & 1;
-                __builtin_amdgcn_sched_barrier(0);
-                if (q + 1 == Cfg::RQ) {
-                    __syncthreads();
-                    __builtin_amdgcn_sched_barrier(0);
-                    load_frags(nbuf, 0, cur ^ 1);
-                } else {
-                    load_frags(buf, q + 1, cur ^ 1);
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-#pragma unroll
-                    for (int i = 0; i < Cfg::TM; ++i)
-#pragma unroll
-                        for (int jj = 0; jj < Cfg::TN; ++jj)
-                            acc[i][jj] = MM::run(af[cur][i][e], bf[cur][jj][e], acc[i][jj]);
-#pragma unroll
-                for (int r = 0; r < Cfg::TM + Cfg::TN; ++r) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                }
-                __builtin_amdgcn_sched_group_barrier(0x008, 4 * Cfg::TM * Cfg::TN - (Cfg::TM + Cfg::TN), 0);
-            }
-            buf = nbuf;
-        }
+        mfma_k_loop<Cfg, RING>(smem, ke - kb, a_row0, b_row0, g, fsw, acc);
         __syncthreads();   // pairs with the loaders' closing barrier
 
         if (publish) {

@@ -23,6 +23,7 @@
 
 #include "t2v_internal.h"
 #include "norm_pool.h"
+#include "k_loops.h"
 
 namespace t2v {
 
@@ -33,6 +34,68 @@ __device__ __forceinline__ void wg_dma16(const float* base, int nbytes, char* ld
     const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, nbytes, 0x00020000);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (__attribute__((address_space(3))) void*)lds_dst, 16, voff, soff, 0, 0);
 #endif
+}
+
+// ---- the MFMA waves' pixel loop, shared by conv_wgrad_kernel and wino_wgrad_sk_kernel ---------------------------------------
+// 2 x 2 waves, each 64 (n) x 64 (c) = 2 x 2 tiles of 32x32.  Software pipeline (one MFMA wave per SIMD has nobody to hide
+// its LDS latency): a stage's PIX/2 pixel pairs run as PIX/8 groups of 4 pairs = 16 MFMAs; the operands of group q+1 are
+// read in the shadow of group q's MFMAs (issue order MFMA, ds_read, MFMA, ds_read, ...); the stage barrier sits before
+// the last group's reads, which are the first of the next stage.  Begins with the B0 barrier, runs `nstages` stages out of
+// ring slots 0, 1, ...; the caller closes.
+template <int PIX, int RING>
+__device__ __forceinline__ void wgrad_mfma_loop(const char* smem, int nstages, int wn, int wc, int fi, int kk, f32x16 (&acc)[2][2]) {
+    constexpr int kStage = 2 * PIX * 128 * 4;
+    constexpr int NQ = PIX / 8;
+    constexpr int U = (NQ % 2) ? 2 : 1;   // stages per unrolled iteration: keeps the operand register set of a group static
+    float av[2][4][2], bv[2][4][2];
+    auto load_group = [&](int buf, int q, int set) {
+        const float* sY = reinterpret_cast<const float*>(smem + buf * kStage);
+        const float* sX = sY + PIX * 128;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int px = 8 * q + 2 * e + kk;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) av[set][e][i] = sY[px * 128 + wn * 64 + i * 32 + fi];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bv[set][e][j] = sX[px * 128 + wc * 64 + j * 32 + fi];
+        }
+    };
+    __syncthreads();  // B0
+    load_group(0, 0, 0);
+    int buf = 0;
+    for (int kt0u = 0; kt0u < nstages; kt0u += U) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (kt0u + u >= nstages) break;   // wave-uniform
+            const int nbuf = buf == RING - 1 ? 0 : buf + 1;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int cur = (u * NQ + q) & 1;
+                __builtin_amdgcn_sched_barrier(0);
+                if (q + 1 == NQ) {
+                    __syncthreads();  // barrier(kt): slot `buf` fully read, stage kt+1 visible
+                    __builtin_amdgcn_sched_barrier(0);
+                    load_group(nbuf, 0, cur ^ 1);
+                } else {
+                    load_group(buf, q + 1, cur ^ 1);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][e][i], bv[cur][e][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+            }
+            buf = nbuf;
+        }
+    }
 }
 
 // PIX pixels per stage (dY tile + X tile, 128 channels each = PIX KiB), RING slots: 32 x 2 (a stage = 4096 MFMA cycles
@@ -147,20 +210,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradParams p) {
                 wg_dma16(p.x, x_bytes, sX + (wid * RW + i * 2) * 512, vx, 0);
             }
         };
-        constexpr int LD = 2 * NI;          // DMA instructions per loader wave and stage
-        constexpr int AHEAD = kWgRing - 1;  // stages in flight beyond the one being computed
-#pragma unroll
-        for (int st = 0; st < AHEAD; ++st) issue_stage(max(0, min(st, nk - 1)), st);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * LD) : "memory");
-        __builtin_amdgcn_s_barrier();
-        int slot = AHEAD % kWgRing;
-        for (int kt = 0; kt < nk; ++kt) {
-            issue_stage(max(0, min(kt + AHEAD, nk - 1)), slot);  // past the end: harmless re-fetch of the last stage
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * LD) : "memory");
-            __builtin_amdgcn_s_barrier();
-            slot = slot == kWgRing - 1 ? 0 : slot + 1;
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        loader_k_loop<kWgRing, 2 * NI>(0, nk, issue_stage);   // (nk == 0, an empty split range: stage 0 once, B0 only)
         return;
     }
 
@@ -175,61 +225,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // Software pipeline (one MFMA wave per SIMD has nobody to hide its LDS latency): the stage's 16 pixel pairs
-    // run as 4 groups of 4 pairs = 16 MFMAs; the operands of group q+1 are read in the shadow of group q's MFMAs
-    // (issue order MFMA, ds_read, MFMA, ds_read, ...); the stage barrier sits before the last group's reads,
-    // which are the first of the next stage.
-    constexpr int NQ = kWgPix / 8;
-    constexpr int U = (NQ % 2) ? 2 : 1;   // stages per unrolled iteration: keeps the operand register set of a group static
-    float av[2][4][2], bv[2][4][2];
-    auto load_group = [&](int buf, int q, int set) {
-        const float* sY = reinterpret_cast<const float*>(smem + buf * kWgStage);
-        const float* sX = sY + kWgPix * 128;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int px = 8 * q + 2 * e + kk;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) av[set][e][i] = sY[px * 128 + wn * 64 + i * 32 + fi];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) bv[set][e][j] = sX[px * 128 + wc * 64 + j * 32 + fi];
-        }
-    };
-    __syncthreads();  // B0
-    load_group(0, 0, 0);
-    int buf = 0;
-    for (int kt0u = 0; kt0u < nk; kt0u += U) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (kt0u + u >= nk) break;   // wave-uniform
-            const int nbuf = buf == kWgRing - 1 ? 0 : buf + 1;
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                const int cur = (u * NQ + q) & 1;
-                __builtin_amdgcn_sched_barrier(0);
-                if (q + 1 == NQ) {
-                    __syncthreads();  // barrier(kt): slot `buf` fully read, stage kt+1 visible
-                    __builtin_amdgcn_sched_barrier(0);
-                    load_group(nbuf, 0, cur ^ 1);
-                } else {
-                    load_group(buf, q + 1, cur ^ 1);
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-#pragma unroll
-                        for (int j = 0; j < 2; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][e][i], bv[cur][e][j], acc[i][j], 0, 0, 0);
-#pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read
-                }
-                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
-            }
-            buf = nbuf;
-        }
-    }
+    wgrad_mfma_loop<PIX, RING>(smem, nk, wn, wc, fi, kk, acc);
 
     // ---- epilogue: D[row n][col c] -> packed dW[n][koff + c]  (koff: position of this tap in K) ----
     const bool combine = p.tickets != nullptr;   // splits > 1: this block's tile is a partial to be summed in-kernel
@@ -331,7 +327,7 @@ typedef unsigned int wg_v4u __attribute__((__vector_size__(16)));
 template <int PIX, int RING>
 __global__ __launch_bounds__(512) void wino_wgrad_sk_kernel(const WinoWgradSkParams p) {
     constexpr int kStage = 2 * PIX * 128 * 4;
-    constexpr int RW = PIX / 4, NI = PIX / 8, LD = 2 * NI, AHEAD = RING - 1;
+    constexpr int RW = PIX / 4, NI = PIX / 8, LD = 2 * NI;
     constexpr int kOOB = 0x7fff0000;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -365,22 +361,6 @@ __global__ __launch_bounds__(512) void wino_wgrad_sk_kernel(const WinoWgradSkPar
     // MFMA waves: 2 x 2 waves, each 64 (n) x 64 (c)
     const int wn = wid >> 1, wc = wid & 1;
     const int fi = lane & 31, kk = lane >> 5;
-    constexpr int NQ = PIX / 8;
-    static_assert(NQ % 2 == 0, "operand register sets alternate per group");
-    float av[2][4][2], bv[2][4][2];
-    auto load_group = [&](int buf, int q, int set) {
-        const float* sY = reinterpret_cast<const float*>(smem + buf * kStage);
-        const float* sX = sY + PIX * 128;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int px = 8 * q + 2 * e + kk;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) av[set][e][i] = sY[px * 128 + wn * 64 + i * 32 + fi];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) bv[set][e][j] = sX[px * 128 + wc * 64 + j * 32 + fi];
-        }
-    };
-
     bool flag_due = false;
     for (int f = 0; f < nf; ++f) {
         int tr;
@@ -409,18 +389,7 @@ __global__ __launch_bounds__(512) void wino_wgrad_sk_kernel(const WinoWgradSkPar
                     wg_dma16(xbase, kOOB, sX + i * 2 * 512, c_ok ? vx[i] : kOOB, so_x);
                 }
             };
-#pragma unroll
-            for (int st = 0; st < AHEAD; ++st) issue_stage(min(kb + st, ke - 1), st);
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * LD) : "memory");
-            __builtin_amdgcn_s_barrier();   // B0
-            int slot = AHEAD % RING;
-            for (int kt = kb; kt < ke; ++kt) {
-                issue_stage(min(kt + AHEAD, ke - 1), slot);
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * LD) : "memory");
-                __builtin_amdgcn_s_barrier();
-                slot = slot == RING - 1 ? 0 : slot + 1;
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            loader_k_loop<RING, LD>(kb, ke, issue_stage);
             __syncthreads();   // the MFMA waves have read their last operands: the next tile's prologue may refill the ring
             continue;
         }
@@ -462,38 +431,7 @@ __global__ __launch_bounds__(512) void wino_wgrad_sk_kernel(const WinoWgradSkPar
                 __hip_atomic_store(p.flags + blockIdx.x * 4 + wid, p.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             flag_due = false;
         }
-        __syncthreads();   // B0
-        load_group(0, 0, 0);
-        int buf = 0;
-        for (int kt = kb; kt < ke; ++kt) {
-            const int nbuf = buf == RING - 1 ? 0 : buf + 1;
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                const int cur = q & 1;
-                __builtin_amdgcn_sched_barrier(0);
-                if (q + 1 == NQ) {
-                    __syncthreads();
-                    __builtin_amdgcn_sched_barrier(0);
-                    load_group(nbuf, 0, cur ^ 1);
-                } else {
-                    load_group(buf, q + 1, cur ^ 1);
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-#pragma unroll
-                        for (int j = 0; j < 2; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][e][i], bv[cur][e][j], acc[i][j], 0, 0, 0);
-#pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                }
-                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
-            }
-            buf = nbuf;
-        }
+        wgrad_mfma_loop<PIX, RING>(smem, ke - kb, wn, wc, fi, kk, acc);
         __syncthreads();   // pairs with the loaders' closing barrier
 
         if (publish) {
