@@ -10,6 +10,10 @@
 
 namespace t2v {
 
+static inline long gcd_l(long a, long b) {
+    while (b) { const long t = a % b; a = b; b = t; }
+    return a;
+}
 static inline int grid_for(long n, int block) {
     long g = (n + block - 1) / block;
     if (g > 2048) g = 2048;
@@ -762,8 +766,7 @@ __global__ __launch_bounds__(256) void inorm_bwd_reduce_kernel(const float4* __r
             ga[k] = gamma ? gamma[c0 + k] : 1.f;
             be[k] = beta ? beta[c0 + k] : 0.f;
         }
-        for (long p = (long)blockIdx.y * 16 + sl; p < npix; p += (long)gridDim.y * 16) {
-            const float4 xv = x[p * C4 + (c0 >> 2)], gv = dy[p * C4 + (c0 >> 2)];
+        auto add = [&](const float4 xv, const float4 gv) {
             const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, gs[4] = {gv.x, gv.y, gv.z, gv.w};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -772,7 +775,21 @@ __global__ __launch_bounds__(256) void inorm_bwd_reduce_kernel(const float4* __r
                 s0[k] += g;
                 s1[k] += g * xh;
             }
+        };
+        // four pixels' loads in flight per thread, added in pixel order (the sums do not depend on the unrolling)
+        const long step = (long)gridDim.y * 16, q = c0 >> 2;
+        long p = (long)blockIdx.y * 16 + sl;
+        for (; p + 3 * step < npix; p += 4 * step) {
+            float4 xv[4], gv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                xv[u] = x[(p + u * step) * C4 + q];
+                gv[u] = dy[(p + u * step) * C4 + q];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) add(xv[u], gv[u]);
         }
+        for (; p < npix; p += step) add(x[p * C4 + q], dy[p * C4 + q]);
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -812,24 +829,49 @@ __global__ __launch_bounds__(256) void inorm_bwd_final_kernel(const float2* __re
                               (sh[1][0][cl] + sh[1][1][cl]) + (sh[1][2][cl] + sh[1][3][cl]));
 }
 // stage 2: dx = rstd * gamma * (g - S0/N - xhat * S1/N)      (biased variance, N = pixels in the statistics)
-__global__ __launch_bounds__(256) void inorm_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+// 16 bytes per lane; the launch makes the thread count a multiple of the C/4 channel quads, so a thread keeps ITS quad
+// across the grid-stride loop and the per-channel terms are loaded and combined once; two float4 pairs in flight per
+// iteration.  (Round 2's form -- 4 bytes per lane, five per-element parameter loads and a modulo -- ran at 3 TB/s.)
+__global__ __launch_bounds__(256) void inorm_bwd_apply_kernel(const float4* __restrict__ x, const float4* __restrict__ dy,
                                                               const float2* __restrict__ mean_rstd,
                                                               const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, int relu,
-                                                              const float2* __restrict__ sums, long npix, int C,
-                                                              float* __restrict__ dx) {
-    const long total = npix * C;
+                                                              const float2* __restrict__ sums, long npix, int C4,
+                                                              float4* __restrict__ dx) {
+    const long total = npix * C4;
     const float invn = 1.f / (float)npix;
-    const long stride = (long)gridDim.x * blockDim.x;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-        const int c = (int)(i % C);
-        const float2 mr = mean_rstd[c];
-        const float2 sm = sums[c];
-        const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
-        const float xh = (x[i] - mr.x) * mr.y;
-        const float g = dy[i] * act_grad(ga * xh + be, relu);
-        dx[i] = mr.y * ga * (g - sm.x * invn - xh * (sm.y * invn));
+    const long stride = (long)gridDim.x * blockDim.x;          // a multiple of C4
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c0 = (int)(i % C4) * 4;
+    float mean[4], rstd[4], ga[4], be[4], k0[4], k1[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float2 mr = mean_rstd[c0 + k], sm = sums[c0 + k];
+        mean[k] = mr.x;
+        rstd[k] = mr.y;
+        ga[k] = gamma ? gamma[c0 + k] : 1.f;
+        be[k] = beta ? beta[c0 + k] : 0.f;
+        k0[k] = sm.x * invn;
+        k1[k] = sm.y * invn;
     }
+    auto one = [&](const float4 xv, const float4 gv) {
+        const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, gs[4] = {gv.x, gv.y, gv.z, gv.w};
+        float o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float xh = (xs[k] - mean[k]) * rstd[k];
+            const float g = gs[k] * act_grad(ga[k] * xh + be[k], relu);
+            o[k] = rstd[k] * ga[k] * (g - k0[k] - xh * k1[k]);
+        }
+        return make_float4(o[0], o[1], o[2], o[3]);
+    };
+    for (; i + stride < total; i += 2 * stride) {
+        const float4 xa = x[i], ga_ = dy[i], xb = x[i + stride], gb = dy[i + stride];
+        dx[i] = one(xa, ga_);
+        dx[i + stride] = one(xb, gb);
+    }
+    if (i < total) dx[i] = one(x[i], dy[i]);
 }
 int launch_inorm_backward(hipStream_t s, const float* x, const float* dy, const float* mean_rstd, const float* gamma,
                           const float* beta, int relu, long npix, int C, float* scratch, float* dx, float* sums) {
@@ -846,9 +888,21 @@ int launch_inorm_backward(hipStream_t s, const float* x, const float* dy, const 
                        reinterpret_cast<float2*>(scratch));
     hipLaunchKernelGGL(inorm_bwd_final_kernel, dim3((C + 63) / 64), dim3(256), 0, s,
                        reinterpret_cast<const float2*>(scratch), slices, C, reinterpret_cast<float2*>(sums));
-    hipLaunchKernelGGL(inorm_bwd_apply_kernel, dim3(grid_for(npix * C, 256)), dim3(256), 0, s, x, dy,
-                       reinterpret_cast<const float2*>(mean_rstd), gamma, beta, relu,
-                       reinterpret_cast<const float2*>(sums), npix, C, dx);
+    {
+        // threads = a multiple of the C/4 channel quads (every thread keeps its quad), ~8 float4 per thread
+        const int C4 = C / 4;
+        const long total4 = npix * C4;
+        long threads = (total4 + 7) / 8;
+        threads = (threads + C4 - 1) / C4 * C4;
+        long blocks = (threads + 255) / 256;
+        if ((blocks * 256) % C4 != 0) {                       // C4 does not divide a whole number of blocks' threads:
+            const long lcm_blocks = C4 / gcd_l(C4, 256);      // round the block count up to where it does
+            blocks = (blocks + lcm_blocks - 1) / lcm_blocks * lcm_blocks;
+        }
+        hipLaunchKernelGGL(inorm_bwd_apply_kernel, dim3((int)blocks), dim3(256), 0, s, reinterpret_cast<const float4*>(x),
+                           reinterpret_cast<const float4*>(dy), reinterpret_cast<const float2*>(mean_rstd), gamma, beta, relu,
+                           reinterpret_cast<const float2*>(sums), npix, C4, reinterpret_cast<float4*>(dx));
+    }
     T2V_HIP_CHECK(hipGetLastError());
     return T2V_OK;
 }
