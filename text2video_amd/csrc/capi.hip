@@ -595,8 +595,9 @@ int t2v_conv2d_backward_weight(t2v_ctx* ctx, void* stream, const t2v_conv_desc* 
         const long part = (long)d->Cout * k.ph[0].Kp;
         w.dw_floats = part;
         w.dw = partial;
-        // (taps folded onto the dY side: tile rows are (tap, channel) pairs -- this shape keeps the reduce launch)
-        T2V_HIP_CHECK(hipMemsetAsync(partial, 0, (size_t)w.splits * part * sizeof(float), st));
+        // (taps folded onto the dY side: tile rows are (tap, channel) pairs -- this shape keeps the reduce launch.  No
+        // zero-fill of the slabs: every real element of every partial is stored by exactly one block -- a block with an
+        // empty pixel range stores zeros -- and the padding columns are summed and never read)
         w.accumulate = 0;
         T2V_TRY(launch_conv_wgrad(st, w));
         return launch_wgrad_reduce(st, partial, w.splits, part, dw_packed, accumulate);
@@ -624,7 +625,9 @@ int t2v_conv2d_backward_weight(t2v_ctx* ctx, void* stream, const t2v_conv_desc* 
         w.accumulate = accumulate;
         return launch_conv_wgrad((hipStream_t)stream, w);
     }
-    T2V_HIP_CHECK(hipMemsetAsync(workspace, 0, (size_t)w.splits * pl.wfloats * sizeof(float), (hipStream_t)stream));
+    // (no zero-fill of the partial slabs either: every real (n, tap, c) element of every slab is stored by exactly one
+    // block, zeros where a split's pixel range is empty; the padding rows / columns of the packed layout are summed as they
+    // are and never read -- tests/ run with the workspaces NaN-filled (scripts/run_poisoned.py))
     w.accumulate = 0;
     T2V_TRY(launch_conv_wgrad((hipStream_t)stream, w));
     return launch_wgrad_reduce((hipStream_t)stream, workspace, w.splits, (long)pl.wfloats, dw_packed, accumulate);
