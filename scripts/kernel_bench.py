@@ -11,6 +11,7 @@ ap.add_argument("--shapes", default="rb1024")
 ap.add_argument("--iters", type=int, default=40)
 ap.add_argument("--warmup", type=int, default=80)
 ap.add_argument("--winograd", type=int, nargs="?", const=1, default=0, help="1 = F(2x2,3x3), 2 = F(4x4,3x3)")
+ap.add_argument("--no_stats", action="store_true", help="without the norm-statistics epilogue (what it costs)")
 ap.add_argument("--stages", type=int, default=7, help="Winograd stage mask: 1 input transform, 2 GEMM, 4 output transform")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -23,7 +24,7 @@ for name in args.shapes.split(","):
     w = torch.randn(*((Cin, Cout, k, k) if tr else (Cout, Cin, k, k)), device=dev) * 0.02
     pw = ops.pack_conv_weight(w, desc, xcs)
     b = torch.randn(Cout, device=dev)
-    sb = ops.conv_stats_buffer(desc, dev) if stats else None
+    sb = ops.conv_stats_buffer(desc, dev) if (stats and not args.no_stats) else None
     ho, wo = ops.conv_out_dims(desc)
     ycs = Cout if Cout % 4 == 0 else 4
     y = torch.empty(ho, wo, ycs, device=dev)

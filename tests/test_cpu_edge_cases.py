@@ -170,3 +170,41 @@ def test_lane_plan_and_lockstep_iteration_cover_the_same_items():
                 assert np.array_equal(ref[name][0], got[name][0]) and ref[name][1] == got[name][1], name
     cut = [d["A_path"] for step in ds.iter_lanes(2, 1, limit=6) for _, d in step]
     assert sorted(cut) == sorted(list(ref)[:6])
+
+
+def test_packed_weight_cache_remembers_what_the_last_step_used(monkeypatch):
+    """train.py's cache of packed weight copies (host logic, no GPU): a copy is made once per optimiser write; after
+    `invalidate_packs` the parameter remembers the makers of the copies USED since the last write (and only those), which
+    `prefetch_packs` re-runs on the side stream on a GPU -- on the CPU it just drops the list; T2V_TRAIN_PACK_CACHE=0
+    bypasses the cache."""
+    import torch
+    from text2video_amd import train as T
+    w = torch.nn.Parameter(torch.arange(6.0))
+    calls = []
+
+    def maker(tag):
+        def make():
+            calls.append(tag)
+            return w.detach() * 2
+        return make
+    a1 = T.cached_pack(w, "a", maker("a"))
+    a2 = T.cached_pack(w, "a", maker("a-again"))
+    b1 = T.cached_pack(w, "b", maker("b"))
+    assert a1 is a2 and calls == ["a", "b"] and torch.equal(b1, w.detach() * 2)
+    T.invalidate_packs(w)
+    assert w._t2v_packs is None and sorted(w._t2v_repack) == ["a", "b"]
+    T.prefetch_packs([w])                     # CPU tensor: nothing is made ahead, the list is dropped
+    assert w._t2v_repack is None and getattr(w, "_t2v_pack_event", None) is None
+    T.cached_pack(w, "a", maker("a2"))        # next "step" uses only "a"
+    T.invalidate_packs(w)
+    assert list(w._t2v_repack) == ["a"] and calls == ["a", "b", "a2"]
+    # a view that names its owner shares the owner's cache
+    v = w.detach()
+    v._t2v_owner = w
+    T.prefetch_packs([w])
+    x1 = T.cached_pack(v, "c", maker("c"))
+    assert T.cached_pack(w, "c", maker("c-again")) is x1
+    monkeypatch.setenv("T2V_TRAIN_PACK_CACHE", "0")
+    n = len(calls)
+    T.cached_pack(w, "c", maker("c3"))
+    assert len(calls) == n + 1
