@@ -448,3 +448,15 @@ def test_fixed_grid_gemm_survives_graph_replay(monkeypatch):
         g.replay()
         torch.cuda.synchronize()
         assert torch.equal(y_static, want[rep % 3]), "replay %d: %d outputs differ" % (rep, int((y_static != want[rep % 3]).sum()))
+
+
+def test_fixed_grid_kernels_race_screen_under_load():
+    """scripts/stress_fixed_grid.py: fixed-grid GEMM stages and weight-gradient reductions on two streams with changing inputs
+    and workspaces reused back to back, a third stream streaming 1 GiB at the same time -- every result bit-equal to one
+    block per tile (the accumulator hand-over crosses XCDs: a stale line or a tag seen early would show under load first)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "stress_fixed_grid.py"), "80"], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "0 of 80 iterations differ" in r.stdout
