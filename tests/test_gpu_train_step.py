@@ -547,3 +547,35 @@ def test_train_step_with_the_fixed_grid_kernels_forced_is_bit_identical(monkeypa
     for la, lb in zip(runs["2"][0], runs["0"][0]):
         assert la.keys() == lb.keys() and all(la[k] == lb[k] for k in la), [(k, la[k], lb[k]) for k in la if la[k] != lb[k]]
     assert all(torch.equal(x, y) for x, y in zip(runs["2"][1], runs["0"][1]))
+
+
+def test_two_stream_generator_forward_and_backward_leave_the_step_unchanged(monkeypatch):
+    """T2V_TRAIN_TWO_STREAMS=1: the previous-frame encoder and the flow branch of the trainable generator run on a second stream
+    (and autograd runs their backward there).  Same losses and updated weights, bit for bit, as on one stream, over three
+    steps (flow branch, face D, temporal D on)."""
+    from text2video_amd import train as T
+    from text2video_amd.options import TrainOptions
+    opt = TrainOptions().parse(["--name", "t", "--dataset_mode", "pose", "--input_nc", "3", "--openpose_only", "--ngf", "32",
+                                "--n_downsample_G", "2", "--n_blocks", "3", "--num_D", "2", "--ndf", "16", "--no_vgg",
+                                "--max_frames_per_gpu", "2", "--n_scales_temporal", "1", "--no_first_img", "--add_face_disc"])
+    H, W = 128, 128
+    rng = np.random.default_rng(41)
+    pose = torch.zeros(2, H, W, 12, device="cuda:0")
+    pose[..., :9] = torch.from_numpy(rng.uniform(-1, 1, (2, H, W, 9)).astype(np.float32)).cuda()
+    real = torch.zeros(2, H, W, 4, device="cuda:0")
+    real[..., :3] = torch.tanh(torch.from_numpy(rng.standard_normal((2, H, W, 3)).astype(np.float32))).cuda()
+    real_prev = torch.cat([real[1:], real[:1]], 0).contiguous()
+    boxes = [(16, 80, 32, 96)] * 2
+    runs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("T2V_TRAIN_TWO_STREAMS", mode)
+        tr = T.Vid2VidTrainer(opt, "cuda:0", seed=6)
+        prev, ls = None, []
+        for _ in range(3):
+            l, prev = tr.train_step(pose, real, boxes, prev, real_prev=real_prev)
+            ls.append(l)
+        runs[mode] = (ls, [p.detach().clone() for n in [tr.G, tr.D, tr.Df] + tr.DT for p in n.parameters()])
+    assert T._FWD_SIDE["stream"] is not None
+    for la, lb in zip(runs["1"][0], runs["0"][0]):
+        assert la.keys() == lb.keys() and all(la[k] == lb[k] for k in la), [(k, la[k], lb[k]) for k in la if la[k] != lb[k]]
+    assert all(torch.equal(x, y) for x, y in zip(runs["1"][1], runs["0"][1]))
