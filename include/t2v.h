@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define T2V_ABI_VERSION 9
+#define T2V_ABI_VERSION 10
 
 typedef enum {
     T2V_OK = 0,
@@ -259,6 +259,12 @@ int t2v_reflect_pad_backward(t2v_ctx* ctx, void* stream, const float* dxp, float
 int t2v_instance_norm_backward(t2v_ctx* ctx, void* stream, const float* x, const float* dy, const float* mean_rstd,
                                const float* gamma, const float* beta, int relu, long npix, int C, float* scratch,
                                float* dx, float* dbeta_dgamma);
+/* ... the same, with the two sums also delivered into the affine parameters' gradient tensors: d_beta[c] (+)= sum g,
+ * d_gamma[c] (+)= sum g*xhat (overwrite != 0: written; else added) -- BatchNormalization_backward's gradBias / gradWeight
+ * accumulation (THCUNN.h:47-62) without a pass of its own */
+int t2v_instance_norm_backward_affine(t2v_ctx* ctx, void* stream, const float* x, const float* dy, const float* mean_rstd,
+                                      const float* gamma, const float* beta, int relu, long npix, int C, float* scratch,
+                                      float* dx, float* dbeta_dgamma, float* d_beta, float* d_gamma, int overwrite);
 /* dpre = dy * act'(.) from the activation OUTPUT y; act: T2V_ACT_TANH, 2 = sigmoid, T2V_ACT_LRELU (slope), 0 = scale by slope,
  * 4 = the fused flow / weight head (T2V_ACT_FLOW_W) on [.,4] storage: ch 0,1 scale by slope, ch 2 sigmoid, ch 3 zero */
 int t2v_act_backward(t2v_ctx* ctx, void* stream, const float* dy, const float* y, int act, float slope, long n,

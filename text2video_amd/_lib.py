@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libt2v_hip.so")
 T2V_OK = 0
 PAD_ZERO, PAD_REFLECT = 0, 1
 ACT_NONE, ACT_TANH, ACT_FLOW_W, ACT_LRELU = 0, 1, 2, 3
-ABI_VERSION = 9
+ABI_VERSION = 10
 MAX_BATCH = 8     # T2V_MAX_BATCH
 ALGO_DIRECT, ALGO_WINOGRAD, ALGO_WINOGRAD_F4 = 0, 1, 2
 
@@ -95,6 +95,8 @@ SIGNATURES = {
     "t2v_reflect_pad_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int]),
     "t2v_instance_norm_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                            c_long, c_int, c_void_p, c_void_p, c_void_p]),
+    "t2v_instance_norm_backward_affine": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                           c_long, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int]),
     "t2v_act_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_long, c_void_p]),
     "t2v_avgpool3x3s2_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int]),
     "t2v_sum_sq_diff_const_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_float, c_long, c_void_p]),

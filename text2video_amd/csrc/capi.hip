@@ -822,6 +822,14 @@ int t2v_instance_norm_backward(t2v_ctx* ctx, void* stream, const float* x, const
     return launch_inorm_backward((hipStream_t)stream, x, dy, mean_rstd, gamma, beta, relu, npix, C, scratch, dx,
                                  dbeta_dgamma);
 }
+int t2v_instance_norm_backward_affine(t2v_ctx* ctx, void* stream, const float* x, const float* dy, const float* mean_rstd,
+                                      const float* gamma, const float* beta, int relu, long npix, int C, float* scratch,
+                                      float* dx, float* dbeta_dgamma, float* d_beta, float* d_gamma, int overwrite) {
+    T2V_REQUIRE(ctx && x && dy && mean_rstd && scratch && dx && dbeta_dgamma && d_beta && d_gamma && npix > 0 && C > 0,
+                "instance_norm_backward_affine: bad arguments");
+    return launch_inorm_backward((hipStream_t)stream, x, dy, mean_rstd, gamma, beta, relu, npix, C, scratch, dx,
+                                 dbeta_dgamma, d_beta, d_gamma, overwrite);
+}
 int t2v_act_backward(t2v_ctx* ctx, void* stream, const float* dy, const float* y, int act, float slope, long n,
                      float* dpre) {
     T2V_REQUIRE(ctx && dy && y && dpre && n > 0, "act_backward: bad arguments");

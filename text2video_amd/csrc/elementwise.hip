@@ -809,8 +809,11 @@ __global__ __launch_bounds__(256) void inorm_bwd_reduce_kernel(const float4* __r
     }
 }
 // block = 64 channels x 4 slice lanes (fixed summation order: lane-strided partial sums, then the 4 lanes)
+// d_beta / d_gamma (optional): the two sums also go straight into the affine parameters' gradient slices -- written when
+// `overwrite`, added otherwise (what a separate unzip2 pass did)
 __global__ __launch_bounds__(256) void inorm_bwd_final_kernel(const float2* __restrict__ partial, int slices, int C,
-                                                              float2* __restrict__ sums) {
+                                                              float2* __restrict__ sums, float* __restrict__ d_beta,
+                                                              float* __restrict__ d_gamma, int overwrite) {
     __shared__ float sh[2][4][64];
     const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl;
@@ -824,9 +827,15 @@ __global__ __launch_bounds__(256) void inorm_bwd_final_kernel(const float2* __re
     sh[0][sl][cl] = s0;
     sh[1][sl][cl] = s1;
     __syncthreads();
-    if (sl == 0 && c < C)   // (dbeta, dgamma) of an affine norm
-        sums[c] = make_float2((sh[0][0][cl] + sh[0][1][cl]) + (sh[0][2][cl] + sh[0][3][cl]),
-                              (sh[1][0][cl] + sh[1][1][cl]) + (sh[1][2][cl] + sh[1][3][cl]));
+    if (sl == 0 && c < C) {   // (dbeta, dgamma) of an affine norm
+        const float2 v = make_float2((sh[0][0][cl] + sh[0][1][cl]) + (sh[0][2][cl] + sh[0][3][cl]),
+                                     (sh[1][0][cl] + sh[1][1][cl]) + (sh[1][2][cl] + sh[1][3][cl]));
+        sums[c] = v;
+        if (d_beta) {
+            d_beta[c] = overwrite ? v.x : d_beta[c] + v.x;
+            d_gamma[c] = overwrite ? v.y : d_gamma[c] + v.y;
+        }
+    }
 }
 // stage 2: dx = rstd * gamma * (g - S0/N - xhat * S1/N)      (biased variance, N = pixels in the statistics)
 // 16 bytes per lane; the launch makes the thread count a multiple of the C/4 channel quads, so a thread keeps ITS quad
@@ -874,7 +883,8 @@ __global__ __launch_bounds__(256) void inorm_bwd_apply_kernel(const float4* __re
     if (i < total) dx[i] = one(x[i], dy[i]);
 }
 int launch_inorm_backward(hipStream_t s, const float* x, const float* dy, const float* mean_rstd, const float* gamma,
-                          const float* beta, int relu, long npix, int C, float* scratch, float* dx, float* sums) {
+                          const float* beta, int relu, long npix, int C, float* scratch, float* dx, float* sums, float* d_beta,
+                          float* d_gamma, int overwrite) {
     T2V_REQUIRE(C % 4 == 0, "inorm_backward: C=%d must be a multiple of 4", C);
     // enough (channel group, pixel slice) blocks to cover the chip a few times over; scratch holds 256*C float2
     int slices = (int)((npix + 63) / 64);
@@ -887,7 +897,8 @@ int launch_inorm_backward(hipStream_t s, const float* x, const float* dy, const 
                        reinterpret_cast<const float2*>(mean_rstd), gamma, beta, relu, npix, C,
                        reinterpret_cast<float2*>(scratch));
     hipLaunchKernelGGL(inorm_bwd_final_kernel, dim3((C + 63) / 64), dim3(256), 0, s,
-                       reinterpret_cast<const float2*>(scratch), slices, C, reinterpret_cast<float2*>(sums));
+                       reinterpret_cast<const float2*>(scratch), slices, C, reinterpret_cast<float2*>(sums), d_beta, d_gamma,
+                       overwrite);
     {
         // threads = a multiple of the C/4 channel quads (every thread keeps its quad), ~8 float4 per thread
         const int C4 = C / 4;

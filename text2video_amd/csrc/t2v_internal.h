@@ -121,7 +121,8 @@ int launch_unzip2(hipStream_t s, const float* src, float* dst0, float* dst1, int
 int launch_pad_copy(hipStream_t s, const float* x, float* xp, int batch, int H, int W, int C, int pad, int reflect);
 int launch_reflect_pad_backward(hipStream_t s, const float* dxp, float* dx, int H, int W, int C, int p);
 int launch_inorm_backward(hipStream_t s, const float* x, const float* dy, const float* mean_rstd, const float* gamma,
-                          const float* beta, int relu, long npix, int C, float* scratch, float* dx, float* sums);
+                          const float* beta, int relu, long npix, int C, float* scratch, float* dx, float* sums,
+                          float* d_beta = nullptr, float* d_gamma = nullptr, int overwrite = 0);
 int launch_act_backward(hipStream_t s, const float* dy, const float* y, int mode, float slope, long n, float* dpre);
 int launch_avgpool3s2_backward(hipStream_t s, const float* dy, float* dx, int H, int W, int C);
 int launch_maxpool2x2(hipStream_t s, const float* x, float* y, int H, int W, int C);

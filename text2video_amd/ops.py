@@ -562,9 +562,10 @@ def reflect_pad_backward(dxp, pad, out=None):
     return dx
 
 
-def instance_norm_backward(x, dy, mean_rstd, gamma=None, beta=None, relu=0, out=None):
+def instance_norm_backward(x, dy, mean_rstd, gamma=None, beta=None, relu=0, out=None, affine_into=None):
     """x, dy: [..., C] (all leading dims are the pixels of ONE statistics group).  Returns
-    (dx, dbeta_dgamma [C,2])."""
+    (dx, dbeta_dgamma [C,2]).  affine_into = (d_beta, d_gamma, overwrite): the two sums also land in those gradient
+    tensors (written or added) inside the same launches."""
     c = context()
     _chk(x, "x")
     _chk(dy, "dy")
@@ -574,6 +575,12 @@ def instance_norm_backward(x, dy, mean_rstd, gamma=None, beta=None, relu=0, out=
     _chk(dx, "dx")
     sums = torch.empty(C, 2, dtype=torch.float32, device=x.device)
     scratch = torch.empty(128 * C * 2, dtype=torch.float32, device=x.device)
+    if affine_into is not None:
+        d_beta, d_gamma, overwrite = affine_into
+        check(c.lib.t2v_instance_norm_backward_affine(c.handle, _stream(), _p(x), _p(dy), _p(mean_rstd), _p(gamma), _p(beta),
+                                                      int(relu), npix, C, _p(scratch), _p(dx), _p(sums), _p(d_beta), _p(d_gamma),
+                                                      int(bool(overwrite))), "instance_norm_backward_affine")
+        return dx, sums
     check(c.lib.t2v_instance_norm_backward(c.handle, _stream(), _p(x), _p(dy), _p(mean_rstd), _p(gamma), _p(beta),
                                            int(relu), npix, C, _p(scratch), _p(dx), _p(sums)), "instance_norm_backward")
     return dx, sums

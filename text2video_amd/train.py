@@ -456,11 +456,17 @@ class _ConvBlock(torch.autograd.Function):
         sl_bt = grad_slot(beta) if (affine and want[4]) else None
         both = sl_g is not None and sl_bt is not None
 
+        def into_slots():           # both affine gradients have bucket slots: the norm backward's final pass fills them
+            if not (both and affine and (want[3] or want[4])):
+                return None
+            first = not sl_g.filled
+            sl_g.filled = sl_bt.filled = True
+            return (sl_bt.view, sl_g.view, first)
+
         def affine_sums(sums):       # [C,2] = (sum g, sum g*xhat) -> d beta, d gamma
             nonlocal dbeta, dgamma
             if both:
-                ops.unzip2_(sums, sl_bt.view, sl_g.view, overwrite=not sl_g.filled)
-                sl_g.filled = sl_bt.filled = True
+                return               # (delivered by the kernel: into_slots)
             else:
                 db_, dg_ = sums.t().contiguous().unbind(0)
                 dbeta = db_ if dbeta is None else dbeta + db_
@@ -470,13 +476,13 @@ class _ConvBlock(torch.autograd.Function):
             # (act_backward's mode 2 is a plain sigmoid; the fused flow / weight head is its mode 4)
             dc = ops.act_backward(dy, y_act, 4 if act == ops.ACT_FLOW_W else act, slope) if act != ops.ACT_NONE else dy
         elif norm == "batch":
-            dc, sums = ops.instance_norm_backward(c, dy, mrs[0], gamma, beta, relu)
+            dc, sums = ops.instance_norm_backward(c, dy, mrs[0], gamma, beta, relu, affine_into=into_slots())
             if affine and (want[3] or want[4]):
                 affine_sums(sums)
         else:
             dc = torch.empty_like(c)
             for i in range(B):
-                _, s_i = ops.instance_norm_backward(c[i], dy[i], mrs[i], gamma, beta, relu, out=dc[i])
+                _, s_i = ops.instance_norm_backward(c[i], dy[i], mrs[i], gamma, beta, relu, out=dc[i], affine_into=into_slots())
                 if affine and (want[3] or want[4]):
                     affine_sums(s_i)
         if both:
