@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define T2V_ABI_VERSION 10
+#define T2V_ABI_VERSION 11
 
 typedef enum {
     T2V_OK = 0,
@@ -148,6 +148,11 @@ int t2v_batch_norm_finalize(t2v_ctx* ctx, void* stream, const t2v_conv_desc* pro
  *   running_var  = (1-momentum)*running_var  + momentum*var*n/(n-1)      (unbiased; var = 1/rstd^2 - eps) */
 int t2v_batch_norm_update_running(t2v_ctx* ctx, void* stream, const float* mean_rstd, float* running_mean,
                                   float* running_var, long n, int C, float momentum, float eps);
+/* t2v_batch_norm_finalize + `times` running-statistics updates (n = batch * output pixels of `producer`) in the same
+ * launch; batch = 1: an instance norm standing for BatchNorm2d(train) on a batch of one */
+int t2v_batch_norm_finalize_running(t2v_ctx* ctx, void* stream, const t2v_conv_desc* producer, int batch,
+                                    const float* stats_partial, float eps, float* mean_rstd, float* running_mean,
+                                    float* running_var, float momentum, int times);
 int t2v_instance_norm_apply(t2v_ctx* ctx, void* stream, const float* x, const float* mean_rstd,
                             const float* gamma, const float* beta, const float* res1,
                             const float* res2, float* y, long npix, int C, int relu);

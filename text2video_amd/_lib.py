@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libt2v_hip.so")
 T2V_OK = 0
 PAD_ZERO, PAD_REFLECT = 0, 1
 ACT_NONE, ACT_TANH, ACT_FLOW_W, ACT_LRELU = 0, 1, 2, 3
-ABI_VERSION = 10
+ABI_VERSION = 11
 MAX_BATCH = 8     # T2V_MAX_BATCH
 ALGO_DIRECT, ALGO_WINOGRAD, ALGO_WINOGRAD_F4 = 0, 1, 2
 
@@ -69,6 +69,8 @@ SIGNATURES = {
                                                    c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int]),
     "t2v_instance_norm_finalize": (c_int, [c_void_p, c_void_p, POINTER(ConvDesc), c_void_p, c_float, c_void_p]),
     "t2v_batch_norm_finalize": (c_int, [c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_void_p, c_float, c_void_p]),
+    "t2v_batch_norm_finalize_running": (c_int, [c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_void_p, c_float, c_void_p,
+                                                c_void_p, c_void_p, c_float, c_int]),
     "t2v_conv_backward_weight_workspace_floats": (c_size_t, [POINTER(ConvDesc), c_int, c_int]),
     "t2v_conv_backward_weight_winograd_supported": (c_int, [POINTER(ConvDesc), c_int, c_int]),
     "t2v_conv_backward_weight_winograd_workspace_floats": (c_size_t, [POINTER(ConvDesc), c_int, c_int]),

@@ -453,20 +453,36 @@ int t2v_instance_norm_finalize(t2v_ctx* ctx, void* stream, const t2v_conv_desc* 
                                  producer->Cout, eps, mean_rstd);
 }
 
-int t2v_batch_norm_finalize(t2v_ctx* ctx, void* stream, const t2v_conv_desc* producer, int batch,
-                            const float* stats_partial, float eps, float* mean_rstd) {
-    T2V_REQUIRE(ctx && stats_partial && mean_rstd && batch >= 1, "batch_norm_finalize: bad arguments");
+static int batch_norm_finalize(hipStream_t s, const t2v_conv_desc* producer, int batch, const float* stats_partial, float eps,
+                               float* mean_rstd, const RunningUpdate* ru) {
     if (producer && is_winograd(producer->algo))
-        return launch_inorm_finalize_winograd((hipStream_t)stream, stats_partial, wino_m(producer->algo), wino_out_h(producer),
-                                              wino_out_w(producer), producer->Cout, eps, mean_rstd, batch);
+        return launch_inorm_finalize_winograd(s, stats_partial, wino_m(producer->algo), wino_out_h(producer),
+                                              wino_out_w(producer), producer->Cout, eps, mean_rstd, batch, nullptr, ru);
     ConvPlan pl;
     T2V_TRY(build_conv_plan(producer, round_up(producer ? producer->Cin : 0, 4), true, &pl));
     if (pl.tile == kTileStem)
-        return launch_inorm_finalize_tiles((hipStream_t)stream, stats_partial, 16, producer->H, producer->W, producer->Cout, eps,
-                                           mean_rstd, batch);
+        return launch_inorm_finalize_tiles(s, stats_partial, 16, producer->H, producer->W, producer->Cout, eps, mean_rstd, batch,
+                                           nullptr, ru);
     // the per-image partial blocks are contiguous: a batch is just `batch` times more partial rows
-    return launch_inorm_finalize((hipStream_t)stream, stats_partial, batch * pl.nparts, pl.kp.mtiles, pl.BM, pl.kp.M,
-                                 producer->Cout, eps, mean_rstd);
+    return launch_inorm_finalize(s, stats_partial, batch * pl.nparts, pl.kp.mtiles, pl.BM, pl.kp.M, producer->Cout, eps,
+                                 mean_rstd, nullptr, ru);
+}
+int t2v_batch_norm_finalize(t2v_ctx* ctx, void* stream, const t2v_conv_desc* producer, int batch,
+                            const float* stats_partial, float eps, float* mean_rstd) {
+    T2V_REQUIRE(ctx && stats_partial && mean_rstd && batch >= 1, "batch_norm_finalize: bad arguments");
+    return batch_norm_finalize((hipStream_t)stream, producer, batch, stats_partial, eps, mean_rstd, nullptr);
+}
+int t2v_batch_norm_finalize_running(t2v_ctx* ctx, void* stream, const t2v_conv_desc* producer, int batch,
+                                    const float* stats_partial, float eps, float* mean_rstd, float* running_mean,
+                                    float* running_var, float momentum, int times) {
+    T2V_REQUIRE(ctx && producer && stats_partial && mean_rstd && running_mean && running_var && batch >= 1 && times >= 1,
+                "batch_norm_finalize_running: bad arguments");
+    int ho = 0, wo = 0;
+    T2V_TRY(t2v_conv_out_dims(producer, &ho, &wo));
+    const long n = (long)batch * ho * wo;
+    T2V_REQUIRE(n >= 2, "batch_norm_finalize_running: the unbiased variance needs at least two values per channel");
+    const RunningUpdate ru{running_mean, running_var, (float)n, momentum, times};
+    return batch_norm_finalize((hipStream_t)stream, producer, batch, stats_partial, eps, mean_rstd, &ru);
 }
 
 // narrow-input regular convs (7x7 stems: 12 / 8 channels; the discriminators' 4x4 first layers: 8): fold the taps

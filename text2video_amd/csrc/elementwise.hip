@@ -37,10 +37,25 @@ static inline int grid_for(long n, int block) {
 // Pixel count of partial `part`: conv-kernel partials cover BM consecutive GEMM rows of a phase; the Winograd
 // output transform's partials (wm = 2 | 4 > 0) cover 128/wm^2 consecutive wm x wm tiles of the ceil(H/wm) x
 // ceil(W/wm) tile grid, ragged at the bottom / right edge and padded with empty tiles at the end.
+// BatchNorm2d's running statistics, moved `times` times by the (mean, rstd) just written (bn_running_update_kernel's
+// arithmetic, so the fused and the stand-alone update agree bit for bit)
+__device__ __forceinline__ void running_update(const RunningUpdate& ru, int c, float2 mr, float eps) {
+    if (ru.mean == nullptr) return;
+    const float var = fmaxf(1.0f / (mr.y * mr.y) - eps, 0.f);
+    const float unbiased = var * (ru.n / (ru.n - 1.0f));
+    float rm = ru.mean[c], rv = ru.var[c];
+    for (int t = 0; t < ru.times; ++t) {
+        rm = (1.0f - ru.momentum) * rm + ru.momentum * mr.x;
+        rv = (1.0f - ru.momentum) * rv + ru.momentum * unbiased;
+    }
+    ru.mean[c] = rm;
+    ru.var[c] = rv;
+}
+
 __global__ __launch_bounds__(16 * kFinSlices) void inorm_finalize_kernel(const float2* __restrict__ stats, int nparts, int mtiles,
                                                              int BM, int M, int C, float eps,
                                                              float2* __restrict__ mean_rstd, int wm, int H, int W,
-                                                             double* __restrict__ scratch) {
+                                                             double* __restrict__ scratch, RunningUpdate ru) {
     // gridDim.y > 1 (scratch given): block y pools every gridDim.y-th group of partials and leaves its four sums
     // in scratch[y][c][4]; inorm_finalize_merge_kernel adds the groups up.  One block per 16 channels cannot pull
     // a 1024x1024 layer's 16384 x 64 partials (8 MB) through a single CU in less than ~1 ms.
@@ -85,12 +100,14 @@ __global__ __launch_bounds__(16 * kFinSlices) void inorm_finalize_kernel(const f
         double m2 = sm2 + s2 - s1 * mean_d;
         m2 = m2 > 0.0 ? m2 : 0.0;
         const float var = (float)(m2 / s0);
-        mean_rstd[c] = make_float2(ref + (float)mean_d, 1.0f / sqrtf(var + eps));
+        const float2 mr = make_float2(ref + (float)mean_d, 1.0f / sqrtf(var + eps));
+        mean_rstd[c] = mr;
+        running_update(ru, c, mr, eps);
     }
 }
 
 __global__ void inorm_finalize_merge_kernel(const float2* __restrict__ stats, const double* __restrict__ scratch, int groups,
-                                            int C, float eps, float2* __restrict__ mean_rstd) {
+                                            int C, float eps, float2* __restrict__ mean_rstd, RunningUpdate ru) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, sm2 = 0.0;
@@ -101,7 +118,9 @@ __global__ void inorm_finalize_merge_kernel(const float2* __restrict__ stats, co
     const double mean_d = s1 / s0;
     double m2 = sm2 + s2 - s1 * mean_d;
     m2 = m2 > 0.0 ? m2 : 0.0;
-    mean_rstd[c] = make_float2(stats[c].x + (float)mean_d, 1.0f / sqrtf((float)(m2 / s0) + eps));
+    const float2 mr = make_float2(stats[c].x + (float)mean_d, 1.0f / sqrtf((float)(m2 / s0) + eps));
+    mean_rstd[c] = mr;
+    running_update(ru, c, mr, eps);
 }
 
 // groups of partial blocks for a launch: 1 (single kernel) unless a scratch buffer is given and the layer is big
@@ -114,38 +133,40 @@ static int finalize_groups(int nparts, int C, const double* scratch) {
     return g < 1 ? 1 : g;
 }
 static int run_finalize(hipStream_t s, const float* stats, int nparts, int mtiles, int BM, int M, int C, float eps,
-                        float* mean_rstd, int wm, int H, int W, double* scratch) {
+                        float* mean_rstd, int wm, int H, int W, double* scratch, const RunningUpdate* ru) {
     const int groups = finalize_groups(nparts, C, scratch);
+    const RunningUpdate none{nullptr, nullptr, 0.f, 0.f, 0};
+    const RunningUpdate upd = ru ? *ru : none;
     hipLaunchKernelGGL(inorm_finalize_kernel, dim3((C + 15) / 16, groups), dim3(16 * kFinSlices), 0, s,
                        reinterpret_cast<const float2*>(stats), nparts, mtiles, BM, M, C, eps,
-                       reinterpret_cast<float2*>(mean_rstd), wm, H, W, groups > 1 ? scratch : nullptr);
+                       reinterpret_cast<float2*>(mean_rstd), wm, H, W, groups > 1 ? scratch : nullptr, groups > 1 ? none : upd);
     T2V_HIP_CHECK(hipGetLastError());
     if (groups > 1) {
         hipLaunchKernelGGL(inorm_finalize_merge_kernel, dim3((C + 255) / 256), dim3(256), 0, s,
                            reinterpret_cast<const float2*>(stats), scratch, groups, C, eps,
-                           reinterpret_cast<float2*>(mean_rstd));
+                           reinterpret_cast<float2*>(mean_rstd), upd);
         T2V_HIP_CHECK(hipGetLastError());
     }
     return T2V_OK;
 }
 
 int launch_inorm_finalize(hipStream_t s, const float* stats, int nparts, int mtiles, int BM, int M, int C,
-                          float eps, float* mean_rstd, double* scratch) {
-    return run_finalize(s, stats, nparts, mtiles, BM, M, C, eps, mean_rstd, 0, 0, 0, scratch);
+                          float eps, float* mean_rstd, double* scratch, const RunningUpdate* ru) {
+    return run_finalize(s, stats, nparts, mtiles, BM, M, C, eps, mean_rstd, 0, 0, 0, scratch, ru);
 }
 // partials of square edge x edge pixel tiles (the stem kernel), `batch` images back to back
 int launch_inorm_finalize_tiles(hipStream_t s, const float* stats, int edge, int H, int W, int C, float eps,
-                                float* mean_rstd, int batch, double* scratch) {
+                                float* mean_rstd, int batch, double* scratch, const RunningUpdate* ru) {
     const int nparts = ((H + edge - 1) / edge) * ((W + edge - 1) / edge);
-    return run_finalize(s, stats, batch * nparts, nparts, edge * edge, H * W, C, eps, mean_rstd, -edge, H, W, scratch);
+    return run_finalize(s, stats, batch * nparts, nparts, edge * edge, H * W, C, eps, mean_rstd, -edge, H, W, scratch, ru);
 }
 
 // partials written by the Winograd output transform F(wm x wm, 3x3) of an H x W map
 int launch_inorm_finalize_winograd(hipStream_t s, const float* stats, int wm, int H, int W, int C, float eps,
-                                   float* mean_rstd, int batch, double* scratch) {
+                                   float* mean_rstd, int batch, double* scratch, const RunningUpdate* ru) {
     const int T = ((H + wm - 1) / wm) * ((W + wm - 1) / wm), Tp = wino_pad_tiles(T);
     const int nparts = Tp / (128 / (wm * wm));   // per image; a batch's partial blocks are contiguous
-    return run_finalize(s, stats, batch * nparts, nparts, 0, H * W, C, eps, mean_rstd, wm, H, W, scratch);
+    return run_finalize(s, stats, batch * nparts, nparts, 0, H * W, C, eps, mean_rstd, wm, H, W, scratch, ru);
 }
 
 // BatchNorm2d's running statistics in training mode ($SP/torch/nn/modules/batchnorm.py:57-64 -> BatchNormalization_

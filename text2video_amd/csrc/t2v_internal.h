@@ -221,12 +221,20 @@ int launch_wino_wgrad_sk(hipStream_t s, const float* V, const float* Md, float* 
 // elementwise.hip
 // scratch (optional): kFinalizeMaxGroups * C * 4 doubles -- lets big layers pool their partials on many CUs
 constexpr int kFinalizeMaxGroups = 64;
+// ru (optional): BatchNorm2d running statistics moved by the statistics being finalized, in the same launch
+struct RunningUpdate {
+    float* mean;
+    float* var;
+    float n;          // values per channel behind the statistics (unbiased-variance factor n / (n - 1))
+    float momentum;
+    int times;        // updates to apply (a forward that stands for two upstream forwards: 2)
+};
 int launch_inorm_finalize_winograd(hipStream_t s, const float* stats, int wm, int H, int W, int C, float eps,
-                                   float* mean_rstd, int batch, double* scratch = nullptr);
+                                   float* mean_rstd, int batch, double* scratch = nullptr, const RunningUpdate* ru = nullptr);
 int launch_inorm_finalize_tiles(hipStream_t s, const float* stats, int edge, int H, int W, int C, float eps,
-                                float* mean_rstd, int batch, double* scratch = nullptr);
+                                float* mean_rstd, int batch, double* scratch = nullptr, const RunningUpdate* ru = nullptr);
 int launch_inorm_finalize(hipStream_t s, const float* stats, int nparts, int mtiles, int BM, int M, int C,
-                          float eps, float* mean_rstd, double* scratch = nullptr);
+                          float eps, float* mean_rstd, double* scratch = nullptr, const RunningUpdate* ru = nullptr);
 // finalize folded into the apply pass (layers with <= 128 partials per channel); geometry arguments as the finalize
 // launchers derive them: conv partials (nparts, mtiles, BM, M, wm = 0), stem tiles (wm = -edge), Winograd (wm = 2 | 4)
 bool inorm_fused_ok(int nparts, int C);

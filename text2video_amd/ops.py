@@ -151,9 +151,16 @@ def conv2d(x, packed_w, bias, desc, y_cs=None, stats=None, out=None):
     return y
 
 
-def instance_norm_finalize(stats, desc, eps=1e-5, out=None):
+def instance_norm_finalize(stats, desc, eps=1e-5, out=None, running=None):
+    """running = (running_mean, running_var, momentum, times): BatchNorm2d(train)'s running statistics (a batch of one) are
+    moved `times` times by these statistics in the same launch (t2v_batch_norm_finalize_running)."""
     c = context()
     mr = out if out is not None else torch.empty(desc.Cout, 2, dtype=torch.float32, device=stats.device)
+    if running is not None:
+        rm, rv, momentum, times = running
+        check(c.lib.t2v_batch_norm_finalize_running(c.handle, _stream(), ctypes.byref(desc), 1, _p(stats), eps, _p(mr), _p(rm), _p(rv),
+                                                    momentum, int(times)), "batch_norm_finalize_running")
+        return mr
     check(c.lib.t2v_instance_norm_finalize(c.handle, _stream(), ctypes.byref(desc), _p(stats), eps, _p(mr)),
           "instance_norm_finalize")
     return mr
@@ -274,11 +281,16 @@ def copy_channels(src, src_c0, dst, dst_c0, nc):
 # ------------------------------------------------------------------------------------------------
 # train-step pieces
 # ------------------------------------------------------------------------------------------------
-def batch_norm_finalize(stats, desc, batch, eps=1e-5):
+def batch_norm_finalize(stats, desc, batch, eps=1e-5, running=None):
     """BatchNorm2d(train) statistics over a batch: `stats` holds `batch` consecutive per-image
-    partial blocks written by conv2d(..., stats=stats[b * n : (b + 1) * n])."""
+    partial blocks written by conv2d(..., stats=stats[b * n : (b + 1) * n]).  running: as instance_norm_finalize."""
     c = context()
     mr = torch.empty(desc.Cout, 2, dtype=torch.float32, device=stats.device)
+    if running is not None:
+        rm, rv, momentum, times = running
+        check(c.lib.t2v_batch_norm_finalize_running(c.handle, _stream(), ctypes.byref(desc), batch, _p(stats), eps, _p(mr), _p(rm),
+                                                    _p(rv), momentum, int(times)), "batch_norm_finalize_running")
+        return mr
     check(c.lib.t2v_batch_norm_finalize(c.handle, _stream(), ctypes.byref(desc), batch, _p(stats), eps, _p(mr)),
           "batch_norm_finalize")
     return mr

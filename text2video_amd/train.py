@@ -337,16 +337,17 @@ def running_stats(gamma, create=True):
     return rs
 
 
-def track_running_stats(gamma, mean_rstd, n):
+def running_update_args(gamma, n):
     """Every training-mode forward of a BatchNorm2d also moves its running statistics
-    ($SP/torch/nn/modules/batchnorm.py:57-64, momentum 0.1, unbiased variance) -- never read on this path (upstream
-    keeps the generator in train mode at test time) but part of a faithful checkpoint.  T2V_BN_RUNNING=0: off."""
+    ($SP/torch/nn/modules/batchnorm.py:57-64, momentum 0.1, unbiased variance) -- never read on this path (upstream keeps
+    the generator in train mode at test time) but part of a faithful checkpoint.  Returns (running_mean,
+    running_var, momentum, times) for the finalize call, which moves them in its own launch, or None (no affine norm,
+    fewer than two values per channel, T2V_BN_RUNNING=0); counts the updates on the statistics' step counter."""
     if gamma is None or n < 2 or os.environ.get("T2V_BN_RUNNING", "1") == "0":
-        return
+        return None
     rs = running_stats(gamma)
-    for _ in range(_BN_UPDATES[0]):
-        ops.batch_norm_update_running(mean_rstd, rs[0], rs[1], n, BN_MOMENTUM)
-        rs[2] += 1
+    rs[2] += _BN_UPDATES[0]
+    return (rs[0], rs[1], BN_MOMENTUM, _BN_UPDATES[0])
 
 
 _ZEROS = {}
@@ -408,16 +409,16 @@ class _ConvBlock(torch.autograd.Function):
             bt = beta.detach() if beta is not None else None
             # the residual add rides in the norm-apply pass (its gradient is the identity)
             rs = res.detach().contiguous() if (res is not None and res.shape == y.shape) else None
+            # (the finalize launch also moves BatchNorm2d's running statistics: running_update_args)
             if norm == "batch":
-                mrs = [ops.batch_norm_finalize(stats, fdesc, B)]
+                mrs = [ops.batch_norm_finalize(stats, fdesc, B, running=running_update_args(gamma, B * ho * wo))]
                 ops.instance_norm_apply(c, mrs[0], g, bt, res1=rs, relu=relu, out=y)
-                track_running_stats(gamma, mrs[0], B * ho * wo)
             else:
                 mrs = []
-                for i in range(B):
-                    mrs.append(ops.instance_norm_finalize(stats[i * n:(i + 1) * n], fdesc))
+                for i in range(B):       # BatchNorm2d(train) on a batch of one
+                    mrs.append(ops.instance_norm_finalize(stats[i * n:(i + 1) * n], fdesc,
+                                                          running=running_update_args(gamma, ho * wo)))
                     ops.instance_norm_apply(c[i], mrs[i], g, bt, res1=rs[i] if rs is not None else None, relu=relu, out=y[i])
-                    track_running_stats(gamma, mrs[i], ho * wo)      # BatchNorm2d(train) on a batch of one
             if rs is not None:
                 res = None
         if res is not None:
@@ -1659,7 +1660,7 @@ class Vid2VidTrainer:
             0.4.1's module carries ($SP/torch/nn/modules/batchnorm.py: running_mean, running_var, num_batches_tracked)
             so that the file also loads strictly into the reference's own modules.  The norm layers run on batch
             statistics in training AND at test time, so the running statistics are never read: they are
-            tracked all the same (track_running_stats: momentum 0.1, unbiased variance, one update per forward) and
+            tracked all the same (running_update_args: momentum 0.1, unbiased variance, one update per forward) and
             written as they stand."""
             sd = {}
             for k, v in net.named_upstream_parameters().items():
