@@ -249,18 +249,22 @@ def test_config4_train_step_512_two_frames():
         assert abs(l1[k] - ld[k]) <= 2e-3 * max(1.0, abs(ld[k])), k
 
 
-def test_fullwidth_gradient_error_is_within_the_fp32_oracles_own():
+@pytest.mark.parametrize("H", [256, 512])
+def test_fullwidth_gradient_error_is_within_the_fp32_oracles_own(H):
     """Conditioning-normalised parity of the backward pass at full width (ngf 128, 9 blocks, 256x256: the
     ResnetBlock convs, their data gradients and weight gradients all take the Winograd F(4x4,3x3) path): the HIP
     gradient's distance from an fp64 evaluation of the oracle, per parameter tensor, against the distance of the fp32
     CPU oracle from the same fp64 evaluation.  The HIP path must be as good as "another fp32 implementation": within
-    a small factor of the oracle's own rounding noise (measured: 1.9x median, 2.8x at the 90th percentile)."""
+    a small factor of the oracle's own rounding noise (measured: 1.9x median, 2.8x at the 90th percentile).
+    512x512 = the config-5 frame size: the 64x64x1024 bottleneck is where the fixed-grid kernels run (forward GEMM stage,
+    transposed data gradient, Winograd-domain weight-gradient reduction; the step's batched-gradient scope is on so that the
+    data gradient takes the transposed algorithm) -- the same bound holds for them against the independent oracle."""
     from oracle.generator_ref import CompositeGenerator
     from text2video_amd import ops
     from text2video_amd import train as T
     from text2video_amd.generator import GeneratorSpec, synthetic_state_dict
-    H = W = 256
-    assert ops.best_conv_algo(ops.conv_desc(32, 32, 1024, 1024, 3, 1, 1, ops.PAD_REFLECT), 1024) == ops.ALGO_WINOGRAD_F4
+    W = H
+    assert ops.best_conv_algo(ops.conv_desc(H // 8, W // 8, 1024, 1024, 3, 1, 1, ops.PAD_REFLECT), 1024) == ops.ALGO_WINOGRAD_F4
     spec = GeneratorSpec(ngf=128, n_downsample=3, n_blocks=9, no_flow=True, norm="batch")
     sd = synthetic_state_dict(spec, 6, "vid2vid")
     rng = np.random.default_rng(0)
@@ -285,8 +289,11 @@ def test_fullwidth_gradient_error_is_within_the_fp32_oracles_own():
     q[..., :6] = prev.permute(0, 2, 3, 1).cuda()
     r = torch.zeros(1, H, W, 4, device="cuda:0")
     r[..., :3] = R.permute(0, 2, 3, 1).cuda()
-    out = G(p, q)
-    gh = torch.autograd.grad((out * r).sum() / R.numel(), list(G.parameters()), allow_unused=True)
+    params = list(G.parameters())
+    with (T.batched_weight_gradients(params) if H == 512 else __import__("contextlib").nullcontext()):
+        out = G(p, q)
+        gh = torch.autograd.grad((out * r).sum() / R.numel(), params, allow_unused=True)
+        gh = T.flush_pending_weight_gradients(params, gh)
     gh = {k: v.cpu() for (k, _), v in zip(G.named_upstream_parameters().items(), gh)}
     assert (out.detach()[..., :3].permute(0, 3, 1, 2).cpu().double() - o64).abs().max().item() <= 2e-4
 
