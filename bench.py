@@ -418,7 +418,8 @@ def main():
         # the fixed-grid form of the F(4x4) GEMM stage (conv_igemm.hip: wino_gemm_sk_ok -- same rule restated here for the
         # label only): whole 128-row tiles, at least one round of the 512 resident blocks, a badly filled last round
         trows = ops.winograd_tile_rows(desc) if algo == ops.ALGO_WINOGRAD_F4 else 0     # tile rows per position, padded
-        sk_tiles = npos * (trows // 128) * (C // 128) if (trows and trows % 128 == 0) else 0
+        sk_tiles = npos * (trows // 128) * (C // 128) if (trows and trows % 128 == 0) else \
+            (npos * (trows // 192) * (C // 64) if (trows and trows % 192 == 0) else 0)      # 128x128 | 192x64 tiles
         fixed_grid = bool(sk_tiles >= 512 and sk_tiles * 100 <= -(-sk_tiles // 512) * 512 * 85
                           and os.environ.get("T2V_WINO_GEMM_SK", "1") != "0")
         prof = os.path.join(ROOT, "profiles", "pmc_summary.json")
@@ -431,7 +432,8 @@ def main():
                                                     if (hb, wb) == (64, 64) else "-")
             except Exception:
                 traffic = None
-        kname = (("wino_gemm_sk_kernel<128x128 tiles on a fixed grid of 2 blocks per CU,fp32 32x32x2>"
+        kname = (("wino_gemm_sk_kernel<%s tiles on a fixed grid of 2 blocks per CU,fp32 32x32x2>"
+                  % ("128x128" if trows % 128 == 0 else "192x64")
                   if fixed_grid else "conv_igemm_kernel<%s,fp32 32x32x2>"
                   % ("128x128" if npos * ntile // 128 * 8 >= 0.8 * 256 * -(-(npos * ntile // 128 * 8) // 256) else "64x64"))
                  + " as %d batched GEMMs [%d x 1024]x[1024 x 1024]: Winograd F(%dx%d,3x3) stage of the 1024->1024 3x3 "

@@ -75,6 +75,7 @@ struct TileCfg {
 using CfgL = TileCfg<32, 2, 2, 2, 2>;  // 128 x 128
 using CfgS = TileCfg<16, 4, 1, 4, 1>;  // 256 x 16 (3-channel heads)
 using CfgQ = TileCfg<32, 2, 2, 1, 1>;  // 64 x 64: finer granularity when 128x128 tiles fill the 256 CUs poorly
+using CfgW = TileCfg<32, 2, 2, 3, 1>;  // 192 x 64: all tile rows of a 512x320 frame's transform position in one tile (fixed grid)
 
 // One LDS-DMA instruction through buffer addressing: 64 lanes x 16 B -> 1 KiB at the wave-uniform LDS
 // address `lds_dst`; source = base + voff (per lane, bytes) + soff (scalar, bytes).  Lanes with
@@ -465,12 +466,11 @@ struct SkKParams {
     int mtiles_g, ntiles, nk, tiles, tiles_per_xcd, blocks_per_xcd;
 };
 
-template <int RING>
+template <class Cfg, int RING>
 __global__ __launch_bounds__(512) void wino_gemm_sk_kernel(const SkKParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    using Cfg = CfgL;
     using MM = Mfma<32>;
-    using acc_t = MM::acc_t;
+    using acc_t = typename MM::acc_t;
     constexpr int BM = Cfg::BM, BN = Cfg::BN, MF = 32;
     constexpr int A_ITERS = BM / 32, B_PER_WAVE = BN / 32, LD_PER_WAVE = A_ITERS + B_PER_WAVE;
 
@@ -496,7 +496,7 @@ __global__ __launch_bounds__(512) void wino_gemm_sk_kernel(const SkKParams p) {
 
     // ---- loader lane geometry (the same for every tile: only the SRD bases move) ----
     const int lrow = lane >> 3, lslot = lane & 7;
-    const int tile_bytes = 128 * p.K * 4;
+    const int a_bytes = BM * p.K * 4, b_bytes = BN * p.K * 4;
     int a_voff[A_ITERS], b_voff[B_PER_WAVE];
 #pragma unroll
     for (int i = 0; i < A_ITERS; ++i) {
@@ -537,9 +537,9 @@ __global__ __launch_bounds__(512) void wino_gemm_sk_kernel(const SkKParams p) {
                 char* dstA = smem + buf * Cfg::STAGE_BYTES + wid * (BM / 4) * 128;
                 char* dstB = smem + buf * Cfg::STAGE_BYTES + BM * 128 + wid * B_PER_WAVE * 8 * 128;
 #pragma unroll
-                for (int i = 0; i < A_ITERS; ++i) dma16(abase, tile_bytes, dstA + i * 8 * 128, a_voff[i], kt * (kBK * 4));
+                for (int i = 0; i < A_ITERS; ++i) dma16(abase, a_bytes, dstA + i * 8 * 128, a_voff[i], kt * (kBK * 4));
 #pragma unroll
-                for (int i = 0; i < B_PER_WAVE; ++i) dma16(bbase, tile_bytes, dstB + i * 8 * 128, b_voff[i], kt * (kBK * 4));
+                for (int i = 0; i < B_PER_WAVE; ++i) dma16(bbase, b_bytes, dstB + i * 8 * 128, b_voff[i], kt * (kBK * 4));
             };
             loader_k_loop<RING, LD_PER_WAVE>(kb, ke, issue_stage);
             __syncthreads();   // MFMA waves have read their last fragments: the next tile's prologue may overwrite the ring
@@ -646,13 +646,22 @@ int wino_gemm_sk_grid_blocks() {
 constexpr int kSkMaxGrid = 1024;
 size_t wino_gemm_sk_scratch_floats() { return (size_t)kSkMaxGrid * (4 * 64 * 64 + 4 * 2); }
 
+// tile of the fixed-grid launch: 128 x 128 where the tile rows are whole 128s; 192 x 64 where they are whole 192s (a 512x320
+// frame: 160 tiles padded to 192 -- all rows of a transform position in one tile); 0: no fixed-grid form
+static int sk_tile_rows(int T, int N) {
+    if (N % 128) return 0;            // (the packed weights hold round_up(N, 128) rows per position: N itself, then)
+    if (T % 128 == 0) return 128;
+    static const int wide = getenv("T2V_WINO_GEMM_SK_WIDE") ? atoi(getenv("T2V_WINO_GEMM_SK_WIDE")) : 1;
+    return (wide && T % 192 == 0) ? 192 : 0;
+}
 bool wino_gemm_sk_ok(int groups, int T, int K, int N, int c_cs) {
     const char* e = getenv("T2V_WINO_GEMM_SK");   // read per call: tests and A/B runs flip it inside one process
-    if ((e && atoi(e) == 0) || T % 128 || N % 128 || K % kBK || c_cs != N || (long)128 * K * 4 >= 0x7fff0000L) return false;
+    const int bm = sk_tile_rows(T, N);
+    if ((e && atoi(e) == 0) || bm == 0 || K % kBK || c_cs != N || (long)192 * K * 4 >= 0x7fff0000L) return false;
     // fewer tiles than resident blocks: one tile per block is already less than one round.  Beyond that the fixed grid
     // pays where whole tiles fill their last round badly -- measured on MI355X (scripts/sk_probe.py, K = N = 1024):
     // 1.125 rounds 189 -> 144 us, 1.69 rounds 241 -> 210 us, 2.25 rounds 352 -> 294 us, 4.5 rounds 583 -> 611 us
-    const long tiles = (long)groups * (T / 128) * (N / 128), grid = wino_gemm_sk_grid_blocks();
+    const long tiles = (long)groups * (T / bm) * (N / (bm == 128 ? 128 : 64)), grid = wino_gemm_sk_grid_blocks();
     if (e && atoi(e) == 2) return true;   // T2V_WINO_GEMM_SK=2: wherever the shape allows (fewer tiles than blocks: the
                                           // spare blocks leave at once -- what the small-shape tests run)
     if (tiles < grid) return false;
@@ -673,6 +682,20 @@ unsigned long long wino_gemm_sk_next_tag() {
     return ++tag_counter;
 }
 
+template <class Cfg>
+static int launch_sk(hipStream_t s, const SkKParams& k, int grid) {
+    auto kern = wino_gemm_sk_kernel<Cfg, 2>;
+    constexpr int LDS_BYTES = 2 * Cfg::STAGE_BYTES;
+    static bool attr_done = false;   // per instantiation
+    if (!attr_done) {
+        T2V_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS_BYTES, s, k);
+    T2V_HIP_CHECK(hipGetLastError());
+    return T2V_OK;
+}
+
 int launch_wino_gemm_sk(hipStream_t s, const SkGemm& g) {
     T2V_REQUIRE(wino_gemm_sk_ok(g.groups, g.T, g.K, g.N, g.c_cs), "stream-K gemm: shape not supported");
     SkKParams k;
@@ -682,21 +705,13 @@ int launch_wino_gemm_sk(hipStream_t s, const SkGemm& g) {
     k.tag = wino_gemm_sk_next_tag();
     k.a_group_stride = g.a_group_stride;
     k.T = g.T; k.K = g.K; k.N = g.N; k.c_cs = g.c_cs;
-    k.mtiles_g = g.T / 128; k.ntiles = g.N / 128; k.nk = g.K / kBK;
+    const int bm = sk_tile_rows(g.T, g.N), bn = bm == 128 ? 128 : 64;
+    k.mtiles_g = g.T / bm; k.ntiles = g.N / bn; k.nk = g.K / kBK;
     k.tiles = g.groups * k.mtiles_g * k.ntiles;
     const int grid = wino_gemm_sk_grid_blocks();
     k.blocks_per_xcd = grid / 8;
     k.tiles_per_xcd = (k.tiles + 7) / 8;
-    auto kern = wino_gemm_sk_kernel<2>;
-    constexpr int LDS_BYTES = 2 * CfgL::STAGE_BYTES;
-    static bool attr_done = false;
-    if (!attr_done) {
-        T2V_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        attr_done = true;
-    }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS_BYTES, s, k);
-    T2V_HIP_CHECK(hipGetLastError());
-    return T2V_OK;
+    return bm == 128 ? launch_sk<CfgL>(s, k, grid) : launch_sk<CfgW>(s, k, grid);
 }
 
 int conv_tile_for(int Cout) { return Cout <= 16 ? kTileS : kTileL; }
