@@ -553,9 +553,11 @@ __global__ __launch_bounds__(512) void wino_gemm_sk_kernel(const SkKParams p) {
             const int src = blockIdx.x - 8;
             const unsigned long long* fl = p.flags + src * 4 + wid;
             // (bounded: ~1 s of polling.  The producer ran before this block was even dispatched; if its tag is still
-            // missing something is broken, and a wrong tile is a better failure than a hung GPU)
-            for (int spin = 0; spin < (1 << 23) && __hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.tag; ++spin)
+            // missing something is broken: the tile is then poisoned with NaNs -- visible, and no hung GPU)
+            int spin = 0;
+            for (; spin < (1 << 23) && __hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.tag; ++spin)
                 __builtin_amdgcn_s_sleep(4);
+            const bool timed_out = spin >= (1 << 23);
             // taken: clear it, so that a replay of this very launch (a captured graph re-issues the same tag) starts clean
             if (lane == 0) __hip_atomic_store(const_cast<unsigned long long*>(fl), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             // write-through (sc1) stores on the producer's side, sc1 loads here: the pair that is coherent across the
@@ -572,7 +574,7 @@ __global__ __launch_bounds__(512) void wino_gemm_sk_kernel(const SkKParams p) {
                         float v[4];
                         __builtin_memcpy(v, &raw, 16);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) acc[i][jj][q * 4 + e] = v[e];
+                        for (int e = 0; e < 4; ++e) acc[i][jj][q * 4 + e] = timed_out ? __builtin_nanf("") : v[e];
                     }
         } else {
 #pragma unroll

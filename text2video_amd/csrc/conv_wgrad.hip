@@ -399,8 +399,10 @@ __global__ __launch_bounds__(512) void wino_wgrad_sk_kernel(const WinoWgradSkPar
         if (init) {
             const int src = blockIdx.x - 8;
             const unsigned long long* fl = p.flags + src * 4 + wid;
-            for (int spin = 0; spin < (1 << 23) && __hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.tag; ++spin)
+            int spin = 0;     // (bounded, ~1 s; on a time-out the tile is poisoned with NaNs: see wino_gemm_sk_kernel)
+            for (; spin < (1 << 23) && __hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.tag; ++spin)
                 __builtin_amdgcn_s_sleep(4);
+            const bool timed_out = spin >= (1 << 23);
             // taken: clear it, so that a replay of this very launch (a captured graph re-issues the same tag) starts clean
             if (lane == 0) __hip_atomic_store(const_cast<unsigned long long*>(fl), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(
@@ -415,7 +417,7 @@ __global__ __launch_bounds__(512) void wino_wgrad_sk_kernel(const WinoWgradSkPar
                         float v[4];
                         __builtin_memcpy(v, &raw, 16);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) acc[i][j][q * 4 + e] = v[e];
+                        for (int e = 0; e < 4; ++e) acc[i][j][q * 4 + e] = timed_out ? __builtin_nanf("") : v[e];
                     }
         } else {
 #pragma unroll
