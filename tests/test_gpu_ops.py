@@ -390,13 +390,14 @@ def test_winograd_f4_output_transform_applies_the_activation(slope):
 
 
 @pytest.mark.parametrize("geom", [(64, 64, 1024, 1024), (64, 88, 640, 640), (128, 128, 256, 256), (64, 128, 512, 1024),
-                                  (128, 128, 512, 256), (64, 40, 1024, 1024), (64, 40, 512, 384)])
+                                  (128, 128, 512, 256), (64, 40, 1024, 1024), (64, 40, 512, 384), (128, 128, 1024, 1024)])
 def test_fixed_grid_winograd_gemm_equals_tile_per_block(geom, monkeypatch):
     """The batched Winograd GEMM on a fixed grid (conv_igemm.hip: wino_gemm_sk_kernel; tiles cut between two blocks are
     finished from the first block's accumulators) against one block per tile: the same K-ordered MFMA chain per output,
     so the conv must be BIT-identical -- also launch after launch on one workspace (a stale hand-over flag or a stale L2
     line of an earlier launch would show as a differing frame).  Tile counts not divisible by the 8 XCDs included, and the
-    192 x 64 tiles of the 512x320 frames (64 x 40 maps: 160 tile rows padded to 192)."""
+    192 x 64 tiles of the 512x320 frames (64 x 40 maps: 160 tile rows padded to 192), and the second schedule (4.5 rounds of
+    tiles at 128 x 128 x 1024: whole rounds + a half round cut in two)."""
     from text2video_amd import ops
     H, W, Cin, Cout = geom
     dev = _dev()

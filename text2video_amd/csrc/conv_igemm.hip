@@ -464,6 +464,7 @@ struct SkKParams {
     long a_group_stride;
     int T, K, N, c_cs;
     int mtiles_g, ntiles, nk, tiles, tiles_per_xcd, blocks_per_xcd;
+    int rounds;   // > 0: `rounds` whole rounds of one tile per block + half a round of tiles cut in two (see the kernel)
 };
 
 template <class Cfg, int RING>
@@ -482,17 +483,38 @@ __global__ __launch_bounds__(512) void wino_gemm_sk_kernel(const SkKParams p) {
 
     // ---- this block's run of units (relative to its XCD's first tile) ----
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-    const int t0 = xcd * p.tiles_per_xcd, t1 = min(t0 + p.tiles_per_xcd, p.tiles);
-    if (t0 >= t1) return;
     const int nk = p.nk;
-    const int ux = (t1 - t0) * nk;
-    const int S = max(nk, (ux + p.blocks_per_xcd - 1) / p.blocks_per_xcd);   // >= one tile: a run never lies inside a tile
-    const int u0 = j * S, u1 = min(u0 + S, ux);
-    if (u0 >= u1) return;
-    const int tf = u0 / nk, tl = (u1 - 1) / nk;
-    const int kf = u0 - tf * nk, kl = u1 - tl * nk;
-    const int has_tail = kf > 0, has_head = kl < nk;
-    const int nf = tl - tf + 1, nmid = nf - has_head - has_tail;
+    // Second schedule (p.rounds > 0), for tile counts of R whole rounds plus exactly half a round (2304 tiles on 512 blocks:
+    // four 512x512 images, or a 1024x1024 frame): the contiguous runs above would put an XCD's 64 blocks into 64 tiles of
+    // 4-5 different positions at once (L2 hit rate 26 %); here every round is one tile per block -- an XCD's blocks on 64
+    // neighbouring tiles, as with one block per tile -- and the half round's tiles are cut in two: the lower half of an XCD's
+    // blocks computes the first K half of one such tile FIRST and hands it over, the upper half finishes it LAST.
+    const bool hybrid = p.rounds > 0;
+    const int half = p.blocks_per_xcd >> 1;
+    int t0 = 0, tf = 0, tl = 0, kf = 0, kl = nk, has_tail = 0, has_head = 0, nf, nmid;
+    if (hybrid) {
+        has_head = j < half;
+        has_tail = !has_head;
+        nmid = p.rounds;
+        nf = p.rounds + 1;
+    } else {
+        t0 = xcd * p.tiles_per_xcd;
+        const int t1 = min(t0 + p.tiles_per_xcd, p.tiles);
+        if (t0 >= t1) return;
+        const int ux = (t1 - t0) * nk;
+        const int S = max(nk, (ux + p.blocks_per_xcd - 1) / p.blocks_per_xcd);   // >= one tile: a run never lies inside a tile
+        const int u0 = j * S, u1 = min(u0 + S, ux);
+        if (u0 >= u1) return;
+        tf = u0 / nk;
+        tl = (u1 - 1) / nk;
+        kf = u0 - tf * nk;
+        kl = u1 - tl * nk;
+        has_tail = kf > 0;
+        has_head = kl < nk;
+        nf = tl - tf + 1;
+        nmid = nf - has_head - has_tail;
+    }
+    const int grid = p.blocks_per_xcd * 8;
 
     // ---- loader lane geometry (the same for every tile: only the SRD bases move) ----
     const int lrow = lane >> 3, lslot = lane & 7;
@@ -519,13 +541,27 @@ __global__ __launch_bounds__(512) void wino_gemm_sk_kernel(const SkKParams p) {
     bool flag_due = false;   // this wave's hand-over stores are in flight; its tag is raised at the next wait point
     for (int f = 0; f < nf; ++f) {
         // processing order: the head handed on to block j+1, the whole tiles, the tail begun by block j-1
-        int tr;
-        if (has_head && f == 0) tr = tl;
-        else if (f - has_head < nmid) tr = tf + has_tail + (f - has_head);
-        else tr = tf;
-        const int kb = tr == tf ? kf : 0, ke = tr == tl ? kl : nk;
+        int tile, kb, ke;
+        if (hybrid) {
+            if ((has_head && f == 0) || (has_tail && f == nf - 1)) {   // half of a tile of the half round
+                tile = p.rounds * grid + xcd * half + (has_head ? j : j - half);
+                kb = has_head ? 0 : nk >> 1;
+                ke = has_head ? nk >> 1 : nk;
+            } else {                                                   // round f - has_head: the XCD's band of that round
+                tile = (f - has_head) * grid + xcd * p.blocks_per_xcd + j;
+                kb = 0;
+                ke = nk;
+            }
+        } else {
+            int tr;
+            if (has_head && f == 0) tr = tl;
+            else if (f - has_head < nmid) tr = tf + has_tail + (f - has_head);
+            else tr = tf;
+            kb = tr == tf ? kf : 0;
+            ke = tr == tl ? kl : nk;
+            tile = t0 + tr;
+        }
         const bool init = kb > 0, publish = ke < nk;
-        const int tile = t0 + tr;
         const int tpg = p.mtiles_g * p.ntiles;
         const int pg = tile / tpg, rem = tile - pg * tpg;
         const int nt = rem / p.mtiles_g, mt = rem - nt * p.mtiles_g;
@@ -549,8 +585,9 @@ __global__ __launch_bounds__(512) void wino_gemm_sk_kernel(const SkKParams p) {
         // ---- MFMA waves ----
         acc_t acc[Cfg::TM][Cfg::TN];
         if (init) {
-            // the accumulators block j-1 (blockIdx - 8) left for this tile; its wave `wid` wrote what this wave reads
-            const int src = blockIdx.x - 8;
+            // the accumulators an earlier block of this XCD left for this tile (block j-1 = blockIdx - 8; block j - half in
+            // the second schedule); its wave `wid` wrote what this wave reads
+            const int src = blockIdx.x - 8 * (hybrid ? half : 1);
             const unsigned long long* fl = p.flags + src * 4 + wid;
             // (bounded: ~1 s of polling.  The producer ran before this block was even dispatched; if its tag is still
             // missing something is broken: the tile is then poisoned with NaNs -- visible, and no hung GPU)
@@ -656,6 +693,11 @@ static int sk_tile_rows(int T, int N) {
     static const int wide = getenv("T2V_WINO_GEMM_SK_WIDE") ? atoi(getenv("T2V_WINO_GEMM_SK_WIDE")) : 1;
     return (wide && T % 192 == 0) ? 192 : 0;
 }
+// R whole rounds + exactly half a round of tiles, an even number of K stages, whole 16-block halves per XCD
+static bool sk_half_round(long tiles, long grid, int nk) {
+    static const int on = getenv("T2V_WINO_GEMM_SK_HALF") ? atoi(getenv("T2V_WINO_GEMM_SK_HALF")) : 1;
+    return on && tiles >= grid && 2 * (tiles % grid) == grid && nk % 2 == 0 && grid % 16 == 0;
+}
 bool wino_gemm_sk_ok(int groups, int T, int K, int N, int c_cs) {
     const char* e = getenv("T2V_WINO_GEMM_SK");   // read per call: tests and A/B runs flip it inside one process
     const int bm = sk_tile_rows(T, N);
@@ -667,6 +709,7 @@ bool wino_gemm_sk_ok(int groups, int T, int K, int N, int c_cs) {
     if (e && atoi(e) == 2) return true;   // T2V_WINO_GEMM_SK=2: wherever the shape allows (fewer tiles than blocks: the
                                           // spare blocks leave at once -- what the small-shape tests run)
     if (tiles < grid) return false;
+    if (sk_half_round(tiles, grid, K / kBK)) return true;     // R.5 rounds: the second schedule (whole rounds + a cut half round)
     const long rounds = (tiles + grid - 1) / grid;
     return tiles * 100 <= rounds * grid * 85;
 }
@@ -713,6 +756,7 @@ int launch_wino_gemm_sk(hipStream_t s, const SkGemm& g) {
     const int grid = wino_gemm_sk_grid_blocks();
     k.blocks_per_xcd = grid / 8;
     k.tiles_per_xcd = (k.tiles + 7) / 8;
+    k.rounds = sk_half_round(k.tiles, grid, k.nk) ? (int)(k.tiles / grid) : 0;
     return bm == 128 ? launch_sk<CfgL>(s, k, grid) : launch_sk<CfgW>(s, k, grid);
 }
 
