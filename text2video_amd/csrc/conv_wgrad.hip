@@ -321,6 +321,7 @@ struct WinoWgradSkParams {
     unsigned long long tag;
     int Tt, Cin, Cout, Cout_p, Kp;
     int ntiles, ctiles, nk, tiles, tiles_per_xcd, blocks_per_xcd;
+    int rounds;   // > 0: whole rounds of one tile per block + half a round cut in two (wino_gemm_sk_kernel's second schedule)
 };
 typedef unsigned int wg_v4u __attribute__((__vector_size__(16)));
 
@@ -337,17 +338,36 @@ __global__ __launch_bounds__(512) void wino_wgrad_sk_kernel(const WinoWgradSkPar
 
     // ---- this block's run of (tile, stage) units, relative to its XCD's first tile (see wino_gemm_sk_kernel) ----
     const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
-    const int t0 = xcd * p.tiles_per_xcd, t1 = min(t0 + p.tiles_per_xcd, p.tiles);
-    if (t0 >= t1) return;
     const int nk = p.nk;
-    const int ux = (t1 - t0) * nk;
-    const int S = max(nk, (ux + p.blocks_per_xcd - 1) / p.blocks_per_xcd);
-    const int u0 = jb * S, u1 = min(u0 + S, ux);
-    if (u0 >= u1) return;
-    const int tf = u0 / nk, tl = (u1 - 1) / nk;
-    const int kf = u0 - tf * nk, kl = u1 - tl * nk;
-    const int has_tail = kf > 0, has_head = kl < nk;
-    const int nf = tl - tf + 1, nmid = nf - has_head - has_tail;
+    // second schedule (p.rounds > 0; 2304 tiles of a 1024 -> 1024 layer on 512 blocks = 4.5 rounds): every whole round one
+    // tile per block -- an XCD's 64 blocks on the 8 x 8 tiles of ONE position, whose 2 + 2 MB of operands fit its L2 -- and
+    // the half round's tiles cut in two K halves, first half FIRST by the lower half of the XCD's blocks, second half LAST
+    const bool hybrid = p.rounds > 0;
+    const int half = p.blocks_per_xcd >> 1;
+    int t0 = 0, tf = 0, tl = 0, kf = 0, kl = nk, has_tail = 0, has_head = 0, nf, nmid;
+    if (hybrid) {
+        has_head = jb < half;
+        has_tail = !has_head;
+        nmid = p.rounds;
+        nf = p.rounds + 1;
+    } else {
+        t0 = xcd * p.tiles_per_xcd;
+        const int t1 = min(t0 + p.tiles_per_xcd, p.tiles);
+        if (t0 >= t1) return;
+        const int ux = (t1 - t0) * nk;
+        const int S = max(nk, (ux + p.blocks_per_xcd - 1) / p.blocks_per_xcd);
+        const int u0 = jb * S, u1 = min(u0 + S, ux);
+        if (u0 >= u1) return;
+        tf = u0 / nk;
+        tl = (u1 - 1) / nk;
+        kf = u0 - tf * nk;
+        kl = u1 - tl * nk;
+        has_tail = kf > 0;
+        has_head = kl < nk;
+        nf = tl - tf + 1;
+        nmid = nf - has_head - has_tail;
+    }
+    const int grid = p.blocks_per_xcd * 8;
 
     // loader lanes: an instruction moves 2 tile rows x 512 B; lane -> (row of the pair, 16-byte chunk of the channel slice)
     const int prow = lane >> 5, chunk = lane & 31;
@@ -363,13 +383,27 @@ __global__ __launch_bounds__(512) void wino_wgrad_sk_kernel(const WinoWgradSkPar
     const int fi = lane & 31, kk = lane >> 5;
     bool flag_due = false;
     for (int f = 0; f < nf; ++f) {
-        int tr;
-        if (has_head && f == 0) tr = tl;
-        else if (f - has_head < nmid) tr = tf + has_tail + (f - has_head);
-        else tr = tf;
-        const int kb = tr == tf ? kf : 0, ke = tr == tl ? kl : nk;
+        int tile, kb, ke;
+        if (hybrid) {
+            if ((has_head && f == 0) || (has_tail && f == nf - 1)) {
+                tile = p.rounds * grid + xcd * half + (has_head ? jb : jb - half);
+                kb = has_head ? 0 : nk >> 1;
+                ke = has_head ? nk >> 1 : nk;
+            } else {
+                tile = (f - has_head) * grid + xcd * p.blocks_per_xcd + jb;
+                kb = 0;
+                ke = nk;
+            }
+        } else {
+            int tr;
+            if (has_head && f == 0) tr = tl;
+            else if (f - has_head < nmid) tr = tf + has_tail + (f - has_head);
+            else tr = tf;
+            kb = tr == tf ? kf : 0;
+            ke = tr == tl ? kl : nk;
+            tile = t0 + tr;
+        }
         const bool init = kb > 0, publish = ke < nk;
-        const int tile = t0 + tr;
         const int tpp = p.ntiles * p.ctiles;
         const int xi = tile / tpp, rem = tile - xi * tpp;
         const int nt = rem / p.ctiles, ct = rem - nt * p.ctiles;   // c tile fastest: neighbours share the M_dy tile
@@ -397,7 +431,7 @@ __global__ __launch_bounds__(512) void wino_wgrad_sk_kernel(const WinoWgradSkPar
         // ---- MFMA waves ----
         f32x16 acc[2][2];
         if (init) {
-            const int src = blockIdx.x - 8;
+            const int src = blockIdx.x - 8 * (hybrid ? half : 1);
             const unsigned long long* fl = p.flags + src * 4 + wid;
             int spin = 0;     // (bounded, ~1 s; on a time-out the tile is poisoned with NaNs: see wino_gemm_sk_kernel)
             for (; spin < (1 << 23) && __hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.tag; ++spin)
@@ -501,6 +535,8 @@ int launch_wino_wgrad_sk(hipStream_t s, const float* V, const float* Md, float* 
     const int grid = wino_gemm_sk_grid_blocks();
     k.blocks_per_xcd = grid / 8;
     k.tiles_per_xcd = (k.tiles + 7) / 8;
+    static const int half_on = getenv("T2V_WGRAD_SK_HALF") ? atoi(getenv("T2V_WGRAD_SK_HALF")) : 1;
+    k.rounds = (half_on && k.tiles >= grid && 2 * (k.tiles % grid) == grid && k.nk % 2 == 0 && grid % 16 == 0) ? k.tiles / grid : 0;
     auto kern = wino_wgrad_sk_kernel<16, 4>;
     constexpr int lds = 4 * 2 * 16 * 128 * 4;
     static bool attr_done = false;
