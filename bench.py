@@ -416,11 +416,12 @@ def main():
         achieved = k_flop / (k_ms * 1e-3) / 1e12
         traffic = None
         # the fixed-grid form of the F(4x4) GEMM stage (conv_igemm.hip: wino_gemm_sk_ok -- same rule restated here for the
-        # label only): whole 128-row tiles, at least one round of the 512 resident blocks, a badly filled last round
+        # label only): whole 128-row tiles, at least one round of the 512 resident blocks, a badly filled last round or exactly
+        # half a round left over
         trows = ops.winograd_tile_rows(desc) if algo == ops.ALGO_WINOGRAD_F4 else 0     # tile rows per position, padded
         sk_tiles = npos * (trows // 128) * (C // 128) if (trows and trows % 128 == 0) else \
             (npos * (trows // 192) * (C // 64) if (trows and trows % 192 == 0) else 0)      # 128x128 | 192x64 tiles
-        fixed_grid = bool(sk_tiles >= 512 and sk_tiles * 100 <= -(-sk_tiles // 512) * 512 * 85
+        fixed_grid = bool(sk_tiles >= 512 and (sk_tiles * 100 <= -(-sk_tiles // 512) * 512 * 85 or 2 * (sk_tiles % 512) == 512)
                           and os.environ.get("T2V_WINO_GEMM_SK", "1") != "0")
         prof = os.path.join(ROOT, "profiles", "pmc_summary.json")
         if os.path.exists(prof):
