@@ -144,6 +144,294 @@ class ClockSampler:
                     source="sysfs pp_dpm_sclk, 50 ms period, during the headline timed region")
 
 
+def gemm_stage_roofline(dev, sd, g0h, g0w, iters):
+    """The dominant kernel of a frame whose global generator G0 runs on g0h x g0w, timed live with HIP events on the
+    stream it is launched on (torch's current stream); returns the `roofline` object."""
+    from text2video_amd import ops
+    # ---- dominant kernel, timed live with HIP events on the stream it is launched on ----
+    # The 1024->1024 3x3 ResnetBlock conv (28 per frame, 84 % of the algorithmic FLOPs) runs as Winograd
+    # F(4x4,3x3) [F(2x2,3x3)]: input transform -> 36 [16] batched GEMMs [T x 1024] x [1024 x 1024] on the
+    # implicit-GEMM kernel -> output transform.  The GEMM launch is the dominant kernel; its roofline is
+    # priced on the MFMA FLOPs it EXECUTES (2*36*T*C*C = 1/4 [4/9] of the direct conv's algorithmic
+    # 2*9*C*C*H*W), never on the direct-conv-equivalent figure.  Where the geometry has no Winograd path the direct kernel is timed.
+    C, hb, wb = 1024, g0h // 8, g0w // 8
+    direct = ops.conv_desc(hb, wb, C, C, 3, 1, 1, ops.PAD_REFLECT)
+    # same selection as the generator (generator.hip enumerate_layers): F(4x4,3x3) > F(2x2,3x3) > direct
+    cap = int(os.environ.get("T2V_CONV_ALGO", "0"))
+    algo = ops.ALGO_DIRECT
+    if cap == 0 and ops.winograd_supported(direct, C, ops.ALGO_WINOGRAD_F4):
+        algo = ops.ALGO_WINOGRAD_F4
+    elif cap in (0, 2) and ops.winograd_supported(direct, C, ops.ALGO_WINOGRAD):
+        algo = ops.ALGO_WINOGRAD
+    use_wino = algo != ops.ALGO_DIRECT
+    wm = 4 if algo == ops.ALGO_WINOGRAD_F4 else 2
+    npos, ntile = (wm + 2) ** 2, -(-hb // wm) * -(-wb // wm)     # (ragged maps: the edge tiles count)
+    desc = ops.conv_desc(hb, wb, C, C, 3, 1, 1, ops.PAD_REFLECT, algo=algo) if use_wino else direct
+    # inputs as the kernel sees them in a frame: conv1 of a ResnetBlock reads the residual stream
+    # (dense, signed), conv2 reads a ReLU output (half zeros) -- alternate the two
+    xs = [torch.randn(hb, wb, C, device=dev), torch.relu(torch.randn(hb, wb, C, device=dev))]
+    wt = ops.pack_conv_weight(sd["model_res_img.0.conv_block.1.weight"].to(dev), desc, C)
+    bias = sd["model_res_img.0.conv_block.1.bias"].to(dev)
+    stats = ops.conv_stats_buffer(desc, dev)
+    y = torch.empty(hb, wb, C, device=dev)
+    if use_wino:
+        wss = [ops.winograd_workspace(desc, C, dev) for _ in range(2)]
+        for i in range(2):   # transformed inputs of both kinds, one workspace each
+            ops.conv2d_winograd(xs[i], wt, bias, desc, stats=stats, out=y, workspace=wss[i], stages=1)
+
+        def launch(i, stages=2):
+            ops.conv2d_winograd(xs[i & 1], wt, bias, desc, stats=stats, out=y, workspace=wss[i & 1], stages=stages)
+    else:
+        def launch(i, stages=0):
+            ops.conv2d(xs[i & 1], wt, bias, desc, y_cs=C, stats=stats, out=y)
+    for i in range(64):   # ~35 ms: the clocks ramp back up for tens of ms after the host-side gap above
+        launch(i)
+    e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    e0.record()
+    for i in range(iters):
+        launch(i)
+    e1.record()
+    for i in range(iters):   # the whole conv (all three stages / the direct kernel)
+        launch(i, 7)
+    e2.record()
+    torch.cuda.synchronize()
+    k_ms = e0.elapsed_time(e1) / iters
+    conv_ms = e1.elapsed_time(e2) / iters
+    conv_flop = 2.0 * 9 * C * C * hb * wb                       # algorithmic (direct-conv) FLOPs of the layer
+    k_flop = 2.0 * npos * ntile * C * C if use_wino else conv_flop
+    achieved = k_flop / (k_ms * 1e-3) / 1e12
+    traffic = None
+    # the fixed-grid form of the F(4x4) GEMM stage (conv_igemm.hip: wino_gemm_sk_ok -- same rule restated here for the
+    # label only): whole 128-row tiles, at least one round of the 512 resident blocks, a badly filled last round or exactly
+    # half a round left over
+    trows = ops.winograd_tile_rows(desc) if algo == ops.ALGO_WINOGRAD_F4 else 0     # tile rows per position, padded
+    sk_tiles = npos * (trows // 128) * (C // 128) if (trows and trows % 128 == 0) else \
+        (npos * (trows // 192) * (C // 64) if (trows and trows % 192 == 0) else 0)      # 128x128 | 192x64 tiles
+    fixed_grid = bool(sk_tiles >= 512 and (sk_tiles * 100 <= -(-sk_tiles // 512) * 512 * 85 or 2 * (sk_tiles % 512) == 512)
+                      and os.environ.get("T2V_WINO_GEMM_SK", "1") != "0")
+    prof = os.path.join(ROOT, "profiles", "pmc_summary.json")
+    if os.path.exists(prof):
+        try:
+            traffic = json.load(open(prof)).get({0: "conv_igemm_rb_hbm_bytes_per_launch",
+                                                 1: "winograd_f2_gemm_hbm_bytes_per_launch",
+                                                 2: ("winograd_f4_gemm_sk_hbm_bytes_per_launch" if fixed_grid else
+                                                     "winograd_f4_gemm_hbm_bytes_per_launch")}[algo]
+                                                if (hb, wb) == (64, 64) else "-")
+        except Exception:
+            traffic = None
+    kname = (("wino_gemm_sk_kernel<%s tiles on a fixed grid of 2 blocks per CU,fp32 32x32x2>"
+              % ("128x128" if trows % 128 == 0 else "192x64")
+              if fixed_grid else "conv_igemm_kernel<%s,fp32 32x32x2>"
+              % ("128x128" if npos * ntile // 128 * 8 >= 0.8 * 256 * -(-(npos * ntile // 128 * 8) // 256) else "64x64"))
+             + " as %d batched GEMMs [%d x 1024]x[1024 x 1024]: Winograd F(%dx%d,3x3) stage of the 1024->1024 3x3 "
+               "ResnetBlock conv @%dx%d" % (npos, ntile, wm, wm, hb, wb)
+             if use_wino else
+             "conv_igemm_kernel<128x128,fp32 32x32x2,reflect,stats> 1024->1024 3x3 @%dx%d" % (hb, wb))
+    roofline = {"bound": "mfma", "kernel": kname,
+                "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+                "traffic_source": ("profiles/pmc_summary.json (separate rocprofv3 --pmc passes of this launch: "
+                                   "2*FETCH_SIZE + WRITE_SIZE, bytes per launch; not measured by this run)"
+                                   if traffic is not None else None),
+                "ms_per_launch": round(k_ms, 4), "gflop_per_launch": round(k_flop / 1e9, 2),
+                "flops_counted": "executed MFMA FLOPs of the launch" if use_wino else "algorithmic conv FLOPs",
+                "layer": {"algo": "winograd_f%dx%d_3x3" % (wm, wm) if use_wino else "direct", "ms_per_conv": round(conv_ms, 4),
+                          "algorithmic_gflop": round(conv_flop / 1e9, 2),
+                          "algorithmic_tflops": round(conv_flop / (conv_ms * 1e-3) / 1e12, 2)}}
+    return roofline
+
+
+def build_models(dev, flow, scales):
+    """configs[1] / configs[3] generators with seeded random-init weights -> (Vid2VidModelG, [state dicts])"""
+    from text2video_amd.generator import GeneratorSpec, HipGenerator, Vid2VidModelG, synthetic_state_dict
+    spec = GeneratorSpec(ngf=128, n_downsample=3, n_blocks=9, no_flow=not flow, norm="batch")
+    sd = synthetic_state_dict(spec, seed=1, flow_gain=0.1)
+    nets, sds = [HipGenerator(spec, dev).load_state_dict(sd)], [sd]
+    if scales == 2:
+        spec1 = GeneratorSpec(ngf=64, n_blocks=3, no_flow=not flow, norm="batch", is_local=True, scale=1)
+        sd1 = synthetic_state_dict(spec1, seed=2, flow_gain=0.1)
+        nets.append(HipGenerator(spec1, dev).load_state_dict(sd1))
+        sds.append(sd1)
+    return Vid2VidModelG(nets), sds
+
+
+def time_frames(model, dev, H, W, K, Wm, seed=0):
+    """The headline's step (window packing from resident uint8 maps -> generator -> FIFO shift -> tensor2im) for ONE
+    sequence on this process's GPU, no collectives: Wm untimed frames, K timed ones -> seconds."""
+    from text2video_amd import ops
+    from text2video_amd.generator import Recurrence
+    poses = torch.from_numpy(synthetic_pose_u8(K + Wm + 2, H, W, seed)).to(dev)
+    window = torch.zeros(H, W, 12, dtype=torch.float32, device=dev)
+    frames = torch.empty(K, H, W, 4, dtype=torch.uint8, device=dev)
+    st = [Recurrence()]
+
+    def step(t, slot):
+        for f in range(3):
+            ops.pose_u8_to_f32(poses[t + f], window, 3 * f)
+        u8 = ops.tensor2im_u8(model.inference_nhwc_batch([window], st)[0])
+        if slot is not None:
+            frames[slot].copy_(u8)
+    for t in range(Wm):
+        step(t, None)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for t in range(K):
+        step(Wm + t, t)
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0
+
+
+def hires_block(dev, K, Wm, iters):
+    """BASELINE configs[3]: 1024x1024 frames, single-scale G0@1024^2 and the two-scale G0@512^2 + local enhancer G1@1024^2
+    (16 frames), flow / no flow, + the GEMM stage of the single-scale generator timed live."""
+    out = {"workload": "configs[3]: loadSize 1024 / fineSize 1024, %d frames after %d warm-up, 1 GPU" % (K, Wm)}
+    for scales, name in ((1, "single_scale"), (2, "two_scale")):
+        blk = {}
+        for flow in (True, False):
+            model, sds = build_models(dev, flow, scales)
+            el = time_frames(model, dev, 1024, 1024, K, Wm, seed=7)
+            gf = (gflop_per_frame(512, 512, flow) + local_gflop_per_frame(1024, 1024, flow)) if scales == 2 \
+                else gflop_per_frame(1024, 1024, flow)
+            key = "flow" if flow else "noflow"
+            blk[key + "_fps"] = round(K / el, 2)
+            blk[key + "_ms"] = round(1e3 * el / K, 2)
+            blk[key + "_algorithmic_tflops"] = round(K / el * gf / 1e3, 1)
+            if flow and scales == 1:
+                r = gemm_stage_roofline(dev, sds[0], 1024, 1024, iters)
+                blk["gemm_stage"] = {k: r[k] for k in ("kernel", "ms_per_launch", "gflop_per_launch", "achieved", "frac")}
+            del model, sds
+            torch.cuda.empty_cache()
+        out[name] = blk
+    return out
+
+
+def train_block(dev, dist_mod, world, rank, backend, steps, iters):
+    """BASELINE configs[4], the work of ONE GPU: Vid2VidTrainer.train_step on 2 frames of 512x512 (max_frames_per_gpu 2, one
+    sequence per GPU), generator WITH its flow branch + 2-scale PatchGAN D + face D, LSGAN + feature matching + flow / warp /
+    weight losses against the zero reference flow, --no_vgg, fused Adam, bucketed gradient exchange (SURVEY 8d config 5;
+    /root/reference/README.md:171-176).  The exchange is timed as step_with - step_without on the process group that is up
+    (world > 1: the real RCCL all-reduce; one GPU: a 1-rank RCCL group, i.e. the collective's launch and device-copy cost
+    without any wire time)."""
+    import torch.distributed as dist
+    from text2video_amd import ops
+    from text2video_amd import train as T
+    from text2video_amd.options import TrainOptions
+    own_group = False
+    if not (dist.is_available() and dist.is_initialized()):
+        from text2video_amd import launch
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(launch.free_port())
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        own_group = True
+    os.environ["T2V_TRAIN_FORCE_DIST"] = "1"      # GradBuckets: run the collectives on a 1-rank group as well
+    H = W = 512
+    F = 2
+    opt = TrainOptions().parse(["--name", "bench", "--dataset_mode", "pose", "--input_nc", "3", "--openpose_only", "--num_D", "2",
+                                "--max_frames_per_gpu", str(F), "--n_scales_temporal", "0", "--no_first_img", "--fineSize", str(H),
+                                "--no_vgg", "--add_face_disc"])
+    tr = T.Vid2VidTrainer(opt, str(dev), seed=1)
+    rng = np.random.default_rng(100 + rank)        # every rank its own clip
+    pose = torch.zeros(F, H, W, 12, device=dev)
+    pose[..., :9] = torch.from_numpy(np.where(rng.random((F, H, W, 1)) < 0.02, rng.uniform(-1, 1, (F, H, W, 9)), -1.0)
+                                     .astype(np.float32)).to(dev)
+    real = torch.zeros(F, H, W, 4, device=dev)
+    real[..., :3] = torch.tanh(torch.from_numpy(rng.standard_normal((F, H, W, 3)).astype(np.float32))).to(dev)
+    real_prev = torch.cat([real[1:], real[:1]], 0).contiguous()
+    side = max(8, H // 32 * 8)
+    boxes = [(H // 8, H // 8 + side, (W - side) // 2, (W - side) // 2 + side)] * F
+    prev = torch.zeros(1, H, W, 8, device=dev)
+    prev[..., :6] = torch.tanh(torch.from_numpy(rng.standard_normal((1, H, W, 6)).astype(np.float32))).to(dev)
+
+    def timed(n, exchange):
+        tr.bucketsG.exchange = tr.bucketsD.exchange = exchange
+        for _ in range(2):
+            tr.train_step(pose, real, boxes, prev.clone(), real_prev=real_prev)
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            losses = tr.train_step(pose, real, boxes, prev.clone(), real_prev=real_prev)[0]
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([el], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            el = float(tmax.item())
+        return 1e3 * el / n, losses
+
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):          # (the zero-reference-flow warning)
+        ms_with, losses = timed(steps, True)
+    nbytes, nbuckets = tr.comm_bytes, len(tr.bucketsG.bounds) + len(tr.bucketsD.bounds)
+    in_sync = None
+    if world > 1:     # same seed, same averaged gradients: the replicas' weights must still be equal
+        chk = torch.stack([p.detach().double().sum() for p in tr.optG.params + tr.optD.params]).sum().reshape(1)
+        if backend != "nccl":
+            chk = chk.cpu()
+        allc = [torch.zeros_like(chk) for _ in range(world)]
+        dist.all_gather(allc, chk)
+        in_sync = all(float(c) == float(allc[0]) for c in allc)
+    ms_without, _ = timed(steps, False)     # (after the checksum: without the exchange the replicas drift apart)
+    block = None
+    if rank == 0:
+        # ---- the step's heaviest kernels, live (HIP events on the launch stream), on the FLOPs they execute ----
+        def ev_time(fn):
+            for _ in range(16):
+                fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / iters
+        C = 1024
+        desc = ops.conv_desc(64, 64, C, C, 3, 1, 1, ops.PAD_REFLECT)
+        kernels = []
+        if ops.backward_weight_winograd_supported(desc, C, C):
+            ws = ops.backward_weight_winograd_workspace(desc, C, F, dev)
+            ops.conv2d_backward_weight_winograd_stages(torch.randn(F, 64, 64, C, device=dev), torch.randn(F, 64, 64, C, device=dev),
+                                                       desc, ws, F, 0, False)
+            dw = torch.empty(C, C, 3, 3, device=dev)
+            ms = ev_time(lambda: ops.conv2d_backward_weight_winograd_reduce(desc, ws, F, C, C, out=dw))
+            gf = 2.0 * 36 * F * 256 * C * C / 1e9
+            kernels.append({"kernel": "wino_wgrad_sk_kernel + filter transform back: Winograd-domain weight gradient of a 1024->1024 "
+                                      "ResnetBlock conv over the step's %d frames (36 per step)" % F,
+                            "ms_per_launch": round(ms, 4), "gflop_per_launch": round(gf, 2),
+                            "achieved": round(gf / ms, 2), "frac": round(gf / ms / PEAK_FP32_MFMA_TFLOPS, 4)})
+        for name, (h, w, ci, co, st, tr_) in (("down 512->1024 3x3 s2 @128x128", (128, 128, 512, 1024, 2, False)),
+                                              ("up 1024->512 convT 3x3 s2 @64x64", (64, 64, 1024, 512, 2, True))):
+            d = ops.conv_desc(h, w, ci, co, 3, st, 1, ops.PAD_ZERO, tr_)
+            ho, wo = ops.conv_out_dims(d)
+            x, dy = torch.randn(1, h, w, ci, device=dev), torch.randn(1, ho, wo, co, device=dev)
+            ms = ev_time(lambda: ops.conv2d_backward_weight(x, dy, d))
+            gf = 2.0 * 9 * ci * co * (h * w if tr_ else ho * wo) / 1e9
+            kernels.append({"kernel": "conv_wgrad_kernel (direct weight gradient, split partials + combine): " + name,
+                            "ms_per_launch": round(ms, 4), "gflop_per_launch": round(gf, 2),
+                            "achieved": round(gf / ms, 2), "frac": round(gf / ms / PEAK_FP32_MFMA_TFLOPS, 4)})
+        block = {"workload": "configs[4] per-GPU work: 512x512, max_frames_per_gpu 2, G (flow branch) + D (num_D 2) + face D, "
+                             "--no_vgg, zero reference flow, Adam; batch = 1 sequence per GPU x %d GPU(s)" % world,
+                 "ms_per_step": round(ms_with, 2), "steps": steps, "warmup": 2,
+                 "exchange": {"group": "%d-rank %s" % (world, "rccl" if backend == "nccl" or own_group else backend),
+                              "ms_per_step_with": round(ms_with, 2), "ms_per_step_without": round(ms_without, 2),
+                              "ms": round(ms_with - ms_without, 2), "bytes": int(nbytes), "buckets": nbuckets,
+                              "collective": "reduce_scatter+all_gather" if tr.bucketsG.rs_ag else "all_reduce(avg)",
+                              "replicas_in_sync": in_sync},
+                 "losses": {k: round(float(v), 4) for k, v in losses.items()},
+                 "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
+                 "kernels": kernels,
+                 "note": "the forward / data-gradient GEMM stage of the step is the headline `roofline` kernel"}
+    del tr
+    torch.cuda.empty_cache()
+    if own_group:
+        dist.destroy_process_group()
+    return block
+
+
 def run_e2e(model_head, model_other, head_flow, n_frames):
     """The drop-in test.py path end to end: a dataset in the layout the reference's L2 driver writes (OpenPose JSONs
     + skeleton jpgs; the committed fadg0 keypoint fixtures, cycled), rasterised by the pose-dataset worker pool ->
@@ -156,7 +444,7 @@ def run_e2e(model_head, model_other, head_flow, n_frames):
     from text2video_amd.options import TestOptions
     src = os.path.join(ROOT, "tests", "golden", "keypoints_fadg0")
     files = sorted(f for f in os.listdir(src) if f.startswith("sa1_"))
-    out = []
+    out, meta = [], {}
     models = {head_flow: model_head}
     if model_other is not None:
         models[not head_flow] = model_other
@@ -205,12 +493,12 @@ def run_e2e(model_head, model_other, head_flow, n_frames):
                 from text2video_amd.pose_dataset import default_pose_workers
                 workers = opt.pose_workers if opt.pose_workers is not None else default_pose_workers()
                 out.append({"geometry": geom, "flow": flow, "fps": round(stats["fps_loop"], 2), "frames": stats["frames"],
-                            "sequences": len(seqs), "batch_sequences": opt.batch_sequences,
-                            "pose_workers": workers, "rasteriser": "bit-exact (curve_fit) mode"})
+                            "sequences": len(seqs), "batch_sequences": opt.batch_sequences})
+                meta["pose_workers"] = workers
         finally:
             shutil.rmtree(tmp, ignore_errors=True)
-    return {"path": "text2video_amd.model.run_test == vid2vid/test.py: rasterise -> H2D -> generator -> D2H -> JPEG",
-            "runs": out}
+    return dict({"path": "text2video_amd.model.run_test == vid2vid/test.py: rasterise -> H2D -> generator -> D2H -> JPEG",
+                 "rasteriser": "bit-exact (curve_fit) mode", "runs": out}, **meta)
 
 
 def main():
@@ -229,6 +517,10 @@ def main():
                     help="2 = config 4's two-scale generator: G0 at H/2 x W/2 + local enhancer G1 at H x W")
     ap.add_argument("--cpu-frames", type=int, default=3, help="frames of the CPU-oracle baseline (0 = skip)")
     ap.add_argument("--kernel-iters", type=int, default=40)
+    ap.add_argument("--hires-frames", type=int, default=16,
+                    help="frames per 1024x1024 run of the `hires` block (configs[3]; 0 = skip; default geometry, 1 GPU only)")
+    ap.add_argument("--train-steps", type=int, default=5,
+                    help="timed optimiser steps of the `train_step` block (configs[4] per-GPU work; 0 = skip; default geometry only)")
     ap.add_argument("--batch-variants", type=lambda v: [int(x) for x in v.split(",") if x], default=[2, 4],
                     help="lock-step batch sizes timed in addition to the headline (config.variants.batch<N>_fps)")
     args = ap.parse_args()
@@ -259,21 +551,12 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     from text2video_amd import ops
-    from text2video_amd.generator import GeneratorSpec, HipGenerator, Vid2VidModelG, synthetic_state_dict
-
     H, W, K, Wm = args.height, args.width, args.steps, args.warmup
     head_flow = args.variant == "flow"
+    default_geometry = (H, W, args.scales) == (512, 512, 1)
 
     def build(flow):
-        spec = GeneratorSpec(ngf=128, n_downsample=3, n_blocks=9, no_flow=not flow, norm="batch")
-        sd = synthetic_state_dict(spec, seed=1, flow_gain=0.1)
-        nets, sds = [HipGenerator(spec, dev).load_state_dict(sd)], [sd]
-        if args.scales == 2:
-            spec1 = GeneratorSpec(ngf=64, n_blocks=3, no_flow=not flow, norm="batch", is_local=True, scale=1)
-            sd1 = synthetic_state_dict(spec1, seed=2, flow_gain=0.1)
-            nets.append(HipGenerator(spec1, dev).load_state_dict(sd1))
-            sds.append(sd1)
-        return Vid2VidModelG(nets), sds
+        return build_models(dev, flow, args.scales)
 
     nposes = K + Wm + 2
     poses = torch.from_numpy(synthetic_pose_u8(nposes, H, W, seed=rank)).to(dev)   # resident in HBM
@@ -361,97 +644,8 @@ def main():
             def gflops(flow):
                 return gflop_per_frame(H, W, flow)
         gf = gflops(head_flow)
-        # ---- dominant kernel, timed live with HIP events on the stream it is launched on ----
-        # The 1024->1024 3x3 ResnetBlock conv (28 per frame, 84 % of the algorithmic FLOPs) runs as Winograd
-        # F(4x4,3x3) [F(2x2,3x3)]: input transform -> 36 [16] batched GEMMs [T x 1024] x [1024 x 1024] on the
-        # implicit-GEMM kernel -> output transform.  The GEMM launch is the dominant kernel; its roofline is
-        # priced on the MFMA FLOPs it EXECUTES (2*36*T*C*C = 1/4 [4/9] of the direct conv's algorithmic
-        # 2*9*C*C*H*W), never on the direct-conv-equivalent figure.  Where the geometry has no Winograd path the direct kernel is timed.
         g0h, g0w = (H // 2, W // 2) if args.scales == 2 else (H, W)   # G0 runs on the half-resolution pyramid level
-        C, hb, wb = 1024, g0h // 8, g0w // 8
-        direct = ops.conv_desc(hb, wb, C, C, 3, 1, 1, ops.PAD_REFLECT)
-        # same selection as the generator (generator.hip enumerate_layers): F(4x4,3x3) > F(2x2,3x3) > direct
-        cap = int(os.environ.get("T2V_CONV_ALGO", "0"))
-        algo = ops.ALGO_DIRECT
-        if cap == 0 and ops.winograd_supported(direct, C, ops.ALGO_WINOGRAD_F4):
-            algo = ops.ALGO_WINOGRAD_F4
-        elif cap in (0, 2) and ops.winograd_supported(direct, C, ops.ALGO_WINOGRAD):
-            algo = ops.ALGO_WINOGRAD
-        use_wino = algo != ops.ALGO_DIRECT
-        wm = 4 if algo == ops.ALGO_WINOGRAD_F4 else 2
-        npos, ntile = (wm + 2) ** 2, (hb // wm) * (wb // wm)
-        desc = ops.conv_desc(hb, wb, C, C, 3, 1, 1, ops.PAD_REFLECT, algo=algo) if use_wino else direct
-        # inputs as the kernel sees them in a frame: conv1 of a ResnetBlock reads the residual stream
-        # (dense, signed), conv2 reads a ReLU output (half zeros) -- alternate the two
-        xs = [torch.randn(hb, wb, C, device=dev), torch.relu(torch.randn(hb, wb, C, device=dev))]
-        wt = ops.pack_conv_weight(sd["model_res_img.0.conv_block.1.weight"].to(dev), desc, C)
-        bias = sd["model_res_img.0.conv_block.1.bias"].to(dev)
-        stats = ops.conv_stats_buffer(desc, dev)
-        y = torch.empty(hb, wb, C, device=dev)
-        if use_wino:
-            wss = [ops.winograd_workspace(desc, C, dev) for _ in range(2)]
-            for i in range(2):   # transformed inputs of both kinds, one workspace each
-                ops.conv2d_winograd(xs[i], wt, bias, desc, stats=stats, out=y, workspace=wss[i], stages=1)
-
-            def launch(i, stages=2):
-                ops.conv2d_winograd(xs[i & 1], wt, bias, desc, stats=stats, out=y, workspace=wss[i & 1], stages=stages)
-        else:
-            def launch(i, stages=0):
-                ops.conv2d(xs[i & 1], wt, bias, desc, y_cs=C, stats=stats, out=y)
-        for i in range(64):   # ~35 ms: the clocks ramp back up for tens of ms after the host-side gap above
-            launch(i)
-        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
-        e0.record()
-        for i in range(args.kernel_iters):
-            launch(i)
-        e1.record()
-        for i in range(args.kernel_iters):   # the whole conv (all three stages / the direct kernel)
-            launch(i, 7)
-        e2.record()
-        torch.cuda.synchronize()
-        k_ms = e0.elapsed_time(e1) / args.kernel_iters
-        conv_ms = e1.elapsed_time(e2) / args.kernel_iters
-        conv_flop = 2.0 * 9 * C * C * hb * wb                       # algorithmic (direct-conv) FLOPs of the layer
-        k_flop = 2.0 * npos * ntile * C * C if use_wino else conv_flop
-        achieved = k_flop / (k_ms * 1e-3) / 1e12
-        traffic = None
-        # the fixed-grid form of the F(4x4) GEMM stage (conv_igemm.hip: wino_gemm_sk_ok -- same rule restated here for the
-        # label only): whole 128-row tiles, at least one round of the 512 resident blocks, a badly filled last round or exactly
-        # half a round left over
-        trows = ops.winograd_tile_rows(desc) if algo == ops.ALGO_WINOGRAD_F4 else 0     # tile rows per position, padded
-        sk_tiles = npos * (trows // 128) * (C // 128) if (trows and trows % 128 == 0) else \
-            (npos * (trows // 192) * (C // 64) if (trows and trows % 192 == 0) else 0)      # 128x128 | 192x64 tiles
-        fixed_grid = bool(sk_tiles >= 512 and (sk_tiles * 100 <= -(-sk_tiles // 512) * 512 * 85 or 2 * (sk_tiles % 512) == 512)
-                          and os.environ.get("T2V_WINO_GEMM_SK", "1") != "0")
-        prof = os.path.join(ROOT, "profiles", "pmc_summary.json")
-        if os.path.exists(prof):
-            try:
-                traffic = json.load(open(prof)).get({0: "conv_igemm_rb_hbm_bytes_per_launch",
-                                                     1: "winograd_f2_gemm_hbm_bytes_per_launch",
-                                                     2: ("winograd_f4_gemm_sk_hbm_bytes_per_launch" if fixed_grid else
-                                                         "winograd_f4_gemm_hbm_bytes_per_launch")}[algo]
-                                                    if (hb, wb) == (64, 64) else "-")
-            except Exception:
-                traffic = None
-        kname = (("wino_gemm_sk_kernel<%s tiles on a fixed grid of 2 blocks per CU,fp32 32x32x2>"
-                  % ("128x128" if trows % 128 == 0 else "192x64")
-                  if fixed_grid else "conv_igemm_kernel<%s,fp32 32x32x2>"
-                  % ("128x128" if npos * ntile // 128 * 8 >= 0.8 * 256 * -(-(npos * ntile // 128 * 8) // 256) else "64x64"))
-                 + " as %d batched GEMMs [%d x 1024]x[1024 x 1024]: Winograd F(%dx%d,3x3) stage of the 1024->1024 3x3 "
-                   "ResnetBlock conv @%dx%d" % (npos, ntile, wm, wm, hb, wb)
-                 if use_wino else
-                 "conv_igemm_kernel<128x128,fp32 32x32x2,reflect,stats> 1024->1024 3x3 @%dx%d" % (hb, wb))
-        roofline = {"bound": "mfma", "kernel": kname,
-                    "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
-                    "traffic_source": ("profiles/pmc_summary.json (separate rocprofv3 --pmc passes of this launch: "
-                                       "2*FETCH_SIZE + WRITE_SIZE, bytes per launch; not measured by this run)"
-                                       if traffic is not None else None),
-                    "ms_per_launch": round(k_ms, 4), "gflop_per_launch": round(k_flop / 1e9, 2),
-                    "flops_counted": "executed MFMA FLOPs of the launch" if use_wino else "algorithmic conv FLOPs",
-                    "layer": {"algo": "winograd_f%dx%d_3x3" % (wm, wm) if use_wino else "direct", "ms_per_conv": round(conv_ms, 4),
-                              "algorithmic_gflop": round(conv_flop / 1e9, 2),
-                              "algorithmic_tflops": round(conv_flop / (conv_ms * 1e-3) / 1e12, 2)}}
+        roofline = gemm_stage_roofline(dev, sd, g0h, g0w, args.kernel_iters)
         # ---- CPU baseline: the oracle on this box's host cores, bounded sample ----
         cpu = None
         if args.cpu_frames > 0 and world == 1:   # reported at N=1 only (rank 0)
@@ -541,6 +735,14 @@ def main():
                        "variants": variants},
             "roofline": roofline, "cpu_baseline": cpu, "e2e": e2e, "box": sampler.summary(),
         }
+        if args.hires_frames > 0 and world == 1 and default_geometry:
+            result["hires"] = hires_block(dev, args.hires_frames, 4, args.kernel_iters)
+    if args.train_steps > 0 and default_geometry:
+        del model, other
+        torch.cuda.empty_cache()
+        train = train_block(dev, dist, world, rank, backend, args.train_steps, args.kernel_iters)
+        if rank == 0:
+            result["train_step"] = train
     if dist:
         dist.barrier()
         dist.destroy_process_group()

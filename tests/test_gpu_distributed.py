@@ -21,12 +21,20 @@ def test_bench_runs_its_rccl_path_on_one_rank():
     env = dict(os.environ, CUDA_VISIBLE_DEVICES="0", T2V_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533",
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2",
-                        "--cpu-frames", "0", "--kernel-iters", "2", "--e2e-frames", "0", "--single-variant"],
+                        "--cpu-frames", "0", "--kernel-iters", "2", "--e2e-frames", "0", "--single-variant",
+                        "--hires-frames", "0", "--train-steps", "2"],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 1 and d["value"] > 30.0 and d["config"]["parallelism"] == "sequence-chunk dp1"
     assert d["config"]["collectives"] == "rccl"
+    # the configs[4] block: a whole train step at 512x512 with the bucketed exchange on the 1-rank RCCL group, timed with and
+    # without the collectives; all of G's and D's gradient bytes went through them
+    t = d["train_step"]
+    assert t["steps"] == 2 and 20.0 < t["ms_per_step"] < 2000.0 and t["exchange"]["group"] == "1-rank rccl"
+    assert t["exchange"]["bytes"] > 1.3e9 and t["exchange"]["buckets"] >= 20
+    assert abs(t["exchange"]["ms"] - (t["exchange"]["ms_per_step_with"] - t["exchange"]["ms_per_step_without"])) < 0.02
+    assert len(t["kernels"]) == 3 and all(0.05 < k["frac"] < 1.0 for k in t["kernels"])
 
 
 def _rccl_worker(tmp):
@@ -256,13 +264,18 @@ def test_bench_two_ranks_on_one_gpu_contract():
     env = dict(os.environ, CUDA_VISIBLE_DEVICES="0", T2V_DIST_BACKEND="gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29561", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
-           "--kernel-iters", "2", "--single-variant"]
+           "--kernel-iters", "2", "--single-variant", "--train-steps", "1"]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 6 and d["scaling"] == "weak" and d["cpu_baseline"] is None and d["e2e"] is None
+    assert "hires" not in d                                          # (N = 1 only)
+    # configs[4] with N = 2: every rank its own clip, the real gradient all-reduce between them, replicas still equal
+    t = d["train_step"]
+    assert t["exchange"]["group"] == "2-rank gloo" and t["exchange"]["replicas_in_sync"] is True
+    assert t["exchange"]["bytes"] > 1.3e9
     assert d["config"]["parallelism"] == "sequence-chunk dp2" and d["config"]["collectives"] == "gloo"
     assert abs(d["value"] - 2 * 1e3 / d["ms_per_step"]) <= 0.01 * d["value"]      # 2 ranks x K frames / max-over-ranks time
     assert d["value"] > 30.0
@@ -280,7 +293,7 @@ def test_plain_bench_command_self_launches_two_ranks():
     """`python3 bench.py --gpus 2 --steps 6` exactly as the driver types it for N = 1 -- no torchrun: bench.py spawns the
     two ranks itself (text2video_amd/launch.py; both on this GPU over gloo here) and rank 0 prints the ONE JSON line."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
-                        "--kernel-iters", "2", "--single-variant"], cwd=ROOT, env=_plain_env(), capture_output=True,
+                        "--kernel-iters", "2", "--single-variant", "--train-steps", "0"], cwd=ROOT, env=_plain_env(), capture_output=True,
                        text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]

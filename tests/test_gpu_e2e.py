@@ -236,7 +236,8 @@ def test_bench_contract_line():
     import json
     env = dict(os.environ, CUDA_VISIBLE_DEVICES="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2",
-                        "--cpu-frames", "1", "--kernel-iters", "4", "--e2e-frames", "12"], cwd=ROOT, env=env,
+                        "--cpu-frames", "1", "--kernel-iters", "4", "--e2e-frames", "12", "--hires-frames", "3", "--train-steps", "2"],
+                       cwd=ROOT, env=env,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -265,7 +266,7 @@ def test_bench_contract_line():
     # end to end through the drop-in test.py frame loop (pose JSONs -> JPEG files)
     runs = d["e2e"]["runs"]
     assert {r["geometry"].split(" ")[0].rstrip(",") for r in runs} == {"512x512", "512x680", "512x320"}
-    assert all(r["frames"] == 12 and r["fps"] > 0 and r["pose_workers"] >= 1 for r in runs)
+    assert all(r["frames"] == 12 and r["fps"] > 0 for r in runs) and d["e2e"]["pose_workers"] >= 1
     # the two-sequence dataset (tmp + tmp_smooth, as the reference's L2 driver writes it), one at a time and in lock-step
     assert sorted(r["batch_sequences"] for r in runs if r["sequences"] == 2) == [1, 1, 2, 2]      # at 512x512 and at the reference's 512x320
     # N independent sequences per GPU in lock-step: aggregate rates beside the single-sequence headline
@@ -274,6 +275,22 @@ def test_bench_contract_line():
     box = d["box"]
     assert box["host"] and "sclk_mhz_mean" in box and (box["sclk_mhz_mean"] is None or 500 < box["sclk_mhz_mean"] < 3500)
     assert rf["traffic"] is None or "pmc_summary.json" in rf["traffic_source"]
+    # BASELINE configs[3]: 1024x1024 frames, single-scale and two-scale generator, both variants, + the GEMM stage at that size
+    hi = d["hires"]
+    for name in ("single_scale", "two_scale"):
+        assert hi[name]["noflow_fps"] > hi[name]["flow_fps"] > 5.0, hi
+    assert hi["two_scale"]["flow_fps"] > hi["single_scale"]["flow_fps"]
+    g = hi["single_scale"]["gemm_stage"]
+    assert g["kernel"].endswith("@128x128") and 0.3 < g["frac"] <= 1.0 and abs(g["achieved"] - g["gflop_per_launch"] / g["ms_per_launch"]) <= 0.02 * g["achieved"]
+    # BASELINE configs[4], one GPU's work: ms per optimiser step, the exchange as step_with - step_without + bytes + buckets,
+    # the step's heaviest kernels against the fp32 MFMA peak
+    t = d["train_step"]
+    assert "configs[4]" in t["workload"] and t["steps"] == 2 and 20.0 < t["ms_per_step"] < 2000.0
+    ex = t["exchange"]
+    assert ex["group"] == "1-rank rccl" and ex["bytes"] > 1.3e9 and ex["buckets"] >= 20 and ex["replicas_in_sync"] is None
+    assert abs(ex["ms"] - (ex["ms_per_step_with"] - ex["ms_per_step_without"])) < 0.02
+    assert len(t["kernels"]) == 3 and all(0.05 < k["frac"] < 1.0 for k in t["kernels"])
+    assert all(np.isfinite(v) for v in t["losses"].values()) and "G_GAN" in t["losses"] and "D_f" in t["losses"]
 
 
 def test_lockstep_sequences_write_the_same_files_as_one_at_a_time(tmp_path):
