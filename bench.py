@@ -501,6 +501,64 @@ def run_e2e(model_head, model_other, head_flow, n_frames):
                  "rasteriser": "bit-exact (curve_fit) mode", "runs": out}, **meta)
 
 
+def cold_start_block(n_maps=87):
+    """The reference starts one process per utterance (text2video_audio.sh:37-44: `cd ../vid2vid; python test.py ...`): the
+    wall time of exactly that command on the configs[0] utterance -- two sequences (tmp, tmp_smooth) of 87 pose maps = 2 x 85
+    frames, 512x384 sources -> scaleHeight 512 + central crop = 512x320, full-size generator with its flow branch read from a
+    1.46 GB latest_net_G0.pth -- measured from outside (subprocess), twice, with the split the process reports itself
+    (--timing_json)."""
+    import shutil
+    import subprocess
+    import tempfile
+    from PIL import Image
+    from text2video_amd.generator import GeneratorSpec, synthetic_state_dict
+    from text2video_amd.keypoints import read_keypoints
+    src = os.path.join(ROOT, "tests", "golden", "keypoints_fadg0")
+    files = sorted(f for f in os.listdir(src) if f.startswith("sa1_"))
+    tmp = tempfile.mkdtemp(prefix="t2v_cold_")
+    try:
+        root = os.path.join(tmp, "datasets", "fadg0")
+        img = Image.fromarray(read_keypoints(os.path.join(src, files[0]), (512, 384)))
+        for q, (seq, stem) in enumerate((("tmp", "%04d.jpg"), ("tmp_smooth", "smooth_%04d.jpg"))):
+            os.makedirs(os.path.join(root, "test_openpose", seq))
+            os.makedirs(os.path.join(root, "test_img", seq))
+            for i in range(n_maps):
+                shutil.copyfile(os.path.join(src, files[(i + 7 * q) % len(files)]),
+                                os.path.join(root, "test_openpose", seq, "%05d.json" % i))
+                img.save(os.path.join(root, "test_img", seq, stem % i))
+        os.makedirs(os.path.join(tmp, "ckpt", "fadg0"))
+        spec = GeneratorSpec(ngf=128, n_downsample=3, n_blocks=9, no_flow=False, norm="batch")
+        torch.save(synthetic_state_dict(spec, seed=1, flow_gain=0.1), os.path.join(tmp, "ckpt", "fadg0", "latest_net_G0.pth"))
+        tj = os.path.join(tmp, "timing.json")
+        cmd = [sys.executable, os.path.join(ROOT, "vid2vid", "test.py")] + \
+            ("--name fadg0 --dataroot %s --dataset_mode pose --input_nc 3 --resize_or_crop scaleHeight --loadSize 512 "
+             "--openpose_only --how_many 1200 --no_first_img --random_drop_prob 0 --results_dir %s --checkpoints_dir %s "
+             "--timing_json %s" % (root, os.path.join(tmp, "results"), os.path.join(tmp, "ckpt"), tj)).split()
+        env = dict(os.environ)
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k, None)
+        walls, split = [], None
+        for _ in range(2):
+            shutil.rmtree(os.path.join(tmp, "results"), ignore_errors=True)
+            t0 = time.perf_counter()
+            r = subprocess.run(cmd, cwd=os.path.join(ROOT, "vid2vid"), env=env, stdout=subprocess.DEVNULL,
+                               stderr=subprocess.PIPE, text=True)
+            walls.append(round(time.perf_counter() - t0, 3))
+            if r.returncode != 0:
+                return {"error": r.stderr[-400:]}
+            split = json.load(open(tj))
+        cs = split["cold_start"]
+        return {"command": "python vid2vid/test.py <text2video_audio.sh:42 flags>, one process per utterance",
+                "workload": "configs[0]-shaped: tmp + tmp_smooth, 2 x %d frames 512x320, flow generator from a %.2f GB checkpoint"
+                            % (n_maps - 2, os.path.getsize(os.path.join(tmp, "ckpt", "fadg0", "latest_net_G0.pth")) / 1e9),
+                "frames": split["frames"], "wall_s": walls, "split_of_last_run": cs,
+                "wall_over_loop": round(walls[-1] / max(cs["loop_s"], 1e-9), 2),
+                "to_last_jpeg_over_loop": (round((cs["process_to_run_test_s"] + cs["to_last_jpeg_s"]) / max(cs["loop_s"], 1e-9), 2)
+                                           if cs.get("process_to_run_test_s") is not None else None)}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -517,6 +575,7 @@ def main():
                     help="2 = config 4's two-scale generator: G0 at H/2 x W/2 + local enhancer G1 at H x W")
     ap.add_argument("--cpu-frames", type=int, default=3, help="frames of the CPU-oracle baseline (0 = skip)")
     ap.add_argument("--kernel-iters", type=int, default=40)
+    ap.add_argument("--no-cold-start", action="store_true", help="skip e2e.cold_start (the test.py command as a subprocess)")
     ap.add_argument("--hires-frames", type=int, default=16,
                     help="frames per 1024x1024 run of the `hires` block (configs[3]; 0 = skip; default geometry, 1 GPU only)")
     ap.add_argument("--train-steps", type=int, default=5,
@@ -704,6 +763,8 @@ def main():
         e2e = None
         if args.e2e_frames > 0 and world == 1 and args.scales == 1:
             e2e = run_e2e(model, other, head_flow, args.e2e_frames)
+            if default_geometry and not args.no_cold_start:
+                e2e["cold_start"] = cold_start_block()
         variants = {("flow_fps" if head_flow else "noflow_fps"): round(fps, 3)}
         if other_elapsed is not None:
             variants["noflow_fps" if head_flow else "flow_fps"] = round(world * K / other_elapsed, 3)

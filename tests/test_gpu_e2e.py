@@ -275,6 +275,10 @@ def test_bench_contract_line():
     box = d["box"]
     assert box["host"] and "sclk_mhz_mean" in box and (box["sclk_mhz_mean"] is None or 500 < box["sclk_mhz_mean"] < 3500)
     assert rf["traffic"] is None or "pmc_summary.json" in rf["traffic_source"]
+    # the one-shot command as the reference starts it (a process per utterance), timed from outside, with its own split
+    cs = d["e2e"]["cold_start"]
+    assert cs["frames"] == 170 and len(cs["wall_s"]) == 2 and cs["wall_s"][-1] > cs["split_of_last_run"]["loop_s"] > 0
+    assert {"checkpoint_read_s", "weights_to_device_s", "pack_s", "first_step_s", "to_last_jpeg_s"} <= set(cs["split_of_last_run"])
     # BASELINE configs[3]: 1024x1024 frames, single-scale and two-scale generator, both variants, + the GEMM stage at that size
     hi = d["hires"]
     for name in ("single_scale", "two_scale"):

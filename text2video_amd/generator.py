@@ -189,6 +189,8 @@ class HipGenerator:
         return self
 
     def _pack(self, gd):
+        import time
+        t0 = time.perf_counter()
         n = len(self.keys)
         arr = (Layer * n)()
         keep = []
@@ -210,6 +212,7 @@ class HipGenerator:
                 arr[i].beta = self._raw[nk + ".bias"].data_ptr()
         torch.cuda.current_stream().synchronize()
         self._packed, self._layers = keep, arr
+        self.pack_seconds = getattr(self, "pack_seconds", 0.0) + time.perf_counter() - t0
 
     # -- forward ---------------------------------------------------------------------------------
     def _workspace(self, H, W, batch=1):

@@ -31,9 +31,27 @@ def generator_specs(opt):
     return specs
 
 
+def process_start_time():
+    """wall-clock time at which this process was created (for the cold-start split: the interpreter start-up and the
+    imports lie between it and the first line of run_test); None where /proc is not readable"""
+    try:
+        with open("/proc/self/stat") as fh:
+            ticks = int(fh.read().rsplit(")", 1)[1].split()[19])         # field 22: starttime, clock ticks after boot
+        with open("/proc/stat") as fh:
+            btime = next(int(l.split()[1]) for l in fh if l.startswith("btime"))
+        return btime + ticks / os.sysconf("SC_CLK_TCK")
+    except Exception:
+        return None
+
+
 def load_checkpoint(path):
-    """torch.save'd state-dict (legacy pickle stream of torch 0.4.1 included), tensors only."""
-    sd = torch.load(path, map_location="cpu", weights_only=True)
+    """torch.save'd state-dict (legacy pickle stream of torch 0.4.1 included), tensors only.  Zip-format files (what
+    save() here and every torch >= 1.6 write) are memory-mapped: the H2D copies then read straight from the page
+    cache instead of from a second host copy of the 1.5 GB file."""
+    try:
+        sd = torch.load(path, map_location="cpu", weights_only=True, mmap=True)
+    except (RuntimeError, ValueError, TypeError):     # legacy (non-zip) stream: cannot be mapped
+        sd = torch.load(path, map_location="cpu", weights_only=True)
     if isinstance(sd, dict) and "state_dict" in sd:
         sd = sd["state_dict"]
     out = {}
@@ -45,14 +63,17 @@ def load_checkpoint(path):
     return out
 
 
-def create_model(opt, device="cuda:0"):
+def create_model(opt, device="cuda:0", marks=None):
+    marks = marks if marks is not None else {}
     if opt.fp16:
         print("warning: --fp16 ignored, the MI355X path computes in exact fp32", file=sys.stderr)
     nets = []
     for s, spec in enumerate(generator_specs(opt)):
         path = os.path.join(opt.checkpoints_dir, opt.name, "%s_net_G%d.pth" % (opt.which_epoch, s))
         if os.path.exists(path):
+            t0 = time.perf_counter()
             sd = load_checkpoint(path)
+            marks["checkpoint_read_s"] = marks.get("checkpoint_read_s", 0.0) + time.perf_counter() - t0
             has_flow = any(k.startswith("model_final_flow") for k in sd)
             if spec.no_flow and has_flow and not getattr(opt, "no_flow_explicit", False):
                 # the architecture follows the checkpoint: it was trained with the flow branch
@@ -66,7 +87,10 @@ def create_model(opt, device="cuda:0"):
             sd = synthetic_state_dict(spec, opt.synthetic_weights + s, flow_gain=0.1)
         else:
             raise FileNotFoundError("%s not found (pass --synthetic_weights SEED to run without a checkpoint)" % path)
+        t0 = time.perf_counter()
         nets.append(HipGenerator(spec, device).load_state_dict(sd))
+        torch.cuda.synchronize(device)
+        marks["weights_to_device_s"] = marks.get("weights_to_device_s", 0.0) + time.perf_counter() - t0
     return Vid2VidModelG(nets, opt.n_frames_G, opt.output_nc, opt.no_first_img)
 
 
@@ -95,10 +119,20 @@ def run_test(opt, model=None, device=None, dataset=None):
     two per utterance: tmp and tmp_smooth) advances N of them in lock-step, one batched generator call per frame
     (t2v_generator_forward_batch); the frames are those of the one-at-a-time loop, only their order of production differs."""
     t_start = time.perf_counter()
+    t_proc = process_start_time()
+    marks = {"process_to_run_test_s": (time.time() - t_proc) if t_proc is not None else None}
     if device is None:      # a plain single-device run computes on --gpu_ids[0]
         ids = getattr(opt, "gpu_ids", None)
         device = "cuda:%d" % (ids[0] if ids else 0)
+    # the rasteriser workers are fresh interpreters (numpy / scipy / PIL imports): started first, they come up while the
+    # checkpoint is read
+    from .pose_dataset import default_pose_workers
+    n_workers = opt.pose_workers if getattr(opt, "pose_workers", None) is not None else default_pose_workers()
+    if n_workers > 1:
+        from .raster_pool import get_pool
+        get_pool(n_workers)
     dataset = dataset if dataset is not None else PoseDataset(opt)
+    marks["dataset_scan_s"] = time.perf_counter() - t_start
     world = int(os.environ.get("WORLD_SIZE", "1"))
     plan = rank = None
     limit = opt.how_many
@@ -114,16 +148,43 @@ def run_test(opt, model=None, device=None, dataset=None):
         limit = None            # already applied globally
         if local_rank is not None:
             device = "cuda:%d" % local_rank
+    n_lanes = max(1, min(int(getattr(opt, "batch_sequences", 2) or 1), _lib_max_batch()))
+    # the first step's pose maps are rasterised by the pool while the model is created (checkpoint -> device)
+    first_steps = dataset.iter_lanes(n_lanes, opt.pose_workers, limit=limit)
+    primer = None
     if model is None:
-        model = create_model(opt, device)
+        import threading
+        primed = {}
+
+        def _prime():
+            try:
+                primed["step"] = next(first_steps)
+            except StopIteration:
+                primed["step"] = None
+            except BaseException as e:      # noqa: BLE001 -- re-raised in the frame loop's thread
+                primed["error"] = e
+        primer = threading.Thread(target=_prime, daemon=True)
+        primer.start()
+        t0 = time.perf_counter()
+        model = create_model(opt, device, marks)
+        marks["create_model_s"] = time.perf_counter() - t0
+
+    def primed_steps():
+        if primer is not None:
+            primer.join()
+            if "error" in primed:
+                raise primed["error"]
+            if primed["step"] is None:
+                return
+            yield primed["step"]
+        for st in first_steps:
+            yield st
     vis = Visualizer(opt)
     dev = torch.device(device)
     cs = ops.round_up(3 * opt.n_frames_G, 4)
     pinned = {}      # shape -> ring of 3 pinned host buffers (allocating pinned memory per frame costs ~0.2 ms)
     counters = {"n": 0, "t_loop0": 0.0}
     tails = {}       # unit index -> FIFO of generated frames the unit ended with (stitch pass)
-
-    n_lanes = max(1, min(int(getattr(opt, "batch_sequences", 2) or 1), _lib_max_batch()))
 
     class Lane:
         """one recurrence being advanced: its FIFO of generated frames, pose window and resident pose maps"""
@@ -151,6 +212,7 @@ def run_test(opt, model=None, device=None, dataset=None):
             for k, data in step:
                 if counters["n"] == 0 and not groups:
                     counters["t_loop0"] = time.perf_counter()
+                    marks.setdefault("to_first_step_s", counters["t_loop0"] - t_start)
                 L = lanes.setdefault(k, Lane())
                 A = data["A"]  # [tG, H, W, 3] uint8
                 H, W = A.shape[1], A.shape[2]
@@ -182,6 +244,9 @@ def run_test(opt, model=None, device=None, dataset=None):
                     now.append((ev, host, data["A_path"], _real_A_u8(data["A"][-1])))
                     print("process image... %s" % data["A_path"])
                     counters["n"] += 1
+            if "first_step_s" not in marks:       # incl. the weight pack / Winograd filter transforms of this geometry
+                torch.cuda.synchronize(dev)
+                marks["first_step_s"] = time.perf_counter() - counters["t_loop0"]
             for p in pending:
                 finish(p)
             pending = now
@@ -190,7 +255,8 @@ def run_test(opt, model=None, device=None, dataset=None):
         for L in lanes.values():
             close_unit(L)
 
-    frame_loop(dataset.iter_lanes(n_lanes, opt.pose_workers, limit=limit), tails)
+    frame_loop(primed_steps(), tails)
+    marks["loop_s"] = time.perf_counter() - counters["t_loop0"] if counters["n"] else 0.0
     n_first_pass = counters["n"]
     stitch = int(getattr(opt, "stitch_frames", 0) or 0)
     if plan is not None and stitch > 0:
@@ -213,6 +279,7 @@ def run_test(opt, model=None, device=None, dataset=None):
                     if stitch >= u[2] - u[3]:      # re-generated to its end: this chunk's tail is the new one
                         tails[j] = redone[jj]
     vis.flush()
+    marks["to_last_jpeg_s"] = time.perf_counter() - t_start
     videos = []
     if getattr(opt, "write_video", False):
         # the reference's next stage (image2video*.py, text2video_audio.sh:44) on the frames just written; under
@@ -234,7 +301,10 @@ def run_test(opt, model=None, device=None, dataset=None):
     t_end = time.perf_counter()
     n = counters["n"]
     stats = {"frames": n_first_pass, "frames_regenerated": n - n_first_pass, "seconds_total": t_end - t_start,
-             "fps_loop": n / (t_end - counters["t_loop0"]) if n else 0.0, "results_dir": vis.save_dir, "videos": videos}
+             "fps_loop": n / (t_end - counters["t_loop0"]) if n else 0.0, "results_dir": vis.save_dir, "videos": videos,
+             "cold_start": dict({k: (round(v, 4) if isinstance(v, float) else v) for k, v in marks.items()},
+                                pack_s=round(sum(getattr(net, "pack_seconds", 0.0) for net in model.nets), 4),
+                                mux_s=round(t_end - t_start - marks["to_last_jpeg_s"], 4))}
     if opt.timing_json:
         with open(opt.timing_json, "w") as fh:
             json.dump(stats, fh)
