@@ -29,13 +29,15 @@
 extern "C" {
 #endif
 
-#define T2V_ABI_VERSION 11
+#define T2V_ABI_VERSION 12
 
 typedef enum {
     T2V_OK = 0,
     T2V_ERR_INVALID = -1,   /* bad argument / unsupported shape */
     T2V_ERR_HIP = -2,       /* a HIP runtime call failed */
-    T2V_ERR_WORKSPACE = -3  /* workspace too small */
+    T2V_ERR_WORKSPACE = -3, /* workspace too small */
+    T2V_ERR_HANDOVER = -4   /* a fixed-grid kernel's accumulator hand-over timed out in an EARLIER launch: that launch's
+                             * output holds NaNs; reported once, the process then runs one block per tile */
 } t2v_status;
 
 enum { T2V_PAD_ZERO = 0, T2V_PAD_REFLECT = 1 };
@@ -58,6 +60,20 @@ int t2v_abi_version(void);
 const char* t2v_last_error(void);
 int t2v_create(t2v_ctx** out, int device);
 int t2v_destroy(t2v_ctx* ctx);
+/* The T2V_* environment switches are read once, at the first t2v_create; this reads them again.
+ * (THCUNN's counterpart are process-global flags such as torch.backends.cudnn.benchmark,
+ * $SP/torch/backends/cudnn/__init__.py:454-455.) */
+void t2v_reload_env(void);
+/* Errors a kernel can only report after the fact (THCUNN: THError out of a later synchronising call).  T2V_OK, or
+ * T2V_ERR_HANDOVER once after a fixed-grid hand-over timed out; every entry point that can launch such a kernel makes the
+ * same check first.  Callers run it after they synchronise a stream. */
+int t2v_check_async_errors(void);
+/* 1 while the fixed-grid ("stream-K") forms of the Winograd GEMM stage / weight-gradient reduction may be used: the
+ * dispatch-order self-test of t2v_create passed and no hand-over has timed out; 0: one block per tile everywhere. */
+int t2v_fixed_grid_enabled(void);
+/* Test hook: raise != 0 sets the sticky error word exactly as a timed-out consumer wave would; raise == 0 clears it and
+ * switches the fixed-grid kernels back on. */
+void t2v_debug_async_error(int raise);
 
 /* ------------------------------------------------------------------------------------------
  * Convolution.  Replaces SpatialReflectionPadding_updateOutput (THCUNN.h:952) +

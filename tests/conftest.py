@@ -32,3 +32,29 @@ def _seeded():
     torch.manual_seed(0)
     np.random.seed(0)
     yield
+
+
+@pytest.fixture
+def t2v_env():
+    """t2v_env(name, value): set a T2V_* switch for this test.  libt2v_hip.so reads its switches once (t2v_create), so
+    every change -- and the restore at the end of the test -- is followed by t2v_reload_env(); the switches train.py reads
+    from os.environ at run time see the change directly."""
+    saved = {}
+
+    def reload():
+        from text2video_amd import _lib
+        if os.path.exists(_lib.LIB_PATH):
+            _lib.load().t2v_reload_env()
+
+    def setenv(name, value):
+        saved.setdefault(name, os.environ.get(name))
+        os.environ[name] = str(value)
+        reload()
+    yield setenv
+    for name, old in saved.items():
+        if old is None:
+            os.environ.pop(name, None)
+        else:
+            os.environ[name] = old
+    if saved:
+        reload()

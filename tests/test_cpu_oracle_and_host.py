@@ -394,7 +394,7 @@ def test_direct_minpack_fit_equals_curve_fit_bit_for_bit():
     import warnings
     from scipy.optimize import curve_fit
     from text2video_amd import keypoints as K
-    assert K._MINPACK is not None
+    assert K._minpack() is not None
     rng = np.random.default_rng(0)
     n = 0
     for i in range(400):

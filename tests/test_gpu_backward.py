@@ -273,7 +273,7 @@ def test_masked_l1_and_flow_head_activation_backward():
     assert (d - want).abs().max().item() <= 1e-6
 
 
-def test_in_kernel_combine_of_split_weight_gradients_equals_the_reduce_launch(monkeypatch):
+def test_in_kernel_combine_of_split_weight_gradients_equals_the_reduce_launch(t2v_env):
     """Direct weight gradients whose pixel reduction is cut into a few ranges: the block that draws the last arrival
     ticket of a (tap, n, c) tile sums the published partials in split order inside the launch (default, <= 4 partials)
     -- bit for bit what the separate reduce launch over zero-filled slabs produces (T2V_WGRAD_COMBINE=0), run after
@@ -288,8 +288,8 @@ def test_in_kernel_combine_of_split_weight_gradients_equals_the_reduce_launch(mo
         dy = torch.randn(B, ho, wo, Cout, device="cuda:0")
         outs = {}
         for mode in ("1", "0"):
-            monkeypatch.setenv("T2V_WGRAD_COMBINE", mode)
-            monkeypatch.setenv("T2V_WGRAD_COMBINE_MAX", "64")       # also the many-partial shapes the default leaves to the reduce launch
+            t2v_env("T2V_WGRAD_COMBINE", mode)
+            t2v_env("T2V_WGRAD_COMBINE_MAX", "64")       # also the many-partial shapes the default leaves to the reduce launch
             for rep in range(2):
                 dwp = ops.conv2d_backward_weight(x, dy, desc)
                 acc = ops.conv2d_backward_weight(x, dy, desc, accumulate_into=dwp.clone())
@@ -301,7 +301,7 @@ def test_in_kernel_combine_of_split_weight_gradients_equals_the_reduce_launch(mo
 
 
 @pytest.mark.parametrize("geom", [(64, 64, 1024, 1024, 2), (64, 88, 640, 896, 2), (32, 32, 512, 488, 3)], ids=["rb1024x2", "ragged", "cout488"])
-def test_fixed_grid_winograd_domain_weight_gradient_equals_tile_per_block(geom, monkeypatch):
+def test_fixed_grid_winograd_domain_weight_gradient_equals_tile_per_block(geom, t2v_env):
     """The 36 Winograd-domain reductions dU[xi] = M_dy[xi]^T V[xi] on a fixed grid (conv_wgrad.hip: wino_wgrad_sk_kernel;
     a tile cut between two blocks is finished from the first block's accumulators) against one block per tile
     (T2V_WGRAD_SK=0): the same t-ordered MFMA chain per element, so dW is BIT-identical -- launch after launch on one
@@ -315,11 +315,11 @@ def test_fixed_grid_winograd_domain_weight_gradient_equals_tile_per_block(geom, 
     ws = ops.backward_weight_winograd_workspace(desc, Cin, B, x.device)
     ws.fill_(float("nan"))
     ops.conv2d_backward_weight_winograd_stages(x, dy, desc, ws, B, 0, False)
-    monkeypatch.setenv("T2V_WGRAD_SK", "0")
+    t2v_env("T2V_WGRAD_SK", "0")
     want = ops.conv2d_backward_weight_winograd_reduce(desc, ws, B, Cin, Cout).clone()
     base = torch.randn_like(want)
     want_acc = ops.conv2d_backward_weight_winograd_reduce(desc, ws, B, Cin, Cout, out=base.clone(), accumulate=True).clone()
-    monkeypatch.setenv("T2V_WGRAD_SK", "1")
+    t2v_env("T2V_WGRAD_SK", "1")
     for rep in range(6):
         got = ops.conv2d_backward_weight_winograd_reduce(desc, ws, B, Cin, Cout)
         assert torch.equal(got, want), "launch %d: %d of %d differ" % (rep, int((got != want).sum()), got.numel())
@@ -330,7 +330,7 @@ def test_fixed_grid_winograd_domain_weight_gradient_equals_tile_per_block(geom, 
 
 @pytest.mark.parametrize("H,W,Cin,Cout", [(32, 32, 64, 64), (16, 32, 128, 64), (64, 64, 128, 128), (64, 128, 256, 128)],
                          ids=["32x32", "16x32", "64x64", "64x128"])
-def test_transposed_winograd_data_gradient_matches_autograd(H, W, Cin, Cout, monkeypatch):
+def test_transposed_winograd_data_gradient_matches_autograd(H, W, Cin, Cout, t2v_env):
     """Data gradient of the ResnetBlock conv (3x3, ReflectionPad 1) by the transposed Winograd algorithm: A dy A^T is read out
     of the weight gradient's batch workspace (two images, both slots), dV = U^T dM on the layer's own tiles, patches
     overlap-added and folded.  Against torch autograd on the CPU (fp64) and against the full-correlation form."""
@@ -367,6 +367,6 @@ def test_transposed_winograd_data_gradient_matches_autograd(H, W, Cin, Cout, mon
     if desc.H * desc.W // 16 % 128 == 0 and Cin % 128 == 0:
         outs = {}
         for mode in ("0", "2"):
-            monkeypatch.setenv("T2V_WINO_GEMM_SK", mode)
+            t2v_env("T2V_WINO_GEMM_SK", mode)
             outs[mode] = [ops.conv2d_backward_data_winograd(desc, B, b, ws, Cin, ut).clone() for b in range(B)]
         assert all(torch.equal(a, c) for a, c in zip(outs["0"], outs["2"]))

@@ -1,8 +1,7 @@
 """N independent recurrences advanced in lock-step on one GPU (t2v_generator_forward_batch): every sequence's frames
 must be the frames the single-sequence path generates for it -- the batch only changes how the ResnetBlock chains'
 kernels are launched (image index in the transforms' grids, N x T tile rows per Winograd GEMM), never a value that
-depends on another sequence; norm statistics stay per image.  Also: the norm statistics finalized by the producing
-kernel's last block (T2V_NORM_TICKET=1) against the separate finalize launch (the default) -- bit-identical frames."""
+depends on another sequence; norm statistics stay per image."""
 import os
 
 import numpy as np
@@ -92,49 +91,6 @@ def test_batch2_frame_matches_the_oracle():
             worst = max(worst, (got - wants[i][k][0]).abs().max().item())
     print("batch 2 vs oracle: max|delta| = %.3g" % worst)
     assert worst <= 1e-3
-
-
-@pytest.mark.parametrize("name,spec_kw,scales,H,W", BATCH_CASES[:3], ids=[c[0] for c in BATCH_CASES[:3]])
-def test_producer_side_norm_finalize_is_bit_identical_to_the_finalize_launch(name, spec_kw, scales, H, W):
-    """The F(4x4) output transform's last block per (image, 64-channel group) pools the partial statistics in the
-    finalize kernel's summation order: frames with T2V_NORM_TICKET=1 and =0 (separate finalize launches, the default)
-    must be bit-identical, at batch 1 and batch 2, over a free-running sequence."""
-    from text2video_amd.generator import Recurrence
-    _, hip = _build(spec_kw, scales)
-    seqs = [_pose_seq(6, H, W, seed=30 + i) for i in range(2)]
-    runs = {}
-    old = os.environ.get("T2V_NORM_TICKET")
-    try:
-        for mode in ("1", "0"):
-            os.environ["T2V_NORM_TICKET"] = mode
-            for nb in (1, 2):
-                states = [Recurrence() for _ in range(nb)]
-                frames = []
-                for t in range(2, 6):
-                    frames.append([o.clone() for o in hip.inference_nhwc_batch([_window(seqs[i], t) for i in range(nb)], states)])
-                runs[(mode, nb)] = frames
-    finally:
-        if old is None:
-            os.environ.pop("T2V_NORM_TICKET", None)
-        else:
-            os.environ["T2V_NORM_TICKET"] = old
-    for nb in (1, 2):
-        for fa, fb in zip(runs[("1", nb)], runs[("0", nb)]):
-            for a, b in zip(fa, fb):
-                assert torch.equal(a, b), "%s batch %d: ticket finalize differs by %g" % (name, nb, (a - b).abs().max().item())
-    # repeated runs of the ticket form are deterministic (the counters are left zeroed)
-    os.environ["T2V_NORM_TICKET"] = "1"
-    try:
-        states = [Recurrence() for _ in range(2)]
-        again = [[o.clone() for o in hip.inference_nhwc_batch([_window(seqs[i], t) for i in range(2)], states)] for t in range(2, 6)]
-    finally:
-        if old is None:
-            os.environ.pop("T2V_NORM_TICKET", None)
-        else:
-            os.environ["T2V_NORM_TICKET"] = old
-    for fa, fb in zip(runs[("1", 2)], again):
-        for a, b in zip(fa, fb):
-            assert torch.equal(a, b)
 
 
 def test_batch_argument_errors():

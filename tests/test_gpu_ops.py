@@ -391,7 +391,7 @@ def test_winograd_f4_output_transform_applies_the_activation(slope):
 
 @pytest.mark.parametrize("geom", [(64, 64, 1024, 1024), (64, 88, 640, 640), (128, 128, 256, 256), (64, 128, 512, 1024),
                                   (128, 128, 512, 256), (64, 40, 1024, 1024), (64, 40, 512, 384), (128, 128, 1024, 1024)])
-def test_fixed_grid_winograd_gemm_equals_tile_per_block(geom, monkeypatch):
+def test_fixed_grid_winograd_gemm_equals_tile_per_block(geom, t2v_env):
     """The batched Winograd GEMM on a fixed grid (conv_igemm.hip: wino_gemm_sk_kernel; tiles cut between two blocks are
     finished from the first block's accumulators) against one block per tile: the same K-ordered MFMA chain per output,
     so the conv must be BIT-identical -- also launch after launch on one workspace (a stale hand-over flag or a stale L2
@@ -407,9 +407,9 @@ def test_fixed_grid_winograd_gemm_equals_tile_per_block(geom, monkeypatch):
     pu = ops.pack_conv_weight(w, desc, Cin)
     ws = ops.winograd_workspace(desc, Cin, dev)
     xs = [_rand(H, W, Cin, seed=10 + i).to(dev) for i in range(3)]
-    monkeypatch.setenv("T2V_WINO_GEMM_SK", "0")
+    t2v_env("T2V_WINO_GEMM_SK", "0")
     want = [ops.conv2d_winograd(x, pu, b, desc, workspace=ws).clone() for x in xs]
-    monkeypatch.setenv("T2V_WINO_GEMM_SK", "2")      # wherever the shape allows, not only where it is faster
+    t2v_env("T2V_WINO_GEMM_SK", "2")      # wherever the shape allows, not only where it is faster
     ws.fill_(float("nan"))
     for rep in range(12):
         x, y0 = xs[rep % 3], want[rep % 3]
@@ -420,14 +420,14 @@ def test_fixed_grid_winograd_gemm_equals_tile_per_block(geom, monkeypatch):
     assert float((_from_nhwc(want[0], Cout) - ref).abs().max()) < 2e-3 * max(1.0, float(ref.abs().max()))
 
 
-def test_fixed_grid_gemm_survives_graph_replay(monkeypatch):
+def test_fixed_grid_gemm_survives_graph_replay(t2v_env):
     """A captured launch is re-issued with the SAME kernel arguments, hand-over tag included: the consumer clears a tag it has
     taken, so a replay does not mistake the previous replay's accumulators for this one's.  Capture one Winograd conv
     (fixed-grid GEMM stage) in a HIP graph, replay it on three different inputs, compare with the eager results."""
     from text2video_amd import ops
     H, W, C = 64, 64, 1024
     dev = _dev()
-    monkeypatch.setenv("T2V_WINO_GEMM_SK", "2")
+    t2v_env("T2V_WINO_GEMM_SK", "2")
     desc = ops.conv_desc(H, W, C, C, 3, 1, 1, ops.PAD_REFLECT, algo=ops.ALGO_WINOGRAD_F4)
     w = _rand(C, C, 3, 3, seed=5, scale=0.03).to(dev)
     b = _rand(C, seed=6).to(dev)
@@ -462,3 +462,36 @@ def test_fixed_grid_kernels_race_screen_under_load():
                        timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "0 of 80 iterations differ" in r.stdout
+
+
+def test_hand_over_timeout_is_reported_once_and_switches_to_one_block_per_tile():
+    """The fixed-grid kernels' guards: the dispatch-order self-test of t2v_create passed on this box; a consumer
+    wave whose producer's tag never shows up raises a sticky error word in pinned host memory (here raised through the test
+    hook, exactly the store the wave makes): the NEXT entry point that could launch a fixed-grid kernel returns
+    T2V_ERR_HANDOVER with a message, once, and from then on the process runs one block per tile -- same bits."""
+    from text2video_amd import _lib, ops
+    dev = _dev()
+    H, W, C = 64, 64, 1024
+    desc = ops.conv_desc(H, W, C, C, 3, 1, 1, ops.PAD_REFLECT, algo=ops.ALGO_WINOGRAD_F4)
+    w = _rand(C, C, 3, 3, seed=5, scale=0.03).to(dev)
+    b = _rand(C, seed=6).to(dev)
+    x = _rand(H, W, C, seed=7).to(dev)
+    pu = ops.pack_conv_weight(w, desc, C)
+    ws = ops.winograd_workspace(desc, C, dev)
+    lib = _lib.load()
+    assert ops.fixed_grid_enabled(), "dispatch-order self-test failed on this box"
+    want = ops.conv2d_winograd(x, pu, b, desc, workspace=ws).clone()      # fixed grid (576 tiles on 512 blocks)
+    torch.cuda.synchronize()
+    ops.check_async_errors()                                               # nothing pending
+    try:
+        lib.t2v_debug_async_error(1)
+        with pytest.raises(RuntimeError, match="hand-over timed out"):
+            ops.conv2d_winograd(x, pu, b, desc, workspace=ws)
+        assert not ops.fixed_grid_enabled()
+        ops.check_async_errors()                                           # reported once
+        got = ops.conv2d_winograd(x, pu, b, desc, workspace=ws)            # one block per tile now
+        assert torch.equal(got, want)
+    finally:
+        lib.t2v_debug_async_error(0)
+    assert ops.fixed_grid_enabled()
+    assert torch.equal(ops.conv2d_winograd(x, pu, b, desc, workspace=ws), want)

@@ -191,7 +191,7 @@ def test_trainer_uses_temporal_discriminators_across_chunks(tmp_path):
     assert sorted(os.listdir(tmp_path / "x")) == ["latest_net_D.pth", "latest_net_D_T0.pth", "latest_net_D_T1.pth", "latest_net_G0.pth"]
 
 
-def test_trainer_batches_the_frames_winograd_weight_gradients(tmp_path, monkeypatch):
+def test_trainer_batches_the_frames_winograd_weight_gradients(tmp_path, monkeypatch, t2v_env):
     """The two frames of a chunk run through every ResnetBlock conv; their Winograd-domain weight gradients are
     reduced together by the backward node that runs last (one K = 2 x tiles reduction).  Same gradients as the
     frame-by-frame reductions (T2V_WGRAD_BATCH=0) up to fp32 summation order."""
@@ -212,7 +212,7 @@ def test_trainer_batches_the_frames_winograd_weight_gradients(tmp_path, monkeypa
     orig = T._batched_winograd_wgrad
     monkeypatch.setattr(T, "_batched_winograd_wgrad", lambda w, x, dc, d, *rest: (calls.append(x.shape[0]), orig(w, x, dc, d, *rest))[1])
     for mode in ("1", "0"):
-        monkeypatch.setenv("T2V_WGRAD_BATCH", mode)
+        t2v_env("T2V_WGRAD_BATCH", mode)
         tr = T.Vid2VidTrainer(TrainOptions().parse(args), "cuda:0")
         n0 = len(calls)
         tr.train_step(pose, real, None, prev.clone())
@@ -315,7 +315,7 @@ def test_trainer_adds_the_vgg_term(tmp_path):
     assert tr2.vgg is None
 
 
-def test_multi_tensor_adam_equals_the_per_tensor_kernel(monkeypatch):
+def test_multi_tensor_adam_equals_the_per_tensor_kernel(t2v_env):
     """FusedAdam.step as ONE launch over all parameter tensors (chunk table on the device) against one launch per tensor:
     identical bits -- tensors longer than a chunk, shorter than a wave, and one that has no gradient in some steps."""
     from text2video_amd import train as T
@@ -325,7 +325,7 @@ def test_multi_tensor_adam_equals_the_per_tensor_kernel(monkeypatch):
     grads = [[torch.randn(n, generator=g) * 0.1 for n in sizes] for _ in range(3)]
     outs = {}
     for mode in ("1", "0"):
-        monkeypatch.setenv("T2V_ADAM_MULTI", mode)
+        t2v_env("T2V_ADAM_MULTI", mode)
         ps = [torch.nn.Parameter(t.clone().cuda()) for t in init]
         opt = T.FusedAdam(ps, lr=1e-2)
         for s in range(3):

@@ -439,7 +439,7 @@ def test_direct_gradient_delivery_equals_autograd_accumulation_and_launches_no_a
     assert adds["0"] > 50 and adds["1"] <= adds["0"] // 2
 
 
-def test_shared_discriminator_forward_equals_the_two_forward_form(monkeypatch):
+def test_shared_discriminator_forward_equals_the_two_forward_form(t2v_env):
     """One discriminator forward on the fake frames serves D's loss (through D's parameters) and G's loss (through the
     frames, D's parameter gradients switched off for that backward pass).  Against the two-forward form upstream runs
     (T2V_D_SHARED_FWD=0: D(fake.detach()) and D(fake) with frozen parameters): the same losses, the same updated weights,
@@ -459,7 +459,7 @@ def test_shared_discriminator_forward_equals_the_two_forward_form(monkeypatch):
     boxes = [(8, 40, 40, 72)] * 2
     runs = {}
     for mode in ("1", "0"):
-        monkeypatch.setenv("T2V_D_SHARED_FWD", mode)
+        t2v_env("T2V_D_SHARED_FWD", mode)
         tr = T.Vid2VidTrainer(opt, "cuda:0", seed=17)
         l1, prev = tr.train_step(pose, real, boxes, None, real_prev=real_prev)
         l2, _ = tr.train_step(pose, real, boxes, prev, real_prev=real_prev)          # temporal windows full from here on
@@ -478,7 +478,7 @@ def test_shared_discriminator_forward_equals_the_two_forward_form(monkeypatch):
         assert n1 == n2 and torch.equal(m1, m2) and torch.equal(v1, v2)
 
 
-def test_weight_gradients_on_the_side_stream_leave_the_step_unchanged(monkeypatch):
+def test_weight_gradients_on_the_side_stream_leave_the_step_unchanged(t2v_env):
     """The weight-gradient kernels of the backward nodes run on a second stream next to the following layers' data
     gradients (train.py: wgrad_fork / wgrad_join), and so do the packed / transformed weight copies of the NEXT step
     right after the optimiser step (prefetch_packs).  Against everything on one stream (both switched off): the same
@@ -500,8 +500,8 @@ def test_weight_gradients_on_the_side_stream_leave_the_step_unchanged(monkeypatc
     boxes = [(16, 80, 32, 96)] * 2
     runs = {}
     for mode in ("1", "0"):
-        monkeypatch.setenv("T2V_WGRAD_STREAM", mode)
-        monkeypatch.setenv("T2V_PACK_PREFETCH", mode)     # (the packed weights of the next step, made on the same side stream)
+        t2v_env("T2V_WGRAD_STREAM", mode)
+        t2v_env("T2V_PACK_PREFETCH", mode)     # (the packed weights of the next step, made on the same side stream)
         tr = T.Vid2VidTrainer(opt, "cuda:0", seed=5)
         prev, ls = None, []
         for _ in range(3):
@@ -518,7 +518,7 @@ def test_weight_gradients_on_the_side_stream_leave_the_step_unchanged(monkeypatc
     assert all(torch.equal(x, y) for x, y in zip(runs["1"][1], runs["0"][1]))
 
 
-def test_train_step_with_the_fixed_grid_kernels_forced_is_bit_identical(monkeypatch):
+def test_train_step_with_the_fixed_grid_kernels_forced_is_bit_identical(t2v_env):
     """Both fixed-grid kernels (Winograd GEMM stage in the forward convs and the transposed data gradient; Winograd-domain
     weight-gradient reduction) forced on at a size whose tile counts are far below the grid -- short runs, many blocks idle,
     every tile whole or cut once -- against one block per tile: losses and updated weights bit for bit."""
@@ -536,8 +536,8 @@ def test_train_step_with_the_fixed_grid_kernels_forced_is_bit_identical(monkeypa
     real_prev = torch.cat([real[1:], real[:1]], 0).contiguous()
     runs = {}
     for mode in ("2", "0"):
-        monkeypatch.setenv("T2V_WINO_GEMM_SK", mode)
-        monkeypatch.setenv("T2V_WGRAD_SK", mode)
+        t2v_env("T2V_WINO_GEMM_SK", mode)
+        t2v_env("T2V_WGRAD_SK", mode)
         tr = T.Vid2VidTrainer(opt, "cuda:0", seed=9)
         prev, ls = None, []
         for _ in range(2):
@@ -549,33 +549,3 @@ def test_train_step_with_the_fixed_grid_kernels_forced_is_bit_identical(monkeypa
     assert all(torch.equal(x, y) for x, y in zip(runs["2"][1], runs["0"][1]))
 
 
-def test_two_stream_generator_forward_and_backward_leave_the_step_unchanged(monkeypatch):
-    """T2V_TRAIN_TWO_STREAMS=1: the previous-frame encoder and the flow branch of the trainable generator run on a second stream
-    (and autograd runs their backward there).  Same losses and updated weights, bit for bit, as on one stream, over three
-    steps (flow branch, face D, temporal D on)."""
-    from text2video_amd import train as T
-    from text2video_amd.options import TrainOptions
-    opt = TrainOptions().parse(["--name", "t", "--dataset_mode", "pose", "--input_nc", "3", "--openpose_only", "--ngf", "32",
-                                "--n_downsample_G", "2", "--n_blocks", "3", "--num_D", "2", "--ndf", "16", "--no_vgg",
-                                "--max_frames_per_gpu", "2", "--n_scales_temporal", "1", "--no_first_img", "--add_face_disc"])
-    H, W = 128, 128
-    rng = np.random.default_rng(41)
-    pose = torch.zeros(2, H, W, 12, device="cuda:0")
-    pose[..., :9] = torch.from_numpy(rng.uniform(-1, 1, (2, H, W, 9)).astype(np.float32)).cuda()
-    real = torch.zeros(2, H, W, 4, device="cuda:0")
-    real[..., :3] = torch.tanh(torch.from_numpy(rng.standard_normal((2, H, W, 3)).astype(np.float32))).cuda()
-    real_prev = torch.cat([real[1:], real[:1]], 0).contiguous()
-    boxes = [(16, 80, 32, 96)] * 2
-    runs = {}
-    for mode in ("1", "0"):
-        monkeypatch.setenv("T2V_TRAIN_TWO_STREAMS", mode)
-        tr = T.Vid2VidTrainer(opt, "cuda:0", seed=6)
-        prev, ls = None, []
-        for _ in range(3):
-            l, prev = tr.train_step(pose, real, boxes, prev, real_prev=real_prev)
-            ls.append(l)
-        runs[mode] = (ls, [p.detach().clone() for n in [tr.G, tr.D, tr.Df] + tr.DT for p in n.parameters()])
-    assert T._FWD_SIDE["stream"] is not None
-    for la, lb in zip(runs["1"][0], runs["0"][0]):
-        assert la.keys() == lb.keys() and all(la[k] == lb[k] for k in la), [(k, la[k], lb[k]) for k in la if la[k] != lb[k]]
-    assert all(torch.equal(x, y) for x, y in zip(runs["1"][1], runs["0"][1]))

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libt2v_hip.so")
 T2V_OK = 0
 PAD_ZERO, PAD_REFLECT = 0, 1
 ACT_NONE, ACT_TANH, ACT_FLOW_W, ACT_LRELU = 0, 1, 2, 3
-ABI_VERSION = 11
+ABI_VERSION = 12
 MAX_BATCH = 8     # T2V_MAX_BATCH
 ALGO_DIRECT, ALGO_WINOGRAD, ALGO_WINOGRAD_F4 = 0, 1, 2
 
@@ -52,6 +52,10 @@ SIGNATURES = {
     "t2v_last_error": (c_char_p, []),
     "t2v_create": (c_int, [POINTER(c_void_p), c_int]),
     "t2v_destroy": (c_int, [c_void_p]),
+    "t2v_reload_env": (None, []),
+    "t2v_check_async_errors": (c_int, []),
+    "t2v_fixed_grid_enabled": (c_int, []),
+    "t2v_debug_async_error": (None, [c_int]),
     "t2v_conv_out_dims": (c_int, [POINTER(ConvDesc), POINTER(c_int), POINTER(c_int)]),
     "t2v_conv_packed_weight_floats": (c_size_t, [POINTER(ConvDesc), c_int]),
     "t2v_conv_pack_weight": (c_int, [c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_void_p, c_void_p]),

@@ -4,6 +4,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
+#include <mutex>
+#include <vector>
+
 #include "conv_plan.h"
 
 namespace t2v {
@@ -17,6 +21,101 @@ void set_error(const char* fmt, ...) {
 }
 
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// ---- environment switches, read once ----
+static Options g_opts;
+static std::once_flag g_opts_once;
+static int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return (e && *e) ? atoi(e) : dflt;
+}
+void options_reload() {
+    Options o;
+    o.wino_gemm_sk = env_int("T2V_WINO_GEMM_SK", 1);
+    o.wino_gemm_sk_wide = env_int("T2V_WINO_GEMM_SK_WIDE", 1);
+    o.wino_gemm_sk_half = env_int("T2V_WINO_GEMM_SK_HALF", 1);
+    o.wgrad_sk = env_int("T2V_WGRAD_SK", 1);
+    o.wgrad_sk_half = env_int("T2V_WGRAD_SK_HALF", 1);
+    o.wgrad_combine = env_int("T2V_WGRAD_COMBINE", 1);
+    o.wgrad_combine_max = env_int("T2V_WGRAD_COMBINE_MAX", 4);
+    o.wgrad_fold = env_int("T2V_WGRAD_FOLD", 1);
+    o.conv_tile = env_int("T2V_CONV_TILE", -1);
+    o.conv_ring = env_int("T2V_CONV_RING", 0);
+    o.conv_head = env_int("T2V_CONV_HEAD", 1);
+    o.conv_cout1 = env_int("T2V_CONV_COUT1", 1);
+    o.conv_stem = env_int("T2V_CONV_STEM", 1);
+    o.chain_lazy = env_int("T2V_CHAIN_LAZY", 1);
+    o.streams = env_int("T2V_STREAMS", 2);
+    g_opts = o;
+}
+const Options& options() {
+    std::call_once(g_opts_once, options_reload);
+    return g_opts;
+}
+
+// ---- fixed-grid hand-over: sticky error word + dispatch-order self-test ----
+static unsigned* g_err_word = nullptr;            // pinned, mapped host memory: kernels store to it, the host reads it
+static std::atomic<int> g_fixed_grid_on{1};
+static std::mutex g_fg_mutex;
+static char g_fg_why[160] = "";
+unsigned* async_error_word() { return g_err_word; }
+bool fixed_grid_enabled() { return g_fixed_grid_on.load(std::memory_order_relaxed) != 0; }
+void fixed_grid_disable(const char* why) {
+    std::lock_guard<std::mutex> lk(g_fg_mutex);
+    if (g_fixed_grid_on.exchange(0)) {
+        snprintf(g_fg_why, sizeof(g_fg_why), "%s", why);
+        fprintf(stderr, "libt2v_hip: fixed-grid kernels switched off (%s); running one block per tile\n", why);
+    }
+}
+int check_async_errors() {
+    if (!g_err_word || *reinterpret_cast<volatile unsigned*>(g_err_word) == 0) return T2V_OK;
+    *reinterpret_cast<volatile unsigned*>(g_err_word) = 0;
+    fixed_grid_disable("an accumulator hand-over timed out");
+    set_error("a fixed-grid kernel's accumulator hand-over timed out in an earlier launch: the output of that launch holds "
+              "NaNs (re-run it); the fixed-grid kernels are now off for this process");
+    return T2V_ERR_HANDOVER;
+}
+
+// blocks shaped like the fixed-grid kernels' (512 threads, 64 KiB of LDS: two per CU), four rounds of them: each draws a
+// ticket as it starts and stays resident for a few microseconds
+__global__ __launch_bounds__(512) void dispatch_order_kernel(unsigned* counter, unsigned* order) {
+    extern __shared__ char smem[];
+    if (threadIdx.x == 0) {
+        order[blockIdx.x] = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        smem[0] = 0;
+    }
+    for (int i = 0; i < 64; ++i) __builtin_amdgcn_s_sleep(32);
+}
+static int fixed_grid_selftest() {
+    const int grid = 4 * wino_gemm_sk_grid_blocks();
+    unsigned* buf = nullptr;
+    T2V_HIP_CHECK(hipMalloc(&buf, (size_t)(grid + 1) * sizeof(unsigned)));
+    int st = T2V_OK;
+    std::vector<unsigned> host(grid + 1);
+    if (hipMemset(buf, 0, (size_t)(grid + 1) * sizeof(unsigned)) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(dispatch_order_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            65536) != hipSuccess)
+        st = T2V_ERR_HIP;
+    if (st == T2V_OK) {
+        hipLaunchKernelGGL(dispatch_order_kernel, dim3(grid), dim3(512), 65536, 0, buf, buf + 1);
+        if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
+            hipMemcpy(host.data(), buf, (size_t)(grid + 1) * sizeof(unsigned), hipMemcpyDeviceToHost) != hipSuccess)
+            st = T2V_ERR_HIP;
+    }
+    (void)hipFree(buf);
+    if (st != T2V_OK) {
+        fixed_grid_disable("the dispatch-order self-test could not run");
+        return T2V_OK;      // not fatal: the tile-per-block kernels need no such guarantee
+    }
+    for (int b = 8; b < grid; ++b)
+        if (host[1 + b - 8] >= host[1 + b]) {
+            char why[128];
+            snprintf(why, sizeof(why), "dispatch-order self-test: block %d started before block %d", b, b - 8);
+            fixed_grid_disable(why);
+            break;
+        }
+    return T2V_OK;
+}
 
 int build_conv_plan(const t2v_conv_desc* d, int x_cs, bool need_stats, ConvPlan* out) {
     T2V_REQUIRE(d && out, "null conv descriptor");
@@ -122,7 +221,7 @@ int build_conv_plan(const t2v_conv_desc* d, int x_cs, bool need_stats, ConvPlan*
         // tile quantisation: with 128x128 tiles a grid that fills the last wave of 256 CUs poorly
         // (e.g. 160 or 344 tiles at the real fadg0 geometries 512x320 / 512x680) idles a third of
         // the chip; 64x64 tiles (several co-resident blocks per CU) even that out
-        static const int force = getenv("T2V_CONV_TILE") ? atoi(getenv("T2V_CONV_TILE")) : -1;
+        const int force = options().conv_tile;
         const long nb = (long)k.mtiles * k.ntiles * k.nphases;
         const double fill = (double)nb / (double)(((nb + 255) / 256) * 256);
         // transposed convs with few blocks: the four phases have 1/2/2/4 taps, and one 128x128 block per CU cannot
@@ -190,22 +289,10 @@ int build_winograd_gemm_plan(const t2v_conv_desc* d, ConvPlan* pl, int nimg) {
     g.H = wino_pos(d->algo); g.W = T; g.Cin = d->Cin; g.Cout = d->Cout; g.kH = g.kW = 1; g.stride = 1; g.pad = 0;
     g.pad_mode = T2V_PAD_ZERO; g.act = T2V_ACT_NONE; g.act_scale = 1.f;
     T2V_TRY(build_conv_plan(&g, d->Cin, /*need_stats: 128- or 64-row tiles only*/ true, pl));
-    // T2V_WINO_GEMM_TILE=0: 128x128 tiles wherever the tile count allows (half the LDS-DMA traffic of the 64x64 tiles the
-    // fill heuristic picks for 2.25-round grids; measured slower alone, and in two-stream frames -- DESIGN 4.3)
-    static const int force_l = getenv("T2V_WINO_GEMM_TILE") ? atoi(getenv("T2V_WINO_GEMM_TILE")) == 0 : 0;
-    if (force_l && pl->tile == kTileQ && T % 128 == 0 && d->Cout > 64) {
-        pl->tile = kTileL;
-        conv_tile_dims(pl->tile, &pl->BM, &pl->BN);
-        pl->kp.ntiles = (g.Cout + pl->BN - 1) / pl->BN;
-        pl->kp.mtiles = (pl->kp.M + pl->BM - 1) / pl->BM;
-        pl->nparts = pl->kp.nphases * pl->kp.mtiles;
-    }
     // A batch (nimg >= 2: T = 512, 1024, ... rows per position) keeps the 128x128 tiles build_conv_plan's fill rule
     // leaves it with: alone the 64x64 tiles are faster at T = 512 (315 vs 335 us per batch-2 launch), inside two-stream
     // frames they lose (11.80 vs 11.41 ms per frame) -- the big tiles leave wave slots to the other stream's kernels.
-    // T2V_WINO_GEMM_TILE=2 forces the 64x64 tiles.
-    static const int force_q = getenv("T2V_WINO_GEMM_TILE") ? atoi(getenv("T2V_WINO_GEMM_TILE")) == 2 : 0;
-    if ((T % pl->BM != 0 || force_q) && pl->tile == kTileL) {   // tile count padded to 64 only: the 64x64 tile config
+    if (T % pl->BM != 0 && pl->tile == kTileL) {   // tile count padded to 64 only: the 64x64 tile config
         pl->tile = kTileQ;
         conv_tile_dims(pl->tile, &pl->BM, &pl->BN);
         pl->kp.ntiles = (g.Cout + pl->BN - 1) / pl->BN;
@@ -225,7 +312,7 @@ int run_conv(t2v_ctx* ctx, hipStream_t s, const ConvPlan& pl, const float* x, co
                 pl.kp.Cout, pl.Cout_p);
     {
         // the generator heads: dedicated halo-tile kernel (conv_head.hip)
-        static const int use_head = getenv("T2V_CONV_HEAD") ? atoi(getenv("T2V_CONV_HEAD")) : 1;
+        const int use_head = options().conv_head;
         const ConvKParams& q = pl.kp;
         if (use_head && !stats && q.nphases == 1 && q.ph[0].ntaps == 49 && q.KW == 7 && q.pad == 3 && q.stride == 1 &&
             q.pad_mode == T2V_PAD_REFLECT && q.Cout <= 3 && q.Cin_s % 16 == 0 && q.Hin >= 4 && q.Win >= 4) {
@@ -238,7 +325,7 @@ int run_conv(t2v_ctx* ctx, hipStream_t s, const ConvPlan& pl, const float* x, co
     }
     {
         // one output channel, long K (the discriminators' last layer): a wave per output pixel (conv_head.hip)
-        static const int use_c1 = getenv("T2V_CONV_COUT1") ? atoi(getenv("T2V_CONV_COUT1")) : 1;
+        const int use_c1 = options().conv_cout1;
         const ConvKParams& q = pl.kp;
         if (use_c1 && !stats && q.nphases == 1 && q.Cout == 1 && q.pad_mode == T2V_PAD_ZERO && q.ostride == 1 &&
             q.ph[0].ntaps == q.KW * q.KW && conv_cout1_supported(q.KW, q.Cin_s) &&
@@ -276,7 +363,8 @@ int winograd_forward(t2v_ctx* ctx, hipStream_t s, const t2v_conv_desc* d, const 
     const WinoBatch& wb = batch ? *batch : one;
     const int nimg = wb.nimg;
     const bool f4 = d->algo == T2V_ALGO_WINOGRAD_F4;
-    T2V_REQUIRE(nimg >= 1 && (f4 || (nimg == 1 && !wb.tickets)), "winograd: batches and in-kernel finalize are F(4x4,3x3) only");
+    if (f4) T2V_TRY(check_async_errors());
+    T2V_REQUIRE(nimg >= 1 && (f4 || nimg == 1), "winograd: batches are F(4x4,3x3) only");
     const size_t T = (size_t)wino_rows_batch(d, d->algo, nimg);
     float* V = workspace;
     float* Mm = workspace + wino_pos(d->algo) * T * d->Cin;
@@ -289,6 +377,7 @@ int winograd_forward(t2v_ctx* ctx, hipStream_t s, const t2v_conv_desc* d, const 
         if (f4 && wino_gemm_sk_ok(36, (int)T, d->Cin, d->Cout, d->Cout)) {
             SkGemm g;
             g.a = V; g.b = w_packed; g.c = Mm; g.scratch = workspace + winograd_vm_floats(d, nimg);
+            g.err = async_error_word();
             g.a_group_stride = (long)T * d->Cin;
             g.groups = 36; g.T = (int)T; g.K = d->Cin; g.N = d->Cout; g.c_cs = d->Cout;
             T2V_TRY(launch_wino_gemm_sk(s, g));
@@ -302,7 +391,7 @@ int winograd_forward(t2v_ctx* ctx, hipStream_t s, const t2v_conv_desc* d, const 
         T2V_REQUIRE(d->act == T2V_ACT_NONE || !stats_partial, "winograd: an activation and norm statistics do not combine");
         if (f4)
             T2V_TRY(launch_winograd4_output(s, Mm, bias, y, stats_partial, wino_out_h(d), wino_out_w(d), d->Cout,
-                                            d->act == T2V_ACT_LRELU, d->act_scale, nimg, wb.tickets, wb.mean_rstd, wb.eps));
+                                            d->act == T2V_ACT_LRELU, d->act_scale, nimg));
         else
             T2V_TRY(launch_winograd_output(s, Mm, bias, y, stats_partial, wino_out_h(d), wino_out_w(d), d->Cout));
     }
@@ -339,8 +428,40 @@ int t2v_create(t2v_ctx** out, int device) {
         set_error("t2v_create: cannot create the side stream / events");
         return T2V_ERR_HIP;
     }
+    (void)options();
+    {   // once per process: the sticky error word and the dispatch-order self-test of the fixed-grid kernels
+        static std::once_flag once;
+        int st = T2V_OK;
+        std::call_once(once, [&]() {
+            void* w = nullptr;
+            if (hipHostMalloc(&w, 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) {
+                fixed_grid_disable("no pinned error word");
+                return;
+            }
+            memset(w, 0, 64);
+            g_err_word = static_cast<unsigned*>(w);
+            st = fixed_grid_selftest();
+        });
+        if (st != T2V_OK) {
+            t2v_destroy(c);
+            return st;
+        }
+    }
     *out = c;
     return T2V_OK;
+}
+
+void t2v_reload_env(void) { options_reload(); }
+int t2v_check_async_errors(void) { return check_async_errors(); }
+int t2v_fixed_grid_enabled(void) { return fixed_grid_enabled() ? 1 : 0; }
+void t2v_debug_async_error(int raise) {
+    if (!g_err_word) return;
+    if (raise) {
+        *reinterpret_cast<volatile unsigned*>(g_err_word) = 1u;      // what a timed-out consumer wave stores
+    } else {
+        *reinterpret_cast<volatile unsigned*>(g_err_word) = 0u;
+        g_fixed_grid_on.store(1);
+    }
 }
 
 int t2v_destroy(t2v_ctx* ctx) {
@@ -488,14 +609,12 @@ int t2v_batch_norm_finalize_running(t2v_ctx* ctx, void* stream, const t2v_conv_d
 // narrow-input regular convs (7x7 stems: 12 / 8 channels; the discriminators' 4x4 first layers: 8): fold the taps
 // into the 128-wide channel side of the block tile
 static bool wgrad_fold(const t2v_conv_desc* d, int x_cs) {
-    static const bool off = getenv("T2V_WGRAD_FOLD") && atoi(getenv("T2V_WGRAD_FOLD")) == 0;
-    return !off && !d->transposed && x_cs < 64 && d->kH * d->kW > 1;
+    return options().wgrad_fold && !d->transposed && x_cs < 64 && d->kH * d->kW > 1;
 }
 
 // few output channels (the 7x7 heads: 3 -> dy_cs 4) on a wide input: fold the taps onto the dY side
 static bool wgrad_fold_n(const t2v_conv_desc* d, int x_cs, int dy_cs) {
-    static const bool off = getenv("T2V_WGRAD_FOLD") && atoi(getenv("T2V_WGRAD_FOLD")) == 0;
-    return !off && !d->transposed && d->stride == 1 && dy_cs <= 16 && x_cs >= 64 && d->kH * d->kW > 1 &&
+    return options().wgrad_fold && !d->transposed && d->stride == 1 && dy_cs <= 16 && x_cs >= 64 && d->kH * d->kW > 1 &&
            d->kH * d->kW <= kMaxTaps;
 }
 static size_t wgrad_padded_floats(const t2v_conv_desc* d, int x_cs, int batch) {
@@ -536,15 +655,9 @@ static size_t wgrad_ticket_floats(const t2v_conv_desc* d, int x_cs, const ConvPl
                                             : (size_t)ntaps * ((d->Cout + 127) / 128) * ((x_cs + 127) / 128);
     return (tiles + 255) / 256 * 256;
 }
-static int wgrad_combine_max_splits() {
-    const char* e = getenv("T2V_WGRAD_COMBINE_MAX");
-    return e ? atoi(e) : 4;
-}
+static int wgrad_combine_max_splits() { return options().wgrad_combine_max; }
 // T2V_WGRAD_COMBINE=0: split partials zero-filled, written and summed by a reduce launch (the round-1 form)
-static bool wgrad_combine_on() {
-    const char* e = getenv("T2V_WGRAD_COMBINE");
-    return !(e && atoi(e) == 0);
-}
+static bool wgrad_combine_on() { return options().wgrad_combine != 0; }
 
 size_t t2v_conv_backward_weight_workspace_floats(const t2v_conv_desc* d, int x_cs, int batch) {
     ConvPlan pl;
@@ -712,6 +825,7 @@ int t2v_conv2d_backward_weight_winograd_stages(t2v_ctx* ctx, void* stream, const
     w.ntaps = 36;
     w.splits = 1;
     w.dw_floats = (long)36 * Cout_p * Kp;
+    T2V_TRY(check_async_errors());
     if (wino_wgrad_sk_ok(Tt, x_cs, d->Cout))
         T2V_TRY(launch_wino_wgrad_sk(s, V, Md, dU, dU + (size_t)36 * Cout_p * Kp, Tt, x_cs, d->Cout, Cout_p, Kp));
     else
@@ -758,6 +872,7 @@ int t2v_conv2d_backward_data_winograd(t2v_ctx* ctx, void* stream, const t2v_conv
     T2V_REQUIRE(ctx && d && wgrad_workspace && ut_packed && scratch && dx && batch >= 1 && slot >= 0 && slot < batch,
                 "backward_data_winograd: bad arguments");
     T2V_REQUIRE(dgrad_winograd_ok(d, x_cs, d->Cout), "backward_data_winograd: shape not supported");
+    T2V_TRY(check_async_errors());
     hipStream_t s = (hipStream_t)stream;
     const int Tp = wino_tiles_padded(d, T2V_ALGO_WINOGRAD_F4), Tt = batch * Tp;
     // M_dy = A dy A^T of all `batch` images sits behind V in the weight gradient's workspace ([36][Tt][Cout] each)
@@ -770,6 +885,7 @@ int t2v_conv2d_backward_data_winograd(t2v_ctx* ctx, void* stream, const t2v_conv
         SkGemm g;
         g.a = Md + (size_t)slot * Tp * d->Cout; g.b = ut_packed; g.c = dV;
         g.scratch = dxp + (size_t)(d->H + 2) * (d->W + 2) * x_cs;
+        g.err = async_error_word();
         g.a_group_stride = (long)Tt * d->Cout;
         g.groups = 36; g.T = Tp; g.K = d->Cout; g.N = x_cs; g.c_cs = x_cs;
         T2V_TRY(launch_wino_gemm_sk(s, g));

@@ -158,10 +158,8 @@ static int launch_head(hipStream_t s, const HeadParams& p) {
 }
 
 int launch_conv_head7x7(hipStream_t s, const HeadParams& p) {
-    static const int force = getenv("T2V_HEAD_CH") ? atoi(getenv("T2V_HEAD_CH")) : 0;
-    // 16 channels per pass (32 KiB, 4 blocks/CU) measured faster than 32 (64 KiB, 2 blocks/CU): 253 vs 402 us
-    const bool wide = force == 32 && p.Cin_s % 32 == 0;
-    return wide ? launch_head<32>(s, p) : launch_head<16>(s, p);
+    // 16 channels per pass (32 KiB, 4 blocks/CU); 32 per pass (64 KiB, 2 blocks/CU) measured slower: 402 vs 253 us
+    return launch_head<16>(s, p);
 }
 
 // ------------------------------------------------------------------------------------------------

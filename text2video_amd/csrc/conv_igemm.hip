@@ -461,6 +461,7 @@ struct SkKParams {
     float* partial;               // [grid][4 waves][64 regs][64 lanes]
     unsigned long long* flags;    // [grid][4 waves]
     unsigned long long tag;       // unique per launch: stale flags of earlier launches never match
+    unsigned* err;                // sticky error word raised by a hand-over that timed out
     long a_group_stride;
     int T, K, N, c_cs;
     int mtiles_g, ntiles, nk, tiles, tiles_per_xcd, blocks_per_xcd;
@@ -589,12 +590,9 @@ __global__ __launch_bounds__(512) void wino_gemm_sk_kernel(const SkKParams p) {
             // the second schedule); its wave `wid` wrote what this wave reads
             const int src = blockIdx.x - 8 * (hybrid ? half : 1);
             const unsigned long long* fl = p.flags + src * 4 + wid;
-            // (bounded: ~1 s of polling.  The producer ran before this block was even dispatched; if its tag is still
-            // missing something is broken: the tile is then poisoned with NaNs -- visible, and no hung GPU)
-            int spin = 0;
-            for (; spin < (1 << 23) && __hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.tag; ++spin)
-                __builtin_amdgcn_s_sleep(4);
-            const bool timed_out = spin >= (1 << 23);
+            // (bounded: 1 s.  The producer ran before this block was even dispatched; if its tag is still missing something
+            // is broken: the tile is then poisoned with NaNs and the host is told through p.err -- no hung GPU, no silent frame)
+            const bool timed_out = handover_wait(fl, p.tag, p.err, lane);
             // taken: clear it, so that a replay of this very launch (a captured graph re-issues the same tag) starts clean
             if (lane == 0) __hip_atomic_store(const_cast<unsigned long long*>(fl), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             // write-through (sc1) stores on the producer's side, sc1 loads here: the pair that is coherent across the
@@ -690,23 +688,21 @@ size_t wino_gemm_sk_scratch_floats() { return (size_t)kSkMaxGrid * (4 * 64 * 64 
 static int sk_tile_rows(int T, int N) {
     if (N % 128) return 0;            // (the packed weights hold round_up(N, 128) rows per position: N itself, then)
     if (T % 128 == 0) return 128;
-    static const int wide = getenv("T2V_WINO_GEMM_SK_WIDE") ? atoi(getenv("T2V_WINO_GEMM_SK_WIDE")) : 1;
-    return (wide && T % 192 == 0) ? 192 : 0;
+    return (options().wino_gemm_sk_wide && T % 192 == 0) ? 192 : 0;
 }
 // R whole rounds + exactly half a round of tiles, an even number of K stages, whole 16-block halves per XCD
 static bool sk_half_round(long tiles, long grid, int nk) {
-    static const int on = getenv("T2V_WINO_GEMM_SK_HALF") ? atoi(getenv("T2V_WINO_GEMM_SK_HALF")) : 1;
-    return on && tiles >= grid && 2 * (tiles % grid) == grid && nk % 2 == 0 && grid % 16 == 0;
+    return options().wino_gemm_sk_half && tiles >= grid && 2 * (tiles % grid) == grid && nk % 2 == 0 && grid % 16 == 0;
 }
 bool wino_gemm_sk_ok(int groups, int T, int K, int N, int c_cs) {
-    const char* e = getenv("T2V_WINO_GEMM_SK");   // read per call: tests and A/B runs flip it inside one process
+    const int mode = fixed_grid_enabled() ? options().wino_gemm_sk : 0;
     const int bm = sk_tile_rows(T, N);
-    if ((e && atoi(e) == 0) || bm == 0 || K % kBK || c_cs != N || (long)192 * K * 4 >= 0x7fff0000L) return false;
+    if (mode == 0 || bm == 0 || K % kBK || c_cs != N || (long)192 * K * 4 >= 0x7fff0000L) return false;
     // fewer tiles than resident blocks: one tile per block is already less than one round.  Beyond that the fixed grid
     // pays where whole tiles fill their last round badly -- measured on MI355X (scripts/sk_probe.py, K = N = 1024):
     // 1.125 rounds 189 -> 144 us, 1.69 rounds 241 -> 210 us, 2.25 rounds 352 -> 294 us, 4.5 rounds 583 -> 611 us
     const long tiles = (long)groups * (T / bm) * (N / (bm == 128 ? 128 : 64)), grid = wino_gemm_sk_grid_blocks();
-    if (e && atoi(e) == 2) return true;   // T2V_WINO_GEMM_SK=2: wherever the shape allows (fewer tiles than blocks: the
+    if (mode == 2) return true;   // T2V_WINO_GEMM_SK=2: wherever the shape allows (fewer tiles than blocks: the
                                           // spare blocks leave at once -- what the small-shape tests run)
     if (tiles < grid) return false;
     if (sk_half_round(tiles, grid, K / kBK)) return true;     // R.5 rounds: the second schedule (whole rounds + a cut half round)
@@ -748,6 +744,7 @@ int launch_wino_gemm_sk(hipStream_t s, const SkGemm& g) {
     k.partial = g.scratch;
     k.flags = reinterpret_cast<unsigned long long*>(g.scratch + (size_t)kSkMaxGrid * 4 * 64 * 64);
     k.tag = wino_gemm_sk_next_tag();
+    k.err = g.err;
     k.a_group_stride = g.a_group_stride;
     k.T = g.T; k.K = g.K; k.N = g.N; k.c_cs = g.c_cs;
     const int bm = sk_tile_rows(g.T, g.N), bn = bm == 128 ? 128 : 64;
@@ -795,14 +792,9 @@ static int launch_pad(hipStream_t s, const ConvKParams& p) {
     // >= 4 blocks per CU queued: let two blocks share the CU (64 KiB ring each); measured on MI355X:
     // 2048-block stem 0.40 vs 0.47 ms, 1024-block layers 0.33 vs 0.345 ms, <= 512 blocks favour RING 3
     const long nblocks = (long)p.mtiles * p.ntiles * p.nphases;
-    static const int force = getenv("T2V_CONV_RING") ? atoi(getenv("T2V_CONV_RING")) : 0;
+    const int force = options().conv_ring;
     // (swept per layer shape with scripts/kernel_bench.py: single-phase launches like two co-resident blocks from 512
     // blocks on; 64x64 tiles of a multi-phase launch prefer the deeper ring)
-    // T2V_GEMM_RING: ring depth of the single-phase 64x64-tile launches only (the Winograd GEMM stages)
-    static const int gemm_ring = getenv("T2V_GEMM_RING") ? atoi(getenv("T2V_GEMM_RING")) : 0;
-    if (gemm_ring && Cfg::MF == 32 && Cfg::BM == 64 && p.nphases == 1)
-        return gemm_ring == 2 ? launch_ring<Cfg, MODE, STATS, REFLECT, 2>(s, p)
-               : gemm_ring == 4 ? launch_ring<Cfg, MODE, STATS, REFLECT, 4>(s, p) : launch_ring<Cfg, MODE, STATS, REFLECT, 3>(s, p);
     const bool two = force ? force == 2
                            : (Cfg::MF == 32 && (Cfg::BM == 64 ? (p.nphases == 1 || nblocks >= 4096)
                                                               : (nblocks >= 1024 || (p.nphases == 1 && nblocks >= 512))));

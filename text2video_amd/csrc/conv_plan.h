@@ -49,14 +49,9 @@ int build_winograd_gemm_plan(const t2v_conv_desc* d, ConvPlan* pl, int nimg = 1)
 // A batch of images through one Winograd conv (F(4x4,3x3) only when nimg > 1): the images' maps x / y are
 // `img_stride_x` / H*W*Cout floats apart, V and M hold nimg*Tp tile rows per transform position (one GEMM with
 // M = nimg*Tp rows per position), the statistics partials follow each other image by image.
-// tickets != nullptr: the output transform also finalizes the norm statistics into mean_rstd (nimg tables of
-// [Cout][2]); see launch_winograd4_output.
 struct WinoBatch {
     int nimg = 1;
     long img_stride_x = 0;     // floats between the input maps
-    int* tickets = nullptr;
-    float* mean_rstd = nullptr;
-    float eps = 1e-5f;
 };
 int winograd_forward(t2v_ctx* ctx, hipStream_t s, const t2v_conv_desc* d, const float* x, const float* w_packed,
                      const float* bias, float* y, float* stats_partial, float* workspace, int stages,

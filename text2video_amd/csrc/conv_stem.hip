@@ -212,8 +212,7 @@ static int launch_stem(hipStream_t s, const StemParams& p) {
 }
 
 bool conv_stem7x7_supported(int H, int W, int Cin_s, int Cout) {
-    static const bool off = getenv("T2V_CONV_STEM") && atoi(getenv("T2V_CONV_STEM")) == 0;
-    return !off && H >= 16 && W >= 16 && (Cin_s == 8 || Cin_s == 12) && (Cout == 64 || Cout == 128);
+    return options().conv_stem && H >= 16 && W >= 16 && (Cin_s == 8 || Cin_s == 12) && (Cout == 64 || Cout == 128);
 }
 
 int launch_conv_stem7x7(hipStream_t s, const StemParams& p) {

@@ -319,6 +319,7 @@ struct WinoWgradSkParams {
     float* partial;               // [grid][4 waves][64 regs][64 lanes]
     unsigned long long* flags;    // [grid][4 waves]
     unsigned long long tag;
+    unsigned* err;                // sticky error word raised by a hand-over that timed out
     int Tt, Cin, Cout, Cout_p, Kp;
     int ntiles, ctiles, nk, tiles, tiles_per_xcd, blocks_per_xcd;
     int rounds;   // > 0: whole rounds of one tile per block + half a round cut in two (wino_gemm_sk_kernel's second schedule)
@@ -433,10 +434,8 @@ __global__ __launch_bounds__(512) void wino_wgrad_sk_kernel(const WinoWgradSkPar
         if (init) {
             const int src = blockIdx.x - 8 * (hybrid ? half : 1);
             const unsigned long long* fl = p.flags + src * 4 + wid;
-            int spin = 0;     // (bounded, ~1 s; on a time-out the tile is poisoned with NaNs: see wino_gemm_sk_kernel)
-            for (; spin < (1 << 23) && __hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.tag; ++spin)
-                __builtin_amdgcn_s_sleep(4);
-            const bool timed_out = spin >= (1 << 23);
+            // (bounded, 1 s; on a time-out the tile is poisoned with NaNs and p.err is raised: see wino_gemm_sk_kernel)
+            const bool timed_out = handover_wait(fl, p.tag, p.err, lane);
             // taken: clear it, so that a replay of this very launch (a captured graph re-issues the same tag) starts clean
             if (lane == 0) __hip_atomic_store(const_cast<unsigned long long*>(fl), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(
@@ -514,9 +513,9 @@ __global__ __launch_bounds__(512) void wino_wgrad_sk_kernel(const WinoWgradSkPar
 }
 
 bool wino_wgrad_sk_ok(int Tt, int Cin, int Cout) {
-    const char* e = getenv("T2V_WGRAD_SK");
-    if ((e && atoi(e) == 0) || Tt % 16 || Cin % 4 || Cout % 4) return false;
-    if (e && atoi(e) == 2) return true;   // T2V_WGRAD_SK=2: also with fewer tiles than blocks (the small-shape tests)
+    const int mode = fixed_grid_enabled() ? options().wgrad_sk : 0;
+    if (mode == 0 || Tt % 16 || Cin % 4 || Cout % 4) return false;
+    if (mode == 2) return true;   // T2V_WGRAD_SK=2: also with fewer tiles than blocks (the small-shape tests)
     const long tiles = 36L * ((Cout + 127) / 128) * ((Cin + 127) / 128);
     return tiles >= wino_gemm_sk_grid_blocks();
 }
@@ -529,14 +528,14 @@ int launch_wino_wgrad_sk(hipStream_t s, const float* V, const float* Md, float* 
     k.partial = scratch;
     k.flags = reinterpret_cast<unsigned long long*>(scratch + wino_gemm_sk_scratch_floats() - 1024 * 4 * 2);
     k.tag = wino_gemm_sk_next_tag();
+    k.err = async_error_word();
     k.Tt = Tt; k.Cin = Cin; k.Cout = Cout; k.Cout_p = Cout_p; k.Kp = Kp;
     k.ntiles = (Cout + 127) / 128; k.ctiles = (Cin + 127) / 128; k.nk = Tt / 16;
     k.tiles = 36 * k.ntiles * k.ctiles;
     const int grid = wino_gemm_sk_grid_blocks();
     k.blocks_per_xcd = grid / 8;
     k.tiles_per_xcd = (k.tiles + 7) / 8;
-    static const int half_on = getenv("T2V_WGRAD_SK_HALF") ? atoi(getenv("T2V_WGRAD_SK_HALF")) : 1;
-    k.rounds = (half_on && k.tiles >= grid && 2 * (k.tiles % grid) == grid && k.nk % 2 == 0 && grid % 16 == 0) ? k.tiles / grid : 0;
+    k.rounds = (options().wgrad_sk_half && k.tiles >= grid && 2 * (k.tiles % grid) == grid && k.nk % 2 == 0 && grid % 16 == 0) ? k.tiles / grid : 0;
     auto kern = wino_wgrad_sk_kernel<16, 4>;
     constexpr int lds = 4 * 2 * 16 * 128 * 4;
     static bool attr_done = false;
@@ -581,22 +580,10 @@ static int launch_wgrad_variant(hipStream_t s, const WgradParams& p) {
     return T2V_OK;
 }
 
+// 16-pixel stages on a 4-slot ring (64 KiB: two blocks per CU).  Swept in round 2: 32-pixel stages on 2 / 3
+// slots, 8-pixel stages and ring depths 3 / 5 all measured slower by 3-8 %.
 int launch_conv_wgrad(hipStream_t s, const WgradParams& p) {
-    static const int pix = getenv("T2V_WGRAD_PIX") ? atoi(getenv("T2V_WGRAD_PIX")) : 16;
-    static const int ring = getenv("T2V_WGRAD_RING") ? atoi(getenv("T2V_WGRAD_RING")) : 4;
-    if (pix == 8 && ring == 4)
-        return p.reflect ? launch_wgrad_variant<true, 8, 4>(s, p) : launch_wgrad_variant<false, 8, 4>(s, p);
-    if (pix == 8)
-        return p.reflect ? launch_wgrad_variant<true, 8, 8>(s, p) : launch_wgrad_variant<false, 8, 8>(s, p);
-    if (pix == 16 && ring == 5)
-        return p.reflect ? launch_wgrad_variant<true, 16, 5>(s, p) : launch_wgrad_variant<false, 16, 5>(s, p);
-    if (pix == 16 && ring == 3)
-        return p.reflect ? launch_wgrad_variant<true, 16, 3>(s, p) : launch_wgrad_variant<false, 16, 3>(s, p);
-    if (pix == 16)
-        return p.reflect ? launch_wgrad_variant<true, 16, 4>(s, p) : launch_wgrad_variant<false, 16, 4>(s, p);
-    if (ring == 3)
-        return p.reflect ? launch_wgrad_variant<true, 32, 3>(s, p) : launch_wgrad_variant<false, 32, 3>(s, p);
-    return p.reflect ? launch_wgrad_variant<true, 32, 2>(s, p) : launch_wgrad_variant<false, 32, 2>(s, p);
+    return p.reflect ? launch_wgrad_variant<true, 16, 4>(s, p) : launch_wgrad_variant<false, 16, 4>(s, p);
 }
 
 }  // namespace t2v

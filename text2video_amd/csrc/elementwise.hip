@@ -261,139 +261,6 @@ int launch_inorm_apply(hipStream_t s, const float* x, const float* mean_rstd, co
     return T2V_OK;
 }
 
-// Finalize folded into the apply pass for layers with few partials (the 64x64-bottleneck layers: 32 partials of 128
-// pixels per channel): a block owns 64 channels x a range of pixels, pools the partials of its channels itself
-// (the arithmetic of inorm_finalize_kernel: count-weighted fp64 moments about the first partial's mean) and then
-// normalises its pixels -- one launch per norm layer instead of two, no mean_rstd round trip.
-constexpr int kFusedMaxParts = 128;
-constexpr int kFusedSweeps = 4;   // 16 pixels per sweep: a block normalises 64 pixels x 64 channels
-// ucount > 0: every partial covers that many pixels (no per-partial geometry)
-__global__ __launch_bounds__(256) void inorm_apply_partials_kernel(
-    const float4* __restrict__ x, const float2* __restrict__ stats, int nparts, int mtiles, int BM, int M, int wm, int H,
-    int W, int C, int ucount, float eps, const float* __restrict__ gamma, const float* __restrict__ beta,
-    const float4* __restrict__ res1, const float4* __restrict__ res2, float4* __restrict__ y, long npix, int relu) {
-    __shared__ double sh[4][4][64];
-    __shared__ float2 mr[64];
-    __shared__ float2 gb[64];
-    const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
-    const int c = blockIdx.y * 64 + cl;
-    // the block's share of the tensor is requested first: its latency covers the pooling of the partials
-    const int q = threadIdx.x & 15, pr = threadIdx.x >> 4;
-    const long p0 = (long)blockIdx.x * (16 * kFusedSweeps);
-    const int C4 = C >> 2;
-    float4 xv[kFusedSweeps], r1v[kFusedSweeps], r2v[kFusedSweeps];
-#pragma unroll
-    for (int k = 0; k < kFusedSweeps; ++k) {
-        const long pix = p0 + 16 * k + pr;
-        const long i = pix * C4 + blockIdx.y * 16 + q;
-        const bool ok = pix < npix;
-        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-        xv[k] = ok ? x[i] : z;
-        r1v[k] = (ok && res1) ? res1[i] : z;
-        r2v[k] = (ok && res2) ? res2[i] : z;
-    }
-    {
-        double s0 = 0.0, s1 = 0.0, s2 = 0.0, sm2 = 0.0;
-        const float ref = stats[c].x;
-        const int per = (nparts + 3) >> 2, p1 = min(nparts, (pl + 1) * per);
-        for (int part = pl * per; part < p1; ++part) {
-            const int nb = ucount > 0 ? ucount : partial_pixels(part, mtiles, BM, M, wm, H, W);
-            if (nb == 0) continue;
-            const float2 v = stats[(size_t)part * C + c];
-            const double d = (double)(v.x - ref), n = (double)nb;
-            s0 += n;
-            s1 += n * d;
-            s2 += n * d * d;
-            sm2 += (double)v.y;
-        }
-        sh[0][pl][cl] = s0;
-        sh[1][pl][cl] = s1;
-        sh[2][pl][cl] = s2;
-        sh[3][pl][cl] = sm2;
-        __syncthreads();
-        if (pl == 0) {
-            for (int k = 1; k < 4; ++k) {   // fixed order
-                s0 += sh[0][k][cl];
-                s1 += sh[1][k][cl];
-                s2 += sh[2][k][cl];
-                sm2 += sh[3][k][cl];
-            }
-            const double mean_d = s1 / s0;
-            double m2 = sm2 + s2 - s1 * mean_d;
-            m2 = m2 > 0.0 ? m2 : 0.0;
-            mr[cl] = make_float2(ref + (float)mean_d, 1.0f / sqrtf((float)(m2 / s0) + eps));
-            gb[cl] = gamma ? make_float2(gamma[c], beta[c]) : make_float2(1.f, 0.f);
-        }
-        __syncthreads();
-    }
-    const float2 m0 = mr[4 * q], m1 = mr[4 * q + 1], m2 = mr[4 * q + 2], m3 = mr[4 * q + 3];
-    const float2 g0 = gb[4 * q], g1 = gb[4 * q + 1], g2 = gb[4 * q + 2], g3 = gb[4 * q + 3];
-#pragma unroll
-    for (int k = 0; k < kFusedSweeps; ++k) {
-        const long pix = p0 + 16 * k + pr;
-        if (pix >= npix) break;
-        const long i = pix * C4 + blockIdx.y * 16 + q;
-        float4 v = xv[k];
-        v.x = (v.x - m0.x) * m0.y;
-        v.y = (v.y - m1.x) * m1.y;
-        v.z = (v.z - m2.x) * m2.y;
-        v.w = (v.w - m3.x) * m3.y;
-        if (gamma) {
-            v.x = v.x * g0.x + g0.y;
-            v.y = v.y * g1.x + g1.y;
-            v.z = v.z * g2.x + g2.y;
-            v.w = v.w * g3.x + g3.y;
-        }
-        if (relu == 1) {
-            v.x = fmaxf(v.x, 0.f);
-            v.y = fmaxf(v.y, 0.f);
-            v.z = fmaxf(v.z, 0.f);
-            v.w = fmaxf(v.w, 0.f);
-        } else if (relu == 2) {  // LeakyReLU(0.2)
-            v.x = v.x > 0.f ? v.x : 0.2f * v.x;
-            v.y = v.y > 0.f ? v.y : 0.2f * v.y;
-            v.z = v.z > 0.f ? v.z : 0.2f * v.z;
-            v.w = v.w > 0.f ? v.w : 0.2f * v.w;
-        }
-        if (res1) { v.x += r1v[k].x; v.y += r1v[k].y; v.z += r1v[k].z; v.w += r1v[k].w; }
-        if (res2) { v.x += r2v[k].x; v.y += r2v[k].y; v.z += r2v[k].z; v.w += r2v[k].w; }
-        y[i] = v;
-    }
-}
-
-// true when the fused pass is switched on (T2V_NORM_FUSED=1) and applies: few partials, whole 64-channel groups.
-// OFF by default: measured on MI355X (scripts/ab_frames.sh, alternating runs on one box, 512x512) the fused pass is
-// 16.8 us against 13.6 + 6.4 us for apply + finalize and removes 40 of 235 launches per frame, yet the FRAME gets slower:
-// 12.42 vs 12.17 ms with flow, 9.58 vs 9.43 ms without, 12.71 vs 12.65 ms on a single stream -- every block repeats
-// the pooling before it can store anything, and the short finalize launches were already hidden behind the other
-// stream's GEMM blocks.
-bool inorm_fused_ok(int nparts, int C) {
-    static const bool on = getenv("T2V_NORM_FUSED") && atoi(getenv("T2V_NORM_FUSED")) == 1;
-    return on && nparts >= 1 && nparts <= kFusedMaxParts && C % 64 == 0;
-}
-// geometry arguments as for the three finalize launchers: (nparts, mtiles, BM, M, wm, H, W)
-int launch_inorm_apply_partials(hipStream_t s, const float* x, const float* stats, int nparts, int mtiles, int BM, int M,
-                                int wm, int H, int W, int C, float eps, const float* gamma, const float* beta,
-                                const float* res1, const float* res2, float* y, long npix, int relu) {
-    T2V_REQUIRE(inorm_fused_ok(nparts, C), "inorm_apply_partials: nparts=%d C=%d not supported", nparts, C);
-    // do all partials cover the same number of pixels?  (then the kernel needs no per-partial geometry)
-    int ucount = 0;
-    if (wm == 0) {
-        ucount = (M % BM == 0) ? BM : 0;
-    } else if (wm > 0) {
-        const int TW = (W + wm - 1) / wm, T = ((H + wm - 1) / wm) * TW, tpb = 128 / (wm * wm);
-        ucount = (H % wm == 0 && W % wm == 0 && T % tpb == 0) ? 128 : 0;
-    }
-    const int ppb = 16 * kFusedSweeps;
-    const int gx = (int)((npix + ppb - 1) / ppb);
-    hipLaunchKernelGGL(inorm_apply_partials_kernel, dim3(gx, C / 64), dim3(256), 0, s, reinterpret_cast<const float4*>(x),
-                       reinterpret_cast<const float2*>(stats), nparts, mtiles, BM, M, wm, H, W, C, ucount, eps, gamma, beta,
-                       reinterpret_cast<const float4*>(res1), reinterpret_cast<const float4*>(res2),
-                       reinterpret_cast<float4*>(y), npix, relu);
-    T2V_HIP_CHECK(hipGetLastError());
-    return T2V_OK;
-}
-
 __global__ void add_kernel(const float4* __restrict__ a, const float4* __restrict__ b, float4* __restrict__ y,
                            long n4) {
     const long stride = (long)gridDim.x * blockDim.x;

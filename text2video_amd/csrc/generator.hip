@@ -112,9 +112,7 @@ struct Buffers {
     float* mean_rstd[2];
     float* wino[2];   // Winograd scratch: transformed input V + transformed output M of the whole batch
     double* fin[2];   // norm finalize scratch (pooled moments per group of partials)
-    int* tickets[2];  // arrival counters of the producers that finalize their own statistics
     size_t stats_stride, mr_stride, fin_stride;   // floats (doubles for fin) between the images' slots
-    size_t ticket_ints;                           // per stream
 };
 
 void plan_buffers(const t2v_gen_desc& g, const std::vector<LayerSpec>& layers, int nimg, Arena& a, Buffers& b) {
@@ -155,15 +153,11 @@ void plan_buffers(const t2v_gen_desc& g, const std::vector<LayerSpec>& layers, i
     b.stats_stride = (max_stats + 63) / 64 * 64;
     b.mr_stride = (size_t)max_c * 2;
     b.fin_stride = (size_t)kFinalizeMaxGroups * max_c * 4;
-    b.ticket_ints = (size_t)kMaxBatch * ((max_c + 63) / 64);
     for (int k = 0; k < 2; ++k) {
         b.stats[k] = a.alloc(N * b.stats_stride);
         b.mean_rstd[k] = a.alloc(N * b.mr_stride);
         b.fin[k] = reinterpret_cast<double*>(a.alloc(N * b.fin_stride * 2));
     }
-    // both streams' counters in one block: one memset per frame clears them
-    b.tickets[0] = reinterpret_cast<int*>(a.alloc(2 * b.ticket_ints));
-    b.tickets[1] = b.tickets[0] + b.ticket_ints;
     size_t max_wino = 0;
     for (const LayerSpec& L : layers)
         if (is_winograd(L.cd.algo)) {
@@ -210,15 +204,6 @@ struct Runner {
     float* stats_of(int im) const { return b.stats[sc] + (size_t)im * b.stats_stride; }
     float* mr_of(int im) const { return b.mean_rstd[sc] + (size_t)im * b.mr_stride; }
     double* fin_of(int im) const { return b.fin[sc] + (size_t)im * b.fin_stride; }
-    // T2V_NORM_TICKET=1: the F(4x4) output transforms finalize their norm statistics in their own last block per
-    // channel group instead of a finalize launch (bit-identical frames, 36 launches per flow frame fewer).  OFF by
-    // default: measured slower (DESIGN 4.3 -- every block drains its stores and takes a ticket, and the last one pools
-    // serially: 57 vs 22 + 2 x 6.6 us per batch-2 conv).  Read per call, so one process can compare the two forms.
-    static bool ticket_on() {
-        const char* e = getenv("T2V_NORM_TICKET");
-        return e && atoi(e) == 1;
-    }
-
     // conv (+ fused stats) -> finalize -> apply of layer `l` for ONE image.  y receives the conv output and is
     // normalised in place: y = [relu](norm(conv(x))) + res1 + res2
     int conv_norm_one(int l, int im, const float* x, float* y, int relu, const float* res1, const float* res2) {
@@ -234,29 +219,13 @@ struct Runner {
         if (is_winograd(L.cd.algo)) {
             const int M = L.cd.H * L.cd.W;
             const int wm = wino_m(L.cd.algo);
-            const int nparts = wino_tiles_padded(&L.cd, L.cd.algo) / (128 / (wm * wm));
-            const bool fused = inorm_fused_ok(nparts, Cout);
-            // the output transform's last block per channel group finalizes the statistics itself
-            const bool ticket = !fused && ticket_on() && wm == 4 && winograd4_ticket_ok(L.cd.H, L.cd.W);
             WinoBatch wb;
-            if (ticket) {
-                wb.tickets = b.tickets[sc];
-                wb.mean_rstd = mr;
-                wb.eps = g.eps;
-            }
             T2V_TRY(winograd_forward(ctx, s, &L.cd, x, w.w, w.bias, y, stats, b.wino[sc], 7, &wb));
-            if (fused)   // the apply pass pools the (few) partials itself: no finalize launch
-                return launch_inorm_apply_partials(s, y, stats, nparts, nparts, 0, M, wm, L.cd.H, L.cd.W, Cout, g.eps,
-                                                   gam, bet, res1, res2, y, (long)M, relu);
-            if (!ticket)
-                T2V_TRY(launch_inorm_finalize_winograd(s, stats, wm, L.cd.H, L.cd.W, Cout, g.eps, mr, 1, fin_of(im)));
+            T2V_TRY(launch_inorm_finalize_winograd(s, stats, wm, L.cd.H, L.cd.W, Cout, g.eps, mr, 1, fin_of(im)));
             return launch_inorm_apply(s, y, mr, gam, bet, res1, res2, y, (long)M, Cout, relu);
         }
         T2V_TRY(build_conv_plan(&L.cd, L.x_cs, true, &pl));
         T2V_TRY(run_conv(ctx, s, pl, x, w.w, w.bias, y, Cout, stats));
-        if (pl.tile != kTileStem && inorm_fused_ok(pl.nparts, Cout))
-            return launch_inorm_apply_partials(s, y, stats, pl.nparts, pl.kp.mtiles, pl.BM, pl.kp.M, 0, 0, 0, Cout, g.eps,
-                                               gam, bet, res1, res2, y, (long)pl.Hout * pl.Wout, relu);
         if (pl.tile == kTileStem)
             T2V_TRY(launch_inorm_finalize_tiles(s, stats, 16, L.cd.H, L.cd.W, Cout, g.eps, mr, 1, fin_of(im)));
         else
@@ -308,18 +277,11 @@ struct Runner {
                                                 b.mean_rstd[sc], g.norm_affine ? lz->norm->gamma : nullptr,
                                                 g.norm_affine ? lz->norm->beta : nullptr, lz->relu, lz->res, lz->xout, nimg,
                                                 (long)b.bott));
-        const bool ticket = ticket_on() && winograd4_ticket_ok(cd.H, cd.W);
         WinoBatch wb;
         wb.nimg = nimg;
         wb.img_stride_x = (long)b.bott;
-        if (ticket) {
-            wb.tickets = b.tickets[sc];
-            wb.mean_rstd = b.mean_rstd[sc];
-            wb.eps = g.eps;
-        }
         // the images' partials are packed back to back by the batched output transform: nparts*Cout*2 floats each
         T2V_TRY(winograd_forward(ctx, s, &cd, x, w.w, w.bias, y_raw, b.stats[sc], b.wino[sc], lz ? 6 : 7, &wb));
-        if (ticket) return T2V_OK;
         const size_t per_img = (size_t)(wino_tiles_padded(&cd, cd.algo) / 8) * cd.Cout * 2;
         for (int im = 0; im < nimg; ++im)
             T2V_TRY(launch_inorm_finalize_winograd(s, b.stats[sc] + im * per_img, 4, cd.H, cd.W, cd.Cout, g.eps, mr_of(im), 1,
@@ -329,8 +291,7 @@ struct Runner {
 
     // The same chain with every norm applied by its consumer: the next conv's input transform normalises (and adds
     // the residual) on the fly, and writes the block output the following block needs as ITS residual on the side.
-    // Only the last norm of the chain runs as an apply pass.  Per block: 8 launches instead of 10 (6 when the output
-    // transforms finalize the statistics themselves) for the WHOLE batch, and one read + one write of the map less
+    // Only the last norm of the chain runs as an apply pass.  Per block: 8 launches instead of 10 for the WHOLE batch, and one read + one write of the map less
     // per conv.  tmp: raw conv1 / conv2 outputs, block outputs (alternating); all hold the batch back to back.
     int res_chain_lazy(const float* x, int count, float* tmp[4], const float** out) {
         const float* cur = x;
@@ -359,8 +320,7 @@ struct Runner {
     // chain of `count` resblocks starting from x (never written; the batch back to back, `bott` floats apart); result
     // pointer in *out.  tmp: 4 distinct buffers != x.
     int res_chain(const float* x, int count, float* tmp[4], const float** out) {
-        static const bool lazy = !(getenv("T2V_CHAIN_LAZY") && atoi(getenv("T2V_CHAIN_LAZY")) == 0);
-        if (lazy && count > 0 && specs[li].cd.algo == T2V_ALGO_WINOGRAD_F4 && b.mr_stride == (size_t)2 * specs[li].cd.Cout)
+        if (options().chain_lazy && count > 0 && specs[li].cd.algo == T2V_ALGO_WINOGRAD_F4 && b.mr_stride == (size_t)2 * specs[li].cd.Cout)
             return res_chain_lazy(x, count, tmp, out);
         const float* cur = x;
         for (int i = 0; i < count; ++i) {
@@ -441,6 +401,7 @@ int t2v_generator_forward_batch(t2v_ctx* ctx, void* stream, const t2v_gen_desc* 
     T2V_REQUIRE(ctx && layers && ios && workspace, "generator_forward: null pointer");
     T2V_REQUIRE(batch >= 1 && batch <= kMaxBatch, "generator_forward: batch %d out of range [1,%d]", batch, kMaxBatch);
     T2V_TRY(check_desc(d));
+    T2V_TRY(check_async_errors());      // a hand-over that timed out in an earlier frame is reported here
     std::vector<LayerSpec> specs;
     enumerate_layers(*d, specs);
     T2V_REQUIRE(n_layers == (int)specs.size(), "generator_forward: expected %d layers, got %d", (int)specs.size(),
@@ -468,7 +429,7 @@ int t2v_generator_forward_batch(t2v_ctx* ctx, void* stream, const t2v_gen_desc* 
     // are the image and flow branches after it.  Each branch is a chain of ~50-100 kernels, a third of them
     // small (norm finalize / apply, Winograd transforms: 5-13 us, launch- and tail-bound); run side by side
     // the other branch's GEMM blocks fill those gaps.  T2V_STREAMS=1 runs everything on the caller's stream.
-    static const bool two_streams = !(getenv("T2V_STREAMS") && atoi(getenv("T2V_STREAMS")) == 1);
+    const bool two_streams = options().streams != 1;
     hipStream_t s2 = two_streams ? ctx->side : s;
     auto fork = [&]() -> int {
         if (!two_streams) return T2V_OK;
@@ -492,9 +453,6 @@ int t2v_generator_forward_batch(t2v_ctx* ctx, void* stream, const t2v_gen_desc* 
     Runner r{ctx, s, *d, specs, layers, b, batch};
     Runner r2{ctx, s2, *d, specs, layers, b, batch};
     r2.sc = two_streams ? 1 : 0;
-    // arrival counters of the producers that finalize their own norm statistics (they leave them zeroed; this
-    // clears whatever an aborted frame, or the allocator, left behind)
-    if (Runner::ticket_on()) T2V_HIP_CHECK(hipMemsetAsync(b.tickets[0], 0, 2 * b.ticket_ints * sizeof(int), s));
 
     Ptrs pose{}, prevp{};
     for (int im = 0; im < batch; ++im) {

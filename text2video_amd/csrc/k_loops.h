@@ -28,4 +28,24 @@ __device__ __forceinline__ void loader_k_loop(int kb, int ke, Issue&& issue_stag
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// The consumer side of the fixed-grid kernels' accumulator hand-over (conv_igemm.hip: wino_gemm_sk_kernel, conv_wgrad.hip:
+// wino_wgrad_sk_kernel): poll the producer wave's tag with agent-scope loads until it shows this launch's value.  The
+// producer (block b - 8, or b - 8 * half) was dispatched before this block and published before anything it waits for, so
+// the wait is normally over before it starts.  It is bounded by TIME -- one second of the 100 MHz constant clock -- not by
+// a poll count: after that the caller poisons its tile with NaNs and the sticky error word `err` (pinned host memory,
+// t2v_internal.h: async_error_word) tells the host, which reports T2V_ERR_HANDOVER from its next entry point and falls
+// back to one block per tile.  Returns true on a time-out.
+constexpr unsigned long long kHandoverTimeoutTicks = 100000000ull;
+__device__ __forceinline__ bool handover_wait(const unsigned long long* flag, unsigned long long tag, unsigned* err, int lane) {
+    if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == tag) return false;
+    const unsigned long long t0 = wall_clock64();
+    for (;;) {
+        __builtin_amdgcn_s_sleep(4);
+        if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == tag) return false;
+        if (wall_clock64() - t0 > kHandoverTimeoutTicks) break;
+    }
+    if (err && lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return true;
+}
+
 }  // namespace t2v

@@ -35,6 +35,40 @@ void set_error(const char* fmt, ...);
     } while (0)
 
 // ---------------------------------------------------------------------------------------------
+// Switches read from the environment ONCE (the first t2v_create, or the first call that needs them) -- never on a launch
+// path.  t2v_reload_env() reads them again: tests and A/B runs that flip a variable inside one process call it.
+// ---------------------------------------------------------------------------------------------
+struct Options {
+    int wino_gemm_sk;        // T2V_WINO_GEMM_SK: 0 off, 1 where it pays (default), 2 wherever the shape allows
+    int wino_gemm_sk_wide;   // T2V_WINO_GEMM_SK_WIDE: 192x64 tiles for tile rows that are whole 192s (default 1)
+    int wino_gemm_sk_half;   // T2V_WINO_GEMM_SK_HALF: second schedule for R + 1/2 rounds (default 1)
+    int wgrad_sk;            // T2V_WGRAD_SK: as wino_gemm_sk, for the Winograd-domain weight gradient
+    int wgrad_sk_half;       // T2V_WGRAD_SK_HALF
+    int wgrad_combine;       // T2V_WGRAD_COMBINE: in-kernel combine of split partials (default 1)
+    int wgrad_combine_max;   // T2V_WGRAD_COMBINE_MAX: ... up to this many partials (default 4)
+    int wgrad_fold;          // T2V_WGRAD_FOLD: taps folded into the tile for narrow layers (default 1)
+    int conv_tile;           // T2V_CONV_TILE: -1 auto (default), 0 / 2 force 128x128 / 64x64 tiles where both exist
+    int conv_ring;           // T2V_CONV_RING: 0 auto (default), 2 / 3 ring depth
+    int conv_head, conv_cout1, conv_stem;   // T2V_CONV_HEAD / _COUT1 / _STEM: the dedicated kernels (default 1)
+    int chain_lazy;          // T2V_CHAIN_LAZY: ResnetBlock chains apply their norms in the next input transform (default 1)
+    int streams;             // T2V_STREAMS: 1 = the generator on the caller's stream only (default 2)
+};
+const Options& options();
+void options_reload();
+
+// The fixed-grid kernels hand accumulators from block b - 8 (b - 8 * half) to block b inside one launch.  That cannot
+// deadlock as long as workgroups are dispatched in index order (the producer publishes before anything it waits for).  Two
+// guards: (i) a self-test at the first t2v_create per process launches an over-subscribed grid whose blocks draw a ticket as
+// they start and checks ticket[b - 8] < ticket[b]; (ii) a consumer whose producer's tag does not show up within the poll
+// bound poisons its tile with NaNs AND raises a sticky error word in pinned host memory.  check_async_errors() -- called by
+// every entry point that may launch a fixed-grid kernel, and exported as t2v_check_async_errors -- then returns
+// T2V_ERR_HANDOVER once and switches the process to one block per tile (fixed_grid_enabled() == false).
+unsigned* async_error_word();      // device-visible; nullptr before the first t2v_create
+bool fixed_grid_enabled();
+void fixed_grid_disable(const char* why);
+int check_async_errors();
+
+// ---------------------------------------------------------------------------------------------
 // implicit-GEMM convolution kernel parameters (conv_igemm.hip)
 //   GEMM view:  D[m][n] = sum_k A[m][k] * B[n][k]
 //     m = pixel of the "GEMM pixel grid" (Hm x Wm), n = output channel,
@@ -150,9 +184,7 @@ int launch_winograd4_dgrad_output(hipStream_t s, const float* dV, float* dxp, in
 int launch_winograd4_dy(hipStream_t s, const float* dy, float* Md, int Ho, int Wo, int N, int dy_cs, int batch, int image);
 int launch_winograd4_dw(hipStream_t s, const float* dU, float* dw, int Cout, int Cin, int Cout_p, int Kp, int accumulate);
 int launch_winograd4_output(hipStream_t s, const float* Mm, const float* bias, float* y, float* stats, int H, int W, int N,
-                            int lrelu, float slope, int nimg = 1, int* tickets = nullptr, float* mean_rstd = nullptr,
-                            float eps = 1e-5f);
-bool winograd4_ticket_ok(int H, int W);
+                            int lrelu, float slope, int nimg = 1);
 int launch_channel_sum(hipStream_t s, const float* x, long npix, int C, int cs, float* scratch, float* out);
 
 // 7x7 reflect-padded head convolution with <= 3 output channels (conv_head.hip)
@@ -205,6 +237,7 @@ struct SkGemm {
     const float* b;        // [groups][N][K]
     float* c;              // [groups][T][c_cs]
     float* scratch;        // wino_gemm_sk_scratch_floats() floats, any content
+    unsigned* err;         // sticky error word a timed-out hand-over raises (async_error_word())
     long a_group_stride;   // floats between the groups of a
     int groups, T, K, N, c_cs;
 };
@@ -235,12 +268,6 @@ int launch_inorm_finalize_tiles(hipStream_t s, const float* stats, int edge, int
                                 float* mean_rstd, int batch, double* scratch = nullptr, const RunningUpdate* ru = nullptr);
 int launch_inorm_finalize(hipStream_t s, const float* stats, int nparts, int mtiles, int BM, int M, int C,
                           float eps, float* mean_rstd, double* scratch = nullptr, const RunningUpdate* ru = nullptr);
-// finalize folded into the apply pass (layers with <= 128 partials per channel); geometry arguments as the finalize
-// launchers derive them: conv partials (nparts, mtiles, BM, M, wm = 0), stem tiles (wm = -edge), Winograd (wm = 2 | 4)
-bool inorm_fused_ok(int nparts, int C);
-int launch_inorm_apply_partials(hipStream_t s, const float* x, const float* stats, int nparts, int mtiles, int BM, int M,
-                                int wm, int H, int W, int C, float eps, const float* gamma, const float* beta,
-                                const float* res1, const float* res2, float* y, long npix, int relu);
 int launch_inorm_apply(hipStream_t s, const float* x, const float* mean_rstd, const float* gamma,
                        const float* beta, const float* res1, const float* res2, float* y, long npix, int C,
                        int relu, int nimg = 1);

@@ -146,7 +146,6 @@ int launch_winograd_input(hipStream_t s, const float* x, float* V, int H, int W,
 // slots, `mask` marks the ones inside the image (all of them except in ragged / padding tiles).  Two passes,
 // tree-summed (exact for constant maps over power-of-two counts), written as the partial inorm_finalize
 // merges; the partial's pixel count is recomputed there from the geometry.
-template <bool PUBLISH = false>
 __device__ __forceinline__ void block_stats_128(const float (&val)[32], unsigned mask, float (*sh)[64], int tl, int cl,
                                                 bool ok, float2* __restrict__ stats, int N, int n) {
     if (stats == nullptr) return;
@@ -175,10 +174,7 @@ __device__ __forceinline__ void block_stats_128(const float (&val)[32], unsigned
         if (pass == 0) {
             mean_b = tot * inv_cnt;
         } else if (tl == 0 && ok) {
-            if (PUBLISH)   // read back inside this launch by the block that finalizes the layer's statistics
-                publish_partial(stats + (size_t)blockIdx.x * N + n, make_float2(mean_b, tot));
-            else
-                stats[(size_t)blockIdx.x * N + n] = make_float2(mean_b, tot);
+            stats[(size_t)blockIdx.x * N + n] = make_float2(mean_b, tot);
         }
     }
 }
@@ -488,25 +484,16 @@ int launch_winograd4_input_lazy(hipStream_t s, const float* x, float* V, int H, 
 // y = A^T M A + bias; block = 64 channels x 4 tile lanes, 8 tiles (2 per thread) = 128 output pixels
 // blockIdx.z = image of a batch: its tiles are rows [image*T, (image+1)*T) of the batch-wide M ([36][Tt][N], packed: only
 // the total is padded), its map / statistics partials (Tp/8 per image) / (mean, rstd) table follow the previous image's.
-// TICKET: the last block to finish a (image, 64-channel group) -- an atomic ticket per group -- pools that group's
-// partials itself, in inorm_finalize_kernel's summation order, and writes (mean, rstd): the norm layer's finalize
-// without a launch of its own (partials published write-through, read back with sc1 loads: norm_pool.h).
-template <bool TICKET>
 __global__ __launch_bounds__(256) void winograd4_output_kernel(const float* __restrict__ Mm, const float* __restrict__ bias,
                                                                float* __restrict__ y, float2* __restrict__ stats, int H,
                                                                int W, int N, int TW, int T, int Tp, int lrelu,
-                                                               float slope, int Tt, int* __restrict__ tickets,
-                                                               float2* __restrict__ mean_rstd, float eps) {
+                                                               float slope, int Tt) {
     __shared__ float sh[4][64];
     {
         const long im = blockIdx.z;
         Mm += im * T * N;                        // packed layout: image i owns rows [i*T, (i+1)*T) of every position's [Tt][N] matrix
         y += im * H * W * N;
         if (stats) stats += im * (Tp / 8) * N;
-        if (TICKET) {
-            tickets += im * gridDim.y;
-            mean_rstd += im * N;
-        }
     }
     const int cl = threadIdx.x & 63, tl = threadIdx.x >> 6;
     const int n = blockIdx.y * 64 + cl;
@@ -542,34 +529,15 @@ __global__ __launch_bounds__(256) void winograd4_output_kernel(const float* __re
                 }
             }
     }
-    block_stats_128<TICKET>(out, mask, sh, tl, cl, ok, stats, N, n);
-    if (TICKET) {
-        if (!last_arriver(tickets + blockIdx.y, gridDim.x, reinterpret_cast<int*>(&sh[0][0]))) return;
-        if (tl == 0 && ok) mean_rstd[n] = pool_partials_ordered(stats, gridDim.x, N, n, gridDim.x, 0, H * W, 4, H, W, eps);
-    }
+    block_stats_128(out, mask, sh, tl, cl, ok, stats, N, n);
 }
-// nimg images: M is [36][nimg*Tp][N]; y, stats, mean_rstd hold the images back to back.  tickets != nullptr (with
-// stats and mean_rstd): the kernel also finalizes the norm statistics (needs Tp/8 <= kTicketMaxParts partials per
-// channel -- winograd4_ticket_ok -- and zeroed tickets: nimg * ceil(N/64) ints, left zeroed again).
-bool winograd4_ticket_ok(int H, int W) {
-    const int TW = (W + 3) / 4, T = ((H + 3) / 4) * TW, Tp = wino_pad_tiles(T);
-    return Tp / 8 <= kTicketMaxParts;
-}
+// nimg images: M is [36][nimg*T padded][N]; y and stats hold the images back to back
 int launch_winograd4_output(hipStream_t s, const float* Mm, const float* bias, float* y, float* stats, int H, int W, int N,
-                            int lrelu, float slope, int nimg, int* tickets, float* mean_rstd, float eps) {
+                            int lrelu, float slope, int nimg) {
     const int TW = (W + 3) / 4, T = ((H + 3) / 4) * TW, Tp = wino_pad_tiles(T);
     const dim3 grid(Tp / 8, (N + 63) / 64, nimg);
-    if (tickets) {
-        T2V_REQUIRE(stats && mean_rstd && Tp / 8 <= kTicketMaxParts, "winograd4_output: ticket finalize needs statistics and "
-                    "<= %d partials per channel", kTicketMaxParts);
-        hipLaunchKernelGGL(winograd4_output_kernel<true>, grid, dim3(256), 0, s, Mm, bias, y, reinterpret_cast<float2*>(stats),
-                           H, W, N, TW, T, Tp, lrelu, slope, wino_pad_tiles(nimg * T), tickets,
-                           reinterpret_cast<float2*>(mean_rstd), eps);
-    } else {
-        hipLaunchKernelGGL(winograd4_output_kernel<false>, grid, dim3(256), 0, s, Mm, bias, y,
-                           reinterpret_cast<float2*>(stats), H, W, N, TW, T, Tp, lrelu, slope, wino_pad_tiles(nimg * T), nullptr,
-                           nullptr, eps);
-    }
+    hipLaunchKernelGGL(winograd4_output_kernel, grid, dim3(256), 0, s, Mm, bias, y, reinterpret_cast<float2*>(stats), H, W, N,
+                       TW, T, Tp, lrelu, slope, wino_pad_tiles(nimg * T));
     T2V_HIP_CHECK(hipGetLastError());
     return T2V_OK;
 }

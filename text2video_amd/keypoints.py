@@ -48,16 +48,26 @@ def _affine(x, a, b):
     return a * x + b
 
 
-try:    # MINPACK's lmdif, the routine scipy.optimize.curve_fit(method='lm') ends up in
-    from scipy.optimize import _minpack as _MINPACK
-    _EPS = float(np.finfo(np.float64).eps)
-except ImportError:      # pragma: no cover -- SciPy layouts without the private module: curve_fit itself
-    _MINPACK = None
+_EPS = float(np.finfo(np.float64).eps)
+_MINPACK = False     # not looked up yet
+
+
+def _minpack():
+    """MINPACK's lmdif, the routine scipy.optimize.curve_fit(method='lm') ends up in.  Imported on first use: the frame
+    loop's own process rasterises nothing when the worker pool does (SciPy costs ~0.2 s of its start-up)."""
+    global _MINPACK
+    if _MINPACK is False:
+        try:
+            from scipy.optimize import _minpack as m
+            _MINPACK = m
+        except ImportError:      # pragma: no cover -- SciPy layouts without the private module: curve_fit itself
+            _MINPACK = None
+    return _MINPACK
 
 
 def _fit_line(u, v, exact_fit):
     if exact_fit:
-        if _MINPACK is not None:
+        if _minpack() is not None:
             # curve_fit(_affine, u, v) = leastsq(p -> _affine(u, *p) - v, p0 = ones(2)) with leastsq's defaults
             # (ftol = xtol = 1.49012e-8, gtol = 0, maxfev = 200*(n+1), epsfcn = eps, factor = 100, no scaling), which
             # calls _minpack._lmdif; calling it directly returns the SAME bits (tests/test_cpu_oracle_and_host.py

@@ -201,6 +201,7 @@ def run_test(opt, model=None, device=None, dataset=None):
         def finish(p):
             ev, host, a_path, real_a = p
             ev.synchronize()
+            ops.check_async_errors()      # e.g. a fixed-grid hand-over that timed out while this frame was computed
             vis.save_images({"real_A": real_a, "fake_B": host.numpy()[..., :3].copy()}, a_path)
 
         def close_unit(L):

@@ -30,6 +30,22 @@ def context(device=None):
     return c
 
 
+def reload_env():
+    """The library reads its T2V_* switches once (t2v_create); a process that changes one afterwards (tests, A/B runs)
+    calls this."""
+    _lib.load().t2v_reload_env()
+
+
+def check_async_errors():
+    """Raise if a kernel of an EARLIER launch reported an error it could only report after the fact (a fixed-grid
+    accumulator hand-over that timed out: that launch's output holds NaNs).  Call after synchronising."""
+    check(_lib.load().t2v_check_async_errors(), "check_async_errors")
+
+
+def fixed_grid_enabled():
+    return bool(_lib.load().t2v_fixed_grid_enabled())
+
+
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 

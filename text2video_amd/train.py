@@ -177,45 +177,6 @@ def wgrad_join():
         _WG_SIDE["pending"] = False
 
 
-# ---- a second stream for the generator's independent halves (experiment: T2V_TRAIN_TWO_STREAMS=1) ----------------------------
-# The previous-frame encoder next to the pose encoder, the flow branch next to the image branch -- what the inference path
-# does inside t2v_generator_forward.  Autograd runs a node's backward on the stream its forward ran on, so the backward
-# pass of those halves moves over with them.
-_FWD_SIDE = {"stream": None}
-
-
-def two_streams_on(t):
-    return t.is_cuda and os.environ.get("T2V_TRAIN_TWO_STREAMS", "0") == "1"
-
-
-@contextlib.contextmanager
-def fwd_fork(after=None, *tensors):
-    """kernels launched in this scope run on the forward side stream, after `after` (an event of the current stream;
-    default: everything it holds so far); `tensors` (allocated on the current stream) are kept for the side stream"""
-    if _FWD_SIDE["stream"] is None:
-        _FWD_SIDE["stream"] = torch.cuda.Stream()
-    fs = _FWD_SIDE["stream"]
-    if after is None:
-        fs.wait_stream(torch.cuda.current_stream())
-    else:
-        fs.wait_event(after)
-    for t in tensors:
-        if t is not None:
-            t.record_stream(fs)
-    with torch.cuda.stream(fs):
-        yield
-
-
-def fwd_join(*tensors):
-    """the current stream waits for the forward side stream; `tensors` (allocated there) are kept for the current stream"""
-    # (always, once the stream exists: its backward nodes are enqueued by the autograd engine, not through fwd_fork)
-    if _FWD_SIDE["stream"] is not None and torch.cuda.current_stream() != _FWD_SIDE["stream"]:
-        torch.cuda.current_stream().wait_stream(_FWD_SIDE["stream"])
-    for t in tensors:
-        if t is not None:
-            t.record_stream(torch.cuda.current_stream())
-
-
 def _batched_winograd_wgrad(w, x, dc, fdesc, slot=None, info=None):
     """Weight gradient of one use of a layer whose forward counted `w._t2v_wg_images` images in this graph: the
     images are transformed into their slots of a workspace kept on the weight; the node that brings the last ones
@@ -274,7 +235,6 @@ def flush_pending_weight_gradients(params, grads):
     those gradients filled in."""
     out = list(grads)
     wgrad_join()
-    fwd_join()
     for i, p in enumerate(params):
         st = getattr(p, "_t2v_wg_state", None)
         if st is None:
@@ -772,20 +732,9 @@ class TrainableGenerator(torch.nn.Module):
             return h
 
         nb_enc, nb_res = s.n_blocks - s.n_blocks // 2, s.n_blocks // 2
-        two = two_streams_on(pose)
-        ev_d = None
-        if two:
-            # the two encoders side by side: the side stream waits only for what was there BEFORE the pose encoder was
-            # enqueued (the keys are consumed in upstream's order, so the host enqueues the pose encoder first)
-            ev0 = torch.cuda.current_stream().record_event()
-            e_pose = encoder(pose, s.input_nc, nb_enc)
-            with fwd_fork(ev0, prev):
-                e_prev = encoder(prev, s.prev_nc, nb_enc)
-            fwd_join(e_prev)
-            d = e_pose + e_prev
-            ev_d = torch.cuda.current_stream().record_event()
-        else:
-            d = encoder(pose, s.input_nc, nb_enc) + encoder(prev, s.prev_nc, nb_enc)
+        # (the independent halves -- the two encoders, the image and flow branches -- on a second stream, as the inference
+        # path runs them, were tried in round 3: +0.7 % with the fixed-grid kernels on; removed)
+        d = encoder(pose, s.input_nc, nb_enc) + encoder(prev, s.prev_nc, nb_enc)
         img_feat = decoder(resblocks(d, nb_res))
         ck, _, _ = next(it)
         raw = conv_block(img_feat, self.p(ck + ".weight"), self.p(ck + ".bias"),
@@ -796,17 +745,14 @@ class TrainableGenerator(torch.nn.Module):
             # raw-only first frame and no loss reads its flow / weight maps: the flow branch would be a dead part of
             # the graph (its batched weight-gradient slots would never be reduced) -- do not run it
             return (raw, raw, None) if full else raw
-        with (fwd_fork(ev_d, d) if two else contextlib.nullcontext()):     # the flow branch beside the image branch
-            flow_feat = decoder(resblocks(d, nb_res))
-            (kf, kw), _, _ = next(it)
-            # model_final_flow (2 outputs, x20) and model_final_w (1 output, sigmoid) read the same features: one
-            # 3-output conv, as in the inference path; autograd's cat splits the gradient back onto the two parameters
-            w3 = _CatParams.apply(self.p(kf + ".weight"), self.p(kw + ".weight"))
-            b3 = _CatParams.apply(self.p(kf + ".bias"), self.p(kw + ".bias"))
-            fw = conv_block(flow_feat, w3, b3, ops.conv_desc(H, W, G, 3, 7, 1, 3, ops.PAD_REFLECT), norm=None, relu=0,
-                            act=ops.ACT_FLOW_W, slope=20.0 * (2 ** s.scale))
-        if two:
-            fwd_join(fw)
+        flow_feat = decoder(resblocks(d, nb_res))
+        (kf, kw), _, _ = next(it)
+        # model_final_flow (2 outputs, x20) and model_final_w (1 output, sigmoid) read the same features: one
+        # 3-output conv, as in the inference path; autograd's cat splits the gradient back onto the two parameters
+        w3 = _CatParams.apply(self.p(kf + ".weight"), self.p(kw + ".weight"))
+        b3 = _CatParams.apply(self.p(kf + ".bias"), self.p(kw + ".bias"))
+        fw = conv_block(flow_feat, w3, b3, ops.conv_desc(H, W, G, 3, 7, 1, 3, ops.PAD_REFLECT), norm=None, relu=0,
+                        act=ops.ACT_FLOW_W, slope=20.0 * (2 ** s.scale))
         fake = raw if use_raw_only else _WarpComposite.apply(raw, fw, prev, s.prev_nc - 3)
         return (fake, raw, fw) if full else fake
 
@@ -1188,7 +1134,6 @@ class GradBuckets:
         # the collective is ordered behind the current stream: let that include the side streams' gradients -- and the main
         # stream's, when this node runs on the forward side stream
         wgrad_join()
-        fwd_join()
         if self._main is not None and torch.cuda.current_stream() != self._main:
             torch.cuda.current_stream().wait_stream(self._main)
         lo, hi = self.bounds[b]
@@ -1217,7 +1162,6 @@ class GradBuckets:
         e.g. the cat of the two flow-head convs; a flushed Winograd reduction) are added into their slots; then every
         bucket not yet launched goes out, in order."""
         wgrad_join()
-        fwd_join()
         for i, g in enumerate(grads):
             if g is not None:
                 sl = self.slots[i]
@@ -1233,7 +1177,6 @@ class GradBuckets:
         parameter, as torch 0.4.1's does).  Returns the bytes exchanged."""
         import torch.distributed as dist
         wgrad_join()
-        fwd_join()
         for work, buf, avg, shard in self._works:
             work.wait()
             if shard is not None:
@@ -1610,6 +1553,7 @@ class Vid2VidTrainer:
         if keys:
             for k, v in zip(keys, torch.stack([losses[k].reshape(()) for k in keys]).tolist()):
                 losses[k] = v
+            ops.check_async_errors()      # (the read-back above synchronised: errors the step's kernels could only flag)
         return losses, prev
 
     def update_learning_rate(self, epoch):
