@@ -71,8 +71,9 @@ def resample(image, flow):
     the last row / column, this rule only on the last) or exactly on an integer position, where the bilinear
     interpolant has a kink and either one-sided derivative is "the" gradient."""
     b, c, h, w = image.shape
-    hor = torch.linspace(-1.0, 1.0, w).view(1, 1, 1, w).expand(b, -1, h, -1)
-    ver = torch.linspace(-1.0, 1.0, h).view(1, 1, h, 1).expand(b, -1, -1, w)
+    # (on the image's device and in its dtype: the tests also evaluate the oracle on the GPU and in fp64)
+    hor = torch.linspace(-1.0, 1.0, w, dtype=image.dtype, device=image.device).view(1, 1, 1, w).expand(b, -1, h, -1)
+    ver = torch.linspace(-1.0, 1.0, h, dtype=image.dtype, device=image.device).view(1, 1, h, 1).expand(b, -1, -1, w)
     grid = torch.cat([hor, ver], 1)
     flow = torch.cat([flow[:, 0:1] / ((w - 1.0) / 2.0), flow[:, 1:2] / ((h - 1.0) / 2.0)], 1)
     final = grid + flow
@@ -103,8 +104,8 @@ def resample(image, flow):
 def resample_modern(image, flow):
     """the same operation through modern torch's F.grid_sample (cross-check of `resample`)"""
     b, c, h, w = image.shape
-    hor = torch.linspace(-1.0, 1.0, w).view(1, 1, 1, w).expand(b, -1, h, -1)
-    ver = torch.linspace(-1.0, 1.0, h).view(1, 1, h, 1).expand(b, -1, -1, w)
+    hor = torch.linspace(-1.0, 1.0, w, dtype=image.dtype, device=image.device).view(1, 1, 1, w).expand(b, -1, h, -1)
+    ver = torch.linspace(-1.0, 1.0, h, dtype=image.dtype, device=image.device).view(1, 1, h, 1).expand(b, -1, -1, w)
     grid = torch.cat([hor, ver], 1)
     flow = torch.cat([flow[:, 0:1] / ((w - 1.0) / 2.0), flow[:, 1:2] / ((h - 1.0) / 2.0)], 1)
     final = (grid + flow).permute(0, 2, 3, 1)
@@ -345,7 +346,7 @@ class Vid2VidInferenceRef:
         first = self.fake_B_prev is None
         if first:
             assert self.no_first_img, "first-frame generator not part of the reference's flag set"
-            z = torch.zeros(tG - 1, self.output_nc, H, W, dtype=A.dtype)
+            z = torch.zeros(tG - 1, self.output_nc, H, W, dtype=A.dtype, device=A.device)
             self.fake_B_prev = self._pyr(z)
         real_A = self._pyr(A)
         use_raw_only = self.no_first_img and first

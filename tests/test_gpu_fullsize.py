@@ -1,9 +1,9 @@
 """GPU tests at BASELINE.json's full sizes: configs[3] (1024x1024, single-scale and two-scale generator), the real fadg0
 geometries of configs[0] (512x680 / 512x320 after scaleHeight 512), and one configs[4]-sized train step (512x512, 2
 frames).  Where a CPU-oracle frame is affordable (a few seconds of host time) the frame is compared with it,
-teacher-forced; otherwise size-independent properties carry the check: bit-reproducibility, the compositor identity,
-and agreement between the two independent convolution kernel families (Winograd vs direct implicit GEMM), each of which
-is oracle-checked at small sizes in test_gpu_generator.py / test_gpu_ops.py."""
+teacher-forced; the sizes the CPU cannot reach (the single-scale 1024x1024 frame, the 512x512 train step) meet the oracle
+evaluated on the GPU in tests/test_gpu_device_oracle.py, and keep their size-independent properties here
+(bit-reproducibility, the compositor identity)."""
 import numpy as np
 import pytest
 import torch
@@ -68,34 +68,23 @@ def test_config3_two_scale_1024_frame_matches_oracle(no_flow):
         assert (fifo - ref.fake_B_prev[lvl]).abs().max().item() <= TOL
 
 
-def test_config3_single_scale_1024_properties():
-    """configs[3], single-scale G0 at 1024x1024 (10.3 / 13.3 TFLOP per frame: a CPU-oracle frame takes minutes).
-    Properties: frames are bit-reproducible; the Winograd path (28 + 8 ResnetBlock convs on F(4x4,3x3)) and the direct
-    implicit-GEMM path (conv_algo = 1) -- two independent kernel families -- agree to <= 1e-3 per pixel on the same
-    frame, with and without flow; the compositor identity out = raw*w + warp*(1-w) holds on the returned taps."""
+def test_config3_single_scale_1024_frames_are_reproducible_and_composite_exactly():
+    """configs[3], single-scale G0 at 1024x1024: size-independent properties (parity with the oracle at this size:
+    tests/test_gpu_device_oracle.py).  Frames are bit-reproducible; the compositor identity out = raw*w + warp*(1-w) holds on
+    the returned taps."""
     from text2video_amd import ops
     H = W = 1024
     poses = _pose_seq(3, H, W, seed=12)
     pose = ops.nchw_to_nhwc(poses.reshape(9, H, W).to("cuda:0"))
     prev = torch.zeros(H, W, 8, device="cuda:0")
     prev[..., :6] = _prev_frames(H, W, 6).reshape(6, H, W).permute(1, 2, 0).cuda()
-    for no_flow in (True, False):
-        _, (wino,) = _full_nets(1, no_flow)
-        _, (direct,) = _full_nets(1, no_flow, conv_algo=1)
-        want = ("out",) if no_flow else ("out", "raw", "flow_w")
-        a1 = wino.forward(pose, prev, False, want=want)
-        a2 = wino.forward(pose, prev, False, want=want)
-        b = direct.forward(pose, prev, False, want=want)
-        assert torch.equal(a1["out"], a2["out"]) and torch.isfinite(a1["out"]).all()
-        err = (a1["out"] - b["out"]).abs().max().item()
-        print("single-scale 1024x1024 %s: Winograd vs direct max|delta| = %.3g" % ("no-flow" if no_flow else "flow", err))
-        assert err <= TOL and a1["out"][..., :3].abs().max().item() <= 1.0 and a1["out"][..., :3].std().item() > 0.01
-        if not no_flow:
-            out = ops.flow_warp_composite(a1["raw"], a1["flow_w"], prev, 3)
-            assert torch.equal(out, a1["out"])
-            assert (a1["flow_w"][..., :2] - b["flow_w"][..., :2]).abs().max().item() <= 5e-3   # pixels, after the x20
-        del wino, direct
-        torch.cuda.empty_cache()
+    _, (wino,) = _full_nets(1, False)
+    want = ("out", "raw", "flow_w")
+    a1 = wino.forward(pose, prev, False, want=want)
+    a2 = wino.forward(pose, prev, False, want=want)
+    assert torch.equal(a1["out"], a2["out"]) and torch.isfinite(a1["out"]).all()
+    assert a1["out"][..., :3].abs().max().item() <= 1.0 and a1["out"][..., :3].std().item() > 0.01
+    assert torch.equal(ops.flow_warp_composite(a1["raw"], a1["flow_w"], prev, 3), a1["out"])
 
 
 @pytest.mark.parametrize("H,W", [(512, 680), (512, 320)], ids=["512x680", "512x320"])
@@ -179,9 +168,8 @@ def test_config4_train_step_512_two_frames():
     """configs[4] per-GPU work: one train step at 512x512 with 2 frames (generator with flow branch + 2-scale
     discriminator + face discriminator).  Losses finite; the step is reproducible (two trainers from the same seed
     give the same losses and the same updated weights, bit for bit); every generator parameter receives a finite,
-    gradient (non-zero except for the conv biases a norm layer cancels); and the gradients of the Winograd path agree with those of the direct implicit-GEMM path
-    (T2V_CONV_ALGO=1) -- both oracle-checked at 64x64 in test_gpu_train_step.py."""
-    import os
+    gradient (non-zero except for the conv biases a norm layer cancels).  Parity of this very step -- every loss, every
+    parameter gradient of G, D and D_f -- against the oracle: tests/test_gpu_device_oracle.py."""
     from text2video_amd import train as T
     from text2video_amd.options import TrainOptions
     opt = TrainOptions().parse(["--name", "t", "--dataset_mode", "pose", "--input_nc", "3", "--openpose_only", "--num_D", "2",
@@ -199,24 +187,19 @@ def test_config4_train_step_512_two_frames():
     prev0[..., :6] = torch.tanh(torch.from_numpy(rng.standard_normal((1, H, W, 6)).astype(np.float32))).cuda()
     boxes = [(64, 192, 192, 320)] * 2
 
-    def one(algo):
-        if algo:
-            os.environ["T2V_CONV_ALGO"] = algo
-        try:
-            tr = T.Vid2VidTrainer(opt, "cuda:0", seed=5)
-            before = [p.detach().clone() for p in tr.optG.params]
-            losses, _ = tr.train_step(pose, real, boxes, prev0.clone(), real_prev=real_prev)
-            grads = [p.grad.clone() if p.grad is not None else None for p in tr.optG.params]
-            after = [p.detach().clone() for p in tr.optG.params]
-            names = list(tr.G.named_upstream_parameters())
-            del tr
-            torch.cuda.empty_cache()
-            return losses, grads, before, after, names
-        finally:
-            os.environ.pop("T2V_CONV_ALGO", None)
+    def one():
+        tr = T.Vid2VidTrainer(opt, "cuda:0", seed=5)
+        before = [p.detach().clone() for p in tr.optG.params]
+        losses, _ = tr.train_step(pose, real, boxes, prev0.clone(), real_prev=real_prev)
+        grads = [p.grad.clone() if p.grad is not None else None for p in tr.optG.params]
+        after = [p.detach().clone() for p in tr.optG.params]
+        names = list(tr.G.named_upstream_parameters())
+        del tr
+        torch.cuda.empty_cache()
+        return losses, grads, before, after, names
 
-    l1, g1, b1, a1, names = one(None)
-    l2, g2, _, a2, _ = one(None)
+    l1, g1, b1, a1, names = one()
+    l2, g2, _, a2, _ = one()
     for k, v in l1.items():
         assert np.isfinite(v), k
         assert v == l2[k], (k, v, l2[k])
@@ -229,36 +212,19 @@ def test_config4_train_step_512_two_frames():
             assert (w1 - w0).abs().max().item() > 0, n
     for x, y in zip(a1, a2):
         assert torch.equal(x, y)
-    # Winograd path vs direct path.  At this width (1024-channel bottleneck, instance norm after every conv) the
-    # parameter gradient is ill-conditioned in fp32 -- the CPU oracle's own fp32 gradient sits 3e-3 (median) to 4e-2
-    # (worst tensor) away from its fp64 evaluation already for the generator alone
-    # (test_fullwidth_gradient_error_is_within_the_fp32_oracles_own below) and the GAN / flow losses of this step add
-    # more cancellation -- so two correct fp32 evaluations agree only at the level measured here, not at 1e-3
-    ld, gd, _, _, _ = one("1")
-    errs = {}
-    for n, x, y in zip(names, g1, gd):
-        scale = y.norm().item()
-        if y.abs().max().item() <= 1e-7:
-            continue       # conv biases in front of a norm layer: mathematically zero gradient
-        errs[n] = (x - y).norm().item() / scale
-    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:3]
-    print("512x512 train step, Winograd vs direct gradients (relative L2 per tensor): worst", ["%s %.1e" % kv for kv in worst],
-          "median %.1e" % float(np.median(list(errs.values()))))
-    assert float(np.median(list(errs.values()))) <= 0.1 and max(errs.values()) <= 0.3
-    for k in l1:
-        assert abs(l1[k] - ld[k]) <= 2e-3 * max(1.0, abs(ld[k])), k
 
 
-@pytest.mark.parametrize("H", [256, 512])
+@pytest.mark.parametrize("H", [256])
 def test_fullwidth_gradient_error_is_within_the_fp32_oracles_own(H):
     """Conditioning-normalised parity of the backward pass at full width (ngf 128, 9 blocks, 256x256: the
     ResnetBlock convs, their data gradients and weight gradients all take the Winograd F(4x4,3x3) path): the HIP
     gradient's distance from an fp64 evaluation of the oracle, per parameter tensor, against the distance of the fp32
     CPU oracle from the same fp64 evaluation.  The HIP path must be as good as "another fp32 implementation": within
     a small factor of the oracle's own rounding noise (measured: 1.9x median, 2.8x at the 90th percentile).
-    512x512 = the config-5 frame size: the 64x64x1024 bottleneck is where the fixed-grid kernels run (forward GEMM stage,
-    transposed data gradient, Winograd-domain weight-gradient reduction; the step's batched-gradient scope is on so that the
-    data gradient takes the transposed algorithm) -- the same bound holds for them against the independent oracle."""
+    At 512x512 -- the config-5 frame size, where the 64x64x1024 bottleneck runs the fixed-grid kernels -- the same bound is
+    asserted against the oracle evaluated on the GPU, with and without the flow branch
+    (tests/test_gpu_device_oracle.py::test_fullwidth_generator_gradient_512_against_the_device_oracle); this CPU-oracle variant
+    is what licenses that reference."""
     from oracle.generator_ref import CompositeGenerator
     from text2video_amd import ops
     from text2video_amd import train as T
