@@ -174,6 +174,13 @@ def _step_setup(size, ngf, n_down, n_blocks, ndf, seed):
     tr = T.Vid2VidTrainer(opt, DEV, seed=seed)
     tr.optG.step = lambda: None
     tr.optD.step = lambda: None
+    # flows of a few pixels, as a trained network predicts: a random-init flow head x20 throws every sample tens of pixels
+    # away, where a 1e-6 difference in the flow picks other bilinear taps and two correct fp32 evaluations stop agreeing
+    with torch.no_grad():
+        for k, p in tr.G.named_upstream_parameters().items():
+            if k.startswith("model_final_flow."):
+                p.mul_(0.1)
+                T.invalidate_packs(p)
 
     def load(mod, named):
         sd = {k: v.detach().cpu().clone() for k, v in named.items()}
@@ -217,12 +224,14 @@ def _oracle_step_on(mods, clip, boxes, device, dtype):
     return oracle_train_step(mods[0], mods[1], mods[2], clip[0], clip[1], clip[2], clip[3], boxes)
 
 
-def _rel_err(g, ref):
-    """per tensor: max |g - ref| / max |ref| over the tensors whose reference gradient is not (mathematically) zero"""
+def _rel_err(g, ref, zero_ref=None):
+    """per tensor: max |g - ref| / max |ref| over the tensors whose gradient is not mathematically zero (conv biases in front
+    of a norm layer: <= 1e-9 in the fp64 evaluation `zero_ref`, rounding noise in any fp32 one)"""
     out = {}
+    zero_ref = ref if zero_ref is None else zero_ref
     for k, r in ref.items():
-        if r.abs().max().item() <= 1e-9:
-            continue        # conv biases in front of a norm layer
+        if zero_ref[k].abs().max().item() <= 1e-9 * max(1.0, max(v.abs().max().item() for v in zero_ref.values())):
+            continue
         assert g[k] is not None, k
         out[k] = (g[k].double().cpu() - r.double().cpu()).abs().max().item() / r.abs().max().item()
     return out
@@ -238,7 +247,7 @@ def test_device_oracle_train_step_is_the_cpu_oracle_step_and_the_hip_step_matche
     l_dev, g_dev = _oracle_step_on(mods, clip, boxes, DEV, torch.float32)
     l_cpu64, g_cpu64 = _oracle_step_on(mods, clip, boxes, "cpu", torch.float64)
     l_dev64, g_dev64 = _oracle_step_on(mods, clip, boxes, DEV, torch.float64)
-    e32 = _rel_err(g_dev, g_cpu)
+    e32 = _rel_err(g_dev, g_cpu, g_cpu64)
     e64 = _rel_err(g_dev64, g_cpu64)
     print("64x64 step, device oracle vs CPU oracle: fp32 gradients max rel %.2e (median %.1e), fp64 max rel %.2e"
           % (max(e32.values()), float(np.median(list(e32.values()))), max(e64.values())))

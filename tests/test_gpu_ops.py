@@ -389,17 +389,27 @@ def test_winograd_f4_output_transform_applies_the_activation(slope):
         ops.conv2d_auto(_to_nhwc(x), U, b.to(_dev()), desc, stats=ops.conv_stats_buffer(desc, _dev()))
 
 
+@pytest.mark.parametrize("ragged", ["1", "0"], ids=["ragged", "whole_tiles"])
 @pytest.mark.parametrize("geom", [(64, 64, 1024, 1024), (64, 88, 640, 640), (128, 128, 256, 256), (64, 128, 512, 1024),
-                                  (128, 128, 512, 256), (64, 40, 1024, 1024), (64, 40, 512, 384), (128, 128, 1024, 1024)])
-def test_fixed_grid_winograd_gemm_equals_tile_per_block(geom, t2v_env):
+                                  (128, 128, 512, 256), (64, 40, 1024, 1024), (64, 40, 512, 384), (128, 128, 1024, 1024),
+                                  (64, 85, 1024, 1024), (64, 56, 1024, 1024), (64, 114, 1024, 1024), (60, 52, 256, 384)])
+def test_fixed_grid_winograd_gemm_equals_tile_per_block(geom, ragged, t2v_env):
     """The batched Winograd GEMM on a fixed grid (conv_igemm.hip: wino_gemm_sk_kernel; tiles cut between two blocks are
     finished from the first block's accumulators) against one block per tile: the same K-ordered MFMA chain per output,
     so the conv must be BIT-identical -- also launch after launch on one workspace (a stale hand-over flag or a stale L2
     line of an earlier launch would show as a differing frame).  Tile counts not divisible by the 8 XCDs included, and the
     192 x 64 tiles of the 512x320 frames (64 x 40 maps: 160 tile rows padded to 192), and the second schedule (4.5 rounds of
-    tiles at 128 x 128 x 1024: whole rounds + a half round cut in two)."""
+    tiles at 128 x 128 x 1024: whole rounds + a half round cut in two).  `ragged`: tile rows that are no whole 128s (the
+    reference's 512x680 frames: 64 x 85 maps, 352 rows = 4 + 4 + 3 fragments; the 16:9 speakers: 64 x 114 -> 464 rows, 64 x 56
+    -> 224; 60 x 52 -> 195 rows, the last fragment part padding) on wino_gemm_skr_kernel's ragged M tiles, or with
+    T2V_WINO_GEMM_SK_RAGGED=0 padded to whole tiles as before."""
     from text2video_amd import ops
     H, W, Cin, Cout = geom
+    rows = -(-H // 4) * -(-W // 4)
+    if ragged == "0" and -(-rows // 32) % 4 == 0:
+        pytest.skip("whole 128-row tiles: the ragged switch changes nothing")
+    t2v_env("T2V_WINO_GEMM_SK_RAGGED", ragged)
+    assert ops.fixed_grid_enabled()
     dev = _dev()
     desc = ops.conv_desc(H, W, Cin, Cout, 3, 1, 1, ops.PAD_REFLECT, algo=ops.ALGO_WINOGRAD_F4)
     w = _rand(Cout, Cin, 3, 3, seed=2, scale=0.03).to(dev)

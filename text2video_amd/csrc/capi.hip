@@ -4,8 +4,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <atomic>
 #include <mutex>
+#include <utility>
 #include <vector>
 
 #include "conv_plan.h"
@@ -34,6 +36,7 @@ void options_reload() {
     o.wino_gemm_sk = env_int("T2V_WINO_GEMM_SK", 1);
     o.wino_gemm_sk_wide = env_int("T2V_WINO_GEMM_SK_WIDE", 1);
     o.wino_gemm_sk_half = env_int("T2V_WINO_GEMM_SK_HALF", 1);
+    o.wino_gemm_sk_ragged = env_int("T2V_WINO_GEMM_SK_RAGGED", 1);
     o.wgrad_sk = env_int("T2V_WGRAD_SK", 1);
     o.wgrad_sk_half = env_int("T2V_WGRAD_SK_HALF", 1);
     o.wgrad_combine = env_int("T2V_WGRAD_COMBINE", 1);
@@ -77,7 +80,7 @@ int check_async_errors() {
 }
 
 // blocks shaped like the fixed-grid kernels' (512 threads, 64 KiB of LDS: two per CU), four rounds of them: each draws a
-// ticket as it starts and stays resident for a few microseconds
+// ticket as it starts and stays resident for some microseconds
 __global__ __launch_bounds__(512) void dispatch_order_kernel(unsigned* counter, unsigned* order) {
     extern __shared__ char smem[];
     if (threadIdx.x == 0) {
@@ -107,13 +110,25 @@ static int fixed_grid_selftest() {
         fixed_grid_disable("the dispatch-order self-test could not run");
         return T2V_OK;      // not fatal: the tile-per-block kernels need no such guarantee
     }
-    for (int b = 8; b < grid; ++b)
-        if (host[1 + b - 8] >= host[1 + b]) {
-            char why[128];
-            snprintf(why, sizeof(why), "dispatch-order self-test: block %d started before block %d", b, b - 8);
-            fixed_grid_disable(why);
-            break;
-        }
+    // Start order per XCD (blocks b = x, x + 8, x + 16, ... run on XCD x under round-robin dispatch).  Blocks dispatched
+    // within a microsecond of each other draw their tickets in any order, so the check is on DISPLACEMENT: with in-order
+    // dispatch a block's rank among its XCD's tickets differs from its index there by less than the blocks the XCD holds
+    // at once (a quarter of this launch's blocks per XCD; the limit is twice that); a queue served out of order (LIFO,
+    // random, reversed) displaces by the whole over-subscribed length.
+    const int per_xcd = grid / 8, limit = per_xcd / 2;
+    for (int x = 0; x < 8 && fixed_grid_enabled(); ++x) {
+        std::vector<std::pair<unsigned, int>> t(per_xcd);
+        for (int q = 0; q < per_xcd; ++q) t[q] = {host[1 + q * 8 + x], q};
+        std::sort(t.begin(), t.end());
+        for (int r = 0; r < per_xcd; ++r)
+            if (abs(t[r].second - r) > limit) {
+                char why[160];
+                snprintf(why, sizeof(why), "dispatch-order self-test: block %d of XCD %d started %d places from its index",
+                         t[r].second * 8 + x, x, abs(t[r].second - r));
+                fixed_grid_disable(why);
+                break;
+            }
+    }
     return T2V_OK;
 }
 
@@ -374,7 +389,15 @@ int winograd_forward(t2v_ctx* ctx, hipStream_t s, const t2v_conv_desc* d, const 
                    : launch_winograd_input(s, x, V, d->H, d->W, d->Cin, d->pad, reflect));
     }
     if (stages & 2) {
-        if (f4 && wino_gemm_sk_ok(36, (int)T, d->Cin, d->Cout, d->Cout)) {
+        const int rows = nimg * wino_tiles_real(d, d->algo);      // real tile rows per position (the rest of T is padding)
+        if (f4 && wino_gemm_skr_ok(36, rows, (int)T, d->Cin, d->Cout, d->Cout)) {
+            SkGemm g;
+            g.a = V; g.b = w_packed; g.c = Mm; g.scratch = workspace + winograd_vm_floats(d, nimg);
+            g.err = async_error_word();
+            g.a_group_stride = (long)T * d->Cin;
+            g.groups = 36; g.T = (int)T; g.K = d->Cin; g.N = d->Cout; g.c_cs = d->Cout;
+            T2V_TRY(launch_wino_gemm_skr(s, g, rows));
+        } else if (f4 && wino_gemm_sk_ok(36, (int)T, d->Cin, d->Cout, d->Cout)) {
             SkGemm g;
             g.a = V; g.b = w_packed; g.c = Mm; g.scratch = workspace + winograd_vm_floats(d, nimg);
             g.err = async_error_word();

@@ -28,6 +28,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <algorithm>
 #include <atomic>
 
 #include "t2v_internal.h"
@@ -670,6 +671,218 @@ __global__ __launch_bounds__(512) void wino_gemm_sk_kernel(const SkKParams p) {
     }
 }
 
+// ---- the same GEMM for tile rows that are no whole 128s: ragged M tiles --------------------------------------------------
+// The reference's own frames (512x680: 352 Winograd tiles per transform position; two 512x320 sequences in lock-step: 320;
+// the 16:9 speakers: 464, 224) pad badly to 128-row tiles (384, 384, 512, 256: 8-17 % of the MFMA work on zero rows).  Here
+// the rows of a position are cut into 32-row MFMA fragments, F = ceil(rows / 32), and every (position, 128-column) group into
+// M tiles of 4, 4, ..., 4, r fragments (r = F mod 4): the full tiles run exactly as in wino_gemm_sk_kernel (2 x 2 waves of
+// 64 x 64), the ragged one as 1 x 4 waves of (32 r) x 32 -- every wave busy on every k step, no zero rows.  A unit is one K
+// stage of one fragment row; the unit list (group-major, M tile fastest, as above) is cut into equal WEIGHT runs per block, a
+// run boundary rounded to the nearest stage of the tile it falls into (both neighbours compute the same boundary).  A run is
+// at least one full tile long, so a tile is cut at most once: head first / tail last, the accumulator hand-over and its
+// guards are those of wino_gemm_sk_kernel, and every output is still the same K-ordered MFMA chain (bit-identical to the
+// other forms of the stage: which wave owns an element changes, its sum does not).
+struct SkrKParams {
+    const float* a;
+    const float* b;
+    float* c;
+    float* partial;
+    unsigned long long* flags;
+    unsigned long long tag;
+    unsigned* err;
+    long a_group_stride;
+    int Tp;                       // rows per position of a / c (the padded pitch)
+    int K, N, c_cs;
+    int F;                        // 32-row fragments per position that hold real rows
+    int ntiles, nk, cgs;          // 128-column tiles, K stages, column groups (positions x ntiles)
+    int cg_per_xcd, blocks_per_xcd;
+    int S;                        // run length per block, in units (>= 4 nk: one full tile)
+};
+using CfgR1 = TileCfg<32, 1, 4, 1, 1>;   //  32 x 128
+using CfgR2 = TileCfg<32, 1, 4, 2, 1>;   //  64 x 128
+using CfgR3 = TileCfg<32, 1, 4, 3, 1>;   //  96 x 128
+
+// one piece [kb, ke) of one tile: the loader waves stream its stages, the MFMA waves start from zeros or from the handed-over
+// accumulators (init), and end by publishing them (ke < nk) or by storing the finished tile
+template <class Cfg, int RING>
+__device__ __forceinline__ void skr_piece(const SkrKParams& p, char* smem, int wid, int lane, bool is_loader, int pg, int nt,
+                                          int row0, int kb, int ke, bool& flag_due) {
+    using MM = Mfma<32>;
+    using acc_t = typename MM::acc_t;
+    constexpr int BM = Cfg::BM, BN = Cfg::BN, MF = 32;
+    constexpr int A_ITERS = BM / 32, B_PER_WAVE = BN / 32, LD_PER_WAVE = A_ITERS + B_PER_WAVE;
+    const bool init = kb > 0, publish = ke < p.nk;
+    const int lrow = lane >> 3, lslot = lane & 7;
+    if (is_loader) {
+        const float* abase = p.a + pg * p.a_group_stride + (long)row0 * p.K;
+        const float* bbase = p.b + ((long)pg * p.N + nt * BN) * p.K;
+        const int a_bytes = BM * p.K * 4, b_bytes = BN * p.K * 4;
+        int a_voff[A_ITERS], b_voff[B_PER_WAVE];
+#pragma unroll
+        for (int i = 0; i < A_ITERS; ++i) {
+            const int r = wid * (BM / 4) + i * 8 + lrow;
+            a_voff[i] = (r * p.K + (lslot ^ ((r >> 1) & 7)) * 4) * 4;
+        }
+#pragma unroll
+        for (int i = 0; i < B_PER_WAVE; ++i) {
+            const int r = (wid * B_PER_WAVE + i) * 8 + lrow;
+            b_voff[i] = (r * p.K + (lslot ^ ((r >> 1) & 7)) * 4) * 4;
+        }
+        auto issue_stage = [&](int kt, int buf) {
+            char* dstA = smem + buf * Cfg::STAGE_BYTES + wid * (BM / 4) * 128;
+            char* dstB = smem + buf * Cfg::STAGE_BYTES + BM * 128 + wid * B_PER_WAVE * 8 * 128;
+#pragma unroll
+            for (int i = 0; i < A_ITERS; ++i) dma16(abase, a_bytes, dstA + i * 8 * 128, a_voff[i], kt * (kBK * 4));
+#pragma unroll
+            for (int i = 0; i < B_PER_WAVE; ++i) dma16(bbase, b_bytes, dstB + i * 8 * 128, b_voff[i], kt * (kBK * 4));
+        };
+        loader_k_loop<RING, LD_PER_WAVE>(kb, ke, issue_stage);
+        __syncthreads();   // the MFMA waves have read their last fragments: the next piece's prologue may overwrite the ring
+        return;
+    }
+    const int wm = wid / Cfg::WAVES_N, wn = wid - wm * Cfg::WAVES_N;
+    const int fr = lane & (MF - 1);
+    const int g = lane / MF;
+    const int fsw = (fr >> 1) & 7;
+    const int a_row0 = wm * (Cfg::TM * MF) + fr;
+    const int b_row0 = wn * (Cfg::TN * MF) + fr;
+    acc_t acc[Cfg::TM][Cfg::TN];
+    if (init) {
+        const int src = blockIdx.x - 8;
+        const unsigned long long* fl = p.flags + src * 4 + wid;
+        const bool timed_out = handover_wait(fl, p.tag, p.err, lane);
+        if (lane == 0) __hip_atomic_store(const_cast<unsigned long long*>(fl), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(p.partial) + (size_t)(src * 4 + wid) * 4096, 0, 16384, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+            for (int jj = 0; jj < Cfg::TN; ++jj)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    auto raw = __builtin_amdgcn_raw_buffer_load_b128(srd, lane * 16, ((i * Cfg::TN + jj) * 4 + q) * 1024, 16);
+                    float v[4];
+                    __builtin_memcpy(v, &raw, 16);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[i][jj][q * 4 + e] = timed_out ? __builtin_nanf("") : v[e];
+                }
+    } else {
+#pragma unroll
+        for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+            for (int jj = 0; jj < Cfg::TN; ++jj)
+#pragma unroll
+                for (int r = 0; r < MM::NREG; ++r) acc[i][jj][r] = 0.f;
+    }
+    if (flag_due) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_store(p.flags + blockIdx.x * 4 + wid, p.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        flag_due = false;
+    }
+    mfma_k_loop<Cfg, RING>(smem, ke - kb, a_row0, b_row0, g, fsw, acc);
+    __syncthreads();   // pairs with the loaders' closing barrier
+    if (publish) {
+        // (the wave -> element mapping of the hand-over is the tile's own: producer and consumer run the same Cfg)
+        const __amdgpu_buffer_rsrc_t srd =
+            __builtin_amdgcn_make_buffer_rsrc(p.partial + (size_t)(blockIdx.x * 4 + wid) * 4096, 0, 16384, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+            for (int jj = 0; jj < Cfg::TN; ++jj)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[i][jj][q * 4 + e];
+                    v4u raw;
+                    __builtin_memcpy(&raw, v, 16);
+                    __builtin_amdgcn_raw_buffer_store_b128(raw, srd, lane * 16, ((i * Cfg::TN + jj) * 4 + q) * 1024, 16);
+                }
+        flag_due = true;
+    } else {
+        const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(
+            p.c + ((size_t)pg * p.Tp + row0) * p.c_cs + nt * BN, 0, 0x7ffffffc, 0x00020000);
+        const int voff = ((wm * (Cfg::TM * MF) + 4 * g) * p.c_cs + wn * (Cfg::TN * MF) + fr) * 4;
+#pragma unroll
+        for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+            for (int r = 0; r < MM::NREG; ++r) {
+                const int soff = (i * MF + (r & 3) + 8 * (r >> 2)) * p.c_cs * 4;
+#pragma unroll
+                for (int jj = 0; jj < Cfg::TN; ++jj)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[i][jj][r]), srd, voff + jj * MF * 4, soff, 0);
+            }
+    }
+}
+
+template <int RING>
+__global__ __launch_bounds__(512, 4) void wino_gemm_skr_kernel(const SkrKParams p) {   // (4 waves per SIMD: two blocks per CU)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool is_loader = wave >= 4;
+    const int wid = wave & 3;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int nk = p.nk, F = p.F, nfull = F >> 2, rem = F & 3, MT = nfull + (rem ? 1 : 0);
+    const int cg0 = xcd * p.cg_per_xcd, cg1 = min(cg0 + p.cg_per_xcd, p.cgs);
+    if (cg0 >= cg1) return;
+    const int cgw = F * nk, Wx = (cg1 - cg0) * cgw;
+    const int u0 = min(j * p.S, Wx), u1 = min(u0 + p.S, Wx);
+    if (u0 >= u1) return;
+    // unit offset inside the XCD's range -> (linear tile index = group * MT + M tile, stage), the stage rounded to the nearest
+    // stage boundary of that tile; a boundary at a tile's end is the start of the next tile
+    auto locate = [&](int u, int& lt, int& st) {
+        const int c = u / cgw, r = u - c * cgw;
+        int mt;
+        if (r < nfull * 4 * nk) {
+            mt = r / (4 * nk);
+            st = (r - mt * 4 * nk + 2) >> 2;
+        } else {
+            mt = nfull;
+            st = rem ? (r - nfull * 4 * nk + (rem >> 1)) / rem : 0;
+        }
+        lt = c * MT + mt;
+        if (st >= nk) {
+            st = 0;
+            ++lt;
+        }
+    };
+    int lt0, k0, lt1, k1;
+    locate(u0, lt0, k0);
+    locate(u1, lt1, k1);
+    const bool has_tail = k0 > 0, has_head = k1 > 0;
+    const int first_whole = lt0 + (has_tail ? 1 : 0);
+    const int nwhole = max(0, lt1 - first_whole);
+    const int nf = nwhole + (has_head ? 1 : 0) + (has_tail ? 1 : 0);
+    bool flag_due = false;
+    for (int f = 0; f < nf; ++f) {
+        int lt, kb = 0, ke = nk;
+        if (has_head && f == 0) {
+            lt = lt1;
+            ke = k1;
+        } else if (f - (has_head ? 1 : 0) < nwhole) {
+            lt = first_whole + f - (has_head ? 1 : 0);
+        } else {
+            lt = lt0;
+            kb = k0;
+        }
+        const int c = lt / MT, mt = lt - c * MT;
+        const int cg = cg0 + c;
+        const int pg = cg / p.ntiles, nt = cg - pg * p.ntiles;
+        const int row0 = mt * 128;
+        const int frs = mt < nfull ? 4 : rem;
+        if (frs == 4) skr_piece<CfgL, RING>(p, smem, wid, lane, is_loader, pg, nt, row0, kb, ke, flag_due);
+        else if (frs == 3) skr_piece<CfgR3, RING>(p, smem, wid, lane, is_loader, pg, nt, row0, kb, ke, flag_due);
+        else if (frs == 2) skr_piece<CfgR2, RING>(p, smem, wid, lane, is_loader, pg, nt, row0, kb, ke, flag_due);
+        else skr_piece<CfgR1, RING>(p, smem, wid, lane, is_loader, pg, nt, row0, kb, ke, flag_due);
+    }
+    if (flag_due && !is_loader) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_store(p.flags + blockIdx.x * 4 + wid, p.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 int wino_gemm_sk_grid_blocks() {
     static int n = 0;
     if (!n) {
@@ -755,6 +968,71 @@ int launch_wino_gemm_sk(hipStream_t s, const SkGemm& g) {
     k.tiles_per_xcd = (k.tiles + 7) / 8;
     k.rounds = sk_half_round(k.tiles, grid, k.nk) ? (int)(k.tiles / grid) : 0;
     return bm == 128 ? launch_sk<CfgL>(s, k, grid) : launch_sk<CfgW>(s, k, grid);
+}
+
+// ---- ragged form: when, and the launch ----
+// `rows` real tile rows per position (all images of a batch, packed), `Tp` the padded pitch.  Taken when the rows are no whole
+// 128s and the run per block -- in (fragment row x stage) units, at least one full tile -- is shorter than what the padded
+// alternatives give a block: the fixed grid on whole 128 / 192-row tiles where that applies, else one block per tile.
+static long skr_run_units(int groups, int rows, int K, int N, int* cg_per_xcd) {
+    const int F = (rows + 31) / 32, nk = K / kBK, cgs = groups * (N / 128), bpx = wino_gemm_sk_grid_blocks() / 8;
+    const int cgx = (cgs + 7) / 8;
+    if (cg_per_xcd) *cg_per_xcd = cgx;
+    const long Wx = (long)cgx * F * nk;
+    return std::max<long>(4L * nk, (Wx + bpx - 1) / bpx);
+}
+bool wino_gemm_skr_ok(int groups, int rows, int Tp, int K, int N, int c_cs) {
+    const int mode = fixed_grid_enabled() ? options().wino_gemm_sk : 0;
+    if (mode == 0 || !options().wino_gemm_sk_ragged || rows < 1 || N % 128 || K % kBK || c_cs != N ||
+        (long)128 * K * 4 >= 0x7fff0000L || (rows + 31) / 32 * 32 > Tp || (long)groups * (N / 128) * ((rows + 31) / 32) * (K / kBK) >= 0x7fffffffL / 2)
+        return false;
+    const int F = (rows + 31) / 32, nk = K / kBK;
+    if (F % 4 == 0) return false;                       // whole 128-row tiles: wino_gemm_sk_kernel's case
+    if (mode == 2) return true;
+    const long grid = wino_gemm_sk_grid_blocks();
+    const long run = skr_run_units(groups, rows, K, N, nullptr);        // fragment rows x stages per block, 2 blocks per CU
+    // the alternatives, in the same units per CU-resident pair of blocks
+    long alt;
+    if (wino_gemm_sk_ok(groups, Tp, K, N, c_cs)) {
+        const int bm = Tp % 128 == 0 ? 128 : 192, bn = bm == 128 ? 128 : 64;
+        const long tiles = (long)groups * (Tp / bm) * (N / bn);
+        const long per_tile = (long)(bm / 32) * nk * bn / 128;           // in units of a 128-column fragment row x stage
+        alt = std::max(per_tile, (tiles * per_tile + grid - 1) / grid);
+    } else {
+        // one block per 64x64 or 128x128 tile, whole rounds of the resident blocks
+        const bool big = Tp % 128 == 0;
+        const long tiles = big ? (long)groups * (Tp / 128) * (N / 128) : (long)groups * (Tp / 64) * (N / 64);
+        const long resident = big ? grid : 2 * grid, per_tile = big ? 4L * nk : nk;
+        alt = (tiles + resident - 1) / resident * per_tile * (big ? 1 : 2);     // (64x64: four blocks per CU = two per "slot")
+    }
+    return run * 100 <= alt * 97;
+}
+
+int launch_wino_gemm_skr(hipStream_t s, const SkGemm& g, int rows) {
+    T2V_REQUIRE(wino_gemm_skr_ok(g.groups, rows, g.T, g.K, g.N, g.c_cs), "ragged fixed-grid gemm: shape not supported");
+    SkrKParams k;
+    k.a = g.a; k.b = g.b; k.c = g.c;
+    k.partial = g.scratch;
+    k.flags = reinterpret_cast<unsigned long long*>(g.scratch + (size_t)kSkMaxGrid * 4 * 64 * 64);
+    k.tag = wino_gemm_sk_next_tag();
+    k.err = g.err;
+    k.a_group_stride = g.a_group_stride;
+    k.Tp = g.T; k.K = g.K; k.N = g.N; k.c_cs = g.c_cs;
+    k.F = (rows + 31) / 32;
+    k.ntiles = g.N / 128; k.nk = g.K / kBK; k.cgs = g.groups * k.ntiles;
+    const int grid = wino_gemm_sk_grid_blocks();
+    k.blocks_per_xcd = grid / 8;
+    k.S = (int)skr_run_units(g.groups, rows, g.K, g.N, &k.cg_per_xcd);
+    auto kern = wino_gemm_skr_kernel<2>;
+    constexpr int LDS_BYTES = 2 * CfgL::STAGE_BYTES;
+    static bool attr_done = false;
+    if (!attr_done) {
+        T2V_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS_BYTES, s, k);
+    T2V_HIP_CHECK(hipGetLastError());
+    return T2V_OK;
 }
 
 int conv_tile_for(int Cout) { return Cout <= 16 ? kTileS : kTileL; }

@@ -42,6 +42,7 @@ struct Options {
     int wino_gemm_sk;        // T2V_WINO_GEMM_SK: 0 off, 1 where it pays (default), 2 wherever the shape allows
     int wino_gemm_sk_wide;   // T2V_WINO_GEMM_SK_WIDE: 192x64 tiles for tile rows that are whole 192s (default 1)
     int wino_gemm_sk_half;   // T2V_WINO_GEMM_SK_HALF: second schedule for R + 1/2 rounds (default 1)
+    int wino_gemm_sk_ragged; // T2V_WINO_GEMM_SK_RAGGED: ragged M tiles for tile rows that are no whole 128s (default 1)
     int wgrad_sk;            // T2V_WGRAD_SK: as wino_gemm_sk, for the Winograd-domain weight gradient
     int wgrad_sk_half;       // T2V_WGRAD_SK_HALF
     int wgrad_combine;       // T2V_WGRAD_COMBINE: in-kernel combine of split partials (default 1)
@@ -59,7 +60,7 @@ void options_reload();
 // The fixed-grid kernels hand accumulators from block b - 8 (b - 8 * half) to block b inside one launch.  That cannot
 // deadlock as long as workgroups are dispatched in index order (the producer publishes before anything it waits for).  Two
 // guards: (i) a self-test at the first t2v_create per process launches an over-subscribed grid whose blocks draw a ticket as
-// they start and checks ticket[b - 8] < ticket[b]; (ii) a consumer whose producer's tag does not show up within the poll
+// they start and checks, per XCD, that no block starts far from its place in index order; (ii) a consumer whose producer's tag does not show up within the poll
 // bound poisons its tile with NaNs AND raises a sticky error word in pinned host memory.  check_async_errors() -- called by
 // every entry point that may launch a fixed-grid kernel, and exported as t2v_check_async_errors -- then returns
 // T2V_ERR_HANDOVER once and switches the process to one block per tile (fixed_grid_enabled() == false).
@@ -244,6 +245,10 @@ struct SkGemm {
 size_t wino_gemm_sk_scratch_floats();
 bool wino_gemm_sk_ok(int groups, int T, int K, int N, int c_cs);
 int launch_wino_gemm_sk(hipStream_t s, const SkGemm& g);
+// the ragged form (conv_igemm.hip: wino_gemm_skr_kernel): `rows` real tile rows per position (<= g.T, the padded pitch), cut
+// into 32-row fragments and M tiles of 4, ..., 4, r fragments -- no MFMA work on padding rows
+bool wino_gemm_skr_ok(int groups, int rows, int Tp, int K, int N, int c_cs);
+int launch_wino_gemm_skr(hipStream_t s, const SkGemm& g, int rows);
 int wino_gemm_sk_grid_blocks();                 // two blocks per CU, a multiple of 8
 unsigned long long wino_gemm_sk_next_tag();     // hand-over tags: unique per launch, process-wide
 // the same scheme for the Winograd-domain weight gradient dU[xi] = M_dy[xi]^T V[xi] (conv_wgrad.hip); scratch as above

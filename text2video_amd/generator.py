@@ -151,63 +151,13 @@ def synthetic_state_dict(spec, seed=1, init="uniform_fan_in", flow_gain=1.0):
     return sd
 
 
-def upload_tensors(tensors, device, chunk_floats=16 << 20, min_bytes=64 << 20):
-    """{name: fp32 tensor} -> the same tensors on `device`.  Host tensors of a real checkpoint (1.5 GB for the generator
-    with its flow branch, memory-mapped by load_checkpoint) go up through a ring of three pinned 64 MiB staging buffers:
-    the host-side copy into a staging buffer (torch's multi-threaded copy, faulting the mapped pages in) runs while the
-    previous buffer's DMA is in flight, and the device side is ONE arena the tensors are views of (256-byte aligned).
-    A plain `.to(device)` of pageable memory moves the same bytes at 3.7 GB/s (0.40 s of the one-shot command's start-up,
-    measured on the MI355X box); small or already-resident state dicts take that path."""
+def upload_tensors(tensors, device):
+    """{name: fp32 tensor} -> the same tensors on `device`.  (Round 4 measured a hand-made staging path for the 1.5 GB of a
+    real checkpoint -- a ring of three pinned 64 MiB buffers filled from the memory-mapped file while the previous buffer's
+    DMA runs -- against the runtime's own pageable copy: 0.98 s vs 0.40 s on the MI355X box.  Faulting the mapped pages in
+    from one Python thread is the bottleneck, which the runtime's copy path avoids; the plain copy stays.)"""
     dev = torch.device(device)
-    host = {k: v for k, v in tensors.items() if not v.is_cuda}
-    if sum(v.numel() * 4 for v in host.values()) < min_bytes:
-        return {k: v.detach().to(dev, torch.float32).contiguous() for k, v in tensors.items()}
-    out = {k: v.detach().to(dev, torch.float32).contiguous() for k, v in tensors.items() if v.is_cuda}
-    offs, total = {}, 0
-    for k, v in host.items():
-        offs[k] = total
-        total += (v.numel() + 63) // 64 * 64
-    arena = torch.empty(total, dtype=torch.float32, device=dev)
-    ring = torch.empty(3, chunk_floats, dtype=torch.float32).pin_memory()
-    events = [None, None, None]
-    stream = torch.cuda.current_stream(dev)
-    slot, fill, base = 0, 0, 0          # staging slot being filled, floats in it, arena offset of its first float
-
-    def flush():
-        nonlocal slot, fill, base
-        if fill:
-            arena[base:base + fill].copy_(ring[slot, :fill], non_blocking=True)
-            events[slot] = torch.cuda.Event()
-            events[slot].record(stream)
-            base += fill
-            slot, fill = (slot + 1) % 3, 0
-            if events[slot] is not None:
-                events[slot].synchronize()      # its DMA (two flushes ago) has read the buffer
-
-    for k, v in host.items():
-        src = v.detach().to(torch.float32).contiguous().view(-1)
-        assert base + fill == offs[k]
-        pos, n = 0, src.numel()
-        while pos < n:
-            m = min(n - pos, chunk_floats - fill)
-            ring[slot, fill:fill + m].copy_(src[pos:pos + m])
-            pos += m
-            fill += m
-            if fill == chunk_floats:
-                flush()
-        pad = (64 - n % 64) % 64              # the next tensor starts on a 256-byte boundary
-        if pad:
-            if fill + pad > chunk_floats:
-                flush()
-                base += pad
-            else:
-                fill += pad
-                if fill == chunk_floats:
-                    flush()
-        out[k] = arena[offs[k]:offs[k] + n].view(v.shape)
-    flush()
-    stream.synchronize()
-    return out
+    return {k: v.detach().to(dev, torch.float32).contiguous() for k, v in tensors.items()}
 
 
 class HipGenerator:
