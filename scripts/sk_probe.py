@@ -25,8 +25,10 @@ def run(H, W, C):
     pu = ops.pack_conv_weight(w, desc, C)
     ws = ops.winograd_workspace(desc, C, dev)
     res = {}
-    for sk in ("0", "1"):
-        os.environ["T2V_WINO_GEMM_SK"] = sk
+    for sk in ("0", "1", "whole"):     # one block per tile | the default rule | the default rule without the ragged M tiles
+        os.environ["T2V_WINO_GEMM_SK"] = "1" if sk == "whole" else sk
+        os.environ["T2V_WINO_GEMM_SK_RAGGED"] = "0" if sk == "whole" else "1"
+        ops.reload_env()
         ws.fill_(float("nan"))
         y = ops.conv2d_winograd(x, pu, b, desc, workspace=ws)
         torch.cuda.synchronize()
@@ -37,14 +39,19 @@ def run(H, W, C):
     d = (res["0"][0] - res["1"][0]).abs()
     print("   nan %d  differing %d of %d  max|d| %.3e  max|y| %.3e" % (int(torch.isnan(res["1"][0]).sum()), int((d > 0).sum()),
           d.numel(), float(torch.nan_to_num(d).max()), float(res["0"][0].abs().max())))
-    print("%3dx%3dx%4d: bit-equal %s; GEMM stage %.1f -> %.1f us, conv %.1f -> %.1f us" %
-          (H, W, C, eq, res["0"][1], res["1"][1], res["0"][2], res["1"][2]), flush=True)
+    rows = -(-H // 4) * -(-W // 4)
+    gf = 2.0 * 36 * rows * C * C / 1e9
+    print("%3dx%3dx%4d (%d tile rows): bit-equal %s; GEMM stage %.1f us one block per tile -> %.1f us whole-tile fixed grid -> %.1f us "
+          "default (%.1f TF on the real rows = %.2f of peak), conv %.1f -> %.1f us" %
+          (H, W, C, rows, eq and torch.equal(res["0"][0], res["whole"][0]), res["0"][1], res["whole"][1], res["1"][1],
+           gf / res["1"][1] * 1e3, gf / res["1"][1] * 1e3 / 157.3, res["0"][2], res["1"][2]), flush=True)
     return eq
 
 if __name__ == "__main__":
     ok = True
     shapes = [(64, 64, 1024), (64, 128, 1024), (32, 32, 1024), (64, 64, 512), (128, 128, 256), (64, 40, 1024), (64, 88, 1024),
-              (128, 128, 1024)]
+              (128, 128, 1024), (64, 85, 1024), (64, 56, 1024), (64, 114, 1024), (64, 80, 1024), (64, 170, 1024)]
+    print("fixed grid enabled:", ops.fixed_grid_enabled())
     if len(sys.argv) > 1:
         shapes = shapes[:int(sys.argv[1])]
     for (H, W, C) in shapes:

@@ -338,3 +338,38 @@ def test_lazy_resblock_chain_is_bit_identical_to_the_apply_form():
     assert np.array_equal(res["0"], res["1"])
 
 
+
+
+def test_alternating_frame_geometries_keep_their_packed_weights():
+    """Two lanes whose sequences have different frame sizes alternate every step of the lock-step loop: the
+    generator keeps the packed / Winograd-transformed weights and the arena of the last geometries, so only the FIRST frame
+    of each geometry packs; the frames are those of a generator that only ever saw that geometry."""
+    from text2video_amd import ops
+    from text2video_amd.generator import GeneratorSpec, HipGenerator, synthetic_state_dict
+    spec = GeneratorSpec(ngf=16, n_downsample=2, n_blocks=2, no_flow=False, norm="batch")
+    sd = synthetic_state_dict(spec, 3, "vid2vid", 0.1)
+    geoms = [(128, 256), (128, 128)]
+
+    def inputs(H, W, seed):
+        pose = ops.nchw_to_nhwc(_pose_seq(3, H, W, seed).reshape(9, H, W).cuda())
+        prev = torch.zeros(H, W, 8, device="cuda:0")
+        prev[..., :6] = torch.tanh(torch.randn(H, W, 6, generator=torch.Generator().manual_seed(seed))).cuda()
+        return pose, prev
+    want = {}
+    for g in geoms:
+        alone = HipGenerator(spec, "cuda:0").load_state_dict(sd)
+        want[g] = [alone.forward(*inputs(*g, seed=t), False)["out"].clone() for t in range(3)]
+    hip = HipGenerator(spec, "cuda:0").load_state_dict(sd)
+    packs = []
+    orig = hip._pack
+    hip._pack = lambda gd: (packs.append((gd.H, gd.W)), orig(gd))[1]
+    for t in range(3):
+        for g in geoms:
+            assert torch.equal(hip.forward(*inputs(*g, seed=t), False)["out"], want[g][t]), (g, t)
+    assert packs == geoms, packs
+    # a third geometry evicts the oldest; coming back to it packs again, the other one is still there
+    hip.forward(*inputs(64, 64, 5), False)
+    hip.forward(*inputs(128, 128, 1), False)
+    assert packs == geoms + [(64, 64)], packs
+    hip.forward(*inputs(128, 256, 1), False)
+    assert packs == geoms + [(64, 64), (128, 256)], packs

@@ -180,6 +180,11 @@ class HipGenerator:
         self._ws = None
         self._ws_hw = None
         self._ws_batch = 0
+        # packed weights + arena of the geometries seen last (two lanes with different frame sizes alternate every
+        # step -- re-packing the Winograd filter transforms each time would cost a weight pack per frame).  Two entries: what
+        # one lock-step pair of sequences can need; each holds ~5.5 GB of transformed weights for the full-size generator.
+        self._geoms = {}
+        self.max_cached_geometries = 2
 
     # -- weights ---------------------------------------------------------------------------------
     def load_state_dict(self, sd):
@@ -195,6 +200,7 @@ class HipGenerator:
             self._raw = upload_tensors({k: sd[k] for k in need}, self.device)
         self._layers = None
         self._ws_hw = None
+        self._geoms = {}
         return self
 
     def _pack(self, gd):
@@ -226,13 +232,21 @@ class HipGenerator:
     # -- forward ---------------------------------------------------------------------------------
     def _workspace(self, H, W, batch=1):
         if self._ws_hw != (H, W):
-            gd = _gen_desc(self.spec, H, W, self.conv_algo)
-            if self.lib.t2v_generator_workspace_bytes(ctypes.byref(gd)) == 0:
-                raise RuntimeError("generator: %s" % self.lib.t2v_last_error().decode())
-            self._pack(gd)
-            self._ws, self._ws_batch = None, 0
+            if self._ws_hw is not None:       # park the geometry in use
+                self._geoms[self._ws_hw] = (self._packed, self._layers, self._gd, self._ws, self._ws_batch)
+                while len(self._geoms) > self.max_cached_geometries:
+                    self._geoms.pop(next(iter(self._geoms)))        # the oldest
+            ent = self._geoms.pop((H, W), None)
+            if ent is not None:
+                self._packed, self._layers, self._gd, self._ws, self._ws_batch = ent
+            else:
+                gd = _gen_desc(self.spec, H, W, self.conv_algo)
+                if self.lib.t2v_generator_workspace_bytes(ctypes.byref(gd)) == 0:
+                    raise RuntimeError("generator: %s" % self.lib.t2v_last_error().decode())
+                self._pack(gd)
+                self._ws, self._ws_batch = None, 0
+                self._gd = gd
             self._ws_hw = (H, W)
-            self._gd = gd
         if self._ws is None or self._ws_batch < batch:     # one arena, sized for the largest batch seen
             nbytes = self.lib.t2v_generator_workspace_bytes_batch(ctypes.byref(self._gd), batch)
             if nbytes == 0:

@@ -44,6 +44,16 @@ def local_device_index(local_rank):
     return idx
 
 
+def _die_with_parent():
+    """child side (preexec): SIGTERM when the launching process dies -- a SIGKILLed parent cannot stop its ranks itself, and
+    ranks blocked in a collective would otherwise stay behind.  prctl(PR_SET_PDEATHSIG = 1, SIGTERM)."""
+    try:
+        import ctypes
+        ctypes.CDLL(None, use_errno=True).prctl(1, int(signal.SIGTERM), 0, 0, 0)
+    except Exception:      # noqa: BLE001 -- not Linux / no libc: the ranks simply keep the old behaviour
+        pass
+
+
 def self_launch(nranks, device_ids=None, argv=None, poll_s=0.05):
     """Run `sys.executable argv` (default: this process's own command line) as `nranks` ranks and return the job's
     exit status: 0 when every rank returned 0, else the first failing rank's status (the remaining ranks are
@@ -58,7 +68,7 @@ def self_launch(nranks, device_ids=None, argv=None, poll_s=0.05):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # the host driver only supports dmabuf IPC (RCCL needs it)
         if device_ids:
             env["T2V_DEVICE_IDS"] = ",".join(str(d) for d in device_ids)
-        procs.append(subprocess.Popen([sys.executable] + argv, env=env))
+        procs.append(subprocess.Popen([sys.executable] + argv, env=env, preexec_fn=_die_with_parent))
 
     def stop_all(sig=signal.SIGTERM):
         for p in procs:

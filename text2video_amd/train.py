@@ -261,6 +261,20 @@ def flush_pending_weight_gradients(params, grads):
 BN_MOMENTUM = 0.1     # nn.BatchNorm2d default ($SP/torch/nn/modules/batchnorm.py:16)
 _BN_UPDATES = [1]     # running-statistics updates per forward (a forward that stands for two upstream forwards: 2)
 _NO_PARAM_GRAD = set()   # ids of parameters whose gradients the backward pass under way must not produce
+_NO_INPUT_DX = [False]   # the backward pass under way wants parameter gradients only: input layers skip their data gradient
+
+
+@contextlib.contextmanager
+def input_gradients_off():
+    """Scope of a backward pass that asks for PARAMETER gradients of a loss network only (D's loss): the network's input
+    layers (conv_block(..., need_dx=2)) skip the data-gradient conv into their input -- with one shared forward on the
+    attached fake frames that input requires grad, but only G's backward pass (param_gradients_off) ever reads it."""
+    old = _NO_INPUT_DX[0]
+    _NO_INPUT_DX[0] = True
+    try:
+        yield
+    finally:
+        _NO_INPUT_DX[0] = old
 
 
 @contextlib.contextmanager
@@ -394,7 +408,7 @@ class _ConvBlock(torch.autograd.Function):
         for prm in (w, b, gamma, beta):
             expect_gradient(prm)
         # (an input nobody differentiates -- the discriminators' real pass -- needs no data-gradient conv)
-        need_dx = bool(need_dx and ctx.needs_input_grad[0])
+        need_dx = int(need_dx) if (need_dx and ctx.needs_input_grad[0]) else 0      # 2: an input layer (input_gradients_off)
         ctx.meta = (desc, ddesc, norm, relu, act, need_dx, mrs, gamma is not None, wino_wgrad, slope)
         ctx.save_for_backward(x, w, c, gamma, beta, y if (norm is None and act != ops.ACT_NONE) else None, b)
         return y
@@ -408,6 +422,8 @@ class _ConvBlock(torch.autograd.Function):
         dgamma = dbeta = None
         # a backward pass that only passes THROUGH this layer (param_gradients_off): data gradient only
         want = [bool(v) for v in ctx.needs_input_grad]
+        if need_dx == 2 and _NO_INPUT_DX[0]:
+            need_dx = 0
         if _NO_PARAM_GRAD and id(getattr(w, "_t2v_owner", w)) in _NO_PARAM_GRAD:
             want[1] = want[2] = want[3] = want[4] = False
         # parameters with a bucket slot get their gradients delivered in place (and None goes back to autograd)
@@ -803,7 +819,7 @@ class TrainableDiscriminator(torch.nn.Module):
                 cur = conv_block(cur, self.p(pre + ".0.weight"), self.p(pre + ".0.bias"), desc, g, b, None, self.norm, 2)
             else:
                 cur = conv_block(cur, self.p(pre + ".0.weight"), self.p(pre + ".0.bias"), desc, norm=None, relu=0,
-                                 act=ops.ACT_NONE if last else ops.ACT_LRELU)
+                                 act=ops.ACT_NONE if last else ops.ACT_LRELU, need_dx=2 if j == 0 else True)
             feats.append(cur)
         return feats
 
@@ -1039,7 +1055,9 @@ class GradBuckets:
     T2V_GRAD_RS_AG=1: reduce-scatter + all-gather per bucket instead of one all-reduce (what a ring all-reduce does
     internally; lets a sharded optimiser step sit between the two halves later).  T2V_GRAD_BUCKET_MB overrides 64."""
 
-    def __init__(self, params, bucket_mb=None, name=""):
+    def __init__(self, params, bucket_mb=None, name="", register=True):
+        """register=False: the parameters keep the gradient slots they have (a temporary set of buckets over parameters a
+        trainer owns must not take the trainer's slots away: ADVICE r3)"""
         import torch.distributed as dist
         self.params = list(params)
         self.name = name
@@ -1080,7 +1098,8 @@ class GradBuckets:
                 p = self.params[i]
                 view = self.flat[bounds[bi][0] + rel: bounds[bi][0] + rel + p.numel()].view(p.shape)
                 self.slots[i] = GradSlot(self, bi, i, view)
-                p._t2v_gslot = self.slots[i]
+                if register:
+                    p._t2v_gslot = self.slots[i]
                 self.bucket_of[i] = bi
         self.members = [[i for i, _ in mem] for mem in members]
         self.nbytes = 0
@@ -1217,7 +1236,7 @@ class GradientExchange:
 
     def __init__(self, params, bucket_mb=64):
         ps = [p for p in params if p.grad is not None]
-        self.b = GradBuckets(ps, bucket_mb) if ps else None
+        self.b = GradBuckets(ps, bucket_mb, register=False) if ps else None
         if self.b is not None:
             self.b.begin_step()
             self.b.absorb([p.grad for p in ps])
@@ -1537,7 +1556,8 @@ class Vid2VidTrainer:
             gG = torch.autograd.grad(loss_G, g_params, retain_graph=True, allow_unused=True)
         gG = flush_pending_weight_gradients(g_params, gG)
         self.bucketsG.absorb(gG)
-        gD = torch.autograd.grad(loss_D, d_params, allow_unused=True)
+        with input_gradients_off():      # D's loss: no data gradient into the (attached) fake frames
+            gD = torch.autograd.grad(loss_D, d_params, allow_unused=True)
         self.bucketsD.absorb(gD)
         if self.time_comm:       # T2V_TRAIN_COMM_TIMING=1: what of the exchange is still running once the backward kernels
             torch.cuda.synchronize()      # have drained = its exposed (not hidden) part
