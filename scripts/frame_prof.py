@@ -1,5 +1,5 @@
 """N frames of the config-2 generator (flow on unless --noflow) for rocprofv3: nothing but the frame loop.
-Usage: [T2V_STREAMS=1] frame_prof.py [--frames 40] [--noflow] [--size 512]"""
+Usage: [T2V_STREAMS=1] frame_prof.py [--frames 40] [--noflow] [--size 512] [--width W] [--batch N]"""
 import argparse, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -10,12 +10,14 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--frames", type=int, default=40)
 ap.add_argument("--noflow", action="store_true")
 ap.add_argument("--size", type=int, default=512)
+ap.add_argument("--width", type=int, default=0, help="frame width when it differs from --size (the reference's 512x320 / 512x680)")
 ap.add_argument("--batch", type=int, default=1, help="independent sequences advanced in lock-step")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 spec = GeneratorSpec(ngf=128, n_downsample=3, n_blocks=9, no_flow=a.noflow, norm="batch")
 model = Vid2VidModelG([HipGenerator(spec, dev).load_state_dict(synthetic_state_dict(spec, 1, flow_gain=0.1))])
-H = W = a.size
+H = a.size
+W = a.width or a.size
 rng = np.random.default_rng(0)
 win = torch.zeros(H, W, 12, device=dev)
 win[..., :9] = torch.from_numpy(np.where(rng.random((H, W, 1)) < 0.02, rng.uniform(-1, 1, (H, W, 9)), -1.0).astype(np.float32)).to(dev)

@@ -1005,7 +1005,10 @@ bool wino_gemm_skr_ok(int groups, int rows, int Tp, int K, int N, int c_cs) {
         const long resident = big ? grid : 2 * grid, per_tile = big ? 4L * nk : nk;
         alt = (tiles + resident - 1) / resident * per_tile * (big ? 1 : 2);     // (64x64: four blocks per CU = two per "slot")
     }
-    return run * 100 <= alt * 97;
+    // (measured on MI355X, scripts/sk_probe.py: a ragged run costs ~5 % more per unit than a whole-tile one -- the 1 x 4 tail
+    // tiles read 4/3 fragments per MFMA and the per-stage barrier does not shrink with the tile: 464 rows = 15 fragments lose
+    // against 16 padded ones, 352 / 320 / 224 / 688 rows win 4-9 %)
+    return run * 100 <= alt * 92;
 }
 
 int launch_wino_gemm_skr(hipStream_t s, const SkGemm& g, int rows) {
