@@ -548,10 +548,30 @@ def cold_start_block(n_maps=87):
                 return {"error": r.stderr[-400:]}
             split = json.load(open(tj))
         cs = split["cold_start"]
+        # the same command as a client of the resident server (--resident: weights stay on the GPU between utterances):
+        # the call that starts the server, then a warm one
+        renv = dict(env, T2V_RESIDENT_KEY="bench-%d" % os.getpid())
+        rwalls, rloop = [], None
+        try:
+            for _ in range(2):
+                shutil.rmtree(os.path.join(tmp, "results"), ignore_errors=True)
+                t0 = time.perf_counter()
+                r = subprocess.run(cmd + ["--resident"], cwd=os.path.join(ROOT, "vid2vid"), env=renv, stdout=subprocess.DEVNULL,
+                                   stderr=subprocess.PIPE, text=True)
+                rwalls.append(round(time.perf_counter() - t0, 3))
+                if r.returncode != 0:
+                    rwalls = None
+                    break
+                rloop = json.load(open(tj))["cold_start"]["loop_s"]
+        finally:
+            subprocess.run(cmd + ["--resident_stop"], cwd=os.path.join(ROOT, "vid2vid"), env=renv, stdout=subprocess.DEVNULL,
+                           stderr=subprocess.DEVNULL)
+        resident = None if not rwalls else {"first_call_wall_s": rwalls[0], "warm_call_wall_s": rwalls[1], "warm_loop_s": rloop,
+                                            "warm_wall_over_loop": round(rwalls[1] / max(rloop, 1e-9), 2)}
         return {"command": "python vid2vid/test.py <text2video_audio.sh:42 flags>, one process per utterance",
                 "workload": "configs[0]-shaped: tmp + tmp_smooth, 2 x %d frames 512x320, flow generator from a %.2f GB checkpoint"
                             % (n_maps - 2, os.path.getsize(os.path.join(tmp, "ckpt", "fadg0", "latest_net_G0.pth")) / 1e9),
-                "frames": split["frames"], "wall_s": walls, "split_of_last_run": cs,
+                "frames": split["frames"], "wall_s": walls, "split_of_last_run": cs, "resident": resident,
                 "wall_over_loop": round(walls[-1] / max(cs["loop_s"], 1e-9), 2),
                 "to_last_jpeg_over_loop": (round((cs["process_to_run_test_s"] + cs["to_last_jpeg_s"]) / max(cs["loop_s"], 1e-9), 2)
                                            if cs.get("process_to_run_test_s") is not None else None)}

@@ -64,6 +64,44 @@ def test_reference_command_line_end_to_end(tmp_path):
     assert r2.returncode != 0 and "not found" in (r2.stderr + r2.stdout)
 
 
+def test_resident_server_serves_the_one_shot_command(tmp_path):
+    """test.py --resident: the command is a thin client of a server process that keeps the model on the GPU between calls
+    (text2video_amd/resident.py).  Same command line, same files as the plain run, byte for byte; the second call reuses the
+    server (its pid in the closing line); a checkpoint / weight change is noticed (another --synthetic_weights seed gives
+    other frames); --resident_stop ends it."""
+    work = _make_dataset(str(tmp_path))
+    base = [sys.executable, os.path.join(ROOT, "vid2vid", "test.py"), "--name", "fadg0", "--dataroot", "datasets/fadg0",
+            "--dataset_mode", "pose", "--input_nc", "3", "--resize_or_crop", "scaleHeight", "--loadSize", "512",
+            "--openpose_only", "--how_many", "1200", "--no_first_img", "--random_drop_prob", "0", "--ngf", "32", "--n_blocks", "3"]
+    env = dict(os.environ, CUDA_VISIBLE_DEVICES="0", T2V_RESIDENT_KEY=str(tmp_path))      # this test's own server
+    res = os.path.join(work, "results", "fadg0", "test_latest")
+
+    def run(extra, seed="1"):
+        shutil.rmtree(os.path.join(work, "results"), ignore_errors=True)
+        r = subprocess.run(base + ["--synthetic_weights", seed] + extra, cwd=work, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        files = sorted(glob.glob(os.path.join(res, "*", "*.jpg")))
+        return r.stdout, {os.path.relpath(f, res): open(f, "rb").read() for f in files}
+
+    try:
+        _, plain = run([])
+        out1, first = run(["--resident", "--resident_idle_s", "120"])
+        out2, second = run(["--resident"])
+        assert len(plain) == 16 and first == plain and second == plain
+        assert "process image..." in out1 and "resident server, pid" in out1 and "resident server, pid" in out2
+        pid = lambda o: o.rsplit("pid", 1)[1].split(")")[0].strip()      # noqa: E731
+        assert pid(out1) == pid(out2)
+        out3, other = run(["--resident"], seed="2")
+        assert pid(out3) == pid(out1) and other.keys() == plain.keys() and other != plain
+        # a failing request is reported with its status, and the server lives on
+        r = subprocess.run(base + ["--resident"], cwd=work, env=env, capture_output=True, text=True, timeout=600)     # no checkpoint, no seed
+        assert r.returncode != 0 and "not found" in (r.stdout + r.stderr)
+        out4, again = run(["--resident"])
+        assert pid(out4) == pid(out1) and again == plain
+    finally:
+        subprocess.run(base + ["--resident_stop"], cwd=work, env=env, capture_output=True, text=True, timeout=120)
+
+
 def test_train_py_then_test_py_roundtrip(tmp_path):
     """train.py (reference flag surface, synthetic sequences: G + multiscale D + face D, Adam) writes
     upstream-format checkpoints that test.py loads and renders frames from."""
@@ -279,6 +317,7 @@ def test_bench_contract_line():
     cs = d["e2e"]["cold_start"]
     assert cs["frames"] == 170 and len(cs["wall_s"]) == 2 and cs["wall_s"][-1] > cs["split_of_last_run"]["loop_s"] > 0
     assert {"checkpoint_read_s", "weights_to_device_s", "pack_s", "first_step_s", "to_last_jpeg_s"} <= set(cs["split_of_last_run"])
+    assert cs["resident"]["warm_call_wall_s"] < cs["wall_s"][-1] and cs["resident"]["warm_loop_s"] > 0
     # BASELINE configs[3]: 1024x1024 frames, single-scale and two-scale generator, both variants, + the GEMM stage at that size
     hi = d["hires"]
     for name in ("single_scale", "two_scale"):

@@ -299,6 +299,7 @@ def run_test(opt, model=None, device=None, dataset=None):
                     out = os.path.join(os.path.dirname(vis.save_dir), "%s_%s.mp4" % (opt.name, os.path.basename(seq_dir)))
                     mux.write_mp4(frames, out, mux.FPS, getattr(opt, "video_audio", None) or None)
                     videos.append(out)
+    vis.close()
     t_end = time.perf_counter()
     n = counters["n"]
     stats = {"frames": n_first_pass, "frames_regenerated": n - n_first_pass, "seconds_total": t_end - t_start,

@@ -56,6 +56,10 @@ def _common(p):
     g("--no_hand_discs", action="store_true", help="do not draw the two radius-8 hand discs")
     g("--pose_workers", type=int, default=None, help="processes rasterising pose maps ahead of the GPU")
     g("--timing_json", type=str, default=None, help="write fps / per-stage timing to this file")
+    g("--resident", action="store_true", help="test.py: run through the resident server (weights stay on the GPU between "
+      "calls; started on first use, text2video_amd/resident.py); T2V_RESIDENT=1 does the same")
+    g("--resident_idle_s", type=float, default=600.0, help="the resident server leaves after this long without a request")
+    g("--resident_stop", action="store_true", help="test.py: stop the resident server of this device selection")
     g("--write_video", action="store_true", help="after the frame loop, mux every sequence's frames into "
       "results/<name>/<name>_<seq>.mp4 at 25 fps (the reference's image2video*.py stage; text2video_amd/mux.py)")
     g("--video_audio", type=str, default=None, help="--write_video: .wav / .mp3 sound track")

@@ -1,0 +1,230 @@
+"""Resident frame-synthesis server behind the one-shot `vid2vid/test.py` command (opt-in: --resident or T2V_RESIDENT=1).
+
+The reference starts a fresh `python test.py ...` per utterance (/root/reference/text2video_audio.sh:37-44,
+text2video_tts.sh:45, text2video_tts_chinese.sh:35).  On the MI355X path an utterance of 2 x 85 frames is 1.35 s of frame loop
+behind ~1.7 s of start-up that no single process can avoid: the interpreter importing torch (1.1 s) and the 1.5 GB checkpoint
+going to the device (0.4 s).  With --resident the command becomes a thin client (no torch import: ~30 ms) of a server process
+that keeps the HIP context, the packed / Winograd-transformed weights and the rasteriser workers across calls:
+
+    client (test.py)  --AF_UNIX /tmp/t2v_resident_<uid>_<key>.sock-->  server (this module, `python -m text2video_amd.resident`)
+      request : one JSON line {argv, cwd, env (T2V_*)}
+      reply   : frames  b"o" | b"e" + u32 length + bytes (the run's stdout / stderr, streamed) ... b"x" + i32 exit status
+
+The first call finds no server, starts one (detached, its own session, log in /tmp) and is served by it; later calls connect.
+The server handles one request at a time (the calls of the reference's scripts are sequential), reloads a checkpoint whose
+file changed, and exits after `--resident_idle_s` seconds without a request (default 600).  `key` = interpreter, package
+location, device selection: two installations or two GPUs never share a server.  test_fifo.py (a named pipe, the model loaded
+once) is the reference-named variant of the same idea; this one needs no change to the calling scripts beyond the flag / the
+environment variable.
+"""
+import hashlib
+import json
+import os
+import socket
+import struct
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEVICE_ENV = ("CUDA_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES")
+
+
+def _gpu_ids(argv):
+    for i, a in enumerate(argv):
+        if a == "--gpu_ids" and i + 1 < len(argv):
+            return argv[i + 1]
+        if a.startswith("--gpu_ids="):
+            return a.split("=", 1)[1]
+    return "0"
+
+
+def socket_path(argv):
+    # (T2V_RESIDENT_KEY: any string; lets independent servers coexist on one device selection)
+    key = json.dumps([sys.executable, ROOT, {k: os.environ.get(k, "") for k in DEVICE_ENV}, _gpu_ids(argv),
+                      os.environ.get("T2V_RESIDENT_KEY", "")])
+    return "/tmp/t2v_resident_%d_%s.sock" % (os.getuid(), hashlib.sha1(key.encode()).hexdigest()[:16])
+
+
+def _connect(path, timeout=None):
+    s = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+    try:
+        s.settimeout(timeout)
+        s.connect(path)
+        s.settimeout(None)
+        return s
+    except OSError:
+        s.close()
+        return None
+
+
+def _recv_exact(s, n):
+    buf = bytearray()
+    while len(buf) < n:
+        chunk = s.recv(n - len(buf))
+        if not chunk:
+            raise EOFError("resident server closed the connection")
+        buf += chunk
+    return bytes(buf)
+
+
+def client(argv, start_timeout=180.0):
+    """Run `test.py argv` through the resident server (started if there is none).  Returns the run's exit status, or None
+    when no server could be reached -- the caller then runs the frame loop itself."""
+    path = socket_path(argv)
+    s = _connect(path, 1.0)
+    if s is None and "--resident_stop" in argv:
+        return 0
+    if s is None:
+        idle = "600"
+        for i, a in enumerate(argv):
+            if a == "--resident_idle_s" and i + 1 < len(argv):
+                idle = argv[i + 1]
+        log = open(path[:-5] + ".log", "ab")
+        try:
+            subprocess.Popen([sys.executable, "-m", "text2video_amd.resident", path, idle], cwd=ROOT, stdin=subprocess.DEVNULL,
+                             stdout=log, stderr=log, start_new_session=True,
+                             env=dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", "")))
+        finally:
+            log.close()
+        t_end = time.time() + start_timeout
+        while s is None and time.time() < t_end:
+            time.sleep(0.05)
+            s = _connect(path, 1.0)
+        if s is None:
+            print("resident: no server came up at %s (see %s.log); running in this process" % (path, path[:-5]), file=sys.stderr)
+            return None
+    try:
+        req = {"argv": list(argv), "cwd": os.getcwd(), "env": {k: v for k, v in os.environ.items() if k.startswith("T2V_")}}
+        s.sendall(json.dumps(req).encode() + b"\n")
+        while True:
+            tag = _recv_exact(s, 1)
+            if tag == b"x":
+                return struct.unpack("<i", _recv_exact(s, 4))[0]
+            data = _recv_exact(s, struct.unpack("<I", _recv_exact(s, 4))[0])
+            out = sys.stdout if tag == b"o" else sys.stderr
+            out.write(data.decode(errors="replace"))
+            out.flush()
+    except (EOFError, OSError) as e:
+        print("resident: connection to the server lost (%s)" % e, file=sys.stderr)
+        return 1
+    finally:
+        s.close()
+
+
+class _Pipe:
+    """file-like: what the frame loop prints goes to the client as it is produced"""
+
+    def __init__(self, conn, tag):
+        self.conn, self.tag = conn, tag
+
+    def write(self, text):
+        if text:
+            data = text.encode()
+            try:
+                self.conn.sendall(self.tag + struct.pack("<I", len(data)) + data)
+            except OSError:
+                pass            # the client went away: the run itself goes on to its end
+        return len(text)
+
+    def flush(self):
+        pass
+
+
+def model_key(opt):
+    """what decides whether a resident model can serve a request: the checkpoint files (path, size, mtime) or the synthetic
+    seed, and the architecture flags"""
+    files = []
+    for s in range(opt.n_scales_spatial):
+        p = os.path.abspath(os.path.join(opt.checkpoints_dir, opt.name, "%s_net_G%d.pth" % (opt.which_epoch, s)))
+        try:
+            st = os.stat(p)
+            files.append((p, st.st_size, st.st_mtime_ns))
+        except OSError:
+            files.append((p, None, None))
+    return json.dumps([files, opt.synthetic_weights, opt.ngf, opt.n_blocks, opt.n_blocks_local, opt.n_downsample_G,
+                       opt.n_frames_G, opt.input_nc, opt.label_nc, opt.output_nc, opt.norm, bool(opt.no_flow),
+                       bool(getattr(opt, "no_flow_explicit", False)), opt.n_scales_spatial, bool(opt.no_first_img), str(opt.gpu_ids)])
+
+
+def serve(path, idle_s):
+    import contextlib
+    from text2video_amd.model import create_model, run_test
+    from text2video_amd.options import TestOptions
+    try:
+        os.unlink(path)
+    except OSError:
+        pass
+    srv = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+    old = os.umask(0o177)
+    try:
+        srv.bind(path)
+    finally:
+        os.umask(old)
+    srv.listen(8)
+    print("resident: serving on %s (pid %d), idle limit %.0f s" % (path, os.getpid(), idle_s), flush=True)
+    models = {}
+    env0 = {k: v for k, v in os.environ.items() if k.startswith("T2V_")}
+    try:
+        while True:
+            srv.settimeout(idle_s)
+            try:
+                conn, _ = srv.accept()
+            except socket.timeout:
+                print("resident: idle for %.0f s, leaving" % idle_s, flush=True)
+                return
+            with conn:
+                rc = 1
+                try:
+                    line = bytearray()
+                    while not line.endswith(b"\n"):
+                        chunk = conn.recv(65536)
+                        if not chunk:
+                            break
+                        line += chunk
+                    req = json.loads(line.decode())
+                    argv = [a for a in req["argv"] if a != "--resident"]
+                    if "--resident_stop" in argv:
+                        conn.sendall(b"x" + struct.pack("<i", 0))
+                        return
+                    os.chdir(req["cwd"])
+                    for k in [k for k in os.environ if k.startswith("T2V_")]:
+                        del os.environ[k]
+                    os.environ.update(env0)
+                    os.environ.update(req.get("env", {}))
+                    from text2video_amd import ops
+                    ops.reload_env()                 # the library reads its switches once: this request's apply from here on
+                    with contextlib.redirect_stdout(_Pipe(conn, b"o")), contextlib.redirect_stderr(_Pipe(conn, b"e")):
+                        try:
+                            opt = TestOptions().parse(argv)
+                            device = "cuda:%d" % (opt.gpu_ids[0] if opt.gpu_ids else 0)
+                            key = model_key(opt)
+                            model = models.get(key)
+                            if model is None:
+                                models.clear()                      # one set of weights resident at a time
+                                model = models[key] = create_model(opt, device)
+                            stats = run_test(opt, model=model, device=device)
+                            print("done: %d frames, %.2f fps in the frame loop -> %s (resident server, pid %d)"
+                                  % (stats["frames"], stats["fps_loop"], stats["results_dir"], os.getpid()))
+                            rc = 0
+                        except SystemExit as e:
+                            rc = e.code if isinstance(e.code, int) else 1
+                        except BaseException:        # noqa: BLE001 -- reported to the client, the server lives on
+                            import traceback
+                            traceback.print_exc()
+                            rc = 1
+                finally:
+                    try:
+                        conn.sendall(b"x" + struct.pack("<i", int(rc)))
+                    except OSError:
+                        pass
+    finally:
+        srv.close()
+        try:
+            os.unlink(path)
+        except OSError:
+            pass
+
+
+if __name__ == "__main__":
+    serve(sys.argv[1], float(sys.argv[2]) if len(sys.argv) > 2 else 600.0)

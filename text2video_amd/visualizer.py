@@ -45,3 +45,8 @@ class Visualizer:
         for f in self.pending:
             f.result()
         self.pending = []
+
+    def close(self):
+        """flush and release the encoder threads (a resident server builds one Visualizer per request)"""
+        self.flush()
+        self.pool.shutdown(wait=True)

@@ -9,6 +9,8 @@ Reads datasets/<name>/test_openpose/<seq>/*.json (+ test_img/<seq>/*.jpg for siz
 results/<name>/test_latest/<seq>/{real_A,fake_B}_*.jpg.  The generator runs on the MI355X through
 libt2v_hip.so; there is no CPU fallback.  `--gpu_ids a,b,...` with more than one device runs one rank per device
 (whole sequences per rank; --shard_chunks also cuts sequences), started by this script itself or by torchrun.
+`--resident` (or T2V_RESIDENT=1 in the environment of an unchanged text2video_audio.sh): the command becomes a thin client of
+a server process that keeps the weights on the GPU between utterances (text2video_amd/resident.py); `--resident_stop` ends it.
 """
 import os
 import sys
@@ -44,6 +46,17 @@ def _warm_hip_runtime():
 
 
 if __name__ == "__main__":
+    _args = sys.argv[1:]
+    _multi = any(a == "--gpu_ids" and i + 1 < len(_args) and "," in _args[i + 1].strip(",") for i, a in enumerate(_args))
+    if ("--resident" in _args or "--resident_stop" in _args or os.environ.get("T2V_RESIDENT") == "1") and not _multi \
+            and "WORLD_SIZE" not in os.environ:
+        # thin client of the resident server (text2video_amd/resident.py): no torch import, no checkpoint load in this process
+        from text2video_amd import resident
+        _rc = resident.client(_args)
+        if _rc is not None:
+            sys.stdout.flush()
+            sys.stderr.flush()
+            os._exit(_rc)
     _warm_hip_runtime()
 
 from text2video_amd.model import run_test      # noqa: E402
