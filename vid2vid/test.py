@@ -18,33 +18,6 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def _warm_hip_runtime():
-    """The reference starts this script once per utterance, so start-up is part of every run: bring the HIP runtime up
-    (hipInit, device context, ~0.2 s) on a thread WHILE the interpreter imports torch (~1 s, mostly Python byte code), instead
-    of at the first device copy afterwards.  The runtime is the one torch ships (the same file torch will map); ctypes calls
-    release the GIL.  Best effort: any failure just leaves the initialisation where it was."""
-    import threading
-
-    def warm():
-        try:
-            import ctypes
-            import importlib.util
-            spec = importlib.util.find_spec("torch")          # located, not imported
-            lib = ctypes.CDLL(os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so"),
-                              mode=ctypes.RTLD_GLOBAL)
-            dev = 0
-            for i, a in enumerate(sys.argv):
-                if a == "--gpu_ids" and i + 1 < len(sys.argv):
-                    dev = max(0, int(sys.argv[i + 1].split(",")[0] or 0))
-            if lib.hipInit(0) == 0 and lib.hipSetDevice(dev) == 0:
-                lib.hipFree(None)                             # forces the device context
-        except Exception:      # noqa: BLE001
-            pass
-    multi = any(a == "--gpu_ids" and i + 1 < len(sys.argv) and "," in sys.argv[i + 1].strip(",") for i, a in enumerate(sys.argv))
-    if "WORLD_SIZE" not in os.environ and not multi:     # (a launcher that fans out ranks must not hold a device context)
-        threading.Thread(target=warm, daemon=True).start()
-
-
 if __name__ == "__main__":
     _args = sys.argv[1:]
     _multi = any(a == "--gpu_ids" and i + 1 < len(_args) and "," in _args[i + 1].strip(",") for i, a in enumerate(_args))
@@ -57,7 +30,6 @@ if __name__ == "__main__":
             sys.stdout.flush()
             sys.stderr.flush()
             os._exit(_rc)
-    _warm_hip_runtime()
 
 from text2video_amd.model import run_test      # noqa: E402
 from text2video_amd.options import TestOptions  # noqa: E402
