@@ -992,23 +992,27 @@ bool wino_gemm_skr_ok(int groups, int rows, int Tp, int K, int N, int c_cs) {
     const long grid = wino_gemm_sk_grid_blocks();
     const long run = skr_run_units(groups, rows, K, N, nullptr);        // fragment rows x stages per block, 2 blocks per CU
     // the alternatives, in the same units per CU-resident pair of blocks
-    long alt;
+    // The alternatives, in the same units per CU-resident pair of blocks, each with its measured cost per unit relative to the
+    // whole-tile fixed grid (MI355X, scripts/sk_probe.py): a ragged run costs ~8 % more per unit (the 1 x 4 tail tiles read 4/3
+    // fragments per MFMA and the per-stage barrier does not shrink with the tile), one block per 128x128 tile ~3 %, one block
+    // per 64x64 tile ~12 % (bound by the LDS-DMA stream).  464 rows = 15 fragments lose against 16 padded ones;
+    // 352 / 224 / 688 rows win 3-5 % against their padded fixed grid, 320 rows 9 % against 64x64 tiles.
+    long alt, alt_cost;
     if (wino_gemm_sk_ok(groups, Tp, K, N, c_cs)) {
         const int bm = Tp % 128 == 0 ? 128 : 192, bn = bm == 128 ? 128 : 64;
         const long tiles = (long)groups * (Tp / bm) * (N / bn);
         const long per_tile = (long)(bm / 32) * nk * bn / 128;           // in units of a 128-column fragment row x stage
         alt = std::max(per_tile, (tiles * per_tile + grid - 1) / grid);
+        alt_cost = 100;
     } else {
         // one block per 64x64 or 128x128 tile, whole rounds of the resident blocks
         const bool big = Tp % 128 == 0;
         const long tiles = big ? (long)groups * (Tp / 128) * (N / 128) : (long)groups * (Tp / 64) * (N / 64);
         const long resident = big ? grid : 2 * grid, per_tile = big ? 4L * nk : nk;
         alt = (tiles + resident - 1) / resident * per_tile * (big ? 1 : 2);     // (64x64: four blocks per CU = two per "slot")
+        alt_cost = big ? 103 : 112;
     }
-    // (measured on MI355X, scripts/sk_probe.py: a ragged run costs ~5 % more per unit than a whole-tile one -- the 1 x 4 tail
-    // tiles read 4/3 fragments per MFMA and the per-stage barrier does not shrink with the tile: 464 rows = 15 fragments lose
-    // against 16 padded ones, 352 / 320 / 224 / 688 rows win 4-9 %)
-    return run * 100 <= alt * 92;
+    return run * 108 <= alt * alt_cost;
 }
 
 int launch_wino_gemm_skr(hipStream_t s, const SkGemm& g, int rows) {
