@@ -25,9 +25,10 @@ def run(H, W, C):
     pu = ops.pack_conv_weight(w, desc, C)
     ws = ops.winograd_workspace(desc, C, dev)
     res = {}
-    for sk in ("0", "1", "whole"):     # one block per tile | the default rule | the default rule without the ragged M tiles
+    for sk in ("0", "1", "whole"):     # one block per tile | the default rule | the default rule without the ragged / tall tiles
         os.environ["T2V_WINO_GEMM_SK"] = "1" if sk == "whole" else sk
         os.environ["T2V_WINO_GEMM_SK_RAGGED"] = "0" if sk == "whole" else "1"
+        os.environ["T2V_WINO_GEMM_SK_TALL"] = "0" if sk == "whole" else "1"
         ops.reload_env()
         ws.fill_(float("nan"))
         y = ops.conv2d_winograd(x, pu, b, desc, workspace=ws)

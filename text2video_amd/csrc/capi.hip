@@ -37,6 +37,7 @@ void options_reload() {
     o.wino_gemm_sk_wide = env_int("T2V_WINO_GEMM_SK_WIDE", 1);
     o.wino_gemm_sk_half = env_int("T2V_WINO_GEMM_SK_HALF", 1);
     o.wino_gemm_sk_ragged = env_int("T2V_WINO_GEMM_SK_RAGGED", 1);
+    o.wino_gemm_sk_tall = env_int("T2V_WINO_GEMM_SK_TALL", 1);
     o.wgrad_sk = env_int("T2V_WGRAD_SK", 1);
     o.wgrad_sk_half = env_int("T2V_WGRAD_SK_HALF", 1);
     o.wgrad_combine = env_int("T2V_WGRAD_COMBINE", 1);
@@ -397,10 +398,11 @@ int winograd_forward(t2v_ctx* ctx, hipStream_t s, const t2v_conv_desc* d, const 
             g.a_group_stride = (long)T * d->Cin;
             g.groups = 36; g.T = (int)T; g.K = d->Cin; g.N = d->Cout; g.c_cs = d->Cout;
             T2V_TRY(launch_wino_gemm_skr(s, g, rows));
-        } else if (f4 && wino_gemm_sk_ok(36, (int)T, d->Cin, d->Cout, d->Cout)) {
+        } else if (f4 && wino_gemm_sk_ok(36, (int)T, d->Cin, d->Cout, d->Cout, rows)) {
             SkGemm g;
             g.a = V; g.b = w_packed; g.c = Mm; g.scratch = workspace + winograd_vm_floats(d, nimg);
             g.err = async_error_word();
+            g.rows = rows;
             g.a_group_stride = (long)T * d->Cin;
             g.groups = 36; g.T = (int)T; g.K = d->Cin; g.N = d->Cout; g.c_cs = d->Cout;
             T2V_TRY(launch_wino_gemm_sk(s, g));

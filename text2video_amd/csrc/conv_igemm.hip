@@ -77,6 +77,7 @@ using CfgL = TileCfg<32, 2, 2, 2, 2>;  // 128 x 128
 using CfgS = TileCfg<16, 4, 1, 4, 1>;  // 256 x 16 (3-channel heads)
 using CfgQ = TileCfg<32, 2, 2, 1, 1>;  // 64 x 64: finer granularity when 128x128 tiles fill the 256 CUs poorly
 using CfgW = TileCfg<32, 2, 2, 3, 1>;  // 192 x 64: all tile rows of a 512x320 frame's transform position in one tile (fixed grid)
+using CfgT = TileCfg<32, 1, 4, 5, 1>;  // 160 x 128: the same rows without the padding, 80 accumulator registers: one block per CU
 
 // One LDS-DMA instruction through buffer addressing: 64 lanes x 16 B -> 1 KiB at the wave-uniform LDS
 // address `lds_dst`; source = base + voff (per lane, bytes) + soff (scalar, bytes).  Lanes with
@@ -476,6 +477,7 @@ __global__ __launch_bounds__(512) void wino_gemm_sk_kernel(const SkKParams p) {
     using acc_t = typename MM::acc_t;
     constexpr int BM = Cfg::BM, BN = Cfg::BN, MF = 32;
     constexpr int A_ITERS = BM / 32, B_PER_WAVE = BN / 32, LD_PER_WAVE = A_ITERS + B_PER_WAVE;
+    constexpr int PW = Cfg::TM * Cfg::TN * 1024 > 4096 ? Cfg::TM * Cfg::TN * 1024 : 4096;   // floats of one wave's hand-over slot
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -599,7 +601,7 @@ __global__ __launch_bounds__(512) void wino_gemm_sk_kernel(const SkKParams p) {
             // write-through (sc1) stores on the producer's side, sc1 loads here: the pair that is coherent across the
             // XCDs' L2s inside one launch; 16 x 16 bytes per lane at scalar offsets off one SRD
             const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<float*>(p.partial) + (size_t)(src * 4 + wid) * 4096, 0, 16384, 0x00020000);
+                const_cast<float*>(p.partial) + (size_t)(src * 4 + wid) * PW, 0, PW * 4, 0x00020000);
 #pragma unroll
             for (int i = 0; i < Cfg::TM; ++i)
 #pragma unroll
@@ -632,7 +634,7 @@ __global__ __launch_bounds__(512) void wino_gemm_sk_kernel(const SkKParams p) {
 
         if (publish) {
             const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(
-                p.partial + (size_t)(blockIdx.x * 4 + wid) * 4096, 0, 16384, 0x00020000);
+                p.partial + (size_t)(blockIdx.x * 4 + wid) * PW, 0, PW * 4, 0x00020000);
 #pragma unroll
             for (int i = 0; i < Cfg::TM; ++i)
 #pragma unroll
@@ -907,8 +909,17 @@ static int sk_tile_rows(int T, int N) {
 static bool sk_half_round(long tiles, long grid, int nk) {
     return options().wino_gemm_sk_half && tiles >= grid && 2 * (tiles % grid) == grid && nk % 2 == 0 && grid % 16 == 0;
 }
-bool wino_gemm_sk_ok(int groups, int T, int K, int N, int c_cs) {
+// 129 .. 160 real rows per position (the 64 x 40 bottleneck of the reference's 512x320 frames: 160 Winograd tiles): ONE
+// 160 x 128 tile per position and column tile -- no padding rows, 0.0141 B of LDS-DMA per MAC (192 x 64: 0.0208) -- whose 80
+// accumulator registers and 108 KiB ring allow one block per CU: a fixed grid of one block per CU, 288 tiles on 256 blocks
+static bool sk_tall(int groups, int rows, int T, int N) {
+    if (!options().wino_gemm_sk_tall || rows <= 128 || rows > 160 || T < 160 || N % 128) return false;
+    const long tiles = (long)groups * (N / 128), grid = wino_gemm_sk_grid_blocks() / 2;
+    return tiles >= grid && tiles * 100 <= ((tiles + grid - 1) / grid) * grid * 85;
+}
+bool wino_gemm_sk_ok(int groups, int T, int K, int N, int c_cs, int rows) {
     const int mode = fixed_grid_enabled() ? options().wino_gemm_sk : 0;
+    if (mode != 0 && rows > 0 && K % kBK == 0 && c_cs == N && sk_tall(groups, rows, T, N)) return true;
     const int bm = sk_tile_rows(T, N);
     if (mode == 0 || bm == 0 || K % kBK || c_cs != N || (long)192 * K * 4 >= 0x7fff0000L) return false;
     // fewer tiles than resident blocks: one tile per block is already less than one round.  Beyond that the fixed grid
@@ -936,10 +947,10 @@ unsigned long long wino_gemm_sk_next_tag() {
     return ++tag_counter;
 }
 
-template <class Cfg>
+template <class Cfg, int RING = 2>
 static int launch_sk(hipStream_t s, const SkKParams& k, int grid) {
-    auto kern = wino_gemm_sk_kernel<Cfg, 2>;
-    constexpr int LDS_BYTES = 2 * Cfg::STAGE_BYTES;
+    auto kern = wino_gemm_sk_kernel<Cfg, RING>;
+    constexpr int LDS_BYTES = RING * Cfg::STAGE_BYTES;
     static bool attr_done = false;   // per instantiation
     if (!attr_done) {
         T2V_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
@@ -951,7 +962,7 @@ static int launch_sk(hipStream_t s, const SkKParams& k, int grid) {
 }
 
 int launch_wino_gemm_sk(hipStream_t s, const SkGemm& g) {
-    T2V_REQUIRE(wino_gemm_sk_ok(g.groups, g.T, g.K, g.N, g.c_cs), "stream-K gemm: shape not supported");
+    T2V_REQUIRE(wino_gemm_sk_ok(g.groups, g.T, g.K, g.N, g.c_cs, g.rows), "stream-K gemm: shape not supported");
     SkKParams k;
     k.a = g.a; k.b = g.b; k.c = g.c;
     k.partial = g.scratch;
@@ -960,6 +971,15 @@ int launch_wino_gemm_sk(hipStream_t s, const SkGemm& g) {
     k.err = g.err;
     k.a_group_stride = g.a_group_stride;
     k.T = g.T; k.K = g.K; k.N = g.N; k.c_cs = g.c_cs;
+    if (g.rows > 0 && sk_tall(g.groups, g.rows, g.T, g.N)) {
+        k.mtiles_g = 1; k.ntiles = g.N / 128; k.nk = g.K / kBK;
+        k.tiles = g.groups * k.ntiles;
+        const int grid = wino_gemm_sk_grid_blocks() / 2;       // one block per CU
+        k.blocks_per_xcd = grid / 8;
+        k.tiles_per_xcd = (k.tiles + 7) / 8;
+        k.rounds = 0;
+        return launch_sk<CfgT, 3>(s, k, grid);
+    }
     const int bm = sk_tile_rows(g.T, g.N), bn = bm == 128 ? 128 : 64;
     k.mtiles_g = g.T / bm; k.ntiles = g.N / bn; k.nk = g.K / kBK;
     k.tiles = g.groups * k.mtiles_g * k.ntiles;
