@@ -210,6 +210,65 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradParams p) {
                 wg_dma16(p.x, x_bytes, sX + (wid * RW + i * 2) * 512, vx, 0);
             }
         };
+        // Fast path (every layer of the generator but the folded stems / heads): the GEMM rows are whole stages long, so the
+        // 16 pixels of a stage are one run of one output row -- the stage's (image, row, first column) live in SGPRs, stepped
+        // with scalar compares, dY needs a scalar offset only and X one add, one multiply-add, one compare and one select per
+        // DMA instruction.  The general path above spends ~55 vector instructions per instruction on stepping and index
+        // arithmetic (481 VALU per 128 MFMA in the PMC passes of round 4: profiles/pmc/r04_wgrad_s2_*), which the MFMA waves
+        // of the same SIMDs pay for in issue slots.
+        const bool fast = !REFLECT && p.fold == 0 && (p.Wm % kWgPix) == 0 && (p.M % kWgPix) == 0;
+        if (fast) {
+            int sb, sy, sx;
+            {
+                const int p0 = kt0 * kWgPix;
+                sb = p0 / p.M;
+                const int m = p0 - sb * p.M;
+                sy = m / p.Wm;
+                sx = m - sy * p.Wm;
+            }
+            sb = __builtin_amdgcn_readfirstlane(sb);
+            sy = __builtin_amdgcn_readfirstlane(sy);
+            sx = __builtin_amdgcn_readfirstlane(sx);
+            int vy_c[NI], lx0[NI];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int lp = wid * RW + i * 2 + prow;           // this lane's pixel inside the stage
+                vy_c[i] = n_ok ? ((lp * p.ostride) * p.Cout_s + n0 + chunk * 4) * 4 : kOOB;
+                lx0[i] = lp * p.stride + ldx;
+            }
+            const int xrow_bytes = p.Win * p.Cin_s * 4;
+            int curf = 0;
+            auto issue_fast = [&](int kt, int slot) {
+                char* sY = smem + slot * kWgStage;
+                char* sX = sY + kWgPix * 512;
+                if (kt > curf) {   // kt == curf + 1
+                    curf = kt;
+                    sx += kWgPix;
+                    if (sx >= p.Wm) {
+                        sx = 0;
+                        if (++sy >= Hm) {
+                            sy = 0;
+                            ++sb;
+                        }
+                    }
+                }
+                const bool inb = sb < p.batch;
+                const int soff_y = (((sb * p.Hout + sy * p.ostride + p.toy[tap]) * p.Wout) + sx * p.ostride + p.tox[tap]) * p.Cout_s * 4;
+                const int iy = sy * p.stride + ldy;
+                const bool rowok = inb && (unsigned)iy < (unsigned)p.Hin;
+                const int soff_x = rowok ? (sb * p.Hin + iy) * xrow_bytes : 0;
+                const int ix0 = sx * p.stride;
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    wg_dma16(p.dy, dy_bytes, sY + (wid * RW + i * 2) * 512, inb ? vy_c[i] : kOOB, inb ? soff_y : 0);
+                    const int ix = ix0 + lx0[i];
+                    const int vx = (rowok && c_ok && (unsigned)ix < (unsigned)p.Win) ? (ix * p.Cin_s + lc) * 4 : kOOB;
+                    wg_dma16(p.x, x_bytes, sX + (wid * RW + i * 2) * 512, vx, soff_x);
+                }
+            };
+            loader_k_loop<kWgRing, 2 * NI>(0, nk, issue_fast);
+            return;
+        }
         loader_k_loop<kWgRing, 2 * NI>(0, nk, issue_stage);   // (nk == 0, an empty split range: stage 0 once, B0 only)
         return;
     }
