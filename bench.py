@@ -201,14 +201,9 @@ def gemm_stage_roofline(dev, sd, g0h, g0w, iters):
     k_flop = 2.0 * npos * ntile * C * C if use_wino else conv_flop
     achieved = k_flop / (k_ms * 1e-3) / 1e12
     traffic = None
-    # the fixed-grid form of the F(4x4) GEMM stage (conv_igemm.hip: wino_gemm_sk_ok -- same rule restated here for the
-    # label only): whole 128-row tiles, at least one round of the 512 resident blocks, a badly filled last round or exactly
-    # half a round left over
-    trows = ops.winograd_tile_rows(desc) if algo == ops.ALGO_WINOGRAD_F4 else 0     # tile rows per position, padded
-    sk_tiles = npos * (trows // 128) * (C // 128) if (trows and trows % 128 == 0) else \
-        (npos * (trows // 192) * (C // 64) if (trows and trows % 192 == 0) else 0)      # 128x128 | 192x64 tiles
-    fixed_grid = bool(sk_tiles >= 512 and (sk_tiles * 100 <= -(-sk_tiles // 512) * 512 * 85 or 2 * (sk_tiles % 512) == 512)
-                      and os.environ.get("T2V_WINO_GEMM_SK", "1") != "0")
+    # which form the GEMM stage takes here (the library's own answer: t2v_conv_winograd_gemm_form)
+    form = ops.winograd_gemm_form(desc) if algo == ops.ALGO_WINOGRAD_F4 else ""
+    fixed_grid = form.startswith("wino_gemm_sk")
     prof = os.path.join(ROOT, "profiles", "pmc_summary.json")
     if os.path.exists(prof):
         try:
@@ -219,10 +214,7 @@ def gemm_stage_roofline(dev, sd, g0h, g0w, iters):
                                                 if (hb, wb) == (64, 64) else "-")
         except Exception:
             traffic = None
-    kname = (("wino_gemm_sk_kernel<%s tiles on a fixed grid of 2 blocks per CU,fp32 32x32x2>"
-              % ("128x128" if trows % 128 == 0 else "192x64")
-              if fixed_grid else "conv_igemm_kernel<%s,fp32 32x32x2>"
-              % ("128x128" if npos * ntile // 128 * 8 >= 0.8 * 256 * -(-(npos * ntile // 128 * 8) // 256) else "64x64"))
+    kname = ((form.replace(">", ",fp32 32x32x2>") if algo == ops.ALGO_WINOGRAD_F4 else "conv_igemm_kernel<fp32 32x32x2>")
              + " as %d batched GEMMs [%d x 1024]x[1024 x 1024]: Winograd F(%dx%d,3x3) stage of the 1024->1024 3x3 "
                "ResnetBlock conv @%dx%d" % (npos, ntile, wm, wm, hb, wb)
              if use_wino else

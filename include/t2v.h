@@ -133,6 +133,13 @@ size_t t2v_conv_winograd_workspace_floats(const t2v_conv_desc* d, int x_cs);
 /* GEMM rows one image contributes per F(4x4,3x3) transform position: its ceil(H/4) x ceil(W/4) tiles padded to the
  * 64 / 128-row granule (the slot pitch of the batch-wide tile lists in the weight-gradient workspace) */
 int t2v_conv_winograd_tile_rows(const t2v_conv_desc* d);
+/* Which form the batched GEMM stage of an F(4x4,3x3) conv over `nimg` images takes under the current switches (reporting
+ * only: bench.py's roofline label): one block per tile, or a fixed grid of resident blocks that hand accumulators over where
+ * a tile is cut -- on 128x128 tiles, 192x64 tiles, 160x128 tiles with one block per CU (129..160 tile rows: the reference's
+ * 512x320 frames), or ragged M tiles of 4,..,4,r 32-row fragments.  -1: not an F(4x4,3x3) conv. */
+enum { T2V_GEMM_TILE_PER_BLOCK_64x64 = 0, T2V_GEMM_TILE_PER_BLOCK_128x128 = 1, T2V_GEMM_FIXED_GRID_128x128 = 2,
+       T2V_GEMM_FIXED_GRID_192x64 = 3, T2V_GEMM_FIXED_GRID_160x128 = 4, T2V_GEMM_FIXED_GRID_RAGGED = 5 };
+int t2v_conv_winograd_gemm_form(const t2v_conv_desc* d, int nimg);
 /* forward with d->algo == T2V_ALGO_WINOGRAD | T2V_ALGO_WINOGRAD_F4; same contract as t2v_conv2d_forward plus the workspace */
 int t2v_conv2d_forward_winograd(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, const float* x, int x_cs,
                                 const float* w_packed, const float* bias, float* y, int y_cs, float* stats_partial,

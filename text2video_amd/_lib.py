@@ -67,6 +67,7 @@ SIGNATURES = {
     "t2v_conv_best_algo": (c_int, [POINTER(ConvDesc), c_int, c_int]),
     "t2v_conv_winograd_workspace_floats": (c_size_t, [POINTER(ConvDesc), c_int]),
     "t2v_conv_winograd_tile_rows": (c_int, [POINTER(ConvDesc)]),
+    "t2v_conv_winograd_gemm_form": (c_int, [POINTER(ConvDesc), c_int]),
     "t2v_conv2d_forward_winograd": (c_int, [c_void_p, c_void_p, POINTER(ConvDesc), c_void_p, c_int, c_void_p, c_void_p,
                                             c_void_p, c_int, c_void_p, c_void_p]),
     "t2v_conv2d_forward_winograd_stages": (c_int, [c_void_p, c_void_p, POINTER(ConvDesc), c_void_p, c_int, c_void_p,

@@ -804,6 +804,17 @@ size_t t2v_conv_backward_weight_winograd_workspace_floats(const t2v_conv_desc* d
 int t2v_conv_winograd_tile_rows(const t2v_conv_desc* d) {
     return d ? wino_tiles_padded(d, T2V_ALGO_WINOGRAD_F4) : 0;
 }
+int t2v_conv_winograd_gemm_form(const t2v_conv_desc* d, int nimg) {
+    if (!d || d->algo != T2V_ALGO_WINOGRAD_F4 || nimg < 1) return -1;
+    const int T = wino_rows_batch(d, d->algo, nimg), rows = nimg * wino_tiles_real(d, d->algo);
+    if (wino_gemm_skr_ok(36, rows, T, d->Cin, d->Cout, d->Cout)) return T2V_GEMM_FIXED_GRID_RAGGED;
+    if (wino_gemm_sk_ok(36, T, d->Cin, d->Cout, d->Cout, rows))
+        return wino_gemm_sk_uses_tall(36, rows, T, d->Cout) ? T2V_GEMM_FIXED_GRID_160x128
+               : (T % 128 == 0 ? T2V_GEMM_FIXED_GRID_128x128 : T2V_GEMM_FIXED_GRID_192x64);
+    ConvPlan pl;
+    if (build_winograd_gemm_plan(d, &pl, nimg) != T2V_OK) return -1;
+    return pl.tile == kTileL ? T2V_GEMM_TILE_PER_BLOCK_128x128 : T2V_GEMM_TILE_PER_BLOCK_64x64;
+}
 int t2v_conv2d_backward_weight_winograd_stages(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, int batch, int b0,
                                                int nb, const float* x, int x_cs, const float* dy, int dy_cs,
                                                float* dw_torch, int accumulate, float* workspace, int stages) {

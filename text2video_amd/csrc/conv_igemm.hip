@@ -917,6 +917,7 @@ static bool sk_tall(int groups, int rows, int T, int N) {
     const long tiles = (long)groups * (N / 128), grid = wino_gemm_sk_grid_blocks() / 2;
     return tiles >= grid && tiles * 100 <= ((tiles + grid - 1) / grid) * grid * 85;
 }
+bool wino_gemm_sk_uses_tall(int groups, int rows, int T, int N) { return rows > 0 && sk_tall(groups, rows, T, N); }
 bool wino_gemm_sk_ok(int groups, int T, int K, int N, int c_cs, int rows) {
     const int mode = fixed_grid_enabled() ? options().wino_gemm_sk : 0;
     if (mode != 0 && rows > 0 && K % kBK == 0 && c_cs == N && sk_tall(groups, rows, T, N)) return true;

@@ -246,6 +246,7 @@ struct SkGemm {
 };
 size_t wino_gemm_sk_scratch_floats();
 bool wino_gemm_sk_ok(int groups, int T, int K, int N, int c_cs, int rows = 0);   // rows: real tile rows per position, if known
+bool wino_gemm_sk_uses_tall(int groups, int rows, int T, int N);     // the 160 x 128 / one-block-per-CU form of that kernel
 int launch_wino_gemm_sk(hipStream_t s, const SkGemm& g);
 // the ragged form (conv_igemm.hip: wino_gemm_skr_kernel): `rows` real tile rows per position (<= g.T, the padded pitch), cut
 // into 32-row fragments and M tiles of 4, ..., 4, r fragments -- no MFMA work on padding rows

@@ -99,6 +99,18 @@ def with_algo(desc, algo):
                     desc.transposed, desc.act, desc.act_scale, desc.output_padding, algo)
 
 
+GEMM_FORMS = {0: "conv_igemm_kernel<64x64 tiles, one block per tile>", 1: "conv_igemm_kernel<128x128 tiles, one block per tile>",
+              2: "wino_gemm_sk_kernel<128x128 tiles on a fixed grid of 2 blocks per CU>",
+              3: "wino_gemm_sk_kernel<192x64 tiles on a fixed grid of 2 blocks per CU>",
+              4: "wino_gemm_sk_kernel<160x128 tiles on a fixed grid of 1 block per CU>",
+              5: "wino_gemm_skr_kernel<ragged 128/96/64/32 x 128 tiles on a fixed grid of 2 blocks per CU>"}
+
+
+def winograd_gemm_form(desc, nimg=1):
+    """name of the kernel form the F(4x4,3x3) GEMM stage of `desc` takes for `nimg` images per launch"""
+    return GEMM_FORMS.get(_lib.load().t2v_conv_winograd_gemm_form(ctypes.byref(desc), nimg), "?")
+
+
 def winograd_tile_rows(desc):
     """GEMM rows one image contributes per F(4x4,3x3) transform position (tile count, padded)"""
     return _lib.load().t2v_conv_winograd_tile_rows(ctypes.byref(desc))
