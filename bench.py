@@ -211,7 +211,9 @@ def gemm_stage_roofline(dev, sd, g0h, g0w, iters):
                                                  1: "winograd_f2_gemm_hbm_bytes_per_launch",
                                                  2: ("winograd_f4_gemm_sk_hbm_bytes_per_launch" if fixed_grid else
                                                      "winograd_f4_gemm_hbm_bytes_per_launch")}[algo]
-                                                if (hb, wb) == (64, 64) else "-")
+                                                if (hb, wb) == (64, 64) else
+                                                {(64, 40): "winograd_f4_gemm_512x320_hbm_bytes_per_launch",
+                                                 (64, 85): "winograd_f4_gemm_512x680_hbm_bytes_per_launch"}.get((hb, wb), "-"))
         except Exception:
             traffic = None
     kname = ((form.replace(">", ",fp32 32x32x2>") if algo == ops.ALGO_WINOGRAD_F4 else "conv_igemm_kernel<fp32 32x32x2>")
