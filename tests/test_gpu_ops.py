@@ -505,3 +505,28 @@ def test_hand_over_timeout_is_reported_once_and_switches_to_one_block_per_tile()
         lib.t2v_debug_async_error(0)
     assert ops.fixed_grid_enabled()
     assert torch.equal(ops.conv2d_winograd(x, pu, b, desc, workspace=ws), want)
+
+
+@pytest.mark.parametrize("geom", [(64, 64, 1024, 1024), (64, 128, 1024, 1024), (64, 64, 512, 1024)])
+def test_one_block_per_cu_256x128_tiles_equal_tile_per_block(geom, t2v_env):
+    """T2V_WINO_GEMM_SK_TALL=2: the 256 tile rows of a 512x512 frame (512 of two) on 256 x 128 tiles, one block per CU
+    (wino_gemm_sk_kernel<TileCfg<32,1,4,8,1>, ring 3>: 128 accumulator registers, 48 KiB stages) -- the same K-ordered MFMA chain
+    per output as one block per tile: bit-identical, launch after launch on a NaN-filled workspace."""
+    from text2video_amd import ops
+    H, W, Cin, Cout = geom
+    dev = _dev()
+    desc = ops.conv_desc(H, W, Cin, Cout, 3, 1, 1, ops.PAD_REFLECT, algo=ops.ALGO_WINOGRAD_F4)
+    w = _rand(Cout, Cin, 3, 3, seed=2, scale=0.03).to(dev)
+    b = _rand(Cout, seed=3).to(dev)
+    pu = ops.pack_conv_weight(w, desc, Cin)
+    ws = ops.winograd_workspace(desc, Cin, dev)
+    xs = [_rand(H, W, Cin, seed=20 + i).to(dev) for i in range(2)]
+    t2v_env("T2V_WINO_GEMM_SK", "0")
+    want = [ops.conv2d_winograd(x, pu, b, desc, workspace=ws).clone() for x in xs]
+    t2v_env("T2V_WINO_GEMM_SK", "1")
+    t2v_env("T2V_WINO_GEMM_SK_TALL", "2")
+    assert "256x128" in ops.winograd_gemm_form(desc), ops.winograd_gemm_form(desc)
+    ws.fill_(float("nan"))
+    for rep in range(8):
+        y = ops.conv2d_winograd(xs[rep % 2], pu, b, desc, workspace=ws)
+        assert torch.equal(y, want[rep % 2]), "launch %d: %d of %d outputs differ" % (rep, int((y != want[rep % 2]).sum()), y.numel())

@@ -809,8 +809,11 @@ int t2v_conv_winograd_gemm_form(const t2v_conv_desc* d, int nimg) {
     const int T = wino_rows_batch(d, d->algo, nimg), rows = nimg * wino_tiles_real(d, d->algo);
     if (wino_gemm_skr_ok(36, rows, T, d->Cin, d->Cout, d->Cout)) return T2V_GEMM_FIXED_GRID_RAGGED;
     if (wino_gemm_sk_ok(36, T, d->Cin, d->Cout, d->Cout, rows))
-        return wino_gemm_sk_uses_tall(36, rows, T, d->Cout) ? T2V_GEMM_FIXED_GRID_160x128
-               : (T % 128 == 0 ? T2V_GEMM_FIXED_GRID_128x128 : T2V_GEMM_FIXED_GRID_192x64);
+        switch (wino_gemm_sk_tall_rows(36, rows, T, d->Cout)) {
+            case 160: return T2V_GEMM_FIXED_GRID_160x128;
+            case 256: return T2V_GEMM_FIXED_GRID_256x128;
+            default: return T % 128 == 0 ? T2V_GEMM_FIXED_GRID_128x128 : T2V_GEMM_FIXED_GRID_192x64;
+        }
     ConvPlan pl;
     if (build_winograd_gemm_plan(d, &pl, nimg) != T2V_OK) return -1;
     return pl.tile == kTileL ? T2V_GEMM_TILE_PER_BLOCK_128x128 : T2V_GEMM_TILE_PER_BLOCK_64x64;

@@ -78,6 +78,8 @@ using CfgS = TileCfg<16, 4, 1, 4, 1>;  // 256 x 16 (3-channel heads)
 using CfgQ = TileCfg<32, 2, 2, 1, 1>;  // 64 x 64: finer granularity when 128x128 tiles fill the 256 CUs poorly
 using CfgW = TileCfg<32, 2, 2, 3, 1>;  // 192 x 64: all tile rows of a 512x320 frame's transform position in one tile (fixed grid)
 using CfgT = TileCfg<32, 1, 4, 5, 1>;  // 160 x 128: the same rows without the padding, 80 accumulator registers: one block per CU
+using CfgT8 = TileCfg<32, 1, 4, 8, 1>; // 256 x 128: a 512x512 frame's 256 tile rows in one tile per position and column, 128
+                                       // accumulator registers, 48 KiB stages: one block per CU as well
 
 // One LDS-DMA instruction through buffer addressing: 64 lanes x 16 B -> 1 KiB at the wave-uniform LDS
 // address `lds_dst`; source = base + voff (per lane, bytes) + soff (scalar, bytes).  Lanes with
@@ -909,15 +911,22 @@ static int sk_tile_rows(int T, int N) {
 static bool sk_half_round(long tiles, long grid, int nk) {
     return options().wino_gemm_sk_half && tiles >= grid && 2 * (tiles % grid) == grid && nk % 2 == 0 && grid % 16 == 0;
 }
-// 129 .. 160 real rows per position (the 64 x 40 bottleneck of the reference's 512x320 frames: 160 Winograd tiles): ONE
+// 129 .. 160 real rows per position (the 64 x 40 bottleneck of the reference's 512x320 frames: 160 Winograd tiles) -- and,
+// with T2V_WINO_GEMM_SK_TALL=2, the 256 rows of a 512x512 frame on 256 x 128 tiles -- : ONE
 // 160 x 128 tile per position and column tile -- no padding rows, 0.0141 B of LDS-DMA per MAC (192 x 64: 0.0208) -- whose 80
 // accumulator registers and 108 KiB ring allow one block per CU: a fixed grid of one block per CU, 288 tiles on 256 blocks
-static bool sk_tall(int groups, int rows, int T, int N) {
-    if (!options().wino_gemm_sk_tall || rows <= 128 || rows > 160 || T < 160 || N % 128) return false;
-    const long tiles = (long)groups * (N / 128), grid = wino_gemm_sk_grid_blocks() / 2;
-    return tiles >= grid && tiles * 100 <= ((tiles + grid - 1) / grid) * grid * 85;
+static int sk_tall_rows(int groups, int rows, int T, int N) {     // tile rows of the one-block-per-CU form (160 | 256), or 0
+    const int mode = options().wino_gemm_sk_tall;
+    if (!mode || rows <= 0 || N % 128) return 0;
+    int bm = 0, mt = 1;
+    if (rows > 128 && rows <= 160 && T >= 160) bm = 160;
+    else if (mode >= 2 && T % 256 == 0 && rows > T - 32 && T <= 512) bm = 256, mt = T / 256;      // 256 (one 512x512 image) | 512 (two)
+    if (!bm) return 0;
+    const long tiles = (long)groups * mt * (N / 128), grid = wino_gemm_sk_grid_blocks() / 2;
+    return (tiles >= grid && tiles * 100 <= ((tiles + grid - 1) / grid) * grid * 90) ? bm : 0;
 }
-bool wino_gemm_sk_uses_tall(int groups, int rows, int T, int N) { return rows > 0 && sk_tall(groups, rows, T, N); }
+static bool sk_tall(int groups, int rows, int T, int N) { return sk_tall_rows(groups, rows, T, N) != 0; }
+int wino_gemm_sk_tall_rows(int groups, int rows, int T, int N) { return rows > 0 ? sk_tall_rows(groups, rows, T, N) : 0; }
 bool wino_gemm_sk_ok(int groups, int T, int K, int N, int c_cs, int rows) {
     const int mode = fixed_grid_enabled() ? options().wino_gemm_sk : 0;
     if (mode != 0 && rows > 0 && K % kBK == 0 && c_cs == N && sk_tall(groups, rows, T, N)) return true;
@@ -972,14 +981,14 @@ int launch_wino_gemm_sk(hipStream_t s, const SkGemm& g) {
     k.err = g.err;
     k.a_group_stride = g.a_group_stride;
     k.T = g.T; k.K = g.K; k.N = g.N; k.c_cs = g.c_cs;
-    if (g.rows > 0 && sk_tall(g.groups, g.rows, g.T, g.N)) {
-        k.mtiles_g = 1; k.ntiles = g.N / 128; k.nk = g.K / kBK;
-        k.tiles = g.groups * k.ntiles;
+    if (const int tall = g.rows > 0 ? sk_tall_rows(g.groups, g.rows, g.T, g.N) : 0) {
+        k.mtiles_g = tall == 160 ? 1 : g.T / 256; k.ntiles = g.N / 128; k.nk = g.K / kBK;
+        k.tiles = g.groups * k.mtiles_g * k.ntiles;
         const int grid = wino_gemm_sk_grid_blocks() / 2;       // one block per CU
         k.blocks_per_xcd = grid / 8;
         k.tiles_per_xcd = (k.tiles + 7) / 8;
         k.rounds = 0;
-        return launch_sk<CfgT, 3>(s, k, grid);
+        return tall == 160 ? launch_sk<CfgT, 3>(s, k, grid) : launch_sk<CfgT8, 3>(s, k, grid);
     }
     const int bm = sk_tile_rows(g.T, g.N), bn = bm == 128 ? 128 : 64;
     k.mtiles_g = g.T / bm; k.ntiles = g.N / bn; k.nk = g.K / kBK;

@@ -42,7 +42,8 @@ struct Options {
     int wino_gemm_sk;        // T2V_WINO_GEMM_SK: 0 off, 1 where it pays (default), 2 wherever the shape allows
     int wino_gemm_sk_wide;   // T2V_WINO_GEMM_SK_WIDE: 192x64 tiles for tile rows that are whole 192s (default 1)
     int wino_gemm_sk_half;   // T2V_WINO_GEMM_SK_HALF: second schedule for R + 1/2 rounds (default 1)
-    int wino_gemm_sk_tall;   // T2V_WINO_GEMM_SK_TALL: 160x128 tiles, one block per CU, for 129..160 tile rows (default 1)
+    int wino_gemm_sk_tall;   // T2V_WINO_GEMM_SK_TALL: one block per CU on 160x128 tiles for 129..160 tile rows (1), and on 256x128
+                             // tiles for 256 / 512 tile rows (2)
     int wino_gemm_sk_ragged; // T2V_WINO_GEMM_SK_RAGGED: ragged M tiles for tile rows that are no whole 128s (default 1)
     int wgrad_sk;            // T2V_WGRAD_SK: as wino_gemm_sk, for the Winograd-domain weight gradient
     int wgrad_sk_half;       // T2V_WGRAD_SK_HALF
@@ -246,7 +247,7 @@ struct SkGemm {
 };
 size_t wino_gemm_sk_scratch_floats();
 bool wino_gemm_sk_ok(int groups, int T, int K, int N, int c_cs, int rows = 0);   // rows: real tile rows per position, if known
-bool wino_gemm_sk_uses_tall(int groups, int rows, int T, int N);     // the 160 x 128 / one-block-per-CU form of that kernel
+int wino_gemm_sk_tall_rows(int groups, int rows, int T, int N);      // 160 | 256: the one-block-per-CU form of that kernel is taken; 0: not
 int launch_wino_gemm_sk(hipStream_t s, const SkGemm& g);
 // the ragged form (conv_igemm.hip: wino_gemm_skr_kernel): `rows` real tile rows per position (<= g.T, the padded pitch), cut
 // into 32-row fragments and M tiles of 4, ..., 4, r fragments -- no MFMA work on padding rows
