@@ -224,9 +224,8 @@ def gemm_stage_roofline(dev, sd, g0h, g0w, iters):
     roofline = {"bound": "mfma", "kernel": kname,
                 "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
-                "traffic_source": ("profiles/pmc_summary.json (separate rocprofv3 --pmc passes of this launch: "
-                                   "2*FETCH_SIZE + WRITE_SIZE, bytes per launch; not measured by this run)"
-                                   if traffic is not None else None),
+                "traffic_source": ("profiles/pmc_summary.json (separate rocprofv3 --pmc passes: 2*FETCH_SIZE + WRITE_SIZE per launch; "
+                                   "not measured by this run)" if traffic is not None else None),
                 "ms_per_launch": round(k_ms, 4), "gflop_per_launch": round(k_flop / 1e9, 2),
                 "flops_counted": "executed MFMA FLOPs of the launch" if use_wino else "algorithmic conv FLOPs",
                 "layer": {"algo": "winograd_f%dx%d_3x3" % (wm, wm) if use_wino else "direct", "ms_per_conv": round(conv_ms, 4),
@@ -278,7 +277,7 @@ def time_frames(model, dev, H, W, K, Wm, seed=0):
 def hires_block(dev, K, Wm, iters):
     """BASELINE configs[3]: 1024x1024 frames, single-scale G0@1024^2 and the two-scale G0@512^2 + local enhancer G1@1024^2
     (16 frames), flow / no flow, + the GEMM stage of the single-scale generator timed live."""
-    out = {"workload": "configs[3]: loadSize 1024 / fineSize 1024, %d frames after %d warm-up, 1 GPU" % (K, Wm)}
+    out = {"workload": "configs[3]: 1024x1024, %d frames after %d warm-up" % (K, Wm)}
     for scales, name in ((1, "single_scale"), (2, "two_scale")):
         blk = {}
         for flow in (True, False):
@@ -395,8 +394,7 @@ def train_block(dev, dist_mod, world, rank, backend, steps, iters):
             dw = torch.empty(C, C, 3, 3, device=dev)
             ms = ev_time(lambda: ops.conv2d_backward_weight_winograd_reduce(desc, ws, F, C, C, out=dw))
             gf = 2.0 * 36 * F * 256 * C * C / 1e9
-            kernels.append({"kernel": "wino_wgrad_sk_kernel + filter transform back: Winograd-domain weight gradient of a 1024->1024 "
-                                      "ResnetBlock conv over the step's %d frames (36 per step)" % F,
+            kernels.append({"kernel": "wino_wgrad_sk_kernel + dW transform: Winograd-domain wgrad, 1024->1024 conv, %d frames" % F,
                             "ms_per_launch": round(ms, 4), "gflop_per_launch": round(gf, 2),
                             "achieved": round(gf / ms, 2), "frac": round(gf / ms / PEAK_FP32_MFMA_TFLOPS, 4)})
         for name, (h, w, ci, co, st, tr_) in (("down 512->1024 3x3 s2 @128x128", (128, 128, 512, 1024, 2, False)),
@@ -406,21 +404,20 @@ def train_block(dev, dist_mod, world, rank, backend, steps, iters):
             x, dy = torch.randn(1, h, w, ci, device=dev), torch.randn(1, ho, wo, co, device=dev)
             ms = ev_time(lambda: ops.conv2d_backward_weight(x, dy, d))
             gf = 2.0 * 9 * ci * co * (h * w if tr_ else ho * wo) / 1e9
-            kernels.append({"kernel": "conv_wgrad_kernel (direct weight gradient, split partials + combine): " + name,
+            kernels.append({"kernel": "conv_wgrad_kernel: " + name,
                             "ms_per_launch": round(ms, 4), "gflop_per_launch": round(gf, 2),
                             "achieved": round(gf / ms, 2), "frac": round(gf / ms / PEAK_FP32_MFMA_TFLOPS, 4)})
-        block = {"workload": "configs[4] per-GPU work: 512x512, max_frames_per_gpu 2, G (flow branch) + D (num_D 2) + face D, "
-                             "--no_vgg, zero reference flow, Adam; batch = 1 sequence per GPU x %d GPU(s)" % world,
+        block = {"workload": "configs[4] per GPU: 512x512, 2 frames, G (flow) + D (num_D 2) + face D, --no_vgg, Adam; %d GPU(s)" % world,
                  "ms_per_step": round(ms_with, 2), "steps": steps, "warmup": warm,
                  "exchange": {"group": "%d-rank %s" % (world, "rccl" if backend == "nccl" or own_group else backend),
                               "ms_per_step_with": round(ms_with, 2), "ms_per_step_without": round(ms_without, 2),
                               "ms": round(ms_with - ms_without, 2), "bytes": int(nbytes), "buckets": nbuckets,
                               "collective": "reduce_scatter+all_gather" if tr.bucketsG.rs_ag else "all_reduce(avg)",
                               "replicas_in_sync": in_sync},
-                 "losses": {k: round(float(v), 4) for k, v in losses.items()},
+                 "losses": {k: round(float(v), 3) for k, v in losses.items() if k in ("G_GAN", "G_GAN_Feat", "D", "D_f")},
                  "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
                  "kernels": kernels,
-                 "note": "the forward / data-gradient GEMM stage of the step is the headline `roofline` kernel"}
+                 "note": "the step's forward / data-gradient GEMM stage is the headline roofline kernel"}
     del tr
     torch.cuda.empty_cache()
     if own_group:
@@ -448,17 +445,17 @@ def run_e2e(model_head, model_other, head_flow, n_frames):
     one = ["tmp"]
     two = ["tmp", "tmp_smooth"]       # what the reference's L2 driver writes per utterance (text2video_audio.sh:24-31)
     cases = [((512, 512), ["--no_pose_crop", "--batch_sequences", "1"], "512x512", [True, False], one),
-             ((512, 384), ["--no_pose_crop", "--batch_sequences", "1"], "512x680 (fadg0 frames, scaleHeight 512, full width)",
+             ((512, 384), ["--no_pose_crop", "--batch_sequences", "1"], "512x680 (fadg0 full width)",
               [head_flow], one),
-             ((512, 384), ["--batch_sequences", "1"], "512x320 (fadg0 frames, scaleHeight 512 + upstream's central-width crop)",
+             ((512, 384), ["--batch_sequences", "1"], "512x320 (fadg0 cropped)",
               [head_flow], one),
-             ((512, 512), ["--no_pose_crop", "--batch_sequences", "1"], "512x512, two sequences one after the other",
+             ((512, 512), ["--no_pose_crop", "--batch_sequences", "1"], "512x512, 2 sequences",
               [head_flow], two),
-             ((512, 512), ["--no_pose_crop", "--batch_sequences", "2"], "512x512, two sequences in lock-step (batch 2)",
+             ((512, 512), ["--no_pose_crop", "--batch_sequences", "2"], "512x512, 2 sequences in lock-step",
               [head_flow], two),
              # the reference's own run: fadg0 frames, scaleHeight 512 + central-width crop, tmp and tmp_smooth
-             ((512, 384), ["--batch_sequences", "1"], "512x320, two sequences one after the other", [head_flow], two),
-             ((512, 384), ["--batch_sequences", "2"], "512x320, two sequences in lock-step (batch 2)", [head_flow], two)]
+             ((512, 384), ["--batch_sequences", "1"], "512x320, 2 sequences", [head_flow], two),
+             ((512, 384), ["--batch_sequences", "2"], "512x320, 2 sequences in lock-step", [head_flow], two)]
     for canvas, extra, geom, flows, seqs in cases:
         tmp = tempfile.mkdtemp(prefix="t2v_e2e_")
         try:
@@ -488,13 +485,12 @@ def run_e2e(model_head, model_other, head_flow, n_frames):
                     stats = run_test(opt, model=m, device="cuda:%d" % torch.cuda.current_device())
                 from text2video_amd.pose_dataset import default_pose_workers
                 workers = opt.pose_workers if opt.pose_workers is not None else default_pose_workers()
-                out.append({"geometry": geom, "flow": flow, "fps": round(stats["fps_loop"], 2), "frames": stats["frames"],
-                            "sequences": len(seqs), "batch_sequences": opt.batch_sequences})
-                meta["pose_workers"] = workers
+                out.append({"geometry": geom, "flow": flow, "fps": round(stats["fps_loop"], 2), "sequences": len(seqs),
+                            "batch_sequences": opt.batch_sequences})
+                meta["pose_workers"], meta["frames_per_run"] = workers, stats["frames"]
         finally:
             shutil.rmtree(tmp, ignore_errors=True)
-    return dict({"path": "text2video_amd.model.run_test == vid2vid/test.py: rasterise -> H2D -> generator -> D2H -> JPEG",
-                 "rasteriser": "bit-exact (curve_fit) mode", "runs": out}, **meta)
+    return dict({"path": "run_test == vid2vid/test.py: rasterise (bit-exact) -> H2D -> generator -> D2H -> JPEG", "runs": out}, **meta)
 
 
 def cold_start_block(n_maps=87):
@@ -564,9 +560,8 @@ def cold_start_block(n_maps=87):
                            stderr=subprocess.DEVNULL)
         resident = None if not rwalls else {"first_call_wall_s": rwalls[0], "warm_call_wall_s": rwalls[1], "warm_loop_s": rloop,
                                             "warm_wall_over_loop": round(rwalls[1] / max(rloop, 1e-9), 2)}
-        return {"command": "python vid2vid/test.py <text2video_audio.sh:42 flags>, one process per utterance",
-                "workload": "configs[0]-shaped: tmp + tmp_smooth, 2 x %d frames 512x320, flow generator from a %.2f GB checkpoint"
-                            % (n_maps - 2, os.path.getsize(os.path.join(tmp, "ckpt", "fadg0", "latest_net_G0.pth")) / 1e9),
+        return {"command": "python vid2vid/test.py <text2video_audio.sh:42 flags> as a subprocess: tmp + tmp_smooth, 2 x %d frames "
+                           "512x320, %.2f GB checkpoint" % (n_maps - 2, os.path.getsize(os.path.join(tmp, "ckpt", "fadg0", "latest_net_G0.pth")) / 1e9),
                 "frames": split["frames"], "wall_s": walls, "split_of_last_run": cs, "resident": resident,
                 "wall_over_loop": round(walls[-1] / max(cs["loop_s"], 1e-9), 2),
                 "to_last_jpeg_over_loop": (round((cs["process_to_run_test_s"] + cs["to_last_jpeg_s"]) / max(cs["loop_s"], 1e-9), 2)
@@ -789,12 +784,9 @@ def main():
         for nb, el in batch_elapsed.items():
             variants["batch%d_fps" % nb] = round(world * nb * K / el, 3)
         if batch_elapsed:
-            variants["batch_note"] = ("batch<N>_fps: N independent sequences per GPU advanced in lock-step through "
-                                      "t2v_generator_forward_batch (headline variant), aggregate frames/s over all N; every "
-                                      "sequence's frames equal the single-sequence frames")
+            variants["batch_note"] = "batch<N>_fps: N independent sequences per GPU in lock-step, aggregate fps; frames bit-equal"
         variants["headline"] = "flow" if head_flow else "noflow"
-        variants["note"] = ("both variants timed in this run over the same K steps and W warm-up frames; `value` is "
-                            "the headline variant")
+        variants["note"] = "both variants timed in this run over the same K steps; `value` is the headline variant"
         result = {
             "metric": "frames/sec 512x512 pose->RGB (vid2vid generator)",
             "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
@@ -817,7 +809,22 @@ def main():
     if args.train_steps > 0 and default_geometry:
         del model, other
         torch.cuda.empty_cache()
-        train = train_block(dev, dist, world, rank, backend, args.train_steps, args.kernel_iters)
+        # (RCCL prints its version banner through C stdio when a group is created: fd 1 points at stderr meanwhile, so that
+        # stdout carries the one JSON line only)
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            train = train_block(dev, dist, world, rank, backend, args.train_steps, args.kernel_iters)
+        finally:
+            try:
+                import ctypes
+                ctypes.CDLL(None).fflush(None)
+            except Exception:
+                pass
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
         if rank == 0:
             result["train_step"] = train
     if dist:

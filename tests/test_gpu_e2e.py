@@ -304,7 +304,7 @@ def test_bench_contract_line():
     # end to end through the drop-in test.py frame loop (pose JSONs -> JPEG files)
     runs = d["e2e"]["runs"]
     assert {r["geometry"].split(" ")[0].rstrip(",") for r in runs} == {"512x512", "512x680", "512x320"}
-    assert all(r["frames"] == 12 and r["fps"] > 0 for r in runs) and d["e2e"]["pose_workers"] >= 1
+    assert all(r["fps"] > 0 for r in runs) and d["e2e"]["frames_per_run"] == 12 and d["e2e"]["pose_workers"] >= 1
     # the two-sequence dataset (tmp + tmp_smooth, as the reference's L2 driver writes it), one at a time and in lock-step
     assert sorted(r["batch_sequences"] for r in runs if r["sequences"] == 2) == [1, 1, 2, 2]      # at 512x512 and at the reference's 512x320
     # N independent sequences per GPU in lock-step: aggregate rates beside the single-sequence headline
@@ -334,6 +334,7 @@ def test_bench_contract_line():
     assert abs(ex["ms"] - (ex["ms_per_step_with"] - ex["ms_per_step_without"])) < 0.02
     assert len(t["kernels"]) == 3 and all(0.05 < k["frac"] < 1.0 for k in t["kernels"])
     assert all(np.isfinite(v) for v in t["losses"].values()) and "G_GAN" in t["losses"] and "D_f" in t["losses"]
+    assert len(lines[0]) < 6500, len(lines[0])       # the driver keeps a bounded tail of stdout: the line stays compact
 
 
 def test_lockstep_sequences_write_the_same_files_as_one_at_a_time(tmp_path):
