@@ -231,8 +231,11 @@ def run_test(opt, model=None, device=None, dataset=None):
                     ops.pose_u8_to_f32(L.dev_maps[f], L.window, 3 * f)
                 groups.setdefault((H, W), []).append((k, L, data))
             now = []
-            for members in groups.values():
-                outs = model.inference_nhwc_batch([L.window for _, L, _ in members], [L.rec for _, L, _ in members])
+            for (gh, gw), members in groups.items():
+                if len(members) > 1 and not model.lockstep_pays(gh, gw):      # (same frames either way: one call per sequence)
+                    outs = [model.inference_nhwc_batch([L.window], [L.rec])[0] for _, L, _ in members]
+                else:
+                    outs = model.inference_nhwc_batch([L.window for _, L, _ in members], [L.rec for _, L, _ in members])
                 for (k, L, data), out in zip(members, outs):
                     u8 = ops.tensor2im_u8(out)
                     ring = pinned.setdefault((k,) + tuple(u8.shape),
