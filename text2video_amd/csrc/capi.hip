@@ -326,6 +326,7 @@ int run_conv(t2v_ctx* ctx, hipStream_t s, const ConvPlan& pl, const float* x, co
     T2V_REQUIRE(ctx && x && w && y, "conv: null pointer");
     T2V_REQUIRE(y_cs >= pl.kp.Cout && y_cs <= pl.Cout_p, "conv: output channel storage %d out of range [%d,%d]", y_cs,
                 pl.kp.Cout, pl.Cout_p);
+    T2V_REQUIRE((long)pl.Hout * pl.Wout * y_cs * 4 < 0x7fff0000L, "conv: output tensor too large for 32-bit buffer offsets");
     {
         // the generator heads: dedicated halo-tile kernel (conv_head.hip)
         const int use_head = options().conv_head;

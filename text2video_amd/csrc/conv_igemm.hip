@@ -417,33 +417,54 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(const ConvKParams p) {
         }
     }
 
+    // ---- store.  Round 4: the PMC passes of the stride-2 / transposed layers showed 2.4-3.4 vector instructions per MFMA,
+    // most of them HERE -- a 32-bit integer division per accumulator row and lane (m -> (row, column) of the GEMM pixel
+    // grid), 64-bit address arithmetic and three activation compares per element: ~3000 instructions per wave and tile,
+    // 8 % of a 36-stage block and up to a third of the transposed convs' 8-stage phase blocks.  Now: m / Wm by one
+    // multiply-high (exact for m < 2^20 and Wm < 2^20), buffer stores off one SRD (out-of-range lanes are dropped by the
+    // hardware), the activation chosen once per tile.
+    const __amdgpu_buffer_rsrc_t ysrd = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.Hout * p.Wout * p.Cout_s * 4, 0x00020000);
+    constexpr int kDrop = 0x7fffff00;      // >= the record count of any output map (checked on the host: < 2 GiB)
+    const bool fastdiv = p.M <= (1 << 20);
+    const unsigned long long magic = (1ull << 40) / (unsigned)p.Wm + 1;
+    int coff[Cfg::TN];
+    bool creal[Cfg::TN];
 #pragma unroll
-    for (int i = 0; i < Cfg::TM; ++i)
+    for (int j = 0; j < Cfg::TN; ++j) {
+        coff[j] = col[j] < p.Cout_s ? col[j] * 4 : kDrop;
+        creal[j] = col[j] < p.Cout;
+    }
+    auto store_tile = [&](auto act) {
 #pragma unroll
-        for (int r = 0; r < MM::NREG; ++r) {
-            const int row = wm * (Cfg::TM * MF) + i * MF + MM::row(r, g);
-            const int m = m0 + row;
-            if (m < p.M) {
-                const int my = m / p.Wm, mx = m - my * p.Wm;
+        for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+            for (int r = 0; r < MM::NREG; ++r) {
+                const int row = wm * (Cfg::TM * MF) + i * MF + MM::row(r, g);
+                const int m = m0 + row;
+                const int my = fastdiv ? (int)(((unsigned long long)(unsigned)m * magic) >> 40) : m / p.Wm;
+                const int mx = m - my * p.Wm;
                 const int oy = my * p.ostride + ph.oy0, ox = mx * p.ostride + ph.ox0;
-                if (oy >= p.Hout || ox >= p.Wout) continue;  // odd-sized transposed output: ragged phase grid
-                float* yrow = p.y + (size_t)(oy * p.Wout + ox) * p.Cout_s;
+                // (oy / ox past the output: the ragged phase grid of an odd-sized transposed output)
+                const bool ok = m < p.M && oy < p.Hout && ox < p.Wout;
+                const int poff = (oy * p.Wout + ox) * p.Cout_s * 4;
 #pragma unroll
                 for (int j = 0; j < Cfg::TN; ++j) {
-                    if (col[j] < p.Cout_s) {
-                        float v = acc[i][j][r];
-                        if (p.act == T2V_ACT_TANH) {
-                            v = tanhf(v);
-                        } else if (p.act == T2V_ACT_FLOW_W) {
-                            v = col[j] < 2 ? v * p.act_scale : 1.f / (1.f + expf(-v));
-                        } else if (p.act == T2V_ACT_LRELU) {
-                            v = v > 0.f ? v : v * p.act_scale;
-                        }
-                        yrow[col[j]] = col[j] < p.Cout ? v : 0.f;
-                    }
+                    const float v = creal[j] ? act(acc[i][j][r], j) : 0.f;
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ysrd, ok ? poff + coff[j] : kDrop, 0, 0);
                 }
             }
-        }
+    };
+    if (p.act == T2V_ACT_NONE) {
+        store_tile([](float v, int) { return v; });
+    } else if (p.act == T2V_ACT_TANH) {
+        store_tile([](float v, int) { return tanhf(v); });
+    } else if (p.act == T2V_ACT_FLOW_W) {
+        const float sc = p.act_scale;
+        store_tile([&](float v, int j) { return col[j] < 2 ? v * sc : 1.f / (1.f + expf(-v)); });
+    } else {
+        const float sc = p.act_scale;
+        store_tile([&](float v, int) { return v > 0.f ? v : v * sc; });
+    }
 }
 
 // ---- the batched Winograd GEMM on a fixed grid ("stream-K") ------------------------------------------------------------
