@@ -9,7 +9,8 @@ import os
 from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_long, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libt2v_hip.so")
+# (T2V_LIBRARY: another build of the same ABI -- same-box A/B runs of a kernel change, scripts/ only)
+LIB_PATH = os.environ.get("T2V_LIBRARY") or os.path.join(_HERE, "lib", "libt2v_hip.so")
 
 T2V_OK = 0
 PAD_ZERO, PAD_REFLECT = 0, 1
