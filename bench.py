@@ -298,7 +298,7 @@ def hires_block(dev, K, Wm, iters):
     return out
 
 
-def train_block(dev, dist_mod, world, rank, backend, steps, iters):
+def train_block(dev, dist_mod, world, rank, backend, steps, iters, ngf=128):
     """BASELINE configs[4], the work of ONE GPU: Vid2VidTrainer.train_step on 2 frames of 512x512 (max_frames_per_gpu 2, one
     sequence per GPU), generator WITH its flow branch + 2-scale PatchGAN D + face D, LSGAN + feature matching + flow / warp /
     weight losses against the zero reference flow, --no_vgg, fused Adam, bucketed gradient exchange (SURVEY 8d config 5;
@@ -321,7 +321,7 @@ def train_block(dev, dist_mod, world, rank, backend, steps, iters):
     F = 2
     opt = TrainOptions().parse(["--name", "bench", "--dataset_mode", "pose", "--input_nc", "3", "--openpose_only", "--num_D", "2",
                                 "--max_frames_per_gpu", str(F), "--n_scales_temporal", "0", "--no_first_img", "--fineSize", str(H),
-                                "--no_vgg", "--add_face_disc"])
+                                "--no_vgg", "--add_face_disc", "--ngf", str(ngf)])
     tr = T.Vid2VidTrainer(opt, str(dev), seed=1)
     rng = np.random.default_rng(100 + rank)        # every rank its own clip
     pose = torch.zeros(F, H, W, 12, device=dev)
@@ -407,7 +407,8 @@ def train_block(dev, dist_mod, world, rank, backend, steps, iters):
             kernels.append({"kernel": "conv_wgrad_kernel: " + name,
                             "ms_per_launch": round(ms, 4), "gflop_per_launch": round(gf, 2),
                             "achieved": round(gf / ms, 2), "frac": round(gf / ms / PEAK_FP32_MFMA_TFLOPS, 4)})
-        block = {"workload": "configs[4] per GPU: 512x512, 2 frames, G (flow) + D (num_D 2) + face D, --no_vgg, Adam; %d GPU(s)" % world,
+        block = {"workload": "configs[4] per GPU: 512x512, 2 frames, G (flow%s) + D (num_D 2) + face D, --no_vgg, Adam; %d GPU(s)"
+                             % ("" if ngf == 128 else ", ngf %d: NOT configs[4], plumbing test only" % ngf, world),
                  "ms_per_step": round(ms_with, 2), "steps": steps, "warmup": warm,
                  "exchange": {"group": "%d-rank %s" % (world, "rccl" if backend == "nccl" or own_group else backend),
                               "ms_per_step_with": round(ms_with, 2), "ms_per_step_without": round(ms_without, 2),
@@ -589,6 +590,7 @@ def main():
     ap.add_argument("--no-cold-start", action="store_true", help="skip e2e.cold_start (the test.py command as a subprocess)")
     ap.add_argument("--hires-frames", type=int, default=16,
                     help="frames per 1024x1024 run of the `hires` block (configs[3]; 0 = skip; default geometry, 1 GPU only)")
+    ap.add_argument("--train-ngf", type=int, default=128, help="(tests only: a narrower generator in the train_step block)")
     ap.add_argument("--train-steps", type=int, default=5,
                     help="timed optimiser steps of the `train_step` block (configs[4] per-GPU work; 0 = skip; default geometry only)")
     ap.add_argument("--batch-variants", type=lambda v: [int(x) for x in v.split(",") if x], default=[2, 4],
@@ -815,7 +817,7 @@ def main():
         saved_fd = os.dup(1)
         os.dup2(2, 1)
         try:
-            train = train_block(dev, dist, world, rank, backend, args.train_steps, args.kernel_iters)
+            train = train_block(dev, dist, world, rank, backend, args.train_steps, args.kernel_iters, args.train_ngf)
         finally:
             try:
                 import ctypes

@@ -264,7 +264,7 @@ def test_bench_two_ranks_on_one_gpu_contract():
     env = dict(os.environ, CUDA_VISIBLE_DEVICES="0", T2V_DIST_BACKEND="gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29561", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
-           "--kernel-iters", "2", "--single-variant", "--train-steps", "1"]
+           "--kernel-iters", "2", "--single-variant", "--train-steps", "1", "--train-ngf", "32"]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -275,7 +275,8 @@ def test_bench_two_ranks_on_one_gpu_contract():
     # configs[4] with N = 2: every rank its own clip, the real gradient all-reduce between them, replicas still equal
     t = d["train_step"]
     assert t["exchange"]["group"] == "2-rank gloo" and t["exchange"]["replicas_in_sync"] is True
-    assert t["exchange"]["bytes"] > 1.3e9
+    assert t["exchange"]["bytes"] > 5e7 and "ngf 32" in t["workload"]      # (a narrow generator here: the gloo exchange of the
+                                                                           # full 1.5 GB through the host takes a minute)
     assert d["config"]["parallelism"] == "sequence-chunk dp2" and d["config"]["collectives"] == "gloo"
     assert abs(d["value"] - 2 * 1e3 / d["ms_per_step"]) <= 0.01 * d["value"]      # 2 ranks x K frames / max-over-ranks time
     assert d["value"] > 30.0
