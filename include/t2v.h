@@ -139,7 +139,8 @@ int t2v_conv_winograd_tile_rows(const t2v_conv_desc* d);
  * 512x320 frames), or ragged M tiles of 4,..,4,r 32-row fragments.  -1: not an F(4x4,3x3) conv. */
 enum { T2V_GEMM_TILE_PER_BLOCK_64x64 = 0, T2V_GEMM_TILE_PER_BLOCK_128x128 = 1, T2V_GEMM_FIXED_GRID_128x128 = 2,
        T2V_GEMM_FIXED_GRID_192x64 = 3, T2V_GEMM_FIXED_GRID_160x128 = 4, T2V_GEMM_FIXED_GRID_RAGGED = 5,
-       T2V_GEMM_FIXED_GRID_256x128 = 6 /* one block per CU, like 160x128 */ };
+       T2V_GEMM_FIXED_GRID_256x128 = 6 /* one block per CU, like 160x128 */,
+       T2V_GEMM_FIXED_GRID_RAGGED_TALL = 7 /* ragged, balanced tiles of 3..6 fragments, one block per CU */ };
 int t2v_conv_winograd_gemm_form(const t2v_conv_desc* d, int nimg);
 /* forward with d->algo == T2V_ALGO_WINOGRAD | T2V_ALGO_WINOGRAD_F4; same contract as t2v_conv2d_forward plus the workspace */
 int t2v_conv2d_forward_winograd(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, const float* x, int x_cs,

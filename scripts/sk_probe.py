@@ -27,7 +27,7 @@ def run(H, W, C):
     res = {}
     for sk in ("0", "1", "whole"):     # one block per tile | the default rule | the default rule without the ragged / tall tiles
         os.environ["T2V_WINO_GEMM_SK"] = "1" if sk == "whole" else sk
-        os.environ["T2V_WINO_GEMM_SK_RAGGED"] = "0" if sk == "whole" else "1"
+        os.environ["T2V_WINO_GEMM_SK_RAGGED"] = "0" if sk == "whole" else os.environ.get("SK_PROBE_RAGGED", "1")
         os.environ["T2V_WINO_GEMM_SK_TALL"] = "0" if sk == "whole" else os.environ.get("SK_PROBE_TALL", "1")
         ops.reload_env()
         ws.fill_(float("nan"))
@@ -53,7 +53,9 @@ if __name__ == "__main__":
     shapes = [(64, 64, 1024), (64, 128, 1024), (32, 32, 1024), (64, 64, 512), (128, 128, 256), (64, 40, 1024), (64, 88, 1024),
               (128, 128, 1024), (64, 85, 1024), (64, 56, 1024), (64, 114, 1024), (64, 80, 1024), (64, 170, 1024)]
     print("fixed grid enabled:", ops.fixed_grid_enabled())
-    if len(sys.argv) > 1:
+    if len(sys.argv) > 1 and sys.argv[1] == "ragged":
+        shapes = [s for s in shapes if -(-(-(-s[0] // 4) * -(-s[1] // 4)) // 32) % 4] + [(64, 136, 1024), (128, 100, 1024)]
+    elif len(sys.argv) > 1:
         shapes = shapes[:int(sys.argv[1])]
     for (H, W, C) in shapes:
         ok &= run(H, W, C)

@@ -389,7 +389,7 @@ def test_winograd_f4_output_transform_applies_the_activation(slope):
         ops.conv2d_auto(_to_nhwc(x), U, b.to(_dev()), desc, stats=ops.conv_stats_buffer(desc, _dev()))
 
 
-@pytest.mark.parametrize("ragged", ["1", "0"], ids=["ragged", "whole_tiles"])
+@pytest.mark.parametrize("ragged", ["1", "0", "2"], ids=["ragged", "whole_tiles", "tall_ragged"])
 @pytest.mark.parametrize("geom", [(64, 64, 1024, 1024), (64, 88, 640, 640), (128, 128, 256, 256), (64, 128, 512, 1024),
                                   (128, 128, 512, 256), (64, 40, 1024, 1024), (64, 40, 512, 384), (128, 128, 1024, 1024),
                                   (64, 85, 1024, 1024), (64, 56, 1024, 1024), (64, 114, 1024, 1024), (60, 52, 256, 384)])
@@ -402,14 +402,21 @@ def test_fixed_grid_winograd_gemm_equals_tile_per_block(geom, ragged, t2v_env):
     tiles at 128 x 128 x 1024: whole rounds + a half round cut in two).  `ragged`: tile rows that are no whole 128s (the
     reference's 512x680 frames: 64 x 85 maps, 352 rows = 4 + 4 + 3 fragments; the 16:9 speakers: 64 x 114 -> 464 rows, 64 x 56
     -> 224; 60 x 52 -> 195 rows, the last fragment part padding) on wino_gemm_skr_kernel's ragged M tiles, or with
-    T2V_WINO_GEMM_SK_RAGGED=0 padded to whole tiles as before."""
+    T2V_WINO_GEMM_SK_RAGGED=0 padded to whole tiles as before, or with =2 on wino_gemm_skt_kernel's balanced tiles of 3..6
+    fragments, one block per CU (352 rows = 6 + 5 fragments, 464 = 5 + 5 + 5, 224 = 4 + 3, 195 = 4 + 3)."""
     from text2video_amd import ops
     H, W, Cin, Cout = geom
     rows = -(-H // 4) * -(-W // 4)
-    if ragged == "0" and -(-rows // 32) % 4 == 0:
+    if ragged != "1" and -(-rows // 32) % 4 == 0:
         pytest.skip("whole 128-row tiles: the ragged switch changes nothing")
     t2v_env("T2V_WINO_GEMM_SK_RAGGED", ragged)
     assert ops.fixed_grid_enabled()
+    if ragged == "2":
+        t2v_env("T2V_WINO_GEMM_SK", "2")
+        form = ops.winograd_gemm_form(ops.conv_desc(H, W, Cin, Cout, 3, 1, 1, ops.PAD_REFLECT, algo=ops.ALGO_WINOGRAD_F4))
+        if "skt_kernel" not in form:
+            assert (Cin, Cout) != (1024, 1024) or -(-rows // 32) < 6, form
+            pytest.skip("too few tiles for one per CU: stays on the two-per-CU ragged form")
     dev = _dev()
     desc = ops.conv_desc(H, W, Cin, Cout, 3, 1, 1, ops.PAD_REFLECT, algo=ops.ALGO_WINOGRAD_F4)
     w = _rand(Cout, Cin, 3, 3, seed=2, scale=0.03).to(dev)

@@ -721,7 +721,9 @@ struct SkrKParams {
     int F;                        // 32-row fragments per position that hold real rows
     int ntiles, nk, cgs;          // 128-column tiles, K stages, column groups (positions x ntiles)
     int cg_per_xcd, blocks_per_xcd;
-    int S;                        // run length per block, in units (>= 4 nk: one full tile)
+    int S;                        // run length per block, in units (>= one full tile)
+    int mt_count, mt_base, mt_extra;   // wino_gemm_skt_kernel: M tiles per column group, the first mt_extra of them mt_base + 1
+                                       // fragments tall, the rest mt_base
 };
 using CfgR1 = TileCfg<32, 1, 4, 1, 1>;   //  32 x 128
 using CfgR2 = TileCfg<32, 1, 4, 2, 1>;   //  64 x 128
@@ -729,9 +731,10 @@ using CfgR3 = TileCfg<32, 1, 4, 3, 1>;   //  96 x 128
 
 // one piece [kb, ke) of one tile: the loader waves stream its stages, the MFMA waves start from zeros or from the handed-over
 // accumulators (init), and end by publishing them (ke < nk) or by storing the finished tile
-template <class Cfg, int RING>
+template <class Cfg, int RING, int PW = 4096>      // PW: floats of one wave's hand-over slot (>= Cfg::TM * Cfg::TN * 1024)
 __device__ __forceinline__ void skr_piece(const SkrKParams& p, char* smem, int wid, int lane, bool is_loader, int pg, int nt,
                                           int row0, int kb, int ke, bool& flag_due) {
+    static_assert(PW >= Cfg::TM * Cfg::TN * 1024, "hand-over slot too small for this tile");
     using MM = Mfma<32>;
     using acc_t = typename MM::acc_t;
     constexpr int BM = Cfg::BM, BN = Cfg::BN, MF = 32;
@@ -778,7 +781,7 @@ __device__ __forceinline__ void skr_piece(const SkrKParams& p, char* smem, int w
         const bool timed_out = handover_wait(fl, p.tag, p.err, lane);
         if (lane == 0) __hip_atomic_store(const_cast<unsigned long long*>(fl), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float*>(p.partial) + (size_t)(src * 4 + wid) * 4096, 0, 16384, 0x00020000);
+            const_cast<float*>(p.partial) + (size_t)(src * 4 + wid) * PW, 0, PW * 4, 0x00020000);
 #pragma unroll
         for (int i = 0; i < Cfg::TM; ++i)
 #pragma unroll
@@ -809,7 +812,7 @@ __device__ __forceinline__ void skr_piece(const SkrKParams& p, char* smem, int w
     if (publish) {
         // (the wave -> element mapping of the hand-over is the tile's own: producer and consumer run the same Cfg)
         const __amdgpu_buffer_rsrc_t srd =
-            __builtin_amdgcn_make_buffer_rsrc(p.partial + (size_t)(blockIdx.x * 4 + wid) * 4096, 0, 16384, 0x00020000);
+            __builtin_amdgcn_make_buffer_rsrc(p.partial + (size_t)(blockIdx.x * 4 + wid) * PW, 0, PW * 4, 0x00020000);
 #pragma unroll
         for (int i = 0; i < Cfg::TM; ++i)
 #pragma unroll
@@ -901,6 +904,86 @@ __global__ __launch_bounds__(512, 4) void wino_gemm_skr_kernel(const SkrKParams 
         else if (frs == 3) skr_piece<CfgR3, RING>(p, smem, wid, lane, is_loader, pg, nt, row0, kb, ke, flag_due);
         else if (frs == 2) skr_piece<CfgR2, RING>(p, smem, wid, lane, is_loader, pg, nt, row0, kb, ke, flag_due);
         else skr_piece<CfgR1, RING>(p, smem, wid, lane, is_loader, pg, nt, row0, kb, ke, flag_due);
+    }
+    if (flag_due && !is_loader) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_store(p.flags + blockIdx.x * 4 + wid, p.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// ---- the ragged form with ONE block per CU: balanced tall tiles ---------------------------------------------------------
+// §4.6's second lesson applied to the first: with one resident block per CU (three-slot ring, up to 256 VGPRs) a tile may be
+// up to 6 fragments = 192 rows tall, so the rows of a position are cut into ceil(F / 6) tiles of nearly equal height
+// (352 rows = 11 fragments: 6 + 5; 464 -> 15: 5 + 5 + 5; 224 -> 7: 4 + 3; 688 -> 22: 6 + 6 + 5 + 5), every one of them run
+// as 1 x 4 waves of (32 tm) x 32.  Less LDS-DMA per MAC than 128-row tiles, and the second stream of a frame finds free
+// wave slots on every CU.  Units, weights, run boundaries and the hand-over are wino_gemm_skr_kernel's.
+using CfgR4 = TileCfg<32, 1, 4, 4, 1>;   // 128 x 128 as 1 x 4 waves
+using CfgR6 = TileCfg<32, 1, 4, 6, 1>;   // 192 x 128
+constexpr int kSktPW = 6144;              // hand-over slot of a wave: 6 fragments
+
+template <int RING>
+__global__ __launch_bounds__(512) void wino_gemm_skt_kernel(const SkrKParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool is_loader = wave >= 4;
+    const int wid = wave & 3;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int nk = p.nk, F = p.F, MT = p.mt_count, base = p.mt_base, extra = p.mt_extra;
+    const int cg0 = xcd * p.cg_per_xcd, cg1 = min(cg0 + p.cg_per_xcd, p.cgs);
+    if (cg0 >= cg1) return;
+    const int cgw = F * nk, Wx = (cg1 - cg0) * cgw;
+    const int u0 = min(j * p.S, Wx), u1 = min(u0 + p.S, Wx);
+    if (u0 >= u1) return;
+    const int big_w = (base + 1) * nk, small_w = base * nk, big_all = extra * big_w;
+    auto locate = [&](int u, int& lt, int& st) {
+        const int c = u / cgw, r = u - c * cgw;
+        int mt, tm, w0;
+        if (r < big_all) {
+            mt = r / big_w;
+            tm = base + 1;
+            w0 = mt * big_w;
+        } else {
+            mt = extra + (r - big_all) / small_w;
+            tm = base;
+            w0 = big_all + (mt - extra) * small_w;
+        }
+        st = (r - w0 + (tm >> 1)) / tm;
+        lt = c * MT + mt;
+        if (st >= nk) {
+            st = 0;
+            ++lt;
+        }
+    };
+    int lt0, k0, lt1, k1;
+    locate(u0, lt0, k0);
+    locate(u1, lt1, k1);
+    const bool has_tail = k0 > 0, has_head = k1 > 0;
+    const int first_whole = lt0 + (has_tail ? 1 : 0);
+    const int nwhole = max(0, lt1 - first_whole);
+    const int nf = nwhole + (has_head ? 1 : 0) + (has_tail ? 1 : 0);
+    bool flag_due = false;
+    for (int f = 0; f < nf; ++f) {
+        int lt, kb = 0, ke = nk;
+        if (has_head && f == 0) {
+            lt = lt1;
+            ke = k1;
+        } else if (f - (has_head ? 1 : 0) < nwhole) {
+            lt = first_whole + f - (has_head ? 1 : 0);
+        } else {
+            lt = lt0;
+            kb = k0;
+        }
+        const int c = lt / MT, mt = lt - c * MT;
+        const int cg = cg0 + c;
+        const int pg = cg / p.ntiles, nt = cg - pg * p.ntiles;
+        const int row0 = 32 * (mt * base + min(mt, extra));
+        const int frs = mt < extra ? base + 1 : base;
+        if (frs == 6) skr_piece<CfgR6, RING, kSktPW>(p, smem, wid, lane, is_loader, pg, nt, row0, kb, ke, flag_due);
+        else if (frs == 5) skr_piece<CfgT, RING, kSktPW>(p, smem, wid, lane, is_loader, pg, nt, row0, kb, ke, flag_due);
+        else if (frs == 4) skr_piece<CfgR4, RING, kSktPW>(p, smem, wid, lane, is_loader, pg, nt, row0, kb, ke, flag_due);
+        else skr_piece<CfgR3, RING, kSktPW>(p, smem, wid, lane, is_loader, pg, nt, row0, kb, ke, flag_due);
     }
     if (flag_due && !is_loader) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1064,6 +1147,49 @@ bool wino_gemm_skr_ok(int groups, int rows, int Tp, int K, int N, int c_cs) {
         alt_cost = big ? 103 : 112;
     }
     return run * 108 <= alt * alt_cost;
+}
+
+// the one-block-per-CU form of the ragged kernel (T2V_WINO_GEMM_SK_RAGGED=2): balanced tiles of 3..6 fragments
+static bool skt_split(int rows, int* mt_count, int* base, int* extra) {
+    const int F = (rows + 31) / 32, MT = (F + 5) / 6;
+    if (F < 6 || F / MT < 3) return false;
+    *mt_count = MT; *base = F / MT; *extra = F % MT;
+    return true;
+}
+bool wino_gemm_skt_ok(int groups, int rows, int Tp, int K, int N, int c_cs) {
+    int mt, base, extra;
+    if (options().wino_gemm_sk_ragged < 2 || !skt_split(rows, &mt, &base, &extra)) return false;
+    const long cgs = (long)groups * (N / 128), grid = wino_gemm_sk_grid_blocks() / 2;
+    return wino_gemm_skr_ok(groups, rows, Tp, K, N, c_cs) && cgs * mt >= grid;      // (at least one tile per block)
+}
+int launch_wino_gemm_skt(hipStream_t s, const SkGemm& g, int rows) {
+    T2V_REQUIRE(wino_gemm_skt_ok(g.groups, rows, g.T, g.K, g.N, g.c_cs), "tall ragged fixed-grid gemm: shape not supported");
+    SkrKParams k;
+    k.a = g.a; k.b = g.b; k.c = g.c;
+    k.partial = g.scratch;
+    k.flags = reinterpret_cast<unsigned long long*>(g.scratch + (size_t)kSkMaxGrid * 4 * 64 * 64);
+    k.tag = wino_gemm_sk_next_tag();
+    k.err = g.err;
+    k.a_group_stride = g.a_group_stride;
+    k.Tp = g.T; k.K = g.K; k.N = g.N; k.c_cs = g.c_cs;
+    k.F = (rows + 31) / 32;
+    k.ntiles = g.N / 128; k.nk = g.K / kBK; k.cgs = g.groups * k.ntiles;
+    skt_split(rows, &k.mt_count, &k.mt_base, &k.mt_extra);
+    const int grid = wino_gemm_sk_grid_blocks() / 2;            // one block per CU
+    k.blocks_per_xcd = grid / 8;
+    k.cg_per_xcd = (k.cgs + 7) / 8;
+    const long Wx = (long)k.cg_per_xcd * k.F * k.nk;
+    k.S = (int)std::max<long>((long)(k.mt_base + (k.mt_extra ? 1 : 0)) * k.nk, (Wx + k.blocks_per_xcd - 1) / k.blocks_per_xcd);
+    auto kern = wino_gemm_skt_kernel<3>;
+    constexpr int LDS_BYTES = 3 * CfgR6::STAGE_BYTES;
+    static bool attr_done = false;
+    if (!attr_done) {
+        T2V_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS_BYTES, s, k);
+    T2V_HIP_CHECK(hipGetLastError());
+    return T2V_OK;
 }
 
 int launch_wino_gemm_skr(hipStream_t s, const SkGemm& g, int rows) {

@@ -44,7 +44,8 @@ struct Options {
     int wino_gemm_sk_half;   // T2V_WINO_GEMM_SK_HALF: second schedule for R + 1/2 rounds (default 1)
     int wino_gemm_sk_tall;   // T2V_WINO_GEMM_SK_TALL: one block per CU on 160x128 tiles for 129..160 tile rows (1), and on 256x128
                              // tiles for 256 / 512 tile rows (2)
-    int wino_gemm_sk_ragged; // T2V_WINO_GEMM_SK_RAGGED: ragged M tiles for tile rows that are no whole 128s (default 1)
+    int wino_gemm_sk_ragged; // T2V_WINO_GEMM_SK_RAGGED: ragged M tiles for tile rows that are no whole 128s: 1 = 4,..,4,r fragments on
+                             // two blocks per CU, 2 = balanced 3..6-fragment tiles on one block per CU where that applies
     int wgrad_sk;            // T2V_WGRAD_SK: as wino_gemm_sk, for the Winograd-domain weight gradient
     int wgrad_sk_half;       // T2V_WGRAD_SK_HALF
     int wgrad_combine;       // T2V_WGRAD_COMBINE: in-kernel combine of split partials (default 1)
@@ -253,6 +254,9 @@ int launch_wino_gemm_sk(hipStream_t s, const SkGemm& g);
 // into 32-row fragments and M tiles of 4, ..., 4, r fragments -- no MFMA work on padding rows
 bool wino_gemm_skr_ok(int groups, int rows, int Tp, int K, int N, int c_cs);
 int launch_wino_gemm_skr(hipStream_t s, const SkGemm& g, int rows);
+// ... and its one-block-per-CU form on balanced tiles of 3..6 fragments (wino_gemm_skt_kernel; T2V_WINO_GEMM_SK_RAGGED=2)
+bool wino_gemm_skt_ok(int groups, int rows, int Tp, int K, int N, int c_cs);
+int launch_wino_gemm_skt(hipStream_t s, const SkGemm& g, int rows);
 int wino_gemm_sk_grid_blocks();                 // two blocks per CU, a multiple of 8
 unsigned long long wino_gemm_sk_next_tag();     // hand-over tags: unique per launch, process-wide
 // the same scheme for the Winograd-domain weight gradient dU[xi] = M_dy[xi]^T V[xi] (conv_wgrad.hip); scratch as above

@@ -104,7 +104,8 @@ GEMM_FORMS = {0: "conv_igemm_kernel<64x64 tiles, one block per tile>", 1: "conv_
               3: "wino_gemm_sk_kernel<192x64 tiles on a fixed grid of 2 blocks per CU>",
               4: "wino_gemm_sk_kernel<160x128 tiles on a fixed grid of 1 block per CU>",
               5: "wino_gemm_skr_kernel<ragged 128/96/64/32 x 128 tiles on a fixed grid of 2 blocks per CU>",
-              6: "wino_gemm_sk_kernel<256x128 tiles on a fixed grid of 1 block per CU>"}
+              6: "wino_gemm_sk_kernel<256x128 tiles on a fixed grid of 1 block per CU>",
+              7: "wino_gemm_skt_kernel<ragged 96..192 x 128 tiles on a fixed grid of 1 block per CU>"}
 
 
 def winograd_gemm_form(desc, nimg=1):
