@@ -392,14 +392,14 @@ int winograd_forward(t2v_ctx* ctx, hipStream_t s, const t2v_conv_desc* d, const 
     }
     if (stages & 2) {
         const int rows = nimg * wino_tiles_real(d, d->algo);      // real tile rows per position (the rest of T is padding)
-        if (f4 && wino_gemm_skr_ok(36, rows, (int)T, d->Cin, d->Cout, d->Cout)) {
+        const bool tall_ragged = f4 && wino_gemm_skt_ok(36, rows, (int)T, d->Cin, d->Cout, d->Cout);
+        if (tall_ragged || (f4 && wino_gemm_skr_ok(36, rows, (int)T, d->Cin, d->Cout, d->Cout))) {
             SkGemm g;
             g.a = V; g.b = w_packed; g.c = Mm; g.scratch = workspace + winograd_vm_floats(d, nimg);
             g.err = async_error_word();
             g.a_group_stride = (long)T * d->Cin;
             g.groups = 36; g.T = (int)T; g.K = d->Cin; g.N = d->Cout; g.c_cs = d->Cout;
-            T2V_TRY(wino_gemm_skt_ok(36, rows, (int)T, d->Cin, d->Cout, d->Cout) ? launch_wino_gemm_skt(s, g, rows)
-                                                                               : launch_wino_gemm_skr(s, g, rows));
+            T2V_TRY(tall_ragged ? launch_wino_gemm_skt(s, g, rows) : launch_wino_gemm_skr(s, g, rows));
         } else if (f4 && wino_gemm_sk_ok(36, (int)T, d->Cin, d->Cout, d->Cout, rows)) {
             SkGemm g;
             g.a = V; g.b = w_packed; g.c = Mm; g.scratch = workspace + winograd_vm_floats(d, nimg);
@@ -809,8 +809,8 @@ int t2v_conv_winograd_tile_rows(const t2v_conv_desc* d) {
 int t2v_conv_winograd_gemm_form(const t2v_conv_desc* d, int nimg) {
     if (!d || d->algo != T2V_ALGO_WINOGRAD_F4 || nimg < 1) return -1;
     const int T = wino_rows_batch(d, d->algo, nimg), rows = nimg * wino_tiles_real(d, d->algo);
-    if (wino_gemm_skr_ok(36, rows, T, d->Cin, d->Cout, d->Cout))
-        return wino_gemm_skt_ok(36, rows, T, d->Cin, d->Cout, d->Cout) ? T2V_GEMM_FIXED_GRID_RAGGED_TALL : T2V_GEMM_FIXED_GRID_RAGGED;
+    if (wino_gemm_skt_ok(36, rows, T, d->Cin, d->Cout, d->Cout)) return T2V_GEMM_FIXED_GRID_RAGGED_TALL;
+    if (wino_gemm_skr_ok(36, rows, T, d->Cin, d->Cout, d->Cout)) return T2V_GEMM_FIXED_GRID_RAGGED;
     if (wino_gemm_sk_ok(36, T, d->Cin, d->Cout, d->Cout, rows))
         switch (wino_gemm_sk_tall_rows(36, rows, T, d->Cout)) {
             case 160: return T2V_GEMM_FIXED_GRID_160x128;

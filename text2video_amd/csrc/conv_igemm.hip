@@ -1115,11 +1115,15 @@ static long skr_run_units(int groups, int rows, int K, int N, int* cg_per_xcd) {
     const long Wx = (long)cgx * F * nk;
     return std::max<long>(4L * nk, (Wx + bpx - 1) / bpx);
 }
-bool wino_gemm_skr_ok(int groups, int rows, int Tp, int K, int N, int c_cs) {
+static bool skr_shape_ok(int groups, int rows, int Tp, int K, int N, int c_cs) {
     const int mode = fixed_grid_enabled() ? options().wino_gemm_sk : 0;
-    if (mode == 0 || !options().wino_gemm_sk_ragged || rows < 1 || N % 128 || K % kBK || c_cs != N ||
-        (long)128 * K * 4 >= 0x7fff0000L || (rows + 31) / 32 * 32 > Tp || (long)groups * (N / 128) * ((rows + 31) / 32) * (K / kBK) >= 0x7fffffffL / 2)
-        return false;
+    return !(mode == 0 || !options().wino_gemm_sk_ragged || rows < 1 || N % 128 || K % kBK || c_cs != N ||
+             (long)128 * K * 4 >= 0x7fff0000L || (rows + 31) / 32 * 32 > Tp ||
+             (long)groups * (N / 128) * ((rows + 31) / 32) * (K / kBK) >= 0x7fffffffL / 2);
+}
+bool wino_gemm_skr_ok(int groups, int rows, int Tp, int K, int N, int c_cs) {
+    if (!skr_shape_ok(groups, rows, Tp, K, N, c_cs)) return false;
+    const int mode = options().wino_gemm_sk;
     const int F = (rows + 31) / 32, nk = K / kBK;
     if (F % 4 == 0) return false;                       // whole 128-row tiles: wino_gemm_sk_kernel's case
     if (mode == 2) return true;
@@ -1160,7 +1164,8 @@ bool wino_gemm_skt_ok(int groups, int rows, int Tp, int K, int N, int c_cs) {
     int mt, base, extra;
     if (options().wino_gemm_sk_ragged < 2 || !skt_split(rows, &mt, &base, &extra)) return false;
     const long cgs = (long)groups * (N / 128), grid = wino_gemm_sk_grid_blocks() / 2;
-    return wino_gemm_skr_ok(groups, rows, Tp, K, N, c_cs) && cgs * mt >= grid;      // (at least one tile per block)
+    if (cgs * mt < grid) return false;                                              // (at least one tile per block)
+    return wino_gemm_skr_ok(groups, rows, Tp, K, N, c_cs);
 }
 int launch_wino_gemm_skt(hipStream_t s, const SkGemm& g, int rows) {
     T2V_REQUIRE(wino_gemm_skt_ok(g.groups, rows, g.T, g.K, g.N, g.c_cs), "tall ragged fixed-grid gemm: shape not supported");

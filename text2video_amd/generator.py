@@ -12,6 +12,8 @@ import ctypes
 from dataclasses import dataclass
 
 import numpy as np
+import os
+
 import torch
 
 from . import _lib, ops
@@ -402,27 +404,12 @@ class Vid2VidModelG:
         return outs
 
     def lockstep_pays(self, H, W):
-        """Whether advancing several sequences of H x W frames through ONE batched call is worth it.  Where a single
-        image's ResnetBlock GEMM stage already runs on 160x128 tiles with one block per CU (129..160 Winograd tile rows: the
-        reference's 512x320 frames) two single calls are as fast as the batch-2 launch on ragged tiles, and leave the second
-        stream room (measured 133.2 vs 131.5 fps end to end) -- everywhere else the batch wins 2-4 %."""
-        key = (H, W)
-        hit = self._lockstep.get(key) if hasattr(self, "_lockstep") else None
-        if hit is None:
-            spec = self.nets[0].spec
-            h, w = (H >> (self.n_scales - 1)) >> spec.n_down, (W >> (self.n_scales - 1)) >> spec.n_down
-            c = spec.ngf << spec.n_down
-            hit = True
-            try:
-                desc = ops.conv_desc(h, w, c, c, 3, 1, 1, ops.PAD_REFLECT, algo=ops.ALGO_WINOGRAD_F4)
-                if ops.winograd_supported(ops.with_algo(desc, 0), c, ops.ALGO_WINOGRAD_F4):
-                    hit = "160x128" not in ops.winograd_gemm_form(desc, 1)
-            except Exception:      # noqa: BLE001 -- a geometry without a Winograd path: batching is never wrong
-                hit = True
-            if not hasattr(self, "_lockstep"):
-                self._lockstep = {}
-            self._lockstep[key] = hit
-        return hit
+        """Whether advancing several sequences of H x W frames through ONE batched call is worth it (run_test asks per
+        geometry).  Measured end to end with the flow branch, two sequences (profiles/r04_ab_lockstep.txt): 512x320 139.3 vs
+        135.2 fps, 512x680 66.3 vs 65.2, 512x512 88.3 vs 86.0 -- the batch wins 2-3 % everywhere since the ragged GEMM of a
+        batch-2 launch runs one block per CU; before that, two single calls on 160x128 tiles were as fast at
+        512x320.  T2V_LOCKSTEP=0 / 1 forces one call per sequence / the batch (scripts/ab_lockstep.py)."""
+        return os.environ.get("T2V_LOCKSTEP", "1") != "0"
 
     def inference_nhwc(self, pose):
         """pose: [H,W,round_up4(3*tG)] fp32 NHWC window (oldest frame first).  Returns [H,W,4] (RGB0)."""
