@@ -28,7 +28,7 @@ fi
 
 if has pmc; then
   # 3. PMC on the GEMM stage inside frames at the reference's geometries, one counter group per run (kernel trace only)
-  for cfg in "320 1 wino_gemm_sk" "320 2 wino_gemm_skr" "680 1 wino_gemm_skr"; do
+  for cfg in "320 1 wino_gemm_sk" "320 2 wino_gemm_skt" "680 1 wino_gemm_skt"; do
     set -- $cfg; w=$1; nb=$2; pat=$3
     i=0
     for grp in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES" "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"; do

@@ -37,9 +37,9 @@ def process_start_time():
     try:
         with open("/proc/self/stat") as fh:
             ticks = int(fh.read().rsplit(")", 1)[1].split()[19])         # field 22: starttime, clock ticks after boot
-        with open("/proc/stat") as fh:
-            btime = next(int(l.split()[1]) for l in fh if l.startswith("btime"))
-        return btime + ticks / os.sysconf("SC_CLK_TCK")
+        # age = now on the boot clock - start on the boot clock (10 ms ticks); /proc/stat's btime is whole seconds only
+        age = time.clock_gettime(time.CLOCK_BOOTTIME) - ticks / os.sysconf("SC_CLK_TCK")
+        return time.time() - age if 0 <= age < 86400 else None
     except Exception:
         return None
 
