@@ -1,5 +1,5 @@
 """N frames of the config-2 generator (flow on unless --noflow) for rocprofv3: nothing but the frame loop.
-Usage: [T2V_STREAMS=1] frame_prof.py [--frames 40] [--noflow] [--size 512] [--width W] [--batch N]"""
+Usage: [T2V_STREAMS=1] frame_prof.py [--frames 40] [--noflow] [--size 512] [--width W] [--batch N] [--scales 2]"""
 import argparse, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -12,10 +12,15 @@ ap.add_argument("--noflow", action="store_true")
 ap.add_argument("--size", type=int, default=512)
 ap.add_argument("--width", type=int, default=0, help="frame width when it differs from --size (the reference's 512x320 / 512x680)")
 ap.add_argument("--batch", type=int, default=1, help="independent sequences advanced in lock-step")
+ap.add_argument("--scales", type=int, default=1, help="2: the coarse generator at half size + the local enhancer (configs[3] two-scale)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 spec = GeneratorSpec(ngf=128, n_downsample=3, n_blocks=9, no_flow=a.noflow, norm="batch")
-model = Vid2VidModelG([HipGenerator(spec, dev).load_state_dict(synthetic_state_dict(spec, 1, flow_gain=0.1))])
+nets = [HipGenerator(spec, dev).load_state_dict(synthetic_state_dict(spec, 1, flow_gain=0.1))]
+if a.scales == 2:
+    spec1 = GeneratorSpec(ngf=64, n_blocks=3, no_flow=a.noflow, norm="batch", is_local=True, scale=1)
+    nets.append(HipGenerator(spec1, dev).load_state_dict(synthetic_state_dict(spec1, 2, flow_gain=0.1)))
+model = Vid2VidModelG(nets)
 H = a.size
 W = a.width or a.size
 rng = np.random.default_rng(0)
