@@ -144,6 +144,24 @@ class ClockSampler:
                     source="sysfs pp_dpm_sclk, 50 ms period, during the headline timed region")
 
 
+def warm_clocks(fn, warm_ms=80.0):
+    """Run fn(i) back to back for ~warm_ms of GPU time before a kernel is timed: after a host-side gap (building inputs,
+    packing weights) the core clock takes tens of ms of load to come back up -- measured with scripts/cadence_probe.py on the
+    512x512 GEMM stage: 158 us per launch in a 40-launch window that follows 64 warm-up launches (9 ms), 141-145 us in the next
+    windows, 139-142 us over 200 launches.  Returns the number of launches issued (so that fn's alternation continues)."""
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(8):
+        fn(i)
+    e1.record()
+    torch.cuda.synchronize()
+    per = max(e0.elapsed_time(e1) / 8, 1e-3)
+    n = 8 + int(min(4000, warm_ms / per))
+    for i in range(8, n):
+        fn(i)
+    return n
+
+
 def gemm_stage_roofline(dev, sd, g0h, g0w, iters):
     """The dominant kernel of a frame whose global generator G0 runs on g0h x g0w, timed live with HIP events on the
     stream it is launched on (torch's current stream); returns the `roofline` object."""
@@ -184,8 +202,7 @@ def gemm_stage_roofline(dev, sd, g0h, g0w, iters):
     else:
         def launch(i, stages=0):
             ops.conv2d(xs[i & 1], wt, bias, desc, y_cs=C, stats=stats, out=y)
-    for i in range(64):   # ~35 ms: the clocks ramp back up for tens of ms after the host-side gap above
-        launch(i)
+    warm_clocks(launch)
     e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
     e0.record()
     for i in range(iters):
@@ -194,7 +211,15 @@ def gemm_stage_roofline(dev, sd, g0h, g0w, iters):
     for i in range(iters):   # the whole conv (all three stages / the direct kernel)
         launch(i, 7)
     e2.record()
+    # the same launches bracketed one by one (an event pair per launch: the kernel's own duration, without the
+    # command processor's gap between two dependent launches of a queue that the back-to-back cadence above includes)
+    pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for i, (a0, a1) in enumerate(pairs):
+        a0.record()
+        launch(i)
+        a1.record()
     torch.cuda.synchronize()
+    k_ms_bracketed = sum(a0.elapsed_time(a1) for a0, a1 in pairs) / iters
     k_ms = e0.elapsed_time(e1) / iters
     conv_ms = e1.elapsed_time(e2) / iters
     conv_flop = 2.0 * 9 * C * C * hb * wb                       # algorithmic (direct-conv) FLOPs of the layer
@@ -226,7 +251,8 @@ def gemm_stage_roofline(dev, sd, g0h, g0w, iters):
                 "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
                 "traffic_source": ("profiles/pmc_summary.json (separate rocprofv3 --pmc passes: 2*FETCH_SIZE + WRITE_SIZE per launch; "
                                    "not measured by this run)" if traffic is not None else None),
-                "ms_per_launch": round(k_ms, 4), "gflop_per_launch": round(k_flop / 1e9, 2),
+                "ms_per_launch": round(k_ms, 4), "ms_per_launch_bracketed": round(k_ms_bracketed, 4),
+                "gflop_per_launch": round(k_flop / 1e9, 2),
                 "flops_counted": "executed MFMA FLOPs of the launch" if use_wino else "algorithmic conv FLOPs",
                 "layer": {"algo": "winograd_f%dx%d_3x3" % (wm, wm) if use_wino else "direct", "ms_per_conv": round(conv_ms, 4),
                           "algorithmic_gflop": round(conv_flop / 1e9, 2),
@@ -375,8 +401,7 @@ def train_block(dev, dist_mod, world, rank, backend, steps, iters, ngf=128):
     if rank == 0:
         # ---- the step's heaviest kernels, live (HIP events on the launch stream), on the FLOPs they execute ----
         def ev_time(fn):
-            for _ in range(16):
-                fn()
+            warm_clocks(lambda i: fn())
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(iters):
@@ -586,7 +611,7 @@ def main():
     ap.add_argument("--scales", type=int, default=1, choices=[1, 2],
                     help="2 = config 4's two-scale generator: G0 at H/2 x W/2 + local enhancer G1 at H x W")
     ap.add_argument("--cpu-frames", type=int, default=3, help="frames of the CPU-oracle baseline (0 = skip)")
-    ap.add_argument("--kernel-iters", type=int, default=40)
+    ap.add_argument("--kernel-iters", type=int, default=200)
     ap.add_argument("--no-cold-start", action="store_true", help="skip e2e.cold_start (the test.py command as a subprocess)")
     ap.add_argument("--hires-frames", type=int, default=16,
                     help="frames per 1024x1024 run of the `hires` block (configs[3]; 0 = skip; default geometry, 1 GPU only)")

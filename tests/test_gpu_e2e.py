@@ -292,6 +292,7 @@ def test_bench_contract_line():
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 157.3
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and 0.3 < rf["frac"] <= 1.0
     assert abs(rf["achieved"] - rf["gflop_per_launch"] / rf["ms_per_launch"]) <= 0.02 * rf["achieved"]
+    assert 0.5 * rf["ms_per_launch"] < rf["ms_per_launch_bracketed"] < 1.15 * rf["ms_per_launch"]      # per-launch event pairs
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["unit"] == "frames/s" and cb["cores"] >= 1 and 0 < cb["value"] < d["value"]
     assert cb["parity"]["frames"] == 2 and 0 < cb["parity"]["max_abs_delta_vs_oracle"] <= cb["parity"]["tolerance"] == 1e-3
