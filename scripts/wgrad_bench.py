@@ -8,6 +8,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--shapes", default="rb1024,down512,down256,down128,up1024,up512,up256")
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--warmup", type=int, default=40)
+ap.add_argument("--batch", type=int, default=1, help="images reduced over in one launch (a train step reduces over its 2 frames)")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 for name in args.shapes.split(","):
@@ -15,8 +16,8 @@ for name in args.shapes.split(","):
     desc = ops.conv_desc(H, W, Cin, Cout, k, st, pad, pm, tr)
     xcs = ops.round_up(Cin, 4)
     ho, wo = ops.conv_out_dims(desc)
-    x = torch.randn(1, H, W, xcs, device=dev)
-    dy = torch.randn(1, ho, wo, ops.round_up(Cout, 4), device=dev)
+    x = torch.randn(args.batch, H, W, xcs, device=dev)
+    dy = torch.randn(args.batch, ho, wo, ops.round_up(Cout, 4), device=dev)
     run = lambda: ops.conv2d_backward_weight(x, dy, desc)
     for _ in range(args.warmup): run()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -24,5 +25,5 @@ for name in args.shapes.split(","):
     for _ in range(args.iters): run()
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / args.iters
-    flop = 2.0 * k * k * Cin * Cout * (H * W if tr else ho * wo)
+    flop = 2.0 * args.batch * k * k * Cin * Cout * (H * W if tr else ho * wo)
     print("%-8s wgrad %8.4f ms  %7.2f GFLOP  %7.2f TFLOP/s" % (name, ms, flop / 1e9, flop / ms / 1e9), flush=True)

@@ -42,6 +42,7 @@ void options_reload() {
     o.wgrad_sk_half = env_int("T2V_WGRAD_SK_HALF", 1);
     o.wgrad_combine = env_int("T2V_WGRAD_COMBINE", 1);
     o.wgrad_combine_max = env_int("T2V_WGRAD_COMBINE_MAX", 4);
+    o.wgrad_splits = env_int("T2V_WGRAD_SPLITS", 0);
     o.wgrad_fold = env_int("T2V_WGRAD_FOLD", 1);
     o.conv_tile = env_int("T2V_CONV_TILE", -1);
     o.conv_ring = env_int("T2V_CONV_RING", 0);
@@ -664,6 +665,7 @@ static int wgrad_splits(const t2v_conv_desc* d, int x_cs, int batch, const ConvP
     if (smax < 1) smax = 1;
     long s = 1, best = -1;
     const long slots = 2 * 256;      // two blocks (2 x 64 KiB of LDS, 104 VGPRs) are resident per CU
+    if (options().wgrad_splits > 0) return (int)std::min<long>(options().wgrad_splits, smax);      // (experiments)
     for (long c = 1; c <= smax; ++c) {
         const long rounds = (blocks * c + slots - 1) / slots;
         // + zeroing, writing and re-reading c partial gradients at ~15 MB per stage time

@@ -49,6 +49,7 @@ struct Options {
     int wgrad_sk;            // T2V_WGRAD_SK: as wino_gemm_sk, for the Winograd-domain weight gradient
     int wgrad_sk_half;       // T2V_WGRAD_SK_HALF
     int wgrad_combine;       // T2V_WGRAD_COMBINE: in-kernel combine of split partials (default 1)
+    int wgrad_splits;        // T2V_WGRAD_SPLITS: > 0 forces the pixel-range split count of the direct weight gradient (experiments)
     int wgrad_combine_max;   // T2V_WGRAD_COMBINE_MAX: ... up to this many partials (default 4)
     int wgrad_fold;          // T2V_WGRAD_FOLD: taps folded into the tile for narrow layers (default 1)
     int conv_tile;           // T2V_CONV_TILE: -1 auto (default), 0 / 2 force 128x128 / 64x64 tiles where both exist
