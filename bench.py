@@ -164,7 +164,26 @@ def warm_clocks(fn, warm_ms=80.0):
 
 def gemm_stage_roofline(dev, sd, g0h, g0w, iters):
     """The dominant kernel of a frame whose global generator G0 runs on g0h x g0w, timed live with HIP events on the
-    stream it is launched on (torch's current stream); returns the `roofline` object."""
+    stream it is launched on (torch's current stream); returns the `roofline` object.  The kernel timed is the one the
+    frames RUN: t2v_generator_forward announces its second stream to the library (overlap hint), which then prefers the
+    form that leaves that stream wave slots -- 256x128 tiles on one block per CU at 512x512: slower alone, faster in the
+    frame -- so the hint is set here too; `alone_best` is the same stage without the hint (the form a single-stream caller
+    gets), when the two differ."""
+    from text2video_amd import ops
+    two_streams = os.environ.get("T2V_STREAMS", "") != "1"
+    prev = ops.set_overlap_hint(two_streams)
+    try:
+        r = _gemm_stage_roofline(dev, sd, g0h, g0w, iters)
+    finally:
+        ops.set_overlap_hint(prev)
+    if two_streams:
+        alone = _gemm_stage_roofline(dev, sd, g0h, g0w, iters)
+        if alone["kernel"] != r["kernel"]:
+            r["alone_best"] = {"kernel": alone["kernel"].split(" as ")[0], "ms_per_launch": alone["ms_per_launch"], "frac": alone["frac"]}
+    return r
+
+
+def _gemm_stage_roofline(dev, sd, g0h, g0w, iters):
     from text2video_amd import ops
     # ---- dominant kernel, timed live with HIP events on the stream it is launched on ----
     # The 1024->1024 3x3 ResnetBlock conv (28 per frame, 84 % of the algorithmic FLOPs) runs as Winograd
@@ -234,7 +253,8 @@ def gemm_stage_roofline(dev, sd, g0h, g0w, iters):
         try:
             traffic = json.load(open(prof)).get({0: "conv_igemm_rb_hbm_bytes_per_launch",
                                                  1: "winograd_f2_gemm_hbm_bytes_per_launch",
-                                                 2: ("winograd_f4_gemm_sk_hbm_bytes_per_launch" if fixed_grid else
+                                                 2: ("winograd_f4_gemm_sk_256x128_hbm_bytes_per_launch" if "256x128" in form else
+                                                     "winograd_f4_gemm_sk_hbm_bytes_per_launch" if fixed_grid else
                                                      "winograd_f4_gemm_hbm_bytes_per_launch")}[algo]
                                                 if (hb, wb) == (64, 64) else
                                                 {(64, 40): "winograd_f4_gemm_512x320_hbm_bytes_per_launch",

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define T2V_ABI_VERSION 12
+#define T2V_ABI_VERSION 13
 
 typedef enum {
     T2V_OK = 0,
@@ -71,6 +71,13 @@ int t2v_check_async_errors(void);
 /* 1 while the fixed-grid ("stream-K") forms of the Winograd GEMM stage / weight-gradient reduction may be used: the
  * dispatch-order self-test of t2v_create passed and no hand-over has timed out; 0: one block per tile everywhere. */
 int t2v_fixed_grid_enabled(void);
+/* Overlap hint (ABI 13): on != 0 tells the library that the caller runs a SECOND stream beside the one it passes in, so that
+ * kernels which leave wave slots to that stream are preferred where they exist (today: the 512x512 ResnetBlock GEMM stage on
+ * 256x128 tiles with one block per CU instead of 128x128 with two -- slower alone, faster in a two-stream frame).  Per calling
+ * thread; returns the previous value.  t2v_generator_forward[_batch] sets it for its own launches; a caller that overlaps
+ * single-op calls itself (or wants t2v_conv_winograd_gemm_form to answer for the generator's frames) sets it explicitly.
+ * (THCUNN has no counterpart: its ops run on the one current stream of THCState.) */
+int t2v_set_overlap_hint(int on);
 /* Test hook: raise != 0 sets the sticky error word exactly as a timed-out consumer wave would; raise == 0 clears it and
  * switches the fixed-grid kernels back on. */
 void t2v_debug_async_error(int raise);

@@ -28,8 +28,10 @@ fi
 
 if has pmc; then
   # 3. PMC on the GEMM stage inside frames at the reference's geometries, one counter group per run (kernel trace only)
-  for cfg in "320 1 wino_gemm_sk" "320 2 wino_gemm_skt" "680 1 wino_gemm_skt"; do
+  # (512 1: the 256x128 / one-block-per-CU form the two-stream frames run under the overlap hint, forced here on one stream)
+  for cfg in "320 1 wino_gemm_sk" "320 2 wino_gemm_skt" "680 1 wino_gemm_skt" "512 1 wino_gemm_sk"; do
     set -- $cfg; w=$1; nb=$2; pat=$3
+    if [ $w = 512 ]; then export T2V_WINO_GEMM_SK_TALL=2; else unset T2V_WINO_GEMM_SK_TALL; fi
     i=0
     for grp in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES" "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"; do
       i=$((i+1)); out=$O/pmc_gemm_${w}_b$nb/p$i; mkdir -p $out
@@ -39,6 +41,7 @@ if has pmc; then
     done
     rm -rf $O/pmc_gemm_${w}_b$nb
   done
+  unset T2V_WINO_GEMM_SK_TALL
 fi
 
 if has train; then

@@ -437,6 +437,46 @@ def test_fixed_grid_winograd_gemm_equals_tile_per_block(geom, ragged, t2v_env):
     assert float((_from_nhwc(want[0], Cout) - ref).abs().max()) < 2e-3 * max(1.0, float(ref.abs().max()))
 
 
+def test_overlap_hint_selects_the_one_block_per_cu_form_and_keeps_the_bits(t2v_env):
+    """t2v_set_overlap_hint (ABI 13): a caller that runs a second stream beside its launches -- t2v_generator_forward's
+    two-stream frames do it themselves -- gets the 512x512 ResnetBlock GEMM stage on 256 x 128 tiles with one block per CU
+    instead of 128 x 128 with two.  Which kernel runs changes, the K-ordered MFMA chain of an output does not: same bits.
+    T2V_OVERLAP_HINT=0 ignores the hint; the hint is per thread and returns its previous value."""
+    from text2video_amd import ops
+    H, W, C = 64, 64, 1024
+    dev = _dev()
+    desc = ops.conv_desc(H, W, C, C, 3, 1, 1, ops.PAD_REFLECT, algo=ops.ALGO_WINOGRAD_F4)
+    w = _rand(C, C, 3, 3, seed=2, scale=0.03).to(dev)
+    b = _rand(C, seed=3).to(dev)
+    pu = ops.pack_conv_weight(w, desc, C)
+    ws = ops.winograd_workspace(desc, C, dev)
+    x = _rand(H, W, C, seed=21).to(dev)
+    assert ops.set_overlap_hint(False) is False
+    assert "128x128" in ops.winograd_gemm_form(desc)
+    want = ops.conv2d_winograd(x, pu, b, desc, workspace=ws).clone()
+    assert ops.set_overlap_hint(True) is False
+    try:
+        assert "256x128" in ops.winograd_gemm_form(desc), ops.winograd_gemm_form(desc)
+        assert "256x128" in ops.winograd_gemm_form(desc, 2) and "128x128" in ops.winograd_gemm_form(desc, 4)
+        ws.fill_(float("nan"))
+        for rep in range(4):
+            assert torch.equal(ops.conv2d_winograd(x, pu, b, desc, workspace=ws), want)
+        t2v_env("T2V_OVERLAP_HINT", "0")
+        assert "128x128" in ops.winograd_gemm_form(desc)
+    finally:
+        assert ops.set_overlap_hint(False) is True
+    # (another thread never sees this thread's hint)
+    import threading
+    seen = []
+    ops.set_overlap_hint(True)
+    try:
+        t = threading.Thread(target=lambda: seen.append(ops.set_overlap_hint(False)))
+        t.start(); t.join()
+    finally:
+        ops.set_overlap_hint(False)
+    assert seen == [False]
+
+
 def test_fixed_grid_gemm_survives_graph_replay(t2v_env):
     """A captured launch is re-issued with the SAME kernel arguments, hand-over tag included: the consumer clears a tag it has
     taken, so a replay does not mistake the previous replay's accumulators for this one's.  Capture one Winograd conv

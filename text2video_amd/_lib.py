@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("T2V_LIBRARY") or os.path.join(_HERE, "lib", "libt2v_h
 T2V_OK = 0
 PAD_ZERO, PAD_REFLECT = 0, 1
 ACT_NONE, ACT_TANH, ACT_FLOW_W, ACT_LRELU = 0, 1, 2, 3
-ABI_VERSION = 12
+ABI_VERSION = 13
 MAX_BATCH = 8     # T2V_MAX_BATCH
 ALGO_DIRECT, ALGO_WINOGRAD, ALGO_WINOGRAD_F4 = 0, 1, 2
 
@@ -54,6 +54,7 @@ SIGNATURES = {
     "t2v_create": (c_int, [POINTER(c_void_p), c_int]),
     "t2v_destroy": (c_int, [c_void_p]),
     "t2v_reload_env": (None, []),
+    "t2v_set_overlap_hint": (c_int, [c_int]),
     "t2v_check_async_errors": (c_int, []),
     "t2v_fixed_grid_enabled": (c_int, []),
     "t2v_debug_async_error": (None, [c_int]),

@@ -31,6 +31,13 @@ static int env_int(const char* name, int dflt) {
     const char* e = getenv(name);
     return (e && *e) ? atoi(e) : dflt;
 }
+static thread_local int g_overlap = 0;
+int set_overlap_hint(int on) {
+    const int prev = g_overlap;
+    g_overlap = on ? 1 : 0;
+    return prev;
+}
+bool overlap_hint() { return g_overlap != 0 && options().overlap_hint != 0; }
 void options_reload() {
     Options o;
     o.wino_gemm_sk = env_int("T2V_WINO_GEMM_SK", 1);
@@ -38,6 +45,7 @@ void options_reload() {
     o.wino_gemm_sk_half = env_int("T2V_WINO_GEMM_SK_HALF", 1);
     o.wino_gemm_sk_ragged = env_int("T2V_WINO_GEMM_SK_RAGGED", 2);
     o.wino_gemm_sk_tall = env_int("T2V_WINO_GEMM_SK_TALL", 1);
+    o.overlap_hint = env_int("T2V_OVERLAP_HINT", 1);
     o.wgrad_sk = env_int("T2V_WGRAD_SK", 1);
     o.wgrad_sk_half = env_int("T2V_WGRAD_SK_HALF", 1);
     o.wgrad_combine = env_int("T2V_WGRAD_COMBINE", 1);
@@ -480,6 +488,7 @@ int t2v_create(t2v_ctx** out, int device) {
 }
 
 void t2v_reload_env(void) { options_reload(); }
+int t2v_set_overlap_hint(int on) { return set_overlap_hint(on); }
 int t2v_check_async_errors(void) { return check_async_errors(); }
 int t2v_fixed_grid_enabled(void) { return fixed_grid_enabled() ? 1 : 0; }
 void t2v_debug_async_error(int raise) {

@@ -1016,7 +1016,8 @@ static bool sk_half_round(long tiles, long grid, int nk) {
     return options().wino_gemm_sk_half && tiles >= grid && 2 * (tiles % grid) == grid && nk % 2 == 0 && grid % 16 == 0;
 }
 // 129 .. 160 real rows per position (the 64 x 40 bottleneck of the reference's 512x320 frames: 160 Winograd tiles) -- and,
-// with T2V_WINO_GEMM_SK_TALL=2, the 256 rows of a 512x512 frame on 256 x 128 tiles -- : ONE
+// under the overlap hint (a caller with a second stream: the generator's two-stream frames) or with
+// T2V_WINO_GEMM_SK_TALL=2, the 256 rows of a 512x512 frame (512 of two) on 256 x 128 tiles -- : ONE
 // 160 x 128 tile per position and column tile -- no padding rows, 0.0141 B of LDS-DMA per MAC (192 x 64: 0.0208) -- whose 80
 // accumulator registers and 108 KiB ring allow one block per CU: a fixed grid of one block per CU, 288 tiles on 256 blocks
 static int sk_tall_rows(int groups, int rows, int T, int N) {     // tile rows of the one-block-per-CU form (160 | 256), or 0
@@ -1024,7 +1025,7 @@ static int sk_tall_rows(int groups, int rows, int T, int N) {     // tile rows o
     if (!mode || rows <= 0 || N % 128) return 0;
     int bm = 0, mt = 1;
     if (rows > 128 && rows <= 160 && T >= 160) bm = 160;
-    else if (mode >= 2 && T % 256 == 0 && rows > T - 32 && T <= 512) bm = 256, mt = T / 256;      // 256 (one 512x512 image) | 512 (two)
+    else if ((mode >= 2 || overlap_hint()) && T % 256 == 0 && rows > T - 32 && T <= 512) bm = 256, mt = T / 256;  // 256 (one 512x512 image) | 512 (two)
     if (!bm) return 0;
     const long tiles = (long)groups * mt * (N / 128), grid = wino_gemm_sk_grid_blocks() / 2;
     return (tiles >= grid && tiles * 100 <= ((tiles + grid - 1) / grid) * grid * 90) ? bm : 0;

@@ -430,6 +430,7 @@ int t2v_generator_forward_batch(t2v_ctx* ctx, void* stream, const t2v_gen_desc* 
     // small (norm finalize / apply, Winograd transforms: 5-13 us, launch- and tail-bound); run side by side
     // the other branch's GEMM blocks fill those gaps.  T2V_STREAMS=1 runs everything on the caller's stream.
     const bool two_streams = options().streams != 1;
+    const OverlapScope overlap(two_streams);     // (kernels that leave the other stream wave slots, where they exist)
     hipStream_t s2 = two_streams ? ctx->side : s;
     auto fork = [&]() -> int {
         if (!two_streams) return T2V_OK;

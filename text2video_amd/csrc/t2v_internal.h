@@ -44,6 +44,7 @@ struct Options {
     int wino_gemm_sk_half;   // T2V_WINO_GEMM_SK_HALF: second schedule for R + 1/2 rounds (default 1)
     int wino_gemm_sk_tall;   // T2V_WINO_GEMM_SK_TALL: one block per CU on 160x128 tiles for 129..160 tile rows (1), and on 256x128
                              // tiles for 256 / 512 tile rows (2)
+    int overlap_hint;        // T2V_OVERLAP_HINT: 0 ignores the overlap hint (t2v_set_overlap_hint / the generator's two-stream frames)
     int wino_gemm_sk_ragged; // T2V_WINO_GEMM_SK_RAGGED: ragged M tiles for tile rows that are no whole 128s: 1 = 4,..,4,r fragments on
                              // two blocks per CU, 2 = balanced 3..6-fragment tiles on one block per CU where that applies
     int wgrad_sk;            // T2V_WGRAD_SK: as wino_gemm_sk, for the Winograd-domain weight gradient
@@ -59,6 +60,15 @@ struct Options {
     int streams;             // T2V_STREAMS: 1 = the generator on the caller's stream only (default 2)
 };
 const Options& options();
+// true while the calling thread has announced a second stream beside its launches (t2v_set_overlap_hint; the generator's
+// two-stream frames set it for their own launches) and T2V_OVERLAP_HINT is not 0
+bool overlap_hint();
+int set_overlap_hint(int on);      // returns the previous value
+struct OverlapScope {
+    int prev;
+    explicit OverlapScope(bool on) : prev(set_overlap_hint(on ? 1 : 0)) {}
+    ~OverlapScope() { set_overlap_hint(prev); }
+};
 void options_reload();
 
 // The fixed-grid kernels hand accumulators from block b - 8 (b - 8 * half) to block b inside one launch.  That cannot

@@ -42,6 +42,12 @@ def check_async_errors():
     check(_lib.load().t2v_check_async_errors(), "check_async_errors")
 
 
+def set_overlap_hint(on):
+    """Tell the library that this thread runs a second stream beside the launches it issues (returns the previous value);
+    t2v_generator_forward does it for its own two-stream frames -- bench.py uses it to time the kernel those frames run"""
+    return bool(_lib.load().t2v_set_overlap_hint(1 if on else 0))
+
+
 def fixed_grid_enabled():
     return bool(_lib.load().t2v_fixed_grid_enabled())
 
