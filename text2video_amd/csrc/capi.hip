@@ -58,7 +58,7 @@ void options_reload() {
     o.conv_cout1 = env_int("T2V_CONV_COUT1", 1);
     o.conv_stem = env_int("T2V_CONV_STEM", 1);
     o.chain_lazy = env_int("T2V_CHAIN_LAZY", 1);
-    o.streams = env_int("T2V_STREAMS", 2);
+    o.streams = env_int("T2V_STREAMS", 0);
     g_opts = o;
 }
 const Options& options() {

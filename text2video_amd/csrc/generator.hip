@@ -429,7 +429,11 @@ int t2v_generator_forward_batch(t2v_ctx* ctx, void* stream, const t2v_gen_desc* 
     // are the image and flow branches after it.  Each branch is a chain of ~50-100 kernels, a third of them
     // small (norm finalize / apply, Winograd transforms: 5-13 us, launch- and tail-bound); run side by side
     // the other branch's GEMM blocks fill those gaps.  T2V_STREAMS=1 runs everything on the caller's stream.
-    const bool two_streams = options().streams != 1;
+    // Not where every kernel fills the chip by itself: a single-scale 1024x1024 frame (128x128 bottleneck, 1024 Winograd
+    // tiles per position; whole-chip launches of 0.5-1.1 ms) is 1.6-2.2 % FASTER on one stream (41.5 vs 42.2 ms, no flow
+    // 31.8 vs 32.5), 768x768 and everything below it 1-5 % slower -- so the default (T2V_STREAMS unset / 0) decides by size.
+    const int bott_tiles = ((d->H >> d->n_downsample) + 3) / 4 * (((d->W >> d->n_downsample) + 3) / 4);
+    const bool two_streams = options().streams == 2 || (options().streams == 0 && (d->is_local || bott_tiles < 1024));
     const OverlapScope overlap(two_streams);     // (kernels that leave the other stream wave slots, where they exist)
     hipStream_t s2 = two_streams ? ctx->side : s;
     auto fork = [&]() -> int {

@@ -57,7 +57,8 @@ struct Options {
     int conv_ring;           // T2V_CONV_RING: 0 auto (default), 2 / 3 ring depth
     int conv_head, conv_cout1, conv_stem;   // T2V_CONV_HEAD / _COUT1 / _STEM: the dedicated kernels (default 1)
     int chain_lazy;          // T2V_CHAIN_LAZY: ResnetBlock chains apply their norms in the next input transform (default 1)
-    int streams;             // T2V_STREAMS: 1 = the generator on the caller's stream only (default 2)
+    int streams;             // T2V_STREAMS: 1 = the generator on the caller's stream only, 2 = always two streams; 0 (default):
+                             // two, except the global generator on a bottleneck of >= 1024 Winograd tiles (1024x1024 frames)
 };
 const Options& options();
 // true while the calling thread has announced a second stream beside its launches (t2v_set_overlap_hint; the generator's
