@@ -9,6 +9,7 @@ SHAPES = {
     "up512": (128, 128, 512, 256, 3, 2, 1, 0, True, True),
     "up256": (256, 256, 256, 128, 3, 2, 1, 0, True, True),
     "stem9": (512, 512, 9, 128, 7, 1, 3, 1, False, True),
+    "stem6": (512, 512, 6, 128, 7, 1, 3, 1, False, True),
     "rb1024_320": (64, 40, 1024, 1024, 3, 1, 1, 1, False, True),
     "rb1024_680": (64, 85, 1024, 1024, 3, 1, 1, 1, False, True),
     "head3": (512, 512, 128, 3, 7, 1, 3, 1, False, False),

@@ -150,6 +150,7 @@ int build_conv_plan(const t2v_conv_desc* d, int x_cs, bool need_stats, ConvPlan*
                 x_cs, d->Cin);
     ConvPlan& pl = *out;
     memset(&pl, 0, sizeof(pl));
+    pl.Cin = d->Cin;
     ConvKParams& k = pl.kp;
     // the small-Cout tile has no statistics epilogue; weights are always packed to the 128-row
     // granule so either tile can read them
@@ -367,6 +368,7 @@ int run_conv(t2v_ctx* ctx, hipStream_t s, const ConvPlan& pl, const float* x, co
         StemParams sp;
         sp.x = x; sp.w = w; sp.bias = bias; sp.y = y; sp.stats = stats;
         sp.H = pl.kp.Hin; sp.W = pl.kp.Win; sp.Cin_s = pl.kp.Cin_s; sp.Kp = pl.kp.ph[0].Kp; sp.Cout = pl.kp.Cout; sp.Cout_s = y_cs;
+        sp.Cin = pl.Cin;
         return launch_conv_stem7x7(s, sp);
     }
     T2V_REQUIRE(pl.tile != kTileStem, "conv: the stem plan needs a statistics buffer");

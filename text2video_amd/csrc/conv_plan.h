@@ -10,6 +10,7 @@ struct ConvPlan {
     int BM, BN;
     int Hout, Wout;
     int Cout_p;       // Cout rounded up to the N tile (rows of the packed weight)
+    int Cin;          // real input channels (<= kp.Cin_s)
     int nparts;       // instance-norm partial-statistics rows (= nphases * mtiles)
     size_t wfloats;   // packed weight size
 };

@@ -33,13 +33,16 @@ __device__ __forceinline__ void st_dma16(const float* base, int nbytes, char* ld
 #endif
 }
 
-template <int CS, int NT>
+// CR = real input channels where the kernel knows how to skip the storage padding (9 of 12, 6 of 8: `DENSE`), else CS
+template <int CS, int NT, int CR = CS>
 struct StemCfg {
     static constexpr int TILE = 16, HALO = TILE + 6, NPIX = HALO * HALO;      // 484 halo pixels
     static constexpr int CQ = CS / 4;                                          // quads per pixel
     static constexpr int RUNQ = 7 * CQ;                                        // quads of one kernel row's run (21 | 14)
     static constexpr int QS = (RUNQ + 1) / 2;                                  // k steps of 8 floats per kernel row (11 | 7)
-    static constexpr int BQ = (2 * QS) | 1;                                    // weight row stride in quads, odd (23 | 15)
+    static constexpr bool DENSE = (CS == 12 && CR == 9) || (CS == 8 && CR == 6);
+    // weight row stride in quads, odd (23 | 15); the dense k order reads one quad pair past the run (tap "7": zeros) -> 25 | 17
+    static constexpr int BQ = DENSE ? (CS == 12 ? 25 : 17) : ((2 * QS) | 1);
     static constexpr int N = NT * 32;
     static constexpr int HALO_INSTR = (NPIX * CQ + 63) / 64;                   // DMA wave-instructions for the halo
     static constexpr int HALO_BYTES = HALO_INSTR * 1024 + 256;                 // + slack read by the padded run
@@ -49,9 +52,9 @@ struct StemCfg {
     static constexpr int LDS = HALO_BYTES + W_BYTES + RED_BYTES;
 };
 
-template <int CS, int NT>
+template <int CS, int NT, int CR>
 __global__ __launch_bounds__(512) void conv_stem7x7_kernel(const StemParams p) {
-    using C = StemCfg<CS, NT>;
+    using C = StemCfg<CS, NT, CR>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* s_halo = smem;
     char* s_w = smem + C::HALO_BYTES;
@@ -121,16 +124,71 @@ __global__ __launch_bounds__(512) void conv_stem7x7_kernel(const StemParams p) {
     for (int kh = 0; kh < 7; ++kh) {
         __syncthreads();   // halo (kh == 0) and this kernel row's weights have landed (the barrier's fence drains vmcnt)
         const char* ar = a_base + kh * (C::HALO * CS * 4);
+        if constexpr (CS == 12 && CR == 9) {
+            // 9 real channels in 12: a pixel's quads are (c0..3) (c4..7) (c8, 0, 0, 0).  k order of a kernel row: 7 steps
+            // "tap kw: quad 0 | quad 1" with 4 MFMAs each, then 4 steps "c8 of tap 2s | c8 of tap 2s+1" with ONE MFMA each
+            // (tap 7 = the pixel after the run against zero weights): 32 MFMAs per row and channel tile instead of 44
 #pragma unroll
-        for (int q = 0; q < C::QS; ++q) {
-            const f32x4s a = *reinterpret_cast<const f32x4s*>(ar + q * 32);
-            f32x4s b[NT];
+            for (int kw = 0; kw < 7; ++kw) {
+                const f32x4s a = *reinterpret_cast<const f32x4s*>(ar + kw * 48);
+                f32x4s b[NT];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) b[t] = *reinterpret_cast<const f32x4s*>(b_base + t * (32 * C::BQ * 16) + q * 32);
+                for (int t = 0; t < NT; ++t) b[t] = *reinterpret_cast<const f32x4s*>(b_base + t * (32 * C::BQ * 16) + kw * 48);
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+                for (int e = 0; e < 4; ++e)
 #pragma unroll
-                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[t][e], acc[t], 0, 0, 0);
+                    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[t][e], acc[t], 0, 0, 0);
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) {
+                const float a1 = *reinterpret_cast<const float*>(ar + g * 32 + s2 * 96 + 32);      // pixel + 2 s2 + g, quad 2
+                float b1[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    b1[t] = *reinterpret_cast<const float*>(b_base + g * 32 + t * (32 * C::BQ * 16) + s2 * 96 + 32);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1[t], acc[t], 0, 0, 0);
+            }
+        } else if constexpr (CS == 8 && CR == 6) {
+            // 6 real channels in 8: quads (c0..3) (c4, c5, 0, 0).  4 steps "quad 0 of tap 2s | of tap 2s+1" with 4 MFMAs,
+            // 4 steps "quad 1 of tap 2s | of tap 2s+1" with 2 (tap 7: zero weights): 24 MFMAs per row instead of 28
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) {
+                const f32x4s a = *reinterpret_cast<const f32x4s*>(ar + g * 16 + s2 * 64);
+                f32x4s b[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    b[t] = *reinterpret_cast<const f32x4s*>(b_base + g * 16 + t * (32 * C::BQ * 16) + s2 * 64);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[t][e], acc[t], 0, 0, 0);
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) {
+                const float2 a2 = *reinterpret_cast<const float2*>(ar + g * 16 + s2 * 64 + 16);
+                float2 b2[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    b2[t] = *reinterpret_cast<const float2*>(b_base + g * 16 + t * (32 * C::BQ * 16) + s2 * 64 + 16);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.x, b2[t].x, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.y, b2[t].y, acc[t], 0, 0, 0);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < C::QS; ++q) {
+                const f32x4s a = *reinterpret_cast<const f32x4s*>(ar + q * 32);
+                f32x4s b[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) b[t] = *reinterpret_cast<const f32x4s*>(b_base + t * (32 * C::BQ * 16) + q * 32);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[t][e], acc[t], 0, 0, 0);
+            }
         }
         __syncthreads();   // every wave is done with these weights
         if (kh + 1 < 7) stage_w(kh + 1);
@@ -197,10 +255,10 @@ __global__ __launch_bounds__(512) void conv_stem7x7_kernel(const StemParams p) {
     }
 }
 
-template <int CS, int NT>
+template <int CS, int NT, int CR>
 static int launch_stem(hipStream_t s, const StemParams& p) {
-    using C = StemCfg<CS, NT>;
-    auto kern = conv_stem7x7_kernel<CS, NT>;
+    using C = StemCfg<CS, NT, CR>;
+    auto kern = conv_stem7x7_kernel<CS, NT, CR>;
     static bool attr_done = false;
     if (!attr_done) {
         T2V_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
@@ -217,8 +275,12 @@ bool conv_stem7x7_supported(int H, int W, int Cin_s, int Cout) {
 
 int launch_conv_stem7x7(hipStream_t s, const StemParams& p) {
     T2V_REQUIRE(conv_stem7x7_supported(p.H, p.W, p.Cin_s, p.Cout) && p.stats && p.Cout_s >= p.Cout, "stem kernel: unsupported launch");
-    if (p.Cin_s == 12) return p.Cout == 128 ? launch_stem<12, 4>(s, p) : launch_stem<12, 2>(s, p);
-    return p.Cout == 128 ? launch_stem<8, 4>(s, p) : launch_stem<8, 2>(s, p);
+    // the generator's own stems (9 pose channels in 12, 6 previous-frame channels in 8) skip the storage padding in K
+    const bool dense = options().conv_stem != 2;      // T2V_CONV_STEM=2: the plain k order (A/B)
+    if (p.Cin_s == 12 && p.Cin == 9 && dense) return p.Cout == 128 ? launch_stem<12, 4, 9>(s, p) : launch_stem<12, 2, 9>(s, p);
+    if (p.Cin_s == 8 && p.Cin == 6 && dense) return p.Cout == 128 ? launch_stem<8, 4, 6>(s, p) : launch_stem<8, 2, 6>(s, p);
+    if (p.Cin_s == 12) return p.Cout == 128 ? launch_stem<12, 4, 12>(s, p) : launch_stem<12, 2, 12>(s, p);
+    return p.Cout == 128 ? launch_stem<8, 4, 8>(s, p) : launch_stem<8, 2, 8>(s, p);
 }
 
 }  // namespace t2v

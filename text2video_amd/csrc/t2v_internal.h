@@ -233,6 +233,7 @@ struct StemParams {
     float* y;
     float* stats;        // [tiles][Cout] (mean, M2) per 16x16 pixel tile
     int H, W, Cin_s, Kp, Cout, Cout_s;
+    int Cin;             // real input channels (<= Cin_s; the weights of the storage padding are zero)
 };
 bool conv_stem7x7_supported(int H, int W, int Cin_s, int Cout);
 int launch_conv_stem7x7(hipStream_t s, const StemParams& p);
