@@ -309,23 +309,38 @@ def test_config4_train_step_512_matches_the_device_oracle_step():
         if tag == "Df.":
             continue        # (checked exactly below)
         assert np.median(a) <= 3 * np.median(b) and np.quantile(a, 0.9) <= 4 * np.quantile(b, 0.9) and a.max() <= 5 * b.max(), tag
-    # D_f by itself: its gradient evaluated IN FP64 on the frames the HIP generator produced is what the HIP step must deliver
-    # -- the generated frames' 2e-5 rms error seen through D_f is the whole of the D_f error above (scripts/step_parity_probe.py)
+    # D_f by itself, on the frames the HIP generator produced: its gradient evaluated in fp64 there is what the HIP step must
+    # deliver -- the generated frames' 2e-5 rms error seen through D_f is the whole of the D_f error above
+    # (scripts/step_parity_probe.py).  Every tensor within a few fp32 roundings of it -- except where a LeakyReLU kink flips: D_f
+    # is a LeakyReLU / batch-norm stack on a 128x128 crop (a million pre-activations per pass), and one of them within fp32
+    # rounding of zero takes the other slope in an fp32 evaluation: with the norm's beta = 0 that element has xhat = 0, so it
+    # moves that channel's SUM of dy (the norm bias gradient, and through the norm's mean(dy) term everything upstream of it:
+    # layer 1's conv weight, layer 0) by 0.8 |dy| and leaves dgamma and the later layers alone.  Measured with
+    # scripts/df_step_probe.py: 2.6e-6 on every tensor on one set of frames; on frames that differ from those by the rounding
+    # of the stems' k order 1e-6 on nine tensors and 4e-4 .. 2e-3 on exactly those four -- the step's gradient being, bit for
+    # bit, what D_f alone computes on the returned frames.  The fp32 oracle is subject to the same event on other elements
+    # (~8 % per pass and implementation).  So: the median against the fp32 oracle's own, and a cap on what one flip can do.
     import copy
     from oracle.generator_ref import MultiscaleDiscriminator      # noqa: F401
-    Dfr = copy.deepcopy(mods[2]).to(device=DEV, dtype=torch.float64)
-    pose64, real64 = clip[0].to(DEV, torch.float64), clip[1].to(DEV, torch.float64)
     mse = torch.nn.MSELoss()
 
     def crop(t):
         return torch.stack([t[i, :, bb[0]:bb[1], bb[2]:bb[3]] for i, bb in enumerate(boxes)])
-    fr = Dfr(torch.cat([crop(pose64[:, 6:9]), crop(real64)], 1))
-    ff = Dfr(torch.cat([crop(pose64[:, 6:9]), crop(f_hip.double())], 1))
-    l_df = 0.5 * (sum(mse(q[-1], torch.zeros_like(q[-1])) for q in ff) + sum(mse(q[-1], torch.ones_like(q[-1])) for q in fr))
-    g_df = {"Df." + k: g for (k, _), g in zip(Dfr.named_parameters(), torch.autograd.grad(l_df, list(Dfr.parameters())))}
-    e_df = _rel_err({k: g_hip[k] for k in g_df}, g_df, {k: g64[k] for k in g_df})
-    print("   D_f on the HIP frames, HIP gradient vs fp64 gradient: max rel %.1e" % max(e_df.values()))
-    assert max(e_df.values()) <= 1e-4
+
+    def df_gradients(dtype):
+        Dfr = copy.deepcopy(mods[2]).to(device=DEV, dtype=dtype)
+        pose_t, real_t, fake_t = clip[0].to(DEV, dtype), clip[1].to(DEV, dtype), f_hip.to(DEV, dtype)
+        fr = Dfr(torch.cat([crop(pose_t[:, 6:9]), crop(real_t)], 1))
+        ff = Dfr(torch.cat([crop(pose_t[:, 6:9]), crop(fake_t)], 1))
+        l_df = 0.5 * (sum(mse(q[-1], torch.zeros_like(q[-1])) for q in ff) + sum(mse(q[-1], torch.ones_like(q[-1])) for q in fr))
+        return {"Df." + k: g for (k, _), g in zip(Dfr.named_parameters(), torch.autograd.grad(l_df, list(Dfr.parameters())))}
+    g_df, g_df32 = df_gradients(torch.float64), df_gradients(torch.float32)
+    zero_ref = {k: g64[k] for k in g_df}
+    e_df, e_df32 = _rel_err({k: g_hip[k] for k in g_df}, g_df, zero_ref), _rel_err(g_df32, g_df, zero_ref)
+    a, b = np.array([e_df[k] for k in e_df]), np.array([e_df32[k] for k in e_df])
+    print("   D_f on the HIP frames vs its fp64 gradient there: HIP median %.1e max %.1e | fp32 oracle median %.1e max %.1e"
+          % (np.median(a), a.max(), np.median(b), b.max()))
+    assert np.median(a) <= max(1e-5, 3 * np.median(b)) and np.sum(a > 1e-4) <= 5 and a.max() <= 1e-2
     flow_keys = [k for k in eh if k.startswith(("G.model_res_flow", "G.model_up_flow", "G.model_final_flow", "G.model_final_w"))]
     a = np.array([eh[k] for k in flow_keys])
     b = np.array([eo[k] for k in flow_keys])
