@@ -19,6 +19,15 @@ SHAPES = {
     "l_rb": (512, 512, 128, 128, 3, 1, 1, 1, False, True),
     "l_up": (512, 512, 128, 64, 3, 2, 1, 0, True, True),
     "l_head": (1024, 1024, 64, 3, 7, 1, 3, 1, False, False),
+    # the 2-scale PatchGAN discriminator of the train step (ndf 64, 4x4 convs, pad 2): scale 0 on 512x512, scale 1 on 256x256
+    "d0": (512, 512, 6, 64, 4, 2, 2, 0, False, False),
+    "d1": (257, 257, 64, 128, 4, 2, 2, 0, False, True),
+    "d2": (129, 129, 128, 256, 4, 2, 2, 0, False, True),
+    "d3": (65, 65, 256, 512, 4, 1, 2, 0, False, True),
+    "d0h": (256, 256, 6, 64, 4, 2, 2, 0, False, False),
+    "d1h": (129, 129, 64, 128, 4, 2, 2, 0, False, True),
+    "d2h": (65, 65, 128, 256, 4, 2, 2, 0, False, True),
+    "d3h": (33, 33, 256, 512, 4, 1, 2, 0, False, True),
     # the tiny maps of the train-step parity test (32x32 frames, ngf 32): few tiles, 64x64 tile config, M < BM
     "t_rb128": (8, 8, 128, 128, 3, 1, 1, 1, False, True),
     "t_down32": (32, 32, 32, 64, 3, 2, 1, 0, False, True),
