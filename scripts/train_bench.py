@@ -21,6 +21,7 @@ ap.add_argument("--high_priority", action="store_true", help="run the steps on a
                 "stream keeps the default priority)")
 ap.add_argument("--host_time", action="store_true", help="also report when the host has finished ENQUEUEING a step (return of "
                 "the last optimiser step, before the losses are read back): host-bound or GPU-bound?")
+ap.add_argument("--cprofile", action="store_true", help="three more steps under cProfile: where the host spends its time")
 ap.add_argument("--force_dist", action="store_true", help="run the gradient exchange on a 1-rank RCCL group and report its "
                 "bytes, buckets and the part still running after the backward pass")
 args = ap.parse_args()
@@ -88,6 +89,17 @@ if args.host_time:
 print("train step %dx%d, %d frames, %s%s%s: %.1f ms/step, peak mem %.1f GB | %s"
       % (H, W, F, "no flow" if args.no_flow else "flow branch on", "" if args.no_face else " + face D", " + VGG" if args.vgg else "",
          dt * 1e3, torch.cuda.max_memory_allocated() / 2**30, " ".join("%s %.3f" % kv for kv in losses.items())))
+if args.cprofile:
+    import cProfile, pstats, io
+    pr = cProfile.Profile()
+    pr.enable()
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    pr.disable()
+    out = io.StringIO()
+    pstats.Stats(pr, stream=out).sort_stats("tottime").print_stats(28)
+    print("\n".join(l[:170] for l in out.getvalue().splitlines()[:60]))
 if args.aten_stacks:
     import collections, traceback
     sites = collections.Counter()
