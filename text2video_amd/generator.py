@@ -159,7 +159,9 @@ def upload_tensors(tensors, device):
     DMA runs -- against the runtime's own pageable copy: 0.98 s vs 0.40 s on the MI355X box.  Faulting the mapped pages in
     from one Python thread is the bottleneck, which the runtime's copy path avoids; the plain copy stays.  Several host
     threads copying their shares on streams of their own change nothing either: 0.27-0.31 s for 1.46 GB with 1, 2, 4, 8, 16
-    threads -- the runtime serialises pageable copies.)"""
+    threads -- the runtime serialises pageable copies.  Registering the mapped file as pinned memory first (hipHostRegister,
+    scripts/upload_register_probe.py) moves the time instead of saving it: 0.22-0.25 s to register 1.46 GB + 0.034 s of copies
+    at 43 GB/s = the plain copy's 0.28-0.30 s.)"""
     dev = torch.device(device)
     return {k: v.detach().to(dev, torch.float32).contiguous() for k, v in tensors.items()}
 
