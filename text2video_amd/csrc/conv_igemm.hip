@@ -1262,10 +1262,12 @@ static int launch_pad(hipStream_t s, const ConvKParams& p) {
     const long nblocks = (long)p.mtiles * p.ntiles * p.nphases;
     const int force = options().conv_ring;
     // (swept per layer shape with scripts/kernel_bench.py: single-phase launches like two co-resident blocks from 512
-    // blocks on; 64x64 tiles of a multi-phase launch prefer the deeper ring)
+    // blocks on; 64x64 tiles of a multi-phase launch prefer the deeper ring.  Round 4: also between 257 and 511 blocks -- one
+    // block per CU would need a second, mostly empty round there: the 344-block stride-2 layers of a 512x680 frame, 456 at
+    // 512x912; frames 16.07 -> 15.88 ms)
     const bool two = force ? force == 2
                            : (Cfg::MF == 32 && (Cfg::BM == 64 ? (p.nphases == 1 || nblocks >= 4096)
-                                                              : (nblocks >= 1024 || (p.nphases == 1 && nblocks >= 512))));
+                                                              : (nblocks >= 1024 || (p.nphases == 1 && nblocks > 256))));
     return two ? launch_ring<Cfg, MODE, STATS, REFLECT, 2>(s, p) : launch_ring<Cfg, MODE, STATS, REFLECT, 3>(s, p);
 }
 
