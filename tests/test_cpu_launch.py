@@ -68,6 +68,24 @@ def test_failing_rank_stops_the_job_with_its_status(tmp_path):
     assert "rank 1 exited with status 7" in r.stderr
 
 
+def test_a_taken_rendezvous_port_is_retried_on_a_fresh_one(tmp_path):
+    """free_port() only probes: a stranger may bind the port before rank 0 does.  The launcher sees the job fail early with the
+    port held by somebody else and starts the ranks again on a fresh port; a failure with the port free is final (above)."""
+    import socket
+    held = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+    held.bind(("127.0.0.1", 0))
+    held.listen(1)
+    try:
+        env = dict(os.environ, T2V_LAUNCH_PORT=str(held.getsockname()[1]))
+        r = _run(tmp_path, 2, "0,1", env=env)
+    finally:
+        held.close()
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "starting the ranks again on a fresh port" in r.stderr
+    outs = [json.load(open(tmp_path / ("rank%d.json" % i))) for i in range(2)]
+    assert all(o["world"] == 2 and o["sum"] == 3.0 for o in outs)
+
+
 def test_local_device_index_follows_gpu_ids(monkeypatch):
     from text2video_amd import launch
     monkeypatch.delenv("T2V_DIST_BACKEND", raising=False)

@@ -54,13 +54,39 @@ def _die_with_parent():
         pass
 
 
+def _port_taken(port):
+    """True when somebody holds 127.0.0.1:port now (the ranks of a failed attempt are gone by the time this is asked)"""
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        try:
+            s.bind(("127.0.0.1", port))
+            return False
+        except OSError:
+            return True
+
+
 def self_launch(nranks, device_ids=None, argv=None, poll_s=0.05):
     """Run `sys.executable argv` (default: this process's own command line) as `nranks` ranks and return the job's
     exit status: 0 when every rank returned 0, else the first failing rank's status (the remaining ranks are
     terminated by PID -- a rank blocked in a collective whose peer died would otherwise wait for its timeout).
-    Ranks inherit stdout / stderr, so rank 0's single JSON / summary line is the job's."""
+    Ranks inherit stdout / stderr, so rank 0's single JSON / summary line is the job's.
+    free_port() can only probe: between its close() and rank 0's bind another process may take the port.  A job
+    that fails within its first minute while a stranger holds its rendezvous port is started again on a fresh one (twice at
+    most); any other failure is final.  T2V_LAUNCH_PORT pins the first attempt's port (tests)."""
     argv = list(sys.argv if argv is None else argv)
-    port = free_port()
+    pinned = os.environ.get("T2V_LAUNCH_PORT")
+    rc = 1
+    for attempt in range(3):
+        port = int(pinned) if (pinned and attempt == 0) else free_port()
+        t0 = time.time()
+        rc = _launch_once(nranks, device_ids, argv, port, poll_s)
+        if rc == 0 or time.time() - t0 > 60.0 or not _port_taken(port):
+            return rc
+        print("launch: rendezvous port %d was taken by another process -- starting the ranks again on a fresh port"
+              % port, file=sys.stderr, flush=True)
+    return rc
+
+
+def _launch_once(nranks, device_ids, argv, port, poll_s):
     procs = []
     for r in range(nranks):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(nranks), LOCAL_WORLD_SIZE=str(nranks),
