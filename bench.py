@@ -586,6 +586,17 @@ def cold_start_block(n_maps=87):
                 return {"error": r.stderr[-400:]}
             split = json.load(open(tj))
         cs = split["cold_start"]
+        # the same command with torch as the frame loop's allocator / stream provider (T2V_LEAN=0: what it was before the
+        # torch-free loop of text2video_amd/leantorch.py)
+        with_torch = None
+        shutil.rmtree(os.path.join(tmp, "results"), ignore_errors=True)
+        t0 = time.perf_counter()
+        r = subprocess.run(cmd, cwd=os.path.join(ROOT, "vid2vid"), env=dict(env, T2V_LEAN="0"), stdout=subprocess.DEVNULL,
+                           stderr=subprocess.PIPE, text=True)
+        if r.returncode == 0:
+            tcs = json.load(open(tj))["cold_start"]
+            with_torch = {"wall_s": round(time.perf_counter() - t0, 3), "process_to_run_test_s": tcs.get("process_to_run_test_s"),
+                          "create_model_s": tcs.get("create_model_s"), "loop_s": tcs.get("loop_s")}
         # the same command as a client of the resident server (--resident: weights stay on the GPU between utterances):
         # the call that starts the server, then a warm one
         renv = dict(env, T2V_RESIDENT_KEY="bench-%d" % os.getpid())
@@ -608,7 +619,8 @@ def cold_start_block(n_maps=87):
                                             "warm_wall_over_loop": round(rwalls[1] / max(rloop, 1e-9), 2)}
         return {"command": "python vid2vid/test.py <text2video_audio.sh:42 flags> as a subprocess: tmp + tmp_smooth, 2 x %d frames "
                            "512x320, %.2f GB checkpoint" % (n_maps - 2, os.path.getsize(os.path.join(tmp, "ckpt", "fadg0", "latest_net_G0.pth")) / 1e9),
-                "frames": split["frames"], "wall_s": walls, "split_of_last_run": cs, "resident": resident,
+                "frames": split["frames"], "wall_s": walls, "split_of_last_run": cs, "with_torch": with_torch,
+                "resident": resident,
                 "wall_over_loop": round(walls[-1] / max(cs["loop_s"], 1e-9), 2),
                 "to_last_jpeg_over_loop": (round((cs["process_to_run_test_s"] + cs["to_last_jpeg_s"]) / max(cs["loop_s"], 1e-9), 2)
                                            if cs.get("process_to_run_test_s") is not None else None)}

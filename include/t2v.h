@@ -11,7 +11,9 @@
  *     channel *storage* stride (a multiple of 4 >= the logical channel count; extra channels
  *     must hold finite values and are ignored / written as zero).
  *   - ownership: the caller allocates every device buffer (tensors, packed weights, workspace)
- *     and keeps it alive until the stream has drained.  The library never allocates device memory.
+ *     and keeps it alive until the stream has drained.  The compute entry points never allocate device memory; a
+ *     host that has no device allocator of its own gets buffers, streams and events from the "host plumbing" section
+ *     at the end (ABI 14).
  *   - asynchronous: work is enqueued on the hipStream_t passed as `void* stream`
  *     (torch.cuda.current_stream().cuda_stream on the Python side); nothing synchronises.
  *   - errors: every call returns T2V_OK (0) or a negative t2v_status; t2v_last_error() returns a
@@ -29,7 +31,7 @@
 extern "C" {
 #endif
 
-#define T2V_ABI_VERSION 13
+#define T2V_ABI_VERSION 14
 
 typedef enum {
     T2V_OK = 0,
@@ -433,6 +435,32 @@ int t2v_generator_forward(t2v_ctx* ctx, void* stream, const t2v_gen_desc* d, con
 size_t t2v_generator_workspace_bytes_batch(const t2v_gen_desc* d, int batch);
 int t2v_generator_forward_batch(t2v_ctx* ctx, void* stream, const t2v_gen_desc* d, const t2v_layer* layers,
                                 int n_layers, const t2v_gen_io* ios, int batch, void* workspace, size_t ws_bytes);
+
+/* ------------------------------------------------------------------------------------------
+ * Host plumbing (ABI 14): device buffers, pinned host buffers, copies, streams and events for a host that has no HIP
+ * binding of its own -- the reference's hosts got these from THC (THCudaMalloc / THCudaFree
+ * $SP/torch/lib/include/THC/THCGeneral.h:143-144, THCudaHostAlloc :147, THCState_getCurrentStream :105,
+ * THCCachingHostAllocator.h).  `vid2vid/test.py` runs its frame loop on these alone (text2video_amd/leantorch.py:
+ * the one-shot command no longer pays for `import torch`); a host that does have an allocator (PyTorch in the tests,
+ * the trainer and the resident server) passes its own pointers and never calls them.  All of them make ctx's device
+ * current.  Nothing here caches: t2v_device_malloc is hipMalloc.
+ * ------------------------------------------------------------------------------------------ */
+int t2v_device_malloc(t2v_ctx* ctx, size_t bytes, void** out);
+int t2v_device_free(t2v_ctx* ctx, void* ptr);
+int t2v_host_malloc(t2v_ctx* ctx, size_t bytes, void** out);      /* page-locked, portable */
+int t2v_host_free(t2v_ctx* ctx, void* ptr);
+enum { T2V_COPY_H2D = 1, T2V_COPY_D2H = 2, T2V_COPY_D2D = 3 };
+/* enqueued on `stream`; asynchronous to the host when the host side is page-locked (a pageable source is staged by the
+ * runtime and the call returns when the host buffer may be reused) */
+int t2v_memcpy(t2v_ctx* ctx, void* stream, void* dst, const void* src, size_t bytes, int kind);
+int t2v_stream_create(t2v_ctx* ctx, void** out);                  /* non-blocking with respect to the null stream */
+int t2v_stream_destroy(t2v_ctx* ctx, void* stream);
+int t2v_stream_synchronize(t2v_ctx* ctx, void* stream);
+int t2v_event_create(t2v_ctx* ctx, void** out);                   /* no timing */
+int t2v_event_record(t2v_ctx* ctx, void* event, void* stream);
+int t2v_event_synchronize(t2v_ctx* ctx, void* event);
+int t2v_event_destroy(t2v_ctx* ctx, void* event);
+int t2v_device_synchronize(t2v_ctx* ctx);
 
 #ifdef __cplusplus
 }

@@ -64,6 +64,42 @@ def test_reference_command_line_end_to_end(tmp_path):
     assert r2.returncode != 0 and "not found" in (r2.stderr + r2.stdout)
 
 
+def test_lean_command_writes_the_same_files(tmp_path):
+    """A plain single-device `test.py` run never imports torch: its frame loop takes buffers, stream and events from the
+    library's host-plumbing entry points (text2video_amd/leantorch.py, include/t2v.h ABI 14) and reads the checkpoint with
+    its own reader.  Same files, byte for byte, as the run on torch (T2V_LEAN=0) -- from a zip-container checkpoint and
+    from the legacy stream torch 0.4.1 wrote."""
+    import json
+    import torch
+    from text2video_amd.generator import GeneratorSpec, synthetic_state_dict
+    work = _make_dataset(str(tmp_path))
+    os.makedirs(os.path.join(work, "checkpoints", "fadg0"))
+    ckpt = os.path.join(work, "checkpoints", "fadg0", "latest_net_G0.pth")
+    sd = synthetic_state_dict(GeneratorSpec(ngf=32, n_downsample=3, n_blocks=3, no_flow=False, norm="batch"), 5, flow_gain=0.1)
+    cmd = [sys.executable, os.path.join(ROOT, "vid2vid", "test.py"), "--name", "fadg0", "--dataroot", "datasets/fadg0",
+           "--dataset_mode", "pose", "--input_nc", "3", "--resize_or_crop", "scaleHeight", "--loadSize", "512",
+           "--openpose_only", "--how_many", "1200", "--no_first_img", "--random_drop_prob", "0", "--ngf", "32", "--n_blocks", "3",
+           "--timing_json", "timing.json"]
+    res = os.path.join(work, "results", "fadg0", "test_latest")
+
+    def run(lean, legacy):
+        shutil.rmtree(os.path.join(work, "results"), ignore_errors=True)
+        torch.save(sd, ckpt, _use_new_zipfile_serialization=not legacy)
+        env = dict(os.environ, CUDA_VISIBLE_DEVICES="0", T2V_LEAN="1" if lean else "0")
+        r = subprocess.run(cmd, cwd=work, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        cs = json.load(open(os.path.join(work, "timing.json")))["cold_start"]
+        assert cs["torch_imported"] is (not lean), (lean, cs)
+        assert "carries a flow branch" in r.stdout          # the architecture followed the checkpoint
+        files = sorted(glob.glob(os.path.join(res, "*", "*.jpg")))
+        return {os.path.relpath(f, res): open(f, "rb").read() for f in files}
+
+    with_torch = run(False, False)
+    assert len(with_torch) == 16
+    assert run(True, False) == with_torch
+    assert run(True, True) == with_torch
+
+
 def test_resident_server_serves_the_one_shot_command(tmp_path):
     """test.py --resident: the command is a thin client of a server process that keeps the model on the GPU between calls
     (text2video_amd/resident.py).  Same command line, same files as the plain run, byte for byte; the second call reuses the

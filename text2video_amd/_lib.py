@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("T2V_LIBRARY") or os.path.join(_HERE, "lib", "libt2v_h
 T2V_OK = 0
 PAD_ZERO, PAD_REFLECT = 0, 1
 ACT_NONE, ACT_TANH, ACT_FLOW_W, ACT_LRELU = 0, 1, 2, 3
-ABI_VERSION = 13
+ABI_VERSION = 14
 MAX_BATCH = 8     # T2V_MAX_BATCH
 ALGO_DIRECT, ALGO_WINOGRAD, ALGO_WINOGRAD_F4 = 0, 1, 2
 
@@ -145,7 +145,22 @@ SIGNATURES = {
     "t2v_generator_workspace_bytes_batch": (c_size_t, [POINTER(GenDesc), c_int]),
     "t2v_generator_forward_batch": (c_int, [c_void_p, c_void_p, POINTER(GenDesc), POINTER(Layer), c_int, POINTER(GenIO),
                                             c_int, c_void_p, c_size_t]),
+    # host plumbing (ABI 14): what text2video_amd/leantorch.py allocates, copies and synchronises with
+    "t2v_device_malloc": (c_int, [c_void_p, c_size_t, POINTER(c_void_p)]),
+    "t2v_device_free": (c_int, [c_void_p, c_void_p]),
+    "t2v_host_malloc": (c_int, [c_void_p, c_size_t, POINTER(c_void_p)]),
+    "t2v_host_free": (c_int, [c_void_p, c_void_p]),
+    "t2v_memcpy": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int]),
+    "t2v_stream_create": (c_int, [c_void_p, POINTER(c_void_p)]),
+    "t2v_stream_destroy": (c_int, [c_void_p, c_void_p]),
+    "t2v_stream_synchronize": (c_int, [c_void_p, c_void_p]),
+    "t2v_event_create": (c_int, [c_void_p, POINTER(c_void_p)]),
+    "t2v_event_record": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "t2v_event_synchronize": (c_int, [c_void_p, c_void_p]),
+    "t2v_event_destroy": (c_int, [c_void_p, c_void_p]),
+    "t2v_device_synchronize": (c_int, [c_void_p]),
 }
+COPY_H2D, COPY_D2H, COPY_D2D = 1, 2, 3
 
 _lib = None
 
@@ -162,10 +177,14 @@ def load():
     # torch must initialise first: it bundles its own libamdhip64.so (same soname as /opt/rocm's).
     # Loaded in this order the one HIP runtime of the process is torch's and device pointers /
     # streams are shared; the other order would put two HIP runtimes in one process.
-    import torch  # noqa: F401
-    hip_rt = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
-    if os.path.exists(hip_rt):
-        ctypes.CDLL(hip_rt, mode=ctypes.RTLD_GLOBAL)
+    # (The torch-free frame loop of vid2vid/test.py -- _xp.LEAN -- never imports torch: the library then brings the
+    # ROCm installation's runtime in through its own RUNPATH.)
+    from ._xp import LEAN
+    if not LEAN:
+        import torch  # noqa: F401
+        hip_rt = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+        if os.path.exists(hip_rt):
+            ctypes.CDLL(hip_rt, mode=ctypes.RTLD_GLOBAL)
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported

@@ -1141,4 +1141,91 @@ int t2v_copy_channels(t2v_ctx* ctx, void* stream, const float* src, int src_cs, 
     return launch_copy_channels((hipStream_t)stream, src, src_cs, src_c0, dst, dst_cs, dst_c0, nc, npix);
 }
 
+// ---- host plumbing (ABI 14): buffers, copies, streams, events for a host without a HIP binding of its own ----
+int t2v_device_malloc(t2v_ctx* ctx, size_t bytes, void** out) {
+    T2V_REQUIRE(ctx && out, "device_malloc: null pointer");
+    T2V_HIP_CHECK(hipSetDevice(ctx->device));
+    *out = nullptr;
+    if (bytes == 0) return T2V_OK;
+    T2V_HIP_CHECK(hipMalloc(out, bytes));
+    return T2V_OK;
+}
+int t2v_device_free(t2v_ctx* ctx, void* ptr) {
+    T2V_REQUIRE(ctx, "device_free: null context");
+    if (!ptr) return T2V_OK;
+    T2V_HIP_CHECK(hipSetDevice(ctx->device));
+    T2V_HIP_CHECK(hipFree(ptr));
+    return T2V_OK;
+}
+int t2v_host_malloc(t2v_ctx* ctx, size_t bytes, void** out) {
+    T2V_REQUIRE(ctx && out && bytes > 0, "host_malloc: bad arguments");
+    T2V_HIP_CHECK(hipSetDevice(ctx->device));
+    T2V_HIP_CHECK(hipHostMalloc(out, bytes, hipHostMallocPortable));
+    return T2V_OK;
+}
+int t2v_host_free(t2v_ctx* ctx, void* ptr) {
+    T2V_REQUIRE(ctx, "host_free: null context");
+    if (!ptr) return T2V_OK;
+    T2V_HIP_CHECK(hipHostFree(ptr));
+    return T2V_OK;
+}
+int t2v_memcpy(t2v_ctx* ctx, void* stream, void* dst, const void* src, size_t bytes, int kind) {
+    T2V_REQUIRE(ctx && (bytes == 0 || (dst && src)), "memcpy: null pointer");
+    T2V_REQUIRE(kind == T2V_COPY_H2D || kind == T2V_COPY_D2H || kind == T2V_COPY_D2D, "memcpy: kind %d", kind);
+    if (bytes == 0) return T2V_OK;
+    T2V_HIP_CHECK(hipSetDevice(ctx->device));
+    hipMemcpyKind k = kind == T2V_COPY_H2D ? hipMemcpyHostToDevice
+                      : (kind == T2V_COPY_D2H ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice);
+    T2V_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, k, (hipStream_t)stream));
+    return T2V_OK;
+}
+int t2v_stream_create(t2v_ctx* ctx, void** out) {
+    T2V_REQUIRE(ctx && out, "stream_create: null pointer");
+    T2V_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t s = nullptr;
+    T2V_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *out = s;
+    return T2V_OK;
+}
+int t2v_stream_destroy(t2v_ctx* ctx, void* stream) {
+    T2V_REQUIRE(ctx, "stream_destroy: null context");
+    if (stream) T2V_HIP_CHECK(hipStreamDestroy((hipStream_t)stream));
+    return T2V_OK;
+}
+int t2v_stream_synchronize(t2v_ctx* ctx, void* stream) {
+    T2V_REQUIRE(ctx, "stream_synchronize: null context");
+    T2V_HIP_CHECK(hipSetDevice(ctx->device));
+    T2V_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    return T2V_OK;
+}
+int t2v_event_create(t2v_ctx* ctx, void** out) {
+    T2V_REQUIRE(ctx && out, "event_create: null pointer");
+    T2V_HIP_CHECK(hipSetDevice(ctx->device));
+    hipEvent_t e = nullptr;
+    T2V_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    *out = e;
+    return T2V_OK;
+}
+int t2v_event_record(t2v_ctx* ctx, void* event, void* stream) {
+    T2V_REQUIRE(ctx && event, "event_record: null pointer");
+    T2V_HIP_CHECK(hipEventRecord((hipEvent_t)event, (hipStream_t)stream));
+    return T2V_OK;
+}
+int t2v_event_synchronize(t2v_ctx* ctx, void* event) {
+    T2V_REQUIRE(ctx && event, "event_synchronize: null pointer");
+    T2V_HIP_CHECK(hipEventSynchronize((hipEvent_t)event));
+    return T2V_OK;
+}
+int t2v_event_destroy(t2v_ctx* ctx, void* event) {
+    T2V_REQUIRE(ctx, "event_destroy: null context");
+    if (event) T2V_HIP_CHECK(hipEventDestroy((hipEvent_t)event));
+    return T2V_OK;
+}
+int t2v_device_synchronize(t2v_ctx* ctx) {
+    T2V_REQUIRE(ctx, "device_synchronize: null context");
+    T2V_HIP_CHECK(hipSetDevice(ctx->device));
+    T2V_HIP_CHECK(hipDeviceSynchronize());
+    return T2V_OK;
+}
+
 }  // extern "C"

@@ -14,7 +14,7 @@ from dataclasses import dataclass
 import numpy as np
 import os
 
-import torch
+from ._xp import torch     # the real torch, or leantorch under vid2vid/test.py's torch-free frame loop
 
 from . import _lib, ops
 from ._lib import GenDesc, GenIO, Layer, check

@@ -57,12 +57,38 @@ def _minpack():
     loop's own process rasterises nothing when the worker pool does (SciPy costs ~0.2 s of its start-up)."""
     global _MINPACK
     if _MINPACK is False:
-        try:
-            from scipy.optimize import _minpack as m
-            _MINPACK = m
-        except ImportError:      # pragma: no cover -- SciPy layouts without the private module: curve_fit itself
-            _MINPACK = None
+        _MINPACK = _load_minpack_extension()
+        if _MINPACK is None:
+            try:
+                from scipy.optimize import _minpack as m
+                _MINPACK = m
+            except ImportError:      # pragma: no cover -- SciPy layouts without the private module: curve_fit itself
+                _MINPACK = None
     return _MINPACK
+
+
+def _load_minpack_extension():
+    """scipy/optimize/_minpack.*.so loaded by file, without `import scipy.optimize`: the extension needs libm only, while the
+    package import around it costs 0.2-0.35 s -- per rasteriser worker, on the critical path of the one-shot command now
+    that the frame loop's process starts without torch (the workers' first maps were what the loop waited for).  The same
+    shared object, so the same bits.  None where SciPy is laid out differently (the caller then imports the package)."""
+    try:
+        import importlib.machinery
+        import importlib.util
+        import os
+        spec = importlib.util.find_spec("scipy")
+        if spec is None or not spec.origin:
+            return None
+        d = os.path.join(os.path.dirname(spec.origin), "optimize")
+        for f in sorted(os.listdir(d)):
+            if f.startswith("_minpack.") and f.endswith((".so", ".pyd")):
+                loader = importlib.machinery.ExtensionFileLoader("_minpack", os.path.join(d, f))
+                m = importlib.util.module_from_spec(importlib.util.spec_from_loader("_minpack", loader))
+                loader.exec_module(m)
+                return m if hasattr(m, "_lmdif") else None
+    except Exception:      # noqa: BLE001 -- any surprise: the package import is the fallback
+        return None
+    return None
 
 
 def _fit_line(u, v, exact_fit):

@@ -10,7 +10,7 @@ import sys
 import time
 
 import numpy as np
-import torch
+from ._xp import torch     # the real torch, or leantorch under vid2vid/test.py's torch-free frame loop
 
 from . import ops
 from .generator import GeneratorSpec, HipGenerator, Vid2VidModelG, synthetic_state_dict
@@ -29,6 +29,11 @@ def generator_specs(opt):
             n_blocks=opt.n_blocks if s == 0 else opt.n_blocks_local, no_flow=opt.no_flow, norm=opt.norm,
             is_local=s > 0, scale=s))
     return specs
+
+
+class LeanUnsupported(RuntimeError):
+    """the torch-free frame loop (text2video_amd/_xp.py) met something only torch can do; vid2vid/test.py re-runs the
+    command with torch"""
 
 
 def process_start_time():
@@ -52,6 +57,11 @@ def load_checkpoint(path):
         sd = torch.load(path, map_location="cpu", weights_only=True, mmap=True)
     except (RuntimeError, ValueError, TypeError):     # legacy (non-zip) stream: cannot be mapped
         sd = torch.load(path, map_location="cpu", weights_only=True)
+    except Exception as e:      # noqa: BLE001
+        from . import _xp
+        if _xp.LEAN:           # a container leantorch.load does not read: vid2vid/test.py starts over with torch
+            raise LeanUnsupported("%s: %s" % (path, e)) from e
+        raise
     if isinstance(sd, dict) and "state_dict" in sd:
         sd = sd["state_dict"]
     out = {}
@@ -309,6 +319,7 @@ def run_test(opt, model=None, device=None, dataset=None):
              "fps_loop": n / (t_end - counters["t_loop0"]) if n else 0.0, "results_dir": vis.save_dir, "videos": videos,
              "cold_start": dict({k: (round(v, 4) if isinstance(v, float) else v) for k, v in marks.items()},
                                 pack_s=round(sum(getattr(net, "pack_seconds", 0.0) for net in model.nets), 4),
+                                torch_imported="torch" in sys.modules,
                                 mux_s=round(t_end - t_start - marks["to_last_jpeg_s"], 4))}
     if opt.timing_json:
         with open(opt.timing_json, "w") as fh:

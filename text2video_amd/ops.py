@@ -8,7 +8,7 @@ allocator / stream provider; every computation below is a call through the C ABI
 """
 import ctypes
 
-import torch
+from ._xp import torch     # the real torch, or leantorch under vid2vid/test.py's torch-free frame loop
 
 from . import _lib
 from ._lib import (ACT_FLOW_W, ACT_LRELU, ACT_NONE, ACT_TANH, ALGO_DIRECT, ALGO_WINOGRAD,  # noqa: F401

@@ -11,6 +11,8 @@ libt2v_hip.so; there is no CPU fallback.  `--gpu_ids a,b,...` with more than one
 (whole sequences per rank; --shard_chunks also cuts sequences), started by this script itself or by torchrun.
 `--resident` (or T2V_RESIDENT=1 in the environment of an unchanged text2video_audio.sh): the command becomes a thin client of
 a server process that keeps the weights on the GPU between utterances (text2video_amd/resident.py); `--resident_stop` ends it.
+A plain single-device run never imports torch: the frame loop takes its device buffers, stream and events from the
+library's own host-plumbing entry points (text2video_amd/_xp.py, leantorch.py; T2V_LEAN=0 keeps torch).
 """
 import os
 import sys
@@ -31,7 +33,14 @@ if __name__ == "__main__":
             sys.stderr.flush()
             os._exit(_rc)
 
-from text2video_amd.model import run_test      # noqa: E402
+    # a plain single-device run: the frame loop without torch (the reference starts this script once per utterance, and
+    # `import torch` was the largest term of its start-up)
+    if not _multi and "WORLD_SIZE" not in os.environ and os.environ.get("T2V_LEAN", "1") != "0" \
+            and not any(a in ("--shard_chunks", "--chunks_per_rank", "--stitch_frames", "--stitch_rounds") for a in _args):
+        from text2video_amd import _xp
+        _xp.use_lean()
+
+from text2video_amd.model import LeanUnsupported, run_test      # noqa: E402
 from text2video_amd.options import TestOptions  # noqa: E402
 
 if __name__ == "__main__":
@@ -40,7 +49,15 @@ if __name__ == "__main__":
     # the sequences are dealt to the ranks (run_test), every rank writes its own frames
     from text2video_amd import launch          # noqa: E402
     launch.fan_out_if_needed(len(opt.gpu_ids), opt.gpu_ids)
-    stats = run_test(opt)
+    try:
+        stats = run_test(opt)
+    except LeanUnsupported as e:       # e.g. a checkpoint container leantorch.load does not read: start over with torch
+        print("note: %s -- running with torch" % e, file=sys.stderr)
+        from text2video_amd import raster_pool     # noqa: E402
+        raster_pool._close_all()
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os.execve(sys.executable, [sys.executable] + sys.argv, dict(os.environ, T2V_LEAN="0"))
     print("done: %d frames, %.2f fps in the frame loop -> %s" % (stats["frames"], stats["fps_loop"],
                                                                 stats["results_dir"]))
     # The reference starts this script once per utterance (text2video_audio.sh:37-44): everything is on disk now, so the
