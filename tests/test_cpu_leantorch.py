@@ -152,6 +152,10 @@ def test_tensor_round_trips_and_free_list(fake):
     assert len(fake.live) < live + 1
     with pytest.raises(TypeError):
         d.numpy()
+    # non_blocking uploads of small pageable arrays go through a ring of page-locked staging buffers (one event per slot)
+    ups = [lt.from_numpy(np.full((5, 7, 3), i, np.uint8)).to(dev, non_blocking=True) for i in range(2 * lt.STAGING_SLOTS + 1)]
+    assert all(np.array_equal(u.cpu().numpy(), np.full((5, 7, 3), i, np.uint8)) for i, u in enumerate(ups))
+    assert len(lt._dev(0).staging) == lt.STAGING_SLOTS and fake.events >= lt.STAGING_SLOTS
 
 
 def test_events_streams_and_decorator(fake):

@@ -185,6 +185,14 @@ def load():
         hip_rt = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
         if os.path.exists(hip_rt):
             ctypes.CDLL(hip_rt, mode=ctypes.RTLD_GLOBAL)
+    elif os.environ.get("T2V_HIP_RUNTIME", "torch") != "system":
+        # torch-free process, same HIP runtime: the copy PyTorch bundles (located without importing torch) -- the one every
+        # measurement and test of this tree ran on; T2V_HIP_RUNTIME=system takes the ROCm installation's instead
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        hip_rt = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so") if spec and spec.origin else ""
+        if os.path.exists(hip_rt):
+            ctypes.CDLL(hip_rt, mode=ctypes.RTLD_GLOBAL)
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported

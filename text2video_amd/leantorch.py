@@ -100,6 +100,39 @@ class _Device:
         self.free = collections.defaultdict(list)     # rounded size -> device pointers
         self.events = []
         self.lock = threading.Lock()
+        self.staging = []          # ring of [pinned ptr, bytes, event, in flight?] for small pageable uploads
+        self.staging_next = 0
+
+    def upload_staged(self, dst_ptr, src_ptr, nbytes):
+        """H2D of a small pageable array through a ring of page-locked buffers.  The runtime's own pageable path returns
+        only when ITS copy has run -- behind everything the stream still holds -- so a frame loop that uploads the next pose
+        map while the previous frame computes would stop running ahead of the GPU (measured on the MI355X box: 1.77 s
+        instead of 1.25 s for the 170-frame utterance).  A slot is reused after its own copy's event."""
+        i = self.staging_next % STAGING_SLOTS
+        self.staging_next += 1
+        if i >= len(self.staging):
+            self.staging.append([None, 0, None, False])
+        slot = self.staging[i]
+        if slot[3]:
+            check(self.lib.t2v_event_synchronize(self.ctx.handle, ctypes.c_void_p(slot[2])), "event_synchronize")
+            slot[3] = False
+        if slot[1] < nbytes:
+            if slot[0]:
+                self.lib.t2v_host_free(self.ctx.handle, ctypes.c_void_p(slot[0]))
+            p = ctypes.c_void_p()
+            size = max(1 << 20, (nbytes + 4095) // 4096 * 4096)
+            check(self.lib.t2v_host_malloc(self.ctx.handle, size, ctypes.byref(p)), "host_malloc")
+            slot[0], slot[1] = p.value, size
+        if slot[2] is None:
+            h = ctypes.c_void_p()
+            check(self.lib.t2v_event_create(self.ctx.handle, ctypes.byref(h)), "event_create")
+            slot[2] = h.value
+        ctypes.memmove(slot[0], src_ptr, nbytes)
+        s = ctypes.c_void_p(self.stream.cuda_stream)
+        check(self.lib.t2v_memcpy(self.ctx.handle, s, ctypes.c_void_p(dst_ptr), ctypes.c_void_p(slot[0]), nbytes, _lib.COPY_H2D),
+              "memcpy h2d")
+        check(self.lib.t2v_event_record(self.ctx.handle, ctypes.c_void_p(slot[2]), s), "event_record")
+        slot[3] = True
 
     def malloc(self, nbytes):
         size = max(256, (nbytes + 255) // 256 * 256)
@@ -126,6 +159,9 @@ class _Device:
         for p in blocks:
             self.lib.t2v_device_free(self.ctx.handle, ctypes.c_void_p(p))
 
+
+STAGING_SLOTS = 8
+STAGING_MAX_BYTES = 8 << 20     # non_blocking uploads up to this size are staged; everything else takes the runtime's own path
 
 _devices = {}
 _current = [0]
@@ -352,6 +388,9 @@ class Tensor:
             return src
         out = empty(src.shape, dtype=src.dtype, device=dev)
         d = out._dev
+        if non_blocking and src._where == "cpu" and 0 < src.nbytes() <= STAGING_MAX_BYTES:
+            d.upload_staged(out._ptr, src.data_ptr(), src.nbytes())
+            return out
         check(d.lib.t2v_memcpy(d.ctx.handle, ctypes.c_void_p(d.stream.cuda_stream), ctypes.c_void_p(out._ptr),
                                ctypes.c_void_p(src.data_ptr()), src.nbytes(), _lib.COPY_H2D), "memcpy h2d")
         out._keep = src          # (a page-locked source is read asynchronously; a pageable one is staged before the call returns)

@@ -194,6 +194,9 @@ def run_test(opt, model=None, device=None, dataset=None):
     cs = ops.round_up(3 * opt.n_frames_G, 4)
     pinned = {}      # shape -> ring of 3 pinned host buffers (allocating pinned memory per frame costs ~0.2 ms)
     counters = {"n": 0, "t_loop0": 0.0}
+    # where the host spends the loop: waiting for the next step's pose maps (rasteriser), uploading them, enqueueing the
+    # generator / tensor2im / D2H, and waiting for the previous step's frames (the GPU) + handing them to the JPEG threads
+    split = marks.setdefault("loop_split", {"wait_pose_s": 0.0, "upload_s": 0.0, "enqueue_s": 0.0, "finish_s": 0.0})
     tails = {}       # unit index -> FIFO of generated frames the unit ended with (stitch pass)
 
     class Lane:
@@ -218,7 +221,15 @@ def run_test(opt, model=None, device=None, dataset=None):
             if L.unit is not None and L.rec.prev is not None:
                 tails[L.unit] = L.rec.prev[0].clone()
 
-        for step in steps:
+        steps = iter(steps)
+        while True:
+            tq = time.perf_counter()
+            try:
+                step = next(steps)       # (the rasteriser pool is ahead of the loop, or the loop waits here)
+            except StopIteration:
+                break
+            split["wait_pose_s"] += time.perf_counter() - tq
+            tq = time.perf_counter()
             groups = {}      # frame geometry -> [(lane object, item)]
             for k, data in step:
                 if counters["n"] == 0 and not groups:
@@ -240,29 +251,42 @@ def run_test(opt, model=None, device=None, dataset=None):
                 for f in range(opt.n_frames_G):
                     ops.pose_u8_to_f32(L.dev_maps[f], L.window, 3 * f)
                 groups.setdefault((H, W), []).append((k, L, data))
+            split["upload_s"] += time.perf_counter() - tq
+            tq = time.perf_counter()
             now = []
             for (gh, gw), members in groups.items():
                 if len(members) > 1 and not model.lockstep_pays(gh, gw):      # (same frames either way: one call per sequence)
                     outs = [model.inference_nhwc_batch([L.window], [L.rec])[0] for _, L, _ in members]
                 else:
                     outs = model.inference_nhwc_batch([L.window for _, L, _ in members], [L.rec for _, L, _ in members])
+                split["generator_s"] = split.get("generator_s", 0.0) + time.perf_counter() - tq
                 for (k, L, data), out in zip(members, outs):
+                    t1 = time.perf_counter()
                     u8 = ops.tensor2im_u8(out)
-                    ring = pinned.setdefault((k,) + tuple(u8.shape),
-                                             [[torch.empty(u8.shape, dtype=torch.uint8, pin_memory=True) for _ in range(3)], 0])
+                    ring = pinned.get((k,) + tuple(u8.shape))
+                    if ring is None:      # (not setdefault: its default would allocate three pinned buffers per frame)
+                        ring = pinned[(k,) + tuple(u8.shape)] = \
+                            [[torch.empty(u8.shape, dtype=torch.uint8, pin_memory=True) for _ in range(3)], 0]
                     host = ring[0][ring[1] % 3]     # the buffer of this lane's frame n-3: its JPEG copy was taken in finish(n-3)
                     ring[1] += 1
+                    t2 = time.perf_counter()
                     host.copy_(u8, non_blocking=True)
+                    t3 = time.perf_counter()
                     ev = torch.cuda.Event()
                     ev.record()
+                    split["tensor2im_s"] = split.get("tensor2im_s", 0.0) + t2 - t1
+                    split["d2h_s"] = split.get("d2h_s", 0.0) + t3 - t2
                     now.append((ev, host, data["A_path"], _real_A_u8(data["A"][-1])))
                     print("process image... %s" % data["A_path"])
                     counters["n"] += 1
+            split["enqueue_s"] += time.perf_counter() - tq
             if "first_step_s" not in marks:       # incl. the weight pack / Winograd filter transforms of this geometry
                 torch.cuda.synchronize(dev)
                 marks["first_step_s"] = time.perf_counter() - counters["t_loop0"]
+            tq = time.perf_counter()
             for p in pending:
                 finish(p)
+            split["finish_s"] += time.perf_counter() - tq
             pending = now
         for p in pending:
             finish(p)
@@ -317,7 +341,8 @@ def run_test(opt, model=None, device=None, dataset=None):
     n = counters["n"]
     stats = {"frames": n_first_pass, "frames_regenerated": n - n_first_pass, "seconds_total": t_end - t_start,
              "fps_loop": n / (t_end - counters["t_loop0"]) if n else 0.0, "results_dir": vis.save_dir, "videos": videos,
-             "cold_start": dict({k: (round(v, 4) if isinstance(v, float) else v) for k, v in marks.items()},
+             "cold_start": dict({k: (round(v, 4) if isinstance(v, float) else
+                                     ({kk: round(vv, 4) for kk, vv in v.items()} if isinstance(v, dict) else v)) for k, v in marks.items()},
                                 pack_s=round(sum(getattr(net, "pack_seconds", 0.0) for net in model.nets), 4),
                                 torch_imported="torch" in sys.modules,
                                 mux_s=round(t_end - t_start - marks["to_last_jpeg_s"], 4))}
