@@ -108,6 +108,7 @@ class _FakePlumbing:
         return 0
 
     t2v_event_record = t2v_event_synchronize = t2v_device_synchronize = t2v_stream_synchronize
+    t2v_stream_destroy = t2v_event_destroy = t2v_stream_synchronize
 
 
 @pytest.fixture
@@ -156,6 +157,33 @@ def test_tensor_round_trips_and_free_list(fake):
     ups = [lt.from_numpy(np.full((5, 7, 3), i, np.uint8)).to(dev, non_blocking=True) for i in range(2 * lt.STAGING_SLOTS + 1)]
     assert all(np.array_equal(u.cpu().numpy(), np.full((5, 7, 3), i, np.uint8)) for i, u in enumerate(ups))
     assert len(lt._dev(0).staging) == lt.STAGING_SLOTS and fake.events >= lt.STAGING_SLOTS
+
+
+@pytest.mark.parametrize("legacy", [False, True], ids=["zip", "legacy-0.4.1-stream"])
+def test_checkpoint_goes_up_as_one_file_span(fake, monkeypatch, tmp_path, legacy):
+    """upload_many: the tensors load() mapped from one file are read by several threads into page-locked chunks (os.preadv)
+    and become views of one device slab; what does not qualify (a legacy stream's unaligned storages, other dtypes) takes
+    .to(device).  Same values either way."""
+    monkeypatch.setattr(lt, "UPLOAD_CHUNK", 4096)
+    monkeypatch.setattr(lt, "UPLOAD_MIN_SPAN", 1024)
+    g = torch.Generator().manual_seed(3)
+    sd = collections.OrderedDict(("layer%d.weight" % i, torch.randn(7 + i, 5, 3, 3, generator=g)) for i in range(12))
+    sd["layer3.bias"] = torch.randn(9, generator=g)
+    path = str(tmp_path / "net.pth")
+    torch.save(sd, path, _use_new_zipfile_serialization=not legacy)
+    host = {k: v.float() for k, v in lt.load(path).items()}
+    up = lt.upload_many(host, "cuda:0")
+    assert list(up) == list(host)
+    for k, v in sd.items():
+        assert up[k].is_cuda and up[k].shape == tuple(v.shape) and np.array_equal(up[k].cpu().numpy(), v.numpy()), k
+    views = [t for t in up.values() if t._base is not None]
+    if legacy:      # storages of a legacy stream start 8 bytes after anything: not 16-byte aligned as a rule
+        assert len(views) < len(up)
+    else:
+        assert len(views) == len(up) and len({id(t._base) for t in views}) == 1
+        assert any(kind == 1 and n == 4096 for kind, n in fake.copies)        # chunked, H2D
+    w = lt.cat([up["layer0.weight"], up["layer0.weight"]], 0)       # (views work as kernel / copy operands)
+    assert np.array_equal(w.cpu().numpy()[:7], sd["layer0.weight"].numpy())
 
 
 def test_events_streams_and_decorator(fake):

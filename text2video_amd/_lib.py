@@ -163,10 +163,18 @@ SIGNATURES = {
 COPY_H2D, COPY_D2H, COPY_D2D = 1, 2, 3
 
 _lib = None
+_load_lock = __import__("threading").RLock()
 
 
 def load():
     """Load libt2v_hip.so and bind every declared symbol.  Raises if anything is missing."""
+    if _lib is not None:
+        return _lib
+    with _load_lock:      # (vid2vid/test.py brings the runtime up on a thread while the main thread still imports)
+        return _load_locked()
+
+
+def _load_locked():
     global _lib
     if _lib is not None:
         return _lib

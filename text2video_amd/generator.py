@@ -163,6 +163,8 @@ def upload_tensors(tensors, device):
     scripts/upload_register_probe.py) moves the time instead of saving it: 0.22-0.25 s to register 1.46 GB + 0.034 s of copies
     at 43 GB/s = the plain copy's 0.28-0.30 s.)"""
     dev = torch.device(device)
+    if hasattr(torch, "upload_many"):      # leantorch: a checkpoint's tensors go up as one file span, read by several threads
+        return torch.upload_many(tensors, dev)
     return {k: v.detach().to(dev, torch.float32).contiguous() for k, v in tensors.items()}
 
 

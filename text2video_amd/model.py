@@ -101,6 +101,8 @@ def create_model(opt, device="cuda:0", marks=None):
         nets.append(HipGenerator(spec, device).load_state_dict(sd))
         torch.cuda.synchronize(device)
         marks["weights_to_device_s"] = marks.get("weights_to_device_s", 0.0) + time.perf_counter() - t0
+        if getattr(torch, "LAST_UPLOAD", None):
+            marks["upload"] = dict(torch.LAST_UPLOAD)
     return Vid2VidModelG(nets, opt.n_frames_G, opt.output_nc, opt.no_first_img)
 
 
@@ -342,7 +344,8 @@ def run_test(opt, model=None, device=None, dataset=None):
     stats = {"frames": n_first_pass, "frames_regenerated": n - n_first_pass, "seconds_total": t_end - t_start,
              "fps_loop": n / (t_end - counters["t_loop0"]) if n else 0.0, "results_dir": vis.save_dir, "videos": videos,
              "cold_start": dict({k: (round(v, 4) if isinstance(v, float) else
-                                     ({kk: round(vv, 4) for kk, vv in v.items()} if isinstance(v, dict) else v)) for k, v in marks.items()},
+                                     ({kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()} if isinstance(v, dict) else v))
+                                for k, v in marks.items()},
                                 pack_s=round(sum(getattr(net, "pack_seconds", 0.0) for net in model.nets), 4),
                                 torch_imported="torch" in sys.modules,
                                 mux_s=round(t_end - t_start - marks["to_last_jpeg_s"], 4))}

@@ -65,7 +65,7 @@ if __name__ == "__main__":
     # tear-down (0.26 s of a 3.3 s run on the MI355X box) is skipped.
     if int(os.environ.get("WORLD_SIZE", "1")) == 1:      # (ranks of a multi-GPU run leave through the normal tear-down)
         from text2video_amd import raster_pool     # noqa: E402
-        raster_pool._close_all()
+        raster_pool._close_all(kill=True)
         sys.stdout.flush()
         sys.stderr.flush()
         os._exit(0)
