@@ -124,6 +124,12 @@ size_t t2v_conv_stats_floats(const t2v_conv_desc* d);
 int t2v_conv2d_forward(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, const float* x, int x_cs,
                        const float* w_packed, const float* bias, float* y, int y_cs,
                        float* stats_partial);
+/* The same for `batch` images in ONE launch (ABI 14; direct algorithm): x = [batch][H][W][x_cs], y = [batch][Hout][Wout][y_cs],
+ * image b's statistics partials at stats_partial + b * t2v_conv_stats_floats(d).  Every image's result is the single-image
+ * call's, bit for bit.  (SpatialConvolutionMM_updateOutput loops over the batch with one GEMM per image, THCUNN.h:664; here the
+ * images share a launch because the discriminators' layers of the train step fill a fraction of the chip each.) */
+int t2v_conv2d_forward_batch(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, int batch, const float* x, int x_cs,
+                             const float* w_packed, const float* bias, float* y, int y_cs, float* stats_partial);
 
 /* Bit mask of the Winograd variants `d` (algo ignored) can run as: 1 = F(2x2,3x3), 2 = F(4x4,3x3).
  * Needs 3x3, stride 1, ReflectionPad 1 or zero padding 0..2 (pad 2: the data gradient of the pad-1 conv),

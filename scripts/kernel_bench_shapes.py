@@ -13,6 +13,19 @@ SHAPES = {
     "rb1024_320": (64, 40, 1024, 1024, 3, 1, 1, 1, False, True),
     "rb1024_680": (64, 85, 1024, 1024, 3, 1, 1, 1, False, True),
     "head3": (512, 512, 128, 3, 7, 1, 3, 1, False, False),
+    # the stride-2 / transposed layers at the reference's own geometries (fadg0: 512x320 cropped, 512x680 full width)
+    "down128_320": (512, 320, 128, 256, 3, 2, 1, 0, False, True),
+    "down256_320": (256, 160, 256, 512, 3, 2, 1, 0, False, True),
+    "down512_320": (128, 80, 512, 1024, 3, 2, 1, 0, False, True),
+    "up1024_320": (64, 40, 1024, 512, 3, 2, 1, 0, True, True),
+    "up512_320": (128, 80, 512, 256, 3, 2, 1, 0, True, True),
+    "up256_320": (256, 160, 256, 128, 3, 2, 1, 0, True, True),
+    "down128_680": (512, 680, 128, 256, 3, 2, 1, 0, False, True),
+    "down256_680": (256, 340, 256, 512, 3, 2, 1, 0, False, True),
+    "down512_680": (128, 170, 512, 1024, 3, 2, 1, 0, False, True),
+    "up1024_680": (64, 85, 1024, 512, 3, 2, 1, 0, True, True),
+    "up512_680": (128, 170, 512, 256, 3, 2, 1, 0, True, True),
+    "up256_680": (256, 340, 256, 128, 3, 2, 1, 0, True, True),
     # local enhancer of the two-scale 1024x1024 generator (ngf 64)
     "l_stem": (1024, 1024, 9, 64, 7, 1, 3, 1, False, True),
     "l_down": (1024, 1024, 64, 128, 3, 2, 1, 0, False, True),

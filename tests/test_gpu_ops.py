@@ -577,3 +577,44 @@ def test_one_block_per_cu_256x128_tiles_equal_tile_per_block(geom, t2v_env):
     for rep in range(8):
         y = ops.conv2d_winograd(xs[rep % 2], pu, b, desc, workspace=ws)
         assert torch.equal(y, want[rep % 2]), "launch %d: %d of %d outputs differ" % (rep, int((y != want[rep % 2]).sum()), y.numel())
+
+
+@pytest.mark.parametrize("case", [
+    # (H, W, Cin, Cout, k, stride, pad, pad_mode, transposed, stats, act, B)
+    ("d1 129x129 64->128 k4 s2 + stats", (129, 129, 64, 128, 4, 2, 2, 0, False, True, 0, 4)),
+    ("d3 33x33 256->512 k4 s1 + stats", (33, 33, 256, 512, 4, 1, 2, 0, False, True, 0, 3)),
+    ("d0 64x64 6->64 k4 s2 lrelu", (64, 64, 6, 64, 4, 2, 2, 0, False, False, 3, 4)),
+    ("dgrad of d2: convT k4 s2", (17, 17, 256, 128, 4, 2, 2, 0, True, False, 0, 2)),
+    ("one output channel (dedicated kernel, image by image)", (20, 20, 512, 1, 4, 1, 2, 0, False, False, 0, 3)),
+    ("7x7 head (dedicated kernel, image by image)", (32, 32, 64, 3, 7, 1, 3, 1, False, False, 1, 2)),
+    ("7x7 stem + stats (dedicated kernel, image by image)", (32, 32, 9, 64, 7, 1, 3, 1, False, True, 0, 2)),
+], ids=lambda c: c[0] if isinstance(c, tuple) and isinstance(c[0], str) else None)
+def test_batched_direct_conv_equals_the_single_image_launches(case):
+    """t2v_conv2d_forward_batch (ABI 14): B images as blockIdx.y of one implicit-GEMM launch -- what the train step's
+    discriminator layers and their data gradients use.  Every image's output and statistics partials are the
+    single-image call's, bit for bit."""
+    from text2video_amd import ops
+    _, (H, W, Cin, Cout, k, st, pad, pm, tr, stats, act, B) = case
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(11)
+    desc = ops.conv_desc(H, W, Cin, Cout, k, st, pad, pm, tr, act, 0.2, output_padding=(0 if (tr and k == 4) else None))
+    xcs = ops.round_up(Cin, 4)
+    x = torch.zeros(B, H, W, xcs)
+    x[..., :Cin] = torch.randn(B, H, W, Cin, generator=g)
+    x = x.to(dev)
+    w = (torch.randn(*((Cin, Cout, k, k) if tr else (Cout, Cin, k, k)), generator=g) * 0.05).to(dev)
+    b = torch.randn(Cout, generator=g).to(dev)
+    pw = ops.pack_conv_weight(w, desc, xcs)
+    ycs = ops.round_up(Cout, 4)
+    n = ops.conv_stats_buffer(desc, dev).numel() if stats else 0
+    s_one = torch.zeros(B * n, device=dev) if stats else None
+    y_one = torch.stack([ops.conv2d(x[i], pw, b, desc, y_cs=ycs, stats=s_one[i * n:(i + 1) * n] if stats else None) for i in range(B)])
+    s_all = torch.full((B * n,), float("nan"), device=dev) if stats else None
+    y_all = torch.full_like(y_one, float("nan"))
+    ops.conv2d_batch(x, pw, b, desc, y_cs=ycs, stats=s_all, out=y_all)
+    assert torch.equal(y_all, y_one)
+    if stats:
+        assert torch.equal(s_all, s_one)
+    # and the dispatcher the trainer calls
+    y_auto = ops.conv2d_auto_batch(x, pw, b, desc, y_cs=ycs, stats=torch.empty_like(s_all) if stats else None)
+    assert torch.equal(y_auto, y_one)

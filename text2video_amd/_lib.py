@@ -65,6 +65,8 @@ SIGNATURES = {
     "t2v_conv_stats_floats": (c_size_t, [POINTER(ConvDesc)]),
     "t2v_conv2d_forward": (c_int, [c_void_p, c_void_p, POINTER(ConvDesc), c_void_p, c_int, c_void_p, c_void_p,
                                    c_void_p, c_int, c_void_p]),
+    "t2v_conv2d_forward_batch": (c_int, [c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_void_p, c_int, c_void_p, c_void_p,
+                                         c_void_p, c_int, c_void_p]),
     "t2v_conv_winograd_supported": (c_int, [POINTER(ConvDesc), c_int]),
     "t2v_conv_best_algo": (c_int, [POINTER(ConvDesc), c_int, c_int]),
     "t2v_conv_winograd_workspace_floats": (c_size_t, [POINTER(ConvDesc), c_int]),

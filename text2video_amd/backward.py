@@ -60,6 +60,15 @@ class ConvDataGrad:
                                            adjoint=self.kind == "flip")
         return self
 
+    def batch(self, dy, out):
+        """dy: [B, Hout, Wout, cs] -> out [B, H, W, round_up4(Cin)]: one launch for a direct-algorithm gradient conv"""
+        if not self.fold:
+            return ops.conv2d_auto_batch(dy, self.packed, None, self.desc, out=out)
+        dxp = ops.conv2d_auto_batch(dy, self.packed, None, self.desc)
+        for i in range(dy.shape[0]):
+            ops.reflect_pad_backward(dxp[i], self.fold, out=out[i])
+        return out
+
     def __call__(self, dy, out=None):
         """dy: [Hout, Wout, cs>=Cout] -> dX [H, W, round_up4(Cin)] (written into `out` if given)."""
         if not self.fold:

@@ -331,9 +331,14 @@ int build_winograd_gemm_plan(const t2v_conv_desc* d, ConvPlan* pl, int nimg) {
     return T2V_OK;
 }
 
-int run_conv(t2v_ctx* ctx, hipStream_t s, const ConvPlan& pl, const float* x, const float* w, const float* bias,
-             float* y, int y_cs, float* stats) {
+// `batch` images in one go (image b at x + b * x_stride, y + b * y_stride, statistics at stats + b * stats_stride, floats):
+// the implicit-GEMM kernel takes them as blockIdx.y of ONE launch -- the discriminators' layers of the train step are 67-552
+// blocks per image, a fraction of the 1024+ block slots of the chip; the dedicated stem / head / one-channel kernels are
+// launched image by image.
+int run_conv_batch(t2v_ctx* ctx, hipStream_t s, const ConvPlan& pl, int batch, const float* x, long x_stride, const float* w,
+                   const float* bias, float* y, int y_cs, long y_stride, float* stats, long stats_stride) {
     T2V_REQUIRE(ctx && x && w && y, "conv: null pointer");
+    T2V_REQUIRE(batch >= 1 && batch <= 65535, "conv: batch %d", batch);
     T2V_REQUIRE(y_cs >= pl.kp.Cout && y_cs <= pl.Cout_p, "conv: output channel storage %d out of range [%d,%d]", y_cs,
                 pl.kp.Cout, pl.Cout_p);
     T2V_REQUIRE((long)pl.Hout * pl.Wout * y_cs * 4 < 0x7fff0000L, "conv: output tensor too large for 32-bit buffer offsets");
@@ -343,11 +348,14 @@ int run_conv(t2v_ctx* ctx, hipStream_t s, const ConvPlan& pl, const float* x, co
         const ConvKParams& q = pl.kp;
         if (use_head && !stats && q.nphases == 1 && q.ph[0].ntaps == 49 && q.KW == 7 && q.pad == 3 && q.stride == 1 &&
             q.pad_mode == T2V_PAD_REFLECT && q.Cout <= 3 && q.Cin_s % 16 == 0 && q.Hin >= 4 && q.Win >= 4) {
-            HeadParams h;
-            h.x = x; h.w = w; h.bias = bias; h.y = y;
-            h.H = q.Hin; h.W = q.Win; h.Cin_s = q.Cin_s; h.Kp = q.ph[0].Kp; h.Cout = q.Cout; h.Cout_s = y_cs;
-            h.act = q.act; h.act_scale = q.act_scale;
-            return launch_conv_head7x7(s, h);
+            for (int b = 0; b < batch; ++b) {
+                HeadParams h;
+                h.x = x + b * x_stride; h.w = w; h.bias = bias; h.y = y + b * y_stride;
+                h.H = q.Hin; h.W = q.Win; h.Cin_s = q.Cin_s; h.Kp = q.ph[0].Kp; h.Cout = q.Cout; h.Cout_s = y_cs;
+                h.act = q.act; h.act_scale = q.act_scale;
+                T2V_TRY(launch_conv_head7x7(s, h));
+            }
+            return T2V_OK;
         }
     }
     {
@@ -357,19 +365,25 @@ int run_conv(t2v_ctx* ctx, hipStream_t s, const ConvPlan& pl, const float* x, co
         if (use_c1 && !stats && q.nphases == 1 && q.Cout == 1 && q.pad_mode == T2V_PAD_ZERO && q.ostride == 1 &&
             q.ph[0].ntaps == q.KW * q.KW && conv_cout1_supported(q.KW, q.Cin_s) &&
             (q.act == T2V_ACT_NONE || q.act == T2V_ACT_LRELU)) {
-            Cout1Params c;
-            c.x = x; c.w = w; c.bias = bias; c.y = y;
-            c.H = q.Hin; c.W = q.Win; c.Cin_s = q.Cin_s; c.ksize = q.KW; c.stride = q.stride; c.pad = q.pad;
-            c.Hout = pl.Hout; c.Wout = pl.Wout; c.Cout_s = y_cs; c.act = q.act; c.act_scale = q.act_scale;
-            return launch_conv_cout1(s, c);
+            for (int b = 0; b < batch; ++b) {
+                Cout1Params c;
+                c.x = x + b * x_stride; c.w = w; c.bias = bias; c.y = y + b * y_stride;
+                c.H = q.Hin; c.W = q.Win; c.Cin_s = q.Cin_s; c.ksize = q.KW; c.stride = q.stride; c.pad = q.pad;
+                c.Hout = pl.Hout; c.Wout = pl.Wout; c.Cout_s = y_cs; c.act = q.act; c.act_scale = q.act_scale;
+                T2V_TRY(launch_conv_cout1(s, c));
+            }
+            return T2V_OK;
         }
     }
     if (pl.tile == kTileStem && stats) {
-        StemParams sp;
-        sp.x = x; sp.w = w; sp.bias = bias; sp.y = y; sp.stats = stats;
-        sp.H = pl.kp.Hin; sp.W = pl.kp.Win; sp.Cin_s = pl.kp.Cin_s; sp.Kp = pl.kp.ph[0].Kp; sp.Cout = pl.kp.Cout; sp.Cout_s = y_cs;
-        sp.Cin = pl.Cin;
-        return launch_conv_stem7x7(s, sp);
+        for (int b = 0; b < batch; ++b) {
+            StemParams sp;
+            sp.x = x + b * x_stride; sp.w = w; sp.bias = bias; sp.y = y + b * y_stride; sp.stats = stats + b * stats_stride;
+            sp.H = pl.kp.Hin; sp.W = pl.kp.Win; sp.Cin_s = pl.kp.Cin_s; sp.Kp = pl.kp.ph[0].Kp; sp.Cout = pl.kp.Cout; sp.Cout_s = y_cs;
+            sp.Cin = pl.Cin;
+            T2V_TRY(launch_conv_stem7x7(s, sp));
+        }
+        return T2V_OK;
     }
     T2V_REQUIRE(pl.tile != kTileStem, "conv: the stem plan needs a statistics buffer");
     ConvKParams k = pl.kp;
@@ -379,7 +393,16 @@ int run_conv(t2v_ctx* ctx, hipStream_t s, const ConvPlan& pl, const float* x, co
     k.y = y;
     k.Cout_s = y_cs;
     k.stats = stats;
+    k.batch = batch;
+    k.x_img_stride = batch > 1 ? x_stride : 0;
+    k.y_img_stride = batch > 1 ? y_stride : 0;
+    k.stats_img_stride = (batch > 1 && stats) ? stats_stride : 0;
     return launch_conv_igemm(s, k, pl.tile);
+}
+
+int run_conv(t2v_ctx* ctx, hipStream_t s, const ConvPlan& pl, const float* x, const float* w, const float* bias,
+             float* y, int y_cs, float* stats) {
+    return run_conv_batch(ctx, s, pl, 1, x, 0, w, bias, y, y_cs, 0, stats, 0);
 }
 
 // all of a Winograd conv (shared with the generator orchestrator): stages bit 1 = input transform,
@@ -595,6 +618,16 @@ int t2v_conv2d_forward(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, const
     ConvPlan pl;
     T2V_TRY(build_conv_plan(d, x_cs, stats_partial != nullptr, &pl));
     return run_conv(ctx, (hipStream_t)stream, pl, x, w_packed, bias, y, y_cs, stats_partial);
+}
+
+int t2v_conv2d_forward_batch(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, int batch, const float* x, int x_cs,
+                             const float* w_packed, const float* bias, float* y, int y_cs, float* stats_partial) {
+    T2V_REQUIRE(d && d->algo == T2V_ALGO_DIRECT, "conv2d_forward_batch: direct convolutions only");
+    T2V_REQUIRE(batch >= 1, "conv2d_forward_batch: batch %d", batch);
+    ConvPlan pl;
+    T2V_TRY(build_conv_plan(d, x_cs, stats_partial != nullptr, &pl));
+    return run_conv_batch(ctx, (hipStream_t)stream, pl, batch, x, (long)d->H * d->W * x_cs, w_packed, bias, y, y_cs,
+                          (long)pl.Hout * pl.Wout * y_cs, stats_partial, (long)t2v_conv_stats_floats(d));
 }
 
 int t2v_instance_norm_finalize(t2v_ctx* ctx, void* stream, const t2v_conv_desc* producer, const float* stats_partial,

@@ -189,6 +189,10 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(const ConvKParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // 0..7
     const bool is_loader = wave >= 4;
     const int wid = wave & 3;  // MFMA wave id / loader share id
+    // image of a batched launch (blockIdx.y; 0 and zero strides otherwise)
+    const float* __restrict__ xg = p.x + (size_t)blockIdx.y * p.x_img_stride;
+    float* __restrict__ yg = p.y + (size_t)blockIdx.y * p.y_img_stride;
+    float* __restrict__ sg = p.stats + (size_t)blockIdx.y * p.stats_img_stride;
 
     // ---- block -> (phase, tile).  Blocks dispatch in blockIdx order and block b runs on XCD b%8.
     // Phases (sub-pixel phases of a transposed conv, heaviest first) follow blockIdx order, which is
@@ -262,7 +266,7 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(const ConvKParams p) {
         if constexpr (MODE == 0) {
             const int cpt = p.Cin_s >> 5;
             const int c0 = (kt - cur_tap * cpt) << 5;  // set_tap(kt / cpt) was called for this stage
-            dma16(p.x, x_bytes, dst, a_voff[i], c0 * 4);
+            dma16(xg, x_bytes, dst, a_voff[i], c0 * 4);
         } else {
             // general path (Cin_s = 8 / 12 stems, narrow test nets): each 16-B chunk has its own tap
             const int k = kt * kBK + a_coff[i];
@@ -278,7 +282,7 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(const ConvKParams p) {
                 dy = p.tdy[ph.tap0 + tap];
                 dx = p.tdx[ph.tap0 + tap];
             }
-            dma16(p.x, x_bytes, dst, pix_off(i, dy, dx, c, kin && a_ok[i]), 0);
+            dma16(xg, x_bytes, dst, pix_off(i, dy, dx, c, kin && a_ok[i]), 0);
         }
     };
     // B-operand (packed weights [Cout_p][Kp]) DMA instruction `instr` (of BN/8 per block)
@@ -409,7 +413,7 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(const ConvKParams p) {
                     mean_b[j] = tot * inv_cnt;
                 } else if (wm == 0 && g == 0 && col[j] < p.Cout) {
                     const size_t part = (size_t)phase * p.mtiles + mt;
-                    float2* dst = reinterpret_cast<float2*>(p.stats) + part * p.Cout + col[j];
+                    float2* dst = reinterpret_cast<float2*>(sg) + part * p.Cout + col[j];
                     *dst = make_float2(mean_b[j], tot);
                 }
             }
@@ -423,7 +427,7 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(const ConvKParams p) {
     // 8 % of a 36-stage block and up to a third of the transposed convs' 8-stage phase blocks.  Now: m / Wm by one
     // multiply-high (exact for m < 2^20 and Wm < 2^20), buffer stores off one SRD (out-of-range lanes are dropped by the
     // hardware), the activation chosen once per tile.
-    const __amdgpu_buffer_rsrc_t ysrd = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.Hout * p.Wout * p.Cout_s * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ysrd = __builtin_amdgcn_make_buffer_rsrc(yg, 0, p.Hout * p.Wout * p.Cout_s * 4, 0x00020000);
     constexpr int kDrop = 0x7fffff00;      // >= the record count of any output map (checked on the host: < 2 GiB)
     const bool fastdiv = p.M <= (1 << 20);
     const unsigned long long magic = (1ull << 40) / (unsigned)p.Wm + 1;
@@ -1250,7 +1254,7 @@ static int launch_ring(hipStream_t s, const ConvKParams& p) {
         attr_done = true;
     }
     const int nblocks = p.mtiles * p.ntiles * p.nphases;
-    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(512), LDS_BYTES, s, p);
+    hipLaunchKernelGGL(kern, dim3(nblocks, p.batch > 1 ? p.batch : 1), dim3(512), LDS_BYTES, s, p);
     T2V_HIP_CHECK(hipGetLastError());
     return T2V_OK;
 }
@@ -1259,7 +1263,7 @@ template <class Cfg, int MODE, bool STATS, bool REFLECT>
 static int launch_pad(hipStream_t s, const ConvKParams& p) {
     // >= 4 blocks per CU queued: let two blocks share the CU (64 KiB ring each); measured on MI355X:
     // 2048-block stem 0.40 vs 0.47 ms, 1024-block layers 0.33 vs 0.345 ms, <= 512 blocks favour RING 3
-    const long nblocks = (long)p.mtiles * p.ntiles * p.nphases;
+    const long nblocks = (long)p.mtiles * p.ntiles * p.nphases * (p.batch > 1 ? p.batch : 1);
     const int force = options().conv_ring;
     // (swept per layer shape with scripts/kernel_bench.py: single-phase launches like two co-resident blocks from 512
     // blocks on; 64x64 tiles of a multi-phase launch prefer the deeper ring.  Round 4: also between 257 and 511 blocks -- one

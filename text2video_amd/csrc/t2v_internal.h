@@ -124,6 +124,10 @@ struct ConvKParams {
     int group_mtiles;     // M tiles per weight group (Winograd: one weight matrix per transform position)
     long group_w_stride;  // float offset between the groups' weight matrices (0: a single matrix)
     int KW, pad;  // MODE 1 (Cin_s % 32 != 0, regular conv): tap -> (kh,kw) by arithmetic
+    // images per launch (blockIdx.y; the discriminators' batches of the train step): image b reads x + b * x_img_stride,
+    // writes y + b * y_img_stride and its statistics partials at stats + b * stats_img_stride (floats; batch <= 1: unused)
+    int batch;
+    long x_img_stride, y_img_stride, stats_img_stride;
     ConvPhase ph[kMaxPhases];
     int tdy[kMaxTaps];  // ints: read with scalar loads (uniform index), never a vector load
     int tdx[kMaxTaps];

@@ -187,6 +187,42 @@ def conv2d(x, packed_w, bias, desc, y_cs=None, stats=None, out=None):
     return y
 
 
+def conv2d_batch(x, packed_w, bias, desc, y_cs=None, stats=None, out=None):
+    """conv2d for a batch x: [B,H,W,x_cs] in ONE launch (direct algorithm) -> y [B,Hout,Wout,y_cs]; `stats` holds B
+    consecutive per-image partial blocks (conv_stats_buffer(desc).numel() floats each).  Every image's result is
+    conv2d's, bit for bit."""
+    c = context()
+    _chk(x, "x")
+    B, x_cs = x.shape[0], x.shape[-1]
+    ho, wo = conv_out_dims(desc)
+    y_cs = round_up(desc.Cout, 4) if y_cs is None else y_cs
+    y = out if out is not None else torch.empty(B, ho, wo, y_cs, dtype=torch.float32, device=x.device)
+    if out is not None:
+        _chk(out, "out")
+    check(c.lib.t2v_conv2d_forward_batch(c.handle, _stream(), ctypes.byref(desc), B, _p(x), x_cs, _p(packed_w), _p(bias),
+                                         _p(y), y_cs, _p(stats)), "conv2d_forward_batch")
+    return y
+
+
+def conv2d_auto_batch(x, packed_w, bias, desc, y_cs=None, stats=None, out=None):
+    """conv2d_auto over a batch [B,...]: one launch for the direct algorithm (T2V_CONV_BATCH=0: image by image), image by
+    image for the Winograd forms (their batches go through the generator's own batched path).  stats: B consecutive blocks."""
+    B = x.shape[0]
+    if out is None:
+        ho, wo = conv_out_dims(desc)
+        out = torch.empty(B, ho, wo, round_up(desc.Cout, 4) if y_cs is None else y_cs, dtype=torch.float32, device=x.device)
+    if desc.algo == ALGO_DIRECT and B > 1 and _CONV_BATCH[0] and x.is_contiguous() and out.is_contiguous() and \
+            (stats is None or stats.is_contiguous()):
+        return conv2d_batch(x, packed_w, bias, desc, y_cs=y_cs, stats=stats, out=out)
+    n = stats.numel() // B if stats is not None else 0
+    for i in range(B):
+        conv2d_auto(x[i], packed_w, bias, desc, y_cs=y_cs, stats=stats[i * n:(i + 1) * n] if stats is not None else None, out=out[i])
+    return out
+
+
+_CONV_BATCH = [__import__("os").environ.get("T2V_CONV_BATCH", "1") != "0"]
+
+
 def instance_norm_finalize(stats, desc, eps=1e-5, out=None, running=None):
     """running = (running_mean, running_var, momentum, times): BatchNorm2d(train)'s running statistics (a batch of one) are
     moved `times` times by these statistics in the same launch (t2v_batch_norm_finalize_running)."""

@@ -369,15 +369,14 @@ class _ConvBlock(torch.autograd.Function):
         pw = cached_pack(w, ("fwd",) + _desc_key(fdesc, xcs), lambda: ops.pack_conv_weight(w.detach().contiguous(), fdesc, xcs))
         c = torch.empty(B, ho, wo, ycs, dtype=torch.float32, device=dev)
         mrs = None
+        # (a batch of a direct-algorithm layer -- the discriminators' -- is ONE launch: ops.conv2d_auto_batch)
         if norm is None:
-            for i in range(B):
-                ops.conv2d_auto(x[i], pw, b.detach(), fdesc, y_cs=ycs, out=c[i])
+            ops.conv2d_auto_batch(x, pw, b.detach(), fdesc, y_cs=ycs, out=c)
             y = c
         else:
             n = ops.conv_stats_buffer(fdesc, dev).numel()
             stats = torch.empty(B * n, dtype=torch.float32, device=dev)
-            for i in range(B):
-                ops.conv2d_auto(x[i], pw, b.detach(), fdesc, y_cs=ycs, stats=stats[i * n:(i + 1) * n], out=c[i])
+            ops.conv2d_auto_batch(x, pw, b.detach(), fdesc, y_cs=ycs, stats=stats, out=c)
             y = torch.empty_like(c)
             g = gamma.detach() if gamma is not None else None
             bt = beta.detach() if beta is not None else None
@@ -523,8 +522,7 @@ class _ConvBlock(torch.autograd.Function):
             dg.packed = cached_pack(w, ("dgrad",) + _desc_key(fdesc, x.shape[-1]), lambda: dg.refresh(w.detach()).packed)
             if ops.round_up(fdesc.Cin, 4) == x.shape[-1]:
                 dx = torch.empty_like(x)
-                for i in range(B):
-                    dg(dc[i], out=dx[i])
+                dg.batch(dc, dx)
             else:   # x carries more channel storage than the layer reads: zero gradient there
                 dx = torch.zeros_like(x)
                 dx[..., :ops.round_up(fdesc.Cin, 4)] = torch.stack([dg(dc[i]) for i in range(B)])
