@@ -149,6 +149,11 @@ def model_key(opt):
 
 def serve(path, idle_s):
     import contextlib
+    # the server's frame loop needs torch as little as the one-shot command's (text2video_amd/_xp.py): without it the call
+    # that starts the server is ~1 s shorter and the resident process ~1 GB of host memory smaller (T2V_LEAN=0 keeps torch)
+    if os.environ.get("T2V_LEAN", "1") != "0":
+        from text2video_amd import _xp
+        _xp.use_lean()
     from text2video_amd.model import create_model, run_test
     from text2video_amd.options import TestOptions
     try:
@@ -202,6 +207,8 @@ def serve(path, idle_s):
                             model = models.get(key)
                             if model is None:
                                 models.clear()                      # one set of weights resident at a time
+                                model = None
+                                ops.torch.cuda.empty_cache()        # (either provider: the old weights' blocks go back to the driver)
                                 model = models[key] = create_model(opt, device)
                             stats = run_test(opt, model=model, device=device)
                             print("done: %d frames, %.2f fps in the frame loop -> %s (resident server, pid %d)"

@@ -23,8 +23,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 if __name__ == "__main__":
     _args = sys.argv[1:]
     _multi = any(a == "--gpu_ids" and i + 1 < len(_args) and "," in _args[i + 1].strip(",") for i, a in enumerate(_args))
+    # (chunked / stitched runs go through text2video_amd/distributed.py, i.e. through torch: neither the torch-free loop nor
+    # the resident server -- itself torch-free -- takes them)
+    _chunked = any(a in ("--shard_chunks", "--chunks_per_rank", "--stitch_frames", "--stitch_rounds") for a in _args)
     if ("--resident" in _args or "--resident_stop" in _args or os.environ.get("T2V_RESIDENT") == "1") and not _multi \
-            and "WORLD_SIZE" not in os.environ:
+            and "WORLD_SIZE" not in os.environ and not _chunked:
         # thin client of the resident server (text2video_amd/resident.py): no torch import, no checkpoint load in this process
         from text2video_amd import resident
         _rc = resident.client(_args)
@@ -35,8 +38,7 @@ if __name__ == "__main__":
 
     # a plain single-device run: the frame loop without torch (the reference starts this script once per utterance, and
     # `import torch` was the largest term of its start-up)
-    if not _multi and "WORLD_SIZE" not in os.environ and os.environ.get("T2V_LEAN", "1") != "0" \
-            and not any(a in ("--shard_chunks", "--chunks_per_rank", "--stitch_frames", "--stitch_rounds") for a in _args):
+    if not _multi and "WORLD_SIZE" not in os.environ and os.environ.get("T2V_LEAN", "1") != "0" and not _chunked:
         from text2video_amd import _xp
         _xp.use_lean()
 
