@@ -177,11 +177,12 @@ def test_checkpoint_goes_up_as_one_file_span(fake, monkeypatch, tmp_path, legacy
     for k, v in sd.items():
         assert up[k].is_cuda and up[k].shape == tuple(v.shape) and np.array_equal(up[k].cpu().numpy(), v.numpy()), k
     views = [t for t in up.values() if t._base is not None]
-    if legacy:      # storages of a legacy stream start 8 bytes after anything: not 16-byte aligned as a rule
-        assert len(views) < len(up)
+    assert len(views) == len(up) and len({id(t._base) for t in views}) == 1
+    assert lt.LAST_UPLOAD["mirrored"] is (not legacy) and "error" not in lt.LAST_UPLOAD
+    if legacy:      # an 8-byte count sits in front of every storage: each tensor gets an aligned place of its own
+        assert all(t.data_ptr() % 256 == views[0]._base.data_ptr() % 256 for t in views)
     else:
-        assert len(views) == len(up) and len({id(t._base) for t in views}) == 1
-        assert any(kind == 1 and n == 4096 for kind, n in fake.copies)        # chunked, H2D
+        assert any(kind == 1 and n == 4096 for kind, n in fake.copies)        # mirrored chunk by chunk
     w = lt.cat([up["layer0.weight"], up["layer0.weight"]], 0)       # (views work as kernel / copy operands)
     assert np.array_equal(w.cpu().numpy()[:7], sd["layer0.weight"].numpy())
 

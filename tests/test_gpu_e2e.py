@@ -85,11 +85,15 @@ def test_lean_command_writes_the_same_files(tmp_path):
     def run(lean, legacy):
         shutil.rmtree(os.path.join(work, "results"), ignore_errors=True)
         torch.save(sd, ckpt, _use_new_zipfile_serialization=not legacy)
-        env = dict(os.environ, CUDA_VISIBLE_DEVICES="0", T2V_LEAN="1" if lean else "0")
+        # (T2V_UPLOAD_MIN_SPAN: this small net's checkpoint also goes up as one file span, as the 1.46 GB one does)
+        env = dict(os.environ, CUDA_VISIBLE_DEVICES="0", T2V_LEAN="1" if lean else "0", T2V_UPLOAD_MIN_SPAN=str(1 << 20))
         r = subprocess.run(cmd, cwd=work, env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         cs = json.load(open(os.path.join(work, "timing.json")))["cold_start"]
         assert cs["torch_imported"] is (not lean), (lean, cs)
+        if lean:      # zip records are mirrored chunk by chunk, a legacy stream's tensors placed one by one; no fallback
+            up = cs["upload"]
+            assert up["mirrored"] is (not legacy) and up["as_views"] == up["tensors"] > 0 and "error" not in up, up
         assert "carries a flow branch" in r.stdout          # the architecture followed the checkpoint
         files = sorted(glob.glob(os.path.join(res, "*", "*.jpg")))
         return {os.path.relpath(f, res): open(f, "rb").read() for f in files}

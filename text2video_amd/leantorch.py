@@ -502,7 +502,8 @@ def cat(tensors, dim=0):
 
 UPLOAD_THREADS = 4
 UPLOAD_CHUNK = 8 << 20
-UPLOAD_MIN_SPAN = 64 << 20      # smaller state dicts are not worth the threads and the pinned buffers
+# smaller state dicts are not worth the threads and the pinned buffers (T2V_UPLOAD_MIN_SPAN: bytes; tests lower it)
+UPLOAD_MIN_SPAN = int(__import__("os").environ.get("T2V_UPLOAD_MIN_SPAN", 64 << 20))
 LAST_UPLOAD = {}                # what the last upload_many did (vid2vid/test.py --timing_json reports it)
 
 
@@ -512,29 +513,42 @@ def upload_many(tensors, dev):
     os.preadv straight into page-locked chunk buffers (the kernel copies out of the page cache; no page of the mapping is
     touched) and sent from there on the threads' own streams into one device slab, of which the tensors are views.  The
     runtime's pageable copy of the mapped tensors -- what `.to(device)` does -- runs at ~6 GB/s on the MI355X box (0.24 s),
-    bound by faulting the mapping's pages in on one thread.  Anything else (other dtypes, unaligned legacy streams, small
-    dicts) takes `.to(device)`.  Host-synchronous: the data is on the device when this returns."""
+    bound by faulting the mapping's pages in on one thread.  Both containers: the zip archive's aligned records are mirrored
+    chunk by chunk, the tensors of a legacy stream (an 8-byte count in front of every storage) are sent piece by piece to
+    aligned places of their own.  Anything else (other dtypes, small dicts) takes `.to(device)`.  Host-synchronous: the data is on the device when this returns."""
     import os
     dev = device(dev)
     out = {}
     cand = {}
     for k, t in tensors.items():
         f = getattr(t, "_file", None)
-        if isinstance(t, Tensor) and t._where == "cpu" and t.dtype is float32 and f is not None and f[1] % 16 == 0 and t.nbytes():
+        if isinstance(t, Tensor) and t._where == "cpu" and t.dtype is float32 and f is not None and t.nbytes():
             cand.setdefault(f[0], []).append((k, t, f[1]))
     for path, items in cand.items():
-        lo = min(off for _, _, off in items) // 256 * 256
+        items.sort(key=lambda it: it[2])
+        lo = items[0][2] // 256 * 256
         hi = max(off + t.nbytes() for _, t, off in items)
         total = sum(t.nbytes() for _, t, _ in items)
         if hi - lo < UPLOAD_MIN_SPAN or hi - lo > 1.25 * total + (1 << 20):
             continue
+        if all(off % 16 == 0 for _, _, off in items):
+            # (the zip container aligns its records to 64 bytes) the device slab mirrors the file span: one copy per chunk
+            pieces, place, slab_bytes = None, [off - lo for _, _, off in items], hi - lo
+        else:
+            # (the legacy stream puts an 8-byte count in front of every storage) every tensor gets its own 256-byte-aligned
+            # place in the slab; a chunk is sent as the pieces of the tensors it holds
+            place, slab_bytes = [], 0
+            for _, t, _ in items:
+                place.append(slab_bytes)
+                slab_bytes += (t.nbytes() + 255) // 256 * 256
+            pieces = [(off, t.nbytes(), d_off) for (_, t, off), d_off in zip(items, place)]
         try:
-            slab = _upload_file_span(path, lo, hi, dev)
+            slab = _upload_file_span(path, lo, hi, dev, pieces, slab_bytes)
         except Exception as e:       # noqa: BLE001 -- e.g. no pinned memory to be had: the plain path below
             LAST_UPLOAD["error"] = "%s: %s" % (type(e).__name__, e)
             continue
-        for k, t, off in items:
-            v = Tensor(t.shape, float32, "cuda", ptr=slab._ptr + (off - lo), size=0, dev=slab._dev)
+        for (k, t, _), d_off in zip(items, place):
+            v = Tensor(t.shape, float32, "cuda", ptr=slab._ptr + d_off, size=0, dev=slab._dev)
             v._base = slab
             out[k] = v
     LAST_UPLOAD["as_views"] = len(out)
@@ -542,16 +556,21 @@ def upload_many(tensors, dev):
         if k not in out:
             out[k] = t.detach().to(dev, float32).contiguous()
     LAST_UPLOAD["tensors"] = len(out)
-    return out
+    return {k: out[k] for k in tensors}
 
 
-def _upload_file_span(path, lo, hi, dev):
+def _upload_file_span(path, lo, hi, dev, pieces, slab_bytes):
+    """file bytes [lo, hi) -> a device slab.  pieces None: the slab mirrors the span.  Else pieces = sorted (file offset,
+    bytes, slab offset): only those ranges are sent, each to its place."""
+    import bisect
     import os
     import time
     t0 = time.perf_counter()
     d = _dev(dev.index)
-    slab = empty(hi - lo, dtype=uint8, device=dev)
-    LAST_UPLOAD.update(span_bytes=hi - lo, slab_alloc_s=round(time.perf_counter() - t0, 4))
+    slab = empty(slab_bytes, dtype=uint8, device=dev)
+    starts = [f for f, _, _ in pieces] if pieces is not None else None
+    LAST_UPLOAD.update(span_bytes=hi - lo, slab_bytes=slab_bytes, mirrored=pieces is None,
+                       slab_alloc_s=round(time.perf_counter() - t0, 4))
     nchunks = (hi - lo + UPLOAD_CHUNK - 1) // UPLOAD_CHUNK
     nthreads = max(1, min(UPLOAD_THREADS, nchunks, os.cpu_count() or 1))
     errors = []
@@ -583,7 +602,17 @@ def _upload_file_span(path, lo, hi, dev):
                     if r <= 0:
                         raise IOError("leantorch.upload_many: short read of %s" % path)
                     got += r
-                check(lib.t2v_memcpy(ctx, stream, ctypes.c_void_p(slab._ptr + c * UPLOAD_CHUNK), sl[0], n, _lib.COPY_H2D), "memcpy h2d")
+                if pieces is None:
+                    check(lib.t2v_memcpy(ctx, stream, ctypes.c_void_p(slab._ptr + c * UPLOAD_CHUNK), sl[0], n, _lib.COPY_H2D), "memcpy h2d")
+                else:       # the tensors (or parts of tensors) this chunk [off, off + n) holds
+                    i = max(0, bisect.bisect_right(starts, off) - 1)
+                    while i < len(pieces) and pieces[i][0] < off + n:
+                        f0, fn, d0 = pieces[i]
+                        a, b = max(off, f0), min(off + n, f0 + fn)
+                        if b > a:
+                            check(lib.t2v_memcpy(ctx, stream, ctypes.c_void_p(slab._ptr + d0 + (a - f0)),
+                                                 ctypes.c_void_p(sl[0].value + (a - off)), b - a, _lib.COPY_H2D), "memcpy h2d")
+                        i += 1
                 check(lib.t2v_event_record(ctx, sl[1], stream), "event_record")
                 sl[2] = True
             check(lib.t2v_stream_synchronize(ctx, stream), "stream_synchronize")
