@@ -10,16 +10,17 @@ and feed the pose dataset directly; frames, names and results layout are those o
 relative to it; default "."); checkpoints / results resolve relative to the working directory exactly as
 for test.py, so run it from ../vid2vid with `--l2_root ../Text2Video`.
 """
+import os
 import sys
 
 from . import l2_driver
-from .model import run_test
 from .options import TestOptions
 from .pose_dataset import PoseDataset
 
 
 def text_to_frames(text, person, opt, root=".", spec=l2_driver.PHONEME, model=None, device="cuda:0"):
     """-> run_test()'s stats dict; frames are written by the Visualizer as test.py would."""
+    from .model import run_test      # (here, not at import: main() chooses the torch-free provider first)
     raw, smooth = l2_driver.synthesize(text, person, root, spec)
     dataset = PoseDataset.from_memory(opt, {"tmp": raw, "tmp_smooth": smooth},
                                       size=l2_driver.canvas_size(spec, person))
@@ -44,7 +45,13 @@ def main(argv=None):
                 "--resize_or_crop", "scaleHeight", "--loadSize", "512", "--openpose_only", "--how_many", "1200",
                 "--no_first_img", "--random_drop_prob", "0"]                      # [REF text2video_audio.sh:42]
     opt = TestOptions().parse(defaults + rest)
-    stats = text_to_frames(text, person, opt, root=root, spec=spec)
+    # one process, one device: the frame loop without torch, as vid2vid/test.py runs it (text2video_amd/_xp.py)
+    if len(opt.gpu_ids) <= 1 and "WORLD_SIZE" not in os.environ and os.environ.get("T2V_LEAN", "1") != "0" and \
+            not getattr(opt, "shard_chunks", False):
+        from . import _xp
+        _xp.use_lean()
+    stats = text_to_frames(text, person, opt, root=root, spec=spec,
+                           device="cuda:%d" % (opt.gpu_ids[0] if opt.gpu_ids else 0))
     print("%d frames, %.1f frames/s -> %s" % (stats["frames"], stats["fps_loop"], stats["results_dir"]))
 
 
