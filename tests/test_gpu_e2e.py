@@ -357,7 +357,13 @@ def test_bench_contract_line():
     # the one-shot command as the reference starts it (a process per utterance), timed from outside, with its own split
     cs = d["e2e"]["cold_start"]
     assert cs["frames"] == 170 and len(cs["wall_s"]) == 2 and cs["wall_s"][-1] > cs["split_of_last_run"]["loop_s"] > 0
-    assert {"checkpoint_read_s", "weights_to_device_s", "pack_s", "first_step_s", "to_last_jpeg_s"} <= set(cs["split_of_last_run"])
+    sp = cs["split_of_last_run"]
+    assert {"process_to_run_test_s", "weights_to_device_s", "first_step_s", "loop_s", "to_last_jpeg_s", "loop_split"} <= set(sp)
+    # the plain command runs without torch (text2video_amd/leantorch.py), its checkpoint goes up as one file span; the same
+    # command with torch is timed beside it
+    assert sp["torch_imported"] is False and sp["upload"]["mirrored"] is True and sp["upload"]["threads"] >= 1
+    assert set(sp["loop_split"]) == {"wait_pose_s", "upload_s", "enqueue_s", "finish_s"}
+    assert cs["with_torch"]["wall_s"] > 0 and cs["with_torch"]["loop_s"] > 0
     assert cs["resident"]["warm_call_wall_s"] < cs["wall_s"][-1] and cs["resident"]["warm_loop_s"] > 0
     # BASELINE configs[3]: 1024x1024 frames, single-scale and two-scale generator, both variants, + the GEMM stage at that size
     hi = d["hires"]
