@@ -59,5 +59,8 @@ int winograd_forward(t2v_ctx* ctx, hipStream_t s, const t2v_conv_desc* d, const 
                      const WinoBatch* batch = nullptr);
 int run_conv(t2v_ctx* ctx, hipStream_t s, const ConvPlan& pl, const float* x, const float* w, const float* bias,
              float* y, int y_cs, float* stats);
+// `batch` images a constant stride apart in one implicit-GEMM launch (blockIdx.y); strides in floats
+int run_conv_batch(t2v_ctx* ctx, hipStream_t s, const ConvPlan& pl, int batch, const float* x, long x_stride, const float* w,
+                   const float* bias, float* y, int y_cs, long y_stride, float* stats, long stats_stride);
 
 }  // namespace t2v

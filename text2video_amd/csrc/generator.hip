@@ -232,7 +232,11 @@ struct Runner {
             T2V_TRY(launch_inorm_finalize(s, stats, pl.nparts, pl.kp.mtiles, pl.BM, pl.kp.M, Cout, g.eps, mr, fin_of(im)));
         return launch_inorm_apply(s, y, mr, gam, bet, res1, res2, y, (long)pl.Hout * pl.Wout, Cout, relu);
     }
-    // the next layer for every image of the batch (one launch sequence per image)
+    // the next layer for every image of the batch (one launch sequence per image).  (The images of a lock-step batch as
+    // blockIdx.y of ONE launch of the stride-2 / transposed convs -- run_conv_batch, what the train step's discriminators
+    // use -- was measured here and dropped: 142.1 / 141.9 vs 142.1 / 141.7 fps for two 512x320 sequences, 67.0 / 66.7 vs
+    // 66.8 / 66.7 at 512x680, 92.0 / 92.0 vs 91.8 / 91.7 at 512x512, alternating runs: inside two-stream frames the other
+    // stream already fills what a 2.5-blocks-per-CU launch leaves idle.)
     int conv_norm(const Ptrs& x, const MutPtrs& y, int relu, const Ptrs& res1) {
         for (int im = 0; im < nimg; ++im) T2V_TRY(conv_norm_one(li, im, x.p[im], y.p[im], relu, res1.p[im], nullptr));
         ++li;
