@@ -539,7 +539,7 @@ def run_e2e(model_head, model_other, head_flow, n_frames):
     return dict({"path": "run_test == vid2vid/test.py: rasterise (bit-exact) -> H2D -> generator -> D2H -> JPEG", "runs": out}, **meta)
 
 
-def cold_start_block(n_maps=87):
+def cold_start_block(n_maps=87, ab_envs=None, ab_reps=3):
     """The reference starts one process per utterance (text2video_audio.sh:37-44: `cd ../vid2vid; python test.py ...`): the
     wall time of exactly that command on the configs[0] utterance -- two sequences (tmp, tmp_smooth) of 87 pose maps = 2 x 85
     frames, 512x384 sources -> scaleHeight 512 + central crop = 512x320, full-size generator with its flow branch read from a
@@ -585,6 +585,20 @@ def cold_start_block(n_maps=87):
             if r.returncode != 0:
                 return {"error": r.stderr[-400:]}
             split = json.load(open(tj))
+        ab = None
+        if ab_envs:       # same-box A/B of environment variants of the plain command (scripts/; not part of the bench line)
+            ab = {name: [] for name in ab_envs}
+            for _ in range(ab_reps):
+                for name, extra in ab_envs.items():
+                    shutil.rmtree(os.path.join(tmp, "results"), ignore_errors=True)
+                    t0 = time.perf_counter()
+                    r = subprocess.run(cmd, cwd=os.path.join(ROOT, "vid2vid"), env=dict(env, **extra), stdout=subprocess.DEVNULL,
+                                       stderr=subprocess.PIPE, text=True)
+                    w = round(time.perf_counter() - t0, 3)
+                    c = json.load(open(tj))["cold_start"] if r.returncode == 0 else {}
+                    ab[name].append({"wall_s": w, "loop_s": c.get("loop_s"), "create_model_s": c.get("create_model_s"),
+                                     "first_step_s": c.get("first_step_s")})
+            return {"ab": ab}
         cs = split["cold_start"]
         # (the line stays short -- the driver keeps a bounded tail of stdout: the full split is in --timing_json)
         for k in ("dataset_scan_s", "checkpoint_read_s", "pack_s", "mux_s"):
