@@ -231,3 +231,27 @@ def test_provider_choice_is_per_process():
             "print('torch ok')\n" % ROOT)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=180)
     assert r.returncode == 0 and "torch ok" in r.stdout, r.stderr[-2000:]
+
+
+def test_unreadable_checkpoint_raises_lean_unsupported(tmp_path):
+    """a state dict the torch-free reader refuses (anything but tensors) surfaces as model.LeanUnsupported in the lean
+    process -- vid2vid/test.py then starts the command over with torch; a readable one comes back as fp32 host tensors with
+    upstream's `module.` prefix and BatchNorm running statistics dropped"""
+    bad = str(tmp_path / "bad.pth")
+    torch.save({"model.0.weight": torch.zeros(2, 2), "fn": os.path.join}, bad)
+    good = str(tmp_path / "good.pth")
+    torch.save({"module.model.0.weight": torch.ones(2, 3).half(), "module.model.1.running_mean": torch.zeros(3)}, good)
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from text2video_amd import _xp\n"
+            "assert _xp.use_lean()\n"
+            "from text2video_amd import model\n"
+            "sd = model.load_checkpoint(%r)\n"
+            "assert list(sd) == ['model.0.weight'] and sd['model.0.weight'].dtype is model.torch.float32, sd\n"
+            "assert sd['model.0.weight'].numpy().tolist() == [[1.0] * 3] * 2\n"
+            "try:\n"
+            "    model.load_checkpoint(%r)\n"
+            "except model.LeanUnsupported as e:\n"
+            "    print('lean unsupported:', e)\n"
+            "assert 'torch' not in sys.modules\n" % (ROOT, good, bad))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "lean unsupported:" in r.stdout and "refusing global" in r.stdout, r.stdout + r.stderr[-2000:]
