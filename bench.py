@@ -539,7 +539,7 @@ def run_e2e(model_head, model_other, head_flow, n_frames):
     return dict({"path": "run_test == vid2vid/test.py: rasterise (bit-exact) -> H2D -> generator -> D2H -> JPEG", "runs": out}, **meta)
 
 
-def cold_start_block(n_maps=87, ab_envs=None, ab_reps=3):
+def cold_start_block(n_maps=87, ab_envs=None, ab_reps=3, wrap=None):
     """The reference starts one process per utterance (text2video_audio.sh:37-44: `cd ../vid2vid; python test.py ...`): the
     wall time of exactly that command on the configs[0] utterance -- two sequences (tmp, tmp_smooth) of 87 pose maps = 2 x 85
     frames, 512x384 sources -> scaleHeight 512 + central crop = 512x320, full-size generator with its flow branch read from a
@@ -585,6 +585,11 @@ def cold_start_block(n_maps=87, ab_envs=None, ab_reps=3):
             if r.returncode != 0:
                 return {"error": r.stderr[-400:]}
             split = json.load(open(tj))
+        if wrap:          # the command under a wrapper (e.g. rocprofv3 --kernel-trace --stats -d DIR --): scripts/, not the bench line
+            shutil.rmtree(os.path.join(tmp, "results"), ignore_errors=True)
+            r = subprocess.run(list(wrap) + cmd, cwd=os.path.join(ROOT, "vid2vid"), env=dict(env, T2V_NO_FAST_EXIT="1"), stdout=subprocess.DEVNULL,
+                               stderr=subprocess.PIPE, text=True)
+            return {"wrapped_rc": r.returncode, "stderr_tail": r.stderr[-300:], "cold_start": json.load(open(tj))["cold_start"]}
         ab = None
         if ab_envs:       # same-box A/B of environment variants of the plain command (scripts/; not part of the bench line)
             ab = {name: [] for name in ab_envs}

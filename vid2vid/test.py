@@ -65,7 +65,9 @@ if __name__ == "__main__":
     # The reference starts this script once per utterance (text2video_audio.sh:37-44): everything is on disk now, so the
     # process ends here -- the rasteriser workers are closed, the streams flushed, and the interpreter / HIP runtime
     # tear-down (0.26 s of a 3.3 s run on the MI355X box) is skipped.
-    if int(os.environ.get("WORLD_SIZE", "1")) == 1:      # (ranks of a multi-GPU run leave through the normal tear-down)
+    # (ranks of a multi-GPU run leave through the normal tear-down; so does a run under a profiler that writes its output at
+    # exit: T2V_NO_FAST_EXIT=1)
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and os.environ.get("T2V_NO_FAST_EXIT") != "1":
         from text2video_amd import raster_pool     # noqa: E402
         raster_pool._close_all(kill=True)
         sys.stdout.flush()
