@@ -446,10 +446,12 @@ def train_block(dev, dist_mod, world, rank, backend, steps, iters, ngf=128):
                                               ("up 1024->512 convT 3x3 s2 @64x64", (64, 64, 1024, 512, 2, True))):
             d = ops.conv_desc(h, w, ci, co, 3, st, 1, ops.PAD_ZERO, tr_)
             ho, wo = ops.conv_out_dims(d)
-            x, dy = torch.randn(1, h, w, ci, device=dev), torch.randn(1, ho, wo, co, device=dev)
-            ms = ev_time(lambda: ops.conv2d_backward_weight(x, dy, d))
-            gf = 2.0 * 9 * ci * co * (h * w if tr_ else ho * wo) / 1e9
-            kernels.append({"kernel": "conv_wgrad_kernel: " + name,
+            # as the step launches it: the clip's two frames from buffers of their own in ONE launch (train._paired_direct_wgrad)
+            xs = [torch.randn(h, w, ci, device=dev) for _ in range(2)]
+            dys = [torch.randn(ho, wo, co, device=dev) for _ in range(2)]
+            ms = ev_time(lambda: ops.conv2d_backward_weight_pair(xs[0], dys[0], xs[1], dys[1], d))
+            gf = 2 * 2.0 * 9 * ci * co * (h * w if tr_ else ho * wo) / 1e9
+            kernels.append({"kernel": "conv_wgrad_kernel, 2 frames per launch: " + name,
                             "ms_per_launch": round(ms, 4), "gflop_per_launch": round(gf, 2),
                             "achieved": round(gf / ms, 2), "frac": round(gf / ms / PEAK_FP32_MFMA_TFLOPS, 4)})
         block = {"workload": "configs[4] per GPU: 512x512, 2 frames, G (flow%s) + D (num_D 2) + face D, --no_vgg, Adam; %d GPU(s)"

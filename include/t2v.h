@@ -245,6 +245,16 @@ size_t t2v_conv_backward_weight_workspace_floats(const t2v_conv_desc* d, int x_c
 int t2v_conv2d_backward_weight(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, int batch, const float* x,
                                int x_cs, const float* dy, int dy_cs, float* dw_packed, int accumulate,
                                float* workspace /* NULL when ..._workspace_floats() == 0 */);
+/* The same with the images of the batch `x_img_stride` / `dy_img_stride` floats apart instead of contiguous (ABI 14): the two
+ * frames of a training clip live in buffers of their own, and one launch over both runs its blocks twice as long as two
+ * launches (the kernel's fixed cost per block is ~8 of a 512<->1024 layer's 36 stage times per frame: 0.64 -> 0.73 of peak).
+ * Any non-zero multiple of 4 bytes, negative included.  Only where t2v_conv_backward_weight_strided_supported() says so
+ * (zero padding, no folded taps, GEMM rows that are whole 16-pixel stages: the stride-2 and transposed layers); workspace as
+ * for t2v_conv2d_backward_weight at the same batch.  The result is that call's on the contiguous batch, bit for bit. */
+int t2v_conv_backward_weight_strided_supported(const t2v_conv_desc* d, int x_cs, int dy_cs);
+int t2v_conv2d_backward_weight_strided(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, int batch, const float* x,
+                                       int x_cs, long x_img_stride, const float* dy, int dy_cs, long dy_img_stride,
+                                       float* dw_packed, int accumulate, float* workspace);
 /* Weight gradient of a 3x3 stride-1 conv in the Winograd domain, F(4x4,3x3): dU[xi] = sum over tiles of
  * (A dy A^T)[xi] x (B^T x B)[xi] -- 36 pixel-reduction GEMMs of a quarter of the direct gradient's FLOPs -- then
  * dW = G^T dU G, written in TORCH layout [Cout][Cin][3][3] (accumulate: += ).  Where

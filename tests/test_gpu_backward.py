@@ -370,3 +370,44 @@ def test_transposed_winograd_data_gradient_matches_autograd(H, W, Cin, Cout, t2v
             t2v_env("T2V_WINO_GEMM_SK", mode)
             outs[mode] = [ops.conv2d_backward_data_winograd(desc, B, b, ws, Cin, ut).clone() for b in range(B)]
         assert all(torch.equal(a, c) for a, c in zip(outs["0"], outs["2"]))
+
+
+@pytest.mark.parametrize("case", [
+    ("down 3x3 s2 64->128 @32x64", (32, 64, 64, 128, 3, 2, 1, 0, False)),
+    ("up convT 3x3 s2 128->64 @16x16", (16, 16, 128, 64, 3, 2, 1, 0, True)),
+    ("4x4 s2 p2 64->128 @62x62 (32x32 out)", (62, 62, 64, 128, 4, 2, 2, 0, False)),
+], ids=lambda c: c[0] if isinstance(c, tuple) and isinstance(c[0], str) else None)
+def test_weight_gradient_over_two_separate_buffers_equals_the_contiguous_batch(case):
+    """t2v_conv2d_backward_weight_strided (ABI 14): the two frames of a clip reduced in ONE launch from buffers of their own
+    (any distance apart, either order in memory) -- bit for bit the weight gradient of the contiguous batch of two, and
+    within rounding of the sum of the two single-image gradients the train step used to launch."""
+    from text2video_amd import ops
+    _, (H, W, Cin, Cout, k, st, pad, pm, tr) = case
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    desc = ops.conv_desc(H, W, Cin, Cout, k, st, pad, pm, tr)
+    ho, wo = ops.conv_out_dims(desc)
+    xcs, ycs = ops.round_up(Cin, 4), ops.round_up(Cout, 4)
+    assert ops.backward_weight_strided_supported(desc, xcs, ycs)
+    x = torch.randn(2, H, W, xcs, generator=g).to(dev)
+    dy = torch.randn(2, ho, wo, ycs, generator=g).to(dev)
+    unpack = lambda packed: ops.unpack_conv_weight(packed, desc, xcs)      # noqa: E731 -- (padding rows of the packed layout hold junk)
+    want = unpack(ops.conv2d_backward_weight(x, dy, desc))
+    # separate allocations with junk in between; second image BELOW the first in memory for one of the operands
+    pad_x, pad_y = torch.full((12345,), float("nan"), device=dev), torch.full((777,), float("nan"), device=dev)
+    x1, x0 = x[1].clone(), x[0].clone()
+    dy0, dy1 = dy[0].clone(), dy[1].clone()
+    assert x0.data_ptr() != x1.data_ptr() and pad_x.numel() and pad_y.numel()
+    got = unpack(ops.conv2d_backward_weight_pair(x0, dy0, x1, dy1, desc))
+    assert torch.equal(got, want)
+    one = unpack(ops.conv2d_backward_weight(x[0:1], dy[0:1], desc)) + unpack(ops.conv2d_backward_weight(x[1:2], dy[1:2], desc))
+    assert (got - one).abs().max().item() <= 1e-4 * one.abs().max().item()
+    acc = ops.conv2d_backward_weight(x, dy, desc)
+    ops.conv2d_backward_weight_pair(x0, dy0, x1, dy1, desc, accumulate_into=acc)
+    assert (unpack(acc) - 2 * want).abs().max().item() <= 1e-5 * want.abs().max().item()
+    # shapes that keep their images contiguous say so, and the entry point refuses them
+    stem = ops.conv_desc(32, 32, 9, 64, 7, 1, 3, 1, False)
+    assert not ops.backward_weight_strided_supported(stem, 12, 64)
+    with pytest.raises(RuntimeError, match="strided"):
+        ops.conv2d_backward_weight_pair(torch.zeros(32, 32, 12, device=dev), torch.zeros(32, 32, 64, device=dev),
+                                        torch.zeros(32, 32, 12, device=dev), torch.zeros(32, 32, 64, device=dev), stem)

@@ -90,6 +90,9 @@ SIGNATURES = {
                                                            c_int]),
     "t2v_conv2d_backward_weight": (c_int, [c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_void_p, c_int, c_void_p,
                                            c_int, c_void_p, c_int, c_void_p]),
+    "t2v_conv_backward_weight_strided_supported": (c_int, [POINTER(ConvDesc), c_int, c_int]),
+    "t2v_conv2d_backward_weight_strided": (c_int, [c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_void_p, c_int, c_long, c_void_p,
+                                                   c_int, c_long, c_void_p, c_int, c_void_p]),
     "t2v_conv_unpack_weight": (c_int, [c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_void_p, c_void_p]),
     "t2v_conv_backward_data_winograd_supported": (c_int, [POINTER(ConvDesc), c_int, c_int]),
     "t2v_conv_backward_data_winograd_weight_floats": (c_size_t, [POINTER(ConvDesc), c_int]),

@@ -747,9 +747,10 @@ size_t t2v_conv_backward_weight_workspace_floats(const t2v_conv_desc* d, int x_c
     return s > 1 ? (size_t)s * pl.wfloats + wgrad_ticket_floats(d, x_cs, pl) : 0;
 }
 
-int t2v_conv2d_backward_weight(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, int batch, const float* x,
-                               int x_cs, const float* dy, int dy_cs, float* dw_packed, int accumulate,
-                               float* workspace) {
+// x_stride / dy_stride: floats between the images (0: the batch's own pitch)
+static int backward_weight_impl(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, int batch, const float* x,
+                                int x_cs, long x_stride, const float* dy, int dy_cs, long dy_stride, float* dw_packed,
+                                int accumulate, float* workspace) {
     T2V_REQUIRE(ctx && x && dy && dw_packed && batch >= 1, "backward_weight: bad arguments");
     ConvPlan pl;
     T2V_TRY(build_conv_plan(d, x_cs, true, &pl));   // 128-row weight granule, plain 128x128 bookkeeping
@@ -772,6 +773,14 @@ int t2v_conv2d_backward_weight(t2v_ctx* ctx, void* stream, const t2v_conv_desc* 
             w.tap_woff[nt] = k.ph[ph].w_off; w.tap_Kp[nt] = k.ph[ph].Kp; w.tap_kidx[nt] = t;
         }
     w.ntaps = nt;
+    w.x_img_stride = (long)d->H * d->W * x_cs;
+    w.dy_img_stride = (long)pl.Hout * pl.Wout * dy_cs;
+    if (x_stride || dy_stride) {
+        T2V_REQUIRE(!(wgrad_fold_n(d, x_cs, dy_cs) && dy_cs == round_up(d->Cout, 4)) && !wgrad_fold(d, x_cs) && conv_wgrad_strided_ok(w),
+                    "backward_weight_strided: this shape keeps its images contiguous (t2v_conv_backward_weight_strided_supported)");
+        if (x_stride) w.x_img_stride = x_stride;
+        if (dy_stride) w.dy_img_stride = dy_stride;
+    }
     if (wgrad_fold_n(d, x_cs, dy_cs) && dy_cs == round_up(d->Cout, 4)) {
         // x -> padded copy (reflection / zeros resolved once), taps folded onto the dY side of the tile
         T2V_REQUIRE(workspace, "backward_weight: this shape needs a workspace of "
@@ -833,6 +842,30 @@ int t2v_conv2d_backward_weight(t2v_ctx* ctx, void* stream, const t2v_conv_desc* 
     w.accumulate = 0;
     T2V_TRY(launch_conv_wgrad((hipStream_t)stream, w));
     return launch_wgrad_reduce((hipStream_t)stream, workspace, w.splits, (long)pl.wfloats, dw_packed, accumulate);
+}
+
+int t2v_conv2d_backward_weight(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, int batch, const float* x,
+                               int x_cs, const float* dy, int dy_cs, float* dw_packed, int accumulate,
+                               float* workspace) {
+    return backward_weight_impl(ctx, stream, d, batch, x, x_cs, 0, dy, dy_cs, 0, dw_packed, accumulate, workspace);
+}
+int t2v_conv_backward_weight_strided_supported(const t2v_conv_desc* d, int x_cs, int dy_cs) {
+    ConvPlan pl;
+    if (!d || build_conv_plan(d, x_cs, true, &pl) != T2V_OK) return 0;
+    if ((wgrad_fold_n(d, x_cs, dy_cs) && dy_cs == round_up(d->Cout, 4)) || wgrad_fold(d, x_cs)) return 0;
+    WgradParams w;
+    memset(&w, 0, sizeof(w));
+    w.reflect = pl.kp.pad_mode == T2V_PAD_REFLECT;
+    w.Wm = pl.kp.Wm;
+    w.M = pl.kp.M;
+    return conv_wgrad_strided_ok(w) ? 1 : 0;
+}
+int t2v_conv2d_backward_weight_strided(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, int batch, const float* x,
+                                       int x_cs, long x_img_stride, const float* dy, int dy_cs, long dy_img_stride,
+                                       float* dw_packed, int accumulate, float* workspace) {
+    T2V_REQUIRE(x_img_stride != 0 && dy_img_stride != 0, "backward_weight_strided: zero image stride");
+    return backward_weight_impl(ctx, stream, d, batch, x, x_cs, x_img_stride, dy, dy_cs, dy_img_stride, dw_packed, accumulate,
+                                workspace);
 }
 
 // ---- weight gradient in the Winograd domain (F(4x4,3x3)) -------------------------------------------------
@@ -899,6 +932,7 @@ int t2v_conv2d_backward_weight_winograd_stages(t2v_ctx* ctx, void* stream, const
     memset(&w, 0, sizeof(w));
     w.x = V; w.dy = Md; w.dw = dU;
     w.batch = 1; w.Hin = 36; w.Win = Tt; w.Cin_s = x_cs;
+    w.x_img_stride = (long)36 * Tt * x_cs; w.dy_img_stride = (long)36 * Tt * d->Cout;
     w.Wm = Tt; w.M = Tt;
     w.Hout = 36; w.Wout = Tt; w.Cout = d->Cout; w.Cout_s = d->Cout;
     w.stride = 1; w.ostride = 1;

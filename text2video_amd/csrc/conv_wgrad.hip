@@ -237,6 +237,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradParams p) {
                 lx0[i] = lp * p.stride + ldx;
             }
             const int xrow_bytes = p.Win * p.Cin_s * 4;
+            const int x_img_bytes = p.Hin * xrow_bytes;
+            const int dy_img_bytes = p.Hout * p.Wout * p.Cout_s * 4;
             int curf = 0;
             auto issue_fast = [&](int kt, int slot) {
                 char* sY = smem + slot * kWgStage;
@@ -253,17 +255,22 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradParams p) {
                     }
                 }
                 const bool inb = sb < p.batch;
-                const int soff_y = (((sb * p.Hout + sy * p.ostride + p.toy[tap]) * p.Wout) + sx * p.ostride + p.tox[tap]) * p.Cout_s * 4;
+                // the stage's image has its own buffer resource: images sit x_img_stride / dy_img_stride floats apart -- the
+                // batch's own pitch, or whatever separates the buffers of two frames (t2v_conv2d_backward_weight_strided)
+                const int sbc = inb ? sb : 0;
+                const float* xb = p.x + (long)sbc * p.x_img_stride;
+                const float* yb = p.dy + (long)sbc * p.dy_img_stride;
+                const int soff_y = (((sy * p.ostride + p.toy[tap]) * p.Wout) + sx * p.ostride + p.tox[tap]) * p.Cout_s * 4;
                 const int iy = sy * p.stride + ldy;
                 const bool rowok = inb && (unsigned)iy < (unsigned)p.Hin;
-                const int soff_x = rowok ? (sb * p.Hin + iy) * xrow_bytes : 0;
+                const int soff_x = rowok ? iy * xrow_bytes : 0;
                 const int ix0 = sx * p.stride;
 #pragma unroll
                 for (int i = 0; i < NI; ++i) {
-                    wg_dma16(p.dy, dy_bytes, sY + (wid * RW + i * 2) * 512, inb ? vy_c[i] : kOOB, inb ? soff_y : 0);
+                    wg_dma16(yb, dy_img_bytes, sY + (wid * RW + i * 2) * 512, inb ? vy_c[i] : kOOB, inb ? soff_y : 0);
                     const int ix = ix0 + lx0[i];
                     const int vx = (rowok && c_ok && (unsigned)ix < (unsigned)p.Win) ? (ix * p.Cin_s + lc) * 4 : kOOB;
-                    wg_dma16(p.x, x_bytes, sX + (wid * RW + i * 2) * 512, vx, soff_x);
+                    wg_dma16(xb, x_img_bytes, sX + (wid * RW + i * 2) * 512, vx, soff_x);
                 }
             };
             loader_k_loop<kWgRing, 2 * NI>(0, nk, issue_fast);
@@ -644,5 +651,7 @@ static int launch_wgrad_variant(hipStream_t s, const WgradParams& p) {
 int launch_conv_wgrad(hipStream_t s, const WgradParams& p) {
     return p.reflect ? launch_wgrad_variant<true, 16, 4>(s, p) : launch_wgrad_variant<false, 16, 4>(s, p);
 }
+// (the kernel's `fast` condition at 16-pixel stages)
+bool conv_wgrad_strided_ok(const WgradParams& p) { return !p.reflect && p.fold == 0 && p.Wm % 16 == 0 && p.M % 16 == 0; }
 
 }  // namespace t2v

@@ -139,6 +139,9 @@ struct WgradParams {
     const float* dy;   // output gradient [batch][Hout][Wout][Cout_s]
     float* dw;         // packed weight gradient (same layout as the packed forward weight)
     int batch, Hin, Win, Cin_s;
+    // floats between consecutive images of x / dy.  The batch's own pitch by default; anything else (two frames of a clip in
+    // buffers of their own: t2v_conv2d_backward_weight_strided) only where conv_wgrad_strided_ok() says so
+    long x_img_stride, dy_img_stride;
     int Wm, M;         // GEMM pixel grid of the forward conv, per image
     int Hout, Wout, Cout, Cout_s;
     int stride, ostride;
@@ -164,6 +167,8 @@ struct WgradParams {
     int tap_kidx[kMaxTaps];             // index of the tap inside its phase
 };
 int launch_conv_wgrad(hipStream_t s, const WgradParams& p);
+// true when the launch takes the scalar-stepped loader path, the one that addresses every image through its own buffer resource
+bool conv_wgrad_strided_ok(const WgradParams& p);
 int launch_wgrad_reduce(hipStream_t s, const float* partial, int splits, long n, float* dw, int accumulate);
 int launch_unpack_conv_weight(hipStream_t s, const float* packed, float* w, int Cout, int Cin, int KH, int KW, int Cin_s,
                               int Kp, int accumulate = 0);

@@ -458,6 +458,30 @@ def conv2d_backward_weight(x, dy, desc, accumulate_into=None):
     return dw
 
 
+def backward_weight_strided_supported(desc, x_cs, dy_cs):
+    return bool(_lib.load().t2v_conv_backward_weight_strided_supported(ctypes.byref(desc), x_cs, dy_cs))
+
+
+def conv2d_backward_weight_pair(x0, dy0, x1, dy1, desc, accumulate_into=None):
+    """packed dW of the two images x0 / x1 ([H,W,x_cs] each, in buffers of their own) and their output gradients in ONE
+    launch (t2v_conv2d_backward_weight_strided): what conv2d_backward_weight computes on torch.stack of them, bit for bit."""
+    c = context()
+    for t, n in ((x0, "x0"), (x1, "x1"), (dy0, "dy0"), (dy1, "dy1")):
+        _chk(t, n)
+    assert x0.shape == x1.shape and dy0.shape == dy1.shape and x0.dim() == 3
+    x_cs, dy_cs = x0.shape[-1], dy0.shape[-1]
+    n = c.lib.t2v_conv_packed_weight_floats(ctypes.byref(desc), x_cs)
+    dw = accumulate_into if accumulate_into is not None else torch.empty(n, dtype=torch.float32, device=x0.device)
+    nws = c.lib.t2v_conv_backward_weight_workspace_floats(ctypes.byref(desc), x_cs, 2)
+    ws = torch.empty(max(nws, 1), dtype=torch.float32, device=x0.device)
+    xs, ys = (x1.data_ptr() - x0.data_ptr()) // 4, (dy1.data_ptr() - dy0.data_ptr()) // 4
+    if xs == 0 or ys == 0:
+        raise ValueError("conv2d_backward_weight_pair: the two images share a buffer")
+    check(c.lib.t2v_conv2d_backward_weight_strided(c.handle, _stream(), ctypes.byref(desc), 2, _p(x0), x_cs, xs, _p(dy0), dy_cs, ys,
+                                                   _p(dw), int(accumulate_into is not None), _p(ws)), "conv2d_backward_weight_strided")
+    return dw
+
+
 def backward_weight_winograd_supported(desc, x_cs, dy_cs):
     return bool(_lib.load().t2v_conv_backward_weight_winograd_supported(ctypes.byref(desc), x_cs, dy_cs))
 

@@ -123,6 +123,33 @@ def deliver(sl, tensor=None, zero=False):
 
 
 _WG_BATCH = [False]
+_DW_PAIR = [False]     # inside a train-step scope: a direct-kernel layer used by exactly two frames reduces both in one launch
+
+
+def _paired_direct_wgrad(w, x, dc, fdesc, slot):
+    """Direct (non-Winograd) weight gradient of a layer that the clip's TWO frames went through (counted in forward:
+    `w._t2v_dw_uses`): the first backward node to arrive leaves its (x, dY) on the weight, the second launches ONE reduction
+    over both frames' buffers (ops.conv2d_backward_weight_pair: two base pointers, no copy) -- the kernel pays a fixed ~8
+    stage times per block, 36 stages long for one frame of a 512<->1024 layer and 73 for two (0.64 -> 0.73 of peak).
+    Returns (taken, dW or None): not taken -> the caller reduces this node alone."""
+    if not _DW_PAIR[0] or getattr(w, "_t2v_dw_uses", 0) != 2 or x.shape[0] != 1:
+        return False, None
+    st = getattr(w, "_t2v_dw_stash", None)
+    if st is None:
+        w._t2v_dw_stash = (x, dc, fdesc)
+        if slot is not None:
+            slot.owner.node_done(slot)
+        return True, None
+    x0, dc0, _ = st
+    w._t2v_dw_stash, w._t2v_dw_uses = None, 0
+    if slot is not None:
+        with (wgrad_fork(x, dc, x0, dc0) if wgrad_stream_on(x) else contextlib.nullcontext()):
+            dwp = ops.conv2d_backward_weight_pair(x0[0], dc0[0], x[0], dc[0], fdesc)
+            ops.unpack_conv_weight_into(dwp, fdesc, x.shape[-1], slot.view, slot.filled)
+        slot.filled = True
+        slot.owner.node_done(slot)
+        return True, None
+    return True, ops.unpack_conv_weight(ops.conv2d_backward_weight_pair(x0[0], dc0[0], x[0], dc[0], fdesc), fdesc, x.shape[-1])
 
 
 @contextlib.contextmanager
@@ -132,11 +159,14 @@ def batched_weight_gradients(params):
     graph that was built but never back-propagated cannot leave a stale count behind.  T2V_WGRAD_BATCH=0: off."""
     for p in params:
         p._t2v_wg_images, p._t2v_wg_state = 0, None
+        p._t2v_dw_uses, p._t2v_dw_stash = 0, None
     _WG_BATCH[0] = os.environ.get("T2V_WGRAD_BATCH", "1") != "0"
+    _DW_PAIR[0] = os.environ.get("T2V_WGRAD_PAIR", "1") != "0"
     try:
         yield
     finally:
         _WG_BATCH[0] = False
+        _DW_PAIR[0] = False
 
 
 # ---- weight gradients on a second stream ---------------------------------------------------------------------------
@@ -236,6 +266,17 @@ def flush_pending_weight_gradients(params, grads):
     out = list(grads)
     wgrad_join()
     for i, p in enumerate(params):
+        half = getattr(p, "_t2v_dw_stash", None)
+        if half is not None:        # a paired direct layer whose second frame never came back: reduce the one that did
+            x0, dc0, fd0 = half
+            sl = grad_slot(p)
+            if sl is not None:
+                ops.unpack_conv_weight_into(ops.conv2d_backward_weight(x0, dc0, fd0), fd0, x0.shape[-1], sl.view, sl.filled)
+                sl.filled = True
+            else:
+                dw = ops.unpack_conv_weight(ops.conv2d_backward_weight(x0, dc0, fd0), fd0, x0.shape[-1])
+                out[i] = dw if out[i] is None else out[i] + dw
+        p._t2v_dw_stash, p._t2v_dw_uses = None, 0
         st = getattr(p, "_t2v_wg_state", None)
         if st is None:
             continue
@@ -404,6 +445,8 @@ class _ConvBlock(torch.autograd.Function):
         if wino_wgrad and w.requires_grad and _WG_BATCH[0]:
             w._t2v_wg_images = getattr(w, "_t2v_wg_images", 0) + B
             wino_wgrad = 2
+        elif not wino_wgrad and w.requires_grad and _DW_PAIR[0] and B == 1 and ops.backward_weight_strided_supported(ddesc, xcs, ycs):
+            w._t2v_dw_uses = getattr(w, "_t2v_dw_uses", 0) + 1      # (exactly two uses: _paired_direct_wgrad)
         for prm in (w, b, gamma, beta):
             expect_gradient(prm)
         # (an input nobody differentiates -- the discriminators' real pass -- needs no data-gradient conv)
@@ -496,7 +539,10 @@ class _ConvBlock(torch.autograd.Function):
             else:
                 dw = ops.conv2d_backward_weight_winograd(x, dc, fdesc)
         else:
-            if sl_w is not None:
+            paired, dw = _paired_direct_wgrad(w, x, dc, fdesc, sl_w)
+            if paired:
+                pass
+            elif sl_w is not None:
                 with (wgrad_fork(x, dc) if wgrad_stream_on(x) else contextlib.nullcontext()):
                     dwp = ops.conv2d_backward_weight(x, dc, fdesc)
                     ops.unpack_conv_weight_into(dwp, fdesc, x.shape[-1], sl_w.view, sl_w.filled)
