@@ -255,3 +255,95 @@ def test_unreadable_checkpoint_raises_lean_unsupported(tmp_path):
             "assert 'torch' not in sys.modules\n" % (ROOT, good, bad))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "lean unsupported:" in r.stdout and "refusing global" in r.stdout, r.stdout + r.stderr[-2000:]
+
+
+class _Payload:
+    """unpickling this object runs os.mkdir(<marker>): the side effect the reader must never perform"""
+
+    def __init__(self, marker):
+        self.marker = marker
+
+    def __reduce__(self):
+        return (os.mkdir, (self.marker,))
+
+
+@pytest.mark.parametrize("position", ["magic", "protocol", "sys_info", "keys", "legacy-body", "zip-data.pkl"])
+def test_crafted_checkpoint_never_executes(tmp_path, position):
+    """a __reduce__ payload in any of the four header / trailer pickles of the legacy 0.4.1 stream
+    ($SP/torch/serialization.py:286-300: magic, protocol, sys_info, <state dict>, storage keys), in its body, or in a zip
+    archive's data.pkl is refused AND its side effect is absent -- the torch-free reader is vid2vid/test.py's default"""
+    import io
+    import pickle
+    import zipfile
+    marker = str(tmp_path / "pwned")
+    path = str(tmp_path / "crafted.pth")
+    evil = _Payload(marker)
+    if position == "zip-data.pkl":
+        with zipfile.ZipFile(path, "w", zipfile.ZIP_STORED) as zf:
+            zf.writestr("archive/data.pkl", pickle.dumps({"w": evil}, protocol=2))
+            zf.writestr("archive/version", b"3\n")
+    else:
+        good = io.BytesIO()
+        torch.save(_state_dict(), good, _use_new_zipfile_serialization=False)
+        good.seek(0)
+        recs = []
+        for _ in range(3):                           # magic, protocol, sys_info
+            a = good.tell()
+            pickle.load(good)
+            recs.append(good.getvalue()[a:good.tell()])
+        a = good.tell()
+
+        class _Skip(pickle.Unpickler):               # the state dict needs torch's persistent_load to be skipped over
+            def persistent_load(self, pid):
+                return None
+
+            def find_class(self, module, name):
+                if module.startswith("torch"):
+                    return lambda *a, **k: None
+                return pickle.Unpickler.find_class(self, module, name)
+        _Skip(good).load()
+        recs.append(good.getvalue()[a:good.tell()])
+        a = good.tell()
+        pickle.load(good)
+        recs.append(good.getvalue()[a:good.tell()])
+        tail = good.getvalue()[good.tell():]
+        idx = {"magic": 0, "protocol": 1, "sys_info": 2, "legacy-body": 3, "keys": 4}[position]
+        recs[idx] = pickle.dumps(evil if position != "legacy-body" else {"w": evil}, protocol=2)
+        with open(path, "wb") as fh:
+            fh.write(b"".join(recs) + tail)
+    with pytest.raises(pickle.UnpicklingError):
+        lt.load(path)
+    assert not os.path.exists(marker), "the payload in the %s record ran" % position
+    # the same file through the product's entry (lean process): LeanUnsupported, side effect still absent
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from text2video_amd import _xp\n"
+            "assert _xp.use_lean()\n"
+            "from text2video_amd import model\n"
+            "try:\n"
+            "    model.load_checkpoint(%r)\n"
+            "except model.LeanUnsupported as e:\n"
+            "    print('lean unsupported:', e)\n" % (ROOT, path))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "lean unsupported:" in r.stdout, r.stdout + r.stderr[-2000:]
+    assert not os.path.exists(marker)
+
+
+def test_short_or_empty_checkpoint_is_lean_unsupported(tmp_path):
+    """a load failure of any type (an empty file cannot even be mapped) becomes LeanUnsupported in the lean
+    process, so vid2vid/test.py starts over with torch instead of dying with a raw exception"""
+    empty = str(tmp_path / "empty.pth")
+    open(empty, "wb").close()
+    short = str(tmp_path / "short.pth")
+    with open(short, "wb") as fh:
+        fh.write(b"PK\x03\x04trunc")
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from text2video_amd import _xp\n"
+            "assert _xp.use_lean()\n"
+            "from text2video_amd import model\n"
+            "for p in %r:\n"
+            "    try:\n"
+            "        model.load_checkpoint(p)\n"
+            "    except model.LeanUnsupported as e:\n"
+            "        print('lean unsupported:', e)\n" % (ROOT, [empty, short]))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.count("lean unsupported:") == 2, r.stdout + r.stderr[-2000:]

@@ -53,14 +53,15 @@ def load_checkpoint(path):
     """torch.save'd state-dict (legacy pickle stream of torch 0.4.1 included), tensors only.  Zip-format files (what
     save() here and every torch >= 1.6 write) are memory-mapped: the H2D copies then read straight from the page
     cache instead of from a second host copy of the 1.5 GB file."""
+    from . import _xp
     try:
-        sd = torch.load(path, map_location="cpu", weights_only=True, mmap=True)
-    except (RuntimeError, ValueError, TypeError):     # legacy (non-zip) stream: cannot be mapped
-        sd = torch.load(path, map_location="cpu", weights_only=True)
+        try:
+            sd = torch.load(path, map_location="cpu", weights_only=True, mmap=True)
+        except (RuntimeError, ValueError, TypeError):     # legacy (non-zip) stream: cannot be mapped
+            sd = torch.load(path, map_location="cpu", weights_only=True)
     except Exception as e:      # noqa: BLE001
-        from . import _xp
         if _xp.LEAN:           # a container leantorch.load does not read: vid2vid/test.py starts over with torch
-            raise LeanUnsupported("%s: %s" % (path, e)) from e
+            raise LeanUnsupported("%s: %s: %s" % (path, type(e).__name__, e)) from e
         raise
     if isinstance(sd, dict) and "state_dict" in sd:
         sd = sd["state_dict"]
