@@ -67,7 +67,7 @@ def test_server_and_model_keys(tmp_path, monkeypatch):
     from text2video_amd.options import TestOptions
     monkeypatch.delenv("T2V_RESIDENT_KEY", raising=False)
     a = resident.socket_path(["--gpu_ids", "0"])
-    assert a == resident.socket_path(["--name", "x"]) and a.startswith("/tmp/t2v_resident_%d_" % os.getuid())
+    assert a == resident.socket_path(["--name", "x"]) and os.path.dirname(a) == resident.run_dir()
     assert resident.socket_path(["--gpu_ids", "1"]) != a                  # another device: another server
     monkeypatch.setenv("CUDA_VISIBLE_DEVICES", "3")
     assert resident.socket_path(["--gpu_ids", "0"]) != a
@@ -95,3 +95,79 @@ def test_thin_client_imports_no_torch():
             "assert 'torch' not in sys.modules and 'numpy' not in sys.modules, sorted(m for m in sys.modules if 'torch' in m)" % root)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr[-1500:]
+
+
+def test_run_dir_is_private_and_refuses_a_planted_one(tmp_path, monkeypatch):
+    """socket, log and lock live in a directory only this user can enter; a symlink or a foreign directory planted at
+    that name is refused, a log planted as a symlink is not followed"""
+    import stat
+    from text2video_amd import resident
+    monkeypatch.setenv("XDG_RUNTIME_DIR", str(tmp_path))
+    d = resident.run_dir()
+    assert d == str(tmp_path / "t2v_resident") and stat.S_IMODE(os.lstat(d).st_mode) == 0o700
+    os.chmod(d, 0o755)
+    assert resident.run_dir() == d and stat.S_IMODE(os.lstat(d).st_mode) == 0o700       # widened: narrowed again
+    os.rmdir(d)
+    os.symlink(str(tmp_path), d)                                          # planted symlink
+    with pytest.raises(PermissionError):
+        resident.run_dir()
+    os.unlink(d)
+    # the spawn path opens the log O_NOFOLLOW: a planted symlink makes the open fail instead of appending to its target
+    victim = tmp_path / "victim.txt"
+    victim.write_text("keep")
+    d = resident.run_dir()
+    monkeypatch.setattr(resident, "socket_path", lambda argv: os.path.join(d, "k.sock"))
+    os.symlink(str(victim), os.path.join(d, "k.log"))
+    monkeypatch.setattr(resident.subprocess, "Popen", lambda *a, **k: (_ for _ in ()).throw(AssertionError("spawned")))
+    with pytest.raises(OSError):
+        resident.client(["--resident"], start_timeout=0.2)
+    assert victim.read_text() == "keep"
+
+
+def test_client_takes_over_when_the_server_says_lean_unsupported(tmp_path, monkeypatch, capsys):
+    """a checkpoint the torch-free server cannot read: the status frame tells the client to run the command itself (None), where
+    vid2vid/test.py's LeanUnsupported handling starts it over with torch"""
+    from text2video_amd import resident
+    path = str(tmp_path / "s.sock")
+    monkeypatch.setattr(resident, "socket_path", lambda argv: path)
+    seen = []
+    t = _fake_server(path, [(b"e", b"resident: x.pth: refusing global -- the client runs this one itself\n"),
+                            (b"x", resident.RC_LEAN_UNSUPPORTED)], seen)
+    assert resident.client(["--resident"]) is None
+    t.join(5)
+    assert "the client runs this one itself" in capsys.readouterr().err
+
+
+def test_two_simultaneous_first_calls_start_one_server(tmp_path, monkeypatch):
+    """the spawn is serialised by a lock file: the second caller finds the first one's server instead of starting its own"""
+    from text2video_amd import resident
+    monkeypatch.setenv("XDG_RUNTIME_DIR", str(tmp_path))
+    path = os.path.join(resident.run_dir(), "k.sock")
+    monkeypatch.setattr(resident, "socket_path", lambda argv: path)
+    spawned, seen = [], []
+
+    class _P:
+        def __init__(self, cmd, **kw):
+            spawned.append(cmd)
+            # the "server": answers two requests, one after the other
+            srv = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+            srv.bind(path)
+            srv.listen(4)
+
+            def run():
+                for _ in range(2):
+                    conn, _a = srv.accept()
+                    with conn:
+                        line = bytearray()
+                        while not line.endswith(b"\n"):
+                            line += conn.recv(4096)
+                        seen.append(1)
+                        conn.sendall(b"x" + struct.pack("<i", 0))
+                srv.close()
+            threading.Thread(target=run, daemon=True).start()
+    monkeypatch.setattr(resident.subprocess, "Popen", _P)
+    rcs = []
+    ts = [threading.Thread(target=lambda: rcs.append(resident.client(["--resident"], start_timeout=10))) for _ in range(2)]
+    [t.start() for t in ts]
+    [t.join(20) for t in ts]
+    assert rcs == [0, 0] and len(spawned) == 1 and len(seen) == 2

@@ -6,11 +6,14 @@ behind ~1.7 s of start-up that no single process can avoid: the interpreter impo
 going to the device (0.4 s).  With --resident the command becomes a thin client (no torch import: ~30 ms) of a server process
 that keeps the HIP context, the packed / Winograd-transformed weights and the rasteriser workers across calls:
 
-    client (test.py)  --AF_UNIX /tmp/t2v_resident_<uid>_<key>.sock-->  server (this module, `python -m text2video_amd.resident`)
+    client (test.py)  --AF_UNIX <run dir>/<key>.sock-->  server (this module, `python -m text2video_amd.resident`)
       request : one JSON line {argv, cwd, env (T2V_*)}
       reply   : frames  b"o" | b"e" + u32 length + bytes (the run's stdout / stderr, streamed) ... b"x" + i32 exit status
 
-The first call finds no server, starts one (detached, its own session, log in /tmp) and is served by it; later calls connect.
+<run dir> is a directory only this user can enter ($XDG_RUNTIME_DIR/t2v_resident, else /tmp/t2v_resident_<uid>: mode 0700,
+owner checked, never a symlink); the log beside the socket is opened O_NOFOLLOW, mode 0600; both ends check the peer's uid
+(SO_PEERCRED); a lock file (flock) makes two simultaneous first calls start ONE server.
+The first call finds no server, starts one (detached, its own session) and is served by it; later calls connect.
 The server handles one request at a time (the calls of the reference's scripts are sequential), reloads a checkpoint whose
 file changed, and exits after `--resident_idle_s` seconds without a request (default 600).  `key` = interpreter, package
 location, device selection: two installations or two GPUs never share a server.  test_fifo.py (a named pipe, the model loaded
@@ -28,6 +31,7 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DEVICE_ENV = ("CUDA_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES")
+RC_LEAN_UNSUPPORTED = -0x4C45414E          # exit-status frame meaning "run it yourself" (never a process exit status)
 
 
 def _gpu_ids(argv):
@@ -39,11 +43,33 @@ def _gpu_ids(argv):
     return "0"
 
 
+def run_dir():
+    """a directory only this user can enter: the socket, the log and the spawn lock live here (never in shared /tmp itself)"""
+    base = os.environ.get("XDG_RUNTIME_DIR")
+    d = os.path.join(base, "t2v_resident") if base and os.path.isdir(base) else "/tmp/t2v_resident_%d" % os.getuid()
+    try:
+        os.mkdir(d, 0o700)
+    except FileExistsError:
+        pass
+    st = os.lstat(d)
+    import stat as _stat
+    if not _stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid():
+        raise PermissionError("resident: %s is not a directory owned by uid %d" % (d, os.getuid()))
+    if st.st_mode & 0o077:
+        os.chmod(d, 0o700)
+    return d
+
+
 def socket_path(argv):
     # (T2V_RESIDENT_KEY: any string; lets independent servers coexist on one device selection)
     key = json.dumps([sys.executable, ROOT, {k: os.environ.get(k, "") for k in DEVICE_ENV}, _gpu_ids(argv),
                       os.environ.get("T2V_RESIDENT_KEY", "")])
-    return "/tmp/t2v_resident_%d_%s.sock" % (os.getuid(), hashlib.sha1(key.encode()).hexdigest()[:16])
+    return os.path.join(run_dir(), "%s.sock" % hashlib.sha1(key.encode()).hexdigest()[:16])
+
+
+def _peer_uid(s):
+    pid, uid, gid = struct.unpack("3i", s.getsockopt(socket.SOL_SOCKET, socket.SO_PEERCRED, struct.calcsize("3i")))
+    return uid
 
 
 def _connect(path, timeout=None):
@@ -52,6 +78,8 @@ def _connect(path, timeout=None):
         s.settimeout(timeout)
         s.connect(path)
         s.settimeout(None)
+        if _peer_uid(s) != os.getuid():          # whoever is bound there is not us: never hand it argv / cwd / env
+            raise OSError("resident: %s is served by another user" % path)
         return s
     except OSError:
         s.close()
@@ -80,17 +108,25 @@ def client(argv, start_timeout=180.0):
         for i, a in enumerate(argv):
             if a == "--resident_idle_s" and i + 1 < len(argv):
                 idle = argv[i + 1]
-        log = open(path[:-5] + ".log", "ab")
+        import fcntl
+        lock = os.open(path[:-5] + ".lock", os.O_CREAT | os.O_RDWR | os.O_NOFOLLOW, 0o600)
         try:
-            subprocess.Popen([sys.executable, "-m", "text2video_amd.resident", path, idle], cwd=ROOT, stdin=subprocess.DEVNULL,
-                             stdout=log, stderr=log, start_new_session=True,
-                             env=dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", "")))
-        finally:
-            log.close()
-        t_end = time.time() + start_timeout
-        while s is None and time.time() < t_end:
-            time.sleep(0.05)
+            fcntl.flock(lock, fcntl.LOCK_EX)       # two first calls at once: the second finds the first's server below
             s = _connect(path, 1.0)
+            if s is None:
+                log = os.open(path[:-5] + ".log", os.O_CREAT | os.O_WRONLY | os.O_APPEND | os.O_NOFOLLOW, 0o600)
+                try:
+                    subprocess.Popen([sys.executable, "-m", "text2video_amd.resident", path, idle], cwd=ROOT,
+                                     stdin=subprocess.DEVNULL, stdout=log, stderr=log, start_new_session=True,
+                                     env=dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", "")))
+                finally:
+                    os.close(log)
+                t_end = time.time() + start_timeout
+                while s is None and time.time() < t_end:
+                    time.sleep(0.05)
+                    s = _connect(path, 1.0)
+        finally:
+            os.close(lock)                          # (closing drops the flock)
         if s is None:
             print("resident: no server came up at %s (see %s.log); running in this process" % (path, path[:-5]), file=sys.stderr)
             return None
@@ -100,7 +136,10 @@ def client(argv, start_timeout=180.0):
         while True:
             tag = _recv_exact(s, 1)
             if tag == b"x":
-                return struct.unpack("<i", _recv_exact(s, 4))[0]
+                rc = struct.unpack("<i", _recv_exact(s, 4))[0]
+                # the torch-free server met a checkpoint only torch reads: this process runs the command itself (and
+                # vid2vid/test.py's own LeanUnsupported handling starts it over with torch)
+                return None if rc == RC_LEAN_UNSUPPORTED else rc
             data = _recv_exact(s, struct.unpack("<I", _recv_exact(s, 4))[0])
             out = sys.stdout if tag == b"o" else sys.stderr
             out.write(data.decode(errors="replace"))
@@ -154,7 +193,7 @@ def serve(path, idle_s):
     if os.environ.get("T2V_LEAN", "1") != "0":
         from text2video_amd import _xp
         _xp.use_lean()
-    from text2video_amd.model import create_model, run_test
+    from text2video_amd.model import LeanUnsupported, create_model, run_test
     from text2video_amd.options import TestOptions
     try:
         os.unlink(path)
@@ -181,6 +220,8 @@ def serve(path, idle_s):
             with conn:
                 rc = 1
                 try:
+                    if _peer_uid(conn) != os.getuid():
+                        continue
                     line = bytearray()
                     while not line.endswith(b"\n"):
                         chunk = conn.recv(65536)
@@ -216,6 +257,10 @@ def serve(path, idle_s):
                             rc = 0
                         except SystemExit as e:
                             rc = e.code if isinstance(e.code, int) else 1
+                        except LeanUnsupported as e:
+                            print("resident: %s -- the client runs this one itself" % e, file=sys.stderr)
+                            models.clear()
+                            rc = RC_LEAN_UNSUPPORTED
                         except BaseException:        # noqa: BLE001 -- reported to the client, the server lives on
                             import traceback
                             traceback.print_exc()
