@@ -369,10 +369,11 @@ def test_flow_branch_gets_its_weight_gradients_when_a_new_sequence_has_no_flow_l
         return {k: gi for (k, _), gi in zip(G.named_upstream_parameters().items(), g)}
 
     ref = grads(False, False)
-    lost = grads(True, False)
+    with pytest.raises(RuntimeError, match="flush_pending_weight_gradients"):      # the failure mode the flush exists for:
+        grads(True, False)                                                          # loud at scope exit, not a lost gradient
     got = grads(True, True)
     flow3x3 = [k for k in ref if k.startswith("model_res_flow") and k.endswith("weight") and ref[k] is not None and ref[k].dim() == 4]
-    assert flow3x3 and any(lost[k] is None for k in flow3x3)              # the failure mode the flush exists for
+    assert flow3x3
     for k in flow3x3:
         assert got[k] is not None, k
         err = (got[k] - ref[k]).abs().max().item() / max(ref[k].abs().max().item(), 1e-12)

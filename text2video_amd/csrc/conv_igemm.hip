@@ -428,14 +428,16 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(const ConvKParams p) {
     // multiply-high (exact for m < 2^20 and Wm < 2^20), buffer stores off one SRD (out-of-range lanes are dropped by the
     // hardware), the activation chosen once per tile.
     const __amdgpu_buffer_rsrc_t ysrd = __builtin_amdgcn_make_buffer_rsrc(yg, 0, p.Hout * p.Wout * p.Cout_s * 4, 0x00020000);
-    constexpr int kDrop = 0x7fffff00;      // >= the record count of any output map (checked on the host: < 2 GiB)
+    // >= the record count of any output map (checked on the host: < 2 GiB); offsets are unsigned, so a pixel offset plus
+    // kDrop (a padding column of a live pixel) stays a defined value >= kDrop and is dropped as well
+    constexpr unsigned kDrop = 0x7fffff00u;
     const bool fastdiv = p.M <= (1 << 20);
     const unsigned long long magic = (1ull << 40) / (unsigned)p.Wm + 1;
-    int coff[Cfg::TN];
+    unsigned coff[Cfg::TN];
     bool creal[Cfg::TN];
 #pragma unroll
     for (int j = 0; j < Cfg::TN; ++j) {
-        coff[j] = col[j] < p.Cout_s ? col[j] * 4 : kDrop;
+        coff[j] = col[j] < p.Cout_s ? (unsigned)col[j] * 4u : kDrop;
         creal[j] = col[j] < p.Cout;
     }
     auto store_tile = [&](auto act) {
@@ -450,11 +452,11 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(const ConvKParams p) {
                 const int oy = my * p.ostride + ph.oy0, ox = mx * p.ostride + ph.ox0;
                 // (oy / ox past the output: the ragged phase grid of an odd-sized transposed output)
                 const bool ok = m < p.M && oy < p.Hout && ox < p.Wout;
-                const int poff = (oy * p.Wout + ox) * p.Cout_s * 4;
+                const unsigned poff = (unsigned)((oy * p.Wout + ox) * p.Cout_s) * 4u;
 #pragma unroll
                 for (int j = 0; j < Cfg::TN; ++j) {
                     const float v = creal[j] ? act(acc[i][j][r], j) : 0.f;
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ysrd, ok ? poff + coff[j] : kDrop, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ysrd, (int)(ok ? poff + coff[j] : kDrop), 0, 0);
                 }
             }
     };
@@ -1005,6 +1007,18 @@ int wino_gemm_sk_grid_blocks() {
     }
     return n;
 }
+// the one-block-per-CU forms ask for 108-120 KiB of dynamic LDS (3-deep rings of 160/192/256-row stages): a device whose
+// opt-in limit is below that (64 KiB parts) takes the tile-per-block / two-per-CU forms instead of failing the frame
+static int lds_optin_bytes() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || v <= 0)
+            v = 64 * 1024;
+        n = v;
+    }
+    return n;
+}
 constexpr int kSkMaxGrid = 1024;
 size_t wino_gemm_sk_scratch_floats() { return (size_t)kSkMaxGrid * (4 * 64 * 64 + 4 * 2); }
 
@@ -1030,7 +1044,7 @@ static int sk_tall_rows(int groups, int rows, int T, int N) {     // tile rows o
     int bm = 0, mt = 1;
     if (rows > 128 && rows <= 160 && T >= 160) bm = 160;
     else if ((mode >= 2 || overlap_hint()) && T % 256 == 0 && rows > T - 32 && T <= 512) bm = 256, mt = T / 256;  // 256 (one 512x512 image) | 512 (two)
-    if (!bm) return 0;
+    if (!bm || lds_optin_bytes() < 3 * (bm == 160 ? CfgT::STAGE_BYTES : CfgT8::STAGE_BYTES)) return 0;
     const long tiles = (long)groups * mt * (N / 128), grid = wino_gemm_sk_grid_blocks() / 2;
     return (tiles >= grid && tiles * 100 <= ((tiles + grid - 1) / grid) * grid * 90) ? bm : 0;
 }
@@ -1168,6 +1182,7 @@ static bool skt_split(int rows, int* mt_count, int* base, int* extra) {
 bool wino_gemm_skt_ok(int groups, int rows, int Tp, int K, int N, int c_cs) {
     int mt, base, extra;
     if (options().wino_gemm_sk_ragged < 2 || !skt_split(rows, &mt, &base, &extra)) return false;
+    if (lds_optin_bytes() < 3 * CfgR6::STAGE_BYTES) return false;
     const long cgs = (long)groups * (N / 128), grid = wino_gemm_sk_grid_blocks() / 2;
     if (cgs * mt < grid) return false;                                              // (at least one tile per block)
     return wino_gemm_skr_ok(groups, rows, Tp, K, N, c_cs);

@@ -258,11 +258,12 @@ def run_test(opt, model=None, device=None, dataset=None):
             tq = time.perf_counter()
             now = []
             for (gh, gw), members in groups.items():
+                tg = time.perf_counter()      # per group: an earlier group's tensor2im / D2H is not this one's generator time
                 if len(members) > 1 and not model.lockstep_pays(gh, gw):      # (same frames either way: one call per sequence)
                     outs = [model.inference_nhwc_batch([L.window], [L.rec])[0] for _, L, _ in members]
                 else:
                     outs = model.inference_nhwc_batch([L.window for _, L, _ in members], [L.rec for _, L, _ in members])
-                split["generator_s"] = split.get("generator_s", 0.0) + time.perf_counter() - tq
+                split["generator_s"] = split.get("generator_s", 0.0) + time.perf_counter() - tg
                 for (k, L, data), out in zip(members, outs):
                     t1 = time.perf_counter()
                     u8 = ops.tensor2im_u8(out)

@@ -164,9 +164,21 @@ def batched_weight_gradients(params):
     _DW_PAIR[0] = os.environ.get("T2V_WGRAD_PAIR", "1") != "0"
     try:
         yield
-    finally:
+    except BaseException:
         _WG_BATCH[0] = False
         _DW_PAIR[0] = False
+        raise
+    _WG_BATCH[0] = False
+    _DW_PAIR[0] = False
+    # a backward pass inside this scope that did not end with flush_pending_weight_gradients() would silently lose the
+    # gradients still parked on the weights (the first half of a pair, transformed slots waiting for their reduction)
+    left = [i for i, p in enumerate(params) if getattr(p, "_t2v_dw_stash", None) is not None
+            or (getattr(p, "_t2v_wg_state", None) is not None and p._t2v_wg_state[1] > 0)]
+    for p in params:
+        p._t2v_dw_stash, p._t2v_dw_uses, p._t2v_wg_state, p._t2v_wg_images = None, 0, None, 0
+    if left:
+        raise RuntimeError("batched_weight_gradients: %d parameter(s) (first: #%d) left the scope with an unreduced weight "
+                           "gradient -- call flush_pending_weight_gradients(params, grads) after the backward pass" % (len(left), left[0]))
 
 
 # ---- weight gradients on a second stream ---------------------------------------------------------------------------
