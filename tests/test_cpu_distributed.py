@@ -330,3 +330,141 @@ def test_chunks_per_rank_reproduces_the_finer_plan_on_fewer_ranks():
     p = plan_units({"a": 10, "b": 8}, 2, 3, shard_chunks=True, chunks_per_rank=2)
     assert [sorted({u[0] for u in r}) for r in p] == [["a"], ["b"]]
     assert plan_units({"a": 10}, 1, 3, shard_chunks=False, chunks_per_rank=4) == [[("a", 0, 10, 2)]]     # only with --shard_chunks
+
+
+# ---- world 8: the metric's other half ("1/2/4/8 MI355X"; the reference's train recipe is 8-way, README.md:171-176) ----------
+# every multi-process test above runs exactly two ranks.  The same code paths with EIGHT live gloo ranks:
+# the chunk plan of configs[2], the two-sequence layout of configs[0] (six ranks idle -- they still have to take part in
+# every collective), the ragged frame gather, and both forms of the gradient exchange with parameter sizes that are not
+# multiples of 8.
+
+WORLD8 = 8
+
+
+@pytest.mark.parametrize("seq_lengths,mode", [
+    ({"seq": 514}, (True, 0, 1, None)),                       # configs[2]: 512 frames -> 8 chunks of 64
+    ({"seq": 514}, (True, 3, 1, None)),                       # ... with a 3-frame stitch pass (the 2-frame FIFO all-gather)
+    ({"tmp": 87, "tmp_smooth": 87}, (False, 0, 1, None)),     # configs[0]'s layout, whole sequences: 6 idle ranks
+    ({"tmp": 87, "tmp_smooth": 87}, (False, 3, 1, None)),     # ... idle ranks inside the tail exchange
+    ({"a": 9, "b": 14, "c": 5}, (True, 2, 2, 17)),            # fewer sequences than ranks, how_many cap, two stitch rounds
+], ids=["cfg2-chunks", "cfg2-chunks-stitched", "cfg0-whole", "cfg0-whole-stitch-on", "ragged-cap"])
+def test_eight_rank_gloo_unit_plans(tmp_path, seq_lengths, mode):
+    from text2video_amd.distributed import plan_units
+    shard, stitch, rounds, how_many = mode
+    mp.spawn(_stitch_worker, args=(WORLD8, _free_port(), seq_lengths, mode, str(tmp_path)), nprocs=WORLD8, join=True)
+    got = _collect(tmp_path)                # (asserts that no frame was produced twice)
+    plan = plan_units(seq_lengths, WORLD8, 3, shard, how_many)
+    assert len(plan) == WORLD8
+    # every output frame the single-process loop would write (how_many: global, dataset order) exists exactly once
+    want_keys, budget = set(), how_many
+    for seq, n in seq_lengths.items():
+        for t in range(2, n):
+            if budget is not None and budget <= 0:
+                break
+            want_keys.add((seq, t))
+            budget = None if budget is None else budget - 1
+    assert set(got) == want_keys
+    if shard:
+        assert all(len(p) >= 1 for p in plan) or sum(len(p) for p in plan) < WORLD8
+    else:
+        assert sum(1 for p in plan if p) == len(seq_lengths)              # whole sequences: the other ranks are idle
+    # frames: a unit that starts a sequence equals the single-process frames up to the first cut; after a cut, the first
+    # `stitch` frames continue from the predecessor's tail, i.e. equal a run over the two chunks joined
+    for p in plan:
+        for seq, s, e, first_out in p:
+            poses = _poses(seq, seq_lengths[seq])
+            if s == 0:
+                ref = _fake_generate(poses[:e])
+                for j in range(ref.shape[0]):
+                    assert torch.equal(got[(seq, 2 + j)], ref[j]), (seq, j)
+            elif stitch == 0:
+                ref = _fake_generate(poses[s:e])                           # a chunk restarts the recurrence
+                for j in range(ref.shape[0]):
+                    assert torch.equal(got[(seq, first_out + j)], ref[j]), (seq, first_out + j)
+    if shard and stitch and seq_lengths == {"seq": 514}:
+        # one round: every continuation chunk's first 3 frames come from its predecessor's (unstitched) tail
+        chunks = sorted(u for p in plan for u in p)
+        for (seq, s0, e0, f0), (_, s1, e1, f1) in zip(chunks, chunks[1:]):
+            poses = _poses(seq, 514)
+            pre, tail = _fake_generate_from(poses[s0:e0], None, None)
+            cont, _ = _fake_generate_from(poses[s1:e1], tail, 3)
+            for j in range(3):
+                assert torch.equal(got[(seq, f1 + j)], cont[j]), (f1, j)
+
+
+def _gather8_worker(rank, world, port, tmpdir):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from text2video_amd import distributed as D
+    D.init_from_env("gloo")
+    counts = [5, 0, 3, 0, 0, 7, 1, 0]                          # ragged, several ranks with nothing at all
+    local = torch.full((counts[rank], 2, 3), float(rank)) + torch.arange(counts[rank], dtype=torch.float32).view(-1, 1, 1) / 16
+    blocks = D.gather_ragged_frames(local, counts)
+    assert [b.shape[0] for b in blocks] == counts
+    for r, b in enumerate(blocks):
+        for j in range(counts[r]):
+            assert torch.equal(b[j], torch.full((2, 3), r + j / 16.0))
+    full = D.gather_frames(torch.full((2, 4), float(rank)))
+    assert full.shape == (16, 4) and all(torch.equal(full[2 * r:2 * r + 2], torch.full((2, 4), float(r))) for r in range(world))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_rank_gloo_ragged_frame_gather(tmp_path):
+    mp.spawn(_gather8_worker, args=(WORLD8, _free_port(), str(tmp_path)), nprocs=WORLD8, join=True)
+
+
+def _buckets8_worker(rank, world, port, tmpdir, rs_ag):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), T2V_GRAD_RS_AG="1" if rs_ag else "0")
+    from text2video_amd import distributed as D
+    from text2video_amd import train as T
+    D.init_from_env("gloo")
+    sizes = (7, 70001, 3, (1 << 18) + 5, 17, 41, 1)            # none a multiple of 8
+    params = [torch.nn.Parameter(torch.zeros(n)) for n in sizes]
+    gb = T.GradBuckets(params, bucket_mb=0.5)
+    assert len(gb.bounds) >= 3 and all((hi - lo) % (256 * world) == 0 for lo, hi in gb.bounds)
+    gen = torch.Generator().manual_seed(1234)                  # every rank draws ALL ranks' gradients: the mean is known locally
+    for step in range(2):
+        per_rank = [[torch.randn(n, generator=gen) for n in sizes] for _ in range(world)]
+        gb.begin_step()
+        uses = [1, 2, 1, 1, 3, 1, 1]
+        for p, u in zip(params, uses):
+            for _ in range(u):
+                T.expect_gradient(p)
+        gb.seal()
+        for i in reversed(range(len(params))):
+            for k in range(uses[i]):
+                T.deliver(T.grad_slot(params[i]), per_rank[rank][i] * (k + 1))
+        assert gb._launched >= 1
+        gb.absorb([None] * len(params))
+        nbytes = gb.finish()
+        assert nbytes == 4 * sum(sizes)
+        for i, p in enumerate(params):
+            scale = sum(k + 1 for k in range(uses[i]))
+            want = torch.stack([per_rank[r][i] for r in range(world)]).double().mean(0).float() * scale
+            assert p.grad.data_ptr() == gb.slots[i].view.data_ptr()
+            assert torch.allclose(p.grad, want, rtol=1e-5, atol=1e-6), (i, (p.grad - want).abs().max().item())
+        T.check_presence_across_ranks([gb], "cpu")
+    # replicas: the averaged gradients are the same bits on every rank (what keeps 8 optimiser replicas in step)
+    digest = torch.tensor([float(gb.flat.double().sum().item())], dtype=torch.float64)
+    all_d = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(all_d, digest)
+    assert all(torch.equal(all_d[0], d) for d in all_d)
+    # plain (non-bucketed) exchange at world 8
+    from text2video_amd.train import allreduce_gradients
+    ps = [torch.nn.Parameter(torch.zeros(n)) for n in (5, 70001, 3)]
+    for i, p in enumerate(ps):
+        p.grad = torch.full_like(p, float(rank + 1) * (i + 1))
+    assert allreduce_gradients(ps, bucket_mb=1) == 4 * 70009
+    for i, p in enumerate(ps):
+        assert torch.allclose(p.grad, torch.full_like(p, (world + 1) / 2.0 * (i + 1)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("rs_ag", [False, True], ids=["all_reduce", "reduce_scatter_all_gather"])
+def test_eight_rank_gloo_grad_buckets_average_equals_mean_of_rank_gradients(tmp_path, rs_ag):
+    """GradBuckets at world 8, AVG all-reduce and reduce-scatter + all-gather, parameter sizes that are no multiples of 8 (the
+    buckets pad to 256 * world): every parameter's gradient equals the mean over the eight ranks' own gradients, and the
+    flat buffers are bit-equal on all ranks afterwards."""
+    mp.spawn(_buckets8_worker, args=(WORLD8, _free_port(), str(tmp_path), rs_ag), nprocs=WORLD8, join=True)

@@ -1,0 +1,187 @@
+"""World-8 dress rehearsal on ONE GPU.  BASELINE's metric is quoted at 1/2/4/8 MI355X and the reference's
+train recipe is 8-way (/root/reference/README.md:171-176, fan-out mechanism
+venv_vid2vid/.../torch/nn/parallel/data_parallel.py:112-120); an 8-GPU node is the driver's to launch, not ours.  What one
+GPU can execute is everything but the wire: the three literal multi-GPU command lines with EIGHT live ranks sharing this
+device (T2V_DIST_BACKEND=gloo -- RCCL refuses two ranks per device; the collectives stage through host memory), started
+plainly so that the entry points' own fan-out (text2video_amd/launch.py) is what runs:
+
+    python bench.py --gpus 8 --steps 6
+    python test.py <reference flags> --gpu_ids 0,1,2,3,4,5,6,7 --shard_chunks
+    python train.py ... --gpu_ids 0,1,2,3,4,5,6,7 --batchSize 8
+
+checked for: the contract line with n_gpus 8, frames equal to the 1-rank run of the same 8-chunk plan, replica weights
+equal on 8 ranks, and nothing left behind (no rank process, no held rendezvous port)."""
+import glob
+import json
+import os
+import shutil
+import subprocess
+import sys
+import time
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+IDS8 = "0,1,2,3,4,5,6,7"
+
+
+def _plain_env(port):
+    """no torchrun variables (the entry points fan out themselves); the first attempt's rendezvous port pinned so that the
+    test can look for it afterwards"""
+    env = dict(os.environ, CUDA_VISIBLE_DEVICES="0", T2V_DIST_BACKEND="gloo", T2V_LAUNCH_PORT=str(port))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "T2V_DEVICE_IDS", "T2V_SELF_LAUNCHED"):
+        env.pop(k, None)
+    return env
+
+
+def _free_port():
+    from text2video_amd.launch import free_port
+    return free_port()
+
+
+def _nothing_left_behind(port):
+    """no process still carries this job's rendezvous port in its environment, and nobody listens on the port"""
+    import psutil
+    from text2video_amd.launch import _port_taken
+    t_end = time.time() + 10.0
+    left = None
+    while time.time() < t_end:
+        left = []
+        for p in psutil.process_iter(["pid"]):
+            try:
+                e = p.environ()
+            except (psutil.Error, OSError):
+                continue
+            if e.get("MASTER_PORT") == str(port) and e.get("T2V_SELF_LAUNCHED") == "1":
+                left.append(p.pid)
+        if not left and not _port_taken(port):
+            return
+        time.sleep(0.25)
+    raise AssertionError("ranks left behind: %s, port %d taken: %s" % (left, port, _port_taken(port)))
+
+
+def test_bench_gpus_8_plain_command_contract_line():
+    """`python bench.py --gpus 8 --steps 6`: eight ranks of the FULL-width generator (8 x 1.5 GB of weights on this one
+    device), barrier + MAX-over-ranks timing, ONE JSON line from rank 0; the configs[4] block runs a real 8-rank bucketed
+    exchange (narrow nets: 1.5 GB through host-staged gloo takes minutes) and reports the replicas in sync."""
+    port = _free_port()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "6", "--warmup", "2",
+                        "--kernel-iters", "2", "--single-variant", "--train-steps", "1", "--train-ngf", "32"],
+                       cwd=ROOT, env=_plain_env(port), capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["steps"] == 6 and d["warmup"] == 2 and d["scaling"] == "weak"
+    assert d["config"]["parallelism"] == "sequence-chunk dp8" and d["config"]["collectives"] == "gloo"
+    assert d["cpu_baseline"] is None and d["e2e"] is None and "hires" not in d                 # N = 1 legs only
+    assert d["metric"].startswith("frames/sec") and d["unit"] == "frames/s" and d["dtype"] == "f32"
+    # value = the frames of ALL eight ranks over the slowest rank's time
+    assert abs(d["value"] - 8 * 1e3 / d["ms_per_step"]) <= 0.01 * d["value"]
+    assert d["value"] > 3.0        # eight processes time-slicing ONE GPU (measured 10.4 fps: context switches between eight
+                                   # HIP contexts, not eight devices) -- the figure is not a prediction of anything
+    t = d["train_step"]
+    assert t["exchange"]["group"] == "8-rank gloo" and t["exchange"]["replicas_in_sync"] is True
+    assert t["exchange"]["bytes"] > 5e7
+    _nothing_left_behind(port)
+
+
+def _dataset(work, seqs, size=(128, 96)):
+    from PIL import Image
+    from text2video_amd.keypoints import read_keypoints
+    src = os.path.join(ROOT, "tests", "golden", "keypoints_fadg0")
+    files = sorted(f for f in os.listdir(src) if f.startswith("sa1_"))
+    root = os.path.join(work, "datasets", "fadg0")
+    img = Image.fromarray(read_keypoints(os.path.join(src, files[0]), size))
+    for seq, n in seqs.items():
+        os.makedirs(os.path.join(root, "test_openpose", seq))
+        os.makedirs(os.path.join(root, "test_img", seq))
+        for i in range(n):
+            shutil.copyfile(os.path.join(src, files[(i * 5 + len(seq)) % len(files)]),
+                            os.path.join(root, "test_openpose", seq, "%05d.json" % i))
+            img.save(os.path.join(root, "test_img", seq, "%04d.jpg" % i))
+
+
+def _test_py(work, extra, env):
+    # the reference's flag line (text2video_audio.sh:37-42) at loadSize 128 with a narrow synthetic generator
+    cmd = [sys.executable, os.path.join(ROOT, "vid2vid", "test.py"), "--name", "fadg0", "--dataroot", "datasets/fadg0",
+           "--dataset_mode", "pose", "--input_nc", "3", "--resize_or_crop", "scaleHeight", "--loadSize", "128", "--openpose_only",
+           "--how_many", "1200", "--no_first_img", "--random_drop_prob", "0", "--synthetic_weights", "1", "--ngf", "16",
+           "--n_blocks", "2", "--n_downsample_G", "2", "--pose_workers", "2"] + extra
+    r = subprocess.run(cmd, cwd=work, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    return r
+
+
+def _frames(work):
+    return {os.path.relpath(p, work): open(p, "rb").read()
+            for p in sorted(glob.glob(os.path.join(work, "results", "fadg0", "test_latest", "*", "fake_B_*.jpg")))}
+
+
+def test_test_py_gpu_ids_0_to_7_shard_chunks_equals_the_one_rank_chunk_plan(tmp_path):
+    """configs[2]'s command shape: one sequence cut into 8 chunks, one rank per listed device.  The JPEG files must equal
+    (a) the ONE-process run of the same plan (--shard_chunks --chunks_per_rank 8: eight chunks in lock-step on one rank) and,
+    with the stitch pass over the whole chunk length and 7 rounds, (b) the unsharded run.  Also the configs[0] layout -- two
+    sequences, eight ranks, whole-sequence sharding: six ranks have nothing to do and must leave cleanly."""
+    ws = {k: str(tmp_path / k) for k in ("single", "plan_one_rank", "eight", "eight_stitched")}
+    for w in ws.values():
+        os.makedirs(w)
+        _dataset(w, {"tmp": 2 + 8 * 3})                 # 24 output frames: 8 chunks of 3
+    port = _free_port()
+    env = _plain_env(port)
+    _test_py(ws["single"], [], env)
+    _test_py(ws["plan_one_rank"], ["--shard_chunks", "--chunks_per_rank", "8"], env)
+    _test_py(ws["eight"], ["--gpu_ids", IDS8, "--shard_chunks"], env)
+    _nothing_left_behind(port)
+    port2 = _free_port()
+    _test_py(ws["eight_stitched"], ["--gpu_ids", IDS8, "--shard_chunks", "--stitch_frames", "100", "--stitch_rounds", "7"],
+             _plain_env(port2))
+    _nothing_left_behind(port2)
+    one, plan1, eight, st = (_frames(ws[k]) for k in ("single", "plan_one_rank", "eight", "eight_stitched"))
+    assert len(one) == 24 and one.keys() == plan1.keys() == eight.keys() == st.keys()
+    assert all(eight[k] == plan1[k] for k in eight), [k for k in eight if eight[k] != plan1[k]]
+    names = sorted(one)
+    assert all(one[k] == eight[k] for k in names[:3]) and any(one[k] != eight[k] for k in names[3:])     # seams at the cuts
+    assert all(one[k] == st[k] for k in names), [k for k in names if one[k] != st[k]]
+    # configs[0]'s layout on eight ranks
+    wa, wb = str(tmp_path / "two_seq_one"), str(tmp_path / "two_seq_eight")
+    for w in (wa, wb):
+        os.makedirs(w)
+        _dataset(w, {"tmp": 7, "tmp_smooth": 6})
+    port3 = _free_port()
+    _test_py(wa, [], _plain_env(port3))
+    _test_py(wb, ["--gpu_ids", IDS8], _plain_env(port3))
+    _nothing_left_behind(port3)
+    a, b = _frames(wa), _frames(wb)
+    assert len(a) == 5 + 4 and a.keys() == b.keys() and all(a[k] == b[k] for k in a)
+
+
+def test_readme_train_command_gpu_ids_0_to_7_batch_8(tmp_path):
+    """/root/reference/README.md:171-176's recipe, `python train.py ... --gpu_ids 0,1,2,3,4,5,6,7 --batchSize 8` (narrow nets,
+    64x64 crops): one rank per listed device, one clip per rank, the bucketed exchange (buckets padded to 256 * 8) averages
+    G's, D's and D_f's gradients over the eight ranks, and after three steps all eight replicas hold the same weights --
+    checked inside run_train by an all-gather of per-network checksums (it raises otherwise)."""
+    port = _free_port()
+    cmd = [sys.executable, os.path.join(ROOT, "vid2vid", "train.py"), "--name", "dp8", "--dataset_mode", "pose",
+           "--input_nc", "3", "--num_D", "2", "--resize_or_crop", "randomScaleHeight_and_scaledCrop", "--loadSize", "68",
+           "--fineSize", "64", "--gpu_ids", IDS8, "--batchSize", "8", "--max_frames_per_gpu", "2", "--niter", "3",
+           "--niter_decay", "0", "--no_first_img", "--n_frames_total", "12", "--max_t_step", "4", "--add_face_disc",
+           "--openpose_only", "--ngf", "16", "--n_blocks", "2", "--n_downsample_G", "2", "--ndf", "16", "--no_vgg",
+           "--synthetic_data", "--checkpoints_dir", str(tmp_path / "ck")]
+    r = subprocess.run(cmd, cwd=str(tmp_path), env=_plain_env(port), capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    assert "replicas in sync after 3 steps" in r.stdout and "on all 8 ranks" in r.stdout
+    assert "done: 3 steps" in r.stdout and "on 8 GPU(s)" in r.stdout
+    assert "warning: --batchSize" not in r.stdout
+    line = [l for l in r.stdout.splitlines() if l.startswith("(iter")][-1]
+    assert float(line.split("all-reduce")[1].split("MB")[0]) > 1.0, line
+    assert os.path.exists(tmp_path / "ck" / "dp8" / "latest_net_G0.pth")
+    # the same recipe through the reduce-scatter + all-gather form of the exchange
+    port2 = _free_port()
+    r = subprocess.run(cmd[:-1] + [str(tmp_path / "ck2")], cwd=str(tmp_path), env=dict(_plain_env(port2), T2V_GRAD_RS_AG="1"),
+                       capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    assert "replicas in sync after 3 steps" in r.stdout and "on all 8 ranks" in r.stdout
+    _nothing_left_behind(port)
+    _nothing_left_behind(port2)

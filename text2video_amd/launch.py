@@ -55,13 +55,16 @@ def _die_with_parent():
 
 
 def _port_taken(port):
-    """True when somebody holds 127.0.0.1:port now (the ranks of a failed attempt are gone by the time this is asked)"""
+    """True when somebody LISTENS on 127.0.0.1:port now (the ranks of a failed attempt are gone by the time this is asked).
+    A connect, not a bind: the port of a finished job stays un-bindable for a minute (its connections sit in TIME_WAIT)
+    although nobody holds it."""
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.settimeout(1.0)
         try:
-            s.bind(("127.0.0.1", port))
-            return False
-        except OSError:
+            s.connect(("127.0.0.1", port))
             return True
+        except OSError:
+            return False
 
 
 def self_launch(nranks, device_ids=None, argv=None, poll_s=0.05):
