@@ -541,7 +541,94 @@ def run_e2e(model_head, model_other, head_flow, n_frames):
     return dict({"path": "run_test == vid2vid/test.py: rasterise (bit-exact) -> H2D -> generator -> D2H -> JPEG", "runs": out}, **meta)
 
 
-def cold_start_block(n_maps=87, ab_envs=None, ab_reps=3, wrap=None):
+UTTERANCE = "She had your dark suit in greasy wash water all year."      # configs[0] (BASELINE.json), fixture tests/golden/l2_inputs
+
+
+def utterance_block(tmp, ckpt_dir, env):
+    """The whole post-alignment utterance as /root/reference/text2video_audio.sh:24-44 chains it -- three processes, each
+    started from the directory the script cd's into, on the configs[0] fixture (tests/golden/l2_inputs = the reference's
+    Text2Video data layout: time stamps, unit tables, key poses):
+
+        (Text2Video)  python interp_landmarks_motion_phoneme_VidTIMIT_smooth.py "$1" $2          [:31]
+        (vid2vid)     python test.py --name $2 --dataroot datasets/$2 ... --random_drop_prob 0      [:42]
+        (vid2vid)     python image2video_real_audio_text2video.py "$1" $2                         [:44]
+
+    wall seconds of each (perf_counter around subprocess.run, the script's `rm -f` lines included), run twice -- and of the
+    in-memory route (`python -m text2video_amd.pipeline`: one process, no JSON / skeleton-JPEG round trip, frames muxed by the
+    same process).  The reference's L2 script alone takes 11.9 s on this fixture (measured in the build container)."""
+    import glob
+    import shutil
+    import subprocess
+    person = "fadg0"
+    t2v, v2v = os.path.join(tmp, "Text2Video"), os.path.join(tmp, "vid2vid")
+    shutil.copytree(os.path.join(ROOT, "tests", "golden", "l2_inputs"), t2v)
+    os.makedirs(os.path.join(t2v, "input_audio_real", person))
+    shutil.copyfile(os.path.join(ROOT, "tests", "golden", "audio", "Shehadyour.mp3"),
+                    os.path.join(t2v, "input_audio_real", person, "Shehadyour.mp3"))
+    os.makedirs(v2v)
+    os.symlink(ckpt_dir, os.path.join(v2v, "checkpoints"))          # test.py's default --checkpoints_dir, as the literal line needs
+    flags = ("--name %s --dataroot datasets/%s --dataset_mode pose --input_nc 3 --resize_or_crop scaleHeight --loadSize 512 "
+             "--openpose_only --how_many 1200 --no_first_img --random_drop_prob 0" % (person, person)).split()
+    stages = (("l2_driver_s", t2v, [os.path.join(ROOT, "Text2Video", "interp_landmarks_motion_phoneme_VidTIMIT_smooth.py"), UTTERANCE, person]),
+              ("test_py_s", v2v, [os.path.join(ROOT, "vid2vid", "test.py")] + flags),
+              ("mux_s", v2v, [os.path.join(ROOT, "vid2vid", "image2video_real_audio_text2video.py"), UTTERANCE, person]))
+
+    def clean():                                                     # the script's rm -f lines (:24-28, :39-40)
+        for d in ("datasets/%s/test_openpose" % person, "datasets/%s/test_img" % person, "results/%s/test_latest" % person):
+            for seq in ("tmp", "tmp_smooth"):
+                for f in glob.glob(os.path.join(v2v, d, seq, "*")):
+                    os.remove(f)
+
+    def chain(extra_env=None):
+        out = {}
+        t_all = time.perf_counter()
+        clean()
+        for key, cwd, argv in stages:
+            t0 = time.perf_counter()
+            r = subprocess.run([sys.executable] + argv, cwd=cwd, env=dict(env, **(extra_env or {})), stdout=subprocess.DEVNULL,
+                               stderr=subprocess.PIPE, text=True)
+            out[key] = round(time.perf_counter() - t0, 3)
+            if r.returncode != 0:
+                return {"error": "%s: %s" % (key, r.stderr[-300:])}
+        out["wall_s"] = round(time.perf_counter() - t_all, 3)
+        return out
+
+    runs = [chain(), chain()]
+    if any("error" in r for r in runs):
+        return {"error": [r.get("error") for r in runs]}
+    frames = len(glob.glob(os.path.join(v2v, "results", person, "test_latest", "*", "fake_B_*.jpg")))
+    videos = sorted(os.path.basename(f) for f in glob.glob(os.path.join(v2v, "results", person, "*.mp4")))
+    # one process: L2 in memory -> frame loop -> mux (text2video_amd/pipeline.py)
+    mem = []
+    for _ in range(2):
+        t0 = time.perf_counter()
+        r = subprocess.run([sys.executable, "-m", "text2video_amd.pipeline", UTTERANCE, person, "--l2_root", "../Text2Video",
+                            "--results_dir", os.path.join(tmp, "results_mem"), "--write_video", "--video_audio",
+                            os.path.join(t2v, "input_audio_real", person, "Shehadyour.mp3")], cwd=v2v,
+                           env=dict(env, PYTHONPATH=ROOT + os.pathsep + env.get("PYTHONPATH", "")), stdout=subprocess.DEVNULL,
+                           stderr=subprocess.PIPE, text=True)
+        if r.returncode != 0:
+            mem = {"error": r.stderr[-300:]}
+            break
+        mem.append(round(time.perf_counter() - t0, 3))
+    # the unchanged three-process chain with the weights resident between utterances (T2V_RESIDENT=1 in the environment of
+    # the unchanged script): the call that starts the server, then a warm utterance
+    renv = {"T2V_RESIDENT": "1", "T2V_RESIDENT_KEY": "bench-utt-%d" % os.getpid()}
+    try:
+        rfirst, rwarm = chain(renv), chain(renv)
+    finally:
+        subprocess.run([sys.executable, os.path.join(ROOT, "vid2vid", "test.py")] + flags + ["--resident_stop"], cwd=v2v,
+                       env=dict(env, **renv), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    last = runs[-1]
+    return {"what": "text2video_audio.sh:24-44 after the aligner, configs[0] utterance: L2 driver | test.py | image2video as 3 processes",
+            "frames": frames, "videos": len(videos), "chain_runs": runs, "chain_wall_s": last["wall_s"],
+            "l2_plus_mux_s": round(last["l2_driver_s"] + last["mux_s"], 3),
+            "l2_plus_mux_below_test_py": bool(last["l2_driver_s"] + last["mux_s"] < last["test_py_s"]),
+            "in_memory_pipeline_wall_s": mem, "chain_resident_warm": rwarm, "chain_resident_first_wall_s": rfirst.get("wall_s"),
+            "reference_l2_driver_s": 11.9}
+
+
+def cold_start_block(n_maps=87, ab_envs=None, ab_reps=3, wrap=None, utterance=False):
     """The reference starts one process per utterance (text2video_audio.sh:37-44: `cd ../vid2vid; python test.py ...`): the
     wall time of exactly that command on the configs[0] utterance -- two sequences (tmp, tmp_smooth) of 87 pose maps = 2 x 85
     frames, 512x384 sources -> scaleHeight 512 + central crop = 512x320, full-size generator with its flow branch read from a
@@ -645,7 +732,9 @@ def cold_start_block(n_maps=87, ab_envs=None, ab_reps=3, wrap=None):
                            stderr=subprocess.DEVNULL)
         resident = None if not rwalls else {"first_call_wall_s": rwalls[0], "warm_call_wall_s": rwalls[1], "warm_loop_s": rloop,
                                             "warm_wall_over_loop": round(rwalls[1] / max(rloop, 1e-9), 2)}
-        return {"command": "python vid2vid/test.py <text2video_audio.sh:42 flags> as a subprocess: tmp + tmp_smooth, 2 x %d frames "
+        utt = utterance_block(tmp, os.path.join(tmp, "ckpt"), env) if utterance else None
+        return {"utterance": utt,
+                "command": "python vid2vid/test.py <text2video_audio.sh:42 flags> as a subprocess: tmp + tmp_smooth, 2 x %d frames "
                            "512x320, %.2f GB checkpoint" % (n_maps - 2, os.path.getsize(os.path.join(tmp, "ckpt", "fadg0", "latest_net_G0.pth")) / 1e9),
                 "frames": split["frames"], "wall_s": walls, "split_of_last_run": cs, "with_torch": with_torch,
                 "resident": resident,
@@ -852,6 +941,8 @@ def main():
             torch.set_num_threads(cores)
             best = max(by_threads, key=lambda k: by_threads[k])
             cpu = {"value": round(by_threads[best], 4), "unit": "frames/s", "cores": best, "kind": "port",
+                   # the box: logical CPUs the host has / this process may run on (`cores` = the thread count that won)
+                   "host_logical_cpus": os.cpu_count(), "host_cpus_available": len(os.sched_getaffinity(0)),
                    "sample": "%d frames %dx%d (%s) after 1 warm-up frame, torch %s CPU fp32; fastest of %s threads"
                              % (nf, H, W, "flow branch on" if head_flow else "no flow branch", torch.__version__,
                                 "/".join(str(k) for k in sorted(by_threads, reverse=True))),
@@ -862,7 +953,8 @@ def main():
         if args.e2e_frames > 0 and world == 1 and args.scales == 1:
             e2e = run_e2e(model, other, head_flow, args.e2e_frames)
             if default_geometry and not args.no_cold_start:
-                e2e["cold_start"] = cold_start_block()
+                e2e["cold_start"] = cold_start_block(utterance=True)
+                e2e["utterance"] = e2e["cold_start"].pop("utterance", None)
         variants = {("flow_fps" if head_flow else "noflow_fps"): round(fps, 3)}
         if other_elapsed is not None:
             variants["noflow_fps" if head_flow else "flow_fps"] = round(world * K / other_elapsed, 3)

@@ -52,6 +52,23 @@ def test_file_contract(tmp_path):
     assert np.array_equal(img, read_keypoints(js, (512, 384)))        # parsed dict == file
 
 
+def test_forked_writers_produce_the_same_files(tmp_path):
+    """run() hands the per-frame files (JSON + skeleton JPEG) to forked writer processes; every file equals the in-process
+    writer's, byte for byte."""
+    text, person, spec, gold, n = CASES[0]
+    a, b = tmp_path / "one", tmp_path / "forked"
+    L.run(text, person, root=INPUTS, spec=spec, dataset_root=str(a), log=lambda *x: None, workers=1)
+    L.run(text, person, root=INPUTS, spec=spec, dataset_root=str(b), log=lambda *x: None, workers=4)
+    count = 0
+    for dirpath, _, files in os.walk(a):
+        for f in files:
+            pa = os.path.join(dirpath, f)
+            pb = os.path.join(str(b), os.path.relpath(pa, str(a)))
+            assert open(pa, "rb").read() == open(pb, "rb").read(), pa
+            count += 1
+    assert count == 4 * n and count == sum(len(fs) for _, _, fs in os.walk(b))
+
+
 def test_key_interval_rules():
     ts = [[0, "a"], [2, "b"], [5, "c"], [9, "d"], [10, "e"]]
     # phoneme driver: gap >= 4 keeps the next key; closer keys are jumped over; the last pair is always taken

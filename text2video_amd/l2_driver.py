@@ -243,30 +243,55 @@ def synthesize(text, person, root=".", spec=PHONEME, ts=None, bank=None):
     return raw, smooth_sequence(raw, spec)
 
 
-def run(text, person, root=".", spec=PHONEME, dataset_root=None, write_images=True, log=print):
+def _write_frame(job):
+    """one frame's two files: the OpenPose JSON and (write_images) its skeleton JPEG"""
+    pose_path, img_path, js, size = job
+    with open(pose_path, "w") as fh:
+        json.dump(js, fh)
+    if img_path is not None:
+        from PIL import Image
+        from .keypoints import read_keypoints
+        img = read_keypoints(js, size)
+        # cv2.imwrite stores the array as BGR; with --no_first_img only the image SIZE is used downstream
+        Image.fromarray(np.ascontiguousarray(img[..., ::-1])).save(img_path)
+
+
+def run(text, person, root=".", spec=PHONEME, dataset_root=None, write_images=True, log=print, workers=None):
     """The reference's file contract: JSON (+ skeleton JPEG) per frame under
-    <dataset_root>/<person>/test_{openpose,img}/{tmp,tmp_smooth}/ [REF :28-37,:213-267]."""
-    from .keypoints import read_keypoints
+    <dataset_root>/<person>/test_{openpose,img}/{tmp,tmp_smooth}/ [REF :28-37,:213-267].
+    The frames' files are independent of each other (6 ms of rasterising + JPEG + JSON each, 2 x 87 of them for the configs[0]
+    utterance = 1.1 s of this script's 1.4 s): they are written by `workers` forked processes (default: up to 8; this process
+    holds no HIP runtime, so a fork costs nothing).  Same files, same bytes (tests/test_cpu_l2_driver.py)."""
     dataset_root = dataset_root or os.path.join(root, "..", "vid2vid", "datasets")
     base = os.path.join(dataset_root, person)
     raw, smooth = synthesize(text, person, root, spec)
     log("total_frame_num %d" % (len(raw) - 1))
     size = canvas_size(spec, person)
     digits = 4 if spec.kind == "phoneme" else 5
+    jobs = []
     for seq, frames, stem in (("tmp", raw, ""), ("tmp_smooth", smooth, "smooth_")):
         pose_dir = os.path.join(base, "test_openpose", seq)
         img_dir = os.path.join(base, "test_img", seq)
         os.makedirs(pose_dir, exist_ok=True)
         os.makedirs(img_dir, exist_ok=True)
         for t, js in enumerate(frames):
-            with open(os.path.join(pose_dir, "%s%05d.json" % (stem, t)), "w") as fh:
-                json.dump(js, fh)
-            if write_images:
-                from PIL import Image
-                img = read_keypoints(js, size)
-                # cv2.imwrite stores the array as BGR; with --no_first_img only the image SIZE is used downstream
-                Image.fromarray(np.ascontiguousarray(img[..., ::-1])).save(
-                    os.path.join(img_dir, "%s%s.jpg" % (stem, str(t).zfill(digits))))
+            jobs.append((os.path.join(pose_dir, "%s%05d.json" % (stem, t)),
+                         os.path.join(img_dir, "%s%s.jpg" % (stem, str(t).zfill(digits))) if write_images else None, js, size))
+    if workers is None:
+        try:
+            workers = min(8, len(os.sched_getaffinity(0)))
+        except (AttributeError, OSError):
+            workers = 1
+    if workers > 1 and len(jobs) >= 4 * workers:
+        import multiprocessing as mp
+        from . import keypoints
+        keypoints._minpack()                  # resolved once here, inherited by the forks
+        keypoints._host_lib()
+        with mp.get_context("fork").Pool(workers) as pool:
+            pool.map(_write_frame, jobs, chunksize=max(1, len(jobs) // (4 * workers)))
+    else:
+        for job in jobs:
+            _write_frame(job)
     return raw, smooth
 
 
