@@ -28,7 +28,6 @@ def run(H, W, C):
     for sk in ("0", "1", "whole"):     # one block per tile | the default rule | the default rule without the ragged / tall tiles
         os.environ["T2V_WINO_GEMM_SK"] = "1" if sk == "whole" else sk
         os.environ["T2V_WINO_GEMM_SK_RAGGED"] = "0" if sk == "whole" else os.environ.get("SK_PROBE_RAGGED", "2")
-        os.environ["T2V_WINO_GEMM_SK_TALL"] = "0" if sk == "whole" else os.environ.get("SK_PROBE_TALL", "1")
         ops.reload_env()
         ws.fill_(float("nan"))
         y = ops.conv2d_winograd(x, pu, b, desc, workspace=ws)

@@ -556,7 +556,8 @@ def test_hand_over_timeout_is_reported_once_and_switches_to_one_block_per_tile()
 
 @pytest.mark.parametrize("geom", [(64, 64, 1024, 1024), (64, 128, 1024, 1024), (64, 64, 512, 1024)])
 def test_one_block_per_cu_256x128_tiles_equal_tile_per_block(geom, t2v_env):
-    """T2V_WINO_GEMM_SK_TALL=2: the 256 tile rows of a 512x512 frame (512 of two) on 256 x 128 tiles, one block per CU
+    """Under the overlap hint (ops.set_overlap_hint: what the generator's two-stream frames set): the 256 tile rows of a 512x512
+    frame (512 of two) on 256 x 128 tiles, one block per CU
     (wino_gemm_sk_kernel<TileCfg<32,1,4,8,1>, ring 3>: 128 accumulator registers, 48 KiB stages) -- the same K-ordered MFMA chain
     per output as one block per tile: bit-identical, launch after launch on a NaN-filled workspace."""
     from text2video_amd import ops
@@ -571,12 +572,15 @@ def test_one_block_per_cu_256x128_tiles_equal_tile_per_block(geom, t2v_env):
     t2v_env("T2V_WINO_GEMM_SK", "0")
     want = [ops.conv2d_winograd(x, pu, b, desc, workspace=ws).clone() for x in xs]
     t2v_env("T2V_WINO_GEMM_SK", "1")
-    t2v_env("T2V_WINO_GEMM_SK_TALL", "2")
-    assert "256x128" in ops.winograd_gemm_form(desc), ops.winograd_gemm_form(desc)
-    ws.fill_(float("nan"))
-    for rep in range(8):
-        y = ops.conv2d_winograd(xs[rep % 2], pu, b, desc, workspace=ws)
-        assert torch.equal(y, want[rep % 2]), "launch %d: %d of %d outputs differ" % (rep, int((y != want[rep % 2]).sum()), y.numel())
+    prev = ops.set_overlap_hint(True)
+    try:
+        assert "256x128" in ops.winograd_gemm_form(desc), ops.winograd_gemm_form(desc)
+        ws.fill_(float("nan"))
+        for rep in range(8):
+            y = ops.conv2d_winograd(xs[rep % 2], pu, b, desc, workspace=ws)
+            assert torch.equal(y, want[rep % 2]), "launch %d: %d of %d outputs differ" % (rep, int((y != want[rep % 2]).sum()), y.numel())
+    finally:
+        ops.set_overlap_hint(prev)
 
 
 @pytest.mark.parametrize("case", [

@@ -41,22 +41,11 @@ bool overlap_hint() { return g_overlap != 0 && options().overlap_hint != 0; }
 void options_reload() {
     Options o;
     o.wino_gemm_sk = env_int("T2V_WINO_GEMM_SK", 1);
-    o.wino_gemm_sk_wide = env_int("T2V_WINO_GEMM_SK_WIDE", 1);
-    o.wino_gemm_sk_half = env_int("T2V_WINO_GEMM_SK_HALF", 1);
     o.wino_gemm_sk_ragged = env_int("T2V_WINO_GEMM_SK_RAGGED", 2);
-    o.wino_gemm_sk_tall = env_int("T2V_WINO_GEMM_SK_TALL", 1);
     o.overlap_hint = env_int("T2V_OVERLAP_HINT", 1);
     o.wgrad_sk = env_int("T2V_WGRAD_SK", 1);
-    o.wgrad_sk_half = env_int("T2V_WGRAD_SK_HALF", 1);
     o.wgrad_combine = env_int("T2V_WGRAD_COMBINE", 1);
     o.wgrad_combine_max = env_int("T2V_WGRAD_COMBINE_MAX", 4);
-    o.wgrad_splits = env_int("T2V_WGRAD_SPLITS", 0);
-    o.wgrad_fold = env_int("T2V_WGRAD_FOLD", 1);
-    o.conv_tile = env_int("T2V_CONV_TILE", -1);
-    o.conv_ring = env_int("T2V_CONV_RING", 0);
-    o.conv_head = env_int("T2V_CONV_HEAD", 1);
-    o.conv_cout1 = env_int("T2V_CONV_COUT1", 1);
-    o.conv_stem = env_int("T2V_CONV_STEM", 1);
     o.chain_lazy = env_int("T2V_CHAIN_LAZY", 1);
     o.streams = env_int("T2V_STREAMS", 0);
     g_opts = o;
@@ -247,7 +236,6 @@ int build_conv_plan(const t2v_conv_desc* d, int x_cs, bool need_stats, ConvPlan*
         // tile quantisation: with 128x128 tiles a grid that fills the last wave of 256 CUs poorly
         // (e.g. 160 or 344 tiles at the real fadg0 geometries 512x320 / 512x680) idles a third of
         // the chip; 64x64 tiles (several co-resident blocks per CU) even that out
-        const int force = options().conv_tile;
         const long nb = (long)k.mtiles * k.ntiles * k.nphases;
         const double fill = (double)nb / (double)(((nb + 255) / 256) * 256);
         // transposed convs with few blocks: the four phases have 1/2/2/4 taps, and one 128x128 block per CU cannot
@@ -256,8 +244,9 @@ int build_conv_plan(const t2v_conv_desc* d, int x_cs, bool need_stats, ConvPlan*
         // Winograd GEMM: 0.84 -> 0.96, 0.259 -> 0.244 ms)
         const long nbq = 4 * nb;
         const double fillq = (double)nbq / (double)(((nbq + 255) / 256) * 256);
-        if (force == kTileQ || (force < 0 && ((fill < 0.8 && nb < 1024) || (k.nphases > 1 && nb <= 512) ||
-                                              (fillq - fill >= 0.1 && nb < 2048)))) {
+        // (rule against forced tiles, per layer, at 512x320 / 512x680 / 512x512: within 1.3 / 2.8 / 1.0 % of the best forced
+        // choice -- profiles/r04_ab_s2_tiles.txt; the forcing switch is gone)
+        if ((fill < 0.8 && nb < 1024) || (k.nphases > 1 && nb <= 512) || (fillq - fill >= 0.1 && nb < 2048)) {
             pl.tile = kTileQ;
             conv_tile_dims(pl.tile, &pl.BM, &pl.BN);
             k.ntiles = (d->Cout + pl.BN - 1) / pl.BN;
@@ -344,9 +333,8 @@ int run_conv_batch(t2v_ctx* ctx, hipStream_t s, const ConvPlan& pl, int batch, c
     T2V_REQUIRE((long)pl.Hout * pl.Wout * y_cs * 4 < 0x7fff0000L, "conv: output tensor too large for 32-bit buffer offsets");
     {
         // the generator heads: dedicated halo-tile kernel (conv_head.hip)
-        const int use_head = options().conv_head;
         const ConvKParams& q = pl.kp;
-        if (use_head && !stats && q.nphases == 1 && q.ph[0].ntaps == 49 && q.KW == 7 && q.pad == 3 && q.stride == 1 &&
+        if (!stats && q.nphases == 1 && q.ph[0].ntaps == 49 && q.KW == 7 && q.pad == 3 && q.stride == 1 &&
             q.pad_mode == T2V_PAD_REFLECT && q.Cout <= 3 && q.Cin_s % 16 == 0 && q.Hin >= 4 && q.Win >= 4) {
             for (int b = 0; b < batch; ++b) {
                 HeadParams h;
@@ -360,9 +348,8 @@ int run_conv_batch(t2v_ctx* ctx, hipStream_t s, const ConvPlan& pl, int batch, c
     }
     {
         // one output channel, long K (the discriminators' last layer): a wave per output pixel (conv_head.hip)
-        const int use_c1 = options().conv_cout1;
         const ConvKParams& q = pl.kp;
-        if (use_c1 && !stats && q.nphases == 1 && q.Cout == 1 && q.pad_mode == T2V_PAD_ZERO && q.ostride == 1 &&
+        if (!stats && q.nphases == 1 && q.Cout == 1 && q.pad_mode == T2V_PAD_ZERO && q.ostride == 1 &&
             q.ph[0].ntaps == q.KW * q.KW && conv_cout1_supported(q.KW, q.Cin_s) &&
             (q.act == T2V_ACT_NONE || q.act == T2V_ACT_LRELU)) {
             for (int b = 0; b < batch; ++b) {
@@ -681,12 +668,12 @@ int t2v_batch_norm_finalize_running(t2v_ctx* ctx, void* stream, const t2v_conv_d
 // narrow-input regular convs (7x7 stems: 12 / 8 channels; the discriminators' 4x4 first layers: 8): fold the taps
 // into the 128-wide channel side of the block tile
 static bool wgrad_fold(const t2v_conv_desc* d, int x_cs) {
-    return options().wgrad_fold && !d->transposed && x_cs < 64 && d->kH * d->kW > 1;
+    return !d->transposed && x_cs < 64 && d->kH * d->kW > 1;
 }
 
 // few output channels (the 7x7 heads: 3 -> dy_cs 4) on a wide input: fold the taps onto the dY side
 static bool wgrad_fold_n(const t2v_conv_desc* d, int x_cs, int dy_cs) {
-    return options().wgrad_fold && !d->transposed && d->stride == 1 && dy_cs <= 16 && x_cs >= 64 && d->kH * d->kW > 1 &&
+    return !d->transposed && d->stride == 1 && dy_cs <= 16 && x_cs >= 64 && d->kH * d->kW > 1 &&
            d->kH * d->kW <= kMaxTaps;
 }
 static size_t wgrad_padded_floats(const t2v_conv_desc* d, int x_cs, int batch) {
@@ -709,7 +696,6 @@ static int wgrad_splits(const t2v_conv_desc* d, int x_cs, int batch, const ConvP
     if (smax < 1) smax = 1;
     long s = 1, best = -1;
     const long slots = 2 * 256;      // two blocks (2 x 64 KiB of LDS, 104 VGPRs) are resident per CU
-    if (options().wgrad_splits > 0) return (int)std::min<long>(options().wgrad_splits, smax);      // (experiments)
     for (long c = 1; c <= smax; ++c) {
         const long rounds = (blocks * c + slots - 1) / slots;
         // + zeroing, writing and re-reading c partial gradients at ~15 MB per stage time

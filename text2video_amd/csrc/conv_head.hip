@@ -3,18 +3,11 @@
 //
 // Why not the implicit-GEMM kernel: with 3 output channels an MFMA tile is >= 80 % padding, and the
 // 49-tap gather re-reads every input pixel 49 times through L2 (6.6 GB at 512x512, the measured
-// bound of the MFMA version: 0.5 ms = 19 TFLOP/s).  This kernel is shaped by the data instead:
-//   * one block = a 16x16 pixel tile, one thread per pixel, 3 fp32 accumulators per thread;
-//   * the 22x22 input halo of the tile is staged ONCE per 16-channel chunk into LDS (LDS-DMA, buffer
-//     addressing: per-lane halo offsets with reflection are computed once per block, the chunk is an
-//     SGPR soffset) and reused by all 49 taps: L2 traffic 1.9x the input instead of 49x;
-//   * LDS image is [4-channel group][halo pixel] so a wave's ds_read_b128 of one tap is contiguous;
-//   * weights are wave-uniform: they stream through SGPRs (s_load from the SAME packed [Cout_p][Kp]
-//     matrix the MFMA kernels use) and feed v_fmac directly -- no LDS or VGPR traffic for B;
-//   * single-buffered 32 KiB halo => 4 blocks (16 waves) per CU: while one block stages its next chunk
-//     the others compute -- thread-level parallelism hides DMA, scalar-load and LDS latency, and the
-//     tap loop stays rolled (48 live weight scalars; a fully unrolled row spilled SGPRs).
-// Bound: fp32 VALU then LDS (6 packed FMAs per ds_read_b128), 9.87 GFLOP per 512x512 launch: 0.16 ms = 62 TFLOP/s.
+// bound of the MFMA version: 0.5 ms = 19 TFLOP/s).  The kernel below is shaped by the data instead -- fp32 VALU
+// (v_pk_fma_f32 at 151 TFLOP/s issue rate with an SGPR-pair multiplier, scripts/pkfma_probe.hip), the 22x22 halo of a
+// 16x16 pixel tile staged once per channel group in LDS and reused by all 49 taps, the weights wave-uniform scalars out of
+// the SAME packed [Cout_p][Kp] matrix the MFMA kernels use.  9.87 GFLOP per 512x512 launch: 132 us = 75 TFLOP/s.
+// (Rounds 1-4 ran a thread-per-pixel form: one ds_read_b128 per 6 packed FMAs made it LDS-bound, 176 us; deleted.)
 #include <stdlib.h>
 
 #include "t2v_internal.h"
@@ -30,135 +23,8 @@ __device__ __forceinline__ void hd_dma16(const float* base, int nbytes, char* ld
 
 constexpr int kHdTile = 16;                 // 16 x 16 output pixels per block
 constexpr int kHdHalo = kHdTile + 6;        // 22
-constexpr int kHdPlane = 512 * 16;          // bytes of one 4-channel plane (484 halo pixels, padded to 8 DMA instr)
-// CH = channels staged per pass: 16 (32 KiB, 4 blocks/CU) or 32 (64 KiB, 2 blocks/CU; one full 128-byte line
-// per halo pixel per pass)
-template <int CH>
-__global__ __launch_bounds__(256) void conv_head7x7_kernel(const HeadParams p) {
-    constexpr int kPlanes = CH / 4;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // also the 4-channel group this wave stages
-    const int tx = tid & 15, ty = tid >> 4;
-    // block b runs on XCD b % 8: give every XCD a contiguous band of tile rows, so that the halo overlap of
-    // neighbouring tiles (22x22 fetched per 16x16 outputs = 1.9x) and the two 64-B chunk halves of a 128-B
-    // line are served by that XCD's own L2 -- inside a frame the input was just written by another kernel
-    // and does not sit in the Infinity Cache (measured: 457 vs 315 us without this).
-    int tile;
-    {
-        const int nb = gridDim.x, b = blockIdx.x;
-        const int xcd = b & 7, idx = b >> 3;
-        const int q = nb >> 3, r = nb & 7;
-        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int tiles_x = (p.W + kHdTile - 1) / kHdTile;
-    const int x0 = (tile % tiles_x) * kHdTile, y0 = (tile / tiles_x) * kHdTile;
-
-    // halo pixel -> byte offset in x (reflection resolved once per block)
-    int voff[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int hp = i * 64 + lane;
-        const int hy = hp / kHdHalo, hx = hp - hy * kHdHalo;
-        int gy = y0 - 3 + hy, gx = x0 - 3 + hx;
-        gy = gy < 0 ? -gy : gy;
-        gx = gx < 0 ? -gx : gx;
-        gy = min(gy, 2 * p.H - 2 - gy);
-        gx = min(gx, 2 * p.W - 2 - gx);
-        gy = max(gy, 0);      // tiles hanging over the bottom/right edge: any valid pixel (their outputs are masked)
-        gx = max(gx, 0);
-        voff[i] = hp < kHdHalo * kHdHalo ? ((gy * p.W + gx) * p.Cin_s + wave * 4) * 4 : 0x7fff0000;
-    }
-    const int x_bytes = p.H * p.W * p.Cin_s * 4;
-    auto stage = [&](int chunk, int buf) {
-#pragma unroll
-        for (int h = 0; h < kPlanes / 4; ++h) {   // this wave's 4-channel planes: wave, wave + 4
-            char* dst = smem + (wave + 4 * h) * kHdPlane;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) hd_dma16(p.x, x_bytes, dst + i * 1024, voff[i], chunk * (CH * 4) + h * 64);
-        }
-    };
-
-    // packed fp32 FMAs (v_pk_fma_f32: two lanes of a register pair per instruction): every output channel keeps an
-    // (even, odd) input-channel pair of partial sums, so one ds_read_b128 feeds 6 packed FMAs instead of 12 scalar ones
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    f32x2 acc0 = {0.f, 0.f}, acc1 = {0.f, 0.f}, acc2 = {0.f, 0.f};
-    const int nchunks = p.Cin_s / CH;
-    const float* __restrict__ w0 = p.w;                 // row 0 of the packed [Cout_p][Kp] weight
-    const float* __restrict__ w1 = p.w + p.Kp;
-    const float* __restrict__ w2 = p.w + 2 * p.Kp;
-    const int lbase = (ty * kHdHalo + tx) * 16;
-
-    const char* sb = smem + lbase;
-    for (int ch = 0; ch < nchunks; ++ch) {
-        stage(ch, 0);
-        __syncthreads();   // chunk landed (the barrier's fence drains vmcnt)
-        for (int kh = 0; kh < 7; ++kh) {
-#pragma unroll 1
-            for (int kw = 0; kw < 7; ++kw) {
-                const int kofs = (kh * 7 + kw) * p.Cin_s + ch * CH;   // wave-uniform: scalar loads below
-                const char* st = sb + (kh * kHdHalo + kw) * 16;
-#pragma unroll
-                for (int q = 0; q < kPlanes; ++q) {
-                    const float4 xv = *reinterpret_cast<const float4*>(st + q * kHdPlane);
-                    const float4 a = *reinterpret_cast<const float4*>(w0 + kofs + q * 4);
-                    const float4 b = *reinterpret_cast<const float4*>(w1 + kofs + q * 4);
-                    const float4 c = *reinterpret_cast<const float4*>(w2 + kofs + q * 4);
-                    const f32x2 xlo = {xv.x, xv.y}, xhi = {xv.z, xv.w};
-                    acc0 = __builtin_elementwise_fma(xlo, (f32x2){a.x, a.y}, acc0);
-                    acc1 = __builtin_elementwise_fma(xlo, (f32x2){b.x, b.y}, acc1);
-                    acc2 = __builtin_elementwise_fma(xlo, (f32x2){c.x, c.y}, acc2);
-                    acc0 = __builtin_elementwise_fma(xhi, (f32x2){a.z, a.w}, acc0);
-                    acc1 = __builtin_elementwise_fma(xhi, (f32x2){b.z, b.w}, acc1);
-                    acc2 = __builtin_elementwise_fma(xhi, (f32x2){c.z, c.w}, acc2);
-                }
-            }
-        }
-        __syncthreads();   // everyone is done with the halo before the next chunk overwrites it
-    }
-
-    const int oy = y0 + ty, ox = x0 + tx;
-    if (oy < p.H && ox < p.W) {
-        float v0 = (acc0.x + acc0.y) + (p.bias ? p.bias[0] : 0.f);
-        float v1 = (acc1.x + acc1.y) + (p.bias && p.Cout > 1 ? p.bias[1] : 0.f);
-        float v2 = (acc2.x + acc2.y) + (p.bias && p.Cout > 2 ? p.bias[2] : 0.f);
-        if (p.act == T2V_ACT_TANH) {
-            v0 = tanhf(v0); v1 = tanhf(v1); v2 = tanhf(v2);
-        } else if (p.act == T2V_ACT_FLOW_W) {
-            v0 *= p.act_scale; v1 *= p.act_scale; v2 = 1.f / (1.f + expf(-v2));
-        } else if (p.act == T2V_ACT_LRELU) {
-            v0 = v0 > 0.f ? v0 : v0 * p.act_scale; v1 = v1 > 0.f ? v1 : v1 * p.act_scale; v2 = v2 > 0.f ? v2 : v2 * p.act_scale;
-        }
-        if (p.Cout < 2) v1 = 0.f;
-        if (p.Cout < 3) v2 = 0.f;
-        float* dst = p.y + (size_t)(oy * p.W + ox) * p.Cout_s;
-        if (p.Cout_s == 4) {
-            *reinterpret_cast<float4*>(dst) = make_float4(v0, v1, v2, 0.f);
-        } else {
-            dst[0] = v0;
-            if (p.Cout_s > 1) dst[1] = v1;
-            if (p.Cout_s > 2) dst[2] = v2;
-            for (int c = 3; c < p.Cout_s; ++c) dst[c] = 0.f;
-        }
-    }
-}
-
-template <int CH>
-static int launch_head(hipStream_t s, const HeadParams& p) {
-    constexpr int lds = (CH / 4) * kHdPlane;
-    auto kern = conv_head7x7_kernel<CH>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        T2V_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_done = true;
-    }
-    hipLaunchKernelGGL(kern, dim3(((p.W + kHdTile - 1) / kHdTile) * ((p.H + kHdTile - 1) / kHdTile)), dim3(256), lds, s, p);
-    T2V_HIP_CHECK(hipGetLastError());
-    return T2V_OK;
-}
-
-// ---- the strip form (round 5) ----------------------------------------------------------------------------------------
-// The tile form above is LDS-bound, not VALU-bound: one ds_read_b128 (8 LDS cycles per wave) feeds 6 packed FMAs (24 VALU
+// ---- the strip form ---------------------------------------------------------------------------------------------------
+// A thread per pixel is LDS-bound, not VALU-bound: one ds_read_b128 (8 LDS cycles per wave) feeds 6 packed FMAs (24 VALU
 // cycles), and with four SIMDs sharing one LDS pipe that is 32 LDS cycles per 24 VALU cycles -- 205 us for 9.87 GFLOP =
 // 0.31 of the fp32 VALU peak.  Here a thread owns a 1 x 4 strip of pixels: the 10 halo pixels of a kernel row are read ONCE
 // and feed 7 taps x 4 pixels x 3 outputs = 168 packed FMAs (16.8 per LDS read instead of 6).  A strip per thread means a
@@ -178,7 +44,9 @@ __global__ __launch_bounds__(256) void conv_head7x7_strip_kernel(const HeadParam
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cin_s = CIN ? CIN : p.Cin_s;
     int tile;
-    {   // XCD-banded tile order, as in the tile form
+    {   // block b runs on XCD b % 8: every XCD gets a contiguous band of tile rows, so that the halo overlap of neighbouring
+        // tiles (22x22 fetched per 16x16 outputs = 1.9x) is served by that XCD's own L2 (measured on the first form of this
+        // kernel: 457 vs 315 us without)
         const int nb = gridDim.x, b = blockIdx.x;
         const int xcd = b & 7, idx = b >> 3;
         const int q = nb >> 3, r = nb & 7;
@@ -355,8 +223,6 @@ __global__ __launch_bounds__(256) void conv_head7x7_strip_kernel(const HeadParam
 }
 
 int launch_conv_head7x7(hipStream_t s, const HeadParams& p) {
-    // (the tile form, 16 channels per pass: T2V_CONV_HEAD=2; its 32-channel variant measured slower: 402 vs 253 us)
-    if (options().conv_head == 2) return launch_head<16>(s, p);
     constexpr int lds = 4 * kHsPlane;
     const dim3 grid(((p.W + kHdTile - 1) / kHdTile) * ((p.H + kHdTile - 1) / kHdTile));
     if (p.Cin_s == 128) hipLaunchKernelGGL(conv_head7x7_strip_kernel<128>, grid, dim3(256), lds, s, p);

@@ -1027,23 +1027,22 @@ size_t wino_gemm_sk_scratch_floats() { return (size_t)kSkMaxGrid * (4 * 64 * 64 
 static int sk_tile_rows(int T, int N) {
     if (N % 128) return 0;            // (the packed weights hold round_up(N, 128) rows per position: N itself, then)
     if (T % 128 == 0) return 128;
-    return (options().wino_gemm_sk_wide && T % 192 == 0) ? 192 : 0;
+    return T % 192 == 0 ? 192 : 0;
 }
 // R whole rounds + exactly half a round of tiles, an even number of K stages, whole 16-block halves per XCD
 static bool sk_half_round(long tiles, long grid, int nk) {
-    return options().wino_gemm_sk_half && tiles >= grid && 2 * (tiles % grid) == grid && nk % 2 == 0 && grid % 16 == 0;
+    return tiles >= grid && 2 * (tiles % grid) == grid && nk % 2 == 0 && grid % 16 == 0;
 }
 // 129 .. 160 real rows per position (the 64 x 40 bottleneck of the reference's 512x320 frames: 160 Winograd tiles) -- and,
-// under the overlap hint (a caller with a second stream: the generator's two-stream frames) or with
-// T2V_WINO_GEMM_SK_TALL=2, the 256 rows of a 512x512 frame (512 of two) on 256 x 128 tiles -- : ONE
+// under the overlap hint (a caller with a second stream: the generator's two-stream frames; t2v_set_overlap_hint),
+// the 256 rows of a 512x512 frame (512 of two) on 256 x 128 tiles -- : ONE
 // 160 x 128 tile per position and column tile -- no padding rows, 0.0141 B of LDS-DMA per MAC (192 x 64: 0.0208) -- whose 80
 // accumulator registers and 108 KiB ring allow one block per CU: a fixed grid of one block per CU, 288 tiles on 256 blocks
 static int sk_tall_rows(int groups, int rows, int T, int N) {     // tile rows of the one-block-per-CU form (160 | 256), or 0
-    const int mode = options().wino_gemm_sk_tall;
-    if (!mode || rows <= 0 || N % 128) return 0;
+    if (rows <= 0 || N % 128) return 0;
     int bm = 0, mt = 1;
     if (rows > 128 && rows <= 160 && T >= 160) bm = 160;
-    else if ((mode >= 2 || overlap_hint()) && T % 256 == 0 && rows > T - 32 && T <= 512) bm = 256, mt = T / 256;  // 256 (one 512x512 image) | 512 (two)
+    else if (overlap_hint() && T % 256 == 0 && rows > T - 32 && T <= 512) bm = 256, mt = T / 256;  // 256 (one 512x512 image) | 512 (two)
     if (!bm || lds_optin_bytes() < 3 * (bm == 160 ? CfgT::STAGE_BYTES : CfgT8::STAGE_BYTES)) return 0;
     const long tiles = (long)groups * mt * (N / 128), grid = wino_gemm_sk_grid_blocks() / 2;
     return (tiles >= grid && tiles * 100 <= ((tiles + grid - 1) / grid) * grid * 90) ? bm : 0;
@@ -1279,14 +1278,12 @@ static int launch_pad(hipStream_t s, const ConvKParams& p) {
     // >= 4 blocks per CU queued: let two blocks share the CU (64 KiB ring each); measured on MI355X:
     // 2048-block stem 0.40 vs 0.47 ms, 1024-block layers 0.33 vs 0.345 ms, <= 512 blocks favour RING 3
     const long nblocks = (long)p.mtiles * p.ntiles * p.nphases * (p.batch > 1 ? p.batch : 1);
-    const int force = options().conv_ring;
     // (swept per layer shape with scripts/kernel_bench.py: single-phase launches like two co-resident blocks from 512
     // blocks on; 64x64 tiles of a multi-phase launch prefer the deeper ring.  Round 4: also between 257 and 511 blocks -- one
     // block per CU would need a second, mostly empty round there: the 344-block stride-2 layers of a 512x680 frame, 456 at
     // 512x912; frames 16.07 -> 15.88 ms)
-    const bool two = force ? force == 2
-                           : (Cfg::MF == 32 && (Cfg::BM == 64 ? (p.nphases == 1 || nblocks >= 4096)
-                                                              : (nblocks >= 1024 || (p.nphases == 1 && nblocks > 256))));
+    const bool two = Cfg::MF == 32 && (Cfg::BM == 64 ? (p.nphases == 1 || nblocks >= 4096)
+                                                     : (nblocks >= 1024 || (p.nphases == 1 && nblocks > 256)));
     return two ? launch_ring<Cfg, MODE, STATS, REFLECT, 2>(s, p) : launch_ring<Cfg, MODE, STATS, REFLECT, 3>(s, p);
 }
 

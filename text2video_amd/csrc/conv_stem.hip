@@ -270,15 +270,14 @@ static int launch_stem(hipStream_t s, const StemParams& p) {
 }
 
 bool conv_stem7x7_supported(int H, int W, int Cin_s, int Cout) {
-    return options().conv_stem && H >= 16 && W >= 16 && (Cin_s == 8 || Cin_s == 12) && (Cout == 64 || Cout == 128);
+    return H >= 16 && W >= 16 && (Cin_s == 8 || Cin_s == 12) && (Cout == 64 || Cout == 128);
 }
 
 int launch_conv_stem7x7(hipStream_t s, const StemParams& p) {
     T2V_REQUIRE(conv_stem7x7_supported(p.H, p.W, p.Cin_s, p.Cout) && p.stats && p.Cout_s >= p.Cout, "stem kernel: unsupported launch");
     // the generator's own stems (9 pose channels in 12, 6 previous-frame channels in 8) skip the storage padding in K
-    const bool dense = options().conv_stem != 2;      // T2V_CONV_STEM=2: the plain k order (A/B)
-    if (p.Cin_s == 12 && p.Cin == 9 && dense) return p.Cout == 128 ? launch_stem<12, 4, 9>(s, p) : launch_stem<12, 2, 9>(s, p);
-    if (p.Cin_s == 8 && p.Cin == 6 && dense) return p.Cout == 128 ? launch_stem<8, 4, 6>(s, p) : launch_stem<8, 2, 6>(s, p);
+    if (p.Cin_s == 12 && p.Cin == 9) return p.Cout == 128 ? launch_stem<12, 4, 9>(s, p) : launch_stem<12, 2, 9>(s, p);
+    if (p.Cin_s == 8 && p.Cin == 6) return p.Cout == 128 ? launch_stem<8, 4, 6>(s, p) : launch_stem<8, 2, 6>(s, p);
     if (p.Cin_s == 12) return p.Cout == 128 ? launch_stem<12, 4, 12>(s, p) : launch_stem<12, 2, 12>(s, p);
     return p.Cout == 128 ? launch_stem<8, 4, 8>(s, p) : launch_stem<8, 2, 8>(s, p);
 }

@@ -601,7 +601,7 @@ int launch_wino_wgrad_sk(hipStream_t s, const float* V, const float* Md, float* 
     const int grid = wino_gemm_sk_grid_blocks();
     k.blocks_per_xcd = grid / 8;
     k.tiles_per_xcd = (k.tiles + 7) / 8;
-    k.rounds = (options().wgrad_sk_half && k.tiles >= grid && 2 * (k.tiles % grid) == grid && k.nk % 2 == 0 && grid % 16 == 0) ? k.tiles / grid : 0;
+    k.rounds = (k.tiles >= grid && 2 * (k.tiles % grid) == grid && k.nk % 2 == 0 && grid % 16 == 0) ? k.tiles / grid : 0;
     auto kern = wino_wgrad_sk_kernel<16, 4>;
     constexpr int lds = 4 * 2 * 16 * 128 * 4;
     static bool attr_done = false;

@@ -40,22 +40,12 @@ void set_error(const char* fmt, ...);
 // ---------------------------------------------------------------------------------------------
 struct Options {
     int wino_gemm_sk;        // T2V_WINO_GEMM_SK: 0 off, 1 where it pays (default), 2 wherever the shape allows
-    int wino_gemm_sk_wide;   // T2V_WINO_GEMM_SK_WIDE: 192x64 tiles for tile rows that are whole 192s (default 1)
-    int wino_gemm_sk_half;   // T2V_WINO_GEMM_SK_HALF: second schedule for R + 1/2 rounds (default 1)
-    int wino_gemm_sk_tall;   // T2V_WINO_GEMM_SK_TALL: one block per CU on 160x128 tiles for 129..160 tile rows (1), and on 256x128
-                             // tiles for 256 / 512 tile rows (2)
     int overlap_hint;        // T2V_OVERLAP_HINT: 0 ignores the overlap hint (t2v_set_overlap_hint / the generator's two-stream frames)
     int wino_gemm_sk_ragged; // T2V_WINO_GEMM_SK_RAGGED: ragged M tiles for tile rows that are no whole 128s: 1 = 4,..,4,r fragments on
                              // two blocks per CU, 2 = balanced 3..6-fragment tiles on one block per CU where that applies
     int wgrad_sk;            // T2V_WGRAD_SK: as wino_gemm_sk, for the Winograd-domain weight gradient
-    int wgrad_sk_half;       // T2V_WGRAD_SK_HALF
     int wgrad_combine;       // T2V_WGRAD_COMBINE: in-kernel combine of split partials (default 1)
-    int wgrad_splits;        // T2V_WGRAD_SPLITS: > 0 forces the pixel-range split count of the direct weight gradient (experiments)
     int wgrad_combine_max;   // T2V_WGRAD_COMBINE_MAX: ... up to this many partials (default 4)
-    int wgrad_fold;          // T2V_WGRAD_FOLD: taps folded into the tile for narrow layers (default 1)
-    int conv_tile;           // T2V_CONV_TILE: -1 auto (default), 0 / 2 force 128x128 / 64x64 tiles where both exist
-    int conv_ring;           // T2V_CONV_RING: 0 auto (default), 2 / 3 ring depth
-    int conv_head, conv_cout1, conv_stem;   // T2V_CONV_HEAD / _COUT1 / _STEM: the dedicated kernels (default 1)
     int chain_lazy;          // T2V_CHAIN_LAZY: ResnetBlock chains apply their norms in the next input transform (default 1)
     int streams;             // T2V_STREAMS: 1 = the generator on the caller's stream only, 2 = always two streams; 0 (default):
                              // two, except the global generator on a bottleneck of >= 1024 Winograd tiles (1024x1024 frames)

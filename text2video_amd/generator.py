@@ -416,8 +416,8 @@ class Vid2VidModelG:
         geometry).  Measured end to end with the flow branch, two sequences (profiles/r04_ab_lockstep.txt): 512x320 139.3 vs
         135.2 fps, 512x680 66.3 vs 65.2, 512x512 88.3 vs 86.0 -- the batch wins 2-3 % everywhere since the ragged GEMM of a
         batch-2 launch runs one block per CU; before that, two single calls on 160x128 tiles were as fast at
-        512x320.  T2V_LOCKSTEP=0 / 1 forces one call per sequence / the batch (scripts/ab_lockstep.py)."""
-        return os.environ.get("T2V_LOCKSTEP", "1") != "0"
+        512x320.  (A geometry rule would go here; today the batch wins everywhere measured.)"""
+        return True
 
     def inference_nhwc(self, pose):
         """pose: [H,W,round_up4(3*tG)] fp32 NHWC window (oldest frame first).  Returns [H,W,4] (RGB0)."""

@@ -150,7 +150,7 @@ def _host_lib():
         import os
         path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libt2v_host.so")
         _HOST = False
-        if os.path.exists(path) and os.environ.get("T2V_RASTER_NUMPY", "0") != "1":
+        if os.path.exists(path):
             try:
                 lib = ctypes.CDLL(path)
                 lib.t2v_raster_stamp.restype = None

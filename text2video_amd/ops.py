@@ -205,22 +205,19 @@ def conv2d_batch(x, packed_w, bias, desc, y_cs=None, stats=None, out=None):
 
 
 def conv2d_auto_batch(x, packed_w, bias, desc, y_cs=None, stats=None, out=None):
-    """conv2d_auto over a batch [B,...]: one launch for the direct algorithm (T2V_CONV_BATCH=0: image by image), image by
+    """conv2d_auto over a batch [B,...]: one launch for the direct algorithm, image by
     image for the Winograd forms (their batches go through the generator's own batched path).  stats: B consecutive blocks."""
     B = x.shape[0]
     if out is None:
         ho, wo = conv_out_dims(desc)
         out = torch.empty(B, ho, wo, round_up(desc.Cout, 4) if y_cs is None else y_cs, dtype=torch.float32, device=x.device)
-    if desc.algo == ALGO_DIRECT and B > 1 and _CONV_BATCH[0] and x.is_contiguous() and out.is_contiguous() and \
+    if desc.algo == ALGO_DIRECT and B > 1 and x.is_contiguous() and out.is_contiguous() and \
             (stats is None or stats.is_contiguous()):
         return conv2d_batch(x, packed_w, bias, desc, y_cs=y_cs, stats=stats, out=out)
     n = stats.numel() // B if stats is not None else 0
     for i in range(B):
         conv2d_auto(x[i], packed_w, bias, desc, y_cs=y_cs, stats=stats[i * n:(i + 1) * n] if stats is not None else None, out=out[i])
     return out
-
-
-_CONV_BATCH = [__import__("os").environ.get("T2V_CONV_BATCH", "1") != "0"]
 
 
 def instance_norm_finalize(stats, desc, eps=1e-5, out=None, running=None):

@@ -369,8 +369,8 @@ def running_update_args(gamma, n):
     ($SP/torch/nn/modules/batchnorm.py:57-64, momentum 0.1, unbiased variance) -- never read on this path (upstream keeps
     the generator in train mode at test time) but part of a faithful checkpoint.  Returns (running_mean,
     running_var, momentum, times) for the finalize call, which moves them in its own launch, or None (no affine norm,
-    fewer than two values per channel, T2V_BN_RUNNING=0); counts the updates on the statistics' step counter."""
-    if gamma is None or n < 2 or os.environ.get("T2V_BN_RUNNING", "1") == "0":
+    fewer than two values per channel); counts the updates on the statistics' step counter."""
+    if gamma is None or n < 2:
         return None
     rs = running_stats(gamma)
     rs[2] += _BN_UPDATES[0]
@@ -411,11 +411,10 @@ class _ConvBlock(torch.autograd.Function):
         # 3x3 stride-1 layers (the ResnetBlock convs) run as Winograd where that is the smaller GEMM; the weight
         # gradient keeps the direct layout (ddesc)
         ddesc = fdesc
-        # (convs with a fused activation -- the VGG19 loss network -- stay on the direct kernel unless
-        # T2V_ACT_WINOGRAD=1: F(4x4)'s 5x larger rounding noise flips visibly more ReLU / max-pool decisions in that
-        # 13-layer net (input-gradient relative L2 error 3.7e-3 instead of 2.3e-3) for 2 ms of a 99 ms step)
-        wino_act = fdesc.act == ops.ACT_LRELU and os.environ.get("T2V_ACT_WINOGRAD", "0") == "1"
-        if (fdesc.act == ops.ACT_NONE or wino_act) and ycs == desc.Cout and int(os.environ.get("T2V_CONV_ALGO", "0")) != 1:
+        # (convs with a fused activation -- the VGG19 loss network -- stay on the direct kernel: F(4x4)'s 5x larger rounding
+        # noise flips visibly more ReLU / max-pool decisions in that 13-layer net -- input-gradient relative L2 error 3.7e-3
+        # instead of 2.3e-3 -- for 2 ms of a 99 ms step)
+        if fdesc.act == ops.ACT_NONE and ycs == desc.Cout and int(os.environ.get("T2V_CONV_ALGO", "0")) != 1:
             algo = ops.best_conv_algo(fdesc, xcs, int(os.environ.get("T2V_CONV_ALGO", "0")))
             if algo != ops.ALGO_DIRECT:
                 fdesc = ops.with_algo(fdesc, algo)
