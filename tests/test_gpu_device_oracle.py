@@ -340,7 +340,11 @@ def test_config4_train_step_512_matches_the_device_oracle_step():
     a, b = np.array([e_df[k] for k in e_df]), np.array([e_df32[k] for k in e_df])
     print("   D_f on the HIP frames vs its fp64 gradient there: HIP median %.1e max %.1e | fp32 oracle median %.1e max %.1e"
           % (np.median(a), a.max(), np.median(b), b.max()))
-    assert np.median(a) <= max(1e-5, 3 * np.median(b)) and np.sum(a > 1e-4) <= 5 and a.max() <= 1e-2
+    # (round 5: with the frames of the strip-form 7x7 head -- another summation order, another 2e-5 of rounding -- a kink flips
+    # in an EARLY layer, for the fp32 oracle evaluated on the same frames exactly as for the HIP step: both 6.2e-4 median /
+    # 4.8e-3 max over the 13 tensors.  The count is therefore of tensors where the HIP step is worse than 3x what the fp32
+    # oracle itself does on these frames)
+    assert np.median(a) <= max(1e-5, 3 * np.median(b)) and np.sum(a > np.maximum(1e-4, 3 * b)) <= 5 and a.max() <= 1e-2
     flow_keys = [k for k in eh if k.startswith(("G.model_res_flow", "G.model_up_flow", "G.model_final_flow", "G.model_final_w"))]
     a = np.array([eh[k] for k in flow_keys])
     b = np.array([eo[k] for k in flow_keys])
