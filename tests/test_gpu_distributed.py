@@ -308,71 +308,6 @@ def _plain_env():
     return env
 
 
-def test_plain_bench_command_self_launches_two_ranks():
-    """`python3 bench.py --gpus 2 --steps 6` exactly as the driver types it for N = 1 -- no torchrun: bench.py spawns the
-    two ranks itself (text2video_amd/launch.py; both on this GPU over gloo here) and rank 0 prints the ONE JSON line."""
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
-                        "--kernel-iters", "2", "--single-variant", "--train-steps", "0"], cwd=ROOT, env=_plain_env(), capture_output=True,
-                       text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1
-    d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["config"]["parallelism"] == "sequence-chunk dp2"
-    assert d["value"] > 30.0
-
-
-def test_readme_train_command_with_gpu_ids_runs_one_rank_per_device(tmp_path):
-    """The reference's one-command multi-GPU recipe (README.md:171-176: `python train.py ... --gpu_ids 0,1,.. --batchSize N`,
-    fanned out by nn.DataParallel there) started plainly: train.py runs one rank per listed device and the replicas stay
-    in sync."""
-    cmd = [sys.executable, os.path.join(ROOT, "vid2vid", "train.py"), "--name", "dp", "--dataset_mode", "pose",
-           "--input_nc", "3", "--num_D", "2", "--resize_or_crop", "randomScaleHeight_and_scaledCrop", "--loadSize", "68",
-           "--fineSize", "64", "--gpu_ids", "0,1", "--batchSize", "2", "--max_frames_per_gpu", "2", "--niter", "3",
-           "--niter_decay", "0", "--no_first_img", "--n_frames_total", "12", "--max_t_step", "4", "--add_face_disc",
-           "--openpose_only", "--ngf", "16", "--n_blocks", "2", "--n_downsample_G", "2", "--ndf", "16", "--no_vgg",
-           "--synthetic_data", "--checkpoints_dir", str(tmp_path / "ck")]
-    r = subprocess.run(cmd, cwd=str(tmp_path), env=_plain_env(), capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
-    assert "replicas in sync after 3 steps" in r.stdout and "on all 2 ranks" in r.stdout
-    assert "done: 3 steps" in r.stdout and "on 2 GPU(s)" in r.stdout
-    assert "warning: --batchSize" not in r.stdout
-    assert os.path.exists(tmp_path / "ck" / "dp" / "latest_net_G0.pth")
-
-
-def test_plain_test_py_with_two_gpu_ids_equals_the_single_device_run(tmp_path):
-    """`python test.py <reference flags> --gpu_ids 0,1` (no torchrun): two ranks, whole sequences each, the JPEG files
-    equal the single-device run's."""
-    import glob
-    import shutil
-    from PIL import Image
-    from text2video_amd.keypoints import read_keypoints
-    src = os.path.join(ROOT, "tests", "golden", "keypoints_fadg0")
-    files = sorted(f for f in os.listdir(src) if f.startswith("sa1_"))
-    works = {}
-    for name in ("one", "two"):
-        w = str(tmp_path / name)
-        root = os.path.join(w, "datasets", "fadg0")
-        for seq, n in {"tmp": 8, "tmp_smooth": 6}.items():
-            os.makedirs(os.path.join(root, "test_openpose", seq))
-            os.makedirs(os.path.join(root, "test_img", seq))
-            img = Image.fromarray(read_keypoints(os.path.join(src, files[0]), (128, 96)))
-            for i in range(n):
-                shutil.copyfile(os.path.join(src, files[(i * 3 + len(seq)) % len(files)]),
-                                os.path.join(root, "test_openpose", seq, "%05d.json" % i))
-                img.save(os.path.join(root, "test_img", seq, "%04d.jpg" % i))
-        works[name] = w
-    env = _plain_env()
-    _run_test_py(works["one"], [], env)
-    _run_test_py(works["two"], ["--gpu_ids", "0,1"], env)
-
-    def frames(work):
-        return {os.path.relpath(p, work): open(p, "rb").read()
-                for p in sorted(glob.glob(os.path.join(work, "results", "fadg0", "test_latest", "*", "fake_B_*.jpg")))}
-    a, b = frames(works["one"]), frames(works["two"])
-    assert len(a) == (8 - 2) + (6 - 2) and a.keys() == b.keys() and all(a[k] == b[k] for k in a)
-
-
 def test_two_ranks_agree_on_the_face_terms_when_one_clip_shows_no_face(tmp_path):
     """--add_face_disc with two ranks whose clips differ: clipA shows the nose-neck limb (a face region exists), clipB has
     the nose key point at confidence 0 (no face region -> that rank alone would skip D_f's terms, leave D_f without
