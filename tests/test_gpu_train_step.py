@@ -550,3 +550,60 @@ def test_train_step_with_the_fixed_grid_kernels_forced_is_bit_identical(t2v_env)
     assert all(torch.equal(x, y) for x, y in zip(runs["2"][1], runs["0"][1]))
 
 
+
+
+def test_weight_gradients_reduced_once_per_layer_equal_one_reduction_per_pass(monkeypatch):
+    """Round 5: a direct-kernel layer that ran several times in the step's graph -- the generator's stride-2 / transposed
+    layers on the clip's two frames, the discriminators' layers on the real, fake and raw pass (two frames each) -- reduces its
+    weight gradient in ONE launch over all of them (train._paired_direct_wgrad; T2V_WGRAD_PAIR=0: one launch per backward node).
+    Same products, another summation tree: every gradient the step delivers equal to rounding; same losses, bit for bit; and the
+    discriminators' layers really were collected (three passes in one reduction)."""
+    from text2video_amd import ops
+    from text2video_amd import train as T
+    from text2video_amd.options import TrainOptions
+    size, dev, F = 128, "cuda:0", 2
+    argv = ["--name", "b", "--dataset_mode", "pose", "--input_nc", "3", "--openpose_only", "--num_D", "2", "--max_frames_per_gpu", "2",
+            "--n_scales_temporal", "0", "--no_first_img", "--fineSize", str(size), "--no_vgg", "--add_face_disc", "--ngf", "32",
+            "--n_blocks", "3", "--ndf", "32"]
+    rng = np.random.default_rng(0)
+    H = W = size
+    pose = torch.zeros(F, H, W, 12, device=dev)
+    pose[..., :9] = torch.from_numpy(np.where(rng.random((F, H, W, 1)) < 0.02, rng.uniform(-1, 1, (F, H, W, 9)), -1.0).astype(np.float32)).to(dev)
+    real = torch.zeros(F, H, W, 4, device=dev)
+    real[..., :3] = torch.tanh(torch.from_numpy(rng.standard_normal((F, H, W, 3)).astype(np.float32))).to(dev)
+    real_prev = torch.cat([real[1:], real[:1]], 0).contiguous()
+    boxes = [(16, 16 + 64, 32, 32 + 64)] * F
+    prev = torch.zeros(1, H, W, 8, device=dev)
+    prev[..., :6] = torch.tanh(torch.from_numpy(rng.standard_normal((1, H, W, 6)).astype(np.float32))).to(dev)
+    batches = []
+    real_bw = ops.conv2d_backward_weight
+
+    def spy(x, dy, desc, accumulate_into=None):
+        batches.append(int(x.shape[0]) if x.dim() == 4 else 1)
+        return real_bw(x, dy, desc, accumulate_into)
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("T2V_WGRAD_PAIR", mode)
+        tr = T.Vid2VidTrainer(TrainOptions().parse(argv), dev, seed=1)
+        tr.optG.step = lambda: None      # keep the weights: only the gradients of this one step are compared
+        tr.optD.step = lambda: None
+        del batches[:]
+        monkeypatch.setattr(ops, "conv2d_backward_weight", spy)
+        losses = tr.train_step(pose, real, boxes, prev.clone(), real_prev=real_prev)[0]
+        torch.cuda.synchronize()
+        monkeypatch.setattr(ops, "conv2d_backward_weight", real_bw)
+        res[mode] = (tr, {k: float(v) for k, v in losses.items()}, list(batches))
+    assert res["0"][1] == res["1"][1]                                  # the forward pass is the same launches
+    assert max(res["0"][2]) == 2 and 6 in res["1"][2]                  # real + fake + raw passes of two frames each: one batch of 6
+    assert len(res["1"][2]) < len(res["0"][2])
+    for name in ("bucketsG", "bucketsD"):
+        b0, b1 = getattr(res["0"][0], name), getattr(res["1"][0], name)
+        n = 0
+        for s0, s1 in zip(b0.slots, b1.slots):
+            if s0 is None or s1 is None or not s0.filled:
+                continue
+            a, b = s0.view.double(), s1.view.double()
+            d = (a - b).norm().item() / max(a.norm().item(), 1e-30)
+            assert d <= 2e-5, (name, n, tuple(a.shape), d)
+            n += 1
+        assert n >= 20, (name, n)

@@ -127,29 +127,53 @@ _DW_PAIR = [False]     # inside a train-step scope: a direct-kernel layer used b
 
 
 def _paired_direct_wgrad(w, x, dc, fdesc, slot):
-    """Direct (non-Winograd) weight gradient of a layer that the clip's TWO frames went through (counted in forward:
-    `w._t2v_dw_uses`): the first backward node to arrive leaves its (x, dY) on the weight, the second launches ONE reduction
-    over both frames' buffers (ops.conv2d_backward_weight_pair: two base pointers, no copy) -- the kernel pays a fixed ~8
-    stage times per block, 36 stages long for one frame of a 512<->1024 layer and 73 for two (0.64 -> 0.73 of peak).
+    """Direct (non-Winograd) weight gradient of a layer that ran several times in this step's graph (counted in forward:
+    `w._t2v_dw_uses`): the backward nodes leave their (x, dY) on the weight, the LAST one to arrive launches ONE reduction over
+    all of them -- the kernel pays a fixed ~8 stage times per block, so one long reduction beats several short ones:
+      * two uses of one image each (the generator's stride-2 / transposed layers on the clip's two frames):
+        ops.conv2d_backward_weight_pair -- two base pointers, no copy; blocks 36 -> 73 stages, 0.64 -> 0.73 of peak;
+      * anything else (the discriminators' layers: real, fake and raw pass of two frames each -- round 5): the operands are
+        concatenated (a few MB per layer) and reduced as one batch: 3 launches of ~180 us at 0.39 of peak -> one.
     Returns (taken, dW or None): not taken -> the caller reduces this node alone."""
-    if not _DW_PAIR[0] or getattr(w, "_t2v_dw_uses", 0) != 2 or x.shape[0] != 1:
+    uses = getattr(w, "_t2v_dw_uses", 0)
+    if not _DW_PAIR[0] or uses < 2:
         return False, None
     st = getattr(w, "_t2v_dw_stash", None)
     if st is None:
-        w._t2v_dw_stash = (x, dc, fdesc)
+        st = w._t2v_dw_stash = [fdesc]
+    st.append((x, dc))
+    if len(st) - 1 < uses:
         if slot is not None:
             slot.owner.node_done(slot)
         return True, None
-    x0, dc0, _ = st
+    parts = st[1:]
     w._t2v_dw_stash, w._t2v_dw_uses = None, 0
+    return True, _reduce_stashed(parts, fdesc, slot)
+
+
+def _reduce_stashed(parts, fdesc, slot, from_node=True):
+    """one weight-gradient launch over the stashed (x, dY) of a layer; into the bucket slot (-> None) or returned.
+    from_node: called by the backward node that brought the last operands (side stream, the node counts as delivered);
+    False: the flush after the backward pass (current stream; every node has been counted already)"""
+    flat = [t for pr in parts for t in pr]
+    xcs = parts[0][0].shape[-1]
+    with (wgrad_fork(*flat) if (from_node and slot is not None and wgrad_stream_on(parts[0][0])) else contextlib.nullcontext()):
+        if len(parts) == 2 and all(pr[0].shape[0] == 1 for pr in parts) and \
+                ops.backward_weight_strided_supported(fdesc, xcs, parts[0][1].shape[-1]):
+            (x0, dc0), (x1, dc1) = parts
+            dwp = ops.conv2d_backward_weight_pair(x0[0], dc0[0], x1[0], dc1[0], fdesc)
+        elif len(parts) == 1:
+            dwp = ops.conv2d_backward_weight(parts[0][0], parts[0][1], fdesc)
+        else:
+            dwp = ops.conv2d_backward_weight(torch.cat([pr[0] for pr in parts]), torch.cat([pr[1] for pr in parts]), fdesc)
+        if slot is not None:
+            ops.unpack_conv_weight_into(dwp, fdesc, xcs, slot.view, slot.filled)
     if slot is not None:
-        with (wgrad_fork(x, dc, x0, dc0) if wgrad_stream_on(x) else contextlib.nullcontext()):
-            dwp = ops.conv2d_backward_weight_pair(x0[0], dc0[0], x[0], dc[0], fdesc)
-            ops.unpack_conv_weight_into(dwp, fdesc, x.shape[-1], slot.view, slot.filled)
         slot.filled = True
-        slot.owner.node_done(slot)
-        return True, None
-    return True, ops.unpack_conv_weight(ops.conv2d_backward_weight_pair(x0[0], dc0[0], x[0], dc[0], fdesc), fdesc, x.shape[-1])
+        if from_node:
+            slot.owner.node_done(slot)
+        return None
+    return ops.unpack_conv_weight(dwp, fdesc, xcs)
 
 
 @contextlib.contextmanager
@@ -279,14 +303,9 @@ def flush_pending_weight_gradients(params, grads):
     wgrad_join()
     for i, p in enumerate(params):
         half = getattr(p, "_t2v_dw_stash", None)
-        if half is not None:        # a paired direct layer whose second frame never came back: reduce the one that did
-            x0, dc0, fd0 = half
-            sl = grad_slot(p)
-            if sl is not None:
-                ops.unpack_conv_weight_into(ops.conv2d_backward_weight(x0, dc0, fd0), fd0, x0.shape[-1], sl.view, sl.filled)
-                sl.filled = True
-            else:
-                dw = ops.unpack_conv_weight(ops.conv2d_backward_weight(x0, dc0, fd0), fd0, x0.shape[-1])
+        if half is not None:        # a layer whose remaining uses never came back: reduce the ones that did
+            dw = _reduce_stashed(half[1:], half[0], grad_slot(p), from_node=False)
+            if dw is not None:
                 out[i] = dw if out[i] is None else out[i] + dw
         p._t2v_dw_stash, p._t2v_dw_uses = None, 0
         st = getattr(p, "_t2v_wg_state", None)
@@ -456,8 +475,9 @@ class _ConvBlock(torch.autograd.Function):
         if wino_wgrad and w.requires_grad and _WG_BATCH[0]:
             w._t2v_wg_images = getattr(w, "_t2v_wg_images", 0) + B
             wino_wgrad = 2
-        elif not wino_wgrad and w.requires_grad and _DW_PAIR[0] and B == 1 and ops.backward_weight_strided_supported(ddesc, xcs, ycs):
-            w._t2v_dw_uses = getattr(w, "_t2v_dw_uses", 0) + 1      # (exactly two uses: _paired_direct_wgrad)
+        elif not wino_wgrad and w.requires_grad and _DW_PAIR[0] and \
+                (B > 1 or ops.backward_weight_strided_supported(ddesc, xcs, ycs)):
+            w._t2v_dw_uses = getattr(w, "_t2v_dw_uses", 0) + 1      # (two or more uses: _paired_direct_wgrad)
         for prm in (w, b, gamma, beta):
             expect_gradient(prm)
         # (an input nobody differentiates -- the discriminators' real pass -- needs no data-gradient conv)
@@ -1448,7 +1468,7 @@ class Vid2VidTrainer:
         losses against flow_ref [F,H,W,4] (flow_x, flow_y in pixels; default zero flow) and its confidence mask
         conf_ref [F,H,W] (default: ||real - resample(real_prev, flow_ref)|| < 0.02, the rule upstream's FlowNet2
         wrapper applies [RECALL]).  Returns (dict of scalar losses, FIFO for the next chunk)."""
-        with batched_weight_gradients(self.optG.params):
+        with batched_weight_gradients(self.optG.params + self.optD.params):
             return self._train_step(pose, real, face_boxes, prev, real_prev, flow_ref, conf_ref)
 
     def _train_step(self, pose, real, face_boxes, prev, real_prev=None, flow_ref=None, conf_ref=None):
@@ -1613,6 +1633,7 @@ class Vid2VidTrainer:
         self.bucketsG.absorb(gG)
         with input_gradients_off():      # D's loss: no data gradient into the (attached) fake frames
             gD = torch.autograd.grad(loss_D, d_params, allow_unused=True)
+        gD = flush_pending_weight_gradients(d_params, gD)      # (a discriminator layer one of whose passes fed no loss term)
         self.bucketsD.absorb(gD)
         if self.time_comm:       # T2V_TRAIN_COMM_TIMING=1: what of the exchange is still running once the backward kernels
             torch.cuda.synchronize()      # have drained = its exposed (not hidden) part
