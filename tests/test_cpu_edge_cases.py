@@ -208,3 +208,86 @@ def test_packed_weight_cache_remembers_what_the_last_step_used(monkeypatch):
     n = len(calls)
     T.cached_pack(w, "c", maker("c3"))
     assert len(calls) == n + 1
+
+
+def test_collected_weight_gradient_bookkeeping(monkeypatch):
+    """train._paired_direct_wgrad (host logic, no GPU; the kernels replaced by CPU stand-ins that sum x^T dy): a layer counted
+    N times in forward reduces ONCE, when its N-th backward node arrives -- two single images through the two-pointer entry,
+    anything else concatenated; every node counts as delivered exactly once; a layer one of whose passes never comes back is
+    reduced by flush_pending_weight_gradients over what did arrive; a scope left with a stash raises."""
+    import pytest
+    import torch
+    from text2video_amd import ops
+    from text2video_amd import train as T
+    calls = []
+
+    def bw(x, dy, desc, accumulate_into=None):
+        calls.append(("batch", int(x.shape[0])))
+        return torch.einsum("bi,bj->ij", x.reshape(x.shape[0], -1), dy.reshape(dy.shape[0], -1))
+
+    def bw_pair(x0, dy0, x1, dy1, desc, accumulate_into=None):
+        calls.append(("pair", 2))
+        return torch.outer(x0.reshape(-1), dy0.reshape(-1)) + torch.outer(x1.reshape(-1), dy1.reshape(-1))
+    monkeypatch.setattr(ops, "conv2d_backward_weight", bw)
+    monkeypatch.setattr(ops, "conv2d_backward_weight_pair", bw_pair)
+    monkeypatch.setattr(ops, "backward_weight_strided_supported", lambda d, a, b: True)
+    monkeypatch.setattr(ops, "unpack_conv_weight", lambda dwp, d, xcs: dwp)
+
+    def into(dwp, d, xcs, view, acc):
+        view.copy_(view + dwp if acc else dwp)
+    monkeypatch.setattr(ops, "unpack_conv_weight_into", into)
+    g = torch.Generator().manual_seed(0)
+
+    def pair(B):
+        return torch.randn(B, 3, generator=g), torch.randn(B, 2, generator=g)
+
+    def want(parts):
+        return sum(torch.einsum("bi,bj->ij", x, dy) for x, dy in parts)
+    w = torch.nn.Parameter(torch.zeros(3, 2))
+    # (1) without a bucket slot: the gradient comes back from the last node, None from the earlier ones
+    with T.batched_weight_gradients([w]):
+        w._t2v_dw_uses = 3
+        parts = [pair(2), pair(2), pair(2)]
+        outs = [T._paired_direct_wgrad(w, x, dy, "desc", None) for x, dy in parts]
+        assert [o[0] for o in outs] == [True, True, True] and outs[0][1] is None and outs[1][1] is None
+        assert torch.allclose(outs[2][1], want(parts)) and calls == [("batch", 6)]
+        assert w._t2v_dw_stash is None and w._t2v_dw_uses == 0
+        # two single images: the two-pointer entry, no copy
+        del calls[:]
+        w._t2v_dw_uses = 2
+        parts = [pair(1), pair(1)]
+        outs = [T._paired_direct_wgrad(w, x, dy, "desc", None) for x, dy in parts]
+        assert torch.allclose(outs[1][1], want(parts)) and calls == [("pair", 2)]
+        # one use: not taken, the caller reduces the node alone
+        w._t2v_dw_uses = 1
+        assert T._paired_direct_wgrad(w, *pair(2), "desc", None) == (False, None)
+    # (2) with a bucket slot: every node counts once, the slot is written once
+    gb = T.GradBuckets([w], bucket_mb=1, register=True)
+    with T.batched_weight_gradients([w]):
+        gb.begin_step()
+        for _ in range(3):
+            T.expect_gradient(w)
+        gb.seal()
+        w._t2v_dw_uses = 3
+        sl = T.grad_slot(w)
+        parts = [pair(2), pair(1), pair(2)]          # (ragged batches are concatenated all the same)
+        del calls[:]
+        for i, (x, dy) in enumerate(parts):
+            assert T._paired_direct_wgrad(w, x, dy, "desc", sl) == (True, None)
+            assert sl.filled is (i == 2)
+        assert calls == [("batch", 5)] and torch.allclose(sl.view, want(parts))
+        gb.absorb([None])
+        gb.finish()
+        assert torch.allclose(w.grad, want(parts))
+    # (3) a pass that never comes back: the flush reduces what arrived; leaving the scope without it raises
+    with T.batched_weight_gradients([w]):
+        w._t2v_dw_uses = 3
+        parts = [pair(2), pair(2)]
+        for x, dy in parts:
+            assert T._paired_direct_wgrad(w, x, dy, "desc", None) == (True, None)
+        out = T.flush_pending_weight_gradients([w], [None])
+        assert torch.allclose(out[0], want(parts)) and w._t2v_dw_stash is None
+    with pytest.raises(RuntimeError, match="flush_pending_weight_gradients"):
+        with T.batched_weight_gradients([w]):
+            w._t2v_dw_uses = 2
+            T._paired_direct_wgrad(w, *pair(1), "desc", None)
