@@ -282,6 +282,9 @@ def run(text, person, root=".", spec=PHONEME, dataset_root=None, write_images=Tr
             workers = min(8, len(os.sched_getaffinity(0)))
         except (AttributeError, OSError):
             workers = 1
+    _t = __import__("sys").modules.get("torch")
+    if _t is not None and getattr(_t, "cuda", None) is not None and _t.cuda.is_initialized():
+        workers = 1      # a live HIP runtime in this process: a fork would copy (and tear down) its mappings per worker
     if workers > 1 and len(jobs) >= 4 * workers:
         import multiprocessing as mp
         from . import keypoints
