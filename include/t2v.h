@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define T2V_ABI_VERSION 14
+#define T2V_ABI_VERSION 15
 
 typedef enum {
     T2V_OK = 0,
@@ -53,8 +53,15 @@ enum { T2V_ACT_NONE = 0, T2V_ACT_TANH = 1, T2V_ACT_FLOW_W = 2 /* ch0,1: x*20 ; c
  * FLOPs than the direct conv).  WINOGRAD_F4 = F(4x4,3x3), 36 batched GEMMs, 4x fewer MFMA FLOPs,
  * interpolation points {0, +-3/4, +-3/2, inf} (rounding error ~4x the direct kernel's, 1.5e-6 of the
  * output's std per conv).  Only where t2v_conv_winograd_supported() says so; packed weights differ
- * per algorithm. */
-enum { T2V_ALGO_DIRECT = 0, T2V_ALGO_WINOGRAD = 1, T2V_ALGO_WINOGRAD_F4 = 2 };
+ * per algorithm.
+ * POLYPHASE (ABI 15) = the stride-2 3x3 convs (zero pad 1) and ConvTranspose2d(3, stride 2, pad 1, output_padding 1) as
+ * polyphase Winograd F(4,2): per dimension the 2-tap sub-correlation on one sub-pixel phase as F(4,2) (5 products per 4
+ * outputs), the 1-tap one as it is -- 81 batched GEMMs [tiles x Cin] x [Cin x Cout] per 4x4 (8x8) output tile instead of
+ * 144 multiply-adds per channel pair: 0.5625x the MFMA FLOPs of SpatialConvolutionMM / SpatialFullDilatedConvolution
+ * (THCUNN.h:664,794), points {0, +-3/4, 3/2, inf}.  Only where t2v_conv_polyphase_supported() says so; it goes through
+ * the *_winograd entry points (pack_weight, workspace_floats, forward_winograd), its statistics partials through the
+ * finalize entries like any producer's. */
+enum { T2V_ALGO_DIRECT = 0, T2V_ALGO_WINOGRAD = 1, T2V_ALGO_WINOGRAD_F4 = 2, T2V_ALGO_POLYPHASE = 3 };
 
 typedef struct t2v_ctx t2v_ctx;
 
@@ -137,6 +144,10 @@ int t2v_conv2d_forward_batch(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d,
  * the ceil(H/m) x ceil(W/m) tile grid (m = 2 | 4) is ragged at the bottom / right edge and padded with
  * empty tiles to a multiple of 128 (extra GEMM rows, masked in the output transform). */
 int t2v_conv_winograd_supported(const t2v_conv_desc* d, int x_cs);
+/* 1 where T2V_ALGO_POLYPHASE applies to `d` (d->algo ignored): 3x3, stride 2; a conv with zero padding 1 and H, W multiples
+ * of 8, or a transposed conv with pad 1 / output_padding 1 and H, W multiples of 4; x_cs == Cin, Cin % 32 == 0, Cout % 128 == 0, no
+ * activation.  t2v_generator_layer_desc() selects it where it measured faster. */
+int t2v_conv_polyphase_supported(const t2v_conv_desc* d, int x_cs);
 /* The algorithm the library itself would pick for `d` (d->algo ignored): the one with the fewest GEMM rows among
  * direct (9 per output pixel), F(2x2,3x3) and F(4x4,3x3) (16 | 36 per tile, tile count padded to 128).
  * cap: 0 = any, 1 = direct only, 2 = at most F(2x2,3x3).  Returns a T2V_ALGO_* value. */

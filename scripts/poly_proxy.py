@@ -13,8 +13,11 @@ def timed(fn, n=60):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
+# second proxy: the same total number of tile rows in 36 positions (a 96x96 / 192x192 map: 576 / 2304 tiles = 256 / 1024 x 81/36)
 for name, (HT, C, N) in {"down3 512->1024 (64x64 out)": (64, 512, 1024), "up1 1024->512 (64x64 in)": (64, 1024, 512),
-                         "down2 256->512 (128x128 out)": (128, 256, 512), "up2 512->256 (128x128 in)": (128, 512, 256)}.items():
+                         "down2 256->512 (128x128 out)": (128, 256, 512), "up2 512->256 (128x128 in)": (128, 512, 256),
+                         "down3 proxy, 96x96 map (576 tiles x 36)": (96, 512, 1024), "up1 proxy, 96x96 map": (96, 1024, 512),
+                         "down2 proxy, 192x192 map (2304 tiles x 36)": (192, 256, 512), "up2 proxy, 192x192 map": (192, 512, 256)}.items():
     desc = ops.conv_desc(HT, HT, C, N, 3, 1, 1, ops.PAD_REFLECT, algo=ops.ALGO_WINOGRAD_F4)
     x = torch.randn(HT, HT, C, device=dev)
     w = torch.randn(N, C, 3, 3, device=dev) * 0.02

@@ -15,9 +15,9 @@ LIB_PATH = os.environ.get("T2V_LIBRARY") or os.path.join(_HERE, "lib", "libt2v_h
 T2V_OK = 0
 PAD_ZERO, PAD_REFLECT = 0, 1
 ACT_NONE, ACT_TANH, ACT_FLOW_W, ACT_LRELU = 0, 1, 2, 3
-ABI_VERSION = 14
+ABI_VERSION = 15
 MAX_BATCH = 8     # T2V_MAX_BATCH
-ALGO_DIRECT, ALGO_WINOGRAD, ALGO_WINOGRAD_F4 = 0, 1, 2
+ALGO_DIRECT, ALGO_WINOGRAD, ALGO_WINOGRAD_F4, ALGO_POLYPHASE = 0, 1, 2, 3
 
 
 class ConvDesc(Structure):
@@ -68,6 +68,7 @@ SIGNATURES = {
     "t2v_conv2d_forward_batch": (c_int, [c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_void_p, c_int, c_void_p, c_void_p,
                                          c_void_p, c_int, c_void_p]),
     "t2v_conv_winograd_supported": (c_int, [POINTER(ConvDesc), c_int]),
+    "t2v_conv_polyphase_supported": (c_int, [POINTER(ConvDesc), c_int]),
     "t2v_conv_best_algo": (c_int, [POINTER(ConvDesc), c_int, c_int]),
     "t2v_conv_winograd_workspace_floats": (c_size_t, [POINTER(ConvDesc), c_int]),
     "t2v_conv_winograd_tile_rows": (c_int, [POINTER(ConvDesc)]),

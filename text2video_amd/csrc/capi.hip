@@ -446,6 +446,68 @@ int winograd_forward(t2v_ctx* ctx, hipStream_t s, const t2v_conv_desc* d, const 
     return T2V_OK;
 }
 
+bool polyphase_supported(const t2v_conv_desc* d, int x_cs) {
+    if (!d || d->kH != 3 || d->kW != 3 || d->stride != 2 || d->pad != 1 || d->pad_mode != T2V_PAD_ZERO) return false;
+    if (d->act != T2V_ACT_NONE || d->Cin % 32 != 0 || x_cs != d->Cin || d->Cout % 128 != 0) return false;
+    if (d->transposed) return d->output_padding == 1 && d->H >= 4 && d->W >= 4 && d->H % 4 == 0 && d->W % 4 == 0;
+    return d->H >= 8 && d->W >= 8 && d->H % 8 == 0 && d->W % 8 == 0;
+}
+
+// where it measured faster than the implicit-GEMM kernel (scripts/poly_check.py, MI355X): both channel counts >= 256 -- the
+// transforms move 81/64 + 81/16 of a layer's input + output, against a GEMM of 0.5625x the direct FLOPs -- and enough tiles to
+// fill the fixed grid.  512->1024 @128x128 301 -> 229 us, 1024->512 (transposed) @64x64 325 -> 214, 256->512 @256x256 272 ->
+// 245, 512->256 (transposed) @128x128 303 -> 248; 128->256 @512x512 284 -> 362 (no)
+bool polyphase_pays(const t2v_conv_desc* d, int x_cs) {
+    return polyphase_supported(d, x_cs) && d->Cin >= 256 && d->Cout >= 256 && poly_tiles_real(d) >= 128;
+}
+
+// stages bit 1 = input transform, 2 = the 81 batched GEMMs, 4 = output transform (bias, statistics partials)
+int polyphase_forward(t2v_ctx* ctx, hipStream_t s, const t2v_conv_desc* d, const float* x, const float* w_packed,
+                      const float* bias, float* y, float* stats_partial, float* workspace, int stages) {
+    T2V_TRY(check_async_errors());
+    const int up = d->transposed ? 1 : 0;
+    const int T = poly_tiles_padded(d), rows = poly_tiles_real(d);
+    float* V = workspace;
+    float* Mm = workspace + (size_t)81 * T * d->Cin;
+    if (stages & 1) T2V_TRY(launch_polyphase_input(s, x, V, d->H, d->W, d->Cin, up, T));
+    if (stages & 2) {
+        SkGemm g;
+        g.a = V; g.b = w_packed; g.c = Mm; g.scratch = workspace + (size_t)81 * T * ((size_t)d->Cin + d->Cout);
+        g.err = async_error_word();
+        g.a_group_stride = (long)T * d->Cin;
+        g.groups = 81; g.T = T; g.K = d->Cin; g.N = d->Cout; g.c_cs = d->Cout;
+        if (wino_gemm_skt_ok(81, rows, T, d->Cin, d->Cout, d->Cout)) {
+            T2V_TRY(launch_wino_gemm_skt(s, g, rows));
+        } else if (wino_gemm_skr_ok(81, rows, T, d->Cin, d->Cout, d->Cout)) {
+            T2V_TRY(launch_wino_gemm_skr(s, g, rows));
+        } else if (wino_gemm_sk_ok(81, T, d->Cin, d->Cout, d->Cout, rows)) {
+            g.rows = rows;
+            T2V_TRY(launch_wino_gemm_sk(s, g));
+        } else {      // one block per tile: the batched GEMM as a 1x1 conv over an 81 x T image
+            t2v_conv_desc gd;
+            memset(&gd, 0, sizeof(gd));
+            gd.H = 81; gd.W = T; gd.Cin = d->Cin; gd.Cout = d->Cout; gd.kH = gd.kW = 1; gd.stride = 1; gd.pad = 0;
+            gd.pad_mode = T2V_PAD_ZERO; gd.act = T2V_ACT_NONE; gd.act_scale = 1.f;
+            ConvPlan pl;
+            T2V_TRY(build_conv_plan(&gd, d->Cin, true, &pl));
+            if (T % pl.BM != 0 && pl.tile == kTileL) {
+                pl.tile = kTileQ;
+                conv_tile_dims(pl.tile, &pl.BM, &pl.BN);
+                pl.kp.ntiles = (gd.Cout + pl.BN - 1) / pl.BN;
+                pl.kp.mtiles = (pl.kp.M + pl.BM - 1) / pl.BM;
+                pl.nparts = pl.kp.nphases * pl.kp.mtiles;
+            }
+            T2V_REQUIRE(T % pl.BM == 0, "polyphase gemm: tile rows %d do not divide %d", pl.BM, T);
+            pl.kp.group_mtiles = T / pl.BM;
+            pl.kp.group_w_stride = (long)pl.Cout_p * d->Cin;
+            T2V_TRY(run_conv(ctx, s, pl, V, w_packed, nullptr, Mm, d->Cout, nullptr));
+        }
+    }
+    if (stages & 4)
+        T2V_TRY(launch_polyphase_output(s, Mm, bias, y, stats_partial, poly_out_h(d), poly_out_w(d), d->Cout, up, T));
+    return T2V_OK;
+}
+
 }  // namespace t2v
 
 using namespace t2v;
@@ -534,8 +596,10 @@ size_t t2v_conv_packed_weight_floats(const t2v_conv_desc* d, int x_cs) {
     ConvPlan pl;
     if (build_conv_plan(d, x_cs, false, &pl) != T2V_OK) return 0;
     if (is_winograd(d->algo)) return winograd_supported(d, x_cs, d->algo) ? (size_t)wino_pos(d->algo) * pl.Cout_p * x_cs : 0;
+    if (d->algo == T2V_ALGO_POLYPHASE) return polyphase_supported(d, x_cs) ? (size_t)81 * pl.Cout_p * x_cs : 0;
     return pl.wfloats;
 }
+int t2v_conv_polyphase_supported(const t2v_conv_desc* d, int x_cs) { return polyphase_supported(d, x_cs) ? 1 : 0; }
 
 int t2v_conv_winograd_supported(const t2v_conv_desc* d, int x_cs) {
     return (winograd_supported(d, x_cs, T2V_ALGO_WINOGRAD) ? 1 : 0) | (winograd_supported(d, x_cs, T2V_ALGO_WINOGRAD_F4) ? 2 : 0);
@@ -544,6 +608,7 @@ int t2v_conv_winograd_supported(const t2v_conv_desc* d, int x_cs) {
 int t2v_conv_best_algo(const t2v_conv_desc* d, int x_cs, int cap) { return d ? best_conv_algo(d, x_cs, cap) : T2V_ALGO_DIRECT; }
 
 size_t t2v_conv_winograd_workspace_floats(const t2v_conv_desc* d, int x_cs) {
+    if (d && d->algo == T2V_ALGO_POLYPHASE) return polyphase_supported(d, x_cs) ? polyphase_workspace_floats(d) : 0;
     if (!d || !winograd_supported(d, x_cs, d->algo)) return 0;
     return winograd_workspace_floats(d);
 }
@@ -552,6 +617,11 @@ int t2v_conv2d_forward_winograd_stages(t2v_ctx* ctx, void* stream, const t2v_con
                                        const float* w_packed, const float* bias, float* y, int y_cs,
                                        float* stats_partial, float* workspace, int stages) {
     T2V_REQUIRE(ctx && d && x && w_packed && y && workspace, "winograd forward: null pointer");
+    if (d->algo == T2V_ALGO_POLYPHASE) {
+        T2V_REQUIRE(polyphase_supported(d, x_cs), "polyphase forward: shape not supported (t2v_conv_polyphase_supported)");
+        T2V_REQUIRE(y_cs == d->Cout, "polyphase forward: output channel storage must equal Cout");
+        return polyphase_forward(ctx, (hipStream_t)stream, d, x, w_packed, bias, y, stats_partial, workspace, stages);
+    }
     T2V_REQUIRE(winograd_supported(d, x_cs, d->algo),
                 "winograd forward: shape/algo not supported (t2v_conv_winograd_supported)");
     T2V_REQUIRE(y_cs == d->Cout, "winograd forward: output channel storage must equal Cout");
@@ -570,6 +640,10 @@ static int pack_weight(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, int x
     ConvPlan pl;
     T2V_TRY(build_conv_plan(d, x_cs, false, &pl));
     hipStream_t s = (hipStream_t)stream;
+    if (d->algo == T2V_ALGO_POLYPHASE) {
+        T2V_REQUIRE(polyphase_supported(d, x_cs) && !adjoint, "pack_weight: polyphase form not supported for this shape");
+        return launch_polyphase_weight(s, w_torch_dev, packed_dev, d->Cout, d->Cin, pl.Cout_p, x_cs, d->transposed ? 1 : 0);
+    }
     if (is_winograd(d->algo)) {
         T2V_REQUIRE(winograd_supported(d, x_cs, d->algo), "pack_weight: Winograd not supported for this shape");
         return (d->algo == T2V_ALGO_WINOGRAD_F4 ? launch_winograd4_weight : launch_winograd_weight)(
@@ -594,6 +668,7 @@ int t2v_conv_pack_weight_adjoint(t2v_ctx* ctx, void* stream, const t2v_conv_desc
 size_t t2v_conv_stats_floats(const t2v_conv_desc* d) {
     if (d && is_winograd(d->algo))   // one partial per 128 output-pixel slots of the padded tile grid
         return (size_t)(wino_tiles_padded(d, d->algo) * wino_m(d->algo) * wino_m(d->algo) / 128) * d->Cout * 2;
+    if (d && d->algo == T2V_ALGO_POLYPHASE) return (size_t)(poly_tiles_padded(d) * poly_m(d) * poly_m(d) / 128) * d->Cout * 2;
     ConvPlan pl;
     if (!d || build_conv_plan(d, round_up(d->Cin, 4), true, &pl) != T2V_OK) return 0;
     return (size_t)pl.nparts * d->Cout * 2;
@@ -624,6 +699,9 @@ int t2v_instance_norm_finalize(t2v_ctx* ctx, void* stream, const t2v_conv_desc* 
         return launch_inorm_finalize_winograd((hipStream_t)stream, stats_partial, wino_m(producer->algo),
                                               wino_out_h(producer), wino_out_w(producer), producer->Cout, eps, mean_rstd, 1);
     }
+    if (producer && producer->algo == T2V_ALGO_POLYPHASE)
+        return launch_inorm_finalize_winograd((hipStream_t)stream, stats_partial, poly_m(producer), poly_out_h(producer),
+                                              poly_out_w(producer), producer->Cout, eps, mean_rstd, 1);
     ConvPlan pl;
     T2V_TRY(build_conv_plan(producer, round_up(producer ? producer->Cin : 0, 4), true, &pl));
     if (pl.tile == kTileStem)
@@ -638,6 +716,9 @@ static int batch_norm_finalize(hipStream_t s, const t2v_conv_desc* producer, int
     if (producer && is_winograd(producer->algo))
         return launch_inorm_finalize_winograd(s, stats_partial, wino_m(producer->algo), wino_out_h(producer),
                                               wino_out_w(producer), producer->Cout, eps, mean_rstd, batch, nullptr, ru);
+    if (producer && producer->algo == T2V_ALGO_POLYPHASE)
+        return launch_inorm_finalize_winograd(s, stats_partial, poly_m(producer), poly_out_h(producer), poly_out_w(producer),
+                                              producer->Cout, eps, mean_rstd, batch, nullptr, ru);
     ConvPlan pl;
     T2V_TRY(build_conv_plan(producer, round_up(producer ? producer->Cin : 0, 4), true, &pl));
     if (pl.tile == kTileStem)

@@ -45,6 +45,22 @@ inline size_t winograd_workspace_floats(const t2v_conv_desc* d, int nimg = 1) {
 // GEMM rows of the whole conv (all positions): what the algorithm choice compares
 inline long wino_gemm_rows(const t2v_conv_desc* d, int algo) { return (long)wino_pos(algo) * wino_tiles_padded(d, algo); }
 bool winograd_supported(const t2v_conv_desc* d, int x_cs, int algo);
+// ---- polyphase Winograd F(4,2) of the stride-2 / transposed 3x3 layers (polyphase.hip): 81 positions, tiles of 4x4 outputs
+// (down) | 4x4 inputs = 8x8 outputs (up)
+bool polyphase_supported(const t2v_conv_desc* d, int x_cs);
+bool polyphase_pays(const t2v_conv_desc* d, int x_cs);      // ... and is the faster form (the generator's selection rule)
+inline int poly_tiles_real(const t2v_conv_desc* d) {
+    return d->transposed ? (d->H / 4) * (d->W / 4) : (d->H / 8) * (d->W / 8);
+}
+inline int poly_tiles_padded(const t2v_conv_desc* d) { return wino_pad_tiles(poly_tiles_real(d)); }
+inline int poly_out_h(const t2v_conv_desc* d) { return d->transposed ? 2 * d->H : d->H / 2; }
+inline int poly_out_w(const t2v_conv_desc* d) { return d->transposed ? 2 * d->W : d->W / 2; }
+inline int poly_m(const t2v_conv_desc* d) { return d->transposed ? 8 : 4; }       // output tile edge (statistics partial geometry)
+inline size_t polyphase_workspace_floats(const t2v_conv_desc* d) {                // V + M + the fixed-grid GEMM's hand-over scratch
+    return (size_t)81 * poly_tiles_padded(d) * ((size_t)d->Cin + d->Cout) + wino_gemm_sk_scratch_floats();
+}
+int polyphase_forward(t2v_ctx* ctx, hipStream_t s, const t2v_conv_desc* d, const float* x, const float* w_packed,
+                      const float* bias, float* y, float* stats_partial, float* workspace, int stages);
 int best_conv_algo(const t2v_conv_desc* d, int x_cs, int cap);
 int build_winograd_gemm_plan(const t2v_conv_desc* d, ConvPlan* pl, int nimg = 1);
 // A batch of images through one Winograd conv (F(4x4,3x3) only when nimg > 1): the images' maps x / y are

@@ -49,8 +49,12 @@ void enumerate_layers(const t2v_gen_desc& g, std::vector<LayerSpec>& out) {
     const int H = g.H, W = g.W;
     auto enc = [&](int in_nc) {
         out.push_back({mk_conv(H, W, in_nc, G, 7, 1, 3, T2V_PAD_REFLECT, 0), round_up(in_nc, 4), true});
-        for (int i = 0; i < n; ++i)
-            out.push_back({mk_conv(H >> i, W >> i, G << i, G << (i + 1), 3, 2, 1, T2V_PAD_ZERO, 0), G << i, true});
+        for (int i = 0; i < n; ++i) {
+            t2v_conv_desc cd = mk_conv(H >> i, W >> i, G << i, G << (i + 1), 3, 2, 1, T2V_PAD_ZERO, 0);
+            // the deep stride-2 layers as polyphase Winograd F(4,2) (polyphase.hip) where that is the faster form
+            if (g.conv_algo == 0 && polyphase_pays(&cd, G << i)) cd.algo = T2V_ALGO_POLYPHASE;
+            out.push_back({cd, G << i, true});
+        }
     };
     auto rbs = [&](int count) {
         const int C = G << n;
@@ -62,7 +66,9 @@ void enumerate_layers(const t2v_gen_desc& g, std::vector<LayerSpec>& out) {
     auto ups = [&]() {
         for (int i = 0; i < n; ++i) {
             const int l = n - i;
-            out.push_back({mk_conv(H >> l, W >> l, G << l, G << (l - 1), 3, 2, 1, T2V_PAD_ZERO, 1), G << l, true});
+            t2v_conv_desc cd = mk_conv(H >> l, W >> l, G << l, G << (l - 1), 3, 2, 1, T2V_PAD_ZERO, 1);
+            if (g.conv_algo == 0 && polyphase_pays(&cd, G << l)) cd.algo = T2V_ALGO_POLYPHASE;
+            out.push_back({cd, G << l, true});
         }
     };
     const int nb_enc = g.is_local ? 0 : g.n_blocks - g.n_blocks / 2;
@@ -144,6 +150,9 @@ void plan_buffers(const t2v_gen_desc& g, const std::vector<LayerSpec>& layers, i
             const int m = wino_m(L.cd.algo);
             const size_t s = (size_t)(wino_tiles_padded(&L.cd, L.cd.algo) * m * m / 128) * L.cd.Cout * 2;
             if (s > max_stats) max_stats = s;
+        } else if (L.has_norm && L.cd.algo == T2V_ALGO_POLYPHASE) {
+            const size_t s = (size_t)(poly_tiles_padded(&L.cd) * poly_m(&L.cd) * poly_m(&L.cd) / 128) * L.cd.Cout * 2;
+            if (s > max_stats) max_stats = s;
         } else if (L.has_norm && build_conv_plan(&L.cd, L.x_cs, true, &pl) == T2V_OK) {
             const size_t s = (size_t)pl.nparts * L.cd.Cout * 2;
             if (s > max_stats) max_stats = s;
@@ -162,6 +171,9 @@ void plan_buffers(const t2v_gen_desc& g, const std::vector<LayerSpec>& layers, i
     for (const LayerSpec& L : layers)
         if (is_winograd(L.cd.algo)) {
             const size_t w = winograd_workspace_floats(&L.cd, L.cd.algo == T2V_ALGO_WINOGRAD_F4 ? nimg : 1);
+            if (w > max_wino) max_wino = w;
+        } else if (L.cd.algo == T2V_ALGO_POLYPHASE) {
+            const size_t w = polyphase_workspace_floats(&L.cd);
             if (w > max_wino) max_wino = w;
         }
     for (int k = 0; k < 2; ++k) b.wino[k] = max_wino ? a.alloc(max_wino) : nullptr;
@@ -223,6 +235,12 @@ struct Runner {
             T2V_TRY(winograd_forward(ctx, s, &L.cd, x, w.w, w.bias, y, stats, b.wino[sc], 7, &wb));
             T2V_TRY(launch_inorm_finalize_winograd(s, stats, wm, L.cd.H, L.cd.W, Cout, g.eps, mr, 1, fin_of(im)));
             return launch_inorm_apply(s, y, mr, gam, bet, res1, res2, y, (long)M, Cout, relu);
+        }
+        if (L.cd.algo == T2V_ALGO_POLYPHASE) {
+            const int Ho = poly_out_h(&L.cd), Wo = poly_out_w(&L.cd);
+            T2V_TRY(polyphase_forward(ctx, s, &L.cd, x, w.w, w.bias, y, stats, b.wino[sc], 7));
+            T2V_TRY(launch_inorm_finalize_winograd(s, stats, poly_m(&L.cd), Ho, Wo, Cout, g.eps, mr, 1, fin_of(im)));
+            return launch_inorm_apply(s, y, mr, gam, bet, res1, res2, y, (long)Ho * Wo, Cout, relu);
         }
         T2V_TRY(build_conv_plan(&L.cd, L.x_cs, true, &pl));
         T2V_TRY(run_conv(ctx, s, pl, x, w.w, w.bias, y, Cout, stats));

@@ -12,7 +12,7 @@ from ._xp import torch     # the real torch, or leantorch under vid2vid/test.py'
 
 from . import _lib
 from ._lib import (ACT_FLOW_W, ACT_LRELU, ACT_NONE, ACT_TANH, ALGO_DIRECT, ALGO_WINOGRAD,  # noqa: F401
-                   ALGO_WINOGRAD_F4, PAD_REFLECT, PAD_ZERO, ConvDesc, check)
+                   ALGO_POLYPHASE, ALGO_WINOGRAD_F4, PAD_REFLECT, PAD_ZERO, ConvDesc, check)
 
 _contexts = {}
 
@@ -85,6 +85,12 @@ def winograd_supported(desc, x_cs=None, algo=None):
     return bool(mask & (2 if algo == ALGO_WINOGRAD_F4 else 1))
 
 
+def polyphase_supported(desc, x_cs=None):
+    """True when `desc` (a stride-2 3x3 conv or its transposed counterpart) can run as ALGO_POLYPHASE (include/t2v.h)."""
+    x_cs = round_up(desc.Cin, 4) if x_cs is None else x_cs
+    return bool(_lib.load().t2v_conv_polyphase_supported(ctypes.byref(desc), x_cs))
+
+
 def best_conv_algo(desc, x_cs=None, cap=0):
     """ALGO_* the library would pick for `desc` (fewest GEMM rows; generator.hip uses the same rule)."""
     x_cs = round_up(desc.Cin, 4) if x_cs is None else x_cs
@@ -93,7 +99,7 @@ def best_conv_algo(desc, x_cs=None, cap=0):
 
 def conv2d_auto(x, packed_w, bias, desc, y_cs=None, stats=None, out=None):
     """conv2d or conv2d_winograd, whichever desc.algo (and the weight packing that goes with it) says."""
-    if desc.algo in (ALGO_WINOGRAD, ALGO_WINOGRAD_F4):
+    if desc.algo in (ALGO_WINOGRAD, ALGO_WINOGRAD_F4, ALGO_POLYPHASE):
         assert y_cs is None or y_cs == desc.Cout
         return conv2d_winograd(x, packed_w, bias, desc, stats=stats, out=out)
     return conv2d(x, packed_w, bias, desc, y_cs=y_cs, stats=stats, out=out)
