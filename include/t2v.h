@@ -144,9 +144,9 @@ int t2v_conv2d_forward_batch(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d,
  * the ceil(H/m) x ceil(W/m) tile grid (m = 2 | 4) is ragged at the bottom / right edge and padded with
  * empty tiles to a multiple of 128 (extra GEMM rows, masked in the output transform). */
 int t2v_conv_winograd_supported(const t2v_conv_desc* d, int x_cs);
-/* 1 where T2V_ALGO_POLYPHASE applies to `d` (d->algo ignored): 3x3, stride 2; a conv with zero padding 1 and H, W multiples
- * of 8, or a transposed conv with pad 1 / output_padding 1 and H, W multiples of 4; x_cs == Cin, Cin % 32 == 0, Cout % 128 == 0, no
- * activation.  t2v_generator_layer_desc() selects it where it measured faster. */
+/* 1 where T2V_ALGO_POLYPHASE applies to `d` (d->algo ignored): 3x3, stride 2; a conv with zero padding 1 and even H, W, or a
+ * transposed conv with pad 1 / output_padding 1; x_cs == Cin, Cin % 32 == 0, Cout % 128 == 0, no activation.  The tile grid
+ * (4x4 outputs | 4x4 inputs) is ragged at the bottom / right edge and padded with empty tiles, as for the Winograd forms.  t2v_generator_layer_desc() selects it where it measured faster. */
 int t2v_conv_polyphase_supported(const t2v_conv_desc* d, int x_cs);
 /* The algorithm the library itself would pick for `d` (d->algo ignored): the one with the fewest GEMM rows among
  * direct (9 per output pixel), F(2x2,3x3) and F(4x4,3x3) (16 | 36 per tile, tile count padded to 128).

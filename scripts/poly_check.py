@@ -15,6 +15,9 @@ def timed(fn, n=40):
     return e0.elapsed_time(e1) / n * 1e3
 shapes = [("down3", 128, 128, 512, 1024, False), ("down2", 256, 256, 256, 512, False), ("up1", 64, 64, 1024, 512, True),
           ("up2", 128, 128, 512, 256, True), ("down3 512x320", 128, 80, 512, 1024, False), ("up1 512x320", 64, 40, 1024, 512, True),
+          ("down3 512x680", 128, 170, 512, 1024, False), ("down2 512x680", 256, 340, 256, 512, False),
+          ("up1 512x680", 64, 85, 1024, 512, True), ("up2 512x680", 128, 170, 512, 256, True), ("ragged small", 10, 14, 32, 128, False),
+          ("ragged small up", 7, 9, 64, 128, True),
           ("down1", 512, 512, 128, 256, False), ("up3", 256, 256, 256, 128, True),
           ("down3 1024^2", 256, 256, 512, 1024, False), ("up1 1024^2", 128, 128, 1024, 512, True),
           ("ngf64 down2", 128, 128, 128, 256, False), ("ngf64 up1", 64, 64, 512, 256, True),

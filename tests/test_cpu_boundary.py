@@ -134,6 +134,47 @@ def test_algorithm_choice_and_winograd_bookkeeping(lib_built):
     assert lib_built.t2v_conv_stats_floats(ctypes.byref(desc(1024, 1024, C=128))) > 0
 
 
+def test_polyphase_bookkeeping_and_generator_selection(lib_built):
+    """T2V_ALGO_POLYPHASE (ABI 15; the deep stride-2 3x3 convs and their transposed counterparts as polyphase Winograd F(4,2)):
+    where it applies, its buffer sizes, and which layers of the generator the library gives it to -- host-side planning only."""
+    from text2video_amd import _lib
+    from text2video_amd._lib import ConvDesc
+
+    def desc(H, W, Cin, Cout, tr=0, stride=2, pad=1, pad_mode=_lib.PAD_ZERO, k=3, act=_lib.ACT_NONE):
+        return ConvDesc(H, W, Cin, Cout, k, k, stride, pad, pad_mode, tr, act, 1.0, 1 if tr else 0, _lib.ALGO_POLYPHASE)
+
+    ok = lambda d: lib_built.t2v_conv_polyphase_supported(ctypes.byref(d), d.Cin)
+    down3, up1 = desc(128, 128, 512, 1024), desc(64, 64, 1024, 512, tr=1)
+    assert ok(down3) == 1 and ok(up1) == 1 and ok(desc(128, 80, 512, 1024)) == 1 and ok(desc(64, 40, 1024, 512, tr=1)) == 1
+    assert ok(desc(128, 170, 512, 1024)) == 1 and ok(desc(64, 85, 1024, 512, tr=1)) == 1       # ragged tile grids (512x680 frames)
+    assert ok(desc(128, 85, 512, 1024)) == 0          # a down conv needs even H, W
+    assert ok(desc(128, 128, 512, 1024, stride=1)) == 0 and ok(desc(128, 128, 512, 1024, pad_mode=_lib.PAD_REFLECT)) == 0
+    assert ok(desc(128, 128, 48, 1024)) == 0 and ok(desc(128, 128, 512, 192)) == 0      # Cin % 32, Cout % 128
+    assert ok(desc(128, 128, 512, 1024, act=_lib.ACT_LRELU)) == 0 and ok(desc(128, 128, 512, 1024, k=4)) == 0
+    assert lib_built.t2v_conv_polyphase_supported(ctypes.byref(down3), 516) == 0        # channel storage must equal Cin
+    # 81 positions: packed weight, V + M of the 256 tiles + the fixed-grid GEMM's hand-over scratch, one partial per 128 pixels
+    assert lib_built.t2v_conv_packed_weight_floats(ctypes.byref(down3), 512) == 81 * 1024 * 512
+    assert lib_built.t2v_conv_winograd_workspace_floats(ctypes.byref(down3), 512) == 81 * 256 * (512 + 1024) + 1024 * 4 * (64 * 64 + 2)
+    assert lib_built.t2v_conv_winograd_workspace_floats(ctypes.byref(up1), 1024) == 81 * 256 * (1024 + 512) + 1024 * 4 * (64 * 64 + 2)
+    assert lib_built.t2v_conv_stats_floats(ctypes.byref(down3)) == (64 * 64 // 128) * 1024 * 2
+    assert lib_built.t2v_conv_stats_floats(ctypes.byref(up1)) == (128 * 128 // 128) * 512 * 2
+    h, w = ctypes.c_int(), ctypes.c_int()
+    assert lib_built.t2v_conv_out_dims(ctypes.byref(up1), ctypes.byref(h), ctypes.byref(w)) == 0 and (h.value, w.value) == (128, 128)
+    # the generator: at ngf 128 the 256->512 / 512->1024 downs and the 1024->512 / 512->256 ups, not the 128<->256 layers
+    from text2video_amd.generator import GeneratorSpec, _gen_desc
+    for (H, W, cap, want) in ((512, 512, 0, 8), (512, 320, 0, 8), (512, 680, 0, 8), (512, 512, 1, 0)):
+        gd = _gen_desc(GeneratorSpec(ngf=128, n_downsample=3, n_blocks=9, no_flow=False, norm="batch"), H, W, cap)
+        n = lib_built.t2v_generator_num_layers(ctypes.byref(gd))
+        algos = []
+        for i in range(n):
+            cd, xcs = ConvDesc(), ctypes.c_int()
+            assert lib_built.t2v_generator_layer_desc(ctypes.byref(gd), i, ctypes.byref(cd), ctypes.byref(xcs)) == 0
+            if cd.algo == _lib.ALGO_POLYPHASE:
+                assert cd.stride == 2 and min(cd.Cin, cd.Cout) >= 256
+            algos.append(cd.algo)
+        assert algos.count(_lib.ALGO_POLYPHASE) == want, (H, W, cap, algos)
+
+
 def test_makefile_rebuilds_objects_when_the_winograd_constants_change():
     """csrc/Makefile: every object depends on winograd_f4_consts.h (generated by scripts/gen_winograd_consts.py); an
     incremental `make` -- what __graft_entry__.build() runs -- must rebuild after the header is regenerated."""
@@ -142,3 +183,4 @@ def test_makefile_rebuilds_objects_when_the_winograd_constants_change():
     mk = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "text2video_amd", "csrc", "Makefile")).read()
     rule = re.search(r"^%\.o: %\.hip (.*)$", mk, re.M).group(1).split()
     assert "winograd_f4_consts.h" in rule and "t2v_internal.h" in rule and "../../include/t2v.h" in rule
+    assert "polyphase_consts.h" in rule

@@ -622,3 +622,50 @@ def test_batched_direct_conv_equals_the_single_image_launches(case):
     # and the dispatcher the trainer calls
     y_auto = ops.conv2d_auto_batch(x, pw, b, desc, y_cs=ycs, stats=torch.empty_like(s_all) if stats else None)
     assert torch.equal(y_auto, y_one)
+
+
+@pytest.mark.parametrize("case", [
+    # (H, W, Cin, Cout, transposed)
+    ("down 512->1024 @128x128 (generator down3)", (128, 128, 512, 1024, False)),
+    ("up 1024->512 @64x64 (generator up1)", (64, 64, 1024, 512, True)),
+    ("down 256->512 @256x160 (512x320 frames)", (256, 160, 256, 512, False)),
+    ("up 512->256 @128x170 (512x680 frames: ragged tiles)", (128, 170, 512, 256, True)),
+    ("down 512->1024 @128x170 (ragged)", (128, 170, 512, 1024, False)),
+    ("small ragged down 32->128 @10x14", (10, 14, 32, 128, False)),
+    ("small ragged up 64->128 @7x9", (7, 9, 64, 128, True)),
+], ids=lambda c: c[0] if isinstance(c, tuple) and isinstance(c[0], str) else None)
+def test_polyphase_winograd_matches_torch_and_the_direct_kernel(case):
+    """T2V_ALGO_POLYPHASE (csrc/polyphase.hip): the stride-2 3x3 conv (SpatialConvolutionMM, THCUNN.h:664) and
+    ConvTranspose2d(3, 2, 1, output_padding 1) (SpatialFullDilatedConvolution, THCUNN.h:794) as polyphase Winograd F(4,2) --
+    against torch in fp64 (the yardstick), within 3x the direct implicit-GEMM kernel's own fp32 error or 1e-5 of the output
+    scale; its statistics partials through the finalize entry give the map's mean / rstd; bias added; launch after launch on a
+    NaN-filled workspace (padding tiles and the hand-over scratch are never read before they are written)."""
+    from text2video_amd import ops
+    _, (H, W, Cin, Cout, tr) = case
+    dev = _dev()
+    d0 = ops.conv_desc(H, W, Cin, Cout, 3, 2, 1, ops.PAD_ZERO, tr)
+    dp = ops.with_algo(d0, ops.ALGO_POLYPHASE)
+    assert ops.polyphase_supported(dp, Cin) and ops.conv_out_dims(dp) == ops.conv_out_dims(d0)
+    w = (_rand(Cin, Cout, 3, 3, seed=2, scale=0.03) if tr else _rand(Cout, Cin, 3, 3, seed=2, scale=0.03)).to(dev)
+    b = _rand(Cout, seed=3, scale=0.1).to(dev)
+    x = torch.relu(_rand(H, W, Cin, seed=4)).to(dev)
+    xr = x.permute(2, 0, 1).unsqueeze(0).double()
+    ref = (torch.nn.functional.conv_transpose2d(xr, w.double(), b.double(), stride=2, padding=1, output_padding=1) if tr else
+           torch.nn.functional.conv2d(xr, w.double(), b.double(), stride=2, padding=1))[0].permute(1, 2, 0)
+    p0, pp = ops.pack_conv_weight(w, d0, Cin), ops.pack_conv_weight(w, dp, Cin)
+    s0, sp = ops.conv_stats_buffer(d0, dev), ops.conv_stats_buffer(dp, dev)
+    y0 = ops.conv2d(x, p0, b, d0, y_cs=Cout, stats=s0)
+    ws = ops.winograd_workspace(dp, Cin, dev)
+    scale = ref.abs().max().item()
+    e0 = (y0.double() - ref).abs().max().item()
+    for rep in range(3):
+        ws.fill_(float("nan"))
+        sp.fill_(float("nan"))
+        yp = ops.conv2d_auto(x, pp, b, dp, stats=sp) if rep == 2 else ops.conv2d_winograd(x, pp, b, dp, stats=sp, workspace=ws)
+        ep = (yp.double() - ref).abs().max().item()
+        assert torch.isfinite(yp).all() and ep <= max(3 * e0, 1e-5 * scale), (rep, ep, e0, scale)
+    mr = ops.instance_norm_finalize(sp, dp).view(-1, 2)
+    mref = torch.stack([ref.mean((0, 1)), 1.0 / torch.sqrt(ref.var((0, 1), unbiased=False) + 1e-5)], 1).float()
+    assert torch.allclose(mr, mref, rtol=2e-5, atol=2e-6), (mr - mref).abs().max().item()
+    assert torch.allclose(mr, ops.instance_norm_finalize(s0, d0).view(-1, 2), rtol=2e-5, atol=2e-6)
+    print("%s: polyphase max|err| %.2e, direct %.2e (output scale %.2f)" % (case[0], ep, e0, scale))

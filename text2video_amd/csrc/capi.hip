@@ -449,8 +449,10 @@ int winograd_forward(t2v_ctx* ctx, hipStream_t s, const t2v_conv_desc* d, const 
 bool polyphase_supported(const t2v_conv_desc* d, int x_cs) {
     if (!d || d->kH != 3 || d->kW != 3 || d->stride != 2 || d->pad != 1 || d->pad_mode != T2V_PAD_ZERO) return false;
     if (d->act != T2V_ACT_NONE || d->Cin % 32 != 0 || x_cs != d->Cin || d->Cout % 128 != 0) return false;
-    if (d->transposed) return d->output_padding == 1 && d->H >= 4 && d->W >= 4 && d->H % 4 == 0 && d->W % 4 == 0;
-    return d->H >= 8 && d->W >= 8 && d->H % 8 == 0 && d->W % 8 == 0;
+    // any map: the tile grid is ragged at the bottom / right edge (outputs masked, inputs past the map read as the zeros they
+    // are) and padded with empty tiles to the GEMM's row granule; a down conv's input must be even-sized
+    if (d->transposed) return d->output_padding == 1 && d->H >= 2 && d->W >= 2;
+    return d->H >= 4 && d->W >= 4 && d->H % 2 == 0 && d->W % 2 == 0;
 }
 
 // where it measured faster than the implicit-GEMM kernel (scripts/poly_check.py, MI355X): both channel counts >= 256 -- the

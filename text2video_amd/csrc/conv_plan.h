@@ -50,7 +50,7 @@ bool winograd_supported(const t2v_conv_desc* d, int x_cs, int algo);
 bool polyphase_supported(const t2v_conv_desc* d, int x_cs);
 bool polyphase_pays(const t2v_conv_desc* d, int x_cs);      // ... and is the faster form (the generator's selection rule)
 inline int poly_tiles_real(const t2v_conv_desc* d) {
-    return d->transposed ? (d->H / 4) * (d->W / 4) : (d->H / 8) * (d->W / 8);
+    return d->transposed ? ((d->H + 3) / 4) * ((d->W + 3) / 4) : ((d->H / 2 + 3) / 4) * ((d->W / 2 + 3) / 4);
 }
 inline int poly_tiles_padded(const t2v_conv_desc* d) { return wino_pad_tiles(poly_tiles_real(d)); }
 inline int poly_out_h(const t2v_conv_desc* d) { return d->transposed ? 2 * d->H : d->H / 2; }
