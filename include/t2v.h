@@ -144,7 +144,8 @@ int t2v_conv2d_forward_batch(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d,
  * the ceil(H/m) x ceil(W/m) tile grid (m = 2 | 4) is ragged at the bottom / right edge and padded with
  * empty tiles to a multiple of 128 (extra GEMM rows, masked in the output transform). */
 int t2v_conv_winograd_supported(const t2v_conv_desc* d, int x_cs);
-/* 1 where T2V_ALGO_POLYPHASE applies to `d` (d->algo ignored): 3x3, stride 2; a conv with zero padding 1 and even H, W, or a
+/* bit 0: T2V_ALGO_POLYPHASE applies to `d` (d->algo ignored); bit 1: ... and is the form the library itself selects (both
+ * channel counts >= 256, >= 128 tiles: where it measured faster than the implicit-GEMM kernel).  Applies to: 3x3, stride 2; a conv with zero padding 1 and even H, W, or a
  * transposed conv with pad 1 / output_padding 1; x_cs == Cin, Cin % 32 == 0, Cout % 128 == 0, no activation.  The tile grid
  * (4x4 outputs | 4x4 inputs) is ragged at the bottom / right edge and padded with empty tiles, as for the Winograd forms.  t2v_generator_layer_desc() selects it where it measured faster. */
 int t2v_conv_polyphase_supported(const t2v_conv_desc* d, int x_cs);

@@ -143,7 +143,8 @@ def test_polyphase_bookkeeping_and_generator_selection(lib_built):
     def desc(H, W, Cin, Cout, tr=0, stride=2, pad=1, pad_mode=_lib.PAD_ZERO, k=3, act=_lib.ACT_NONE):
         return ConvDesc(H, W, Cin, Cout, k, k, stride, pad, pad_mode, tr, act, 1.0, 1 if tr else 0, _lib.ALGO_POLYPHASE)
 
-    ok = lambda d: lib_built.t2v_conv_polyphase_supported(ctypes.byref(d), d.Cin)
+    ok = lambda d: lib_built.t2v_conv_polyphase_supported(ctypes.byref(d), d.Cin) & 1
+    pays = lambda d: lib_built.t2v_conv_polyphase_supported(ctypes.byref(d), d.Cin) >> 1
     down3, up1 = desc(128, 128, 512, 1024), desc(64, 64, 1024, 512, tr=1)
     assert ok(down3) == 1 and ok(up1) == 1 and ok(desc(128, 80, 512, 1024)) == 1 and ok(desc(64, 40, 1024, 512, tr=1)) == 1
     assert ok(desc(128, 170, 512, 1024)) == 1 and ok(desc(64, 85, 1024, 512, tr=1)) == 1       # ragged tile grids (512x680 frames)
@@ -152,6 +153,7 @@ def test_polyphase_bookkeeping_and_generator_selection(lib_built):
     assert ok(desc(128, 128, 48, 1024)) == 0 and ok(desc(128, 128, 512, 192)) == 0      # Cin % 32, Cout % 128
     assert ok(desc(128, 128, 512, 1024, act=_lib.ACT_LRELU)) == 0 and ok(desc(128, 128, 512, 1024, k=4)) == 0
     assert lib_built.t2v_conv_polyphase_supported(ctypes.byref(down3), 516) == 0        # channel storage must equal Cin
+    assert pays(down3) == 1 and pays(up1) == 1 and pays(desc(512, 512, 128, 256)) == 0 and pays(desc(16, 16, 512, 1024)) == 0
     # 81 positions: packed weight, V + M of the 256 tiles + the fixed-grid GEMM's hand-over scratch, one partial per 128 pixels
     assert lib_built.t2v_conv_packed_weight_floats(ctypes.byref(down3), 512) == 81 * 1024 * 512
     assert lib_built.t2v_conv_winograd_workspace_floats(ctypes.byref(down3), 512) == 81 * 256 * (512 + 1024) + 1024 * 4 * (64 * 64 + 2)

@@ -28,6 +28,7 @@ class ConvDataGrad:
             # forward: [H,W] -> [2H,2W]; gradient: conv k3 s2 p1 on dY
             self.desc = ops.conv_desc(2 * d.H, 2 * d.W, d.Cout, d.Cin, 3, 2, 1, ops.PAD_ZERO)
             self.kind = "same"
+            self._polyphase()
         elif d.stride == 2:
             ho, wo = ops.conv_out_dims(d)
             # output_padding so that the transposed conv reproduces the forward input size
@@ -36,6 +37,7 @@ class ConvDataGrad:
             assert op_h == op_w and op_h in (0, 1), "unsupported stride-2 geometry"
             self.desc = ops.conv_desc(ho, wo, d.Cout, d.Cin, d.kH, 2, d.pad, ops.PAD_ZERO, True, output_padding=op_h)
             self.kind = "same"
+            self._polyphase()
         else:
             ho, wo = ops.conv_out_dims(d)
             if d.pad_mode == ops.PAD_REFLECT and d.pad > 0:
@@ -52,6 +54,13 @@ class ConvDataGrad:
                 if algo != ops.ALGO_DIRECT:
                     self.desc = ops.with_algo(self.desc, algo)
         self.packed = None
+
+    def _polyphase(self):
+        """the gradient of a deep stride-2 3x3 layer is a transposed one (and vice versa) with the SAME weight tensor: both
+        run as polyphase Winograd F(4,2) where the library selects that form (csrc/polyphase.hip)"""
+        if int(os.environ.get("T2V_CONV_ALGO", "0")) == 0 and self.desc.kH == 3 and \
+                ops.polyphase_pays(self.desc, ops.round_up(self.desc.Cin, 4)):
+            self.desc = ops.with_algo(self.desc, ops.ALGO_POLYPHASE)
 
     def refresh(self, weight):
         """weight: the forward layer's torch-layout weight on the device."""

@@ -601,7 +601,9 @@ size_t t2v_conv_packed_weight_floats(const t2v_conv_desc* d, int x_cs) {
     if (d->algo == T2V_ALGO_POLYPHASE) return polyphase_supported(d, x_cs) ? (size_t)81 * pl.Cout_p * x_cs : 0;
     return pl.wfloats;
 }
-int t2v_conv_polyphase_supported(const t2v_conv_desc* d, int x_cs) { return polyphase_supported(d, x_cs) ? 1 : 0; }
+int t2v_conv_polyphase_supported(const t2v_conv_desc* d, int x_cs) {
+    return (polyphase_supported(d, x_cs) ? 1 : 0) | (polyphase_pays(d, x_cs) ? 2 : 0);
+}
 
 int t2v_conv_winograd_supported(const t2v_conv_desc* d, int x_cs) {
     return (winograd_supported(d, x_cs, T2V_ALGO_WINOGRAD) ? 1 : 0) | (winograd_supported(d, x_cs, T2V_ALGO_WINOGRAD_F4) ? 2 : 0);

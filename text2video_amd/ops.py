@@ -88,7 +88,13 @@ def winograd_supported(desc, x_cs=None, algo=None):
 def polyphase_supported(desc, x_cs=None):
     """True when `desc` (a stride-2 3x3 conv or its transposed counterpart) can run as ALGO_POLYPHASE (include/t2v.h)."""
     x_cs = round_up(desc.Cin, 4) if x_cs is None else x_cs
-    return bool(_lib.load().t2v_conv_polyphase_supported(ctypes.byref(desc), x_cs))
+    return bool(_lib.load().t2v_conv_polyphase_supported(ctypes.byref(desc), x_cs) & 1)
+
+
+def polyphase_pays(desc, x_cs=None):
+    """... and the library's own rule selects it for this shape (the faster form: both channel counts >= 256)"""
+    x_cs = round_up(desc.Cin, 4) if x_cs is None else x_cs
+    return bool(_lib.load().t2v_conv_polyphase_supported(ctypes.byref(desc), x_cs) & 2)
 
 
 def best_conv_algo(desc, x_cs=None, cap=0):

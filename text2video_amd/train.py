@@ -437,6 +437,11 @@ class _ConvBlock(torch.autograd.Function):
             algo = ops.best_conv_algo(fdesc, xcs, int(os.environ.get("T2V_CONV_ALGO", "0")))
             if algo != ops.ALGO_DIRECT:
                 fdesc = ops.with_algo(fdesc, algo)
+            elif int(os.environ.get("T2V_CONV_ALGO", "0")) == 0 and desc.stride == 2 and ops.polyphase_pays(fdesc, xcs):
+                # the deep stride-2 / transposed layers as polyphase Winograd F(4,2), as in the inference frames
+                # (csrc/polyphase.hip); the weight gradient keeps the direct layout (ddesc), the data gradient is the
+                # polyphase form of the adjoint geometry (backward.ConvDataGrad)
+                fdesc = ops.with_algo(fdesc, ops.ALGO_POLYPHASE)
         pw = cached_pack(w, ("fwd",) + _desc_key(fdesc, xcs), lambda: ops.pack_conv_weight(w.detach().contiguous(), fdesc, xcs))
         c = torch.empty(B, ho, wo, ycs, dtype=torch.float32, device=dev)
         mrs = None
