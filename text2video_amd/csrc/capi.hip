@@ -465,13 +465,16 @@ bool polyphase_pays(const t2v_conv_desc* d, int x_cs) {
 
 // stages bit 1 = input transform, 2 = the 81 batched GEMMs, 4 = output transform (bias, statistics partials)
 int polyphase_forward(t2v_ctx* ctx, hipStream_t s, const t2v_conv_desc* d, const float* x, const float* w_packed,
-                      const float* bias, float* y, float* stats_partial, float* workspace, int stages) {
+                      const float* bias, float* y, float* stats_partial, float* workspace, int stages,
+                      const PolyLazyNorm* lazy) {
     T2V_TRY(check_async_errors());
     const int up = d->transposed ? 1 : 0;
     const int T = poly_tiles_padded(d), rows = poly_tiles_real(d);
     float* V = workspace;
     float* Mm = workspace + (size_t)81 * T * d->Cin;
-    if (stages & 1) T2V_TRY(launch_polyphase_input(s, x, V, d->H, d->W, d->Cin, up, T));
+    if (stages & 1)
+        T2V_TRY(lazy ? launch_polyphase_input(s, x, V, d->H, d->W, d->Cin, up, T, lazy->mean_rstd, lazy->gamma, lazy->beta, lazy->relu)
+                     : launch_polyphase_input(s, x, V, d->H, d->W, d->Cin, up, T));
     if (stages & 2) {
         SkGemm g;
         g.a = V; g.b = w_packed; g.c = Mm; g.scratch = workspace + (size_t)81 * T * ((size_t)d->Cin + d->Cout);

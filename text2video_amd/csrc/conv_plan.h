@@ -59,8 +59,16 @@ inline int poly_m(const t2v_conv_desc* d) { return d->transposed ? 8 : 4; }     
 inline size_t polyphase_workspace_floats(const t2v_conv_desc* d) {                // V + M + the fixed-grid GEMM's hand-over scratch
     return (size_t)81 * poly_tiles_padded(d) * ((size_t)d->Cin + d->Cout) + wino_gemm_sk_scratch_floats();
 }
+// lazy != null: x is the previous layer's raw conv output; its norm (+ ReLU) is applied inside the input transform
+struct PolyLazyNorm {
+    const float* mean_rstd;
+    const float* gamma;
+    const float* beta;
+    int relu;
+};
 int polyphase_forward(t2v_ctx* ctx, hipStream_t s, const t2v_conv_desc* d, const float* x, const float* w_packed,
-                      const float* bias, float* y, float* stats_partial, float* workspace, int stages);
+                      const float* bias, float* y, float* stats_partial, float* workspace, int stages,
+                      const PolyLazyNorm* lazy = nullptr);
 int best_conv_algo(const t2v_conv_desc* d, int x_cs, int cap);
 int build_winograd_gemm_plan(const t2v_conv_desc* d, ConvPlan* pl, int nimg = 1);
 // A batch of images through one Winograd conv (F(4x4,3x3) only when nimg > 1): the images' maps x / y are

@@ -218,7 +218,11 @@ struct Runner {
     double* fin_of(int im) const { return b.fin[sc] + (size_t)im * b.fin_stride; }
     // conv (+ fused stats) -> finalize -> apply of layer `l` for ONE image.  y receives the conv output and is
     // normalised in place: y = [relu](norm(conv(x))) + res1 + res2
-    int conv_norm_one(int l, int im, const float* x, float* y, int relu, const float* res1, const float* res2) {
+    // lazy_in: x is layer l-1's raw conv output, whose (mean, rstd) still sit in mr_of(im) -- this (polyphase) layer's input
+    // transform normalises it; lazy_out: leave y raw for the next layer to do the same (no apply pass: a read and a write of
+    // the map less).  Same arithmetic in the same order: the frames are bit-identical to the apply form (T2V_CHAIN_LAZY=0).
+    int conv_norm_one(int l, int im, const float* x, float* y, int relu, const float* res1, const float* res2,
+                      bool lazy_in = false, bool lazy_out = false) {
         const LayerSpec& L = specs[l];
         const t2v_layer& w = layers[l];
         ConvPlan pl;
@@ -236,18 +240,23 @@ struct Runner {
             T2V_TRY(launch_inorm_finalize_winograd(s, stats, wm, L.cd.H, L.cd.W, Cout, g.eps, mr, 1, fin_of(im)));
             return launch_inorm_apply(s, y, mr, gam, bet, res1, res2, y, (long)M, Cout, relu);
         }
+        T2V_REQUIRE(!lazy_out || (relu == 1 && !res1 && !res2), "internal: a lazy output carries a plain norm + ReLU");
         if (L.cd.algo == T2V_ALGO_POLYPHASE) {
             const int Ho = poly_out_h(&L.cd), Wo = poly_out_w(&L.cd);
-            T2V_TRY(polyphase_forward(ctx, s, &L.cd, x, w.w, w.bias, y, stats, b.wino[sc], 7));
+            const PolyLazyNorm ln{mr, g.norm_affine ? layers[l - 1].gamma : nullptr, g.norm_affine ? layers[l - 1].beta : nullptr, 1};
+            T2V_TRY(polyphase_forward(ctx, s, &L.cd, x, w.w, w.bias, y, stats, b.wino[sc], 7, lazy_in ? &ln : nullptr));
             T2V_TRY(launch_inorm_finalize_winograd(s, stats, poly_m(&L.cd), Ho, Wo, Cout, g.eps, mr, 1, fin_of(im)));
+            if (lazy_out) return T2V_OK;
             return launch_inorm_apply(s, y, mr, gam, bet, res1, res2, y, (long)Ho * Wo, Cout, relu);
         }
+        T2V_REQUIRE(!lazy_in, "internal: only the polyphase input transform applies a pending norm");
         T2V_TRY(build_conv_plan(&L.cd, L.x_cs, true, &pl));
         T2V_TRY(run_conv(ctx, s, pl, x, w.w, w.bias, y, Cout, stats));
         if (pl.tile == kTileStem)
             T2V_TRY(launch_inorm_finalize_tiles(s, stats, 16, L.cd.H, L.cd.W, Cout, g.eps, mr, 1, fin_of(im)));
         else
             T2V_TRY(launch_inorm_finalize(s, stats, pl.nparts, pl.kp.mtiles, pl.BM, pl.kp.M, Cout, g.eps, mr, fin_of(im)));
+        if (lazy_out) return T2V_OK;
         return launch_inorm_apply(s, y, mr, gam, bet, res1, res2, y, (long)pl.Hout * pl.Wout, Cout, relu);
     }
     // the next layer for every image of the batch (one launch sequence per image).  (The images of a lock-step batch as
@@ -255,11 +264,14 @@ struct Runner {
     // use -- was measured here and dropped: 142.1 / 141.9 vs 142.1 / 141.7 fps for two 512x320 sequences, 67.0 / 66.7 vs
     // 66.8 / 66.7 at 512x680, 92.0 / 92.0 vs 91.8 / 91.7 at 512x512, alternating runs: inside two-stream frames the other
     // stream already fills what a 2.5-blocks-per-CU launch leaves idle.)
-    int conv_norm(const Ptrs& x, const MutPtrs& y, int relu, const Ptrs& res1) {
-        for (int im = 0; im < nimg; ++im) T2V_TRY(conv_norm_one(li, im, x.p[im], y.p[im], relu, res1.p[im], nullptr));
+    int conv_norm(const Ptrs& x, const MutPtrs& y, int relu, const Ptrs& res1, bool lazy_in = false, bool lazy_out = false) {
+        for (int im = 0; im < nimg; ++im)
+            T2V_TRY(conv_norm_one(li, im, x.p[im], y.p[im], relu, res1.p[im], nullptr, lazy_in, lazy_out));
         ++li;
         return T2V_OK;
     }
+    // the layer after the current one is a polyphase layer that consumes this one's output and nothing else does
+    bool next_takes_raw() const { return options().chain_lazy && specs[li + 1].cd.algo == T2V_ALGO_POLYPHASE; }
 
     int head(const Ptrs& x, const MutPtrs& y) {
         const LayerSpec& L = specs[li];
@@ -358,8 +370,13 @@ struct Runner {
     // c7,N,R, (d,N,R) x n, RB x nb
     int encoder(const Ptrs& x, float** act, int nb, float* tmp[4], const float** out) {
         const int n = g.is_local ? 1 : g.n_downsample;
-        T2V_TRY(conv_norm(x, at(act[0], b.lvl[0]), 1, Ptrs{}));
-        for (int i = 0; i < n; ++i) T2V_TRY(conv_norm(at(act[i], b.lvl[i]), at(act[i + 1], b.lvl[i + 1]), 1, Ptrs{}));
+        bool raw = n > 0 && next_takes_raw();      // (the stem's output feeds the first stride-2 layer only)
+        T2V_TRY(conv_norm(x, at(act[0], b.lvl[0]), 1, Ptrs{}, false, raw));
+        for (int i = 0; i < n; ++i) {
+            const bool raw_out = i + 1 < n && next_takes_raw();
+            T2V_TRY(conv_norm(at(act[i], b.lvl[i]), at(act[i + 1], b.lvl[i + 1]), 1, Ptrs{}, raw, raw_out));
+            raw = raw_out;
+        }
         if (nb == 0) {
             *out = act[n];
             return T2V_OK;
@@ -371,10 +388,13 @@ struct Runner {
         const int n = g.is_local ? 1 : g.n_downsample;
         const float* cur = x;
         size_t cur_stride = b.bott;
+        bool raw = false;
         for (int i = 0; i < n; ++i) {
             const int l = n - 1 - i;
             float* y = dec[l];
-            T2V_TRY(conv_norm(at(cur, cur_stride), at(y, b.lvl[l]), 1, Ptrs{}));
+            const bool raw_out = i + 1 < n && next_takes_raw();
+            T2V_TRY(conv_norm(at(cur, cur_stride), at(y, b.lvl[l]), 1, Ptrs{}, raw, raw_out));
+            raw = raw_out;
             cur = y;
             cur_stride = b.lvl[l];
         }

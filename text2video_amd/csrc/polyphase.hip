@@ -150,9 +150,16 @@ int launch_polyphase_weight(hipStream_t s, const float* w, float* U, int Cout, i
 // samples (taken as they are).  UP: the 5 x 5 patch starts at input (4 ty, 4 tx) (zeros past the map); all five samples feed
 // F(4,2), the first four are also the 1-tap samples.  The four (transformed | plain) x (transformed | plain) sub-blocks are
 // done one after the other, so that at most 25 values per channel are live.
-template <bool UP>
+// NORM: x is the previous layer's conv output that has not gone through its norm layer yet; the transform applies
+// relu((x - mean) * rstd [* gamma + beta]) on the fly -- inorm_apply_kernel's arithmetic in the same order, so the result is
+// bit-identical to apply-then-transform -- and that layer's apply pass (a read and a write of the map) is dropped.  The zero
+// padding pads the NORMALISED map: samples outside stay exact zeros.
+template <bool UP, bool NORM>
 __global__ __launch_bounds__(256) void polyphase_input_kernel(const float2* __restrict__ x, float2* __restrict__ V, int H, int W,
-                                                             int C2, int TW, int T, int Tt) {
+                                                             int C2, int TW, int T, int Tt,
+                                                             const float2* __restrict__ mean_rstd,
+                                                             const float2* __restrict__ gamma,
+                                                             const float2* __restrict__ beta, int relu) {
     const long total = (long)Tt * C2;
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
@@ -167,8 +174,31 @@ __global__ __launch_bounds__(256) void polyphase_input_kernel(const float2* __re
         // sample k of the F(4,2) set / of the plain set, per dimension -> input index
         auto wrow = [&](int k, int t) { return UP ? 4 * t + k : 8 * t - 1 + 2 * k; };       // k = 0..4
         auto prow = [&](int k, int t) { return UP ? 4 * t + k : 8 * t + 2 * k; };           // k = 0..3
+        float2 mr0 = make_float2(0.f, 1.f), mr1 = make_float2(0.f, 1.f), gm = make_float2(1.f, 1.f), bt = make_float2(0.f, 0.f);
+        if (NORM) {
+            mr0 = mean_rstd[2 * c2];
+            mr1 = mean_rstd[2 * c2 + 1];
+            if (gamma) {
+                gm = gamma[c2];
+                bt = beta[c2];
+            }
+        }
         auto load = [&](int yy, int xx) {
-            return ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) ? x[((long)yy * W + xx) * C2 + c2] : make_float2(0.f, 0.f);
+            if (!((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)) return make_float2(0.f, 0.f);
+            float2 v = x[((long)yy * W + xx) * C2 + c2];
+            if (NORM) {
+                v.x = (v.x - mr0.x) * mr0.y;
+                v.y = (v.y - mr1.x) * mr1.y;
+                if (gamma) {
+                    v.x = v.x * gm.x + bt.x;
+                    v.y = v.y * gm.y + bt.y;
+                }
+                if (relu == 1) {
+                    v.x = fmaxf(v.x, 0.f);
+                    v.y = fmaxf(v.y, 0.f);
+                }
+            }
+            return v;
         };
         auto store = [&](int pr, int pc, float vx, float vy) { V[((long)(pr * 9 + pc) * Tt + tile) * C2 + c2] = make_float2(vx, vy); };
         // (1) transformed rows x transformed columns: 5 x 5 -> 5 x 5
@@ -237,17 +267,19 @@ __global__ __launch_bounds__(256) void polyphase_input_kernel(const float2* __re
             }
     }
 }
-// H, W: the INPUT map; tiles: 4x4 outputs of the H/2 x W/2 map (down) | 4x4 inputs (up); Tt = padded tile rows of V
-int launch_polyphase_input(hipStream_t s, const float* x, float* V, int H, int W, int C, int up, int Tt) {
+// H, W: the INPUT map; tiles: 4x4 outputs of the H/2 x W/2 map (down) | 4x4 inputs (up); Tt = padded tile rows of V.
+// mean_rstd != null: x still has to go through its norm layer (relu: 0 | 1 after it)
+int launch_polyphase_input(hipStream_t s, const float* x, float* V, int H, int W, int C, int up, int Tt, const float* mean_rstd,
+                           const float* gamma, const float* beta, int relu) {
+    T2V_REQUIRE((gamma == nullptr) == (beta == nullptr) && (relu == 0 || relu == 1), "polyphase_input: bad norm arguments");
     const int TH = up ? (H + 3) / 4 : (H / 2 + 3) / 4, TW = up ? (W + 3) / 4 : (W / 2 + 3) / 4;
     const int T = TH * TW;
     const int grid = pp_grid((long)Tt * (C / 2), 256);
-    if (up)
-        hipLaunchKernelGGL(polyphase_input_kernel<true>, dim3(grid), dim3(256), 0, s, reinterpret_cast<const float2*>(x),
-                           reinterpret_cast<float2*>(V), H, W, C / 2, TW, T, Tt);
-    else
-        hipLaunchKernelGGL(polyphase_input_kernel<false>, dim3(grid), dim3(256), 0, s, reinterpret_cast<const float2*>(x),
-                           reinterpret_cast<float2*>(V), H, W, C / 2, TW, T, Tt);
+    auto kern = up ? (mean_rstd ? polyphase_input_kernel<true, true> : polyphase_input_kernel<true, false>)
+                   : (mean_rstd ? polyphase_input_kernel<false, true> : polyphase_input_kernel<false, false>);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, s, reinterpret_cast<const float2*>(x), reinterpret_cast<float2*>(V), H, W,
+                       C / 2, TW, T, Tt, reinterpret_cast<const float2*>(mean_rstd), reinterpret_cast<const float2*>(gamma),
+                       reinterpret_cast<const float2*>(beta), relu);
     T2V_HIP_CHECK(hipGetLastError());
     return T2V_OK;
 }

@@ -198,7 +198,8 @@ int launch_winograd4_input_lazy(hipStream_t s, const float* x, float* V, int H, 
 int launch_winograd4_dgrad_output(hipStream_t s, const float* dV, float* dxp, int H, int W, int C);
 // polyphase.hip
 int launch_polyphase_weight(hipStream_t s, const float* w, float* U, int Cout, int Cin, int Cout_p, int Cin_s, int up);
-int launch_polyphase_input(hipStream_t s, const float* x, float* V, int H, int W, int C, int up, int Tt);
+int launch_polyphase_input(hipStream_t s, const float* x, float* V, int H, int W, int C, int up, int Tt,
+                           const float* mean_rstd = nullptr, const float* gamma = nullptr, const float* beta = nullptr, int relu = 0);
 int launch_polyphase_output(hipStream_t s, const float* Mm, const float* bias, float* y, float* stats, int Ho, int Wo, int N,
                             int up, int Tt);
 int launch_winograd4_dy(hipStream_t s, const float* dy, float* Md, int Ho, int Wo, int N, int dy_cs, int batch, int image);
