@@ -634,7 +634,7 @@ def test_batched_direct_conv_equals_the_single_image_launches(case):
     ("small ragged down 32->128 @10x14", (10, 14, 32, 128, False)),
     ("small ragged up 64->128 @7x9", (7, 9, 64, 128, True)),
 ], ids=lambda c: c[0] if isinstance(c, tuple) and isinstance(c[0], str) else None)
-def test_polyphase_winograd_matches_torch_and_the_direct_kernel(case):
+def test_polyphase_winograd_matches_torch_and_the_direct_kernel(case, t2v_env):
     """T2V_ALGO_POLYPHASE (csrc/polyphase.hip): the stride-2 3x3 conv (SpatialConvolutionMM, THCUNN.h:664) and
     ConvTranspose2d(3, 2, 1, output_padding 1) (SpatialFullDilatedConvolution, THCUNN.h:794) as polyphase Winograd F(4,2) --
     against torch in fp64 (the yardstick), within 3x the direct implicit-GEMM kernel's own fp32 error or 1e-5 of the output
@@ -668,4 +668,10 @@ def test_polyphase_winograd_matches_torch_and_the_direct_kernel(case):
     mref = torch.stack([ref.mean((0, 1)), 1.0 / torch.sqrt(ref.var((0, 1), unbiased=False) + 1e-5)], 1).float()
     assert torch.allclose(mr, mref, rtol=2e-5, atol=2e-6), (mr - mref).abs().max().item()
     assert torch.allclose(mr, ops.instance_norm_finalize(s0, d0).view(-1, 2), rtol=2e-5, atol=2e-6)
+    # the 81 GEMMs on one block per tile (the fixed-grid kernels off: what a failed dispatch-order self-test leaves): every
+    # output is the same K-ordered MFMA chain, so the conv is the same bits
+    t2v_env("T2V_WINO_GEMM_SK", "0")
+    ws.fill_(float("nan"))
+    assert torch.equal(ops.conv2d_winograd(x, pp, b, dp, stats=sp, workspace=ws), yp)
+    t2v_env("T2V_WINO_GEMM_SK", "1")
     print("%s: polyphase max|err| %.2e, direct %.2e (output scale %.2f)" % (case[0], ep, e0, scale))
