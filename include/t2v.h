@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define T2V_ABI_VERSION 15
+#define T2V_ABI_VERSION 16
 
 typedef enum {
     T2V_OK = 0,
@@ -284,6 +284,14 @@ int t2v_conv2d_backward_weight_winograd(t2v_ctx* ctx, void* stream, const t2v_co
 int t2v_conv2d_backward_weight_winograd_stages(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, int batch, int b0,
                                                int nb, const float* x, int x_cs, const float* dy, int dy_cs,
                                                float* dw_torch, int accumulate, float* workspace, int stages);
+/* The forward pass of such a layer in a train step (ABI 16): t2v_conv2d_forward_winograd (algo T2V_ALGO_WINOGRAD_F4, one image)
+ * with V = B^T d B written into slot `slot` of the weight gradient's batch-wide workspace (`wgrad_workspace` sized by
+ * t2v_conv_backward_weight_winograd_workspace_floats(d, x_cs, batch)) and read by the forward GEMM from there.  The backward
+ * pass then calls _stages(stages & 1) with x == NULL for that image: only A dy A^T is transformed, the input transform of the
+ * forward pass is not repeated (updateOutput and accGradParameters of THCUNN.h:664 share their im2col-equivalent). */
+int t2v_conv2d_forward_winograd_keep_v(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, const float* x, int x_cs,
+                                       const float* w_packed, const float* bias, float* y, int y_cs, float* stats_partial,
+                                       float* workspace, float* wgrad_workspace, int batch, int slot);
 
 /* Data gradient of a 3x3 stride-1 ReflectionPad(1) conv by the TRANSPOSED Winograd algorithm (updateGradInput of
  * SpatialConvolutionMM + SpatialReflectionPadding_updateGradInput, THCUNN.h:664,952): forward is V = B^T d B, M = U V,
@@ -299,6 +307,15 @@ int t2v_conv_pack_weight_transposed(t2v_ctx* ctx, void* stream, const t2v_conv_d
                                     float* packed_dev);
 int t2v_conv2d_backward_data_winograd(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, int batch, int slot,
                                       const float* wgrad_workspace, int x_cs, const float* ut_packed, float* scratch, float* dx);
+/* The same with the FORWARD layer's own packed weights (t2v_conv_pack_weight of `d` with algo T2V_ALGO_WINOGRAD_F4 at the
+ * same x_cs): U [36][Cout][x_cs] is the [K][N] operand of dV = dM U as it lies; the fixed-grid GEMM reads it in place (two
+ * k rows of 128 columns per LDS-DMA instruction, ds_read_b64 per k), the same MFMA chains as with the transposed copy and so
+ * the same bits -- no t2v_conv_pack_weight_transposed per optimiser step and no second copy of the transformed weights.
+ * _takes_forward_weights: 1 where that form exists (whole 128 x 128 tiles on the fixed grid, Cout % 128 == 0, x_cs % 128 == 0). */
+int t2v_conv_backward_data_winograd_takes_forward_weights(const t2v_conv_desc* d, int x_cs, int dy_cs);
+int t2v_conv2d_backward_data_winograd_fw(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, int batch, int slot,
+                                         const float* wgrad_workspace, int x_cs, const float* u_forward_packed, float* scratch,
+                                         float* dx);
 
 int t2v_conv_unpack_weight(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, int x_cs, const float* packed_dev,
                            float* w_torch_dev);

@@ -370,6 +370,38 @@ def test_transposed_winograd_data_gradient_matches_autograd(H, W, Cin, Cout, t2v
             t2v_env("T2V_WINO_GEMM_SK", mode)
             outs[mode] = [ops.conv2d_backward_data_winograd(desc, B, b, ws, Cin, ut).clone() for b in range(B)]
         assert all(torch.equal(a, c) for a, c in zip(outs["0"], outs["2"]))
+        # ... and so does the [K][N] form of that GEMM, which reads the FORWARD layer's packing in place of the transposed copy
+        if Cout % 128 == 0:
+            assert ops.backward_data_winograd_takes_forward_weights(desc, Cin, Cout)      # (T2V_WINO_GEMM_SK=2 still set)
+            u = ops.pack_conv_weight(wd, desc, Cin)
+            fw = [ops.conv2d_backward_data_winograd(desc, B, b, ws, Cin, u, forward_weights=True) for b in range(B)]
+            assert all(torch.equal(a, c) for a, c in zip(fw, outs["2"]))
+            t2v_env("T2V_WINO_GEMM_SK", "1")      # fewer tiles than blocks: not offered, and refused loudly
+            assert not ops.backward_data_winograd_takes_forward_weights(desc, Cin, Cout)
+            with pytest.raises(RuntimeError, match="takes_forward_weights"):
+                ops.conv2d_backward_data_winograd(desc, B, 0, ws, Cin, u, forward_weights=True)
+
+
+def test_data_gradient_reads_the_forward_weights_in_place_at_the_generator_bottleneck():
+    """1024 -> 1024 at 64x64 (the ResnetBlock conv of a 512x512 frame; 576 tiles on 512 blocks: accumulator hand-overs in
+    play): the data gradient with the forward packing as its [K][N] operand is bit for bit the one with the transposed copy."""
+    from text2video_amd import ops
+    g = torch.Generator().manual_seed(11)
+    H = W = 64
+    C = 1024
+    desc = ops.with_algo(ops.conv_desc(H, W, C, C, 3, 1, 1, ops.PAD_REFLECT), ops.ALGO_WINOGRAD_F4)
+    assert ops.backward_data_winograd_takes_forward_weights(desc, C, C)
+    xs = torch.randn(1, H, W, C, generator=g).cuda()
+    dys = torch.randn(1, H, W, C, generator=g).cuda()
+    wd = (torch.randn(C, C, 3, 3, generator=g) * 0.02).cuda()
+    ws = ops.backward_weight_winograd_workspace(desc, C, 1, "cuda:0")
+    ops.conv2d_backward_weight_winograd_stages(xs, dys, desc, ws, 1, 0, False)
+    want = ops.conv2d_backward_data_winograd(desc, 1, 0, ws, C, ops.pack_conv_weight_transposed(wd, desc, C))
+    u = ops.pack_conv_weight(wd, desc, C)
+    for rep in range(3):
+        got = ops.conv2d_backward_data_winograd(desc, 1, 0, ws, C, u, forward_weights=True)
+        assert torch.equal(got, want), "launch %d: %d of %d differ" % (rep, int((got != want).sum()), got.numel())
+    assert bool(torch.isfinite(want).all()) and want.abs().max().item() > 1.0
 
 
 @pytest.mark.parametrize("case", [

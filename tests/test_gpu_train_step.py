@@ -552,6 +552,52 @@ def test_train_step_with_the_fixed_grid_kernels_forced_is_bit_identical(t2v_env)
 
 
 
+def test_kept_input_transforms_and_in_place_forward_weights_leave_the_step_unchanged(t2v_env, monkeypatch):
+    """Round 5: from a layer's second step on the forward conv writes its input transform V into the weight gradient's
+    workspace (train._keep_v_slot: backward transforms dy only), and the data gradient reads the forward packing of the
+    weights in place (the [K][N] form of the fixed-grid GEMM) instead of a transposed copy.  Against both switched off:
+    losses and updated weights bit for bit over three steps -- the slots are handed out so that the reduction order is the
+    un-kept path's -- and the kept path really ran."""
+    from text2video_amd import ops, train as T
+    from text2video_amd.options import TrainOptions
+    opt = TrainOptions().parse(["--name", "t", "--dataset_mode", "pose", "--input_nc", "3", "--openpose_only", "--ngf", "64",
+                                "--n_downsample_G", "1", "--n_blocks", "2", "--num_D", "1", "--ndf", "16", "--no_vgg",
+                                "--max_frames_per_gpu", "2", "--n_scales_temporal", "0", "--no_first_img"])
+    H, W = 128, 128      # bottleneck 64 x 64 x 128 channels: 256 tile rows, one 128-wide channel tile
+    rng = np.random.default_rng(8)
+    pose = torch.zeros(2, H, W, 12, device="cuda:0")
+    pose[..., :9] = torch.from_numpy(rng.uniform(-1, 1, (2, H, W, 9)).astype(np.float32)).cuda()
+    real = torch.zeros(2, H, W, 4, device="cuda:0")
+    real[..., :3] = torch.tanh(torch.from_numpy(rng.standard_normal((2, H, W, 3)).astype(np.float32))).cuda()
+    real_prev = torch.cat([real[1:], real[:1]], 0).contiguous()
+    t2v_env("T2V_WINO_GEMM_SK", "2")          # (the fixed grid wherever the shape allows: these tile counts are below it)
+    calls = {"dy": 0, "fw": 0}
+    dy_only, dgrad = ops.conv2d_backward_weight_winograd_dy, ops.conv2d_backward_data_winograd
+    monkeypatch.setattr(ops, "conv2d_backward_weight_winograd_dy",
+                        lambda *a, **k: (calls.__setitem__("dy", calls["dy"] + 1), dy_only(*a, **k))[1])
+    monkeypatch.setattr(ops, "conv2d_backward_data_winograd",
+                        lambda *a, **k: (calls.__setitem__("fw", calls["fw"] + int(k.get("forward_weights", False))), dgrad(*a, **k))[1])
+    runs = {}
+    for mode in ("1", "0"):
+        t2v_env("T2V_WGRAD_KEEP_V", mode)
+        t2v_env("T2V_DGRAD_FORWARD_WEIGHTS", mode)
+        tr = T.Vid2VidTrainer(opt, "cuda:0", seed=9)
+        prev, ls = None, []
+        for _ in range(3):
+            l, prev = tr.train_step(pose, real, None, prev, real_prev=real_prev)
+            ls.append(l)
+        runs[mode] = (ls, [p.detach().clone() for n in (tr.G, tr.D) for p in n.parameters()], dict(calls))
+        if mode == "1":
+            assert max(getattr(p, "_t2v_wg_expect", 0) for p in tr.G.parameters()) == 2      # two frames per step
+    kept, plain = runs["1"][2], runs["0"][2]
+    # steps 2 and 3 kept V (the first has no expectation yet); with both off nothing more was added
+    assert kept["dy"] > 0 and kept["dy"] % 4 == 0 and plain["dy"] == kept["dy"], (kept, plain)
+    assert kept["fw"] > 0 and plain["fw"] == kept["fw"], (kept, plain)
+    for la, lb in zip(runs["1"][0], runs["0"][0]):
+        assert la.keys() == lb.keys() and all(la[k] == lb[k] for k in la), [(k, la[k], lb[k]) for k in la if la[k] != lb[k]]
+    assert all(torch.equal(x, y) for x, y in zip(runs["1"][1], runs["0"][1]))
+
+
 def test_weight_gradients_reduced_once_per_layer_equal_one_reduction_per_pass(monkeypatch):
     """Round 5: a direct-kernel layer that ran several times in the step's graph -- the generator's stride-2 / transposed
     layers on the clip's two frames, the discriminators' layers on the real, fake and raw pass (two frames each) -- reduces its

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("T2V_LIBRARY") or os.path.join(_HERE, "lib", "libt2v_h
 T2V_OK = 0
 PAD_ZERO, PAD_REFLECT = 0, 1
 ACT_NONE, ACT_TANH, ACT_FLOW_W, ACT_LRELU = 0, 1, 2, 3
-ABI_VERSION = 15
+ABI_VERSION = 16
 MAX_BATCH = 8     # T2V_MAX_BATCH
 ALGO_DIRECT, ALGO_WINOGRAD, ALGO_WINOGRAD_F4, ALGO_POLYPHASE = 0, 1, 2, 3
 
@@ -77,6 +77,8 @@ SIGNATURES = {
                                             c_void_p, c_int, c_void_p, c_void_p]),
     "t2v_conv2d_forward_winograd_stages": (c_int, [c_void_p, c_void_p, POINTER(ConvDesc), c_void_p, c_int, c_void_p,
                                                    c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int]),
+    "t2v_conv2d_forward_winograd_keep_v": (c_int, [c_void_p, c_void_p, POINTER(ConvDesc), c_void_p, c_int, c_void_p,
+                                                   c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int]),
     "t2v_instance_norm_finalize": (c_int, [c_void_p, c_void_p, POINTER(ConvDesc), c_void_p, c_float, c_void_p]),
     "t2v_batch_norm_finalize": (c_int, [c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_void_p, c_float, c_void_p]),
     "t2v_batch_norm_finalize_running": (c_int, [c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_void_p, c_float, c_void_p,
@@ -101,6 +103,9 @@ SIGNATURES = {
     "t2v_conv_pack_weight_transposed": (c_int, [c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_void_p, c_void_p]),
     "t2v_conv2d_backward_data_winograd": (c_int, [c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_int, c_void_p, c_int, c_void_p,
                                                   c_void_p, c_void_p]),
+    "t2v_conv_backward_data_winograd_takes_forward_weights": (c_int, [POINTER(ConvDesc), c_int, c_int]),
+    "t2v_conv2d_backward_data_winograd_fw": (c_int, [c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_int, c_void_p, c_int, c_void_p,
+                                                     c_void_p, c_void_p]),
     "t2v_conv_unpack_weight_into": (c_int, [c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_void_p, c_void_p, c_int]),
     "t2v_accumulate": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int]),
     "t2v_scale": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_float]),

@@ -404,10 +404,17 @@ int winograd_forward(t2v_ctx* ctx, hipStream_t s, const t2v_conv_desc* d, const 
     if (f4) T2V_TRY(check_async_errors());
     T2V_REQUIRE(nimg >= 1 && (f4 || nimg == 1), "winograd: batches are F(4x4,3x3) only");
     const size_t T = (size_t)wino_rows_batch(d, d->algo, nimg);
-    float* V = workspace;
+    const bool keep = wb.keep_v != nullptr;
+    T2V_REQUIRE(!keep || (f4 && nimg == 1 && wb.keep_slot >= 0 && wb.keep_slot < wb.keep_total),
+                "winograd: V is kept for the weight gradient of single F(4x4,3x3) images only");
+    // (kept: slot keep_slot of [36][keep_total * Tp][Cin]; the positions are keep_total * Tp rows apart)
+    float* V = keep ? wb.keep_v + (size_t)wb.keep_slot * T * d->Cin : workspace;
+    const long v_group_stride = (long)(keep ? wb.keep_total : 1) * (long)T * d->Cin;
     float* Mm = workspace + wino_pos(d->algo) * T * d->Cin;
     if (stages & 1) {
         const int reflect = d->pad_mode == T2V_PAD_REFLECT;
+        if (keep) T2V_TRY(launch_winograd4_input(s, x, wb.keep_v, d->H, d->W, d->Cin, d->pad, reflect, wb.keep_total, wb.keep_slot));
+        else
         T2V_TRY(f4 ? launch_winograd4_input(s, x, V, d->H, d->W, d->Cin, d->pad, reflect, nimg, 0, nimg, wb.img_stride_x)
                    : launch_winograd_input(s, x, V, d->H, d->W, d->Cin, d->pad, reflect));
     }
@@ -418,7 +425,7 @@ int winograd_forward(t2v_ctx* ctx, hipStream_t s, const t2v_conv_desc* d, const 
             SkGemm g;
             g.a = V; g.b = w_packed; g.c = Mm; g.scratch = workspace + winograd_vm_floats(d, nimg);
             g.err = async_error_word();
-            g.a_group_stride = (long)T * d->Cin;
+            g.a_group_stride = v_group_stride;
             g.groups = 36; g.T = (int)T; g.K = d->Cin; g.N = d->Cout; g.c_cs = d->Cout;
             T2V_TRY(tall_ragged ? launch_wino_gemm_skt(s, g, rows) : launch_wino_gemm_skr(s, g, rows));
         } else if (f4 && wino_gemm_sk_ok(36, (int)T, d->Cin, d->Cout, d->Cout, rows)) {
@@ -426,12 +433,16 @@ int winograd_forward(t2v_ctx* ctx, hipStream_t s, const t2v_conv_desc* d, const 
             g.a = V; g.b = w_packed; g.c = Mm; g.scratch = workspace + winograd_vm_floats(d, nimg);
             g.err = async_error_word();
             g.rows = rows;
-            g.a_group_stride = (long)T * d->Cin;
+            g.a_group_stride = v_group_stride;
             g.groups = 36; g.T = (int)T; g.K = d->Cin; g.N = d->Cout; g.c_cs = d->Cout;
             T2V_TRY(launch_wino_gemm_sk(s, g));
         } else {
             ConvPlan pl;
             T2V_TRY(build_winograd_gemm_plan(d, &pl, nimg));
+            if (keep) {   // the [36][T] "image" of the 1x1 plan is a window of the batch-wide one: row pitch keep_total * T
+                T2V_REQUIRE(v_group_stride * 36 * 4 < 0x7fff0000L, "winograd: kept V too large for 32-bit buffer offsets");
+                pl.kp.Win = wb.keep_total * (int)T;
+            }
             T2V_TRY(run_conv(ctx, s, pl, V, w_packed, nullptr, Mm, d->Cout, nullptr));
         }
     }
@@ -633,6 +644,26 @@ int t2v_conv2d_forward_winograd_stages(t2v_ctx* ctx, void* stream, const t2v_con
                 "winograd forward: shape/algo not supported (t2v_conv_winograd_supported)");
     T2V_REQUIRE(y_cs == d->Cout, "winograd forward: output channel storage must equal Cout");
     return winograd_forward(ctx, (hipStream_t)stream, d, x, w_packed, bias, y, stats_partial, workspace, stages);
+}
+
+static bool wgrad_winograd_ok(const t2v_conv_desc* d, int x_cs, int dy_cs);
+int t2v_conv2d_forward_winograd_keep_v(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, const float* x, int x_cs,
+                                       const float* w_packed, const float* bias, float* y, int y_cs, float* stats_partial,
+                                       float* workspace, float* wgrad_workspace, int batch, int slot) {
+    T2V_REQUIRE(ctx && d && x && w_packed && y && workspace && wgrad_workspace, "winograd forward (V kept): null pointer");
+    T2V_REQUIRE(d->algo == T2V_ALGO_WINOGRAD_F4 && winograd_supported(d, x_cs, d->algo) && x_cs == d->Cin &&
+                    wgrad_winograd_ok(d, x_cs, d->Cout),
+                "winograd forward (V kept): F(4x4,3x3) layers with a Winograd-domain weight gradient only "
+                "(t2v_conv_backward_weight_winograd_supported)");
+    T2V_REQUIRE(y_cs == d->Cout, "winograd forward: output channel storage must equal Cout");
+    T2V_REQUIRE(batch >= 1 && slot >= 0 && slot < batch, "winograd forward (V kept): slot %d of %d", slot, batch);
+    T2V_REQUIRE((long)36 * batch * wino_tiles_padded(d, d->algo) * x_cs * 4 < 0x7fff0000L,
+                "winograd forward (V kept): batch-wide V too large for 32-bit buffer offsets");
+    WinoBatch wb;
+    wb.keep_v = wgrad_workspace;     // V is the first tensor of the weight gradient's workspace
+    wb.keep_total = batch;
+    wb.keep_slot = slot;
+    return winograd_forward(ctx, (hipStream_t)stream, d, x, w_packed, bias, y, stats_partial, workspace, 7, &wb);
 }
 
 int t2v_conv2d_forward_winograd(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, const float* x, int x_cs,
@@ -991,8 +1022,10 @@ int t2v_conv2d_backward_weight_winograd_stages(t2v_ctx* ctx, void* stream, const
     T2V_REQUIRE((long)36 * Tt * x_cs * 4 < 0x7fff0000L && (long)36 * Tt * d->Cout * 4 < 0x7fff0000L,
                 "backward_weight_winograd: transformed tensors too large for 32-bit buffer offsets (split the batch)");
     if (stages & 1) {   // transforms of images [b0, b0 + nb) into their slots of the batch-wide tile lists
-        T2V_REQUIRE(x && dy, "backward_weight_winograd: null image pointers");
+        // (x == null: the forward pass has put V of these images there -- t2v_conv2d_forward_winograd_keep_v)
+        T2V_REQUIRE(dy, "backward_weight_winograd: null image pointers");
         for (int b = 0; b < nb; ++b) {
+            if (x)
             T2V_TRY(launch_winograd4_input(s, x + (size_t)b * d->H * d->W * x_cs, V, d->H, d->W, x_cs, d->pad,
                                            d->pad_mode == T2V_PAD_REFLECT, batch, b0 + b));
             T2V_TRY(launch_winograd4_dy(s, dy + (size_t)b * Ho * Wo * dy_cs, Md, Ho, Wo, d->Cout, dy_cs, batch, b0 + b));
@@ -1063,8 +1096,37 @@ int t2v_conv_pack_weight_transposed(t2v_ctx* ctx, void* stream, const t2v_conv_d
     return launch_winograd4_weight((hipStream_t)stream, w_forward_dev, packed_dev, /*rows*/ d->Cin, /*K*/ d->Cout,
                                    round_up(x_cs, 128), round_up(d->Cout, kBK), /*transpose, no flip*/ 2);
 }
+// the forward layer's own packed U [36][Cout_p][x_cs] serves as the B matrix [K = Cout][N = x_cs] of dV = dM U when the
+// fixed-grid GEMM has its [K][N] form for the shape (conv_igemm.hip: wino_gemm_sk_kernel<.., BKN>) and no padding rows sit
+// between the positions
+static bool dgrad_winograd_forward_weights_ok(const t2v_conv_desc* d, int x_cs, int dy_cs) {
+    if (!dgrad_winograd_ok(d, x_cs, dy_cs)) return false;
+    t2v_conv_desc f = *d;
+    f.algo = T2V_ALGO_WINOGRAD_F4;
+    ConvPlan pl;
+    if (!winograd_supported(&f, x_cs, f.algo) || build_conv_plan(&f, x_cs, false, &pl) != T2V_OK || pl.Cout_p != d->Cout) return false;
+    return wino_gemm_sk_bkn_ok(36, wino_tiles_padded(d, T2V_ALGO_WINOGRAD_F4), d->Cout, x_cs, x_cs);
+}
+int t2v_conv_backward_data_winograd_takes_forward_weights(const t2v_conv_desc* d, int x_cs, int dy_cs) {
+    return d && dgrad_winograd_forward_weights_ok(d, x_cs, dy_cs) ? 1 : 0;
+}
+static int backward_data_winograd(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, int batch, int slot,
+                                  const float* wgrad_workspace, int x_cs, const float* ut_packed, bool forward_weights,
+                                  float* scratch, float* dx);
 int t2v_conv2d_backward_data_winograd(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, int batch, int slot,
                                       const float* wgrad_workspace, int x_cs, const float* ut_packed, float* scratch, float* dx) {
+    return backward_data_winograd(ctx, stream, d, batch, slot, wgrad_workspace, x_cs, ut_packed, false, scratch, dx);
+}
+int t2v_conv2d_backward_data_winograd_fw(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, int batch, int slot,
+                                         const float* wgrad_workspace, int x_cs, const float* u_forward_packed, float* scratch,
+                                         float* dx) {
+    T2V_REQUIRE(d && dgrad_winograd_forward_weights_ok(d, x_cs, d->Cout),
+                "backward_data_winograd_fw: shape not supported (t2v_conv_backward_data_winograd_takes_forward_weights)");
+    return backward_data_winograd(ctx, stream, d, batch, slot, wgrad_workspace, x_cs, u_forward_packed, true, scratch, dx);
+}
+static int backward_data_winograd(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, int batch, int slot,
+                                  const float* wgrad_workspace, int x_cs, const float* ut_packed, bool forward_weights,
+                                  float* scratch, float* dx) {
     T2V_REQUIRE(ctx && d && wgrad_workspace && ut_packed && scratch && dx && batch >= 1 && slot >= 0 && slot < batch,
                 "backward_data_winograd: bad arguments");
     T2V_REQUIRE(dgrad_winograd_ok(d, x_cs, d->Cout), "backward_data_winograd: shape not supported");
@@ -1077,8 +1139,9 @@ int t2v_conv2d_backward_data_winograd(t2v_ctx* ctx, void* stream, const t2v_conv
     float* dxp = scratch + (size_t)36 * Tp * x_cs;
     // dV[xi][t][c] = sum_n M_dy[xi][slot*Tp + t][n] * U[xi][n][c]: the batched GEMM of a conv with the channel roles swapped,
     // reading its rows out of the batch-wide matrix (input row pitch Tt, Tp rows per position)
-    if (wino_gemm_sk_ok(36, Tp, d->Cout, x_cs, x_cs) && round_up(x_cs, 128) == x_cs) {
+    if (forward_weights || (wino_gemm_sk_ok(36, Tp, d->Cout, x_cs, x_cs) && round_up(x_cs, 128) == x_cs)) {
         SkGemm g;
+        g.b_kn = forward_weights;
         g.a = Md + (size_t)slot * Tp * d->Cout; g.b = ut_packed; g.c = dV;
         g.scratch = dxp + (size_t)(d->H + 2) * (d->W + 2) * x_cs;
         g.err = async_error_word();

@@ -103,13 +103,22 @@ __device__ __forceinline__ void dma16(const float* base, int nbytes, char* lds_d
 //     group 0 of the next stage can be prefetched from the other slot under the last group's MFMAs.
 // Runs `nstages` stages out of ring slots 0, 1, ... (the loaders start every run at slot 0) and begins with the B0 barrier
 // (stage 0 has landed); the caller closes with its own barrier.
-template <class Cfg, int RING>
+//
+// BKN: the B stage lies in LDS as [32 k][BN columns] (B is stored [K][N] in memory: wino_gemm_sk_kernel<.., BKN = true>, the
+// data gradient reading the FORWARD layer's U).  A lane then holds the two neighbouring columns b_row0, b_row0 + 1 of its
+// wave's 64 (b_row0 = 64 wn + 2 (lane & 31)) and reads them with one ds_read_b64 per k: the same k of the same stage goes
+// into the same MFMA as in the [N][K] form, so the accumulation chains -- and the bits -- are the same.
+template <class Cfg, int RING, bool BKN = false>
 __device__ __forceinline__ void mfma_k_loop(const char* smem, int nstages, int a_row0, int b_row0, int g, int fsw,
                                             typename Mfma<Cfg::MF>::acc_t (&acc)[Cfg::TM][Cfg::TN]) {
     using MM = Mfma<Cfg::MF>;
     constexpr int MF = Cfg::MF, BM = Cfg::BM;
     static_assert(Cfg::RQ % 2 == 0, "fragment register sets alternate per group");
-    f32x4 af[2][Cfg::TM], bf[2][Cfg::TN];
+    static_assert(!BKN || (Cfg::TN == 2 && Cfg::MF == 32), "[K][N] B stages: 64 columns per wave, two per lane");
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    constexpr int B_READS = BKN ? 4 : Cfg::TN;
+    f32x4 af[2][Cfg::TM], bf[2][BKN ? 1 : Cfg::TN];
+    f32x2 bk[2][BKN ? 4 : 1];
     auto load_frags = [&](int buf, int q, int set) {
         const char* sA = smem + buf * Cfg::STAGE_BYTES;
         const char* sB = sA + BM * 128;
@@ -117,9 +126,15 @@ __device__ __forceinline__ void mfma_k_loop(const char* smem, int nstages, int a
 #pragma unroll
         for (int i = 0; i < Cfg::TM; ++i)
             af[set][i] = *reinterpret_cast<const f32x4*>(sA + (a_row0 + i * MF) * 128 + slot);
+        if constexpr (BKN) {
 #pragma unroll
-        for (int j = 0; j < Cfg::TN; ++j)
-            bf[set][j] = *reinterpret_cast<const f32x4*>(sB + (b_row0 + j * MF) * 128 + slot);
+            for (int e = 0; e < 4; ++e)
+                bk[set][e] = *reinterpret_cast<const f32x2*>(sB + ((q * Cfg::NG + g) * 4 + e) * (Cfg::BN * 4) + b_row0 * 4);
+        } else {
+#pragma unroll
+            for (int j = 0; j < Cfg::TN; ++j)
+                bf[set][j] = *reinterpret_cast<const f32x4*>(sB + (b_row0 + j * MF) * 128 + slot);
+        }
     };
     __syncthreads();  // B0
     load_frags(0, 0, 0);
@@ -144,16 +159,20 @@ __device__ __forceinline__ void mfma_k_loop(const char* smem, int nstages, int a
 #pragma unroll
                 for (int i = 0; i < Cfg::TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < Cfg::TN; ++j)
-                        acc[i][j] = MM::run(af[cur][i][e], bf[cur][j][e], acc[i][j]);
+                    for (int j = 0; j < Cfg::TN; ++j) {
+                        float bv;
+                        if constexpr (BKN) bv = bk[cur][e][j];
+                        else bv = bf[cur][j][e];
+                        acc[i][j] = MM::run(af[cur][i][e], bv, acc[i][j]);
+                    }
             // issue order inside the group: MFMA, ds_read, MFMA, ds_read, ... so that every fragment read of the NEXT
             // group issues in the shadow of an executing MFMA
 #pragma unroll
-            for (int r = 0; r < Cfg::TM + Cfg::TN; ++r) {
+            for (int r = 0; r < Cfg::TM + B_READS; ++r) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read
             }
-            __builtin_amdgcn_sched_group_barrier(0x008, 4 * Cfg::TM * Cfg::TN - (Cfg::TM + Cfg::TN), 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4 * Cfg::TM * Cfg::TN - (Cfg::TM + B_READS), 0);
         }
         buf = nbuf;
     }
@@ -499,7 +518,11 @@ struct SkKParams {
     int rounds;   // > 0: `rounds` whole rounds of one tile per block + half a round of tiles cut in two (see the kernel)
 };
 
-template <class Cfg, int RING>
+// BKN: B is [groups][K][N] (N contiguous) instead of [groups][N][K]: the data gradient of a Winograd layer contracts over the
+// forward layer's OUTPUT channels, i.e. over the rows of the forward U [36][Cout][Cin] -- read in place, no transposed copy
+// of the weights (36 x 45 us of winograd4_weight_adjoint_kernel and 5.4 GB per train step of a 1024-channel generator).
+// A loader instruction fetches two k rows of 128 columns (1 KiB); see mfma_k_loop for the MFMA side.
+template <class Cfg, int RING, bool BKN = false>
 __global__ __launch_bounds__(512) void wino_gemm_sk_kernel(const SkKParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using MM = Mfma<32>;
@@ -550,8 +573,10 @@ __global__ __launch_bounds__(512) void wino_gemm_sk_kernel(const SkKParams p) {
     const int grid = p.blocks_per_xcd * 8;
 
     // ---- loader lane geometry (the same for every tile: only the SRD bases move) ----
+    static_assert(!BKN || BN == 128, "[K][N] B: 128-column tiles (a 512-byte LDS row per k)");
     const int lrow = lane >> 3, lslot = lane & 7;
-    const int a_bytes = BM * p.K * 4, b_bytes = BN * p.K * 4;
+    const int a_bytes = BM * p.K * 4, b_bytes = BKN ? ((p.K - 1) * p.N + BN) * 4 : BN * p.K * 4;
+    const int b_stage_step = BKN ? kBK * p.N * 4 : kBK * 4;   // bytes from one K stage to the next
     int a_voff[A_ITERS], b_voff[B_PER_WAVE];
 #pragma unroll
     for (int i = 0; i < A_ITERS; ++i) {
@@ -560,8 +585,13 @@ __global__ __launch_bounds__(512) void wino_gemm_sk_kernel(const SkKParams p) {
     }
 #pragma unroll
     for (int i = 0; i < B_PER_WAVE; ++i) {
-        const int r = (wid * B_PER_WAVE + i) * 8 + lrow;
-        b_voff[i] = (r * p.K + (lslot ^ ((r >> 1) & 7)) * 4) * 4;
+        if constexpr (BKN) {
+            const int kr = (wid * B_PER_WAVE + i) * 2 + (lane >> 5);   // k row of the stage; LDS row kr = [128 columns]
+            b_voff[i] = (kr * p.N + (lane & 31) * 4) * 4;
+        } else {
+            const int r = (wid * B_PER_WAVE + i) * 8 + lrow;
+            b_voff[i] = (r * p.K + (lslot ^ ((r >> 1) & 7)) * 4) * 4;
+        }
     }
 
     // ---- MFMA fragment geometry ----
@@ -570,7 +600,7 @@ __global__ __launch_bounds__(512) void wino_gemm_sk_kernel(const SkKParams p) {
     const int g = lane / MF;
     const int fsw = (fr >> 1) & 7;
     const int a_row0 = wm * (Cfg::TM * MF) + fr;
-    const int b_row0 = wn * (Cfg::TN * MF) + fr;
+    const int b_row0 = wn * (Cfg::TN * MF) + (BKN ? 2 * fr : fr);   // BKN: the first of this lane's two columns
     bool flag_due = false;   // this wave's hand-over stores are in flight; its tag is raised at the next wait point
     for (int f = 0; f < nf; ++f) {
         // processing order: the head handed on to block j+1, the whole tiles, the tail begun by block j-1
@@ -601,14 +631,14 @@ __global__ __launch_bounds__(512) void wino_gemm_sk_kernel(const SkKParams p) {
 
         if (is_loader) {
             const float* abase = p.a + pg * p.a_group_stride + (long)mt * BM * p.K;
-            const float* bbase = p.b + ((long)pg * p.N + nt * BN) * p.K;
+            const float* bbase = BKN ? p.b + (long)pg * p.K * p.N + nt * BN : p.b + ((long)pg * p.N + nt * BN) * p.K;
             auto issue_stage = [&](int kt, int buf) {
                 char* dstA = smem + buf * Cfg::STAGE_BYTES + wid * (BM / 4) * 128;
                 char* dstB = smem + buf * Cfg::STAGE_BYTES + BM * 128 + wid * B_PER_WAVE * 8 * 128;
 #pragma unroll
                 for (int i = 0; i < A_ITERS; ++i) dma16(abase, a_bytes, dstA + i * 8 * 128, a_voff[i], kt * (kBK * 4));
 #pragma unroll
-                for (int i = 0; i < B_PER_WAVE; ++i) dma16(bbase, b_bytes, dstB + i * 8 * 128, b_voff[i], kt * (kBK * 4));
+                for (int i = 0; i < B_PER_WAVE; ++i) dma16(bbase, b_bytes, dstB + i * 8 * 128, b_voff[i], kt * b_stage_step);
             };
             loader_k_loop<RING, LD_PER_WAVE>(kb, ke, issue_stage);
             __syncthreads();   // MFMA waves have read their last fragments: the next tile's prologue may overwrite the ring
@@ -658,7 +688,7 @@ __global__ __launch_bounds__(512) void wino_gemm_sk_kernel(const SkKParams p) {
                 __hip_atomic_store(p.flags + blockIdx.x * 4 + wid, p.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             flag_due = false;
         }
-        mfma_k_loop<Cfg, RING>(smem, ke - kb, a_row0, b_row0, g, fsw, acc);
+        mfma_k_loop<Cfg, RING, BKN>(smem, ke - kb, a_row0, b_row0, g, fsw, acc);
         __syncthreads();   // pairs with the loaders' closing barrier
 
         if (publish) {
@@ -682,7 +712,8 @@ __global__ __launch_bounds__(512) void wino_gemm_sk_kernel(const SkKParams p) {
             // one SRD on the tile's first output row, one per-lane offset (its row group and column), the rest scalar
             const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(
                 p.c + ((size_t)pg * p.T + (size_t)mt * BM) * p.c_cs + nt * BN, 0, 0x7ffffffc, 0x00020000);
-            const int voff = ((wm * (Cfg::TM * MF) + 4 * g) * p.c_cs + wn * (Cfg::TN * MF) + fr) * 4;
+            // (BKN: MFMA column tile jj of this lane is the tile's column b_row0 + jj)
+            const int voff = ((wm * (Cfg::TM * MF) + 4 * g) * p.c_cs + (BKN ? b_row0 : wn * (Cfg::TN * MF) + fr)) * 4;
 #pragma unroll
             for (int i = 0; i < Cfg::TM; ++i)
 #pragma unroll
@@ -691,7 +722,7 @@ __global__ __launch_bounds__(512) void wino_gemm_sk_kernel(const SkKParams p) {
 #pragma unroll
                     for (int jj = 0; jj < Cfg::TN; ++jj) {
                         const float v = acc[i][jj][r];
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), srd, voff + jj * MF * 4, soff, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), srd, voff + jj * (BKN ? 4 : MF * 4), soff, 0);
                     }
                 }
         }
@@ -1066,6 +1097,11 @@ bool wino_gemm_sk_ok(int groups, int T, int K, int N, int c_cs, int rows) {
     return tiles * 100 <= rounds * grid * 85;
 }
 
+// B given as [groups][K][N]: whole 128 x 128 tiles on two blocks per CU only (what a 512x512 train frame's 256 tile rows run)
+bool wino_gemm_sk_bkn_ok(int groups, int T, int K, int N, int c_cs) {
+    return wino_gemm_sk_ok(groups, T, K, N, c_cs, 0) && sk_tile_rows(T, N) == 128 && (long)K * N * 4 < 0x7fff0000L;
+}
+
 unsigned long long wino_gemm_sk_next_tag() {
     static std::atomic<unsigned long long> tag_counter{0};
     if (tag_counter.load() == 0) {
@@ -1079,9 +1115,9 @@ unsigned long long wino_gemm_sk_next_tag() {
     return ++tag_counter;
 }
 
-template <class Cfg, int RING = 2>
+template <class Cfg, int RING = 2, bool BKN = false>
 static int launch_sk(hipStream_t s, const SkKParams& k, int grid) {
-    auto kern = wino_gemm_sk_kernel<Cfg, RING>;
+    auto kern = wino_gemm_sk_kernel<Cfg, RING, BKN>;
     constexpr int LDS_BYTES = RING * Cfg::STAGE_BYTES;
     static bool attr_done = false;   // per instantiation
     if (!attr_done) {
@@ -1103,7 +1139,9 @@ int launch_wino_gemm_sk(hipStream_t s, const SkGemm& g) {
     k.err = g.err;
     k.a_group_stride = g.a_group_stride;
     k.T = g.T; k.K = g.K; k.N = g.N; k.c_cs = g.c_cs;
-    if (const int tall = g.rows > 0 ? sk_tall_rows(g.groups, g.rows, g.T, g.N) : 0) {
+    if (g.b_kn) {
+        T2V_REQUIRE(wino_gemm_sk_bkn_ok(g.groups, g.T, g.K, g.N, g.c_cs), "stream-K gemm, B as [K][N]: shape not supported");
+    } else if (const int tall = g.rows > 0 ? sk_tall_rows(g.groups, g.rows, g.T, g.N) : 0) {
         k.mtiles_g = tall == 160 ? 1 : g.T / 256; k.ntiles = g.N / 128; k.nk = g.K / kBK;
         k.tiles = g.groups * k.mtiles_g * k.ntiles;
         const int grid = wino_gemm_sk_grid_blocks() / 2;       // one block per CU
@@ -1119,6 +1157,7 @@ int launch_wino_gemm_sk(hipStream_t s, const SkGemm& g) {
     k.blocks_per_xcd = grid / 8;
     k.tiles_per_xcd = (k.tiles + 7) / 8;
     k.rounds = sk_half_round(k.tiles, grid, k.nk) ? (int)(k.tiles / grid) : 0;
+    if (g.b_kn) return launch_sk<CfgL, 2, true>(s, k, grid);
     return bm == 128 ? launch_sk<CfgL>(s, k, grid) : launch_sk<CfgW>(s, k, grid);
 }
 

@@ -77,6 +77,10 @@ int build_winograd_gemm_plan(const t2v_conv_desc* d, ConvPlan* pl, int nimg = 1)
 struct WinoBatch {
     int nimg = 1;
     long img_stride_x = 0;     // floats between the input maps
+    // keep_v != null (nimg == 1): V goes into slot `keep_slot` of a batch-wide tile list [36][keep_total * Tp][Cin] -- the
+    // Winograd-domain weight gradient's workspace -- instead of the call's own workspace, and the GEMM reads it from there
+    float* keep_v = nullptr;
+    int keep_total = 1, keep_slot = 0;
 };
 int winograd_forward(t2v_ctx* ctx, hipStream_t s, const t2v_conv_desc* d, const float* x, const float* w_packed,
                      const float* bias, float* y, float* stats_partial, float* workspace, int stages,

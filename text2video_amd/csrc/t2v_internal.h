@@ -263,9 +263,11 @@ struct SkGemm {
     int rows = 0;          // real tile rows per position (<= T) when the caller knows them: selects the 160 x 128 tiles
     long a_group_stride;   // floats between the groups of a
     int groups, T, K, N, c_cs;
+    bool b_kn = false;     // b is [groups][K][N] (wino_gemm_sk_bkn_ok): a data gradient reading the forward layer's U in place
 };
 size_t wino_gemm_sk_scratch_floats();
 bool wino_gemm_sk_ok(int groups, int T, int K, int N, int c_cs, int rows = 0);   // rows: real tile rows per position, if known
+bool wino_gemm_sk_bkn_ok(int groups, int T, int K, int N, int c_cs);
 int wino_gemm_sk_tall_rows(int groups, int rows, int T, int N);      // 160 | 256: the one-block-per-CU form of that kernel is taken; 0: not
 int launch_wino_gemm_sk(hipStream_t s, const SkGemm& g);
 // the ragged form (conv_igemm.hip: wino_gemm_skr_kernel): `rows` real tile rows per position (<= g.T, the padded pitch), cut

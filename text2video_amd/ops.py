@@ -143,15 +143,24 @@ def winograd_workspace(desc, x_cs, device):
     return torch.empty(n, dtype=torch.float32, device=device)
 
 
-def conv2d_winograd(x, packed_u, bias, desc, stats=None, out=None, workspace=None, stages=7):
+def conv2d_winograd(x, packed_u, bias, desc, stats=None, out=None, workspace=None, stages=7, keep_v=None):
     """3x3 stride-1 reflect-pad-1 conv through Winograd (desc.algo: ALGO_WINOGRAD F(2x2,3x3) | ALGO_WINOGRAD_F4 F(4x4,3x3)).
-    stages: bit mask 1 = input transform, 2 = batched GEMM, 4 = output transform (all by default)."""
+    stages: bit mask 1 = input transform, 2 = batched GEMM, 4 = output transform (all by default).
+    keep_v = (wgrad_ws, batch, slot): the input transform lands in that slot of the Winograd-domain weight gradient's workspace
+    (backward_weight_winograd_workspace) and stays there for the backward pass (conv2d_backward_weight_winograd_dy)."""
     c = context()
     _chk(x, "x")
     x_cs = x.shape[-1]
     ws = workspace if workspace is not None else winograd_workspace(desc, x_cs, x.device)
     ho, wo = conv_out_dims(desc)
     y = out if out is not None else torch.empty(ho, wo, desc.Cout, dtype=torch.float32, device=x.device)
+    if keep_v is not None:
+        assert stages == 7
+        wg, batch, slot = keep_v
+        check(c.lib.t2v_conv2d_forward_winograd_keep_v(c.handle, _stream(), ctypes.byref(desc), _p(x), x_cs, _p(packed_u), _p(bias),
+                                                       _p(y), desc.Cout, _p(stats), _p(ws), _p(wg), batch, slot),
+              "conv2d_forward_winograd_keep_v")
+        return y
     check(c.lib.t2v_conv2d_forward_winograd_stages(c.handle, _stream(), ctypes.byref(desc), _p(x), x_cs, _p(packed_u),
                                                    _p(bias), _p(y), desc.Cout, _p(stats), _p(ws), stages),
           "conv2d_forward_winograd")
@@ -542,6 +551,18 @@ def conv2d_backward_weight_winograd_stages(x, dy, desc, ws, batch, b0, reduce, o
     return dw
 
 
+def conv2d_backward_weight_winograd_dy(dy, desc, ws, batch, slot, x_cs):
+    """A dy A^T of one image ([Ho,Wo,Cout] or [1,Ho,Wo,Cout]) into slot `slot` of `ws`, whose V slot the forward pass has
+    filled already (conv2d_winograd(keep_v=...))."""
+    c = context()
+    if dy.dim() == 3:
+        dy = dy.unsqueeze(0)
+    _chk(dy, "dy")
+    check(c.lib.t2v_conv2d_backward_weight_winograd_stages(c.handle, _stream(), ctypes.byref(desc), batch, slot, 1, None, x_cs,
+                                                           _p(dy), dy.shape[-1], None, 0, _p(ws), 1),
+          "conv2d_backward_weight_winograd_stages")
+
+
 def conv2d_backward_weight_winograd_reduce(desc, ws, batch, x_cs, dy_cs, out=None, accumulate=False):
     """Reduction stage alone over the `batch` slots already transformed into `ws` -> dW in torch layout."""
     c = context()
@@ -567,15 +588,22 @@ def pack_conv_weight_transposed(w, desc, x_cs):
     return out
 
 
-def conv2d_backward_data_winograd(desc, batch, slot, wgrad_ws, x_cs, ut, out=None):
+def backward_data_winograd_takes_forward_weights(desc, x_cs, dy_cs):
+    """the data gradient reads the forward layer's own F(4x4) packing (pack_conv_weight) in place: no transposed copy"""
+    return bool(_lib.load().t2v_conv_backward_data_winograd_takes_forward_weights(ctypes.byref(desc), x_cs, dy_cs))
+
+
+def conv2d_backward_data_winograd(desc, batch, slot, wgrad_ws, x_cs, ut, out=None, forward_weights=False):
     """dx [H,W,x_cs] of image `slot` of a batch whose A dy A^T already sits in the weight gradient's workspace `wgrad_ws`
-    (conv2d_backward_weight_winograd_stages): the transposed Winograd algorithm (include/t2v.h)."""
+    (conv2d_backward_weight_winograd_stages): the transposed Winograd algorithm (include/t2v.h).  `ut`: the transposed
+    packing (pack_conv_weight_transposed), or with forward_weights the forward layer's own F(4x4) packing."""
     c = context()
     dx = torch.empty(desc.H, desc.W, x_cs, dtype=torch.float32, device=wgrad_ws.device) if out is None else out
     n = c.lib.t2v_conv_backward_data_winograd_scratch_floats(ctypes.byref(desc), x_cs)
     scratch = torch.empty(n, dtype=torch.float32, device=wgrad_ws.device)
-    check(c.lib.t2v_conv2d_backward_data_winograd(c.handle, _stream(), ctypes.byref(desc), batch, slot, _p(wgrad_ws), x_cs, _p(ut),
-                                                  _p(scratch), _p(dx)), "conv2d_backward_data_winograd")
+    fn = c.lib.t2v_conv2d_backward_data_winograd_fw if forward_weights else c.lib.t2v_conv2d_backward_data_winograd
+    check(fn(c.handle, _stream(), ctypes.byref(desc), batch, slot, _p(wgrad_ws), x_cs, _p(ut), _p(scratch), _p(dx)),
+          "conv2d_backward_data_winograd")
     return dx
 
 

@@ -183,6 +183,7 @@ def batched_weight_gradients(params):
     graph that was built but never back-propagated cannot leave a stale count behind.  T2V_WGRAD_BATCH=0: off."""
     for p in params:
         p._t2v_wg_images, p._t2v_wg_state = 0, None
+        p._t2v_wg_seen = 0
         p._t2v_dw_uses, p._t2v_dw_stash = 0, None
     _WG_BATCH[0] = os.environ.get("T2V_WGRAD_BATCH", "1") != "0"
     _DW_PAIR[0] = os.environ.get("T2V_WGRAD_PAIR", "1") != "0"
@@ -200,6 +201,8 @@ def batched_weight_gradients(params):
             or (getattr(p, "_t2v_wg_state", None) is not None and p._t2v_wg_state[1] > 0)]
     for p in params:
         p._t2v_dw_stash, p._t2v_dw_uses, p._t2v_wg_state, p._t2v_wg_images = None, 0, None, 0
+        # what the layer saw in this step is what the next one prepares for (_keep_v_slot)
+        p._t2v_wg_expect = getattr(p, "_t2v_wg_seen", 0)
     if left:
         raise RuntimeError("batched_weight_gradients: %d parameter(s) (first: #%d) left the scope with an unreduced weight "
                            "gradient -- call flush_pending_weight_gradients(params, grads) after the backward pass" % (len(left), left[0]))
@@ -243,12 +246,83 @@ def wgrad_join():
         _WG_SIDE["pending"] = False
 
 
+def _keep_v_slot(w, x, ddesc, xcs, ycs):
+    """Forward side of a batched Winograd-domain weight gradient (use number `w._t2v_wg_images` of this step, not counted
+    yet): from a layer's second step on, the workspace of its weight gradient exists BEFORE the forward pass -- sized for
+    the images the previous step counted (`_t2v_wg_expect`) -- and the forward conv writes its input transform V straight
+    into a slot of it: backward transforms dy only (72 input transforms of 13.5 us fewer per step of the 512x512 config).
+    The slots are handed out from the top, so that the backward nodes -- which arrive in reverse -- fill them in the order
+    the un-kept path would: the same reduction order, the same bits.  Returns (workspace, slots, slot) or None: not kept
+    (first step, a batch, more uses than expected, T2V_WGRAD_KEEP_V=0)."""
+    expect = getattr(w, "_t2v_wg_expect", 0)
+    idx = getattr(w, "_t2v_wg_images", 0)
+    if x.shape[0] != 1 or expect < 1 or idx >= expect or xcs != ddesc.Cin or os.environ.get("T2V_WGRAD_KEEP_V", "1") == "0":
+        return None
+    st = getattr(w, "_t2v_wg_state", None)
+    if st is None:
+        if idx != 0:
+            return None       # an earlier use of this step went without: stay on that path
+        st = [ops.backward_weight_winograd_workspace(ddesc, xcs, expect, x.device), 0, _desc_key(ddesc, xcs), ddesc, xcs, ycs,
+              expect, [False] * expect]
+        w._t2v_wg_state = st
+    if len(st) < 8 or st[2] != _desc_key(ddesc, xcs):
+        return None
+    return st[0], expect, expect - 1 - idx
+
+
+def _kept_winograd_wgrad(w, dc, fdesc, kept, slot=None, info=None):
+    """backward side of _keep_v_slot: A dy A^T of this node's image into ITS slot; the node that completes the set -- every
+    use the forward pass counted has come back -- zeroes the slots nobody filled (a step with fewer uses than expected)
+    and runs the one reduction"""
+    ws, total, k = kept
+    st = w._t2v_wg_state
+    assert st is not None and st[0] is ws and not st[7][k]
+    if info is not None:
+        info[:] = [ws, total, k]
+    ops.conv2d_backward_weight_winograd_dy(dc, fdesc, ws, total, k, st[4])
+    st[7][k] = True
+    st[1] += 1
+    last = st[1] == min(getattr(w, "_t2v_wg_images", 0), total)
+    dw = None
+    if last:
+        _zero_unfilled_slots(st)
+        if slot is not None:
+            with (wgrad_fork(ws) if wgrad_stream_on(dc) else contextlib.nullcontext()):
+                ops.conv2d_backward_weight_winograd_reduce(fdesc, ws, total, st[4], st[5], out=slot.view, accumulate=slot.filled)
+            slot.filled = True
+        else:
+            dw = ops.conv2d_backward_weight_winograd_reduce(fdesc, ws, total, st[4], st[5])
+        w._t2v_wg_state, w._t2v_wg_images = None, 0
+    if slot is not None:
+        slot.owner.node_done(slot)
+    return dw
+
+
+def _zero_unfilled_slots(st):
+    """slots of a kept-V workspace whose A dy A^T never came (and whose V may never have been written): zero both -- a zero
+    image contributes nothing, whatever bit pattern the allocation held would"""
+    ws, fdesc, xcs, total, filled = st[0], st[3], st[4], st[6], st[7]
+    if all(filled):
+        return
+    tp = ops.winograd_tile_rows(fdesc)
+    nv = 36 * total * tp * xcs
+    v = ws[:nv].view(36, total, tp * xcs)
+    md = ws[nv:nv + 36 * total * tp * fdesc.Cout].view(36, total, tp * fdesc.Cout)
+    for k, f in enumerate(filled):
+        if not f:
+            v[:, k].zero_()
+            md[:, k].zero_()
+
+
 def _batched_winograd_wgrad(w, x, dc, fdesc, slot=None, info=None):
     """Weight gradient of one use of a layer whose forward counted `w._t2v_wg_images` images in this graph: the
     images are transformed into their slots of a workspace kept on the weight; the node that brings the last ones
     runs the single reduction over all of them and returns dW, the earlier ones return None (a zero gradient --
     autograd sums the nodes' results).  One K = images x tiles reduction instead of one short one per frame."""
     total = getattr(w, "_t2v_wg_images", 0)
+    st0 = getattr(w, "_t2v_wg_state", None)
+    if st0 is not None and len(st0) >= 8:
+        total = 0     # this step's workspace belongs to the uses that kept their V (_keep_v_slot); this one did not
     if total < x.shape[0]:     # no count on this object: reduce on the spot
         if slot is not None:
             with (wgrad_fork(x, dc) if wgrad_stream_on(x) else contextlib.nullcontext()):
@@ -310,6 +384,19 @@ def flush_pending_weight_gradients(params, grads):
         p._t2v_dw_stash, p._t2v_dw_uses = None, 0
         st = getattr(p, "_t2v_wg_state", None)
         if st is None:
+            continue
+        if len(st) >= 8:      # kept V (_keep_v_slot): the slots that did come back, the others zeroed
+            if st[1] > 0:
+                _zero_unfilled_slots(st)
+                ws, fdesc, xcs, dycs, total = st[0], st[3], st[4], st[5], st[6]
+                sl = grad_slot(p)
+                if sl is not None:
+                    ops.conv2d_backward_weight_winograd_reduce(fdesc, ws, total, xcs, dycs, out=sl.view, accumulate=sl.filled)
+                    sl.filled = True
+                else:
+                    dw = ops.conv2d_backward_weight_winograd_reduce(fdesc, ws, total, xcs, dycs)
+                    out[i] = dw if out[i] is None else out[i] + dw
+            p._t2v_wg_state, p._t2v_wg_images = None, 0
             continue
         ws, done, _, fdesc, xcs, dycs = st
         total = p._t2v_wg_images
@@ -445,14 +532,25 @@ class _ConvBlock(torch.autograd.Function):
         pw = cached_pack(w, ("fwd",) + _desc_key(fdesc, xcs), lambda: ops.pack_conv_weight(w.detach().contiguous(), fdesc, xcs))
         c = torch.empty(B, ho, wo, ycs, dtype=torch.float32, device=dev)
         mrs = None
+        # weight gradient in the Winograd domain where the forward took F(4x4,3x3) (a quarter of the FLOPs)
+        wino_wgrad = fdesc.algo == ops.ALGO_WINOGRAD_F4 and ops.backward_weight_winograd_supported(ddesc, xcs, ycs) \
+            and os.environ.get("T2V_WGRAD_WINOGRAD", "1") != "0"
+        # ... whose workspace, from the layer's second step on, takes this conv's input transform right now (_keep_v_slot)
+        kept = _keep_v_slot(w, x, ddesc, xcs, ycs) if (wino_wgrad and ctx.needs_input_grad[1] and _WG_BATCH[0]) else None
         # (a batch of a direct-algorithm layer -- the discriminators' -- is ONE launch: ops.conv2d_auto_batch)
         if norm is None:
-            ops.conv2d_auto_batch(x, pw, b.detach(), fdesc, y_cs=ycs, out=c)
+            if kept is not None:
+                ops.conv2d_winograd(x[0], pw, b.detach(), fdesc, out=c[0], keep_v=kept)
+            else:
+                ops.conv2d_auto_batch(x, pw, b.detach(), fdesc, y_cs=ycs, out=c)
             y = c
         else:
             n = ops.conv_stats_buffer(fdesc, dev).numel()
             stats = torch.empty(B * n, dtype=torch.float32, device=dev)
-            ops.conv2d_auto_batch(x, pw, b.detach(), fdesc, y_cs=ycs, stats=stats, out=c)
+            if kept is not None:
+                ops.conv2d_winograd(x[0], pw, b.detach(), fdesc, stats=stats, out=c[0], keep_v=kept)
+            else:
+                ops.conv2d_auto_batch(x, pw, b.detach(), fdesc, y_cs=ycs, stats=stats, out=c)
             y = torch.empty_like(c)
             g = gamma.detach() if gamma is not None else None
             bt = beta.detach() if beta is not None else None
@@ -472,13 +570,11 @@ class _ConvBlock(torch.autograd.Function):
                 res = None
         if res is not None:
             y = y + res   # residual add (plumbing-level elementwise; its gradient is the identity)
-        # weight gradient in the Winograd domain where the forward took F(4x4,3x3) (a quarter of the FLOPs)
-        wino_wgrad = fdesc.algo == ops.ALGO_WINOGRAD_F4 and ops.backward_weight_winograd_supported(ddesc, xcs, ycs) \
-            and os.environ.get("T2V_WGRAD_WINOGRAD", "1") != "0"
         # every use of the layer in this graph (one per frame of the clip) is counted on the weight: their Winograd-
         # domain gradients are reduced together by the last backward node to run (T2V_WGRAD_BATCH=0: one by one)
         if wino_wgrad and w.requires_grad and _WG_BATCH[0]:
             w._t2v_wg_images = getattr(w, "_t2v_wg_images", 0) + B
+            w._t2v_wg_seen = getattr(w, "_t2v_wg_seen", 0) + B
             wino_wgrad = 2
         elif not wino_wgrad and w.requires_grad and _DW_PAIR[0] and \
                 (B > 1 or ops.backward_weight_strided_supported(ddesc, xcs, ycs)):
@@ -488,6 +584,7 @@ class _ConvBlock(torch.autograd.Function):
         # (an input nobody differentiates -- the discriminators' real pass -- needs no data-gradient conv)
         need_dx = int(need_dx) if (need_dx and ctx.needs_input_grad[0]) else 0      # 2: an input layer (input_gradients_off)
         ctx.meta = (desc, ddesc, norm, relu, act, need_dx, mrs, gamma is not None, wino_wgrad, slope)
+        ctx.kept = kept
         ctx.save_for_backward(x, w, c, gamma, beta, y if (norm is None and act != ops.ACT_NONE) else None, b)
         return y
 
@@ -563,7 +660,10 @@ class _ConvBlock(torch.autograd.Function):
             dw = None
         elif wino_wgrad == 2:
             wg_info = []
-            dw = _batched_winograd_wgrad(w, x, dc, fdesc, sl_w, wg_info)
+            if ctx.kept is not None:
+                dw = _kept_winograd_wgrad(w, dc, fdesc, ctx.kept, sl_w, wg_info)
+            else:
+                dw = _batched_winograd_wgrad(w, x, dc, fdesc, sl_w, wg_info)
         elif wino_wgrad:
             if sl_w is not None:
                 with (wgrad_fork(x, dc) if wgrad_stream_on(x) else contextlib.nullcontext()):
@@ -595,10 +695,19 @@ class _ConvBlock(torch.autograd.Function):
             # TRANSPOSED Winograd algorithm reads it from there -- U^T dM on the layer's own 256 tiles instead of the
             # full-correlation form's 289 -> 320, no second transform of dy, no flipped filter transform
             ws_, total_, done_ = wg_info
-            ut = cached_pack(w, ("dgradT",) + _desc_key(fdesc, xcs_), lambda: ops.pack_conv_weight_transposed(w.detach(), fdesc, xcs_))
+            # ... and where the fixed-grid GEMM has its [K][N] form for the shape, U^T is the forward pass's own packing read in
+            # place (T2V_DGRAD_FORWARD_WEIGHTS=0: the transposed copy, same bits)
+            fw = os.environ.get("T2V_DGRAD_FORWARD_WEIGHTS", "1") != "0" \
+                and ops.backward_data_winograd_takes_forward_weights(fdesc, xcs_, dc.shape[-1])
+            if fw:
+                # (wino_wgrad: the forward pass ran this layer as F(4x4) and holds that packing under this key)
+                f4 = ops.with_algo(fdesc, ops.ALGO_WINOGRAD_F4)
+                ut = cached_pack(w, ("fwd",) + _desc_key(f4, xcs_), lambda: ops.pack_conv_weight(w.detach().contiguous(), f4, xcs_))
+            else:
+                ut = cached_pack(w, ("dgradT",) + _desc_key(fdesc, xcs_), lambda: ops.pack_conv_weight_transposed(w.detach(), fdesc, xcs_))
             dx = torch.empty_like(x)
             for i in range(B):
-                ops.conv2d_backward_data_winograd(fdesc, total_, done_ + i, ws_, xcs_, ut, out=dx[i])
+                ops.conv2d_backward_data_winograd(fdesc, total_, done_ + i, ws_, xcs_, ut, out=dx[i], forward_weights=fw)
         elif need_dx:
             dg = ConvDataGrad(fdesc)
             dg.packed = cached_pack(w, ("dgrad",) + _desc_key(fdesc, x.shape[-1]), lambda: dg.refresh(w.detach()).packed)
