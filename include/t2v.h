@@ -289,6 +289,15 @@ int t2v_conv2d_backward_weight_winograd_stages(t2v_ctx* ctx, void* stream, const
  * t2v_conv_backward_weight_winograd_workspace_floats(d, x_cs, batch)) and read by the forward GEMM from there.  The backward
  * pass then calls _stages(stages & 1) with x == NULL for that image: only A dy A^T is transformed, the input transform of the
  * forward pass is not repeated (updateOutput and accGradParameters of THCUNN.h:664 share their im2col-equivalent). */
+/* A dy A^T of one image into slot `slot`, for a layer followed by a norm (+ ReLU): `dy` is the gradient BEHIND the norm,
+ * `conv_out` the layer's raw output, `sums` the (sum g, sum g*xhat) of t2v_instance_norm_backward[_affine] called with
+ * dx == NULL.  The gradient in front of the norm (BatchNormalization_backward's gradInput, THCUNN.h:47) is formed per
+ * loaded element -- inorm backward's arithmetic in its order, bit for bit -- and never stored: where the data gradient reads
+ * A dy A^T from this workspace (t2v_conv2d_backward_data_winograd) nothing else needs it. */
+int t2v_conv2d_backward_weight_winograd_dy_norm(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, int batch, int slot,
+                                                int x_cs, const float* conv_out, const float* dy, const float* mean_rstd,
+                                                const float* gamma, const float* beta, int relu, const float* sums,
+                                                float* workspace);
 int t2v_conv2d_forward_winograd_keep_v(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, const float* x, int x_cs,
                                        const float* w_packed, const float* bias, float* y, int y_cs, float* stats_partial,
                                        float* workspace, float* wgrad_workspace, int batch, int slot);
@@ -339,7 +348,7 @@ int t2v_reflect_pad_backward(t2v_ctx* ctx, void* stream, const float* dxp, float
 /* BatchNormalization_backward(train) / instance norm backward fused with the activation derivative:
  *   g = dy * act'(gamma*xhat+beta); dx = rstd*gamma*(g - mean(g) - xhat*mean(g*xhat)); dbeta_dgamma[c] = (sum g, sum g*xhat)
  * x = the conv output that was normalised, npix = pixels in the statistics (all images of a batch-norm batch),
- * relu as in t2v_instance_norm_apply, C % 4 == 0, scratch >= 128*C*2 floats. */
+ * relu as in t2v_instance_norm_apply, C % 4 == 0, scratch >= 128*C*2 floats.  dx may be NULL (ABI 16): the sums only. */
 int t2v_instance_norm_backward(t2v_ctx* ctx, void* stream, const float* x, const float* dy, const float* mean_rstd,
                                const float* gamma, const float* beta, int relu, long npix, int C, float* scratch,
                                float* dx, float* dbeta_dgamma);

@@ -382,6 +382,33 @@ def test_transposed_winograd_data_gradient_matches_autograd(H, W, Cin, Cout, t2v
                 ops.conv2d_backward_data_winograd(desc, B, 0, ws, Cin, u, forward_weights=True)
 
 
+@pytest.mark.parametrize("relu,affine", [(1, False), (0, True), (2, True)], ids=["relu", "affine", "lrelu+affine"])
+def test_dy_transform_with_the_norm_backward_inside_equals_apply_then_transform(relu, affine):
+    """A dy A^T of the gradient in FRONT of a norm layer, formed inside the transform from the gradient behind it, the conv
+    output and the norm backward's two sums (t2v_conv2d_backward_weight_winograd_dy_norm) -- bit for bit the transform of
+    the tensor instance_norm_backward writes out; a 36 x 20 map (ragged tile grid), slot 1 of 2."""
+    from text2video_amd import ops
+    g = torch.Generator().manual_seed(5)
+    H, W, C = 36, 20, 64
+    desc = ops.conv_desc(H, W, C, C, 3, 1, 1, ops.PAD_REFLECT)
+    c = torch.randn(H, W, C, generator=g).cuda()
+    dy = torch.randn(H, W, C, generator=g).cuda()
+    mr = torch.stack([c.mean((0, 1)), 1.0 / torch.sqrt(c.var((0, 1), unbiased=False) + 1e-5)], 1).contiguous()
+    gamma = (1.0 + 0.3 * torch.randn(C, generator=g)).cuda() if affine else None
+    beta = (0.2 * torch.randn(C, generator=g)).cuda() if affine else None
+    dc, sums = ops.instance_norm_backward(c, dy, mr, gamma, beta, relu)
+    none, sums2 = ops.instance_norm_backward(c, dy, mr, gamma, beta, relu, sums_only=True)
+    assert none is None and torch.equal(sums, sums2)
+    ws = [ops.backward_weight_winograd_workspace(desc, C, 2, "cuda:0").fill_(float("nan")) for _ in range(2)]
+    ops.conv2d_backward_weight_winograd_dy(dc, desc, ws[0], 2, 1, C)
+    ops.conv2d_backward_weight_winograd_dy_norm(c, dy, mr, gamma, beta, relu, sums2, desc, ws[1], 2, 1, C)
+    tp = ops.winograd_tile_rows(desc)
+    md = [w[36 * 2 * tp * C:36 * 2 * tp * C * 2].view(36, 2, tp, C) for w in ws]
+    assert torch.equal(md[0][:, 1], md[1][:, 1]) and bool(torch.isfinite(md[1][:, 1]).all())
+    assert bool(torch.isnan(md[1][:, 0]).all())              # the other slot untouched
+    assert md[1][:, 1].abs().max().item() > 0.1
+
+
 def test_data_gradient_reads_the_forward_weights_in_place_at_the_generator_bottleneck():
     """1024 -> 1024 at 64x64 (the ResnetBlock conv of a 512x512 frame; 576 tiles on 512 blocks: accumulator hand-overs in
     play): the data gradient with the forward packing as its [K][N] operand is bit for bit the one with the transposed copy."""

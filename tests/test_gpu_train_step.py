@@ -554,8 +554,9 @@ def test_train_step_with_the_fixed_grid_kernels_forced_is_bit_identical(t2v_env)
 
 def test_kept_input_transforms_and_in_place_forward_weights_leave_the_step_unchanged(t2v_env, monkeypatch):
     """Round 5: from a layer's second step on the forward conv writes its input transform V into the weight gradient's
-    workspace (train._keep_v_slot: backward transforms dy only), and the data gradient reads the forward packing of the
-    weights in place (the [K][N] form of the fixed-grid GEMM) instead of a transposed copy.  Against both switched off:
+    workspace (train._keep_v_slot: backward transforms dy only -- and forms the gradient in front of the norm inside that
+    transform instead of writing it out), and the data gradient reads the forward packing of the
+    weights in place (the [K][N] form of the fixed-grid GEMM) instead of a transposed copy.  Against all three switched off:
     losses and updated weights bit for bit over three steps -- the slots are handed out so that the reduction order is the
     un-kept path's -- and the kept path really ran."""
     from text2video_amd import ops, train as T
@@ -572,8 +573,9 @@ def test_kept_input_transforms_and_in_place_forward_weights_leave_the_step_uncha
     real_prev = torch.cat([real[1:], real[:1]], 0).contiguous()
     t2v_env("T2V_WINO_GEMM_SK", "2")          # (the fixed grid wherever the shape allows: these tile counts are below it)
     calls = {"dy": 0, "fw": 0}
-    dy_only, dgrad = ops.conv2d_backward_weight_winograd_dy, ops.conv2d_backward_data_winograd
-    monkeypatch.setattr(ops, "conv2d_backward_weight_winograd_dy",
+    dy_only, dgrad = ops.conv2d_backward_weight_winograd_dy_norm, ops.conv2d_backward_data_winograd
+    # (the transform of dy that also forms the gradient in front of the norm: it runs where V was kept -- every such layer here)
+    monkeypatch.setattr(ops, "conv2d_backward_weight_winograd_dy_norm",
                         lambda *a, **k: (calls.__setitem__("dy", calls["dy"] + 1), dy_only(*a, **k))[1])
     monkeypatch.setattr(ops, "conv2d_backward_data_winograd",
                         lambda *a, **k: (calls.__setitem__("fw", calls["fw"] + int(k.get("forward_weights", False))), dgrad(*a, **k))[1])
@@ -581,6 +583,7 @@ def test_kept_input_transforms_and_in_place_forward_weights_leave_the_step_uncha
     for mode in ("1", "0"):
         t2v_env("T2V_WGRAD_KEEP_V", mode)
         t2v_env("T2V_DGRAD_FORWARD_WEIGHTS", mode)
+        t2v_env("T2V_DY_NORM_FUSED", mode)
         tr = T.Vid2VidTrainer(opt, "cuda:0", seed=9)
         prev, ls = None, []
         for _ in range(3):

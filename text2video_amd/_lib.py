@@ -77,6 +77,8 @@ SIGNATURES = {
                                             c_void_p, c_int, c_void_p, c_void_p]),
     "t2v_conv2d_forward_winograd_stages": (c_int, [c_void_p, c_void_p, POINTER(ConvDesc), c_void_p, c_int, c_void_p,
                                                    c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int]),
+    "t2v_conv2d_backward_weight_winograd_dy_norm": (c_int, [c_void_p, c_void_p, POINTER(ConvDesc), c_int, c_int, c_int, c_void_p,
+                                                            c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "t2v_conv2d_forward_winograd_keep_v": (c_int, [c_void_p, c_void_p, POINTER(ConvDesc), c_void_p, c_int, c_void_p,
                                                    c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int]),
     "t2v_instance_norm_finalize": (c_int, [c_void_p, c_void_p, POINTER(ConvDesc), c_void_p, c_float, c_void_p]),

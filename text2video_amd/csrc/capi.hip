@@ -1062,6 +1062,21 @@ int t2v_conv2d_backward_weight_winograd_stages(t2v_ctx* ctx, void* stream, const
     return launch_winograd4_dw(s, dU, dw_torch, d->Cout, d->Cin, Cout_p, Kp, accumulate);
 }
 
+int t2v_conv2d_backward_weight_winograd_dy_norm(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, int batch, int slot,
+                                                int x_cs, const float* conv_out, const float* dy, const float* mean_rstd,
+                                                const float* gamma, const float* beta, int relu, const float* sums,
+                                                float* workspace) {
+    T2V_REQUIRE(ctx && d && conv_out && dy && mean_rstd && sums && workspace && batch >= 1 && slot >= 0 && slot < batch,
+                "backward_weight_winograd_dy_norm: bad arguments");
+    T2V_REQUIRE(wgrad_winograd_ok(d, x_cs, d->Cout), "backward_weight_winograd_dy_norm: shape not supported "
+                                                     "(t2v_conv_backward_weight_winograd_supported)");
+    const int Tp = wino_tiles_padded(d, T2V_ALGO_WINOGRAD_F4), Tt = batch * Tp;
+    T2V_REQUIRE((long)36 * Tt * d->Cout * 4 < 0x7fff0000L, "backward_weight_winograd_dy_norm: A dy A^T too large for 32-bit offsets");
+    float* Md = workspace + (size_t)36 * Tt * x_cs;
+    return launch_winograd4_dy_norm((hipStream_t)stream, dy, conv_out, mean_rstd, gamma, beta, relu, sums, Md, wino_out_h(d),
+                                    wino_out_w(d), d->Cout, batch, slot);
+}
+
 int t2v_conv2d_backward_weight_winograd(t2v_ctx* ctx, void* stream, const t2v_conv_desc* d, int batch, const float* x,
                                         int x_cs, const float* dy, int dy_cs, float* dw_torch, int accumulate,
                                         float* workspace) {
@@ -1208,7 +1223,8 @@ int t2v_reflect_pad_backward(t2v_ctx* ctx, void* stream, const float* dxp, float
 int t2v_instance_norm_backward(t2v_ctx* ctx, void* stream, const float* x, const float* dy, const float* mean_rstd,
                                const float* gamma, const float* beta, int relu, long npix, int C, float* scratch,
                                float* dx, float* dbeta_dgamma) {
-    T2V_REQUIRE(ctx && x && dy && mean_rstd && scratch && dx && dbeta_dgamma && npix > 0 && C > 0,
+    // (dx == null: the two sums only -- the gradient itself is formed by its consumer, t2v_conv2d_backward_weight_winograd_dy_norm)
+    T2V_REQUIRE(ctx && x && dy && mean_rstd && scratch && dbeta_dgamma && npix > 0 && C > 0,
                 "instance_norm_backward: bad arguments");
     return launch_inorm_backward((hipStream_t)stream, x, dy, mean_rstd, gamma, beta, relu, npix, C, scratch, dx,
                                  dbeta_dgamma);
@@ -1216,7 +1232,7 @@ int t2v_instance_norm_backward(t2v_ctx* ctx, void* stream, const float* x, const
 int t2v_instance_norm_backward_affine(t2v_ctx* ctx, void* stream, const float* x, const float* dy, const float* mean_rstd,
                                       const float* gamma, const float* beta, int relu, long npix, int C, float* scratch,
                                       float* dx, float* dbeta_dgamma, float* d_beta, float* d_gamma, int overwrite) {
-    T2V_REQUIRE(ctx && x && dy && mean_rstd && scratch && dx && dbeta_dgamma && d_beta && d_gamma && npix > 0 && C > 0,
+    T2V_REQUIRE(ctx && x && dy && mean_rstd && scratch && dbeta_dgamma && d_beta && d_gamma && npix > 0 && C > 0,
                 "instance_norm_backward_affine: bad arguments");
     return launch_inorm_backward((hipStream_t)stream, x, dy, mean_rstd, gamma, beta, relu, npix, C, scratch, dx,
                                  dbeta_dgamma, d_beta, d_gamma, overwrite);

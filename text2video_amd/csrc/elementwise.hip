@@ -787,7 +787,7 @@ int launch_inorm_backward(hipStream_t s, const float* x, const float* dy, const 
     hipLaunchKernelGGL(inorm_bwd_final_kernel, dim3((C + 63) / 64), dim3(256), 0, s,
                        reinterpret_cast<const float2*>(scratch), slices, C, reinterpret_cast<float2*>(sums), d_beta, d_gamma,
                        overwrite);
-    {
+    if (dx) {
         // threads = a multiple of the C/4 channel quads (every thread keeps its quad), ~8 float4 per thread
         const int C4 = C / 4;
         const long total4 = npix * C4;

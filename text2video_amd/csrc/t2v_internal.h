@@ -203,6 +203,9 @@ int launch_polyphase_input(hipStream_t s, const float* x, float* V, int H, int W
 int launch_polyphase_output(hipStream_t s, const float* Mm, const float* bias, float* y, float* stats, int Ho, int Wo, int N,
                             int up, int Tt);
 int launch_winograd4_dy(hipStream_t s, const float* dy, float* Md, int Ho, int Wo, int N, int dy_cs, int batch, int image);
+int launch_winograd4_dy_norm(hipStream_t s, const float* dy, const float* x, const float* mean_rstd, const float* gamma,
+                             const float* beta, int relu, const float* sums, float* Md, int Ho, int Wo, int N, int batch,
+                             int image);
 int launch_winograd4_dw(hipStream_t s, const float* dU, float* dw, int Cout, int Cin, int Cout_p, int Kp, int accumulate);
 int launch_winograd4_output(hipStream_t s, const float* Mm, const float* bias, float* y, float* stats, int H, int W, int N,
                             int lrelu, float slope, int nimg = 1);

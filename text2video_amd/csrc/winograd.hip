@@ -639,13 +639,47 @@ int launch_winograd4_dgrad_output(hipStream_t s, const float* dV, float* dxp, in
 // The reductions over tiles are 36 pixel-reduction GEMMs of 1/4 of the direct weight gradient's FLOPs; they run
 // on conv_wgrad_kernel unchanged (the transform position plays the role of the tap: row xi of a [36][T] "image").
 // winograd4_dy_kernel: Mdy[a*6+b][t0+tile][n] = (A dy A^T)[a][b], dy tile 4x4 (zero outside the map)
+// NORM: `dy` is the gradient behind the layer's norm (+ activation) and `nb.x` the conv's raw output: the gradient in front of
+// the norm -- rstd * gamma * (g - S0/N - xhat * S1/N), g = dy * act'(gamma * xhat + beta): the arithmetic of
+// inorm_bwd_apply_kernel (elementwise.hip) in the same order, the same bits -- is formed per loaded element and never
+// written out (nothing else reads it where the data gradient takes A dy A^T from this workspace)
+struct DyNormBackward {
+    const float2* x;           // the conv's raw output [Ho][Wo][cs2]
+    const float2* mean_rstd;   // [C] (mean, rstd)
+    const float* gamma;        // may be null
+    const float* beta;
+    const float2* sums;        // [C] (S0, S1) of inorm_bwd_final_kernel
+    float invn;
+    int relu;
+};
+template <bool NORM>
 __global__ __launch_bounds__(256) void winograd4_dy_kernel(const float2* __restrict__ dy, float2* __restrict__ Md, int Ho,
-                                                           int Wo, int C2, int cs2, int TW, int T, int Tp, int Tt, int t0) {
+                                                           int Wo, int C2, int cs2, int TW, int T, int Tp, int Tt, int t0,
+                                                           const DyNormBackward nb) {
     const long total = (long)Tp * C2;
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
         const long tile = i / C2;
         const int c2 = (int)(i - tile * C2);
+        float mean[2], rstd[2], ga[2], be[2], k0[2], k1[2];
+        if constexpr (NORM) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const float2 mr = nb.mean_rstd[2 * c2 + k], sm = nb.sums[2 * c2 + k];
+                mean[k] = mr.x;
+                rstd[k] = mr.y;
+                ga[k] = nb.gamma ? nb.gamma[2 * c2 + k] : 1.f;
+                be[k] = nb.beta ? nb.beta[2 * c2 + k] : 0.f;
+                k0[k] = sm.x * nb.invn;
+                k1[k] = sm.y * nb.invn;
+            }
+        }
+        auto front = [&](float xv, float gv, int k) {     // (inorm_bwd_apply_kernel's `one`)
+            const float xh = (xv - mean[k]) * rstd[k];
+            const float pre = ga[k] * xh + be[k];
+            const float g = gv * (nb.relu == 1 ? (pre > 0.f ? 1.f : 0.f) : (nb.relu == 2 ? (pre > 0.f ? 1.f : 0.2f) : 1.f));
+            return rstd[k] * ga[k] * (g - k0[k] - xh * k1[k]);
+        };
         if (tile >= T) {
 #pragma unroll
             for (int xi = 0; xi < 36; ++xi) Md[((long)xi * Tt + t0 + tile) * C2 + c2] = make_float2(0.f, 0.f);
@@ -660,7 +694,13 @@ __global__ __launch_bounds__(256) void winograd4_dy_kernel(const float2* __restr
 #pragma unroll
             for (int j2 = 0; j2 < 4; ++j2) {
                 const int oy = 4 * ty + i2, ox = 4 * tx + j2;
-                const float2 d = (oy < Ho && ox < Wo) ? dy[((long)oy * Wo + ox) * cs2 + c2] : make_float2(0.f, 0.f);
+                float2 d = (oy < Ho && ox < Wo) ? dy[((long)oy * Wo + ox) * cs2 + c2] : make_float2(0.f, 0.f);
+                if constexpr (NORM) {
+                    if (oy < Ho && ox < Wo) {
+                        const float2 xv = nb.x[((long)oy * Wo + ox) * cs2 + c2];
+                        d = make_float2(front(xv.x, d.x, 0), front(xv.y, d.y, 1));
+                    }
+                }
                 vx[j2] = d.x;
                 vy[j2] = d.y;
             }
@@ -701,9 +741,28 @@ __global__ __launch_bounds__(256) void winograd4_dy_kernel(const float2* __restr
 }
 int launch_winograd4_dy(hipStream_t s, const float* dy, float* Md, int Ho, int Wo, int N, int dy_cs, int batch, int image) {
     const int TW = (Wo + 3) / 4, T = ((Ho + 3) / 4) * TW, Tp = wino_pad_tiles(T);
-    hipLaunchKernelGGL(winograd4_dy_kernel, dim3(wg_grid((long)Tp * (N / 2), 256)), dim3(256), 0, s,
+    hipLaunchKernelGGL(winograd4_dy_kernel<false>, dim3(wg_grid((long)Tp * (N / 2), 256)), dim3(256), 0, s,
                        reinterpret_cast<const float2*>(dy), reinterpret_cast<float2*>(Md), Ho, Wo, N / 2, dy_cs / 2, TW, T, Tp,
-                       batch * Tp, image * Tp);
+                       batch * Tp, image * Tp, DyNormBackward{});
+    T2V_HIP_CHECK(hipGetLastError());
+    return T2V_OK;
+}
+// ... of a gradient that still has to pass the layer's norm backwards (winograd4_dy_kernel<true>); x, dy: [Ho][Wo][N]
+int launch_winograd4_dy_norm(hipStream_t s, const float* dy, const float* x, const float* mean_rstd, const float* gamma,
+                             const float* beta, int relu, const float* sums, float* Md, int Ho, int Wo, int N, int batch,
+                             int image) {
+    const int TW = (Wo + 3) / 4, T = ((Ho + 3) / 4) * TW, Tp = wino_pad_tiles(T);
+    DyNormBackward nb;
+    nb.x = reinterpret_cast<const float2*>(x);
+    nb.mean_rstd = reinterpret_cast<const float2*>(mean_rstd);
+    nb.gamma = gamma;
+    nb.beta = beta;
+    nb.sums = reinterpret_cast<const float2*>(sums);
+    nb.invn = 1.f / (float)((long)Ho * Wo);
+    nb.relu = relu;
+    hipLaunchKernelGGL(winograd4_dy_kernel<true>, dim3(wg_grid((long)Tp * (N / 2), 256)), dim3(256), 0, s,
+                       reinterpret_cast<const float2*>(dy), reinterpret_cast<float2*>(Md), Ho, Wo, N / 2, N / 2, TW, T, Tp,
+                       batch * Tp, image * Tp, nb);
     T2V_HIP_CHECK(hipGetLastError());
     return T2V_OK;
 }

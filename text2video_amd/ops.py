@@ -563,6 +563,18 @@ def conv2d_backward_weight_winograd_dy(dy, desc, ws, batch, slot, x_cs):
           "conv2d_backward_weight_winograd_stages")
 
 
+def conv2d_backward_weight_winograd_dy_norm(conv_out, dy, mean_rstd, gamma, beta, relu, sums, desc, ws, batch, slot, x_cs):
+    """conv2d_backward_weight_winograd_dy of the gradient in FRONT of the layer's norm, formed on the fly from the gradient
+    behind it (`dy`), the conv's raw output and the sums of instance_norm_backward(..., sums_only=True): one image."""
+    c = context()
+    _chk(conv_out, "conv_out")
+    _chk(dy, "dy")
+    assert conv_out.numel() == dy.numel() and conv_out.shape[-1] == desc.Cout
+    check(c.lib.t2v_conv2d_backward_weight_winograd_dy_norm(c.handle, _stream(), ctypes.byref(desc), batch, slot, x_cs, _p(conv_out),
+                                                            _p(dy), _p(mean_rstd), _p(gamma), _p(beta), int(relu), _p(sums), _p(ws)),
+          "conv2d_backward_weight_winograd_dy_norm")
+
+
 def conv2d_backward_weight_winograd_reduce(desc, ws, batch, x_cs, dy_cs, out=None, accumulate=False):
     """Reduction stage alone over the `batch` slots already transformed into `ws` -> dW in torch layout."""
     c = context()
@@ -707,17 +719,19 @@ def reflect_pad_backward(dxp, pad, out=None):
     return dx
 
 
-def instance_norm_backward(x, dy, mean_rstd, gamma=None, beta=None, relu=0, out=None, affine_into=None):
+def instance_norm_backward(x, dy, mean_rstd, gamma=None, beta=None, relu=0, out=None, affine_into=None, sums_only=False):
     """x, dy: [..., C] (all leading dims are the pixels of ONE statistics group).  Returns
     (dx, dbeta_dgamma [C,2]).  affine_into = (d_beta, d_gamma, overwrite): the two sums also land in those gradient
-    tensors (written or added) inside the same launches."""
+    tensors (written or added) inside the same launches.  sums_only: dx is None -- its consumer forms it
+    (conv2d_backward_weight_winograd_dy_norm)."""
     c = context()
     _chk(x, "x")
     _chk(dy, "dy")
     C = x.shape[-1]
     npix = x.numel() // C
-    dx = out if out is not None else torch.empty_like(x)
-    _chk(dx, "dx")
+    dx = None if sums_only else (out if out is not None else torch.empty_like(x))
+    if dx is not None:
+        _chk(dx, "dx")
     sums = torch.empty(C, 2, dtype=torch.float32, device=x.device)
     scratch = torch.empty(128 * C * 2, dtype=torch.float32, device=x.device)
     if affine_into is not None:

@@ -270,16 +270,20 @@ def _keep_v_slot(w, x, ddesc, xcs, ycs):
     return st[0], expect, expect - 1 - idx
 
 
-def _kept_winograd_wgrad(w, dc, fdesc, kept, slot=None, info=None):
+def _kept_winograd_wgrad(w, dc, fdesc, kept, slot=None, info=None, lazy_dc=None):
     """backward side of _keep_v_slot: A dy A^T of this node's image into ITS slot; the node that completes the set -- every
     use the forward pass counted has come back -- zeroes the slots nobody filled (a step with fewer uses than expected)
-    and runs the one reduction"""
+    and runs the one reduction.  lazy_dc = (conv output, gradient behind the norm, mean_rstd, gamma, beta, relu, sums)
+    instead of dc: the gradient in front of the norm is formed inside the transform."""
     ws, total, k = kept
     st = w._t2v_wg_state
     assert st is not None and st[0] is ws and not st[7][k]
     if info is not None:
         info[:] = [ws, total, k]
-    ops.conv2d_backward_weight_winograd_dy(dc, fdesc, ws, total, k, st[4])
+    if lazy_dc is not None:
+        ops.conv2d_backward_weight_winograd_dy_norm(*lazy_dc, fdesc, ws, total, k, st[4])
+    else:
+        ops.conv2d_backward_weight_winograd_dy(dc, fdesc, ws, total, k, st[4])
     st[7][k] = True
     st[1] += 1
     last = st[1] == min(getattr(w, "_t2v_wg_images", 0), total)
@@ -287,7 +291,7 @@ def _kept_winograd_wgrad(w, dc, fdesc, kept, slot=None, info=None):
     if last:
         _zero_unfilled_slots(st)
         if slot is not None:
-            with (wgrad_fork(ws) if wgrad_stream_on(dc) else contextlib.nullcontext()):
+            with (wgrad_fork(ws) if wgrad_stream_on(ws) else contextlib.nullcontext()):
                 ops.conv2d_backward_weight_winograd_reduce(fdesc, ws, total, st[4], st[5], out=slot.view, accumulate=slot.filled)
             slot.filled = True
         else:
@@ -624,7 +628,20 @@ class _ConvBlock(torch.autograd.Function):
                 dbeta = db_ if dbeta is None else dbeta + db_
                 dgamma = dg_ if dgamma is None else dgamma + dg_
 
-        if norm is None:
+        # Where this node's gradient in front of the norm would be read by nothing but the transform A dy A^T (the weight
+        # gradient's workspace holds V already, the data gradient takes A dy A^T from there), it is not written at all: the
+        # norm backward delivers its two sums, the transform forms the gradient per loaded element (T2V_DY_NORM_FUSED=0: off)
+        dgrad_t = wino_wgrad == 2 and os.environ.get("T2V_DGRAD_TRANSPOSED", "1") != "0" and \
+            ops.backward_data_winograd_supported(fdesc, x.shape[-1], c.shape[-1])
+        lazy_dc = None
+        if norm is not None and B == 1 and wino_wgrad == 2 and want[1] and ctx.kept is not None and (dgrad_t or not need_dx) \
+                and os.environ.get("T2V_DY_NORM_FUSED", "1") != "0":
+            _, sums = ops.instance_norm_backward(c[0], dy[0], mrs[0], gamma, beta, relu, affine_into=into_slots(), sums_only=True)
+            if affine and (want[3] or want[4]):
+                affine_sums(sums)
+            lazy_dc = (c[0], dy[0], mrs[0], gamma, beta, relu, sums)
+            dc = None
+        elif norm is None:
             # (act_backward's mode 2 is a plain sigmoid; the fused flow / weight head is its mode 4)
             dc = ops.act_backward(dy, y_act, 4 if act == ops.ACT_FLOW_W else act, slope) if act != ops.ACT_NONE else dy
         elif norm == "batch":
@@ -661,7 +678,7 @@ class _ConvBlock(torch.autograd.Function):
         elif wino_wgrad == 2:
             wg_info = []
             if ctx.kept is not None:
-                dw = _kept_winograd_wgrad(w, dc, fdesc, ctx.kept, sl_w, wg_info)
+                dw = _kept_winograd_wgrad(w, dc, fdesc, ctx.kept, sl_w, wg_info, lazy_dc)
             else:
                 dw = _batched_winograd_wgrad(w, x, dc, fdesc, sl_w, wg_info)
         elif wino_wgrad:
@@ -689,8 +706,7 @@ class _ConvBlock(torch.autograd.Function):
                 dw = ops.unpack_conv_weight(ops.conv2d_backward_weight(x, dc, fdesc), fdesc, x.shape[-1])
         dx = None
         xcs_ = x.shape[-1]
-        if need_dx and wino_wgrad == 2 and want[1] and len(wg_info) == 3 and os.environ.get("T2V_DGRAD_TRANSPOSED", "1") != "0" \
-                and ops.backward_data_winograd_supported(fdesc, xcs_, dc.shape[-1]):
+        if need_dx and wino_wgrad == 2 and want[1] and len(wg_info) == 3 and dgrad_t:
             # The weight gradient has just put A dy A^T of these images into its workspace: the data gradient by the
             # TRANSPOSED Winograd algorithm reads it from there -- U^T dM on the layer's own 256 tiles instead of the
             # full-correlation form's 289 -> 320, no second transform of dy, no flipped filter transform
@@ -698,7 +714,7 @@ class _ConvBlock(torch.autograd.Function):
             # ... and where the fixed-grid GEMM has its [K][N] form for the shape, U^T is the forward pass's own packing read in
             # place (T2V_DGRAD_FORWARD_WEIGHTS=0: the transposed copy, same bits)
             fw = os.environ.get("T2V_DGRAD_FORWARD_WEIGHTS", "1") != "0" \
-                and ops.backward_data_winograd_takes_forward_weights(fdesc, xcs_, dc.shape[-1])
+                and ops.backward_data_winograd_takes_forward_weights(fdesc, xcs_, c.shape[-1])
             if fw:
                 # (wino_wgrad: the forward pass ran this layer as F(4x4) and holds that packing under this key)
                 f4 = ops.with_algo(fdesc, ops.ALGO_WINOGRAD_F4)
