@@ -382,6 +382,21 @@ def test_transposed_winograd_data_gradient_matches_autograd(H, W, Cin, Cout, t2v
                 ops.conv2d_backward_data_winograd(desc, B, 0, ws, Cin, u, forward_weights=True)
 
 
+@pytest.mark.parametrize("npix,C,cs", [(512 * 512, 3, 4), (257 * 257 * 2, 64, 64), (35 * 35, 1, 4), (1000, 130, 132),
+                                       (77, 512, 512), (999, 5, 5), (1, 8, 8)])
+def test_channel_sum_matches_a_float64_sum(npix, C, cs):
+    """the bias gradient's per-channel sum over pixels (16-byte loads where the channel storage allows, the 4-byte form
+    otherwise): against a float64 sum, for heads (3 of 4 channels), a discriminator's first layer, a single channel, channel
+    counts that are no multiple of 4 and a single pixel"""
+    from text2video_amd import ops
+    g = torch.Generator().manual_seed(npix % 97 + C)
+    x = torch.randn(npix, cs, generator=g) + 0.25
+    got = ops.channel_sum(x.cuda(), C).cpu().double()
+    want = x.double().sum(0)[:C]
+    assert got.shape == (C,)
+    assert (got - want).abs().max().item() <= 2e-6 * x.double().abs().sum(0)[:C].max().item() + 1e-6
+
+
 @pytest.mark.parametrize("relu,affine", [(1, False), (0, True), (2, True)], ids=["relu", "affine", "lrelu+affine"])
 def test_dy_transform_with_the_norm_backward_inside_equals_apply_then_transform(relu, affine):
     """A dy A^T of the gradient in FRONT of a norm layer, formed inside the transform from the gradient behind it, the conv

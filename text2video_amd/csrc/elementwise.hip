@@ -3,7 +3,10 @@
 //   weight repacking and NCHW<->NHWC / uint8 plumbing.  All NHWC, 16-byte accesses where the
 //   layout allows, grid-stride with <= 2048 blocks (cdna_hip_programming.md Guideline 11/13).
 #include <math.h>
+#include <stdint.h>
 #include <stdlib.h>
+
+#include <algorithm>
 
 #include "t2v_internal.h"
 #include "norm_pool.h"
@@ -1034,19 +1037,74 @@ __global__ __launch_bounds__(256) void channel_sum_partial_kernel(const float* _
     __syncthreads();
     if (sl == 0 && c < C) partial[(size_t)blockIdx.y * C + c] = (sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl]);
 }
-__global__ void channel_sum_final_kernel(const float* __restrict__ partial, int slices, int C, float* __restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// ... 16 bytes per lane where the channel storage allows: Qp (a power of two >= the quads a block sums, <= 64) quad lanes x
+// 256 / Qp pixel lanes, four pixels' loads in flight per thread, pixel lanes added in a fixed order.  (The 4-byte form above
+// keeps 4 of 64 lanes busy on a 3-channel head and one load in flight everywhere: 38 us for the 34 MB of a discriminator's
+// first layer.)
+__global__ __launch_bounds__(256) void channel_sum_partial4_kernel(const float4* __restrict__ x, long npix, int Q, int cs4, int Qp,
+                                                                   float4* __restrict__ partial) {
+    __shared__ float4 sh[256];
+    const int ql = threadIdx.x & (Qp - 1), pl = threadIdx.x / Qp, PL = 256 / Qp;
+    const int q = blockIdx.x * 64 + ql;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto add = [&](const float4 v) { s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; };
+    if (q < Q) {
+        const long step = (long)gridDim.y * PL;
+        long p = (long)blockIdx.y * PL + pl;
+        for (; p + 3 * step < npix; p += 4 * step) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = x[(p + u * step) * cs4 + q];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) add(v[u]);
+        }
+        for (; p < npix; p += step) add(x[p * cs4 + q]);
+    }
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x < Qp && q < Q) {
+        float4 a = sh[ql];
+        for (int i = 1; i < PL; ++i) {   // fixed order
+            const float4 v = sh[i * Qp + ql];
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+        partial[(size_t)blockIdx.y * Q + q] = a;
+    }
+}
+// block = 64 channels x 4 slice lanes; `pitch` floats per slice
+__global__ __launch_bounds__(256) void channel_sum_final_kernel(const float* __restrict__ partial, int slices, int C, int pitch,
+                                                                float* __restrict__ out) {
+    __shared__ float sh[4][64];
+    const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
     float s = 0.f;
-    for (int i = 0; i < slices; ++i) s += partial[(size_t)i * C + c];
-    out[c] = s;
+    if (c < C)
+        for (int i = sl; i < slices; i += 4) s += partial[(size_t)i * pitch + c];
+    sh[sl][cl] = s;
+    __syncthreads();
+    if (sl == 0 && c < C) out[c] = (sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl]);
 }
 int launch_channel_sum(hipStream_t s, const float* x, long npix, int C, int cs, float* scratch, float* out) {
+    if (cs % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(scratch) & 15) == 0) {
+        const int Q = (C + 3) / 4;
+        int Qp = 1;
+        while (Qp < Q && Qp < 64) Qp *= 2;
+        const int PL = 256 / Qp, xb = (Q + 63) / 64;
+        long slices = (npix + (long)PL * 16 - 1) / ((long)PL * 16);      // ~16 pixels per thread ...
+        slices = std::min<long>(slices, std::max(1, 2048 / xb));         // ... up to ~8 blocks per CU
+        slices = std::min<long>(slices, (long)256 * C / (4 * Q));        // (scratch: 256 * C floats)
+        slices = std::max<long>(slices, 1);
+        hipLaunchKernelGGL(channel_sum_partial4_kernel, dim3(xb, (int)slices), dim3(256), 0, s, reinterpret_cast<const float4*>(x),
+                           npix, Q, cs / 4, Qp, reinterpret_cast<float4*>(scratch));
+        hipLaunchKernelGGL(channel_sum_final_kernel, dim3((C + 63) / 64), dim3(256), 0, s, scratch, (int)slices, C, 4 * Q, out);
+        T2V_HIP_CHECK(hipGetLastError());
+        return T2V_OK;
+    }
     int slices = (int)((npix + 511) / 512);
     if (slices > 256) slices = 256;
     if (slices < 1) slices = 1;
     hipLaunchKernelGGL(channel_sum_partial_kernel, dim3((C + 63) / 64, slices), dim3(256), 0, s, x, npix, C, cs, scratch);
-    hipLaunchKernelGGL(channel_sum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, s, scratch, slices, C, out);
+    hipLaunchKernelGGL(channel_sum_final_kernel, dim3((C + 63) / 64), dim3(256), 0, s, scratch, slices, C, C, out);
     T2V_HIP_CHECK(hipGetLastError());
     return T2V_OK;
 }
