@@ -352,20 +352,23 @@ def test_flow_branch_gets_its_weight_gradients_when_a_new_sequence_has_no_flow_l
     spec = GeneratorSpec(ngf=16, n_downsample=2, n_blocks=2, no_flow=False, norm="batch")
     sd = synthetic_state_dict(spec, 3, "vid2vid", flow_gain=0.1)
 
-    def grads(batched, flush):
+    def grads(batched, flush, passes=1):
         G = T.TrainableGenerator(spec, sd, "cuda:0")
         params = list(G.parameters())
         prev0 = torch.zeros(1, H, W, 8, device="cuda:0")
-        ctx = T.batched_weight_gradients(params) if batched else __import__("contextlib").nullcontext()
-        with ctx:
-            f0, _, _ = G(pose[0:1], prev0, use_raw_only=True, full=True, need_flow=True)     # flow branch built, never used
-            prev1 = torch.zeros_like(prev0)
-            prev1[..., 3:6] = f0.detach()[..., :3]
-            f1, _, _ = G(pose[1:2], prev1, use_raw_only=False, full=True)
-            loss = (f0[..., :3] * real[0:1, ..., :3]).sum() + (f1[..., :3] * real[1:2, ..., :3]).sum()
-            g = torch.autograd.grad(loss, params, allow_unused=True)
-            if flush:
-                g = T.flush_pending_weight_gradients(params, g)
+        for _ in range(passes):      # (from the second pass on the forward convs keep V in the weight gradients' workspaces)
+            ctx = T.batched_weight_gradients(params) if batched else __import__("contextlib").nullcontext()
+            with ctx:
+                f0, _, _ = G(pose[0:1], prev0, use_raw_only=True, full=True, need_flow=True)     # flow branch built, never used
+                prev1 = torch.zeros_like(prev0)
+                prev1[..., 3:6] = f0.detach()[..., :3]
+                f1, _, _ = G(pose[1:2], prev1, use_raw_only=False, full=True)
+                loss = (f0[..., :3] * real[0:1, ..., :3]).sum() + (f1[..., :3] * real[1:2, ..., :3]).sum()
+                g = torch.autograd.grad(loss, params, allow_unused=True)
+                if flush:
+                    g = T.flush_pending_weight_gradients(params, g)
+        if passes > 1:
+            assert max(getattr(p, "_t2v_wg_expect", 0) for p in params) == 2
         return {k: gi for (k, _), gi in zip(G.named_upstream_parameters().items(), g)}
 
     ref = grads(False, False)
@@ -378,6 +381,11 @@ def test_flow_branch_gets_its_weight_gradients_when_a_new_sequence_has_no_flow_l
         assert got[k] is not None, k
         err = (got[k] - ref[k]).abs().max().item() / max(ref[k].abs().max().item(), 1e-12)
         assert err <= 2e-3, (k, err)
+    # ... and with V kept by the forward pass (second pass over the same weights): frame 0's slot of a flow-branch layer holds
+    # its V but never receives A dy A^T -- the flush zeroes it and reduces; the same bits as the un-kept flush
+    kept = grads(True, True, passes=2)
+    for k in flow3x3:
+        assert kept[k] is not None and torch.equal(kept[k], got[k]), k
 
 
 def test_direct_gradient_delivery_equals_autograd_accumulation_and_launches_no_aten_adds():
@@ -550,6 +558,46 @@ def test_train_step_with_the_fixed_grid_kernels_forced_is_bit_identical(t2v_env)
     assert all(torch.equal(x, y) for x, y in zip(runs["2"][1], runs["0"][1]))
 
 
+
+
+@pytest.mark.parametrize("first,second", [(2, 1), (1, 2), (2, 3)], ids=["fewer", "more", "three"])
+def test_kept_workspaces_when_a_step_uses_a_layer_more_or_less_often_than_the_one_before(first, second):
+    """The workspace that keeps V is sized for the uses the PREVIOUS step counted (train._keep_v_slot).  A step with fewer
+    uses zeroes the slots nobody filled before the one reduction; one with more reduces the extra uses on the spot, added
+    to the same gradient.  Against the same graph on fresh weights (nothing kept): the ResnetBlock weights' gradients to
+    rounding."""
+    from text2video_amd import train as T
+    from text2video_amd.generator import GeneratorSpec, synthetic_state_dict
+    spec = GeneratorSpec(ngf=16, n_downsample=2, n_blocks=2, no_flow=True, norm="batch")
+    sd = synthetic_state_dict(spec, 3, "vid2vid")
+    H, W = 128, 256
+    rng = np.random.default_rng(12)
+    pose = torch.zeros(3, H, W, 12, device="cuda:0")
+    pose[..., :9] = torch.from_numpy(rng.uniform(-1, 1, (3, H, W, 9)).astype(np.float32)).cuda()
+    tgt = torch.from_numpy(rng.standard_normal((3, H, W, 3)).astype(np.float32)).cuda()
+
+    def run(G, frames):
+        params = list(G.parameters())
+        with T.batched_weight_gradients(params):
+            loss = 0.0
+            prev = torch.zeros(1, H, W, 8, device="cuda:0")
+            for i in range(frames):
+                f, _, _ = G(pose[i:i + 1], prev, use_raw_only=True, full=True)
+                loss = loss + (f[..., :3] * tgt[i:i + 1]).sum()
+            g = T.flush_pending_weight_gradients(params, torch.autograd.grad(loss, params, allow_unused=True))
+        return {k: gi for (k, _), gi in zip(G.named_upstream_parameters().items(), g)}
+
+    G = T.TrainableGenerator(spec, sd, "cuda:0")
+    run(G, first)
+    res = [p for k, p in G.named_upstream_parameters().items() if k.startswith("model_res") and p.dim() == 4]
+    assert res and all(getattr(p, "_t2v_wg_expect", 0) == first for p in res)
+    got = run(G, second)
+    ref = run(T.TrainableGenerator(spec, sd, "cuda:0"), second)
+    keys = [k for k in ref if k.startswith("model_res") and ref[k] is not None and ref[k].dim() == 4]
+    assert keys
+    for k in keys:
+        err = (got[k] - ref[k]).abs().max().item() / max(ref[k].abs().max().item(), 1e-12)
+        assert err <= 1e-5, (k, err)
 
 
 def test_kept_input_transforms_and_in_place_forward_weights_leave_the_step_unchanged(t2v_env, monkeypatch):
