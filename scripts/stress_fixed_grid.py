@@ -1,5 +1,6 @@
 """Race screen of the fixed-grid kernels' accumulator hand-over under load: two streams run Winograd convs (fixed-grid GEMM
-stage) and Winograd-domain weight-gradient reductions (fixed grid) on their own workspaces at the same time, with changing
+stage) and Winograd-domain weight-gradient reductions (fixed grid) + the data gradient on the forward packing of the weights
+(the [K][N] form of the fixed-grid GEMM) on their own workspaces at the same time, with changing
 inputs, while a third stream streams memory; every result must equal the one-block-per-tile result bit for bit.
 usage: stress_fixed_grid.py [iterations=200]"""
 import os, sys
@@ -22,13 +23,18 @@ dys = [torch.randn(2, H, W, C, device=dev) for _ in range(2)]
 x2 = [torch.randn(2, H, W, C, device=dev) for _ in range(2)]
 os.environ["T2V_WINO_GEMM_SK"] = "0"
 os.environ["T2V_WGRAD_SK"] = "0"
+ops.reload_env()
 want_y = [ops.conv2d_winograd(x, pu, b, desc).clone() for x in xs]
-want_dw = []
+want_dw, want_dx = [], []
+ut = ops.pack_conv_weight_transposed(w, desc, C)
 for i in range(2):
     ws = ops.backward_weight_winograd_workspace(ddesc, C, 2, dev)
     want_dw.append(ops.conv2d_backward_weight_winograd_stages(x2[i], dys[i], ddesc, ws, 2, 0, True).clone())
+    want_dx.append(ops.conv2d_backward_data_winograd(desc, 2, 1, ws, C, ut).clone())      # one block per tile, transposed copy
 os.environ["T2V_WINO_GEMM_SK"] = "1"
 os.environ["T2V_WGRAD_SK"] = "1"
+ops.reload_env()
+assert ops.backward_data_winograd_takes_forward_weights(desc, C, C)
 torch.cuda.synchronize()
 sA, sB, sC = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
 wsA = [ops.winograd_workspace(desc, C, dev) for _ in range(2)]
@@ -43,8 +49,10 @@ for it in range(iters):
         yb = ops.conv2d_winograd(xs[(it + 1) % 4], pu, b, desc, workspace=wsA[it & 1])     # same workspace, back to back
     with torch.cuda.stream(sB):
         dw = ops.conv2d_backward_weight_winograd_stages(x2[it & 1], dys[it & 1], ddesc, wsB, 2, 0, True)
+        dx = ops.conv2d_backward_data_winograd(desc, 2, 1, wsB, C, pu, forward_weights=True)
     torch.cuda.synchronize()
-    ok = torch.equal(ya, want_y[it % 4]) and torch.equal(yb, want_y[(it + 1) % 4]) and torch.equal(dw, want_dw[it & 1])
+    ok = torch.equal(ya, want_y[it % 4]) and torch.equal(yb, want_y[(it + 1) % 4]) and torch.equal(dw, want_dw[it & 1]) \
+        and torch.equal(dx, want_dx[it & 1])
     bad += not ok
 print("fixed-grid kernels under load: %d of %d iterations differ" % (bad, iters))
 sys.exit(1 if bad else 0)
