@@ -42,6 +42,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+SPEC_SCLK_MHZ = 2400.0         # ... at the 2.4 GHz peak engine clock (256 CUs x 256 FLOP/clk/CU x 2.4 GHz)
+REF_SCLK_MHZ = 2360.0          # the clock the round-4/5 train-step targets were quoted at (<= 88 ms x 2.36 / sclk)
 
 
 def gflop_per_frame(H, W, flow, ngf=128, n_down=3, n_blocks=9):
@@ -88,10 +90,10 @@ class ClockSampler:
     50 ms by a background thread while a timed region runs; plus the box / device identity.  Best effort: fields are
     None where the files are missing."""
 
-    def __init__(self, device_index):
+    def __init__(self, device_index, period=0.05):
         import glob
         import socket
-        self.path, self.samples, self._stop, self._thr = None, [], None, None
+        self.path, self.samples, self._stop, self._thr, self.period = None, [], None, None, period
         self.ident = {"host": socket.gethostname(), "gpu": None, "unique_id": None, "pci_bus_id": None}
         try:
             props = torch.cuda.get_device_properties(device_index)
@@ -127,7 +129,7 @@ class ClockSampler:
                     v = self._read()
                     if v:
                         self.samples.append(v)
-                    self._stop.wait(0.05)
+                    self._stop.wait(self.period)
             self._thr = threading.Thread(target=loop, daemon=True)
             self._thr.start()
         return self
@@ -136,6 +138,16 @@ class ClockSampler:
         if self._thr is not None:
             self._stop.set()
             self._thr.join()
+
+    def fork(self, period=0.01):
+        """a fresh sampler on the same sysfs file (another timed region of the same run: the roofline kernel loop, the
+        train-step block); 10 ms period by default -- those regions last 30-500 ms"""
+        c = ClockSampler.__new__(ClockSampler)
+        c.path, c.samples, c._stop, c._thr, c.period, c.ident = self.path, [], None, None, period, self.ident
+        return c
+
+    def mean_mhz(self):
+        return round(sum(self.samples) / len(self.samples), 1) if self.samples else None
 
     def summary(self):
         s = self.samples
@@ -162,7 +174,7 @@ def warm_clocks(fn, warm_ms=80.0):
     return n
 
 
-def gemm_stage_roofline(dev, sd, g0h, g0w, iters):
+def gemm_stage_roofline(dev, sd, g0h, g0w, iters, clocks=None):
     """The dominant kernel of a frame whose global generator G0 runs on g0h x g0w, timed live with HIP events on the
     stream it is launched on (torch's current stream); returns the `roofline` object.  The kernel timed is the one the
     frames RUN: t2v_generator_forward announces its second stream to the library (overlap hint), which then prefers the
@@ -173,7 +185,7 @@ def gemm_stage_roofline(dev, sd, g0h, g0w, iters):
     two_streams = os.environ.get("T2V_STREAMS", "") != "1"
     prev = ops.set_overlap_hint(two_streams)
     try:
-        r = _gemm_stage_roofline(dev, sd, g0h, g0w, iters)
+        r = _gemm_stage_roofline(dev, sd, g0h, g0w, iters, clocks)
     finally:
         ops.set_overlap_hint(prev)
     if two_streams:
@@ -183,7 +195,8 @@ def gemm_stage_roofline(dev, sd, g0h, g0w, iters):
     return r
 
 
-def _gemm_stage_roofline(dev, sd, g0h, g0w, iters):
+def _gemm_stage_roofline(dev, sd, g0h, g0w, iters, clocks=None):
+    import contextlib
     from text2video_amd import ops
     # ---- dominant kernel, timed live with HIP events on the stream it is launched on ----
     # The 1024->1024 3x3 ResnetBlock conv (28 per frame, 84 % of the algorithmic FLOPs) runs as Winograd
@@ -223,10 +236,21 @@ def _gemm_stage_roofline(dev, sd, g0h, g0w, iters):
             ops.conv2d(xs[i & 1], wt, bias, desc, y_cs=C, stats=stats, out=y)
     warm_clocks(launch)
     e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
-    e0.record()
-    for i in range(iters):
-        launch(i)
-    e1.record()
+    # the core clock DURING the kernel loop (sysfs, 10 ms period; the loop is repeated until the sampler has seen >= 60 ms of
+    # it -- the timed figure is the last repetition's): `frac` is against the 2.4 GHz spec peak, `frac_at_sclk` against the
+    # peak at the clock this box actually ran the loop at, so that a slow box and a slow kernel read differently
+    ksamp = clocks.fork(0.01) if clocks is not None else None
+    with (ksamp if ksamp is not None else contextlib.nullcontext()):
+        for _rep in range(6):
+            e0.record()
+            for i in range(iters):
+                launch(i)
+            e1.record()
+            if ksamp is None or ksamp.path is None:
+                break
+            torch.cuda.synchronize()
+            if len(ksamp.samples) >= 6:
+                break
     for i in range(iters):   # the whole conv (all three stages / the direct kernel)
         launch(i, 7)
     e2.record()
@@ -266,9 +290,14 @@ def _gemm_stage_roofline(dev, sd, g0h, g0w, iters):
                "ResnetBlock conv @%dx%d" % (npos, ntile, wm, wm, hb, wb)
              if use_wino else
              "conv_igemm_kernel<128x128,fp32 32x32x2,reflect,stats> 1024->1024 3x3 @%dx%d" % (hb, wb))
+    sclk = ksamp.mean_mhz() if ksamp is not None else None
     roofline = {"bound": "mfma", "kernel": kname,
                 "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+                "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
+                "sclk_mhz": sclk, "sclk_samples": len(ksamp.samples) if ksamp is not None else 0,
+                "peak_at_sclk": round(PEAK_FP32_MFMA_TFLOPS * sclk / SPEC_SCLK_MHZ, 1) if sclk else None,
+                "frac_at_sclk": round(achieved / (PEAK_FP32_MFMA_TFLOPS * sclk / SPEC_SCLK_MHZ), 4) if sclk else None,
+                "traffic": traffic,
                 "traffic_source": ("profiles/pmc_summary.json (separate rocprofv3 --pmc passes: 2*FETCH_SIZE + WRITE_SIZE per launch; "
                                    "not measured by this run)" if traffic is not None else None),
                 "ms_per_launch": round(k_ms, 4), "ms_per_launch_bracketed": round(k_ms_bracketed, 4),
@@ -344,7 +373,7 @@ def hires_block(dev, K, Wm, iters):
     return out
 
 
-def train_block(dev, dist_mod, world, rank, backend, steps, iters, ngf=128):
+def train_block(dev, dist_mod, world, rank, backend, steps, iters, ngf=128, clocks=None):
     """BASELINE configs[4], the work of ONE GPU: Vid2VidTrainer.train_step on 2 frames of 512x512 (max_frames_per_gpu 2, one
     sequence per GPU), generator WITH its flow branch + 2-scale PatchGAN D + face D, LSGAN + feature matching + flow / warp /
     weight losses against the zero reference flow, --no_vgg, fused Adam, bucketed gradient exchange (SURVEY 8d config 5;
@@ -360,7 +389,9 @@ def train_block(dev, dist_mod, world, rank, backend, steps, iters, ngf=128):
         from text2video_amd import launch
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(launch.free_port())
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        import datetime
+        from text2video_amd import distributed as D
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev, timeout=datetime.timedelta(seconds=D.dist_timeout_s()))
         own_group = True
     os.environ["T2V_TRAIN_FORCE_DIST"] = "1"      # GradBuckets: run the collectives on a 1-rank group as well
     H = W = 512
@@ -383,20 +414,27 @@ def train_block(dev, dist_mod, world, rank, backend, steps, iters, ngf=128):
 
     warm = 2 if steps >= 3 else 1
 
+    sclk = {}
+
     def timed(n, exchange):
+        import contextlib
         tr.bucketsG.exchange = tr.bucketsD.exchange = exchange
         for _ in range(warm):
             tr.train_step(pose, real, boxes, prev.clone(), real_prev=real_prev)
         torch.cuda.synchronize()
         dist.barrier()
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(n):
-            losses = tr.train_step(pose, real, boxes, prev.clone(), real_prev=real_prev)[0]
-        torch.cuda.synchronize()
-        dist.barrier()
-        torch.cuda.synchronize()
-        el = time.perf_counter() - t0
+        samp = clocks.fork(0.02) if clocks is not None else None      # this rank's core clock during the timed steps
+        with (samp if samp is not None else contextlib.nullcontext()):
+            t0 = time.perf_counter()
+            for _ in range(n):
+                losses = tr.train_step(pose, real, boxes, prev.clone(), real_prev=real_prev)[0]
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+        if samp is not None:
+            sclk[exchange] = samp.mean_mhz()
         if world > 1:
             tmax = torch.tensor([el], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -457,6 +495,11 @@ def train_block(dev, dist_mod, world, rank, backend, steps, iters, ngf=128):
         block = {"workload": "configs[4] per GPU: 512x512, 2 frames, G (flow%s) + D (num_D 2) + face D, --no_vgg, Adam; %d GPU(s)"
                              % ("" if ngf == 128 else ", ngf %d: NOT configs[4], plumbing test only" % ngf, world),
                  "ms_per_step": round(ms_with, 2), "steps": steps, "warmup": warm,
+                 # rank 0's core clock during the two timed regions, and the step scaled to the clock the round-4/5 targets
+                 # were quoted at (ms x sclk / 2360: the step is GPU-bound, its kernels MFMA-bound)
+                 "sclk_mhz": sclk.get(False), "sclk_mhz_with_exchange": sclk.get(True),
+                 "ms_per_step_without_at_%dmhz" % REF_SCLK_MHZ:
+                     round(ms_without * sclk[False] / REF_SCLK_MHZ, 2) if sclk.get(False) else None,
                  "exchange": {"group": "%d-rank %s" % (world, "rccl" if backend == "nccl" or own_group else backend),
                               "ms_per_step_with": round(ms_with, 2), "ms_per_step_without": round(ms_without, 2),
                               "ms": round(ms_with - ms_without, 2), "bytes": int(nbytes), "buckets": nbuckets,
@@ -772,6 +815,13 @@ def main():
     args = ap.parse_args()
 
     from text2video_amd import launch
+    if args.gpus > 1 and not launch.under_launcher() and os.environ.get("T2V_DIST_BACKEND", "nccl") == "nccl" \
+            and torch.cuda.device_count() < args.gpus:
+        # fail before any rank starts: N ranks on fewer than N devices would sit in RCCL's communicator set-up until it times out
+        print("bench.py: --gpus %d needs %d visible GPUs, this node shows %d (HIP_VISIBLE_DEVICES=%s)"
+              % (args.gpus, args.gpus, torch.cuda.device_count(), os.environ.get("HIP_VISIBLE_DEVICES", "<unset>")),
+              file=sys.stderr, flush=True)
+        sys.exit(2)
     # plain `python bench.py --gpus N` (no torchrun environment): run the N ranks ourselves, one per GPU
     launch.fan_out_if_needed(args.gpus)
     rank = int(os.environ.get("RANK", "0"))
@@ -784,17 +834,24 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     backend = os.environ.get("T2V_DIST_BACKEND", "nccl")   # "nccl" = RCCL; "gloo": several ranks on one GPU (tests only)
     local_rank = launch.local_device_index(local_rank)
+    if backend == "nccl" and torch.cuda.device_count() <= local_rank:
+        print("bench.py: rank %d of %d computes on device %d, but this process sees %d GPU(s) (HIP_VISIBLE_DEVICES=%s): RCCL needs "
+              "one device per rank" % (rank, world, local_rank, torch.cuda.device_count(), os.environ.get("HIP_VISIBLE_DEVICES", "<unset>")),
+              file=sys.stderr, flush=True)
+        sys.exit(2)
+    if world > 1:
+        launch.pin_to_numa_node(local_rank)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist = None
+    dist = D = None
     if world > 1 or os.environ.get("T2V_BENCH_FORCE_DIST") == "1":   # the env var exercises the RCCL path on 1 GPU
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        # the job's timeout (T2V_DIST_TIMEOUT_S, default 300 s) on the rendezvous and on every collective, then a roll call
+        # that names a rank that never arrived (text2video_amd/distributed.py)
+        from text2video_amd import distributed as D
+        D.init_group(backend, rank, world, dev if backend == "nccl" else None)
 
     from text2video_amd import ops
     H, W, K, Wm = args.height, args.width, args.steps, args.warmup
@@ -842,6 +899,7 @@ def main():
         for t in range(Wm):
             step(t, None)
         if dist:    # untimed: RCCL sets up its channels / registers the buffers on the first collective of a shape
+            D.rendezvous("warm-up done")      # (a rank that died in its warm-up is named here, not timed out on below)
             all_gather_frames()
         torch.cuda.synchronize()
         if dist:
@@ -891,7 +949,7 @@ def main():
                 return gflop_per_frame(H, W, flow)
         gf = gflops(head_flow)
         g0h, g0w = (H // 2, W // 2) if args.scales == 2 else (H, W)   # G0 runs on the half-resolution pyramid level
-        roofline = gemm_stage_roofline(dev, sd, g0h, g0w, args.kernel_iters)
+        roofline = gemm_stage_roofline(dev, sd, g0h, g0w, args.kernel_iters, sampler)
         # ---- CPU baseline: the oracle on this box's host cores, bounded sample ----
         cpu = None
         if args.cpu_frames > 0 and world == 1:   # reported at N=1 only (rank 0)
@@ -977,7 +1035,10 @@ def main():
                                       " + local enhancer (n_scales_spatial 2)" if args.scales == 2 else "",
                                       "flow branch + flow-warp compositor ON" if head_flow else "no flow branch"),
                        "frames_per_gpu": K, "parallelism": "sequence-chunk dp%d" % world,
-                       "collectives": ("rccl" if backend == "nccl" else backend) if dist else "none (single process)",
+                       # what the process group itself reports (not what --gpus asked for)
+                       "collectives": ("%s, %d ranks" % ("rccl" if backend == "nccl" else backend, dist.get_world_size()))
+                                      if dist else "none (single process)",
+                       "world_size": dist.get_world_size() if dist else 1,
                        "algorithmic_gflop_per_frame": round(gf, 1),
                        "algorithmic_tflops": round(fps * gf / 1e3, 2),
                        "variants": variants},
@@ -994,7 +1055,7 @@ def main():
         saved_fd = os.dup(1)
         os.dup2(2, 1)
         try:
-            train = train_block(dev, dist, world, rank, backend, args.train_steps, args.kernel_iters, args.train_ngf)
+            train = train_block(dev, dist, world, rank, backend, args.train_steps, args.kernel_iters, args.train_ngf, sampler)
         finally:
             try:
                 import ctypes
@@ -1019,4 +1080,5 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    from text2video_amd.distributed import fail_loudly
+    fail_loudly(main)      # a rank's exception (a collective's timeout included): one line naming the rank, exit status 3

@@ -13,6 +13,7 @@ ap.add_argument("--warmup", type=int, default=80)
 ap.add_argument("--winograd", type=int, nargs="?", const=1, default=0, help="1 = F(2x2,3x3), 2 = F(4x4,3x3)")
 ap.add_argument("--no_stats", action="store_true", help="without the norm-statistics epilogue (what it costs)")
 ap.add_argument("--stages", type=int, default=7, help="Winograd stage mask: 1 input transform, 2 GEMM, 4 output transform")
+ap.add_argument("--batch", type=int, default=1, help="images per launch (t2v_conv2d_forward_batch; direct algorithm)")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 for name in args.shapes.split(","):
@@ -26,13 +27,20 @@ for name in args.shapes.split(","):
     b = torch.randn(Cout, device=dev)
     sb = ops.conv_stats_buffer(desc, dev) if (stats and not args.no_stats) else None
     ho, wo = ops.conv_out_dims(desc)
-    ycs = Cout if Cout % 4 == 0 else 4
+    ycs = ops.round_up(Cout, 4)
     y = torch.empty(ho, wo, ycs, device=dev)
     flop = 2.0 * k * k * Cin * Cout * (H * W if tr else ho * wo)
     wws = ops.winograd_workspace(desc, xcs, dev) if args.winograd else None
     if args.winograd:
         ops.conv2d_winograd(x, pw, b, desc, stats=sb, out=y, workspace=wws)
-    run = (lambda: ops.conv2d_winograd(x, pw, b, desc, stats=sb, out=y, workspace=wws, stages=args.stages)) if args.winograd else \
+    if args.batch > 1:
+        B = args.batch
+        xb = torch.randn(B, H, W, xcs, device=dev)
+        yb = torch.empty(B, ho, wo, ycs, device=dev)
+        sbb = torch.empty(B * sb.numel(), device=dev) if sb is not None else None
+        flop *= B
+    run = (lambda: ops.conv2d_batch(xb, pw, b, desc, y_cs=ycs, stats=sbb, out=yb)) if args.batch > 1 else \
+        (lambda: ops.conv2d_winograd(x, pw, b, desc, stats=sb, out=y, workspace=wws, stages=args.stages)) if args.winograd else \
         (lambda: ops.conv2d(x, pw, b, desc, y_cs=ycs, stats=sb, out=y))
     for _ in range(args.warmup):  # clocks ramp over tens of ms: warm up long enough
         run()

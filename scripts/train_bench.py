@@ -17,6 +17,9 @@ ap.add_argument("--no_face", action="store_true")
 ap.add_argument("--vgg", action="store_true", help="add the VGG19 perceptual loss (seeded random weights)")
 ap.add_argument("--aten_stacks", action="store_true", help="one step under torch.profiler: where the ATen fills / adds / "
                 "copies of the step come from (python call sites, by count)")
+ap.add_argument("--aten_kernels", action="store_true", help="one step under torch.profiler with stacks: every ATen operator that "
+                "launches a fill / add / mul / copy / cat kernel, by the innermost text2video_amd frame that issued it (the autograd "
+                "engine's own -- gradient accumulation, materialised zero gradients -- show up as <autograd engine>)")
 ap.add_argument("--high_priority", action="store_true", help="run the steps on a high-priority stream (the weight-gradient side "
                 "stream keeps the default priority)")
 ap.add_argument("--host_time", action="store_true", help="also report when the host has finished ENQUEUEING a step (return of "
@@ -121,6 +124,32 @@ if args.aten_stacks:
     torch.cuda.synchronize()
     for (name, where), n in sites.most_common(70):
         print("%4d  %-12s %s" % (n, name, where))
+if args.aten_kernels:
+    import collections
+    from torch.profiler import profile, ProfilerActivity
+    step(); torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
+        step()
+        torch.cuda.synchronize()
+    want = ("aten::fill_", "aten::zero_", "aten::add", "aten::add_", "aten::mul", "aten::mul_", "aten::copy_", "aten::cat", "aten::sum",
+            "aten::div", "aten::stack", "aten::sub", "aten::neg", "aten::norm", "aten::lt", "aten::_to_copy", "aten::linalg_vector_norm")
+    sites = collections.Counter()
+    dev_us = collections.Counter()
+    for ev in prof.events():
+        if ev.name not in want or ev.device_time_total <= 0 and not ev.kernels:
+            continue
+        if not ev.kernels:
+            continue
+        fr = [f for f in (ev.stack or []) if "text2video_amd" in f or "train_bench" in f]
+        where = fr[0].split("/")[-1] if fr else "<autograd engine>"
+        shape = str(ev.input_shapes[0]) if ev.input_shapes else ""
+        key = (ev.name, where[:70], shape[:28])
+        sites[key] += 1
+        dev_us[key] += sum(k.duration for k in ev.kernels)
+    tot = sum(dev_us.values())
+    print("ATen operators with device kernels in one step: %d launches, %.3f ms of kernel time" % (sum(sites.values()), tot / 1e3))
+    for key, n in sorted(sites.items(), key=lambda kv: -dev_us[kv[0]])[:80]:
+        print("%4d %8.1f us  %-14s %-30s %s" % (n, dev_us[key], key[0], key[2], key[1]))
 if args.force_dist:
     print("gradient exchange (1-rank RCCL%s): %.1f MB per step in %d + %d buckets, %.2f ms still running after the backward pass"
           % (", reduce-scatter + all-gather" if os.environ.get("T2V_GRAD_RS_AG") == "1" else ", all-reduce", tr.comm_bytes / 2**20,

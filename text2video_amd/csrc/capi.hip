@@ -48,6 +48,7 @@ void options_reload() {
     o.wgrad_combine_max = env_int("T2V_WGRAD_COMBINE_MAX", 4);
     o.chain_lazy = env_int("T2V_CHAIN_LAZY", 1);
     o.streams = env_int("T2V_STREAMS", 0);
+    o.conv_tile = env_int("T2V_CONV_TILE", 0);
     g_opts = o;
 }
 const Options& options() {
@@ -246,7 +247,8 @@ int build_conv_plan(const t2v_conv_desc* d, int x_cs, bool need_stats, ConvPlan*
         const double fillq = (double)nbq / (double)(((nbq + 255) / 256) * 256);
         // (rule against forced tiles, per layer, at 512x320 / 512x680 / 512x512: within 1.3 / 2.8 / 1.0 % of the best forced
         // choice -- profiles/r04_ab_s2_tiles.txt; the forcing switch is gone)
-        if ((fill < 0.8 && nb < 1024) || (k.nphases > 1 && nb <= 512) || (fillq - fill >= 0.1 && nb < 2048)) {
+        const int force = options().conv_tile;
+        if (force == 2 || (force != 1 && ((fill < 0.8 && nb < 1024) || (k.nphases > 1 && nb <= 512) || (fillq - fill >= 0.1 && nb < 2048)))) {
             pl.tile = kTileQ;
             conv_tile_dims(pl.tile, &pl.BM, &pl.BN);
             k.ntiles = (d->Cout + pl.BN - 1) / pl.BN;

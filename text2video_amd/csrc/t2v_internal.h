@@ -47,6 +47,7 @@ struct Options {
     int wgrad_combine;       // T2V_WGRAD_COMBINE: in-kernel combine of split partials (default 1)
     int wgrad_combine_max;   // T2V_WGRAD_COMBINE_MAX: ... up to this many partials (default 4)
     int chain_lazy;          // T2V_CHAIN_LAZY: ResnetBlock chains apply their norms in the next input transform (default 1)
+    int conv_tile;           // T2V_CONV_TILE (measurement): 1 = keep the 128x128 tile where the fill rule would take 64x64, 2 = always 64x64
     int streams;             // T2V_STREAMS: 1 = the generator on the caller's stream only, 2 = always two streams; 0 (default):
                              // two, except the global generator on a bottleneck of >= 1024 Winograd tiles (1024x1024 frames)
 };

@@ -19,6 +19,107 @@ import torch
 import torch.distributed as dist
 
 
+EXIT_RANK_FAILURE = 3          # exit status of a rank that gave up on its peers (timeouts, a peer that never arrived)
+
+
+class RankFailure(RuntimeError):
+    """A peer did not show up / a collective did not complete inside T2V_DIST_TIMEOUT_S."""
+
+
+def dist_timeout_s():
+    """Seconds every rendezvous and every collective may take before it is an error (T2V_DIST_TIMEOUT_S, default 300;
+    the libraries' own defaults are 10 min for RCCL and 30 min for gloo: a wedged rank would cost the job's whole lease)."""
+    try:
+        return max(1.0, float(os.environ.get("T2V_DIST_TIMEOUT_S", "300")))
+    except ValueError:
+        return 300.0
+
+
+_STORE = [None]
+
+
+def _roll_call(store, tag, rank, world, t):
+    """sign in under `tag`, wait for everybody; RankFailure naming the absentees after `t` seconds"""
+    import datetime
+    keys = ["t2v/rdv/%s/%d" % (tag, r) for r in range(world)]
+    try:
+        store.set(keys[rank], "1")
+        store.wait(keys, datetime.timedelta(seconds=t))
+    except Exception as e:      # noqa: BLE001 -- DistStoreError (timeout) / a dead store host
+        try:
+            missing = [r for r in range(world) if not store.check([keys[r]])]
+        except Exception:       # noqa: BLE001 -- the store itself is gone: rank 0 hosts it
+            missing = [0]
+        raise RankFailure("rank(s) %s did not reach '%s' within %.0f s (reported by rank %d of %d; %s)"
+                          % (missing, tag, t, rank, world, type(e).__name__)) from e
+
+
+def init_group(backend, rank, world, device=None):
+    """dist.init_process_group with the job's timeout on the rendezvous AND on every later collective (RCCL: the
+    watchdog aborts the process when one overruns; gloo: the call raises).  The key-value store is created here, FIRST,
+    and a roll call runs on it before the backend's own rendezvous: a rank that never started is reported BY NUMBER on
+    every rank that waited for it (the backends only say that "somebody" timed out)."""
+    import datetime
+    t = dist_timeout_s()
+    td = datetime.timedelta(seconds=t)
+    addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
+    port = int(os.environ.get("MASTER_PORT", "29500"))
+    try:
+        store = dist.TCPStore(addr, port, world, is_master=(rank == 0), timeout=td, wait_for_workers=False)
+    except Exception as e:      # noqa: BLE001 -- rank 0 (the store's host) never came up, or the port is not reachable
+        raise RankFailure("rank %d of %d: no rendezvous store at %s:%d within %.0f s -- rank(s) [0] did not start, or the "
+                          "address is unreachable (%s)" % (rank, world, addr, port, t, type(e).__name__)) from e
+    _STORE[0] = store
+    _roll_call(store, "start", rank, world, t)
+    kw = {"timeout": td, "store": store}
+    if backend == "nccl" and device is not None:
+        kw["device_id"] = device
+    try:
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    except Exception as e:      # noqa: BLE001
+        raise RankFailure("rank %d of %d: the process group (%s) did not come up within %.0f s (%s: %s)"
+                          % (rank, world, backend, t, type(e).__name__, str(e).splitlines()[0] if str(e) else "")) from e
+
+
+_RDV_SEQ = {}
+
+
+def rendezvous(tag, timeout_s=None):
+    """Roll call through the job's key-value store (no collective, so it works before the first one and on any
+    backend): every rank signs in under `tag`, then waits for all the others.  On a timeout the ranks that did not
+    sign in are named -- `RankFailure: rank(s) [5] did not reach 'tails' ...` -- on every rank that waited.  The
+    reference's DataParallel re-raises the first worker's exception in the caller
+    ($SP/torch/nn/parallel/parallel_apply.py:40-78); a process per GPU needs the store for the same report.  A no-op
+    in a single process and on a group that init_group did not create (torchrun-initialised test groups)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1 or _STORE[0] is None:
+        return
+    n = _RDV_SEQ[tag] = _RDV_SEQ.get(tag, 0) + 1
+    _roll_call(_STORE[0], "%s/%d" % (tag, n), dist.get_rank(), dist.get_world_size(),
+               dist_timeout_s() if timeout_s is None else float(timeout_s))
+
+
+def fail_loudly(fn, *args, **kw):
+    """Run a rank's main function; any exception (a collective's timeout, RankFailure, an error of this rank's own)
+    becomes ONE stderr line naming the rank and a non-zero exit status -- through os._exit: the tear-down of a process
+    group whose peers are gone can block for its own timeout again.  The launcher (launch.self_launch / torchrun)
+    stops the other ranks on the first non-zero status."""
+    import sys
+    import traceback
+    try:
+        return fn(*args, **kw)
+    except SystemExit:
+        raise
+    except BaseException as e:      # noqa: BLE001
+        if int(os.environ.get("WORLD_SIZE", "1")) <= 1:
+            raise
+        traceback.print_exc()
+        print("[t2v] rank %s of %s FAILED: %s: %s" % (os.environ.get("RANK", "?"), os.environ.get("WORLD_SIZE", "?"),
+                                                     type(e).__name__, str(e).splitlines()[0] if str(e) else ""),
+              file=sys.stderr, flush=True)
+        sys.stdout.flush()
+        os._exit(EXIT_RANK_FAILURE)
+
+
 def init_from_env(backend=None):
     """torchrun-style env (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).  Returns (rank, local_rank, world)."""
     rank = int(os.environ.get("RANK", "0"))
@@ -29,6 +130,9 @@ def init_from_env(backend=None):
         # GPUs are allowed (single-GPU tests): ranks then share devices
         from .launch import local_device_index
         local_rank = local_device_index(local_rank)
+    if world > 1:
+        from .launch import pin_to_numa_node
+        pin_to_numa_node(local_rank)       # before any worker pool is forked: the pose workers inherit the mask
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
@@ -36,11 +140,15 @@ def init_from_env(backend=None):
             # "nccl" is RCCL on ROCm.  T2V_DIST_BACKEND=gloo: several ranks on ONE GPU (tests of the multi-rank frame loop
             # on a single-GPU box; RCCL refuses two ranks per device) -- the collectives then stage through host memory
             backend = os.environ.get("T2V_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
-        kw = {}
+        device = None
         if backend == "nccl":
+            if torch.cuda.device_count() <= local_rank:
+                raise RankFailure("rank %d wants device %d but this process sees %d GPU(s) (RCCL needs one device per rank; "
+                                  "T2V_DIST_BACKEND=gloo lets ranks share a device in tests)"
+                                  % (rank, local_rank, torch.cuda.device_count()))
             torch.cuda.set_device(local_rank)
-            kw["device_id"] = torch.device("cuda", local_rank)
-        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+            device = torch.device("cuda", local_rank)
+        init_group(backend, rank, world, device)
     return rank, local_rank, world
 
 
@@ -138,6 +246,7 @@ def exchange_tails(plan, rank, my_tails):
     world = len(plan)
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return {(u[0], u[2]): t for u, t in zip(plan[rank], my_tails)}
+    rendezvous("tails")        # (names a rank that never got here, before the collective that would only time out)
     shapes = [None] * world
     dist.all_gather_object(shapes, [tuple(t.shape) for t in my_tails])
     kinds = {s for per_rank in shapes for s in per_rank}

@@ -44,6 +44,106 @@ def local_device_index(local_rank):
     return idx
 
 
+_PINNED = []
+
+
+def parse_cpulist(text):
+    """'0-3,8,10-11' -> [0, 1, 2, 3, 8, 10, 11] (the kernel's cpulist format)"""
+    out = []
+    for part in text.strip().split(","):
+        part = part.strip()
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        out += list(range(int(a), int(b or a) + 1))
+    return out
+
+
+def device_pci_address(index):
+    """'dddd:bb:dd.f' of HIP device `index`, or None (no GPU / an older torch without the fields)"""
+    try:
+        import torch
+        if not torch.cuda.is_available() or index >= torch.cuda.device_count():
+            return None
+        p = torch.cuda.get_device_properties(index)
+        return "%04x:%02x:%02x.0" % (getattr(p, "pci_domain_id", 0), p.pci_bus_id, p.pci_device_id)
+    except Exception:      # noqa: BLE001
+        return None
+
+
+def numa_node_of(pci_address, sysfs="/sys"):
+    """NUMA node of a PCI function (the file /sys/class/drm/card*/device/numa_node resolves to), or None when the file
+    is missing or says -1 (one node / a VM without topology)"""
+    try:
+        node = int(open(os.path.join(sysfs, "bus/pci/devices", pci_address, "numa_node")).read().strip())
+    except (OSError, ValueError, TypeError):
+        return None
+    return node if node >= 0 else None
+
+
+def numa_cpu_share(node, peers, my_index, sysfs="/sys", allowed=None):
+    """The CPUs of NUMA node `node` this rank takes when `peers` ranks have their GPU on that node and this one is number
+    `my_index` among them: whole physical cores (a core's SMT siblings stay together), contiguous blocks, every rank the
+    same count; restricted to `allowed` (the mask the job was started with).  None when the topology cannot be read."""
+    try:
+        cpus = parse_cpulist(open(os.path.join(sysfs, "devices/system/node/node%d/cpulist" % node)).read())
+    except (OSError, ValueError):
+        return None
+    if allowed is not None:
+        cpus = [c for c in cpus if c in allowed]
+    if not cpus:
+        return None
+    cores, seen = [], set()
+    for c in cpus:
+        if c in seen:
+            continue
+        try:
+            sib = parse_cpulist(open(os.path.join(sysfs, "devices/system/cpu/cpu%d/topology/thread_siblings_list" % c)).read())
+        except (OSError, ValueError):
+            sib = [c]
+        grp = [t for t in sib if t in cpus and t not in seen] or [c]
+        seen.update(grp)
+        cores.append(sorted(grp))
+    peers = max(1, peers)
+    per = len(cores) // peers
+    if per == 0:          # more ranks than cores on the node: share the node
+        return sorted(c for g in cores for c in g)
+    mine = cores[my_index * per:(my_index + 1) * per]
+    return sorted(c for g in mine for c in g)
+
+
+def pin_to_numa_node(device_index, sysfs="/sys", pci_of=device_pci_address, apply=True):
+    """Restrict this rank (and everything it forks later: the pose-rasteriser workers, the JPEG threads) to its share of
+    the CPUs of the NUMA node its GPU hangs off -- 8 ranks x (1 launch thread + 4 workers) otherwise migrate across both
+    sockets of the host and reach their pinned staging buffers through the inter-socket link.  The ranks of the node
+    split its cores evenly (numa_cpu_share).  A no-op (returns None) when T2V_CPU_AFFINITY=0, off Linux, without a GPU,
+    or when sysfs does not say where the device is.  Returns the CPU list applied."""
+    if os.environ.get("T2V_CPU_AFFINITY", "1") == "0" or not hasattr(os, "sched_setaffinity"):
+        return None
+    if apply and _PINNED:          # once per process (a second split would start from the first one's share)
+        return _PINNED[0]
+    try:
+        node = numa_node_of(pci_of(device_index), sysfs)
+        if node is None:
+            return None
+        nlocal = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+        me = int(os.environ.get("LOCAL_RANK", "0"))
+        on_node = [lr for lr in range(nlocal)
+                   if numa_node_of(pci_of(local_device_index(lr)), sysfs) == node]
+        if me not in on_node:
+            on_node = sorted(set(on_node + [me]))
+        allowed = set(os.sched_getaffinity(0))
+        share = numa_cpu_share(node, len(on_node), on_node.index(me), sysfs, allowed)
+        if not share:
+            return None
+        if apply:
+            os.sched_setaffinity(0, share)
+            _PINNED.append(share)
+        return share
+    except Exception:      # noqa: BLE001 -- placement is an optimisation: never the reason a rank does not start
+        return None
+
+
 def _die_with_parent():
     """child side (preexec): SIGTERM when the launching process dies -- a SIGKILLed parent cannot stop its ranks itself, and
     ranks blocked in a collective would otherwise stay behind.  prctl(PR_SET_PDEATHSIG = 1, SIGTERM)."""

@@ -140,6 +140,11 @@ def run_test(opt, model=None, device=None, dataset=None):
     # the rasteriser workers are fresh interpreters (numpy / scipy / PIL imports): started first, they come up while the
     # checkpoint is read
     from .pose_dataset import default_pose_workers
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        # a rank of a multi-GPU job: onto the CPUs of its GPU's NUMA node BEFORE the worker pool starts (the workers inherit
+        # the mask); a no-op where sysfs does not place the device (launch.pin_to_numa_node)
+        from . import launch as _launch
+        _launch.pin_to_numa_node(_launch.local_device_index(int(os.environ.get("LOCAL_RANK", "0"))))
     n_workers = opt.pose_workers if getattr(opt, "pose_workers", None) is not None else default_pose_workers()
     if n_workers > 1:
         from .raster_pool import get_pool

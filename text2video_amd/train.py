@@ -1871,6 +1871,7 @@ def run_train(opt, steps=None):
     dev = "cuda:%d" % local_rank
     torch.cuda.set_device(local_rank)
     trainer = Vid2VidTrainer(opt, dev)
+    Dm.rendezvous("trainer built")      # (before the first gradient exchange: a rank that died building its replica is named)
     if rank == 0 and getattr(opt, "batchSize", world) not in (1, world):
         print("warning: --batchSize %d, but the batch is one clip per rank = %d (list %d devices in --gpu_ids)"
               % (opt.batchSize, world, opt.batchSize), flush=True)

@@ -52,7 +52,13 @@ if __name__ == "__main__":
     from text2video_amd import launch          # noqa: E402
     launch.fan_out_if_needed(len(opt.gpu_ids), opt.gpu_ids)
     try:
-        stats = run_test(opt)
+        if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+            # a rank of a multi-GPU job: its exception (a collective's timeout, a peer that never arrived) becomes one stderr
+            # line naming the rank and exit status 3; the launcher stops the others (text2video_amd/distributed.py)
+            from text2video_amd.distributed import fail_loudly     # noqa: E402
+            stats = fail_loudly(run_test, opt)
+        else:
+            stats = run_test(opt)
     except LeanUnsupported as e:       # e.g. a checkpoint container leantorch.load does not read: start over with torch
         print("note: %s -- running with torch" % e, file=sys.stderr)
         from text2video_amd import raster_pool     # noqa: E402

@@ -27,5 +27,6 @@ if __name__ == "__main__":
     opt = TrainOptions().parse(save=False)
     from text2video_amd import launch            # noqa: E402
     launch.fan_out_if_needed(len(opt.gpu_ids), opt.gpu_ids)
-    stats = run_train(opt)
+    from text2video_amd.distributed import fail_loudly      # noqa: E402
+    stats = fail_loudly(run_train, opt)      # (a rank's exception: one line naming the rank, exit status 3; single runs re-raise)
     print("done: %d steps, median %.1f ms/step on %d GPU(s)" % (stats["steps"], stats["ms_per_step"], stats["world"]))
