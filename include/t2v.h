@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define T2V_ABI_VERSION 16
+#define T2V_ABI_VERSION 17
 
 typedef enum {
     T2V_OK = 0,
@@ -391,6 +391,17 @@ int t2v_sum_abs_diff_masked(t2v_ctx* ctx, void* stream, const float* a, const fl
                             int c0, int C, int cs, float* scratch, float* out);
 int t2v_sum_abs_diff_masked_backward(t2v_ctx* ctx, void* stream, const float* a, const float* b, const float* mask,
                                      float scale, long npix, int c0, int C, int cs, float* da);
+/* All scalar loss terms of a train step in one launch (MSECriterion / AbsCriterion _updateOutput AND _updateGradInput,
+ * THCUNN.h:356,365,18,27, for every term at once).  Term t is described by three device tables:
+ *   term_ptrs[4t..]   = a, b, seed (device addresses; b / seed may be 0), n (op 0: pixels; op 1, 2: floats)
+ *   term_ints[2t..]   = op, cs     op 0: sum (a[i*cs] - c)^2 over the pixels, seed[i*cs] = 2 s (a - c), pad channels 0
+ *                                  op 1: sum |a - b|, seed = s sign(a - b);   op 2: no value, seed = 0
+ *   term_floats[3t..] = c, s (seed scale), v (value scale: out[t] = v * sum)
+ * Block b of the first kernel reduces `chunk` (a multiple of 4) elements of term chunk_term[b] starting at chunk_off[b] into
+ * partials[b]; the chunks of a term are consecutive, term_chunk0[t] .. term_chunk0[t+1].  Deterministic (no atomics). */
+int t2v_loss_terms(t2v_ctx* ctx, void* stream, const int64_t* term_ptrs, const int32_t* term_ints, const float* term_floats,
+                   const int32_t* chunk_term, const int64_t* chunk_off, const int32_t* term_chunk0, int nterms, int nchunks,
+                   int chunk, float* partials, float* out);
 /* lr, betas and eps are doubles, as adam.py holds them: 1-beta, the bias corrections and the step size are evaluated
  * in double and rounded to fp32 once (adam.py:86-96 does the same through Python floats). */
 int t2v_adam_step(t2v_ctx* ctx, void* stream, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,

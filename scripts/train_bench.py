@@ -141,7 +141,14 @@ if args.aten_kernels:
         if not ev.kernels:
             continue
         fr = [f for f in (ev.stack or []) if "text2video_amd" in f or "train_bench" in f]
-        where = fr[0].split("/")[-1] if fr else "<autograd engine>"
+        if fr:
+            where = fr[0].split("/")[-1]
+        else:       # no Python stack in this build: the chain of enclosing profiler ranges (autograd Function names, aten parents)
+            chain, q = [], ev.cpu_parent
+            while q is not None and len(chain) < 4:
+                chain.append(q.name.replace("aten::", ""))
+                q = q.cpu_parent
+            where = " < ".join(chain) if chain else "<top level>"
         shape = str(ev.input_shapes[0]) if ev.input_shapes else ""
         key = (ev.name, where[:70], shape[:28])
         sites[key] += 1

@@ -190,6 +190,66 @@ def _collect(tmp_path):
     return got
 
 
+def _two_scale_generate(poses, packed_state, n_frames):
+    """a recurrence with the state layout of the two-scale generator (n_scales_spatial 2): per pyramid level an [h, w, 8]
+    FIFO holding the two previous outputs in channels 0-2 / 3-5; the fine output depends on the coarse one.  State in and
+    out in the packed form the tail exchange moves (distributed.pack_state)."""
+    from text2video_amd import distributed as D
+    H, W = 4, 6
+    if packed_state is None:
+        fine, coarse = torch.zeros(H, W, 8), torch.zeros(H // 2, W // 2, 8)
+    else:
+        fine, coarse = D.unpack_state(packed_state)
+    outs = []
+    stop = poses.shape[0] if n_frames is None else 2 + n_frames
+    for t in range(2, stop):
+        drive = poses[t - 2:t + 1].sum()
+        oc = torch.tanh(0.3 * drive + 0.5 * coarse[..., 3:6] - 0.25 * coarse[..., 0:3] + torch.arange(3) * 0.01)
+        up = oc.repeat_interleave(2, 0).repeat_interleave(2, 1)
+        of = torch.tanh(0.2 * drive + 0.4 * fine[..., 3:6] - 0.3 * fine[..., 0:3] + 0.5 * up)
+        coarse = torch.cat([coarse[..., 3:6], oc, torch.zeros(H // 2, W // 2, 2)], -1)
+        fine = torch.cat([fine[..., 3:6], of, torch.zeros(H, W, 2)], -1)
+        outs.append(of)
+    return torch.stack(outs), D.pack_state([fine, coarse])
+
+
+def _two_scale_stitch_worker(rank, world, port, n, stitch, tmpdir):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from text2video_amd import distributed as D
+    D.init_from_env("gloo")
+    plan = D.plan_units({"only": n}, world, 3, True)
+    poses = _poses("only", n)
+    frames = D.run_units(plan[rank], plan, rank, lambda u, st, k: _two_scale_generate(poses[u[1]:u[2]], st, k), stitch, 1)
+    everything = [None] * world
+    dist.all_gather_object(everything, [(u, f) for u, f in zip(plan[rank], frames)])
+    if rank == 0:
+        torch.save(everything, os.path.join(tmpdir, "out.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_stitch_pass_carries_both_pyramid_levels_of_a_two_scale_generator(tmp_path):
+    """configs[2] x configs[3]: a generator with n_scales_spatial 2 keeps one FIFO per pyramid level; the chunk tails the
+    ranks all-gather carry both (packed into one tensor), and the stitched chunks reproduce the unsharded sequence bit for
+    bit.  pack_state / unpack_state round-trip levels of different sizes exactly."""
+    from text2video_amd import distributed as D
+    lv = [torch.randn(5, 7, 8), torch.randn(3, 4, 8), torch.randn(2, 2, 8)]
+    back = D.unpack_state(D.pack_state(lv))
+    assert len(back) == 3 and all(torch.equal(a, b) for a, b in zip(lv, back))
+    n = 19
+    want, _ = _two_scale_generate(_poses("only", n), None, None)
+    res = {}
+    for name, stitch in (("off", 0), ("full", 1000)):
+        d = tmp_path / name
+        d.mkdir()
+        mp.spawn(_two_scale_stitch_worker, args=(2, _free_port(), n, stitch, str(d)), nprocs=2, join=True)
+        res[name] = _collect(d)
+        assert set(res[name]) == {("only", t) for t in range(2, n)}
+    assert all(torch.equal(res["full"][("only", t)], want[t - 2]) for t in range(2, n))
+    assert any(not torch.equal(res["off"][("only", t)], want[t - 2]) for t in range(2, n))      # the seam the pass closes
+
+
 @pytest.mark.parametrize("seq_lengths,how_many", [({"tmp": 12, "tmp_smooth": 12}, None), ({"only": 21}, None),
                                                   ({"a": 9, "b": 14, "c": 5}, 13)])
 def test_multi_rank_frames_equal_single_rank_frames_by_default(tmp_path, seq_lengths, how_many):

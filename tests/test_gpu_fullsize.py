@@ -4,6 +4,8 @@ frames).  Where a CPU-oracle frame is affordable (a few seconds of host time) th
 teacher-forced; the sizes the CPU cannot reach (the single-scale 1024x1024 frame, the 512x512 train step) meet the oracle
 evaluated on the GPU in tests/test_gpu_device_oracle.py, and keep their size-independent properties here
 (bit-reproducibility, the compositor identity)."""
+import functools
+
 import numpy as np
 import pytest
 import torch
@@ -25,8 +27,11 @@ def _prev_frames(H, W, seed):
     return torch.tanh(torch.randn(2, 3, H, W, generator=g))
 
 
+@functools.lru_cache(maxsize=None)
 def _full_nets(scales, no_flow, conv_algo=None, flow_gain=0.1):
-    """configs[1] / configs[3] networks: G0 = ngf 128, 3 down-samplings, 9 blocks; G1 = ngf 64, 3 local blocks."""
+    """configs[1] / configs[3] networks: G0 = ngf 128, 3 down-samplings, 9 blocks; G1 = ngf 64, 3 local blocks.
+    Built once per variant and module run (1.1-1.5 GB of seeded weights each: the seven tests on the flow G0 share one pair;
+    the nets hold weights and packings only -- every test wraps them in its own Vid2VidInferenceRef / Vid2VidModelG state)."""
     from oracle.generator_ref import CompositeGenerator, CompositeLocalGenerator
     from text2video_amd.generator import GeneratorSpec, HipGenerator, synthetic_state_dict
     specs = [GeneratorSpec(ngf=128, n_downsample=3, n_blocks=9, no_flow=no_flow, norm="batch")]

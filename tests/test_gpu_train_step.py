@@ -467,6 +467,7 @@ def test_shared_discriminator_forward_equals_the_two_forward_form(t2v_env):
     real_prev = torch.cat([real[1:], real[:1]], 0).contiguous()
     boxes = [(8, 40, 40, 72)] * 2
     runs = {}
+    t2v_env("T2V_D_BATCHED", "0")       # (both forms one pass per launch; the batched default against this form: next test)
     for mode in ("1", "0"):
         t2v_env("T2V_D_SHARED_FWD", mode)
         tr = T.Vid2VidTrainer(opt, "cuda:0", seed=17)
@@ -484,6 +485,57 @@ def test_shared_discriminator_forward_equals_the_two_forward_form(t2v_env):
     assert all(torch.equal(x, y) for x, y in zip(a[2], b[2]))
     assert len(a[3]) == len(b[3]) > 4
     for (m1, v1, n1), (m2, v2, n2) in zip(a[3], b[3]):
+        assert n1 == n2 and torch.equal(m1, m2) and torch.equal(v1, v2)
+
+
+def test_batched_discriminator_passes_and_one_launch_loss_terms_equal_the_pass_by_pass_step(t2v_env):
+    """Round 6 (default path): every discriminator runs its real / fake / raw passes as ONE batch per layer -- BatchNorm
+    statistics per pass -- and all LSGAN / feature-matching terms are one launch that also writes the gradient seeds both
+    backward passes start from (train.LossBook, t2v_loss_terms).  Against the pass-by-pass step with the scalar graph on
+    autograd (T2V_D_BATCHED=0), image + face + temporal discriminators on, flow branch on, two steps (temporal windows full
+    in the second): the same forward -- BatchNorm running statistics bit for bit --, the same losses to fp32 rounding of the
+    term weights, every delivered gradient equal to rounding."""
+    from text2video_amd import train as T
+    from text2video_amd.options import TrainOptions
+    opt = TrainOptions().parse(["--name", "t", "--dataset_mode", "pose", "--input_nc", "3", "--openpose_only", "--ngf", "16",
+                                "--n_downsample_G", "2", "--n_blocks", "2", "--num_D", "2", "--ndf", "16", "--no_vgg",
+                                "--max_frames_per_gpu", "2", "--n_scales_temporal", "1", "--no_first_img", "--add_face_disc"])
+    H, W = 64, 128
+    rng = np.random.default_rng(21)
+    pose = torch.zeros(2, H, W, 12, device="cuda:0")
+    pose[..., :9] = torch.from_numpy(rng.uniform(-1, 1, (2, H, W, 9)).astype(np.float32)).cuda()
+    real = torch.zeros(2, H, W, 4, device="cuda:0")
+    real[..., :3] = torch.tanh(torch.from_numpy(rng.standard_normal((2, H, W, 3)).astype(np.float32))).cuda()
+    real_prev = torch.cat([real[1:], real[:1]], 0).contiguous()
+    boxes = [(8, 40, 40, 72)] * 2
+    runs = {}
+    for mode in ("1", "0"):
+        t2v_env("T2V_D_BATCHED", mode)
+        tr = T.Vid2VidTrainer(opt, "cuda:0", seed=17)
+        tr.optG.step = lambda: None      # keep the weights: the two steps' gradients are compared, not Adam's sign decisions
+        tr.optD.step = lambda: None
+        out = []
+        prev = None
+        for _ in range(2):
+            losses, prev = tr.train_step(pose, real, boxes, prev, real_prev=real_prev)
+            grads = [s.view.double().clone() for b in (tr.bucketsG, tr.bucketsD) for s in b.slots if s is not None and s.filled]
+            out.append((losses, grads))
+        nets = [tr.G, tr.D, tr.Df] + tr.DT
+        stats = [T.running_stats(p, create=False) for n in nets for k, p in n.named_upstream_parameters().items()
+                 if k.endswith(".weight") and p.dim() == 1]
+        runs[mode] = (out, [(s[0].clone(), s[1].clone(), s[2]) for s in stats if s is not None])
+    (a, sa), (b, sb) = runs["1"], runs["0"]
+    assert "D_T0" in a[1][0] and "D_f" in a[1][0] and "G_f_GAN_Feat" in a[1][0]
+    for (la, ga), (lb, gb) in zip(a, b):
+        assert list(la.keys()) == list(lb.keys()), (list(la), list(lb))
+        for k in la:
+            assert abs(la[k] - lb[k]) <= 2e-6 * max(1.0, abs(lb[k])), (k, la[k], lb[k])
+        assert len(ga) == len(gb) > 40
+        for i, (x, y) in enumerate(zip(ga, gb)):
+            d = (x - y).norm().item() / max(y.norm().item(), 1e-30)
+            assert d <= 5e-5, (i, tuple(x.shape), d)       # (seeds rounded once on the host instead of through a chain of fp32 products)
+    assert len(sa) == len(sb) > 4
+    for (m1, v1, n1), (m2, v2, n2) in zip(sa, sb):
         assert n1 == n2 and torch.equal(m1, m2) and torch.equal(v1, v2)
 
 
@@ -679,6 +731,7 @@ def test_weight_gradients_reduced_once_per_layer_equal_one_reduction_per_pass(mo
         batches.append(int(x.shape[0]) if x.dim() == 4 else 1)
         return real_bw(x, dy, desc, accumulate_into)
     res = {}
+    monkeypatch.setenv("T2V_D_BATCHED", "0")       # (the batched default has one node per discriminator layer to begin with)
     for mode in ("0", "1"):
         monkeypatch.setenv("T2V_WGRAD_PAIR", mode)
         tr = T.Vid2VidTrainer(TrainOptions().parse(argv), dev, seed=1)

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("T2V_LIBRARY") or os.path.join(_HERE, "lib", "libt2v_h
 T2V_OK = 0
 PAD_ZERO, PAD_REFLECT = 0, 1
 ACT_NONE, ACT_TANH, ACT_FLOW_W, ACT_LRELU = 0, 1, 2, 3
-ABI_VERSION = 16
+ABI_VERSION = 17
 MAX_BATCH = 8     # T2V_MAX_BATCH
 ALGO_DIRECT, ALGO_WINOGRAD, ALGO_WINOGRAD_F4, ALGO_POLYPHASE = 0, 1, 2, 3
 
@@ -129,6 +129,8 @@ SIGNATURES = {
                                         c_void_p, c_void_p]),
     "t2v_sum_abs_diff_masked_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_long, c_int,
                                                  c_int, c_int, c_void_p]),
+    "t2v_loss_terms": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                               c_int, c_void_p, c_void_p]),
     "t2v_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_double, c_double,
                               c_double, c_double, c_int]),
     "t2v_adam_step_multi": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,

@@ -1285,6 +1285,17 @@ int t2v_sum_abs_diff_masked_backward(t2v_ctx* ctx, void* stream, const float* a,
                 "sum_abs_diff_masked_backward: bad arguments");
     return launch_masked_l1_backward((hipStream_t)stream, a, b, mask, scale, npix, c0, C, cs, da);
 }
+int t2v_loss_terms(t2v_ctx* ctx, void* stream, const int64_t* term_ptrs, const int32_t* term_ints, const float* term_floats,
+                   const int32_t* chunk_term, const int64_t* chunk_off, const int32_t* term_chunk0, int nterms, int nchunks,
+                   int chunk, float* partials, float* out) {
+    T2V_REQUIRE(ctx && term_ptrs && term_ints && term_floats && chunk_term && chunk_off && term_chunk0 && partials && out,
+                "loss_terms: null pointer");
+    T2V_REQUIRE(nterms > 0 && nchunks > 0 && chunk > 0 && chunk % 4 == 0, "loss_terms: nterms %d nchunks %d chunk %d", nterms,
+                nchunks, chunk);
+    return launch_loss_terms((hipStream_t)stream, reinterpret_cast<const long long*>(term_ptrs), term_ints, term_floats,
+                             chunk_term, reinterpret_cast<const long long*>(chunk_off), term_chunk0, nterms, nchunks, chunk,
+                             partials, out);
+}
 int t2v_adam_step(t2v_ctx* ctx, void* stream, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
                   long n, double lr, double beta1, double beta2, double eps, int step) {
     T2V_REQUIRE(ctx && param && grad && exp_avg && exp_avg_sq && n > 0 && step >= 1, "adam_step: bad arguments");

@@ -379,6 +379,87 @@ int launch_reduce(hipStream_t s, int op, const float* a, const float* b, float c
     return T2V_OK;
 }
 
+// ---- all scalar loss terms of a train step in ONE launch (+ one per-term final pass) ------------------------------------------
+// The step has ~65 such terms (LSGAN MSE on the logits of every discriminator scale and pass, feature-matching L1 on every
+// intermediate feature map): run one by one they were ~65 x (partial + final reduction) forward, ~65 gradient kernels
+// backward and ~140 one-element ATen multiplies / adds / divides around them -- 1-2 ms of 3-5 us launches in a 90 ms step.
+// Here a term is a row of three small device tables; block b works on `chunk` consecutive elements of term chunk_term[b]
+// and, in the same pass over the operands, writes the term's gradient seed (its weight is a host number, so the gradient
+// needs no upstream scalar):
+//   op 0  MSE against a constant on channel 0 of an [n][cs] logit tensor: sum (x - c)^2, seed = 2 s (x - c) | 0 in the pad channels
+//   op 1  L1: sum |a - b|, seed = s sign(a - b)
+//   op 2  no value: the seed rows are exact zeros (passes a loss does not reach)
+// The final kernel sums a term's partials in chunk order (deterministic, no atomics) and applies the term's value scale.
+__global__ __launch_bounds__(256) void loss_terms_kernel(const long long* __restrict__ tp, const int* __restrict__ ti,
+                                                         const float* __restrict__ tf, const int* __restrict__ chunk_term,
+                                                         const long long* __restrict__ chunk_off, int chunk,
+                                                         float* __restrict__ part) {
+    __shared__ float sh[4];
+    const int t = chunk_term[blockIdx.x];
+    const long long off = chunk_off[blockIdx.x];
+    const float* __restrict__ a = reinterpret_cast<const float*>(tp[4 * t]);
+    const float* __restrict__ b = reinterpret_cast<const float*>(tp[4 * t + 1]);
+    float* __restrict__ seed = reinterpret_cast<float*>(tp[4 * t + 2]);
+    const long long end = min(tp[4 * t + 3], off + (long long)chunk);
+    const int op = ti[2 * t], cs = ti[2 * t + 1];
+    const float c = tf[3 * t], ss = tf[3 * t + 1];
+    float s = 0.f;
+    if (op == 0) {
+        for (long long i = off + threadIdx.x; i < end; i += blockDim.x) {
+            const float d = a[i * cs] - c;
+            s += d * d;
+            if (seed) {
+                seed[i * cs] = 2.f * ss * d;
+                for (int k = 1; k < cs; ++k) seed[i * cs + k] = 0.f;
+            }
+        }
+    } else if (op == 1) {
+        // 16-byte lanes over the aligned body (chunk offsets are multiples of 4; torch allocations are 256-byte aligned and
+        // the slices taken of them start at whole images), scalars for a ragged tail
+        long long body = off;
+        if ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)seed) & 15) == 0) {
+            const long long n4 = (end - off) >> 2;
+            const float4* a4 = reinterpret_cast<const float4*>(a + off);
+            const float4* b4 = reinterpret_cast<const float4*>(b + off);
+            float4* s4 = seed ? reinterpret_cast<float4*>(seed + off) : nullptr;
+            auto sg = [&](float d) { return d > 0.f ? ss : (d < 0.f ? -ss : 0.f); };
+            for (long long i = threadIdx.x; i < n4; i += blockDim.x) {
+                const float4 av = a4[i], bv = b4[i];
+                const float d0 = av.x - bv.x, d1 = av.y - bv.y, d2 = av.z - bv.z, d3 = av.w - bv.w;
+                s += (fabsf(d0) + fabsf(d1)) + (fabsf(d2) + fabsf(d3));
+                if (s4) s4[i] = make_float4(sg(d0), sg(d1), sg(d2), sg(d3));
+            }
+            body = off + (n4 << 2);
+        }
+        for (long long i = body + threadIdx.x; i < end; i += blockDim.x) {
+            const float d = a[i] - b[i];
+            s += fabsf(d);
+            if (seed) seed[i] = d > 0.f ? ss : (d < 0.f ? -ss : 0.f);
+        }
+    } else if (seed) {
+        for (long long i = off + threadIdx.x; i < end; i += blockDim.x) seed[i] = 0.f;
+    }
+    const float tot = block_sum(s, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = tot;
+}
+__global__ __launch_bounds__(256) void loss_terms_final_kernel(const float* __restrict__ part, const int* __restrict__ term_chunk0,
+                                                               const float* __restrict__ tf, float* __restrict__ out) {
+    __shared__ float sh[4];
+    const int t = blockIdx.x;
+    float s = 0.f;
+    for (int i = term_chunk0[t] + threadIdx.x; i < term_chunk0[t + 1]; i += blockDim.x) s += part[i];
+    const float tot = block_sum(s, sh);
+    if (threadIdx.x == 0) out[t] = tot * tf[3 * t + 2];
+}
+int launch_loss_terms(hipStream_t s, const long long* tp, const int* ti, const float* tf, const int* chunk_term,
+                      const long long* chunk_off, const int* term_chunk0, int nterms, int nchunks, int chunk, float* part,
+                      float* out) {
+    hipLaunchKernelGGL(loss_terms_kernel, dim3(nchunks), dim3(256), 0, s, tp, ti, tf, chunk_term, chunk_off, chunk, part);
+    hipLaunchKernelGGL(loss_terms_final_kernel, dim3(nterms), dim3(256), 0, s, part, term_chunk0, tf, out);
+    T2V_HIP_CHECK(hipGetLastError());
+    return T2V_OK;
+}
+
 // torch.optim.Adam.step ($SP/torch/optim/adam.py:86-98), same operation order
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, long n, float b1, float b2, float omb1, float omb2, float eps,

@@ -320,6 +320,9 @@ void convT_phase_taps_host(int phase, int k, int pad, int* ntaps, int kh[4], int
 int launch_nchw_to_nhwc(hipStream_t s, const float* src, float* dst, int C, int H, int W, int Cs);
 int launch_nhwc_to_nchw(hipStream_t s, const float* src, float* dst, int C, int H, int W, int Cs);
 int launch_reduce(hipStream_t s, int op, const float* a, const float* b, float c, long n, float* scratch, float* out);
+int launch_loss_terms(hipStream_t s, const long long* tp, const int* ti, const float* tf, const int* chunk_term,
+                      const long long* chunk_off, const int* term_chunk0, int nterms, int nchunks, int chunk, float* part,
+                      float* out);
 int launch_adam(hipStream_t s, float* p, const float* g, float* m, float* v, long n, double lr, double b1, double b2,
                 double eps, int step);
 int launch_adam_multi(hipStream_t s, const long long* ptrs, const long long* nelem, const float* step_size,

@@ -238,6 +238,29 @@ def plan_units(seq_lengths, world, n_frames_G=3, shard_chunks=False, how_many=No
     return plan
 
 
+def pack_state(levels):
+    """The FIFO state of a generator with a spatial pyramid (n_scales_spatial > 1: one [h,w,cs] FIFO per level, finest
+    first) as ONE flat fp32 tensor, so that the tail exchange moves it like a single-level tail: a header
+    (number of levels, then h, w, cs per level -- exact as floats) followed by the levels' values."""
+    head = [float(len(levels))] + [float(v) for t in levels for v in t.shape]
+    assert all(t.dim() == 3 for t in levels)
+    return torch.cat([torch.tensor(head, dtype=torch.float32, device=levels[0].device)]
+                     + [t.reshape(-1).to(torch.float32) for t in levels])
+
+
+def unpack_state(flat):
+    """inverse of pack_state: the list of per-level FIFOs (clones: the caller owns them)"""
+    n = int(flat[0].item())
+    dims = [int(v) for v in flat[1:1 + 3 * n].tolist()]
+    out, o = [], 1 + 3 * n
+    for i in range(n):
+        h, w, c = dims[3 * i:3 * i + 3]
+        out.append(flat[o:o + h * w * c].reshape(h, w, c).clone())
+        o += h * w * c
+    assert o == flat.numel(), "unpack_state: %d values for a header that describes %d" % (flat.numel(), o)
+    return out
+
+
 def exchange_tails(plan, rank, my_tails):
     """The stitch pass's collective.  my_tails: one tensor per unit of plan[rank] (the FIFO of generated frames the
     unit ended with; one shape everywhere).  All-gathers them (RCCL over xGMI / gloo) and returns

@@ -227,7 +227,11 @@ def run_test(opt, model=None, device=None, dataset=None):
 
         def close_unit(L):
             if L.unit is not None and L.rec.prev is not None:
-                tails[L.unit] = L.rec.prev[0].clone()
+                if len(L.rec.prev) == 1:
+                    tails[L.unit] = L.rec.prev[0].clone()
+                else:       # a spatial pyramid (n_scales_spatial > 1): every level's FIFO travels, packed into one tensor
+                    from . import distributed as D
+                    tails[L.unit] = D.pack_state(L.rec.prev)
 
         steps = iter(steps)
         while True:
@@ -250,7 +254,12 @@ def run_test(opt, model=None, device=None, dataset=None):
                     close_unit(L)
                     L.rec.reset()
                     if start_state is not None:      # stitch pass: continue from the predecessor chunk's last frames
-                        L.rec.prev = [start_state[data["unit"]].clone()]
+                        st0 = start_state[data["unit"]]
+                        if st0.dim() == 1:           # (packed pyramid levels: distributed.pack_state)
+                            from . import distributed as D
+                            L.rec.prev = D.unpack_state(st0)
+                        else:
+                            L.rec.prev = [st0.clone()]
                     L.window = torch.zeros(H, W, cs, dtype=torch.float32, device=dev)
                     L.dev_maps = [torch.from_numpy(A[f]).to(dev) for f in range(opt.n_frames_G)]
                 else:
@@ -310,8 +319,6 @@ def run_test(opt, model=None, device=None, dataset=None):
         # all-gather the chunk tails (2 generated frames per chunk) and re-generate the first `stitch` frames of every
         # continuation chunk from its predecessor's; the JPEGs of those frames are overwritten
         from . import distributed as D
-        if model.n_scales != 1:
-            raise NotImplementedError("--stitch_frames with n_scales_spatial > 1")
         vis.flush()
         units = plan[rank]
         for _ in range(max(1, int(getattr(opt, "stitch_rounds", 1) or 1))):

@@ -442,6 +442,14 @@ def sum_abs_diff_masked_backward(a, b, mask, c0, C, scale):
     return da
 
 
+def loss_terms(term_ptrs, term_ints, term_floats, chunk_term, chunk_off, term_chunk0, nterms, nchunks, chunk, partials, out):
+    """all scalar loss terms of a step (values and gradient seeds) in one launch: t2v_loss_terms (include/t2v.h)"""
+    c = context()
+    check(c.lib.t2v_loss_terms(c.handle, _stream(), _p(term_ptrs), _p(term_ints), _p(term_floats), _p(chunk_term), _p(chunk_off),
+                               _p(term_chunk0), int(nterms), int(nchunks), int(chunk), _p(partials), _p(out)), "loss_terms")
+    return out
+
+
 def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step):
     """In-place fused Adam update of one flat fp32 tensor (torch.optim.Adam.step semantics)."""
     c = context()

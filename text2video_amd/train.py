@@ -90,12 +90,26 @@ def prefetch_packs(params):
 # collective, and a bucket's all-reduce starts the moment its last gradient has landed.
 # ------------------------------------------------------------------------------------------------
 class GradSlot:
-    __slots__ = ("owner", "bucket", "idx", "view", "expect", "got", "filled")
+    __slots__ = ("owner", "bucket", "idx", "view", "expect", "got", "_filled", "zero_valid")
 
     def __init__(self, owner, bucket, idx, view):
         self.owner, self.bucket, self.idx, self.view = owner, bucket, idx, view
         self.expect = self.got = 0
-        self.filled = False       # the slot holds this step's (partial) gradient
+        self._filled = False      # the slot holds this step's (partial) gradient
+        # the slot's memory holds exact zeros put there by deliver(zero=True) and nothing has written it since: the ~100
+        # biases in front of norm layers get that delivery every step -- one 4 KB memset each, once, instead of per step
+        # (an exchange averages zeros with the other ranks' zeros: the same layers are zero-delivered on every rank)
+        self.zero_valid = False
+
+    @property
+    def filled(self):
+        return self._filled
+
+    @filled.setter
+    def filled(self, v):
+        self._filled = bool(v)
+        if v:                     # every writer of the slot's memory marks it filled: the zeros are gone
+            self.zero_valid = False
 
 
 def grad_slot(p):
@@ -117,8 +131,9 @@ def deliver(sl, tensor=None, zero=False):
         _acc(sl.view, tensor, not sl.filled)
         sl.filled = True
     elif zero and not sl.filled:
-        _zero(sl.view)
-        sl.filled = True
+        if not sl.zero_valid:
+            _zero(sl.view)
+        sl._filled, sl.zero_valid = True, True
     sl.owner.node_done(sl)
 
 
@@ -474,7 +489,7 @@ def running_stats(gamma, create=True):
     return rs
 
 
-def running_update_args(gamma, n):
+def running_update_args(gamma, n, times=None):
     """Every training-mode forward of a BatchNorm2d also moves its running statistics
     ($SP/torch/nn/modules/batchnorm.py:57-64, momentum 0.1, unbiased variance) -- never read on this path (upstream keeps
     the generator in train mode at test time) but part of a faithful checkpoint.  Returns (running_mean,
@@ -482,9 +497,10 @@ def running_update_args(gamma, n):
     fewer than two values per channel); counts the updates on the statistics' step counter."""
     if gamma is None or n < 2:
         return None
+    times = _BN_UPDATES[0] if times is None else int(times)
     rs = running_stats(gamma)
-    rs[2] += _BN_UPDATES[0]
-    return (rs[0], rs[1], BN_MOMENTUM, _BN_UPDATES[0])
+    rs[2] += times
+    return (rs[0], rs[1], BN_MOMENTUM, times)
 
 
 _ZEROS = {}
@@ -510,8 +526,14 @@ class _ConvBlock(torch.autograd.Function):
     activation `act` (ACT_NONE / ACT_TANH / ACT_LRELU) is fused into the conv epilogue."""
 
     @staticmethod
-    def forward(ctx, x, w, b, gamma, beta, res, desc, norm, relu, act, need_dx, slope=0.2):
+    def forward(ctx, x, w, b, gamma, beta, res, desc, norm, relu, act, need_dx, slope=0.2, groups=1, bn_times=None, pt_skip=0):
+        # groups > 1 (norm 'batch'): the batch is `groups` independent passes of B / groups images each -- the discriminators'
+        # real / fake / raw passes in ONE node: one conv launch, one data-gradient launch, one weight-gradient launch over
+        # all of them; the BatchNorm statistics (and their running averages, moved bn_times[g] times) stay per pass.
+        # pt_skip: leading images nobody differentiates in a pass-through backward (param_gradients_off: the generator's
+        # loss reaches the fake / raw passes only) -- that backward runs on the images [pt_skip:] alone.
         B = x.shape[0]
+        assert B % groups == 0, "conv_block: batch %d is not %d equal passes" % (B, groups)
         dev = x.device
         xcs = x.shape[-1]
         ho, wo = ops.conv_out_dims(desc)
@@ -561,7 +583,15 @@ class _ConvBlock(torch.autograd.Function):
             # the residual add rides in the norm-apply pass (its gradient is the identity)
             rs = res.detach().contiguous() if (res is not None and res.shape == y.shape) else None
             # (the finalize launch also moves BatchNorm2d's running statistics: running_update_args)
-            if norm == "batch":
+            if norm == "batch" and groups > 1:
+                gB, mrs = B // groups, []
+                for gi in range(groups):
+                    sl = slice(gi * gB, (gi + 1) * gB)
+                    mrs.append(ops.batch_norm_finalize(stats[gi * gB * n:(gi + 1) * gB * n], fdesc, gB,
+                                                       running=running_update_args(gamma, gB * ho * wo,
+                                                                                   bn_times[gi] if bn_times else None)))
+                    ops.instance_norm_apply(c[sl], mrs[gi], g, bt, res1=rs[sl] if rs is not None else None, relu=relu, out=y[sl])
+            elif norm == "batch":
                 mrs = [ops.batch_norm_finalize(stats, fdesc, B, running=running_update_args(gamma, B * ho * wo))]
                 ops.instance_norm_apply(c, mrs[0], g, bt, res1=rs, relu=relu, out=y)
             else:
@@ -588,6 +618,7 @@ class _ConvBlock(torch.autograd.Function):
         # (an input nobody differentiates -- the discriminators' real pass -- needs no data-gradient conv)
         need_dx = int(need_dx) if (need_dx and ctx.needs_input_grad[0]) else 0      # 2: an input layer (input_gradients_off)
         ctx.meta = (desc, ddesc, norm, relu, act, need_dx, mrs, gamma is not None, wino_wgrad, slope)
+        ctx.groups, ctx.pt_skip = groups, int(pt_skip)
         ctx.kept = kept
         ctx.save_for_backward(x, w, c, gamma, beta, y if (norm is None and act != ops.ACT_NONE) else None, b)
         return y
@@ -597,14 +628,24 @@ class _ConvBlock(torch.autograd.Function):
         desc, fdesc, norm, relu, act, need_dx, mrs, affine, wino_wgrad, slope = ctx.meta
         x, w, c, gamma, beta, y_act, b = ctx.saved_tensors
         dy = dy.contiguous()
-        B = x.shape[0]
         dgamma = dbeta = None
         # a backward pass that only passes THROUGH this layer (param_gradients_off): data gradient only
         want = [bool(v) for v in ctx.needs_input_grad]
         if need_dx == 2 and _NO_INPUT_DX[0]:
             need_dx = 0
+        groups, g0, img0, x_full = ctx.groups, 0, 0, x
+        gB = x.shape[0] // groups
         if _NO_PARAM_GRAD and id(getattr(w, "_t2v_owner", w)) in _NO_PARAM_GRAD:
             want[1] = want[2] = want[3] = want[4] = False
+            if ctx.pt_skip:
+                # ... and only through the passes the loss reaches: the leading `pt_skip` images (the real pass) carry no
+                # gradient in this backward -- their rows of dy are never read, their rows of dx are exact zeros
+                img0 = ctx.pt_skip
+                assert not wino_wgrad and 0 < img0 < x.shape[0] and (groups == 1 or img0 % gB == 0)
+                g0 = img0 // gB if groups > 1 else 0
+                x, c, dy = x[img0:], c[img0:], dy[img0:]
+                y_act = y_act[img0:] if y_act is not None else None
+        B = x.shape[0]
         # parameters with a bucket slot get their gradients delivered in place (and None goes back to autograd)
         sl_w = grad_slot(w) if want[1] else None
         sl_b = grad_slot(b) if want[2] else None
@@ -644,6 +685,13 @@ class _ConvBlock(torch.autograd.Function):
         elif norm is None:
             # (act_backward's mode 2 is a plain sigmoid; the fused flow / weight head is its mode 4)
             dc = ops.act_backward(dy, y_act, 4 if act == ops.ACT_FLOW_W else act, slope) if act != ops.ACT_NONE else dy
+        elif norm == "batch" and groups > 1:
+            dc = torch.empty_like(c)
+            for gi in range(g0, groups):       # statistics per pass: the norm's adjoint per pass
+                sl = slice((gi - g0) * gB, (gi - g0 + 1) * gB)
+                _, s_i = ops.instance_norm_backward(c[sl], dy[sl], mrs[gi], gamma, beta, relu, out=dc[sl], affine_into=into_slots())
+                if affine and (want[3] or want[4]):
+                    affine_sums(s_i)
         elif norm == "batch":
             dc, sums = ops.instance_norm_backward(c, dy, mrs[0], gamma, beta, relu, affine_into=into_slots())
             if affine and (want[3] or want[4]):
@@ -651,7 +699,7 @@ class _ConvBlock(torch.autograd.Function):
         else:
             dc = torch.empty_like(c)
             for i in range(B):
-                _, s_i = ops.instance_norm_backward(c[i], dy[i], mrs[i], gamma, beta, relu, out=dc[i], affine_into=into_slots())
+                _, s_i = ops.instance_norm_backward(c[i], dy[i], mrs[img0 + i], gamma, beta, relu, out=dc[i], affine_into=into_slots())
                 if affine and (want[3] or want[4]):
                     affine_sums(s_i)
         if both:
@@ -728,12 +776,16 @@ class _ConvBlock(torch.autograd.Function):
             dg = ConvDataGrad(fdesc)
             dg.packed = cached_pack(w, ("dgrad",) + _desc_key(fdesc, x.shape[-1]), lambda: dg.refresh(w.detach()).packed)
             if ops.round_up(fdesc.Cin, 4) == x.shape[-1]:
-                dx = torch.empty_like(x)
-                dg.batch(dc, dx)
+                dx = torch.empty_like(x_full)
+                if img0:
+                    ops.zero_(dx[:img0])
+                dg.batch(dc, dx[img0:])
             else:   # x carries more channel storage than the layer reads: zero gradient there
-                dx = torch.zeros_like(x)
-                dx[..., :ops.round_up(fdesc.Cin, 4)] = torch.stack([dg(dc[i]) for i in range(B)])
-        return dx, dw, db, dgamma, dbeta, (dy if ctx.needs_input_grad[5] else None), None, None, None, None, None, None
+                dx = torch.zeros_like(x_full)
+                dx[img0:, ..., :ops.round_up(fdesc.Cin, 4)] = torch.stack([dg(dc[i]) for i in range(B)])
+        elif img0:
+            raise RuntimeError("conv_block: pt_skip is for layers with a data gradient")
+        return (dx, dw, db, dgamma, dbeta, (dy if ctx.needs_input_grad[5] else None)) + (None,) * 9
 
 
 class _CatParams(torch.autograd.Function):
@@ -765,9 +817,10 @@ class _CatParams(torch.autograd.Function):
 
 
 def conv_block(x, w, b, desc, gamma=None, beta=None, res=None, norm="instance", relu=1, act=ops.ACT_NONE,
-               need_dx=True, slope=0.2):
-    """slope: negative-side factor of act == ACT_LRELU (0.2 in the discriminators; 0 makes it a ReLU)."""
-    return _ConvBlock.apply(x, w, b, gamma, beta, res, desc, norm, relu, act, need_dx, slope)
+               need_dx=True, slope=0.2, groups=1, bn_times=None, pt_skip=0):
+    """slope: negative-side factor of act == ACT_LRELU (0.2 in the discriminators; 0 makes it a ReLU).
+    groups / bn_times / pt_skip: several independent passes in one batch (_ConvBlock.forward)."""
+    return _ConvBlock.apply(x, w, b, gamma, beta, res, desc, norm, relu, act, need_dx, slope, groups, bn_times, pt_skip)
 
 
 class _AvgPool(torch.autograd.Function):
@@ -1004,7 +1057,7 @@ class TrainableDiscriminator(torch.nn.Module):
     def named_upstream_parameters(self):
         return {k.replace("/", "."): v for k, v in self.params.items()}
 
-    def _single(self, x, i):
+    def _single(self, x, i, groups=1, bn_times=None, pt_skip=0):
         ndf = self.ndfs[i]
         chans = [(self.input_nc, ndf, 2, False)]
         nf = ndf
@@ -1021,22 +1074,27 @@ class TrainableDiscriminator(torch.nn.Module):
             if has_norm:
                 g = self.p(pre + ".1.weight") if self.norm == "batch" else None
                 b = self.p(pre + ".1.bias") if self.norm == "batch" else None
-                cur = conv_block(cur, self.p(pre + ".0.weight"), self.p(pre + ".0.bias"), desc, g, b, None, self.norm, 2)
+                cur = conv_block(cur, self.p(pre + ".0.weight"), self.p(pre + ".0.bias"), desc, g, b, None, self.norm, 2,
+                                 groups=groups, bn_times=bn_times, pt_skip=pt_skip)
             else:
                 cur = conv_block(cur, self.p(pre + ".0.weight"), self.p(pre + ".0.bias"), desc, norm=None, relu=0,
-                                 act=ops.ACT_NONE if last else ops.ACT_LRELU, need_dx=2 if j == 0 else True)
+                                 act=ops.ACT_NONE if last else ops.ACT_LRELU, need_dx=2 if j == 0 else True,
+                                 groups=groups, pt_skip=pt_skip)
             feats.append(cur)
         return feats
 
-    def forward(self, x, frozen=False):
+    def forward(self, x, frozen=False, groups=1, bn_times=None, pt_skip=0):
         """x [B,H,W,cs] -> result[i] = stage outputs of the i-th finest scale.  frozen=True: the parameters enter
         detached (the generator-side passes: only the data gradient is wanted, so the backward nodes skip the
-        weight-gradient kernels; the packed-weight cache is keyed on the parameter either way)."""
+        weight-gradient kernels; the packed-weight cache is keyed on the parameter either way).
+        groups > 1: x holds that many independent passes of B / groups images (real | fake | raw): every layer is ONE
+        launch over all of them, the BatchNorm statistics stay per pass and move their running averages bn_times[g]
+        times; pt_skip: leading images a pass-through backward (the generator's loss) skips (_ConvBlock)."""
         self._frozen = frozen
         try:
             result = []
             for i in range(self.num_D):
-                result.append(self._single(x, self.num_D - 1 - i))
+                result.append(self._single(x, self.num_D - 1 - i, groups, bn_times, pt_skip))
                 if i != self.num_D - 1:
                     x = _AvgPool.apply(x)
             return result
@@ -1139,6 +1197,123 @@ def feature_matching_loss(pred_fake, pred_real, n_layers=3, lambda_feat=10.0):
             f, r = pred_fake[i][j], pred_real[i][j].detach()
             total = total + _L1.apply(f, r, f.numel()) * ((1.0 / num_D) * (4.0 / (n_layers + 1)) * lambda_feat)
     return total
+
+
+class LossBook:
+    """The scalar loss terms of one train step, evaluated together (ops.loss_terms: one launch for the values AND the
+    gradient seeds of all terms, one per-term final pass).
+
+    Every term's weight is a host number -- lambda_feat, the 1/2 of the discriminator loss, face_weight, 1 / n of the
+    mean -- so the gradient of the total with respect to a term's operand is known without any device scalar: the term
+    kernel writes it (the `seed`) in the same pass that reduces the value, and the backward passes start from those seeds
+    (torch.autograd.grad(outputs=<operands>, grad_outputs=<seeds>)) instead of from a scalar graph of one-element
+    multiplies and adds.  Values come back in one vector: `read()` sums them by name on the host."""
+
+    CHUNK = 1 << 14
+
+    def __init__(self, device):
+        self.dev = torch.device(device)
+        self.terms = []
+        self.out = None
+        self._host = self._devb = self._part = None
+        self._pending = None
+
+    def reset(self):
+        self.terms, self.out = [], None
+
+    def mse(self, name, x, target, weight, seed=None):
+        """weight * mean((x[..., 0] - target)^2): x a contiguous [.., cs] block of logit rows (LSGAN; THCUNN.h:356); seed (same
+        block of a gradient tensor) receives weight * 2 (x - target) / n in channel 0 and zeros in the pad channels"""
+        cs = x.shape[-1]
+        n = x.numel() // cs
+        assert x.is_contiguous() and (seed is None or (seed.is_contiguous() and seed.shape == x.shape))
+        self.terms.append((name, 0, x, None, seed, n, cs, float(target), weight / n, weight / n))
+
+    def l1(self, name, a, b, weight, seed=None):
+        """weight * mean(|a - b|) (feature matching; THCUNN.h:18), gradient with respect to `a` only"""
+        n = a.numel()
+        assert a.is_contiguous() and b.is_contiguous() and a.shape == b.shape
+        assert seed is None or (seed.is_contiguous() and seed.shape == a.shape)
+        self.terms.append((name, 1, a, b, seed, n, 1, 0.0, weight / n, weight / n))
+
+    def zero(self, seed):
+        """rows of a gradient tensor no loss term reaches in that backward pass: exact zeros"""
+        assert seed.is_contiguous()
+        self.terms.append((None, 2, seed, None, seed, seed.numel(), 1, 0.0, 0.0, 0.0))
+
+    def run(self):
+        """enqueue the launch for the terms collected so far"""
+        import numpy as np
+        T = len(self.terms)
+        if T == 0:
+            return
+        ch = self.CHUNK
+        counts = [max(1, -(-t[5] // ch)) for t in self.terms]
+        NC = sum(counts)
+        # one staging buffer, 8-byte aligned segments: term_ptrs | chunk_off | term_ints | chunk_term | term_chunk0 | term_floats
+        segs, o = {}, 0
+        for key, nbytes in (("tp", 32 * T), ("co", 8 * NC), ("ti", 8 * T), ("ct", 4 * NC), ("t0", 4 * (T + 1)), ("tf", 12 * T)):
+            segs[key] = (o, nbytes)
+            o += -(-nbytes // 8) * 8
+        if self._host is None or self._host.numel() < o:
+            cap = max(o, 1 << 16)
+            self._host = torch.empty(cap, dtype=torch.uint8).pin_memory()
+            self._devb = torch.empty(cap, dtype=torch.uint8, device=self.dev)
+        if self._part is None or self._part.numel() < NC + T:
+            self._part = torch.empty(max(NC + T, 1 << 14), dtype=torch.float32, device=self.dev)
+        if self._pending is not None:
+            self._pending.synchronize()      # the previous launch's table copy has left the pinned staging buffer
+        hv = self._host.numpy()
+
+        def view(key, dt):
+            a, nb = segs[key]
+            return hv[a:a + nb].view(dt)
+        tp, co, ti, ct, t0, tf = view("tp", np.int64), view("co", np.int64), view("ti", np.int32), view("ct", np.int32), \
+            view("t0", np.int32), view("tf", np.float32)
+        c0 = 0
+        for t, (name, op, a, b, seed, n, cs, c, ss, vs) in enumerate(self.terms):
+            tp[4 * t:4 * t + 4] = (a.data_ptr(), b.data_ptr() if b is not None else 0, seed.data_ptr() if seed is not None else 0, n)
+            ti[2 * t:2 * t + 2] = (op, cs)
+            tf[3 * t:3 * t + 3] = (c, ss, vs)
+            t0[t] = c0
+            k = counts[t]
+            ct[c0:c0 + k] = t
+            co[c0:c0 + k] = np.arange(k, dtype=np.int64) * ch
+            c0 += k
+        t0[T] = c0
+        self._devb[:o].copy_(self._host[:o], non_blocking=True)
+
+        def dev(key):
+            a, nb = segs[key]
+            return self._devb[a:a + nb]
+        self.out = self._part[NC:NC + T]
+        ops.loss_terms(dev("tp"), dev("ti"), dev("tf"), dev("ct"), dev("co"), dev("t0"), T, NC, ch, self._part, self.out)
+        self._pending = torch.cuda.current_stream().record_event()
+        # the launch is enqueued: let go of the operands (views into the step's autograd graph -- held here they would keep
+        # the whole graph alive into the next step's forward pass); the names stay for read()
+        self.terms = [(t[0],) for t in self.terms]
+
+    def value_tensors(self):
+        """{name: [indices into self.out]} of the named terms"""
+        idx = {}
+        for t, term in enumerate(self.terms):
+            if term[0] is not None:
+                idx.setdefault(term[0], []).append(t)
+        return idx
+
+    def read(self, extra=None):
+        """one host read for the step: {name: value} of the named terms (+ the one-element device tensors in `extra`)"""
+        names = self.value_tensors()
+        keys = list((extra or {}).keys())
+        parts = ([self.out] if self.out is not None else []) + [extra[k].detach().reshape(1).float() for k in keys]
+        if not parts:
+            return {}
+        host = torch.cat(parts).tolist()
+        T = len(self.terms) if self.out is not None else 0
+        res = {k: sum(host[i] for i in ix) for k, ix in names.items()}
+        for j, k in enumerate(keys):
+            res[k] = host[T + j]
+        return res
 
 
 # ------------------------------------------------------------------------------------------------
@@ -1350,7 +1525,7 @@ class GradBuckets:
     def _launch(self, b):
         # parameters no backward node reached contribute exact zeros (and get no optimiser step: see finish)
         for i in self.members[b]:
-            if not self.slots[i].filled:
+            if not self.slots[i].filled and not self.slots[i].zero_valid:
                 _zero(self.slots[i].view)
         if not self.exchange:
             return
@@ -1591,6 +1766,181 @@ class Vid2VidTrainer:
         z = torch.zeros(A3.shape[:-1] + (2,), dtype=torch.float32, device=A3.device)
         return torch.cat([A3, img4[..., :3], z], -1).contiguous()
 
+    def _vgg_term(self, fake, raw, real):
+        """lambda_feat * VGGLoss(fake, real) (+ the same on the raw frame with a flow branch) [RECALL upstream: criterionVGG],
+        or None without a VGG19"""
+        if self.vgg is None:
+            return None
+        with torch.no_grad():
+            real_taps = self.vgg(real)
+        loss = vgg_loss(self.vgg, fake, real, real_taps) * self.opt.lambda_feat
+        if raw is not None:
+            loss = loss + vgg_loss(self.vgg, raw, real, real_taps) * self.opt.lambda_feat
+        return loss
+
+    def _flow_terms(self, fake, fw_all, real, real_prev, prevs, flow_ref, conf_ref, first):
+        """-> (sum of the flow / warp / weight losses, {name: term})"""
+        opt, dev = self.opt, fake.device
+        F_, H, W = fake.shape[0], fake.shape[1], fake.shape[2]
+        # flow / warp / weight losses [RECALL upstream Vid2VidModelD.forward, compute_flow_losses]:
+        #   F_Flow = MaskedL1(flow, flow_ref, conf) * lambda_F      F_Warp = MaskedL1(resample(real_B_prev, flow), real_B, conf) * lambda_T
+        #   W      = MaskedL1(weight, 0, conf)  (--no_first_img)    G_Warp = MaskedL1(fake_B, resample(fake_B_prev, flow_ref), conf) * lambda_T
+        # flow_ref / conf_ref come from FlowNet2 upstream; here they are inputs (zero flow by default)
+        with torch.no_grad():
+            if flow_ref is None:
+                if not getattr(self, "_warned_zero_flow", False):
+                    self._warned_zero_flow = True
+                    print("warning: flow / warp / weight losses run against a synthetic ZERO reference flow (FlowNet2 is not "
+                          "in the reference tree; pass flow_ref / conf_ref, or --no_flow to train without the flow branch)",
+                          flush=True)
+                flow_ref = torch.zeros(F_, H, W, 4, dtype=torch.float32, device=dev)
+                real_prev_warp = real_prev
+            else:
+                real_prev_warp = torch.stack([ops.flow_warp(flow_ref[i], real_prev[i], 0) for i in range(F_)])
+            if conf_ref is None:
+                conf_ref = ((real[..., :3] - real_prev_warp[..., :3]).norm(dim=-1) < 0.02).float()
+            fake_prev = torch.cat(prevs, 0)
+            fake_prev_warp = torch.stack([ops.flow_warp(flow_ref[i], fake_prev[i], self.spec.prev_nc - 3)
+                                          for i in range(F_)])
+            if first:
+                # no generated previous frame exists for a sequence's first frame: upstream warps the REAL previous
+                # frame there (fake_B_prev = real_B_prev[:, 0:1] when there is no previous chunk [RECALL
+                # compute_fake_B_prev]); the all-zero FIFO stays the generator's INPUT only
+                fake_prev_warp[0] = real_prev_warp[0]
+        loss_F_flow = masked_l1(fw_all, flow_ref, conf_ref, 2, 0) * opt.lambda_F
+        loss_F_warp = masked_l1(_Resample.apply(fw_all, real_prev.contiguous(), 0), real, conf_ref, 3) * opt.lambda_T
+        # the weight-map loss exists only under --no_first_img upstream (zero otherwise) [RECALL]
+        loss_W = masked_l1(fw_all, None, conf_ref, 1, 2) if getattr(opt, "no_first_img", False) else 0.0
+        loss_G_warp = masked_l1(fake, fake_prev_warp, conf_ref, 3) * opt.lambda_T
+        return (loss_F_flow + loss_F_warp + loss_W + loss_G_warp,
+                {"F_Flow": loss_F_flow, "F_Warp": loss_F_warp, "W": loss_W, "G_Warp": loss_G_warp})
+
+    def _d_pass(self, net, inputs, book, names, face_weight=1.0):
+        """One discriminator on its real input and its one or two generated inputs (fake, raw) as ONE batch of passes
+        (TrainableDiscriminator.forward(groups=...)): every layer is one conv launch, one data-gradient launch and one
+        weight-gradient launch for all passes.  Registers the LSGAN and feature-matching terms of compute_loss_D /
+        compute_loss_G [RECALL upstream Vid2VidModelD] with `book` and returns (tensors, seeds for G's backward, tensors,
+        seeds for D's backward).
+        The one forward on a generated input serves both losses (as T2V_D_SHARED_FWD did for the one-pass-per-launch path): D's
+        loss reaches D's parameters through it, G's loss reaches the frames through it with D's parameter gradients switched
+        off (param_gradients_off); the running statistics still move twice for those passes (upstream's two forwards).
+        names = (D, G_GAN, G_GAN_Feat) of the reported sums: D = 0.5 (real + fake [+ raw, with the real term counted again
+        as upstream does])."""
+        opt = self.opt
+        n_d, n_gan, n_feat = names
+        P = len(inputs)
+        F_ = inputs[0].shape[0]
+        feats = net(torch.cat(inputs, 0), groups=P, bn_times=[1] + [2] * (P - 1), pt_skip=F_)
+        num_D = len(feats)
+        fm_w = 0.0 if opt.no_ganFeat else (1.0 / num_D) * (4.0 / (opt.n_layers_D + 1)) * opt.lambda_feat * face_weight
+        tG, sG, tD, sD = [], [], [], []
+        for st in feats:
+            logits = st[-1]
+            gG, gD = torch.empty_like(logits), torch.empty_like(logits)
+            book.zero(gG[:F_])
+            book.mse(n_d, logits[:F_], 1.0, 0.5 * (P - 1), seed=gD[:F_])
+            for g in range(1, P):
+                sl = slice(g * F_, (g + 1) * F_)
+                book.mse(n_d, logits[sl], 0.0, 0.5, seed=gD[sl])
+                book.mse(n_gan, logits[sl], 1.0, face_weight, seed=gG[sl])
+            tG.append(logits); sG.append(gG); tD.append(logits); sD.append(gD)
+            if fm_w:
+                for f in st[:-1]:
+                    gf = torch.empty_like(f)
+                    book.zero(gf[:F_])
+                    for g in range(1, P):
+                        sl = slice(g * F_, (g + 1) * F_)
+                        book.l1(n_feat, f[sl], f[:F_], fm_w, seed=gf[sl])
+                    tG.append(f); sG.append(gf)
+        return tG, sG, tD, sD
+
+    def _train_step_batched(self, pose, real, face_boxes, prev, real_prev, flow_ref, conf_ref, first, fakes, raws, fws, prevs,
+                            fake, A3):
+        """The step from the generated frames on (default path): every discriminator runs its real / fake / raw passes as one
+        batch (_d_pass), the LSGAN and feature-matching terms are one launch (LossBook), and both backward passes start from
+        the terms' gradient seeds.  The flow / warp / weight and VGG terms stay scalar nodes of the autograd graph."""
+        opt, dev = self.opt, pose.device
+        F_, H, W = pose.shape[0], pose.shape[1], pose.shape[2]
+        flow_on = not self.spec.no_flow
+        book = self.book = getattr(self, "book", None) or LossBook(dev)
+        book.reset()
+        raw = torch.cat(raws, 0) if flow_on else None
+        fw_all = torch.cat(fws, 0) if (flow_on and real_prev is not None) else None
+        tG, sG, tD, sD = self._d_pass(self.D, [self._d_input(A3, real), self._d_input(A3, fake)]
+                                      + ([self._d_input(A3, raw)] if flow_on else []), book, ("D", "G_GAN", "G_GAN_Feat"))
+        rest, extra = None, {}          # the terms that stay on the scalar graph: their sum, their values
+        vgg_term = self._vgg_term(fake, raw, real)
+        if vgg_term is not None:
+            rest, extra["G_VGG"] = vgg_term, vgg_term
+        if flow_on and real_prev is not None:
+            flow_sum, flow_named = self._flow_terms(fake, fw_all, real, real_prev, prevs, flow_ref, conf_ref, first)
+            rest = flow_sum if rest is None else rest + flow_sum
+            extra.update(flow_named)
+        if self.Df is not None and face_boxes is not None:
+            def crop(t):
+                return torch.stack([t[i, b[0]:b[1], b[2]:b[3]] for i, b in enumerate(face_boxes)]).contiguous()
+            cA = crop(A3)
+            # face_weight = 2 on the generator's face terms [RECALL upstream Vid2VidModelD.forward]
+            a, b_, c, d = self._d_pass(self.Df, [self._d_input(cA, crop(real)), self._d_input(cA, crop(fake))], book,
+                                         ("D_f", "G_f_GAN", "G_f_GAN_Feat"), 2.0)
+            tG += a; sG += b_; tD += c; sD += d
+        # temporal discriminators: every window (t-2d, t-d, t), d = n_frames_D**s, that ends on a frame of this chunk;
+        # older frames come from the sequence history (generated ones detached)
+        if self.DT:
+            n_old = len(self._hist_real)
+            reals = self._hist_real + [real[i] for i in range(F_)]
+            fks = self._hist_fake + [fake[i] for i in range(F_)]
+            for sc, dt in enumerate(self.DT):
+                d_ = self.tD ** sc
+                ends = [t for t in range(n_old, n_old + F_) if t - (self.tD - 1) * d_ >= 0]
+                if not ends:
+                    continue
+
+                def stack(frames):
+                    rows = []
+                    for t in ends:
+                        w = [frames[t - (self.tD - 1 - k) * d_][..., :3] for k in range(self.tD)]
+                        z = torch.zeros(H, W, ops.round_up(dt.input_nc, 4) - 3 * self.tD, dtype=torch.float32, device=dev)
+                        rows.append(torch.cat(w + [z], -1))
+                    return torch.stack(rows).contiguous()
+                a, b_, c, d = self._d_pass(dt, [stack(reals), stack(fks)], book,
+                                           ("D_T%d" % sc, "G_T_GAN%d" % sc, "G_T_GAN_Feat%d" % sc))
+                tG += a; sG += b_; tD += c; sD += d
+            keep = (self.tD - 1) * self.tD ** (len(self.DT) - 1)
+            self._hist_real = [r.detach() for r in reals][-keep:]
+            self._hist_fake = [f.detach() for f in fks][-keep:]
+        book.run()          # values and gradient seeds of all LSGAN / feature-matching terms: one launch
+        g_params, d_params = self.optG.params, self.optD.params
+        self.bucketsG.seal()
+        self.bucketsD.seal()
+        if rest is not None and torch.is_tensor(rest) and rest.requires_grad:
+            tG, sG = tG + [rest], sG + [None]
+        with param_gradients_off(d_params):
+            gG = torch.autograd.grad(tG, g_params, grad_outputs=sG, retain_graph=True, allow_unused=True)
+        gG = flush_pending_weight_gradients(g_params, gG)
+        self.bucketsG.absorb(gG)
+        with input_gradients_off():      # D's loss: no data gradient into the (attached) generated frames
+            gD = torch.autograd.grad(tD, d_params, grad_outputs=sD, allow_unused=True)
+        gD = flush_pending_weight_gradients(d_params, gD)
+        self.bucketsD.absorb(gD)
+        if self.time_comm:
+            torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        self.comm_bytes = self.bucketsG.finish() + self.bucketsD.finish()
+        if self.time_comm and self.comm_bytes:
+            torch.cuda.synchronize()
+            self.comm_ms = 1e3 * (time.perf_counter() - t0)
+        check_presence_across_ranks([self.bucketsG, self.bucketsD], dev)
+        self.optG.step()
+        self.optD.step()
+        losses = book.read({k: v for k, v in extra.items() if torch.is_tensor(v)})      # (the step's one host read)
+        losses.update({k: float(v) for k, v in extra.items() if not torch.is_tensor(v)})
+        ops.check_async_errors()      # (the read-back above synchronised: errors the step's kernels could only flag)
+        # (reported in the order the one-term-per-launch path reports them)
+        order = ["G_GAN", "G_GAN_Feat", "D", "G_VGG", "F_Flow", "F_Warp", "W", "G_Warp", "G_f_GAN", "G_f_GAN_Feat", "D_f"] + \
+            [n % sc for sc in range(len(self.DT)) for n in ("G_T_GAN%d", "G_T_GAN_Feat%d", "D_T%d")]
+        return {k: losses[k] for k in order if k in losses}, prev
+
     def train_step(self, pose, real, face_boxes=None, prev=None, real_prev=None, flow_ref=None, conf_ref=None):
         """pose [F,H,W,12] (sliding windows), real [F,H,W,4] NHWC on the device; face_boxes: list of
         (ys,ye,xs,xe) per frame; prev: the carried FIFO of generated frames (None: a new sequence starts).
@@ -1633,7 +1983,13 @@ class Vid2VidTrainer:
         # switched off for that backward pass (param_gradients_off) -- the same values either way, a D forward less per
         # fake input.  The running statistics still move twice (upstream's two forwards).
         shared = os.environ.get("T2V_D_SHARED_FWD", "1") != "0"
+        # T2V_D_BATCHED=0: one launch per pass and per loss term, the scalar graph on autograd (the form this path replaced;
+        # kept as its test twin)
+        batched = shared and os.environ.get("T2V_D_BATCHED", "1") != "0"
         self._shared_d = shared
+        if batched:
+            return self._train_step_batched(pose, real, face_boxes, prev, real_prev, flow_ref, conf_ref, first, fakes, raws, fws,
+                                            prevs, fake, A3)
 
         def d_fake(net, x_attached):
             """-> (prediction for D's loss, prediction for G's loss)"""
@@ -1662,13 +2018,8 @@ class Vid2VidTrainer:
                 loss_G_fm = loss_G_fm + feature_matching_loss(pfg_r, pr, opt.n_layers_D, opt.lambda_feat)
         loss_D = 0.5 * (loss_D_fake + loss_D_real)
         loss_G = loss_G_gan + loss_G_fm
-        loss_G_vgg = None
-        if self.vgg is not None:   # [RECALL upstream: criterionVGG(fake_B, real_B) * lambda_feat (+ the same on fake_B_raw)]
-            with torch.no_grad():
-                real_taps = self.vgg(real)
-            loss_G_vgg = vgg_loss(self.vgg, fake, real, real_taps) * opt.lambda_feat
-            if flow_on:
-                loss_G_vgg = loss_G_vgg + vgg_loss(self.vgg, raw, real, real_taps) * opt.lambda_feat
+        loss_G_vgg = self._vgg_term(fake, raw if flow_on else None, real)
+        if loss_G_vgg is not None:
             loss_G = loss_G + loss_G_vgg
         def _f(t):   # kept on the device: one host read at the end of the step instead of a sync per loss term
             return t.detach() if torch.is_tensor(t) else float(t)
@@ -1677,38 +2028,9 @@ class Vid2VidTrainer:
         if loss_G_vgg is not None:
             losses["G_VGG"] = _f(loss_G_vgg)
         if flow_on and real_prev is not None:
-            # flow / warp / weight losses [RECALL upstream Vid2VidModelD.forward, compute_flow_losses]:
-            #   F_Flow = MaskedL1(flow, flow_ref, conf) * lambda_F      F_Warp = MaskedL1(resample(real_B_prev, flow), real_B, conf) * lambda_T
-            #   W      = MaskedL1(weight, 0, conf)  (--no_first_img)    G_Warp = MaskedL1(fake_B, resample(fake_B_prev, flow_ref), conf) * lambda_T
-            # flow_ref / conf_ref come from FlowNet2 upstream; here they are inputs (zero flow by default)
-            with torch.no_grad():
-                if flow_ref is None:
-                    if not getattr(self, "_warned_zero_flow", False):
-                        self._warned_zero_flow = True
-                        print("warning: flow / warp / weight losses run against a synthetic ZERO reference flow (FlowNet2 is not "
-                              "in the reference tree; pass flow_ref / conf_ref, or --no_flow to train without the flow branch)",
-                              flush=True)
-                    flow_ref = torch.zeros(F_, H, W, 4, dtype=torch.float32, device=dev)
-                    real_prev_warp = real_prev
-                else:
-                    real_prev_warp = torch.stack([ops.flow_warp(flow_ref[i], real_prev[i], 0) for i in range(F_)])
-                if conf_ref is None:
-                    conf_ref = ((real[..., :3] - real_prev_warp[..., :3]).norm(dim=-1) < 0.02).float()
-                fake_prev = torch.cat(prevs, 0)
-                fake_prev_warp = torch.stack([ops.flow_warp(flow_ref[i], fake_prev[i], self.spec.prev_nc - 3)
-                                              for i in range(F_)])
-                if first:
-                    # no generated previous frame exists for a sequence's first frame: upstream warps the REAL previous
-                    # frame there (fake_B_prev = real_B_prev[:, 0:1] when there is no previous chunk [RECALL
-                    # compute_fake_B_prev]); the all-zero FIFO stays the generator's INPUT only
-                    fake_prev_warp[0] = real_prev_warp[0]
-            loss_F_flow = masked_l1(fw_all, flow_ref, conf_ref, 2, 0) * opt.lambda_F
-            loss_F_warp = masked_l1(_Resample.apply(fw_all, real_prev.contiguous(), 0), real, conf_ref, 3) * opt.lambda_T
-            # the weight-map loss exists only under --no_first_img upstream (zero otherwise) [RECALL]
-            loss_W = masked_l1(fw_all, None, conf_ref, 1, 2) if getattr(opt, "no_first_img", False) else 0.0
-            loss_G_warp = masked_l1(fake, fake_prev_warp, conf_ref, 3) * opt.lambda_T
-            loss_G = loss_G + loss_F_flow + loss_F_warp + loss_W + loss_G_warp
-            losses.update({"F_Flow": _f(loss_F_flow), "F_Warp": _f(loss_F_warp), "W": _f(loss_W), "G_Warp": _f(loss_G_warp)})
+            flow_sum, flow_named = self._flow_terms(fake, fw_all, real, real_prev, prevs, flow_ref, conf_ref, first)
+            loss_G = loss_G + flow_sum
+            losses.update({k: _f(v) for k, v in flow_named.items()})
         if self.Df is not None and face_boxes is not None:
             def crop(t):
                 return torch.stack([t[i, b[0]:b[1], b[2]:b[3]] for i, b in enumerate(face_boxes)]).contiguous()
