@@ -1,2 +1,3 @@
 mkdir -p gpurun_out/r06
-python scripts/train_bench.py --iters 2 --aten_kernels 2>&1 | tail -75 | cut -c1-220 > gpurun_out/r06/aten_kernels_batched2.txt
+timeout 1200 python -m pytest tests/test_gpu_device_oracle.py -q -s -k "face_discriminator" 2>&1 | grep "seed \|D_f on\|passed\|failed" > gpurun_out/r06/df_bound_seeds.txt
+cat gpurun_out/r06/df_bound_seeds.txt

@@ -162,8 +162,9 @@ def oracle_train_step(Gr, Dr, Dfr, pose, real, real_prev, prev0, boxes, lam_feat
     return {k: float(v.detach()) for k, v in losses.items()}, {k: v.detach() for k, v in grads.items()}, fake.detach()
 
 
-def _step_setup(size, ngf, n_down, n_blocks, ndf, seed):
-    """a Vid2VidTrainer (HIP) with its optimiser steps patched away, the oracle modules holding the same weights, one clip"""
+def _step_setup(size, ngf, n_down, n_blocks, ndf, seed, data_seed=0):
+    """a Vid2VidTrainer (HIP) with its optimiser steps patched away, the oracle modules holding the same weights, one clip
+    (data_seed: another clip)"""
     from oracle.generator_ref import CompositeGenerator, MultiscaleDiscriminator
     from text2video_amd import train as T
     from text2video_amd.options import TrainOptions
@@ -191,11 +192,11 @@ def _step_setup(size, ngf, n_down, n_blocks, ndf, seed):
     Dr = load(MultiscaleDiscriminator(6, ndf, 3, 2, "batch"), tr.D.named_upstream_parameters())
     Dfr = load(MultiscaleDiscriminator(6, ndf, 3, 1, "batch"), tr.Df.named_upstream_parameters())
     H = W = size
-    pose = _pose(2, H, W, 51)
-    real = _frames(2, 3, H, W, 52)
-    real_prev = torch.cat([_frames(1, 3, H, W, 53), real[:1]], 0)
+    pose = _pose(2, H, W, 51 + data_seed)
+    real = _frames(2, 3, H, W, 52 + data_seed)
+    real_prev = torch.cat([_frames(1, 3, H, W, 53 + data_seed), real[:1]], 0)
     real_prev[:, :, :, : W // 2] = real[:, :, :, : W // 2]        # a region where the zero reference flow is "confident"
-    prev0 = _frames(1, 6, H, W, 54)
+    prev0 = _frames(1, 6, H, W, 54 + data_seed)
     side = max(8, size // 32 * 8)
     boxes = [(H // 8, H // 8 + side, (W - side) // 2, (W - side) // 2 + side)] * 2
     return tr, (Gr, Dr, Dfr), (pose, real, real_prev, prev0), boxes
@@ -272,6 +273,97 @@ def test_device_oracle_train_step_is_the_cpu_oracle_step_and_the_hip_step_matche
     assert any(k.startswith("G.model_res_flow") for k in eh) and any(k.startswith("G.model_final_w") for k in eh)
 
 
+def test_second_step_with_kept_input_transforms_matches_the_device_oracle_at_128():
+    """From a layer's SECOND step on the forward convs leave their input transforms in the weight gradient's workspace, the
+    transform of dy forms the gradient in front of the norm itself, and the data gradients read the forward packing of the
+    weights in place (train._keep_v_slot, T2V_DY_NORM_FUSED, T2V_DGRAD_FORWARD_WEIGHTS) -- paths the one-step oracle tests
+    never enter.  Here two steps on the same weights (the optimiser steps are patched away) and the same clip, at a size
+    whose bottleneck (32 x 32 x 128) runs F(4x4,3x3): the second step -- checked to have taken the kept path -- against the
+    oracle step evaluated on the GPU in fp64 (licensed by the 64x64 test above), to the bounds the first step meets."""
+    from text2video_amd import ops
+    tr, mods, clip, boxes = _step_setup(128, 32, 2, 2, 16, seed=7)
+    l64, g64, f64 = _oracle_step_on(mods, clip, boxes, DEV, torch.float64)
+    l32, g32, _ = _oracle_step_on(mods, clip, boxes, DEV, torch.float32)
+    eo = _rel_err(g32, g64)
+    kept = {"n": 0}
+    dy_norm = ops.conv2d_backward_weight_winograd_dy_norm
+    ops.conv2d_backward_weight_winograd_dy_norm = lambda *a, **k: (kept.__setitem__("n", kept["n"] + 1), dy_norm(*a, **k))[1]
+    try:
+        steps = [_hip_step(tr, clip, boxes) for _ in range(2)]
+        counts = kept["n"]
+    finally:
+        ops.conv2d_backward_weight_winograd_dy_norm = dy_norm
+    assert counts > 0, "the second step did not take the kept-V path"
+    for n, (l_hip, g_hip, f_hip) in enumerate(steps):
+        assert (f_hip.double() - f64).abs().max().item() <= 2e-4
+        for k in l64:
+            assert abs(l_hip[k] - l64[k]) <= 2e-4 * max(1.0, abs(l64[k])), (n, k, l_hip[k], l64[k])
+        eh = _rel_err(g_hip, g64)
+        for tag in ("G.", "D.", "Df."):
+            a = np.array([v for k, v in eh.items() if k.startswith(tag)])
+            b = np.array([eo[k] for k in eh if k.startswith(tag)])
+            print("128x128 step %d %-3s vs fp64: HIP median %.1e max %.1e | fp32 device oracle median %.1e max %.1e"
+                  % (n + 1, tag, np.median(a), a.max(), np.median(b), b.max()))
+            assert a.max() <= max(3e-3, 2 * b.max()) and np.median(a) <= max(4e-4, 2 * np.median(b)), (n, tag)
+
+
+def _df_on_hip_frames(mods, clip, boxes, f_hip, g_hip, seed):
+    # D_f by itself, on the frames the HIP generator produced: its gradient evaluated in fp64 there is what the HIP step must
+    # deliver -- the generated frames' 2e-5 rms error seen through D_f is the whole of the D_f error above
+    # (scripts/step_parity_probe.py).  Every tensor within a few fp32 roundings of it -- except where a LeakyReLU kink flips: D_f
+    # is a LeakyReLU / batch-norm stack on a 128x128 crop (a million pre-activations per pass), and one of them within fp32
+    # rounding of zero takes the other slope in an fp32 evaluation: with the norm's beta = 0 that element has xhat = 0, so it
+    # moves that channel's SUM of dy (the norm bias gradient, and through the norm's mean(dy) term everything upstream of it:
+    # layer 1's conv weight, layer 0) by 0.8 |dy| and leaves dgamma and the later layers alone.  Measured with
+    # scripts/df_step_probe.py: 2.6e-6 on every tensor on one set of frames; on frames that differ from those by the rounding
+    # of the stems' k order 1e-6 on nine tensors and 4e-4 .. 2e-3 on exactly those four -- the step's gradient being, bit for
+    # bit, what D_f alone computes on the returned frames.  The fp32 oracle is subject to the same event on other elements
+    # (~8 % per pass and implementation).  So: the median against the fp32 oracle's own, and a cap on what one flip can do.
+    import copy
+    from oracle.generator_ref import MultiscaleDiscriminator      # noqa: F401
+    mse = torch.nn.MSELoss()
+
+    def crop(t):
+        return torch.stack([t[i, :, bb[0]:bb[1], bb[2]:bb[3]] for i, bb in enumerate(boxes)])
+
+    def df_gradients(dtype):
+        Dfr = copy.deepcopy(mods[2]).to(device=DEV, dtype=dtype)
+        pose_t, real_t, fake_t = clip[0].to(DEV, dtype), clip[1].to(DEV, dtype), f_hip.to(DEV, dtype)
+        fr = Dfr(torch.cat([crop(pose_t[:, 6:9]), crop(real_t)], 1))
+        ff = Dfr(torch.cat([crop(pose_t[:, 6:9]), crop(fake_t)], 1))
+        l_df = 0.5 * (sum(mse(q[-1], torch.zeros_like(q[-1])) for q in ff) + sum(mse(q[-1], torch.ones_like(q[-1])) for q in fr))
+        return {"Df." + k: g for (k, _), g in zip(Dfr.named_parameters(), torch.autograd.grad(l_df, list(Dfr.parameters())))}
+    g_df, g_df32 = df_gradients(torch.float64), df_gradients(torch.float32)
+    zero_ref = g_df      # (conv biases in front of a norm layer: an exactly zero gradient, <= 1e-9 in fp64)
+    e_df, e_df32 = _rel_err({k: g_hip[k] for k in g_df}, g_df, zero_ref), _rel_err(g_df32, g_df, zero_ref)
+    a, b = np.array([e_df[k] for k in e_df]), np.array([e_df32[k] for k in e_df])
+    print("   D_f on the HIP frames vs its fp64 gradient there: HIP median %.1e max %.1e | fp32 oracle median %.1e max %.1e"
+          % (np.median(a), a.max(), np.median(b), b.max()))
+    # (round 5: with the frames of the strip-form 7x7 head -- another summation order, another 2e-5 of rounding -- a kink flips
+    # in an EARLY layer, for the fp32 oracle evaluated on the same frames exactly as for the HIP step: both 6.2e-4 median /
+    # 4.8e-3 max over the 13 tensors.  The count is therefore of tensors where the HIP step is worse than 3x what the fp32
+    # oracle itself does on these frames.  Round 6: held on three seeds -- the per-seed counts are printed and kept in
+    # profiles/r06_df_bound_seeds.txt)
+    n_hip, n_o32 = int(np.sum(a > np.maximum(1e-4, 3 * b))), int(np.sum(b > 1e-4))
+    print("   seed %d: D_f tensors above max(1e-4, 3 x fp32 oracle): HIP %d of %d | fp32 oracle above 1e-4: %d of %d"
+          % (seed, n_hip, len(a), n_o32, len(b)))
+    # (seed 6: a kink flips for BOTH fp32 evaluations on the same elements -- HIP and fp32 oracle 3.0e-3 / 2.9e-3 ... 3.79e-2 /
+    # 3.79e-2 tensor by tensor, no tensor worse than 3x the oracle's -- so the cap on the worst tensor is relative to the fp32
+    # oracle's own worst as well: an absolute 1e-2 alone would reject the oracle itself there)
+    assert np.median(a) <= max(1e-5, 3 * np.median(b)) and n_hip <= 5 and a.max() <= max(1e-2, 2 * b.max())
+
+
+@pytest.mark.parametrize("seed", [5, 6, 7])
+def test_config4_face_discriminator_gradient_on_the_hip_frames(seed):
+    """The D_f criterion of the 512x512 step (see _df_on_hip_frames) on three seeds: weights, clip and so the generated frames
+    differ per seed; the bound -- at most 5 of D_f's 13 tensors more than max(1e-4, 3 x the fp32 oracle's own error) away from
+    D_f's fp64 gradient on the HIP frames, none beyond 1e-2 -- holds on each.  (The full-step comparison runs on seed 5:
+    test_config4_train_step_512_matches_the_device_oracle_step.)"""
+    tr, mods, clip, boxes = _step_setup(512, 128, 3, 9, 64, seed=seed, data_seed=10 * (seed - 5))
+    _, g_hip, f_hip = _hip_step(tr, clip, boxes)
+    _df_on_hip_frames(mods, clip, boxes, f_hip, g_hip, seed)
+
+
 def test_config4_train_step_512_matches_the_device_oracle_step():
     """BASELINE configs[4], one GPU's work, at full size and full width: Vid2VidTrainer.train_step (2 frames of 512x512,
     ngf 128 / 9 blocks with the flow branch, 2-scale D, face D on 128x128 crops, all losses) against the oracle step on the GPU.
@@ -309,42 +401,7 @@ def test_config4_train_step_512_matches_the_device_oracle_step():
         if tag == "Df.":
             continue        # (checked exactly below)
         assert np.median(a) <= 3 * np.median(b) and np.quantile(a, 0.9) <= 4 * np.quantile(b, 0.9) and a.max() <= 5 * b.max(), tag
-    # D_f by itself, on the frames the HIP generator produced: its gradient evaluated in fp64 there is what the HIP step must
-    # deliver -- the generated frames' 2e-5 rms error seen through D_f is the whole of the D_f error above
-    # (scripts/step_parity_probe.py).  Every tensor within a few fp32 roundings of it -- except where a LeakyReLU kink flips: D_f
-    # is a LeakyReLU / batch-norm stack on a 128x128 crop (a million pre-activations per pass), and one of them within fp32
-    # rounding of zero takes the other slope in an fp32 evaluation: with the norm's beta = 0 that element has xhat = 0, so it
-    # moves that channel's SUM of dy (the norm bias gradient, and through the norm's mean(dy) term everything upstream of it:
-    # layer 1's conv weight, layer 0) by 0.8 |dy| and leaves dgamma and the later layers alone.  Measured with
-    # scripts/df_step_probe.py: 2.6e-6 on every tensor on one set of frames; on frames that differ from those by the rounding
-    # of the stems' k order 1e-6 on nine tensors and 4e-4 .. 2e-3 on exactly those four -- the step's gradient being, bit for
-    # bit, what D_f alone computes on the returned frames.  The fp32 oracle is subject to the same event on other elements
-    # (~8 % per pass and implementation).  So: the median against the fp32 oracle's own, and a cap on what one flip can do.
-    import copy
-    from oracle.generator_ref import MultiscaleDiscriminator      # noqa: F401
-    mse = torch.nn.MSELoss()
-
-    def crop(t):
-        return torch.stack([t[i, :, bb[0]:bb[1], bb[2]:bb[3]] for i, bb in enumerate(boxes)])
-
-    def df_gradients(dtype):
-        Dfr = copy.deepcopy(mods[2]).to(device=DEV, dtype=dtype)
-        pose_t, real_t, fake_t = clip[0].to(DEV, dtype), clip[1].to(DEV, dtype), f_hip.to(DEV, dtype)
-        fr = Dfr(torch.cat([crop(pose_t[:, 6:9]), crop(real_t)], 1))
-        ff = Dfr(torch.cat([crop(pose_t[:, 6:9]), crop(fake_t)], 1))
-        l_df = 0.5 * (sum(mse(q[-1], torch.zeros_like(q[-1])) for q in ff) + sum(mse(q[-1], torch.ones_like(q[-1])) for q in fr))
-        return {"Df." + k: g for (k, _), g in zip(Dfr.named_parameters(), torch.autograd.grad(l_df, list(Dfr.parameters())))}
-    g_df, g_df32 = df_gradients(torch.float64), df_gradients(torch.float32)
-    zero_ref = {k: g64[k] for k in g_df}
-    e_df, e_df32 = _rel_err({k: g_hip[k] for k in g_df}, g_df, zero_ref), _rel_err(g_df32, g_df, zero_ref)
-    a, b = np.array([e_df[k] for k in e_df]), np.array([e_df32[k] for k in e_df])
-    print("   D_f on the HIP frames vs its fp64 gradient there: HIP median %.1e max %.1e | fp32 oracle median %.1e max %.1e"
-          % (np.median(a), a.max(), np.median(b), b.max()))
-    # (round 5: with the frames of the strip-form 7x7 head -- another summation order, another 2e-5 of rounding -- a kink flips
-    # in an EARLY layer, for the fp32 oracle evaluated on the same frames exactly as for the HIP step: both 6.2e-4 median /
-    # 4.8e-3 max over the 13 tensors.  The count is therefore of tensors where the HIP step is worse than 3x what the fp32
-    # oracle itself does on these frames)
-    assert np.median(a) <= max(1e-5, 3 * np.median(b)) and np.sum(a > np.maximum(1e-4, 3 * b)) <= 5 and a.max() <= 1e-2
+    _df_on_hip_frames(mods, clip, boxes, f_hip, g_hip, 5)
     flow_keys = [k for k in eh if k.startswith(("G.model_res_flow", "G.model_up_flow", "G.model_final_flow", "G.model_final_w"))]
     a = np.array([eh[k] for k in flow_keys])
     b = np.array([eo[k] for k in flow_keys])
