@@ -295,11 +295,9 @@ def _gemm_stage_roofline(dev, sd, g0h, g0w, iters, clocks=None):
                 "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
                 "sclk_mhz": sclk, "sclk_samples": len(ksamp.samples) if ksamp is not None else 0,
-                "peak_at_sclk": round(PEAK_FP32_MFMA_TFLOPS * sclk / SPEC_SCLK_MHZ, 1) if sclk else None,
                 "frac_at_sclk": round(achieved / (PEAK_FP32_MFMA_TFLOPS * sclk / SPEC_SCLK_MHZ), 4) if sclk else None,
                 "traffic": traffic,
-                "traffic_source": ("profiles/pmc_summary.json (separate rocprofv3 --pmc passes: 2*FETCH_SIZE + WRITE_SIZE per launch; "
-                                   "not measured by this run)" if traffic is not None else None),
+                "traffic_source": "profiles/pmc_summary.json (rocprofv3 --pmc passes; not measured by this run)" if traffic is not None else None,
                 "ms_per_launch": round(k_ms, 4), "ms_per_launch_bracketed": round(k_ms_bracketed, 4),
                 "gflop_per_launch": round(k_flop / 1e9, 2),
                 "flops_counted": "executed MFMA FLOPs of the launch" if use_wino else "algorithmic conv FLOPs",
@@ -349,7 +347,69 @@ def time_frames(model, dev, H, W, K, Wm, seed=0):
     return time.perf_counter() - t0
 
 
-def hires_block(dev, K, Wm, iters):
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured for a float4 copy)
+
+
+def hires_hbm_rows(dev, iters):
+    """configs[3]'s HBM-bound kernels (north_star: "HBM-bound conv tiles"; SURVEY 8d: the 7x7 stems / heads, the norm
+    apply and the local enhancer's 64 / 128-channel full- and half-resolution convs), each timed alone with HIP events at
+    its 1024x1024 shape: achieved rate = ALGORITHMIC bytes (every input and output element once, 4 B; weights are KBs)
+    / launch time, as a fraction of the 8 TB/s HBM peak.  (The 1024-channel bottleneck of the single-scale generator is the
+    MFMA-bound `gemm_stage` next to this list.)"""
+    from text2video_amd import ops
+    rows = []
+
+    def timed(fn):
+        warm_clocks(lambda i: fn(), 40.0)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n = max(10, iters // 5)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n
+
+    def conv_row(name, H, W, cin, cout, k, stride, pad, pm, transposed, stats, act=0):
+        desc = ops.conv_desc(H, W, cin, cout, k, stride, pad, pm, transposed, act)
+        xcs, ycs = ops.round_up(cin, 4), ops.round_up(cout, 4)
+        x = torch.randn(H, W, xcs, device=dev)
+        w = torch.randn(*((cin, cout, k, k) if transposed else (cout, cin, k, k)), device=dev) * 0.02
+        pw, b = ops.pack_conv_weight(w, desc, xcs), torch.zeros(cout, device=dev)
+        sb = ops.conv_stats_buffer(desc, dev) if stats else None
+        ho, wo = ops.conv_out_dims(desc)
+        y = torch.empty(ho, wo, ycs, device=dev)
+        ms = timed(lambda: ops.conv2d(x, pw, b, desc, y_cs=ycs, stats=sb, out=y))
+        nbytes = 4.0 * (H * W * cin + ho * wo * cout)
+        flop = 2.0 * k * k * cin * cout * (H * W if transposed else ho * wo)
+        rows.append([name, round(ms, 3), round(nbytes / 1e6), round(nbytes / ms / 1e6), round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 3),
+                     round(flop / ms / 1e9, 1)])
+        del x, y, pw
+
+    R, Z = ops.PAD_REFLECT, ops.PAD_ZERO
+    # (names: generator, layer, channels @ input size; stems / down / ResnetBlock / up carry the norm-statistics epilogue)
+    conv_row("G0 stem7x7 9>128@1024", 1024, 1024, 9, 128, 7, 1, 3, R, False, True)
+    conv_row("G0 head7x7 128>3@1024", 1024, 1024, 128, 3, 7, 1, 3, R, False, False, ops.ACT_TANH)
+    conv_row("G1 stem7x7 9>64@1024", 1024, 1024, 9, 64, 7, 1, 3, R, False, True)
+    conv_row("G1 down3x3s2 64>128@1024", 1024, 1024, 64, 128, 3, 2, 1, Z, False, True)
+    conv_row("G1 res3x3 128>128@512", 512, 512, 128, 128, 3, 1, 1, R, False, True)
+    conv_row("G1 upT3x3s2 128>64@512", 512, 512, 128, 64, 3, 2, 1, Z, True, True)
+    conv_row("G1 head7x7 64>3@1024", 1024, 1024, 64, 3, 7, 1, 3, R, False, False, ops.ACT_TANH)
+    # norm apply + ReLU on the largest activation of the frame
+    x = torch.randn(1024, 1024, 128, device=dev)
+    y = torch.empty_like(x)
+    mr = torch.stack([torch.zeros(128, device=dev), torch.ones(128, device=dev)], 1).contiguous()
+    ms = timed(lambda: ops.instance_norm_apply(x, mr, None, None, relu=True, out=y))
+    nbytes = 2.0 * x.numel() * 4
+    rows.append(["norm apply+ReLU 128@1024", round(ms, 3), round(nbytes / 1e6), round(nbytes / ms / 1e6),
+                 round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 3), 0.0])
+    del x, y
+    torch.cuda.empty_cache()
+    return {"columns": "kernel, ms, algorithmic MB, GB/s, frac of 8000 GB/s HBM peak, algorithmic TFLOP/s (fp32 MFMA peak 157.3)",
+            "rows": rows}
+
+
+def hires_block(dev, K, Wm, iters, clocks=None):
     """BASELINE configs[3]: 1024x1024 frames, single-scale G0@1024^2 and the two-scale G0@512^2 + local enhancer G1@1024^2
     (16 frames), flow / no flow, + the GEMM stage of the single-scale generator timed live."""
     out = {"workload": "configs[3]: 1024x1024, %d frames after %d warm-up" % (K, Wm)}
@@ -365,11 +425,14 @@ def hires_block(dev, K, Wm, iters):
             blk[key + "_ms"] = round(1e3 * el / K, 2)
             blk[key + "_algorithmic_tflops"] = round(K / el * gf / 1e3, 1)
             if flow and scales == 1:
-                r = gemm_stage_roofline(dev, sds[0], 1024, 1024, iters)
-                blk["gemm_stage"] = {k: r[k] for k in ("kernel", "ms_per_launch", "gflop_per_launch", "achieved", "frac")}
+                r = gemm_stage_roofline(dev, sds[0], 1024, 1024, iters, clocks)
+                blk["gemm_stage"] = {k: r[k] for k in ("kernel", "ms_per_launch", "gflop_per_launch", "achieved", "frac", "sclk_mhz",
+                                                       "frac_at_sclk")}
+                blk["gemm_stage"]["kernel"] = r["kernel"].split(" as ")[0] + " @128x128"
             del model, sds
             torch.cuda.empty_cache()
         out[name] = blk
+    out["hbm_bound"] = hires_hbm_rows(dev, iters)
     return out
 
 
@@ -477,7 +540,7 @@ def train_block(dev, dist_mod, world, rank, backend, steps, iters, ngf=128, cloc
             dw = torch.empty(C, C, 3, 3, device=dev)
             ms = ev_time(lambda: ops.conv2d_backward_weight_winograd_reduce(desc, ws, F, C, C, out=dw))
             gf = 2.0 * 36 * F * 256 * C * C / 1e9
-            kernels.append({"kernel": "wino_wgrad_sk_kernel + dW transform: Winograd-domain wgrad, 1024->1024 conv, %d frames" % F,
+            kernels.append({"kernel": "wino_wgrad_sk + dW transform, 1024->1024 conv, %d frames" % F,
                             "ms_per_launch": round(ms, 4), "gflop_per_launch": round(gf, 2),
                             "achieved": round(gf / ms, 2), "frac": round(gf / ms / PEAK_FP32_MFMA_TFLOPS, 4)})
         for name, (h, w, ci, co, st, tr_) in (("down 512->1024 3x3 s2 @128x128", (128, 128, 512, 1024, 2, False)),
@@ -489,7 +552,7 @@ def train_block(dev, dist_mod, world, rank, backend, steps, iters, ngf=128, cloc
             dys = [torch.randn(ho, wo, co, device=dev) for _ in range(2)]
             ms = ev_time(lambda: ops.conv2d_backward_weight_pair(xs[0], dys[0], xs[1], dys[1], d))
             gf = 2 * 2.0 * 9 * ci * co * (h * w if tr_ else ho * wo) / 1e9
-            kernels.append({"kernel": "conv_wgrad_kernel, 2 frames per launch: " + name,
+            kernels.append({"kernel": "conv_wgrad, 2 frames: " + name,
                             "ms_per_launch": round(ms, 4), "gflop_per_launch": round(gf, 2),
                             "achieved": round(gf / ms, 2), "frac": round(gf / ms / PEAK_FP32_MFMA_TFLOPS, 4)})
         block = {"workload": "configs[4] per GPU: 512x512, 2 frames, G (flow%s) + D (num_D 2) + face D, --no_vgg, Adam; %d GPU(s)"
@@ -507,8 +570,7 @@ def train_block(dev, dist_mod, world, rank, backend, steps, iters, ngf=128, cloc
                               "replicas_in_sync": in_sync},
                  "losses": {k: round(float(v), 3) for k, v in losses.items() if k in ("G_GAN", "G_GAN_Feat", "D", "D_f")},
                  "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
-                 "kernels": kernels,
-                 "note": "the step's forward / data-gradient GEMM stage is the headline roofline kernel"}
+                 "kernels": kernels}
     del tr
     torch.cuda.empty_cache()
     if own_group:
@@ -1021,9 +1083,9 @@ def main():
         for nb, el in batch_elapsed.items():
             variants["batch%d_fps" % nb] = round(world * nb * K / el, 3)
         if batch_elapsed:
-            variants["batch_note"] = "batch<N>_fps: N independent sequences per GPU in lock-step, aggregate fps; frames bit-equal"
+            variants["batch_note"] = "batch<N>_fps: N sequences per GPU in lock-step, aggregate; frames bit-equal"
         variants["headline"] = "flow" if head_flow else "noflow"
-        variants["note"] = "both variants timed in this run over the same K steps; `value` is the headline variant"
+        variants["note"] = "both variants timed in this run over K steps; `value` = headline"
         result = {
             "metric": "frames/sec 512x512 pose->RGB (vid2vid generator)",
             "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
@@ -1045,7 +1107,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu, "e2e": e2e, "box": sampler.summary(),
         }
         if args.hires_frames > 0 and world == 1 and default_geometry:
-            result["hires"] = hires_block(dev, args.hires_frames, 4, args.kernel_iters)
+            result["hires"] = hires_block(dev, args.hires_frames, 4, args.kernel_iters, sampler)
     if args.train_steps > 0 and default_geometry:
         del model, other
         torch.cuda.empty_cache()

@@ -22,6 +22,20 @@ def lib_built():
     return _lib.load()
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _oracle_threads():
+    """The CPU oracle (stock torch convolutions) runs 2.7x SLOWER on the 128-256 threads torch takes by default on the GPU
+    boxes' hosts than on 8-32 (bench.py's cpu_baseline.by_threads, rounds 3-5: 0.11 fps at 128 threads, 0.29-0.31 at 32 / 8):
+    the oracle-heavy GPU tests were paying for that.  16 threads unless T2V_TEST_CPU_THREADS says otherwise; a no-op on hosts
+    with fewer cores (this only changes how the checker is scheduled, not what it computes in fp64; fp32 summation order inside
+    torch's kernels may differ with the thread count -- the tolerances are for "another correct fp32 implementation")."""
+    import torch
+    want = int(os.environ.get("T2V_TEST_CPU_THREADS", "16"))
+    if want > 0 and torch.get_num_threads() > want:
+        torch.set_num_threads(want)
+    yield
+
+
 @pytest.fixture(autouse=True)
 def _seeded():
     """Every test starts from the same torch / numpy global RNG state: modules built with torch's default

@@ -291,3 +291,29 @@ def test_collected_weight_gradient_bookkeeping(monkeypatch):
         with T.batched_weight_gradients([w]):
             w._t2v_dw_uses = 2
             T._paired_direct_wgrad(w, *pair(1), "desc", None)
+
+
+def test_direct_weight_gradient_splits_a_batch_that_passes_the_kernels_offset_limit(monkeypatch):
+    """a discriminator layer's passes are reduced as ONE batch; the weight-gradient kernel addresses its operands
+    with 32-bit byte offsets, so a batch whose x or dY would pass 2 GiB (many frames per GPU at 2048x1024) must be reduced in
+    chunks that accumulate -- host logic, the kernel replaced by a stand-in."""
+    import torch
+    from text2video_amd import ops
+    from text2video_amd import train as T
+    calls = []
+
+    def fake(x, dy, desc, accumulate_into=None):
+        calls.append((x.shape[0], accumulate_into is not None))
+        part = torch.einsum("bhwc,bhwn->cn", x, dy)
+        return part if accumulate_into is None else accumulate_into.add_(part)
+    monkeypatch.setattr(ops, "conv2d_backward_weight", fake)
+    x, dy = torch.randn(6, 5, 7, 4), torch.randn(6, 5, 7, 8)
+    whole = T.direct_weight_gradient(x, dy, None)
+    assert calls == [(6, False)]
+    del calls[:]
+    monkeypatch.setattr(T, "_WGRAD_MAX_BYTES", 4 * (5 + 8) * (7 + 8) * 4 * 2 + 1)       # room for two (padded) images per launch
+    chunked = T.direct_weight_gradient(x, dy, None)
+    assert calls == [(2, False), (2, True), (2, True)] and torch.allclose(chunked, whole, atol=1e-5)
+    del calls[:]
+    monkeypatch.setattr(T, "_WGRAD_MAX_BYTES", 16)                                      # not even one: one image per launch
+    assert torch.allclose(T.direct_weight_gradient(x, dy, None), whole, atol=1e-5) and [c[0] for c in calls] == [1] * 6

@@ -171,3 +171,16 @@ def test_two_simultaneous_first_calls_start_one_server(tmp_path, monkeypatch):
     [t.start() for t in ts]
     [t.join(20) for t in ts]
     assert rcs == [0, 0] and len(spawned) == 1 and len(seen) == 2
+
+
+def test_a_run_directory_owned_by_somebody_else_falls_back_to_the_in_process_run(monkeypatch, capsys):
+    """any local user can pre-create /tmp/t2v_resident_<uid>; the client must then hand the call back to the caller
+    (None: run the frame loop in this process) instead of crashing on the PermissionError -- and --resident_stop is a no-op."""
+    from text2video_amd import resident
+
+    def refuse():
+        raise PermissionError("resident: /tmp/t2v_resident_0 is not a directory owned by uid 0")
+    monkeypatch.setattr(resident, "run_dir", refuse)
+    assert resident.client(["--name", "x"]) is None
+    assert resident.client(["--name", "x", "--resident_stop"]) == 0
+    assert "running in this process" in capsys.readouterr().err

@@ -27,7 +27,7 @@ def test_bench_runs_its_rccl_path_on_one_rank():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 1 and d["value"] > 30.0 and d["config"]["parallelism"] == "sequence-chunk dp1"
-    assert d["config"]["collectives"] == "rccl"
+    assert d["config"]["collectives"] == "rccl, 1 ranks" and d["config"]["world_size"] == 1
     # the configs[4] block: a whole train step at 512x512 with the bucketed exchange on the 1-rank RCCL group, timed with and
     # without the collectives; all of G's and D's gradient bytes went through them
     t = d["train_step"]
@@ -295,7 +295,7 @@ def test_bench_two_ranks_on_one_gpu_contract():
     assert t["exchange"]["group"] == "2-rank gloo" and t["exchange"]["replicas_in_sync"] is True
     assert t["exchange"]["bytes"] > 5e7 and "ngf 32" in t["workload"]      # (a narrow generator here: the gloo exchange of the
                                                                            # full 1.5 GB through the host takes a minute)
-    assert d["config"]["parallelism"] == "sequence-chunk dp2" and d["config"]["collectives"] == "gloo"
+    assert d["config"]["parallelism"] == "sequence-chunk dp2" and d["config"]["collectives"] == "gloo, 2 ranks"
     assert abs(d["value"] - 2 * 1e3 / d["ms_per_step"]) <= 0.01 * d["value"]      # 2 ranks x K frames / max-over-ranks time
     assert d["value"] > 30.0
 

@@ -382,10 +382,23 @@ def test_bench_contract_line():
     assert hi["two_scale"]["flow_fps"] > hi["single_scale"]["flow_fps"]
     g = hi["single_scale"]["gemm_stage"]
     assert g["kernel"].endswith("@128x128") and 0.3 < g["frac"] <= 1.0 and abs(g["achieved"] - g["gflop_per_launch"] / g["ms_per_launch"]) <= 0.02 * g["achieved"]
+    # ... and the HBM-bound kernels of that config (north_star: "HBM-bound conv tiles"): algorithmic bytes / launch time / 8 TB/s
+    hb = hi["hbm_bound"]["rows"]
+    assert len(hb) == 8 and all(len(r) == 6 and r[1] > 0 and 0.005 < r[4] < 1.0 and abs(r[4] - r[3] / 8000.0) < 2e-3 for r in hb), hb
+    assert {r[0].split(" ")[0] for r in hb} == {"G0", "G1", "norm"}
+    # the core clock during the roofline kernel's loop and during the train block (round 6): a slow box and a slow kernel
+    # read differently -- frac is against the 2.4 GHz spec peak, frac_at_sclk against the peak at the sampled clock
+    assert "sclk_mhz" in rf and "frac_at_sclk" in rf
+    if rf["sclk_mhz"]:
+        assert 500 < rf["sclk_mhz"] < 3500 and abs(rf["frac_at_sclk"] - rf["frac"] * 2400.0 / rf["sclk_mhz"]) < 5e-3
+        assert rf["frac_at_sclk"] <= 1.0 and rf["sclk_samples"] >= 3
     # BASELINE configs[4], one GPU's work: ms per optimiser step, the exchange as step_with - step_without + bytes + buckets,
     # the step's heaviest kernels against the fp32 MFMA peak
     t = d["train_step"]
     assert "configs[4]" in t["workload"] and t["steps"] == 2 and 20.0 < t["ms_per_step"] < 2000.0
+    assert "sclk_mhz" in t and "ms_per_step_without_at_2360mhz" in t
+    if t["sclk_mhz"]:
+        assert abs(t["ms_per_step_without_at_2360mhz"] - t["exchange"]["ms_per_step_without"] * t["sclk_mhz"] / 2360.0) < 0.02
     ex = t["exchange"]
     assert ex["group"] == "1-rank rccl" and ex["bytes"] > 1.3e9 and ex["buckets"] >= 20 and ex["replicas_in_sync"] is None
     assert abs(ex["ms"] - (ex["ms_per_step_with"] - ex["ms_per_step_without"])) < 0.02

@@ -389,10 +389,27 @@ def test_winograd_f4_output_transform_applies_the_activation(slope):
         ops.conv2d_auto(_to_nhwc(x), U, b.to(_dev()), desc, stats=ops.conv_stats_buffer(desc, _dev()))
 
 
-@pytest.mark.parametrize("ragged", ["1", "0", "2"], ids=["ragged", "whole_tiles", "tall_ragged"])
-@pytest.mark.parametrize("geom", [(64, 64, 1024, 1024), (64, 88, 640, 640), (128, 128, 256, 256), (64, 128, 512, 1024),
-                                  (128, 128, 512, 256), (64, 40, 1024, 1024), (64, 40, 512, 384), (128, 128, 1024, 1024),
-                                  (64, 85, 1024, 1024), (64, 56, 1024, 1024), (64, 114, 1024, 1024), (60, 52, 256, 384)])
+_FG_GEOMS = [(64, 64, 1024, 1024), (64, 88, 640, 640), (128, 128, 256, 256), (64, 128, 512, 1024), (128, 128, 512, 256),
+             (64, 40, 1024, 1024), (64, 40, 512, 384), (128, 128, 1024, 1024), (64, 85, 1024, 1024), (64, 56, 1024, 1024),
+             (64, 114, 1024, 1024), (60, 52, 256, 384)]
+# too few tiles for one block per CU: T2V_WINO_GEMM_SK_RAGGED=2 stays on the two-per-CU ragged form there (= the "1" case)
+_FG_NO_TALL = {(64, 40, 1024, 1024), (64, 40, 512, 384), (60, 52, 256, 384)}
+_FG_NAMES = {"1": "ragged", "0": "whole_tiles", "2": "tall_ragged"}
+
+
+def _fg_cases():
+    """(geometry, T2V_WINO_GEMM_SK_RAGGED) pairs that differ: with whole 128-row tiles the ragged switch changes nothing (one
+    case), the balanced one-block-per-CU tiles exist only where there are enough of them"""
+    out = []
+    for g in _FG_GEOMS:
+        frags = -(-(-(-g[0] // 4) * -(-g[1] // 4)) // 32)
+        for r in ("1", "0", "2"):
+            if r == "1" or (frags % 4 != 0 and not (r == "2" and g in _FG_NO_TALL)):
+                out.append(pytest.param(g, r, id="%dx%dx%dx%d-%s" % (g + (_FG_NAMES[r],))))
+    return out
+
+
+@pytest.mark.parametrize("geom,ragged", _fg_cases())
 def test_fixed_grid_winograd_gemm_equals_tile_per_block(geom, ragged, t2v_env):
     """The batched Winograd GEMM on a fixed grid (conv_igemm.hip: wino_gemm_sk_kernel; tiles cut between two blocks are
     finished from the first block's accumulators) against one block per tile: the same K-ordered MFMA chain per output,
@@ -407,16 +424,12 @@ def test_fixed_grid_winograd_gemm_equals_tile_per_block(geom, ragged, t2v_env):
     from text2video_amd import ops
     H, W, Cin, Cout = geom
     rows = -(-H // 4) * -(-W // 4)
-    if ragged != "1" and -(-rows // 32) % 4 == 0:
-        pytest.skip("whole 128-row tiles: the ragged switch changes nothing")
     t2v_env("T2V_WINO_GEMM_SK_RAGGED", ragged)
     assert ops.fixed_grid_enabled()
     if ragged == "2":
         t2v_env("T2V_WINO_GEMM_SK", "2")
         form = ops.winograd_gemm_form(ops.conv_desc(H, W, Cin, Cout, 3, 1, 1, ops.PAD_REFLECT, algo=ops.ALGO_WINOGRAD_F4))
-        if "skt_kernel" not in form:
-            assert (Cin, Cout) != (1024, 1024) or -(-rows // 32) < 6, form
-            pytest.skip("too few tiles for one per CU: stays on the two-per-CU ragged form")
+        assert "skt_kernel" in form, form        # (the geometries without that form are not in the list: _FG_NO_TALL)
     dev = _dev()
     desc = ops.conv_desc(H, W, Cin, Cout, 3, 1, 1, ops.PAD_REFLECT, algo=ops.ALGO_WINOGRAD_F4)
     w = _rand(Cout, Cin, 3, 3, seed=2, scale=0.03).to(dev)

@@ -74,7 +74,7 @@ def test_bench_gpus_8_plain_command_contract_line():
     assert len(lines) == 1, lines
     d = json.loads(lines[0])
     assert d["n_gpus"] == 8 and d["steps"] == 6 and d["warmup"] == 2 and d["scaling"] == "weak"
-    assert d["config"]["parallelism"] == "sequence-chunk dp8" and d["config"]["collectives"] == "gloo"
+    assert d["config"]["parallelism"] == "sequence-chunk dp8" and d["config"]["collectives"] == "gloo, 8 ranks"
     assert d["cpu_baseline"] is None and d["e2e"] is None and "hires" not in d                 # N = 1 legs only
     assert d["metric"].startswith("frames/sec") and d["unit"] == "frames/s" and d["dtype"] == "f32"
     # value = the frames of ALL eight ranks over the slowest rank's time

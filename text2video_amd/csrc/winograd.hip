@@ -661,7 +661,9 @@ __global__ __launch_bounds__(256) void winograd4_dy_kernel(const float2* __restr
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
         const long tile = i / C2;
         const int c2 = (int)(i - tile * C2);
-        float mean[2], rstd[2], ga[2], be[2], k0[2], k1[2];
+        // (value-initialised: without NORM nothing below reads them -- `front` is only called under `if constexpr (NORM)` --
+        // but a lambda capturing indeterminate arrays is one edit away from reading them)
+        float mean[2] = {0.f, 0.f}, rstd[2] = {1.f, 1.f}, ga[2] = {1.f, 1.f}, be[2] = {0.f, 0.f}, k0[2] = {0.f, 0.f}, k1[2] = {0.f, 0.f};
         if constexpr (NORM) {
 #pragma unroll
             for (int k = 0; k < 2; ++k) {

@@ -166,6 +166,23 @@ def _paired_direct_wgrad(w, x, dc, fdesc, slot):
     return True, _reduce_stashed(parts, fdesc, slot)
 
 
+_WGRAD_MAX_BYTES = 0x7fff0000        # the weight-gradient kernel addresses its operands with 32-bit byte offsets (capi.hip)
+
+
+def direct_weight_gradient(x, dc, fdesc):
+    """packed dW of a batch [B,...] in as few launches as the kernel's 2 GiB operand limit allows: ONE for every shape of the
+    512 / 1024 configs; a batch whose x or dY (or padded x) would pass the limit -- many frames per GPU at 2048x1024 -- is
+    reduced in chunks of images, accumulating (three passes in one batch are 3x the single pass)."""
+    B = x.shape[0]
+    padded = (x.shape[1] + 8) * (x.shape[2] + 8) * x.shape[3] if x.dim() == 4 else x[0].numel()     # (the kernel pads x by <= 3 px)
+    per = 4 * max(padded, dc[0].numel(), 1)
+    step = max(1, min(B, (_WGRAD_MAX_BYTES - 1) // per))
+    dwp = None
+    for i in range(0, B, step):
+        dwp = ops.conv2d_backward_weight(x[i:i + step], dc[i:i + step], fdesc, accumulate_into=dwp)
+    return dwp
+
+
 def _reduce_stashed(parts, fdesc, slot, from_node=True):
     """one weight-gradient launch over the stashed (x, dY) of a layer; into the bucket slot (-> None) or returned.
     from_node: called by the backward node that brought the last operands (side stream, the node counts as delivered);
@@ -178,9 +195,9 @@ def _reduce_stashed(parts, fdesc, slot, from_node=True):
             (x0, dc0), (x1, dc1) = parts
             dwp = ops.conv2d_backward_weight_pair(x0[0], dc0[0], x1[0], dc1[0], fdesc)
         elif len(parts) == 1:
-            dwp = ops.conv2d_backward_weight(parts[0][0], parts[0][1], fdesc)
+            dwp = direct_weight_gradient(parts[0][0], parts[0][1], fdesc)
         else:
-            dwp = ops.conv2d_backward_weight(torch.cat([pr[0] for pr in parts]), torch.cat([pr[1] for pr in parts]), fdesc)
+            dwp = direct_weight_gradient(torch.cat([pr[0] for pr in parts]), torch.cat([pr[1] for pr in parts]), fdesc)
         if slot is not None:
             ops.unpack_conv_weight_into(dwp, fdesc, xcs, slot.view, slot.filled)
     if slot is not None:
@@ -207,6 +224,10 @@ def batched_weight_gradients(params):
     except BaseException:
         _WG_BATCH[0] = False
         _DW_PAIR[0] = False
+        # an exception inside the step (OOM, an asynchronous error): let go of what the nodes parked on the weights -- operand
+        # lists, kept-V workspaces: GPU memory a retry needs
+        for p in params:
+            p._t2v_dw_stash, p._t2v_dw_uses, p._t2v_wg_state, p._t2v_wg_images, p._t2v_wg_seen = None, 0, None, 0, 0
         raise
     _WG_BATCH[0] = False
     _DW_PAIR[0] = False
@@ -745,13 +766,13 @@ class _ConvBlock(torch.autograd.Function):
                 pass
             elif sl_w is not None:
                 with (wgrad_fork(x, dc) if wgrad_stream_on(x) else contextlib.nullcontext()):
-                    dwp = ops.conv2d_backward_weight(x, dc, fdesc)
+                    dwp = direct_weight_gradient(x, dc, fdesc)
                     ops.unpack_conv_weight_into(dwp, fdesc, x.shape[-1], sl_w.view, sl_w.filled)
                 sl_w.filled = True
                 sl_w.owner.node_done(sl_w)
                 dw = None
             else:
-                dw = ops.unpack_conv_weight(ops.conv2d_backward_weight(x, dc, fdesc), fdesc, x.shape[-1])
+                dw = ops.unpack_conv_weight(direct_weight_gradient(x, dc, fdesc), fdesc, x.shape[-1])
         dx = None
         xcs_ = x.shape[-1]
         if need_dx and wino_wgrad == 2 and want[1] and len(wg_info) == 3 and dgrad_t:
