@@ -521,14 +521,20 @@ def train_block(dev, dist_mod, world, rank, backend, steps, iters, ngf=128, cloc
     block = None
     if rank == 0:
         # ---- the step's heaviest kernels, live (HIP events on the launch stream), on the FLOPs they execute ----
+        kclk = []      # the core clock during each kernel's loop (a sagging clock and a slow kernel read differently)
+
         def ev_time(fn):
+            import contextlib
             warm_clocks(lambda i: fn())
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(iters):
-                fn()
-            e1.record()
-            torch.cuda.synchronize()
+            samp = clocks.fork(0.01) if clocks is not None else None
+            with (samp if samp is not None else contextlib.nullcontext()):
+                e0.record()
+                for _ in range(iters):
+                    fn()
+                e1.record()
+                torch.cuda.synchronize()
+            kclk.append(samp.mean_mhz() if samp is not None else None)
             return e0.elapsed_time(e1) / iters
         C = 1024
         desc = ops.conv_desc(64, 64, C, C, 3, 1, 1, ops.PAD_REFLECT)
@@ -570,7 +576,7 @@ def train_block(dev, dist_mod, world, rank, backend, steps, iters, ngf=128, cloc
                               "replicas_in_sync": in_sync},
                  "losses": {k: round(float(v), 3) for k, v in losses.items() if k in ("G_GAN", "G_GAN_Feat", "D", "D_f")},
                  "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
-                 "kernels": kernels}
+                 "kernels": [dict(k, sclk_mhz=c) for k, c in zip(kernels, kclk)]}
     del tr
     torch.cuda.empty_cache()
     if own_group:

@@ -380,3 +380,41 @@ def test_chunk_plan_on_one_gpu_equals_the_two_rank_chunk_plan(tmp_path):
     assert all(two[k] == cpr[k] for k in two)                       # the same chunks, the same frames
     assert any(one[k] != cpr[k] for k in one)                       # ... which restart the recurrence at the cut
     assert all(one[k] == st[k] for k in one)                        # stitched over the whole chunk: the unsharded sequence
+
+
+def test_stitch_pass_with_a_two_scale_generator_reproduces_the_unsharded_run(tmp_path):
+    """configs[2] x configs[3]: `test.py --n_scales_spatial 2 --shard_chunks --chunks_per_rank 2 --stitch_frames
+    <chunk length>` -- the generator keeps one FIFO per pyramid level, the stitch pass's tail carries both
+    (distributed.pack_state) -- writes the files of the unsharded two-scale run, byte for byte; without the stitch pass the
+    frames after the cut differ."""
+    import glob
+    import shutil
+    from PIL import Image
+    from text2video_amd.keypoints import read_keypoints
+    src = os.path.join(ROOT, "tests", "golden", "keypoints_fadg0")
+    files = sorted(f for f in os.listdir(src) if f.startswith("sa1_"))
+    env = _plain_env()
+
+    def work(name):
+        w = str(tmp_path / name)
+        root = os.path.join(w, "datasets", "fadg0")
+        os.makedirs(os.path.join(root, "test_openpose", "tmp"))
+        os.makedirs(os.path.join(root, "test_img", "tmp"))
+        img = Image.fromarray(read_keypoints(os.path.join(src, files[0]), (128, 96)))
+        for i in range(12):
+            shutil.copyfile(os.path.join(src, files[(i * 5 + 3) % len(files)]), os.path.join(root, "test_openpose", "tmp", "%05d.json" % i))
+            img.save(os.path.join(root, "test_img", "tmp", "%04d.jpg" % i))
+        return w
+
+    def frames(w):
+        return {os.path.relpath(p, w): open(p, "rb").read()
+                for p in sorted(glob.glob(os.path.join(w, "results", "fadg0", "test_latest", "*", "fake_B_*.jpg")))}
+    two = ["--n_scales_spatial", "2", "--n_blocks_local", "1"]
+    ws = {k: work(k) for k in ("single", "chunks", "stitched")}
+    _run_test_py(ws["single"], two, env)
+    _run_test_py(ws["chunks"], two + ["--shard_chunks", "--chunks_per_rank", "2"], env)
+    _run_test_py(ws["stitched"], two + ["--shard_chunks", "--chunks_per_rank", "2", "--stitch_frames", "100"], env)
+    one, ch, st = (frames(ws[k]) for k in ("single", "chunks", "stitched"))
+    assert len(one) == 10 and one.keys() == ch.keys() == st.keys()
+    assert any(one[k] != ch[k] for k in one)          # the chunk restarts both levels' recurrences at the cut
+    assert all(one[k] == st[k] for k in one)          # ... the stitch pass carries both levels' tails across it
