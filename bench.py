@@ -649,7 +649,7 @@ def run_e2e(model_head, model_other, head_flow, n_frames):
                 meta["pose_workers"], meta["frames_per_run"] = workers, stats["frames"]
         finally:
             shutil.rmtree(tmp, ignore_errors=True)
-    return dict({"path": "run_test == vid2vid/test.py: rasterise (bit-exact) -> H2D -> generator -> D2H -> JPEG", "runs": out}, **meta)
+    return dict({"path": "vid2vid/test.py loop: rasterise (bit-exact) -> H2D -> generator -> D2H -> JPEG", "runs": out}, **meta)
 
 
 UTTERANCE = "She had your dark suit in greasy wash water all year."      # configs[0] (BASELINE.json), fixture tests/golden/l2_inputs
@@ -731,7 +731,7 @@ def utterance_block(tmp, ckpt_dir, env):
         subprocess.run([sys.executable, os.path.join(ROOT, "vid2vid", "test.py")] + flags + ["--resident_stop"], cwd=v2v,
                        env=dict(env, **renv), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     last = runs[-1]
-    return {"what": "text2video_audio.sh:24-44 after the aligner, configs[0] utterance: L2 driver | test.py | image2video as 3 processes",
+    return {"what": "text2video_audio.sh:24-44 on the configs[0] utterance: L2 driver | test.py | image2video, 3 processes",
             "frames": frames, "videos": len(videos), "chain_runs": runs, "chain_wall_s": last["wall_s"],
             "l2_plus_mux_s": round(last["l2_driver_s"] + last["mux_s"], 3),
             "l2_plus_mux_below_test_py": bool(last["l2_driver_s"] + last["mux_s"] < last["test_py_s"]),
@@ -1089,7 +1089,7 @@ def main():
         for nb, el in batch_elapsed.items():
             variants["batch%d_fps" % nb] = round(world * nb * K / el, 3)
         if batch_elapsed:
-            variants["batch_note"] = "batch<N>_fps: N sequences per GPU in lock-step, aggregate; frames bit-equal"
+            variants["batch_note"] = "batch<N>_fps: N sequences in lock-step, aggregate"
         variants["headline"] = "flow" if head_flow else "noflow"
         variants["note"] = "both variants timed in this run over K steps; `value` = headline"
         result = {
