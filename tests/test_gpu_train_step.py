@@ -488,7 +488,8 @@ def test_shared_discriminator_forward_equals_the_two_forward_form(t2v_env):
         assert n1 == n2 and torch.equal(m1, m2) and torch.equal(v1, v2)
 
 
-def test_batched_discriminator_passes_and_one_launch_loss_terms_equal_the_pass_by_pass_step(t2v_env):
+@pytest.mark.parametrize("extra", [[], ["--no_flow", "--norm", "instance", "--no_ganFeat"]], ids=["flow_batchnorm", "noflow_instancenorm_noFM"])
+def test_batched_discriminator_passes_and_one_launch_loss_terms_equal_the_pass_by_pass_step(t2v_env, extra):
     """Round 6 (default path): every discriminator runs its real / fake / raw passes as ONE batch per layer -- BatchNorm
     statistics per pass -- and all LSGAN / feature-matching terms are one launch that also writes the gradient seeds both
     backward passes start from (train.LossBook, t2v_loss_terms).  Against the pass-by-pass step with the scalar graph on
@@ -499,14 +500,15 @@ def test_batched_discriminator_passes_and_one_launch_loss_terms_equal_the_pass_b
     from text2video_amd.options import TrainOptions
     opt = TrainOptions().parse(["--name", "t", "--dataset_mode", "pose", "--input_nc", "3", "--openpose_only", "--ngf", "16",
                                 "--n_downsample_G", "2", "--n_blocks", "2", "--num_D", "2", "--ndf", "16", "--no_vgg",
-                                "--max_frames_per_gpu", "2", "--n_scales_temporal", "1", "--no_first_img", "--add_face_disc"])
+                                "--max_frames_per_gpu", "2", "--n_scales_temporal", "1", "--no_first_img", "--add_face_disc"] + extra)
+    # (second case: two passes per discriminator instead of three, statistics per image, no feature-matching terms)
     H, W = 64, 128
     rng = np.random.default_rng(21)
     pose = torch.zeros(2, H, W, 12, device="cuda:0")
     pose[..., :9] = torch.from_numpy(rng.uniform(-1, 1, (2, H, W, 9)).astype(np.float32)).cuda()
     real = torch.zeros(2, H, W, 4, device="cuda:0")
     real[..., :3] = torch.tanh(torch.from_numpy(rng.standard_normal((2, H, W, 3)).astype(np.float32))).cuda()
-    real_prev = torch.cat([real[1:], real[:1]], 0).contiguous()
+    real_prev = torch.cat([real[1:], real[:1]], 0).contiguous() if not extra else None
     boxes = [(8, 40, 40, 72)] * 2
     runs = {}
     for mode in ("1", "0"):
@@ -526,6 +528,7 @@ def test_batched_discriminator_passes_and_one_launch_loss_terms_equal_the_pass_b
         runs[mode] = (out, [(s[0].clone(), s[1].clone(), s[2]) for s in stats if s is not None])
     (a, sa), (b, sb) = runs["1"], runs["0"]
     assert "D_T0" in a[1][0] and "D_f" in a[1][0] and "G_f_GAN_Feat" in a[1][0]
+    assert (a[1][0]["G_f_GAN_Feat"] == 0.0) == bool(extra)         # (--no_ganFeat: reported as 0 by both forms)
     for (la, ga), (lb, gb) in zip(a, b):
         assert list(la.keys()) == list(lb.keys()), (list(la), list(lb))
         for k in la:
@@ -534,7 +537,7 @@ def test_batched_discriminator_passes_and_one_launch_loss_terms_equal_the_pass_b
         for i, (x, y) in enumerate(zip(ga, gb)):
             d = (x - y).norm().item() / max(y.norm().item(), 1e-30)
             assert d <= 5e-5, (i, tuple(x.shape), d)       # (seeds rounded once on the host instead of through a chain of fp32 products)
-    assert len(sa) == len(sb) > 4
+    assert len(sa) == len(sb) and (len(sa) > 4 or extra)        # (no running statistics without affine norms)
     for (m1, v1, n1), (m2, v2, n2) in zip(sa, sb):
         assert n1 == n2 and torch.equal(m1, m2) and torch.equal(v1, v2)
 

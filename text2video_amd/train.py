@@ -1236,11 +1236,12 @@ class LossBook:
         self.dev = torch.device(device)
         self.terms = []
         self.out = None
+        self.zero_names = []      # named terms that are switched off in this step: reported as 0.0
         self._host = self._devb = self._part = None
         self._pending = None
 
     def reset(self):
-        self.terms, self.out = [], None
+        self.terms, self.out, self.zero_names = [], None, []
 
     def mse(self, name, x, target, weight, seed=None):
         """weight * mean((x[..., 0] - target)^2): x a contiguous [.., cs] block of logit rows (LSGAN; THCUNN.h:356); seed (same
@@ -1855,6 +1856,8 @@ class Vid2VidTrainer:
         num_D = len(feats)
         fm_w = 0.0 if opt.no_ganFeat else (1.0 / num_D) * (4.0 / (opt.n_layers_D + 1)) * opt.lambda_feat * face_weight
         tG, sG, tD, sD = [], [], [], []
+        if not fm_w:
+            book.zero_names.append(n_feat)        # (--no_ganFeat: the term is reported as 0, as the pass-by-pass form does)
         for st in feats:
             logits = st[-1]
             gG, gD = torch.empty_like(logits), torch.empty_like(logits)
@@ -1956,6 +1959,8 @@ class Vid2VidTrainer:
         self.optD.step()
         losses = book.read({k: v for k, v in extra.items() if torch.is_tensor(v)})      # (the step's one host read)
         losses.update({k: float(v) for k, v in extra.items() if not torch.is_tensor(v)})
+        for k in book.zero_names:
+            losses.setdefault(k, 0.0)
         ops.check_async_errors()      # (the read-back above synchronised: errors the step's kernels could only flag)
         # (reported in the order the one-term-per-launch path reports them)
         order = ["G_GAN", "G_GAN_Feat", "D", "G_VGG", "F_Flow", "F_Warp", "W", "G_Warp", "G_f_GAN", "G_f_GAN_Feat", "D_f"] + \
