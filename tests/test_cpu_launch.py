@@ -134,6 +134,8 @@ WEDGE_SCRIPT = textwrap.dedent("""
         t = torch.ones(1)
         dist.all_reduce(t)
         print("rank %%d done %%g" %% (rank, float(t)), flush=True)
+        dist.barrier()
+        dist.destroy_process_group()       # (leaving with a live group aborts now and then at interpreter exit)
 
     D.fail_loudly(main)
 """) % ROOT

@@ -64,8 +64,14 @@ def init_group(backend, rank, world, device=None):
     td = datetime.timedelta(seconds=t)
     addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
     port = int(os.environ.get("MASTER_PORT", "29500"))
+    # under torchrun the elastic agent already serves a store on MASTER_PORT (TORCHELASTIC_USE_AGENT_STORE): every rank is
+    # a client of it, under the per-attempt prefix torch's own env:// rendezvous uses; started by launch.py (or by hand),
+    # rank 0 hosts the store
+    agent = os.environ.get("TORCHELASTIC_USE_AGENT_STORE", "") == "True"
     try:
-        store = dist.TCPStore(addr, port, world, is_master=(rank == 0), timeout=td, wait_for_workers=False)
+        store = dist.TCPStore(addr, port, world, is_master=(rank == 0 and not agent), timeout=td, wait_for_workers=False)
+        if agent:
+            store = dist.PrefixStore("/worker/attempt_%s/t2v" % os.environ.get("TORCHELASTIC_RESTART_COUNT", "0"), store)
     except Exception as e:      # noqa: BLE001 -- rank 0 (the store's host) never came up, or the port is not reachable
         raise RankFailure("rank %d of %d: no rendezvous store at %s:%d within %.0f s -- rank(s) [0] did not start, or the "
                           "address is unreachable (%s)" % (rank, world, addr, port, t, type(e).__name__)) from e
@@ -96,6 +102,17 @@ def rendezvous(tag, timeout_s=None):
     n = _RDV_SEQ[tag] = _RDV_SEQ.get(tag, 0) + 1
     _roll_call(_STORE[0], "%s/%d" % (tag, n), dist.get_rank(), dist.get_world_size(),
                dist_timeout_s() if timeout_s is None else float(timeout_s))
+
+
+def leave_group():
+    """The orderly end of a rank of a multi-rank job: roll call (everybody has finished), then tear the group down.  Leaving
+    the interpreter with a live process group aborts now and then in the backends' own threads (`terminate called without an
+    active exception`, status -6) -- which the launcher would report as a failed job."""
+    if dist.is_available() and dist.is_initialized():
+        if dist.get_world_size() > 1:
+            rendezvous("done")
+        dist.destroy_process_group()
+        _STORE[0] = None
 
 
 def fail_loudly(fn, *args, **kw):

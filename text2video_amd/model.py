@@ -366,4 +366,7 @@ def run_test(opt, model=None, device=None, dataset=None):
     if opt.timing_json:
         with open(opt.timing_json, "w") as fh:
             json.dump(stats, fh)
+    if plan is not None and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        from . import distributed as D
+        D.leave_group()
     return stats

@@ -2354,4 +2354,6 @@ def run_train(opt, steps=None):
                   flush=True)
     if rank == 0:      # the final (or step-capped) save carries its position too
         trainer.save("latest", last_pos)
+    if world > 1:
+        Dm.leave_group()
     return {"ms_per_step": 1e3 * float(np.median(stats)) if stats else 0.0, "steps": it, "world": world}
