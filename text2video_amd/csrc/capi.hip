@@ -49,6 +49,7 @@ void options_reload() {
     o.chain_lazy = env_int("T2V_CHAIN_LAZY", 1);
     o.streams = env_int("T2V_STREAMS", 0);
     o.conv_tile = env_int("T2V_CONV_TILE", 0);
+    o.xcd_slices = env_int("T2V_XCD_SLICES", 1);
     g_opts = o;
 }
 const Options& options() {

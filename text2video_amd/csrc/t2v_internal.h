@@ -50,6 +50,8 @@ struct Options {
     int conv_tile;           // T2V_CONV_TILE (measurement): 1 = keep the 128x128 tile where the fill rule would take 64x64, 2 = always 64x64
     int streams;             // T2V_STREAMS: 1 = the generator on the caller's stream only, 2 = always two streams; 0 (default):
                              // two, except the global generator on a bottleneck of >= 1024 Winograd tiles (1024x1024 frames)
+    int xcd_slices;          // T2V_XCD_SLICES: overlap-reading transforms give every XCD its own channel slices (default 1; 0 = the
+                             // flat thread index: the A/B twin, same bits)
 };
 const Options& options();
 // true while the calling thread has announced a second stream beside its launches (t2v_set_overlap_hint; the generator's

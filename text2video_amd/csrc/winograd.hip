@@ -332,7 +332,7 @@ int launch_winograd4_weight(hipStream_t s, const float* w, float* U, int Cout, i
 // (its own T plus the zero rows that pad the whole matrix up to Tt).  Two layouts: slots of Tp rows per image (the weight
 // gradient's batch workspace: img_tiles = last_tiles = Tp) and packed (a forward batch: image i owns rows [i*T, (i+1)*T), only
 // the total is padded -- two 160-tile images are 320 GEMM rows per position, not 2 x 192).
-template <int MODE>
+template <int MODE, bool XCD = false>
 __global__ __launch_bounds__(256) void winograd4_input_kernel(const float2* __restrict__ x, float2* __restrict__ V, int H,
                                                               int W, int C2, int TW, int T, int img_tiles, int pad, int reflect,
                                                               int Tt, int t0, const float2* __restrict__ mean_rstd,
@@ -353,15 +353,12 @@ __global__ __launch_bounds__(256) void winograd4_input_kernel(const float2* __re
             xout += im * img_stride;
         }
     }
-    const long total = (long)(blockIdx.y == gridDim.y - 1 ? last_tiles : img_tiles) * C2;
-    const long stride = (long)gridDim.x * blockDim.x;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-        const long tile = i / C2;
-        const int c2 = (int)(i - tile * C2);
+    const int ntiles = blockIdx.y == gridDim.y - 1 ? last_tiles : img_tiles;
+    auto item = [&](const long tile, const int c2) {
         if (tile >= T) {   // padding tiles: zeros
 #pragma unroll
             for (int xi = 0; xi < 36; ++xi) V[((long)xi * Tt + t0 + tile) * C2 + c2] = make_float2(0.f, 0.f);
-            continue;
+            return;
         }
         const int ty = (int)(tile / TW), tx = (int)(tile - (long)ty * TW);
         int ry[6], rx[6];
@@ -441,7 +438,30 @@ __global__ __launch_bounds__(256) void winograd4_input_kernel(const float2* __re
             for (int a2 = 0; a2 < 6; ++a2)
                 V[((long)(a2 * 6 + j) * Tt + t0 + tile) * C2 + c2] = make_float2(cdot<6>(f4::kBT[a2], cx), cdot<6>(f4::kBT[a2], cy));
         }
+    };
+    if constexpr (XCD) {
+        // XCD x owns the channel slices {x, x + 8, ..} of 64 pairs for ALL tiles (C2 % 512 == 0): the up to four tiles whose
+        // 6x6 patches share an input pixel read it through one L2 instead of through the fabric from four XCDs (block b runs on
+        // XCD b % 8: observed, relied on for speed only).  A wave = one tile x one slice; the same arithmetic per item
+        const long it = (long)(blockIdx.x >> 3) * 4 + (threadIdx.x >> 6);
+        if (it < (long)(C2 >> 9) * ntiles) {
+            const int sl = (int)(it / ntiles);
+            item(it - (long)sl * ntiles, ((sl << 3) + (int)(blockIdx.x & 7)) * 64 + (int)(threadIdx.x & 63));
+        }
+    } else {
+        const long total = (long)ntiles * C2;
+        const long stride = (long)gridDim.x * blockDim.x;
+        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+            const long tile = i / C2;
+            item(tile, (int)(i - tile * C2));
+        }
     }
+}
+// grid.x of the XCD form for `tiles` tiles of C2 channel pairs (0: the shape does not take it)
+static inline unsigned xcd_slice_grid(long tiles, int C2) {
+    if (C2 % 512 || !options().xcd_slices) return 0;
+    const long g = (((long)(C2 >> 9) * tiles + 3) / 4) * 8;
+    return g <= 0x7fffffffL ? (unsigned)g : 0;
 }
 // Slot layout (the weight gradient's batch workspace): the image at `x` goes to slot `image` of a V sized for `batch`
 // slots of Tp rows.  Packed layout (nimg > 0: a forward batch): the nimg images starting at `x` (img_stride floats apart)
@@ -454,7 +474,10 @@ int launch_winograd4_input(hipStream_t s, const float* x, float* V, int H, int W
     const int n = packed ? nimg : 1;
     const int Tt = packed ? wino_pad_tiles(n * T) : batch * Tp;
     const int img_tiles = packed ? T : Tp, last_tiles = packed ? Tt - (n - 1) * T : Tp, t0 = packed ? 0 : image * Tp;
-    hipLaunchKernelGGL(winograd4_input_kernel<0>, dim3(wg_grid((long)(last_tiles > img_tiles ? last_tiles : img_tiles) * (C / 2), 256), n),
+    const long most = last_tiles > img_tiles ? last_tiles : img_tiles;
+    const unsigned xg = xcd_slice_grid(most, C / 2);
+    auto kern = xg ? winograd4_input_kernel<0, true> : winograd4_input_kernel<0, false>;
+    hipLaunchKernelGGL(kern, dim3(xg ? xg : wg_grid(most * (C / 2), 256), n),
                        dim3(256), 0, s, reinterpret_cast<const float2*>(x), reinterpret_cast<float2*>(V), H, W, C / 2, TW, T,
                        img_tiles, pad, reflect, Tt, t0, nullptr, nullptr, nullptr, nullptr, nullptr, img_stride / 2, last_tiles);
     T2V_HIP_CHECK(hipGetLastError());
@@ -471,8 +494,10 @@ int launch_winograd4_input_lazy(hipStream_t s, const float* x, float* V, int H, 
     const int Ho = H + 2 * pad - 2, Wo = W + 2 * pad - 2;
     const int TW = (Wo + 3) / 4, T = ((Ho + 3) / 4) * TW;
     const int Tt = wino_pad_tiles(nimg * T), last_tiles = Tt - (nimg - 1) * T;      // packed layout
-    auto kern = relu_only ? winograd4_input_kernel<1> : winograd4_input_kernel<2>;
-    hipLaunchKernelGGL(kern, dim3(wg_grid((long)last_tiles * (C / 2), 256), nimg), dim3(256), 0, s,
+    const unsigned xg = xcd_slice_grid(last_tiles, C / 2);      // (last_tiles >= T: the image with the padding rows walks the most)
+    auto kern = xg ? (relu_only ? winograd4_input_kernel<1, true> : winograd4_input_kernel<2, true>)
+                   : (relu_only ? winograd4_input_kernel<1, false> : winograd4_input_kernel<2, false>);
+    hipLaunchKernelGGL(kern, dim3(xg ? xg : wg_grid((long)last_tiles * (C / 2), 256), nimg), dim3(256), 0, s,
                        reinterpret_cast<const float2*>(x), reinterpret_cast<float2*>(V), H, W, C / 2, TW, T, T, pad, reflect, Tt, 0,
                        reinterpret_cast<const float2*>(mean_rstd), reinterpret_cast<const float2*>(gamma),
                        reinterpret_cast<const float2*>(beta), reinterpret_cast<const float2*>(res),
@@ -595,38 +620,65 @@ __device__ __forceinline__ void dgrad_gather_tile(const float2* __restrict__ dV,
     }
 }
 
+// One (padded 4x4 block, channel pair) item: gather from the up to four patches that cover it, write the 16 padded pixels.
+__device__ __forceinline__ void dgrad_output_item(const float2* __restrict__ dV, float2* __restrict__ dxp, int H, int W, int C2,
+                                                  int TH, int TW, int Tp, int by, int bx, int c2) {
+    float ox[4][4], oy[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ox[r][q] = oy[r][q] = 0.f;
+    if (by < TH && bx < TW) dgrad_gather_tile<0, 0>(dV, (long)by * TW + bx, Tp, C2, c2, ox, oy);
+    if (by < TH && bx >= 1) dgrad_gather_tile<0, 1>(dV, (long)by * TW + bx - 1, Tp, C2, c2, ox, oy);
+    if (by >= 1 && bx < TW) dgrad_gather_tile<1, 0>(dV, (long)(by - 1) * TW + bx, Tp, C2, c2, ox, oy);
+    if (by >= 1 && bx >= 1) dgrad_gather_tile<1, 1>(dV, (long)(by - 1) * TW + bx - 1, Tp, C2, c2, ox, oy);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int py = 4 * by + r, px = 4 * bx + q;
+            if (py < H + 2 && px < W + 2) dxp[((long)py * (W + 2) + px) * C2 + c2] = make_float2(ox[r][q], oy[r][q]);
+        }
+}
+// XCD = true (C2 a multiple of 512, launch_winograd4_dgrad_output): every element of dV is read by the four padded blocks its
+// patch overlaps.  With a thread index that runs over (block, channel pair) those four readers are workgroups on four different
+// XCDs (block b runs on XCD b % 8 -- observed, relied on for speed only), each pulling the line through the fabric into its own
+// L2: 4 x 37.7 MB per 1024-channel 64x64 layer.  Here XCD x owns the channel slices {x, x + 8, ...} of 64 pairs (512 contiguous
+// bytes per (position, tile)) for ALL blocks: the four readers of a line sit on one XCD, three of them hit its L2 (reuse distance
+// one row of tiles, 0.3 MB per slice).  A wave = one padded block x one slice; the arithmetic per item is the same: same bits.
+template <bool XCD>
 __global__ __launch_bounds__(256) void winograd4_dgrad_output_kernel(const float2* __restrict__ dV, float2* __restrict__ dxp,
                                                                      int H, int W, int C2, int TH, int TW, int Tp) {
-    const long total = (long)(TH + 1) * (TW + 1) * C2;
-    const long stride = (long)gridDim.x * blockDim.x;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-        const long blk = i / C2;
-        const int c2 = (int)(i - blk * C2);
-        const int by = (int)(blk / (TW + 1)), bx = (int)(blk - (long)by * (TW + 1));
-        float ox[4][4], oy[4][4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) ox[r][q] = oy[r][q] = 0.f;
-        if (by < TH && bx < TW) dgrad_gather_tile<0, 0>(dV, (long)by * TW + bx, Tp, C2, c2, ox, oy);
-        if (by < TH && bx >= 1) dgrad_gather_tile<0, 1>(dV, (long)by * TW + bx - 1, Tp, C2, c2, ox, oy);
-        if (by >= 1 && bx < TW) dgrad_gather_tile<1, 0>(dV, (long)(by - 1) * TW + bx, Tp, C2, c2, ox, oy);
-        if (by >= 1 && bx >= 1) dgrad_gather_tile<1, 1>(dV, (long)(by - 1) * TW + bx - 1, Tp, C2, c2, ox, oy);
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int py = 4 * by + r, px = 4 * bx + q;
-                if (py < H + 2 && px < W + 2) dxp[((long)py * (W + 2) + px) * C2 + c2] = make_float2(ox[r][q], oy[r][q]);
-            }
+    if constexpr (XCD) {
+        const int nblk = (TH + 1) * (TW + 1), spx = C2 >> 9;          // slices per XCD
+        const int xcd = blockIdx.x & 7;
+        const long item = (long)(blockIdx.x >> 3) * 4 + (threadIdx.x >> 6);
+        if (item >= (long)spx * nblk) return;
+        const int sl = (int)(item / nblk), blk = (int)(item - (long)sl * nblk);
+        const int by = blk / (TW + 1), bx = blk - by * (TW + 1);
+        dgrad_output_item(dV, dxp, H, W, C2, TH, TW, Tp, by, bx, ((sl << 3) + xcd) * 64 + (threadIdx.x & 63));
+    } else {
+        const long total = (long)(TH + 1) * (TW + 1) * C2;
+        const long stride = (long)gridDim.x * blockDim.x;
+        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+            const long blk = i / C2;
+            const int c2 = (int)(i - blk * C2);
+            const int by = (int)(blk / (TW + 1)), bx = (int)(blk - (long)by * (TW + 1));
+            dgrad_output_item(dV, dxp, H, W, C2, TH, TW, Tp, by, bx, c2);
+        }
     }
 }
 // dV [36][Tp][C] of an H x W map (H, W multiples of 4, pad 1) -> dxp [(H+2)][(W+2)][C]
 int launch_winograd4_dgrad_output(hipStream_t s, const float* dV, float* dxp, int H, int W, int C) {
     T2V_REQUIRE(H % 4 == 0 && W % 4 == 0 && C % 2 == 0, "winograd4_dgrad_output: H, W must be multiples of 4");
-    const int TH = H / 4, TW = W / 4, Tp = wino_pad_tiles(TH * TW);
-    hipLaunchKernelGGL(winograd4_dgrad_output_kernel, dim3(wg_grid((long)(TH + 1) * (TW + 1) * (C / 2), 256)), dim3(256), 0, s,
-                       reinterpret_cast<const float2*>(dV), reinterpret_cast<float2*>(dxp), H, W, C / 2, TH, TW, Tp);
+    const int TH = H / 4, TW = W / 4, Tp = wino_pad_tiles(TH * TW), C2 = C / 2;
+    const long per_xcd = ((long)(C2 >> 9) * (TH + 1) * (TW + 1) + 3) / 4;
+    if (C2 % 512 == 0 && options().xcd_slices && per_xcd * 8 <= 0x7fffffffL)
+        hipLaunchKernelGGL(winograd4_dgrad_output_kernel<true>, dim3((unsigned)(per_xcd * 8)), dim3(256), 0, s,
+                           reinterpret_cast<const float2*>(dV), reinterpret_cast<float2*>(dxp), H, W, C2, TH, TW, Tp);
+    else
+        hipLaunchKernelGGL(winograd4_dgrad_output_kernel<false>, dim3(wg_grid((long)(TH + 1) * (TW + 1) * C2, 256)), dim3(256), 0,
+                           s, reinterpret_cast<const float2*>(dV), reinterpret_cast<float2*>(dxp), H, W, C2, TH, TW, Tp);
     T2V_HIP_CHECK(hipGetLastError());
     return T2V_OK;
 }
