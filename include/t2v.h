@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define T2V_ABI_VERSION 17
+#define T2V_ABI_VERSION 18
 
 typedef enum {
     T2V_OK = 0,
@@ -85,6 +85,12 @@ int t2v_fixed_grid_enabled(void);
  * 256x128 tiles with one block per CU instead of 128x128 with two -- slower alone, faster in a two-stream frame).  Per calling
  * thread; returns the previous value.  t2v_generator_forward[_batch] sets it for its own launches; a caller that overlaps
  * single-op calls itself (or wants t2v_conv_winograd_gemm_form to answer for the generator's frames) sets it explicitly.
+ * on == 2 (ABI 18): the second stream carries fixed-grid GEMMs of its OWN (the train step's weight gradients beside its data
+ * gradients): the whole-tile fixed-grid GEMM and the Winograd-domain weight gradient then launch ONE 128x128 block per CU
+ * (half a CU's LDS and registers each) instead of two, so that the two streams' launches -- and the bandwidth-bound kernels
+ * between two GEMMs -- are resident side by side instead of queueing behind a grid that keeps every CU full until its last
+ * block leaves.  The tile forms chosen are those of on == 0; the results carry the same bits.  T2V_SK_BLOCKS_PER_CU=1 / 2
+ * forces one / two per CU whatever the hint.
  * (THCUNN has no counterpart: its ops run on the one current stream of THCState.) */
 int t2v_set_overlap_hint(int on);
 /* Test hook: raise != 0 sets the sticky error word exactly as a timed-out consumer wave would; raise == 0 clears it and

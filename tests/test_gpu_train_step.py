@@ -582,7 +582,7 @@ def test_weight_gradients_on_the_side_stream_leave_the_step_unchanged(t2v_env):
     assert all(torch.equal(x, y) for x, y in zip(runs["1"][1], runs["0"][1]))
 
 
-def test_train_step_with_the_fixed_grid_kernels_forced_is_bit_identical(t2v_env):
+def test_train_step_with_the_fixed_grid_kernels_forced_is_bit_identical(t2v_env, monkeypatch):
     """Both fixed-grid kernels (Winograd GEMM stage in the forward convs and the transposed data gradient; Winograd-domain
     weight-gradient reduction) forced on at a size whose tile counts are far below the grid -- short runs, many blocks idle,
     every tile whole or cut once -- against one block per tile: losses and updated weights bit for bit."""
@@ -599,18 +599,27 @@ def test_train_step_with_the_fixed_grid_kernels_forced_is_bit_identical(t2v_env)
     real[..., :3] = torch.tanh(torch.from_numpy(rng.standard_normal((2, H, W, 3)).astype(np.float32))).cuda()
     real_prev = torch.cat([real[1:], real[:1]], 0).contiguous()
     runs = {}
-    for mode in ("2", "0"):
-        t2v_env("T2V_WINO_GEMM_SK", mode)
-        t2v_env("T2V_WGRAD_SK", mode)
+    hints = []
+    real_hint = T.ops.set_overlap_hint
+    monkeypatch.setattr(T.ops, "set_overlap_hint", lambda on: (hints.append(on), real_hint(on))[1])
+    # "2": forced, and from the step's first side-stream weight gradient on ONE block per CU (overlap hint 2: the two streams'
+    # fixed-grid launches resident side by side); "2 two-per-CU": forced, two per CU throughout; "0": one block per tile
+    for mode in ("2", "2 two-per-CU", "0"):
+        t2v_env("T2V_WINO_GEMM_SK", mode[0])
+        t2v_env("T2V_WGRAD_SK", mode[0])
+        t2v_env("T2V_TRAIN_SK_HINT", "0" if "two-per-CU" in mode else "1")
+        del hints[:]
         tr = T.Vid2VidTrainer(opt, "cuda:0", seed=9)
         prev, ls = None, []
         for _ in range(2):
             l, prev = tr.train_step(pose, real, None, prev, real_prev=real_prev)
             ls.append(l)
         runs[mode] = (ls, [p.detach().clone() for n in (tr.G, tr.D) for p in n.parameters()])
-    for la, lb in zip(runs["2"][0], runs["0"][0]):
-        assert la.keys() == lb.keys() and all(la[k] == lb[k] for k in la), [(k, la[k], lb[k]) for k in la if la[k] != lb[k]]
-    assert all(torch.equal(x, y) for x, y in zip(runs["2"][1], runs["0"][1]))
+        assert (2 in hints) == ("two-per-CU" not in mode) and hints[-1] == 0      # raised inside the step, lowered at its end
+    for other in ("2 two-per-CU", "0"):
+        for la, lb in zip(runs["2"][0], runs[other][0]):
+            assert la.keys() == lb.keys() and all(la[k] == lb[k] for k in la), [(k, la[k], lb[k]) for k in la if la[k] != lb[k]]
+        assert all(torch.equal(x, y) for x, y in zip(runs["2"][1], runs[other][1]))
 
 
 

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("T2V_LIBRARY") or os.path.join(_HERE, "lib", "libt2v_h
 T2V_OK = 0
 PAD_ZERO, PAD_REFLECT = 0, 1
 ACT_NONE, ACT_TANH, ACT_FLOW_W, ACT_LRELU = 0, 1, 2, 3
-ABI_VERSION = 17
+ABI_VERSION = 18
 MAX_BATCH = 8     # T2V_MAX_BATCH
 ALGO_DIRECT, ALGO_WINOGRAD, ALGO_WINOGRAD_F4, ALGO_POLYPHASE = 0, 1, 2, 3
 

@@ -34,10 +34,15 @@ static int env_int(const char* name, int dflt) {
 static thread_local int g_overlap = 0;
 int set_overlap_hint(int on) {
     const int prev = g_overlap;
-    g_overlap = on ? 1 : 0;
+    g_overlap = on == 2 ? 2 : (on ? 1 : 0);
     return prev;
 }
-bool overlap_hint() { return g_overlap != 0 && options().overlap_hint != 0; }
+bool overlap_hint() { return g_overlap == 1 && options().overlap_hint != 0; }
+int sk_launch_blocks() {
+    const int two = wino_gemm_sk_grid_blocks(), mode = options().sk_blocks_per_cu;
+    const bool one = mode == 1 || (mode == 0 && g_overlap == 2 && options().overlap_hint != 0);
+    return one && two % 16 == 0 ? two / 2 : two;
+}
 void options_reload() {
     Options o;
     o.wino_gemm_sk = env_int("T2V_WINO_GEMM_SK", 1);
@@ -50,6 +55,7 @@ void options_reload() {
     o.streams = env_int("T2V_STREAMS", 0);
     o.conv_tile = env_int("T2V_CONV_TILE", 0);
     o.xcd_slices = env_int("T2V_XCD_SLICES", 1);
+    o.sk_blocks_per_cu = env_int("T2V_SK_BLOCKS_PER_CU", 0);
     g_opts = o;
 }
 const Options& options() {

@@ -1153,7 +1153,7 @@ int launch_wino_gemm_sk(hipStream_t s, const SkGemm& g) {
     const int bm = sk_tile_rows(g.T, g.N), bn = bm == 128 ? 128 : 64;
     k.mtiles_g = g.T / bm; k.ntiles = g.N / bn; k.nk = g.K / kBK;
     k.tiles = g.groups * k.mtiles_g * k.ntiles;
-    const int grid = wino_gemm_sk_grid_blocks();
+    const int grid = sk_launch_blocks();      // (one block per CU while the caller's second stream runs fixed-grid GEMMs of its own)
     k.blocks_per_xcd = grid / 8;
     k.tiles_per_xcd = (k.tiles + 7) / 8;
     k.rounds = sk_half_round(k.tiles, grid, k.nk) ? (int)(k.tiles / grid) : 0;

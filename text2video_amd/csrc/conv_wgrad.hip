@@ -598,7 +598,7 @@ int launch_wino_wgrad_sk(hipStream_t s, const float* V, const float* Md, float* 
     k.Tt = Tt; k.Cin = Cin; k.Cout = Cout; k.Cout_p = Cout_p; k.Kp = Kp;
     k.ntiles = (Cout + 127) / 128; k.ctiles = (Cin + 127) / 128; k.nk = Tt / 16;
     k.tiles = 36 * k.ntiles * k.ctiles;
-    const int grid = wino_gemm_sk_grid_blocks();
+    const int grid = sk_launch_blocks();
     k.blocks_per_xcd = grid / 8;
     k.tiles_per_xcd = (k.tiles + 7) / 8;
     k.rounds = (k.tiles >= grid && 2 * (k.tiles % grid) == grid && k.nk % 2 == 0 && grid % 16 == 0) ? k.tiles / grid : 0;

@@ -50,6 +50,7 @@ struct Options {
     int conv_tile;           // T2V_CONV_TILE (measurement): 1 = keep the 128x128 tile where the fill rule would take 64x64, 2 = always 64x64
     int streams;             // T2V_STREAMS: 1 = the generator on the caller's stream only, 2 = always two streams; 0 (default):
                              // two, except the global generator on a bottleneck of >= 1024 Winograd tiles (1024x1024 frames)
+    int sk_blocks_per_cu;    // T2V_SK_BLOCKS_PER_CU: 0 (default) = by the overlap hint, 1 / 2 = always one / two blocks per CU
     int xcd_slices;          // T2V_XCD_SLICES: overlap-reading transforms give every XCD its own channel slices (default 1; 0 = the
                              // flat thread index: the A/B twin, same bits)
 };
@@ -284,6 +285,13 @@ int launch_wino_gemm_skr(hipStream_t s, const SkGemm& g, int rows);
 bool wino_gemm_skt_ok(int groups, int rows, int Tp, int K, int N, int c_cs);
 int launch_wino_gemm_skt(hipStream_t s, const SkGemm& g, int rows);
 int wino_gemm_sk_grid_blocks();                 // two blocks per CU, a multiple of 8
+// blocks the whole-tile fixed-grid GEMM and the Winograd-domain weight gradient LAUNCH: wino_gemm_sk_grid_blocks(), or half of
+// it (one block per CU) while the calling thread's overlap hint is 2 (t2v_set_overlap_hint) / T2V_SK_BLOCKS_PER_CU=1.  A
+// 128 x 128 block holds half a CU (64 KiB of LDS, 8 waves of <= 128 VGPRs): with one per CU the launch of the caller's OTHER
+// stream -- another fixed-grid GEMM, or the bandwidth-bound kernels between two of them -- is resident beside it instead of
+// queueing behind a grid that keeps every CU full until its last block leaves.  Which block owns a tile changes, an output's
+// K-ordered accumulation chain does not: the same bits.  The shape rules (*_ok) keep counting with two per CU.
+int sk_launch_blocks();
 unsigned long long wino_gemm_sk_next_tag();     // hand-over tags: unique per launch, process-wide
 // the same scheme for the Winograd-domain weight gradient dU[xi] = M_dy[xi]^T V[xi] (conv_wgrad.hip); scratch as above
 bool wino_wgrad_sk_ok(int Tt, int Cin, int Cout);

@@ -44,8 +44,11 @@ def check_async_errors():
 
 def set_overlap_hint(on):
     """Tell the library that this thread runs a second stream beside the launches it issues (returns the previous value);
-    t2v_generator_forward does it for its own two-stream frames -- bench.py uses it to time the kernel those frames run"""
-    return bool(_lib.load().t2v_set_overlap_hint(1 if on else 0))
+    t2v_generator_forward does it for its own two-stream frames -- bench.py uses it to time the kernel those frames run.
+    on == 2: the second stream carries fixed-grid GEMMs of its own (the train step's weight gradients): the whole-tile
+    fixed-grid GEMM and the Winograd-domain weight gradient launch ONE block per CU, so that the two streams' launches are
+    resident side by side (include/t2v.h, t2v_set_overlap_hint)."""
+    return int(_lib.load().t2v_set_overlap_hint(2 if on == 2 else (1 if on else 0)))
 
 
 def fixed_grid_enabled():

@@ -73,7 +73,7 @@ def prefetch_packs(params):
         for p, _ in todo:
             p._t2v_repack = None
         return
-    with wgrad_fork():
+    with wgrad_fork(gemm=False):
         for p, makers in todo:
             p._t2v_packs = (p._version, {k: mk() for k, mk in makers.items()}, dict(makers), set())
             p._t2v_repack = None
@@ -219,11 +219,15 @@ def batched_weight_gradients(params):
         p._t2v_dw_uses, p._t2v_dw_stash = 0, None
     _WG_BATCH[0] = os.environ.get("T2V_WGRAD_BATCH", "1") != "0"
     _DW_PAIR[0] = os.environ.get("T2V_WGRAD_PAIR", "1") != "0"
+    _WG_SIDE["gemm"] = False
+    if params and params[0].is_cuda:
+        side_gemm_hint()
     try:
         yield
     except BaseException:
         _WG_BATCH[0] = False
         _DW_PAIR[0] = False
+        _WG_SIDE["gemm"] = False
         # an exception inside the step (OOM, an asynchronous error): let go of what the nodes parked on the weights -- operand
         # lists, kept-V workspaces: GPU memory a retry needs
         for p in params:
@@ -231,6 +235,9 @@ def batched_weight_gradients(params):
         raise
     _WG_BATCH[0] = False
     _DW_PAIR[0] = False
+    _WG_SIDE["gemm"] = False
+    if params and params[0].is_cuda:
+        side_gemm_hint()
     # a backward pass inside this scope that did not end with flush_pending_weight_gradients() would silently lose the
     # gradients still parked on the weights (the first half of a pair, transformed slots waiting for their reduction)
     left = [i for i, p in enumerate(params) if getattr(p, "_t2v_dw_stash", None) is not None
@@ -252,17 +259,32 @@ def batched_weight_gradients(params):
 # filled by the other stream's blocks, as in the two-stream inference frames.  The side stream waits for the node's dc;
 # the main stream waits for the side stream before anything reads a slot (bucket collectives, absorb, finish).
 # T2V_WGRAD_STREAM=0: everything on one stream.
-_WG_SIDE = {"stream": None, "pending": False}
+# From the step's first weight gradient on the side stream to the end of the step BOTH streams carry fixed-grid GEMMs (data
+# gradient | Winograd-domain weight gradient).  A two-per-CU grid keeps every CU full until its last block leaves: the other
+# stream's launch -- and the bandwidth-bound kernels between two of the main stream's GEMMs -- queue behind it, the step was
+# the sum of its kernels (585 us per ResnetBlock layer of the second frame's backward pass against 591 us of kernels).  With
+# the overlap hint 2 (ops.set_overlap_hint) those kernels launch ONE block per CU and are resident side by side: 513 us per
+# layer, the same bits (profiles/r06_train_two_queues_{two,one}_per_cu.txt).  The hint is per thread and the backward nodes run on the
+# autograd engine's thread: every node (and the flush on the calling thread) sets it from the shared flag.
+# T2V_TRAIN_SK_HINT=0: two blocks per CU throughout.
+_WG_SIDE = {"stream": None, "pending": False, "gemm": False}
 
 
 def wgrad_stream_on(t):
     return t.is_cuda and os.environ.get("T2V_WGRAD_STREAM", "1") != "0"
 
 
+def side_gemm_hint():
+    """this thread's launches from here on: one block per CU for the fixed-grid GEMMs while the side stream has GEMMs of its
+    own in this step, the library's default otherwise"""
+    ops.set_overlap_hint(2 if _WG_SIDE["gemm"] else 0)
+
+
 @contextlib.contextmanager
-def wgrad_fork(*tensors):
+def wgrad_fork(*tensors, gemm=True):
     """kernels launched in this scope run on the side stream, after everything the current stream holds so far; the
-    tensors named (inputs allocated on the current stream) stay allocated until the side stream is done with them"""
+    tensors named (inputs allocated on the current stream) stay allocated until the side stream is done with them.
+    gemm: the scope launches weight-gradient GEMMs (not the repacking of weights after the optimiser step)"""
     if _WG_SIDE["stream"] is None:
         _WG_SIDE["stream"] = torch.cuda.Stream()
     side = _WG_SIDE["stream"]
@@ -271,6 +293,9 @@ def wgrad_fork(*tensors):
         if t is not None:
             t.record_stream(side)
     _WG_SIDE["pending"] = True
+    if gemm and not _WG_SIDE["gemm"] and os.environ.get("T2V_TRAIN_SK_HINT", "1") != "0":
+        _WG_SIDE["gemm"] = True
+        side_gemm_hint()
     with torch.cuda.stream(side):
         yield
 
@@ -415,6 +440,8 @@ def flush_pending_weight_gradients(params, grads):
     those gradients filled in."""
     out = list(grads)
     wgrad_join()
+    if params and params[0].is_cuda:
+        side_gemm_hint()       # (this thread: the backward nodes set theirs on the autograd engine's)
     for i, p in enumerate(params):
         half = getattr(p, "_t2v_dw_stash", None)
         if half is not None:        # a layer whose remaining uses never came back: reduce the ones that did
@@ -650,6 +677,8 @@ class _ConvBlock(torch.autograd.Function):
         x, w, c, gamma, beta, y_act, b = ctx.saved_tensors
         dy = dy.contiguous()
         dgamma = dbeta = None
+        if dy.is_cuda:
+            side_gemm_hint()
         # a backward pass that only passes THROUGH this layer (param_gradients_off): data gradient only
         want = [bool(v) for v in ctx.needs_input_grad]
         if need_dx == 2 and _NO_INPUT_DX[0]:
