@@ -177,10 +177,10 @@ def warm_clocks(fn, warm_ms=80.0):
 def gemm_stage_roofline(dev, sd, g0h, g0w, iters, clocks=None):
     """The dominant kernel of a frame whose global generator G0 runs on g0h x g0w, timed live with HIP events on the
     stream it is launched on (torch's current stream); returns the `roofline` object.  The kernel timed is the one the
-    frames RUN: t2v_generator_forward announces its second stream to the library (overlap hint), which then prefers the
-    form that leaves that stream wave slots -- 256x128 tiles on one block per CU at 512x512: slower alone, faster in the
-    frame -- so the hint is set here too; `alone_best` is the same stage without the hint (the form a single-stream caller
-    gets), when the two differ."""
+    frames RUN: t2v_generator_forward announces its second stream to the library (overlap hint), which may then prefer a
+    form that leaves that stream wave slots (256x128 tiles on one block per CU: two 512x512 images in lock-step, and one
+    with T2V_OVERLAP_HINT_SINGLE=1) -- so the hint is set here too; `alone_best` is the same stage without the hint (the
+    form a single-stream caller gets), when the two differ."""
     from text2video_amd import ops
     two_streams = os.environ.get("T2V_STREAMS", "") != "1"
     prev = ops.set_overlap_hint(two_streams)

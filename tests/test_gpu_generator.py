@@ -306,8 +306,8 @@ def test_two_stream_frames_are_reproducible(no_flow):
 
 
 def test_frames_do_not_depend_on_the_overlap_hint_or_the_stream_count(t2v_env):
-    """Full-width generator (ngf 128, 9 blocks, flow branch), 512x512: (i) the two-stream frame -- whose ResnetBlock GEMM stage
-    runs on 256x128 tiles with one block per CU under the overlap hint -- is BIT-identical to the frame with T2V_OVERLAP_HINT=0
+    """Full-width generator (ngf 128, 9 blocks, flow branch), 512x512: (i) the two-stream frame -- and the one whose ResnetBlock GEMM stage
+    runs on 256x128 tiles with one block per CU under the overlap hint (T2V_OVERLAP_HINT_SINGLE=1) -- is BIT-identical to the frame with T2V_OVERLAP_HINT=0
     (128x128 tiles, two per CU) and to the single-stream frame (which kernel owns a tile changes, an output's K-ordered MFMA
     chain does not)."""
     from text2video_amd import ops
@@ -330,11 +330,14 @@ def test_frames_do_not_depend_on_the_overlap_hint_or_the_stream_count(t2v_env):
         torch.cuda.synchronize()
         return out
     base = run()                                     # two streams, hint on
+    t2v_env("T2V_OVERLAP_HINT_SINGLE", "1")          # the rule of rounds 4-5: one image's GEMM stage on the tall form too
     prev = ops.set_overlap_hint(True)
     try:
-        assert "256x128" in ops.winograd_gemm_form(desc)      # (what the generator's own scope selects)
+        assert "256x128" in ops.winograd_gemm_form(desc)      # (what the generator's own scope then selects)
     finally:
         ops.set_overlap_hint(prev)
+    tall = run()
+    t2v_env("T2V_OVERLAP_HINT_SINGLE", "0")
     t2v_env("T2V_OVERLAP_HINT", "0")
     no_hint = run()
     t2v_env("T2V_OVERLAP_HINT", "1")
@@ -342,7 +345,7 @@ def test_frames_do_not_depend_on_the_overlap_hint_or_the_stream_count(t2v_env):
     one_stream = run()
     t2v_env("T2V_STREAMS", "0")
     for t in range(3):
-        assert torch.equal(base[t], no_hint[t]) and torch.equal(base[t], one_stream[t]), t
+        assert torch.equal(base[t], no_hint[t]) and torch.equal(base[t], one_stream[t]) and torch.equal(base[t], tall[t]), t
         assert torch.isfinite(base[t]).all() and base[t][..., :3].abs().max().item() > 0.05
 
 

@@ -452,8 +452,8 @@ def test_fixed_grid_winograd_gemm_equals_tile_per_block(geom, ragged, t2v_env):
 
 def test_overlap_hint_selects_the_one_block_per_cu_form_and_keeps_the_bits(t2v_env):
     """t2v_set_overlap_hint (ABI 13): a caller that runs a second stream beside its launches -- t2v_generator_forward's
-    two-stream frames do it themselves -- gets the 512x512 ResnetBlock GEMM stage on 256 x 128 tiles with one block per CU
-    instead of 128 x 128 with two.  Which kernel runs changes, the K-ordered MFMA chain of an output does not: same bits.
+    two-stream frames do it themselves -- gets the ResnetBlock GEMM stage of TWO 512x512 images in lock-step (of one with
+    T2V_OVERLAP_HINT_SINGLE=1) on 256 x 128 tiles with one block per CU instead of 128 x 128 with two.  Which kernel runs changes, the K-ordered MFMA chain of an output does not: same bits.
     T2V_OVERLAP_HINT=0 ignores the hint; the hint is per thread and returns its previous value."""
     from text2video_amd import ops
     H, W, C = 64, 64, 1024
@@ -464,20 +464,29 @@ def test_overlap_hint_selects_the_one_block_per_cu_form_and_keeps_the_bits(t2v_e
     pu = ops.pack_conv_weight(w, desc, C)
     ws = ops.winograd_workspace(desc, C, dev)
     x = _rand(H, W, C, seed=21).to(dev)
-    assert ops.set_overlap_hint(False) is False
+    assert ops.set_overlap_hint(False) == 0
     assert "128x128" in ops.winograd_gemm_form(desc)
     want = ops.conv2d_winograd(x, pu, b, desc, workspace=ws).clone()
-    assert ops.set_overlap_hint(True) is False
+    # hint 2 (ABI 18: the second stream runs fixed-grid GEMMs of its own -- a train step's weight gradients): the tile form
+    # of no hint on ONE block per CU (half the grid); which block owns a tile changes, the bits do not
+    assert ops.set_overlap_hint(2) == 0
+    assert "128x128" in ops.winograd_gemm_form(desc)
+    for rep in range(3):
+        assert torch.equal(ops.conv2d_winograd(x, pu, b, desc, workspace=ws), want)
+    assert ops.set_overlap_hint(True) == 2
     try:
-        assert "256x128" in ops.winograd_gemm_form(desc), ops.winograd_gemm_form(desc)
+        # one image keeps 128 x 128 tiles (round 6: its frame is no faster on the tall form any more), two in lock-step take it
+        assert "128x128" in ops.winograd_gemm_form(desc), ops.winograd_gemm_form(desc)
         assert "256x128" in ops.winograd_gemm_form(desc, 2) and "128x128" in ops.winograd_gemm_form(desc, 4)
+        t2v_env("T2V_OVERLAP_HINT_SINGLE", "1")      # (the rule of rounds 4-5)
+        assert "256x128" in ops.winograd_gemm_form(desc), ops.winograd_gemm_form(desc)
         ws.fill_(float("nan"))
         for rep in range(4):
             assert torch.equal(ops.conv2d_winograd(x, pu, b, desc, workspace=ws), want)
         t2v_env("T2V_OVERLAP_HINT", "0")
         assert "128x128" in ops.winograd_gemm_form(desc)
     finally:
-        assert ops.set_overlap_hint(False) is True
+        assert ops.set_overlap_hint(False) == 1
     # (another thread never sees this thread's hint)
     import threading
     seen = []
@@ -487,7 +496,7 @@ def test_overlap_hint_selects_the_one_block_per_cu_form_and_keeps_the_bits(t2v_e
         t.start(); t.join()
     finally:
         ops.set_overlap_hint(False)
-    assert seen == [False]
+    assert seen == [0]
 
 
 def test_fixed_grid_gemm_survives_graph_replay(t2v_env):
@@ -585,6 +594,7 @@ def test_one_block_per_cu_256x128_tiles_equal_tile_per_block(geom, t2v_env):
     t2v_env("T2V_WINO_GEMM_SK", "0")
     want = [ops.conv2d_winograd(x, pu, b, desc, workspace=ws).clone() for x in xs]
     t2v_env("T2V_WINO_GEMM_SK", "1")
+    t2v_env("T2V_OVERLAP_HINT_SINGLE", "1")      # (one image's 256 rows on the tall form as well: the library's rule keeps it for two)
     prev = ops.set_overlap_hint(True)
     try:
         assert "256x128" in ops.winograd_gemm_form(desc), ops.winograd_gemm_form(desc)

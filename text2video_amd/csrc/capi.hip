@@ -48,6 +48,7 @@ void options_reload() {
     o.wino_gemm_sk = env_int("T2V_WINO_GEMM_SK", 1);
     o.wino_gemm_sk_ragged = env_int("T2V_WINO_GEMM_SK_RAGGED", 2);
     o.overlap_hint = env_int("T2V_OVERLAP_HINT", 1);
+    o.overlap_hint_single = env_int("T2V_OVERLAP_HINT_SINGLE", 0);
     o.wgrad_sk = env_int("T2V_WGRAD_SK", 1);
     o.wgrad_combine = env_int("T2V_WGRAD_COMBINE", 1);
     o.wgrad_combine_max = env_int("T2V_WGRAD_COMBINE_MAX", 4);

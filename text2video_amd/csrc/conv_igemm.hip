@@ -1073,7 +1073,11 @@ static int sk_tall_rows(int groups, int rows, int T, int N) {     // tile rows o
     if (rows <= 0 || N % 128) return 0;
     int bm = 0, mt = 1;
     if (rows > 128 && rows <= 160 && T >= 160) bm = 160;
-    else if (overlap_hint() && T % 256 == 0 && rows > T - 32 && T <= 512) bm = 256, mt = T / 256;  // 256 (one 512x512 image) | 512 (two)
+    // 512 rows (two 512x512 images in lock-step).  One image's 256 rows took this form too until round 6: with the transforms'
+    // XCD slices (winograd.hip) the frame is no faster for it any more (10.25 vs 10.23 ms with the flow branch, 8.05 vs 7.96
+    // without; two sequences still gain 2.5 %: 10.03 vs 10.28 ms per step) -- T2V_OVERLAP_HINT_SINGLE=1 brings it back
+    else if (overlap_hint() && T % 256 == 0 && rows > T - 32 && T <= 512 && (T == 512 || options().overlap_hint_single))
+        bm = 256, mt = T / 256;
     if (!bm || lds_optin_bytes() < 3 * (bm == 160 ? CfgT::STAGE_BYTES : CfgT8::STAGE_BYTES)) return 0;
     const long tiles = (long)groups * mt * (N / 128), grid = wino_gemm_sk_grid_blocks() / 2;
     return (tiles >= grid && tiles * 100 <= ((tiles + grid - 1) / grid) * grid * 90) ? bm : 0;

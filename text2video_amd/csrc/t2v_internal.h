@@ -41,6 +41,7 @@ void set_error(const char* fmt, ...);
 struct Options {
     int wino_gemm_sk;        // T2V_WINO_GEMM_SK: 0 off, 1 where it pays (default), 2 wherever the shape allows
     int overlap_hint;        // T2V_OVERLAP_HINT: 0 ignores the overlap hint (t2v_set_overlap_hint / the generator's two-stream frames)
+    int overlap_hint_single; // T2V_OVERLAP_HINT_SINGLE: 1 = under the hint ONE 512x512 image's GEMM stage takes the 256 x 128 form as well (rounds 4-5)
     int wino_gemm_sk_ragged; // T2V_WINO_GEMM_SK_RAGGED: ragged M tiles for tile rows that are no whole 128s: 1 = 4,..,4,r fragments on
                              // two blocks per CU, 2 = balanced 3..6-fragment tiles on one block per CU where that applies
     int wgrad_sk;            // T2V_WGRAD_SK: as wino_gemm_sk, for the Winograd-domain weight gradient
