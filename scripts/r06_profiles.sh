@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-6 profile set, one GPU box.  Outputs under gpurun_out/r06p/ (copied into profiles/r06_* afterwards).
-#   usage: r06_profiles.sh [bench] [frames] [train] [pmc]      (default: all)
+#   usage: r06_profiles.sh [bench] [frames] [train] [pmc] [pmcgemm]      (default: the first four)
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/r06p; mkdir -p $O
@@ -46,5 +46,17 @@ if has pmc; then
     cat gpurun_out/pmc_wgrad_$shape/p*/summary.txt > $O/pmc_wgrad_${shape}_2frames.txt
   done
   rm -rf gpurun_out/pmc_wgrad_*
+fi
+if has pmcgemm; then
+  # PMC on the bench line's dominant kernel -- the Winograd GEMM stage on 128x128 tiles, fixed grid of two blocks per CU --
+  # inside two-stream 512x512 frames, one counter group per run (kernel trace only)
+  i=0
+  for grp in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES" "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"; do
+    i=$((i+1)); out=$O/pmc_gemm_512/p$i; mkdir -p $out
+    timeout 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $out -o pmc -- python scripts/frame_prof.py --frames 6 > $out/log.txt 2>&1
+    f=$(find $out -name "*counter_collection.csv" | head -1)
+    python scripts/pmc_summary.py ${f%_counter_collection.csv} wino_gemm_sk > $O/pmc_wino4_gemm_512x512_2streams_p$i.txt 2>&1
+  done
+  rm -rf $O/pmc_gemm_512
 fi
 ls -la $O
