@@ -1123,12 +1123,16 @@ template <class Cfg, int RING = 2, bool BKN = false>
 static int launch_sk(hipStream_t s, const SkKParams& k, int grid) {
     auto kern = wino_gemm_sk_kernel<Cfg, RING, BKN>;
     constexpr int LDS_BYTES = RING * Cfg::STAGE_BYTES;
+    constexpr int LDS_MAX = LDS_BYTES > kSkExclusiveLds ? LDS_BYTES : kSkExclusiveLds;
     static bool attr_done = false;   // per instantiation
     if (!attr_done) {
-        T2V_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        T2V_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
         attr_done = true;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS_BYTES, s, k);
+    // a two-per-CU form launched on ONE block per CU (sk_launch_blocks under overlap hint 2) keeps its CU's second GEMM slot
+    // shut as well (conv_wgrad.hip: launch_wino_wgrad_sk)
+    const bool exclusive = RING == 2 && grid < wino_gemm_sk_grid_blocks();
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), exclusive ? LDS_MAX : LDS_BYTES, s, k);
     T2V_HIP_CHECK(hipGetLastError());
     return T2V_OK;
 }
