@@ -1050,6 +1050,7 @@ static int lds_optin_bytes() {
     }
     return n;
 }
+int sk_exclusive_lds(int own_bytes) { return std::max(own_bytes, std::min(kSkExclusiveLds, lds_optin_bytes())); }
 constexpr int kSkMaxGrid = 1024;
 size_t wino_gemm_sk_scratch_floats() { return (size_t)kSkMaxGrid * (4 * 64 * 64 + 4 * 2); }
 
@@ -1123,7 +1124,7 @@ template <class Cfg, int RING = 2, bool BKN = false>
 static int launch_sk(hipStream_t s, const SkKParams& k, int grid) {
     auto kern = wino_gemm_sk_kernel<Cfg, RING, BKN>;
     constexpr int LDS_BYTES = RING * Cfg::STAGE_BYTES;
-    constexpr int LDS_MAX = LDS_BYTES > kSkExclusiveLds ? LDS_BYTES : kSkExclusiveLds;
+    static const int LDS_MAX = sk_exclusive_lds(LDS_BYTES);
     static bool attr_done = false;   // per instantiation
     if (!attr_done) {
         T2V_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));

@@ -606,13 +606,13 @@ int launch_wino_wgrad_sk(hipStream_t s, const float* V, const float* Md, float* 
     constexpr int lds = 4 * 2 * 16 * 128 * 4;
     static bool attr_done = false;
     if (!attr_done) {
-        T2V_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kSkExclusiveLds));
+        T2V_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, sk_exclusive_lds(lds)));
         attr_done = true;
     }
     // one block per CU (the caller's two streams both carry GEMMs): the block also asks for more than half a CU's LDS, so that
     // the OTHER stream's GEMM block cannot move in beside it -- two GEMMs on a CU share the MFMA pipe without gain and leave
     // the bandwidth-bound kernels no room (today the kernel's 131 registers have the same effect)
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), grid < wino_gemm_sk_grid_blocks() ? kSkExclusiveLds : lds, s, k);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), grid < wino_gemm_sk_grid_blocks() ? sk_exclusive_lds(lds) : lds, s, k);
     T2V_HIP_CHECK(hipGetLastError());
     return T2V_OK;
 }

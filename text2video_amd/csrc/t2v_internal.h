@@ -294,6 +294,7 @@ int wino_gemm_sk_grid_blocks();                 // two blocks per CU, a multiple
 // K-ordered accumulation chain does not: the same bits.  The shape rules (*_ok) keep counting with two per CU.
 int sk_launch_blocks();
 constexpr int kSkExclusiveLds = 96 * 1024;      // dynamic LDS a one-per-CU launch asks for: no second GEMM block on its CU
+int sk_exclusive_lds(int own_bytes);            // ... clamped to what the device lets a block opt in to (never below the kernel's own need)
 unsigned long long wino_gemm_sk_next_tag();     // hand-over tags: unique per launch, process-wide
 // the same scheme for the Winograd-domain weight gradient dU[xi] = M_dy[xi]^T V[xi] (conv_wgrad.hip); scratch as above
 bool wino_wgrad_sk_ok(int Tt, int Cin, int Cout);
