@@ -56,6 +56,14 @@ def main(path, steps=4):
         print("  gaps of %3g-%-5g us: %4d, %.2f ms" % (lo, hi, len(g), sum(x[0] for x in g) / 1e6))
     for d, at, a, b, q in sorted(gaps, reverse=True)[:25]:
         print("    %7.1f us at %6.2f ms: %-45s -> %-45s (queue %s)" % (d / 1e3, at, a[:45], b[:45], q))
+    # phase marks (ms from the step's start): the loss terms close the forward passes, the first / last Winograd-domain weight
+    # gradient bracket the second backward pass of the generator, the generator's Adam launch closes the backward passes
+    def first(name, last=False):
+        es = [e for e in step if name in e[3]]
+        return None if not es else ((es[-1][1] if last else es[0][0]) - t0) / 1e6
+    marks = [("loss_terms", first("loss_terms_kernel")), ("first wino_wgrad_sk", first("wino_wgrad_sk")),
+             ("last wino_wgrad_sk ends", first("wino_wgrad_sk", True)), ("first adam_multi", first("adam_multi")), ("end", (t1 - t0) / 1e6)]
+    print("  marks: " + ", ".join("%s %.2f" % (k, v) for k, v in marks if v is not None))
     if len(sys.argv) > 3:      # timeline dump: every launch that starts inside [a, b) ms of the step
         a, b = (float(v) for v in sys.argv[3].split("-"))
         for s_, e_, q, n in step:

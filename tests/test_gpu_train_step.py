@@ -582,6 +582,42 @@ def test_weight_gradients_on_the_side_stream_leave_the_step_unchanged(t2v_env):
     assert all(torch.equal(x, y) for x, y in zip(runs["1"][1], runs["0"][1]))
 
 
+def test_discriminator_backward_on_its_own_stream_equals_the_engines_pass(t2v_env):
+    """The discriminators' own backward pass is walked by hand on a second stream before the generator's pass is enqueued
+    (Vid2VidTrainer._d_backward_on_its_own_stream) instead of running under the autograd engine after it (T2V_D_BWD_STREAM=0):
+    the same nodes, kernels and operands -- losses and updated weights of G, D and the face D bit for bit over three steps,
+    with and without the weights' packed copies made ahead (a copy made on the spot by one stream is used by the other)."""
+    from text2video_amd import train as T
+    from text2video_amd.options import TrainOptions
+    opt = TrainOptions().parse(["--name", "t", "--dataset_mode", "pose", "--input_nc", "3", "--openpose_only", "--ngf", "32",
+                                "--n_downsample_G", "2", "--n_blocks", "3", "--num_D", "2", "--ndf", "16", "--no_vgg",
+                                "--max_frames_per_gpu", "2", "--n_scales_temporal", "0", "--no_first_img", "--add_face_disc"])
+    H, W = 128, 128
+    rng = np.random.default_rng(34)
+    pose = torch.zeros(2, H, W, 12, device="cuda:0")
+    pose[..., :9] = torch.from_numpy(rng.uniform(-1, 1, (2, H, W, 9)).astype(np.float32)).cuda()
+    real = torch.zeros(2, H, W, 4, device="cuda:0")
+    real[..., :3] = torch.tanh(torch.from_numpy(rng.standard_normal((2, H, W, 3)).astype(np.float32))).cuda()
+    real_prev = torch.cat([real[1:], real[:1]], 0).contiguous()
+    boxes = [(16, 80, 32, 96)] * 2
+    runs = {}
+    for mode in ("1", "1 lazy packs", "0", "0 caller's stream"):
+        t2v_env("T2V_D_BWD_STREAM", mode[0])
+        t2v_env("T2V_PACK_PREFETCH", "0" if "lazy" in mode else "1")
+        t2v_env("T2V_TRAIN_HIGH_PRIORITY", "0" if "caller" in mode else "1")      # (the step on its own high-priority stream)
+        tr = T.Vid2VidTrainer(opt, "cuda:0", seed=6)
+        prev, ls = None, []
+        for _ in range(3):
+            l, prev = tr.train_step(pose, real, boxes, prev, real_prev=real_prev)
+            ls.append(l)
+        runs[mode] = (ls, [p.detach().clone() for n in (tr.G, tr.D, tr.Df) for p in n.parameters()])
+        assert (getattr(tr, "_d_stream", None) is not None) == (mode[0] == "1")
+    for other in ("1 lazy packs", "0", "0 caller's stream"):
+        for la, lb in zip(runs["1"][0], runs[other][0]):
+            assert la.keys() == lb.keys() and all(la[k] == lb[k] for k in la), [(k, la[k], lb[k]) for k in la if la[k] != lb[k]]
+        assert all(torch.equal(x, y) for x, y in zip(runs["1"][1], runs[other][1]))
+
+
 def test_train_step_with_the_fixed_grid_kernels_forced_is_bit_identical(t2v_env, monkeypatch):
     """Both fixed-grid kernels (Winograd GEMM stage in the forward convs and the transposed data gradient; Winograd-domain
     weight-gradient reduction) forced on at a size whose tile counts are far below the grid -- short runs, many blocks idle,

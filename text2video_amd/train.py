@@ -42,6 +42,7 @@ def cached_pack(w, key, make):
         ent = (w._version, {}, {}, set())       # version, copies, how each was made, which were used since the last write
         w._t2v_packs = ent
         w._t2v_pack_event = None
+        w._t2v_pack_made = {}
     elif getattr(w, "_t2v_pack_event", None) is not None:
         # packed ahead on the side stream (prefetch_packs): a use waits for that batch (on whichever stream it runs; a wait
         # for an event that has completed costs nothing)
@@ -49,6 +50,18 @@ def cached_pack(w, key, make):
     if key not in ent[1]:
         ent[1][key] = make()
         ent[2][key] = make
+        if w.is_cuda:      # made on the spot (a first step, T2V_PACK_PREFETCH=0): by whom, and when it is complete
+            cur = torch.cuda.current_stream()
+            made = getattr(w, "_t2v_pack_made", None)
+            if made is None:
+                made = w._t2v_pack_made = {}
+            made[key] = (cur, cur.record_event())
+    elif w.is_cuda:
+        # the discriminators' layers are used from two streams in one step (their own backward pass on the trainer's
+        # `_d_stream`, the generator's pass through them on the current one): a copy made on the other stream is waited for
+        m = (getattr(w, "_t2v_pack_made", None) or {}).get(key)
+        if m is not None and m[0] != torch.cuda.current_stream():
+            torch.cuda.current_stream().wait_event(m[1])
     ent[3].add(key)
     return ent[1][key]
 
@@ -61,6 +74,7 @@ def invalidate_packs(p):
     p._t2v_repack = {k: ent[2][k] for k in ent[3]} if (ent is not None and ent[3]) else None
     p._t2v_packs = None
     p._t2v_pack_event = None
+    p._t2v_pack_made = None
 
 
 def prefetch_packs(params):
@@ -559,6 +573,8 @@ def _zeros(n, device):
     z = _ZEROS.get((n, device))
     if z is None:
         z = _ZEROS[(n, device)] = torch.zeros(n, dtype=torch.float32, device=device)
+        if z.is_cuda:
+            torch.cuda.current_stream().synchronize()      # (once per size: the vector is read from more than one stream)
     return z
 
 
@@ -1907,6 +1923,38 @@ class Vid2VidTrainer:
                     tG.append(f); sG.append(gf)
         return tG, sG, tD, sD
 
+    def _d_backward_on_its_own_stream(self, outputs, seeds, d_params):
+        """The discriminators' own backward pass (their LSGAN terms: seeds on the logits only) without the autograd engine:
+        every output is the end of a chain of _ConvBlock nodes, a node object is its own `ctx`, so each chain is
+        `dy = _ConvBlock.backward(node, dy)[0]` from the logits down to the layer that owes no data gradient
+        (input_gradients_off).  The nodes deliver their parameter gradients into the bucket slots as under the engine -- the
+        same kernels on the same operands in the same order: the same bits -- but on THIS call's stream, the trainer's
+        `_d_stream`, which waits for everything the current stream holds (forward passes, loss seeds) and which the caller
+        joins before it touches D's gradients.  The engine would run these nodes on the stream of their forward, i.e. behind
+        the generator's whole backward pass.  The graph stays alive until the step returns (the generator's pass retains it),
+        so the saved tensors both passes read are not handed back to the allocator while this stream still reads them.
+        Returns the stream, or None: not applicable (T2V_D_BWD_STREAM=0, a parameter without a bucket slot -- T2V_GRAD_DIRECT=0
+        -- or an output that is no _ConvBlock result): the caller takes the engine."""
+        if os.environ.get("T2V_D_BWD_STREAM", "1") == "0" or not outputs or not outputs[0].is_cuda:
+            return None
+        node_cls = _ConvBlock._backward_cls
+        if any(grad_slot(p) is None for p in d_params) or any(not isinstance(y.grad_fn, node_cls) for y in outputs):
+            return None
+        if getattr(self, "_d_stream", None) is None:
+            self._d_stream = torch.cuda.Stream()
+        side = self._d_stream
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), input_gradients_off():
+            for y, g in zip(outputs, seeds):
+                node = y.grad_fn
+                while g is not None and isinstance(node, node_cls):
+                    res = _ConvBlock.backward(node, g)
+                    if any(r is not None for r in res[1:]):
+                        raise RuntimeError("discriminator backward by hand: a node returned a gradient it should have delivered")
+                    g, node = res[0], node.next_functions[0][0]
+        side_gemm_hint()
+        return side
+
     def _train_step_batched(self, pose, real, face_boxes, prev, real_prev, flow_ref, conf_ref, first, fakes, raws, fws, prevs,
                             fake, A3):
         """The step from the generated frames on (default path): every discriminator runs its real / fake / raw passes as one
@@ -1968,12 +2016,21 @@ class Vid2VidTrainer:
         self.bucketsD.seal()
         if rest is not None and torch.is_tensor(rest) and rest.requires_grad:
             tG, sG = tG + [rest], sG + [None]
+        # D's loss reaches D's parameters through plain chains of _ConvBlock nodes (logits -> ... -> first layer, no data
+        # gradient into the frames) and shares nothing with the generator's backward pass but the saved tensors both read:
+        # the chains are walked by hand on a stream of their own BEFORE the generator's pass is enqueued, so that the GPU runs
+        # them beside its first ~20 ms -- which otherwise have no second queue (DESIGN 6b "what the step's two queues do")
+        d_side = self._d_backward_on_its_own_stream(tD, sD, d_params)
         with param_gradients_off(d_params):
             gG = torch.autograd.grad(tG, g_params, grad_outputs=sG, retain_graph=True, allow_unused=True)
         gG = flush_pending_weight_gradients(g_params, gG)
         self.bucketsG.absorb(gG)
-        with input_gradients_off():      # D's loss: no data gradient into the (attached) generated frames
-            gD = torch.autograd.grad(tD, d_params, grad_outputs=sD, allow_unused=True)
+        if d_side is not None:
+            torch.cuda.current_stream().wait_stream(d_side)
+            gD = [None] * len(d_params)
+        else:
+            with input_gradients_off():      # D's loss: no data gradient into the (attached) generated frames
+                gD = torch.autograd.grad(tD, d_params, grad_outputs=sD, allow_unused=True)
         gD = flush_pending_weight_gradients(d_params, gD)
         self.bucketsD.absorb(gD)
         if self.time_comm:
@@ -2003,6 +2060,21 @@ class Vid2VidTrainer:
         losses against flow_ref [F,H,W,4] (flow_x, flow_y in pixels; default zero flow) and its confidence mask
         conf_ref [F,H,W] (default: ||real - resample(real_prev, flow_ref)|| < 0.02, the rule upstream's FlowNet2
         wrapper applies [RECALL]).  Returns (dict of scalar losses, FIFO for the next chunk)."""
+        # The step's own launches go out on a HIGH-priority stream (the device offers two levels): the weight gradients
+        # and the discriminators' backward pass on the side streams are filler for what the generator's passes leave free, not
+        # competitors for it -- with the discriminators' pass beside the generator's the step measured 85.7 -> 84.6 ms
+        # (mean of four alternating pairs).  The caller's stream waits for it on the way out.  T2V_TRAIN_HIGH_PRIORITY=0: off.
+        cur = torch.cuda.current_stream() if pose.is_cuda else None
+        if cur is not None and os.environ.get("T2V_TRAIN_HIGH_PRIORITY", "1") != "0":
+            if getattr(self, "_hp_stream", None) is None:
+                self._hp_stream = torch.cuda.Stream(priority=-1)
+            hp = self._hp_stream
+            if cur != hp:
+                hp.wait_stream(cur)
+                with torch.cuda.stream(hp):
+                    out = self.train_step(pose, real, face_boxes, prev, real_prev, flow_ref, conf_ref)
+                cur.wait_stream(hp)
+                return out
         with batched_weight_gradients(self.optG.params + self.optD.params):
             return self._train_step(pose, real, face_boxes, prev, real_prev, flow_ref, conf_ref)
 
