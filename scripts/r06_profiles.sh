@@ -31,7 +31,7 @@ if has train; then
     T2V_D_BATCHED=0 python scripts/train_bench.py --iters 12
     python scripts/train_bench.py --iters 12
     python scripts/train_bench.py --iters 5 --force_dist ) 2>&1 | grep -v "amdgpu.ids\|^warning" > $O/train_bench.txt
-  T2V_WGRAD_STREAM=0 T2V_PACK_PREFETCH=0 bash scripts/prof_train.sh > $O/train_step_kernel_summary_1stream.txt 2>&1
+  T2V_WGRAD_STREAM=0 T2V_PACK_PREFETCH=0 T2V_D_BWD_STREAM=0 bash scripts/prof_train.sh > $O/train_step_kernel_summary_1stream.txt 2>&1
   cp $(find gpurun_out/prof_train -name "*kernel_stats.csv" | head -1) $O/train_step_kernel_stats_1stream.csv
   tr=$(find gpurun_out/prof_train -name "*kernel_trace.csv" | head -1)
   python scripts/trace_shapes.py $tr 4 > $O/train_step_shapes_1stream.txt

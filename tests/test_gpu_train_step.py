@@ -601,10 +601,9 @@ def test_discriminator_backward_on_its_own_stream_equals_the_engines_pass(t2v_en
     real_prev = torch.cat([real[1:], real[:1]], 0).contiguous()
     boxes = [(16, 80, 32, 96)] * 2
     runs = {}
-    for mode in ("1", "1 lazy packs", "0", "0 caller's stream"):
+    for mode in ("1", "1 lazy packs", "0"):
         t2v_env("T2V_D_BWD_STREAM", mode[0])
         t2v_env("T2V_PACK_PREFETCH", "0" if "lazy" in mode else "1")
-        t2v_env("T2V_TRAIN_HIGH_PRIORITY", "0" if "caller" in mode else "1")      # (the step on its own high-priority stream)
         tr = T.Vid2VidTrainer(opt, "cuda:0", seed=6)
         prev, ls = None, []
         for _ in range(3):
@@ -612,7 +611,7 @@ def test_discriminator_backward_on_its_own_stream_equals_the_engines_pass(t2v_en
             ls.append(l)
         runs[mode] = (ls, [p.detach().clone() for n in (tr.G, tr.D, tr.Df) for p in n.parameters()])
         assert (getattr(tr, "_d_stream", None) is not None) == (mode[0] == "1")
-    for other in ("1 lazy packs", "0", "0 caller's stream"):
+    for other in ("1 lazy packs", "0"):
         for la, lb in zip(runs["1"][0], runs[other][0]):
             assert la.keys() == lb.keys() and all(la[k] == lb[k] for k in la), [(k, la[k], lb[k]) for k in la if la[k] != lb[k]]
         assert all(torch.equal(x, y) for x, y in zip(runs["1"][1], runs[other][1]))

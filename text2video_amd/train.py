@@ -285,7 +285,7 @@ _WG_SIDE = {"stream": None, "pending": False, "gemm": False}
 
 
 def wgrad_stream_on(t):
-    return t.is_cuda and os.environ.get("T2V_WGRAD_STREAM", "1") != "0"
+    return t.is_cuda and not _WG_SIDE.get("inline") and os.environ.get("T2V_WGRAD_STREAM", "1") != "0"
 
 
 def side_gemm_hint():
@@ -1597,11 +1597,29 @@ class GradBuckets:
         if not self.exchange:
             return
         import torch.distributed as dist
-        # the collective is ordered behind the current stream: let that include the side streams' gradients -- and the main
-        # stream's, when this node runs on the forward side stream
+        # The collective is ordered behind the stream it is issued on, and it needs the weight-gradient stream's kernels AND the
+        # current stream's (and the step's main stream's, when this node runs on another).  With weight gradients in flight it
+        # is issued FROM the weight-gradient stream, which first takes in what the other streams hold so far: the backward
+        # pass itself does not stop.  (Until round 6 the current stream joined the weight-gradient stream here, 36 times per
+        # step: the data-gradient chain waited for every layer's weight gradient, and the two queues of DESIGN 6b ran one
+        # after the other again whenever the exchange was on.)  T2V_EXCHANGE_FROM_SIDE=0: the join.
+        cur = torch.cuda.current_stream() if self.flat.is_cuda else None
+        side = _WG_SIDE["stream"] if (cur is not None and _WG_SIDE["pending"]
+                                      and os.environ.get("T2V_EXCHANGE_FROM_SIDE", "1") != "0") else None
+        if side is not None and side != cur:
+            side.wait_stream(cur)
+            if self._main is not None and cur != self._main:
+                side.wait_stream(self._main)
+            with torch.cuda.stream(side):
+                self._issue(b)
+            return
         wgrad_join()
         if self._main is not None and torch.cuda.current_stream() != self._main:
             torch.cuda.current_stream().wait_stream(self._main)
+        self._issue(b)
+
+    def _issue(self, b):
+        import torch.distributed as dist
         lo, hi = self.bounds[b]
         buf = self.flat[lo:hi]
         avg = dist.get_backend() == "nccl"       # RCCL averages in the collective; gloo sums (scaled in finish)
@@ -1933,9 +1951,11 @@ class Vid2VidTrainer:
         joins before it touches D's gradients.  The engine would run these nodes on the stream of their forward, i.e. behind
         the generator's whole backward pass.  The graph stays alive until the step returns (the generator's pass retains it),
         so the saved tensors both passes read are not handed back to the allocator while this stream still reads them.
-        Returns the stream, or None: not applicable (T2V_D_BWD_STREAM=0, a parameter without a bucket slot -- T2V_GRAD_DIRECT=0
-        -- or an output that is no _ConvBlock result): the caller takes the engine."""
-        if os.environ.get("T2V_D_BWD_STREAM", "1") == "0" or not outputs or not outputs[0].is_cuda:
+        Returns the stream, or None: not switched on (T2V_D_BWD_STREAM=1; OFF by default: the step is 1 ms faster with it where
+        no process group exists -- scripts/train_bench.py, 86.9 -> 85.9 ms -- and 3 ms SLOWER in bench.py's block, which runs
+        the step as a rank of a job: 84.4 -> 87.3 ms) or not applicable (a parameter without a bucket slot --
+        T2V_GRAD_DIRECT=0 -- or an output that is no _ConvBlock result): the caller takes the engine."""
+        if os.environ.get("T2V_D_BWD_STREAM", "0") != "1" or not outputs or not outputs[0].is_cuda:
             return None
         node_cls = _ConvBlock._backward_cls
         if any(grad_slot(p) is None for p in d_params) or any(not isinstance(y.grad_fn, node_cls) for y in outputs):
@@ -1944,14 +1964,24 @@ class Vid2VidTrainer:
             self._d_stream = torch.cuda.Stream()
         side = self._d_stream
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side), input_gradients_off():
-            for y, g in zip(outputs, seeds):
-                node = y.grad_fn
-                while g is not None and isinstance(node, node_cls):
-                    res = _ConvBlock.backward(node, g)
-                    if any(r is not None for r in res[1:]):
-                        raise RuntimeError("discriminator backward by hand: a node returned a gradient it should have delivered")
-                    g, node = res[0], node.next_functions[0][0]
+        # the weight gradients of these nodes stay ON this stream (it is a side stream already): on the shared weight-gradient
+        # stream they would stand between the generator's pass and every bucket it sends off (GradBuckets._launch joins that
+        # stream first) -- the filler would become a dependency of the critical path (bench.py's step with the exchange:
+        # 90.5 ms against 82.1 without).  Two streams carry GEMMs from here on: one block per CU (side_gemm_hint)
+        if os.environ.get("T2V_TRAIN_SK_HINT", "1") != "0" and wgrad_stream_on(outputs[0]):
+            _WG_SIDE["gemm"] = True
+        _WG_SIDE["inline"] = True
+        try:
+            with torch.cuda.stream(side), input_gradients_off():
+                for y, g in zip(outputs, seeds):
+                    node = y.grad_fn
+                    while g is not None and isinstance(node, node_cls):
+                        res = _ConvBlock.backward(node, g)
+                        if any(r is not None for r in res[1:]):
+                            raise RuntimeError("discriminator backward by hand: a node returned a gradient it should have delivered")
+                        g, node = res[0], node.next_functions[0][0]
+        finally:
+            _WG_SIDE["inline"] = False
         side_gemm_hint()
         return side
 
@@ -2018,8 +2048,9 @@ class Vid2VidTrainer:
             tG, sG = tG + [rest], sG + [None]
         # D's loss reaches D's parameters through plain chains of _ConvBlock nodes (logits -> ... -> first layer, no data
         # gradient into the frames) and shares nothing with the generator's backward pass but the saved tensors both read:
-        # the chains are walked by hand on a stream of their own BEFORE the generator's pass is enqueued, so that the GPU runs
-        # them beside its first ~20 ms -- which otherwise have no second queue (DESIGN 6b "what the step's two queues do")
+        # with T2V_D_BWD_STREAM=1 the chains are walked by hand on a stream of their own BEFORE the generator's pass is
+        # enqueued, so that the GPU runs them beside its first ~20 ms, which otherwise have no second queue (measured both
+        # ways, off by default: DESIGN 6b "the discriminators' own backward pass beside the generator's")
         d_side = self._d_backward_on_its_own_stream(tD, sD, d_params)
         with param_gradients_off(d_params):
             gG = torch.autograd.grad(tG, g_params, grad_outputs=sG, retain_graph=True, allow_unused=True)
@@ -2060,21 +2091,6 @@ class Vid2VidTrainer:
         losses against flow_ref [F,H,W,4] (flow_x, flow_y in pixels; default zero flow) and its confidence mask
         conf_ref [F,H,W] (default: ||real - resample(real_prev, flow_ref)|| < 0.02, the rule upstream's FlowNet2
         wrapper applies [RECALL]).  Returns (dict of scalar losses, FIFO for the next chunk)."""
-        # The step's own launches go out on a HIGH-priority stream (the device offers two levels): the weight gradients
-        # and the discriminators' backward pass on the side streams are filler for what the generator's passes leave free, not
-        # competitors for it -- with the discriminators' pass beside the generator's the step measured 85.7 -> 84.6 ms
-        # (mean of four alternating pairs).  The caller's stream waits for it on the way out.  T2V_TRAIN_HIGH_PRIORITY=0: off.
-        cur = torch.cuda.current_stream() if pose.is_cuda else None
-        if cur is not None and os.environ.get("T2V_TRAIN_HIGH_PRIORITY", "1") != "0":
-            if getattr(self, "_hp_stream", None) is None:
-                self._hp_stream = torch.cuda.Stream(priority=-1)
-            hp = self._hp_stream
-            if cur != hp:
-                hp.wait_stream(cur)
-                with torch.cuda.stream(hp):
-                    out = self.train_step(pose, real, face_boxes, prev, real_prev, flow_ref, conf_ref)
-                cur.wait_stream(hp)
-                return out
         with batched_weight_gradients(self.optG.params + self.optD.params):
             return self._train_step(pose, real, face_boxes, prev, real_prev, flow_ref, conf_ref)
 
