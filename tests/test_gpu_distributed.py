@@ -93,6 +93,15 @@ def _rccl_worker(tmp):
     out["rs_ag_bytes"] = tr2.comm_bytes
     out["rs_ag_same_losses"] = all(losses[k] == losses2[k] for k in losses)
     out["rs_ag_same_weights"] = all(bool(torch.equal(a, b)) for a, b in zip(tr.optG.params, tr2.optG.params))
+    # ... and with every bucket's collective issued from the current stream after joining the weight-gradient stream (the form
+    # until round 6; default now: issued FROM the weight-gradient stream, the backward pass does not stop)
+    os.environ["T2V_EXCHANGE_FROM_SIDE"] = "0"
+    tr3 = T.Vid2VidTrainer(opt, "cuda:0", seed=5)
+    losses3, _ = tr3.train_step(pose, real, None, None, real_prev=real.flip(0).contiguous())
+    del os.environ["T2V_EXCHANGE_FROM_SIDE"]
+    out["join_same_losses"] = all(losses[k] == losses3[k] for k in losses) and tr3.comm_bytes == tr.comm_bytes
+    out["join_same_weights"] = all(bool(torch.equal(a, b)) for a, b in zip(tr.optG.params + tr.optD.params,
+                                                                            tr3.optG.params + tr3.optD.params))
     dist.barrier()
     dist.destroy_process_group()
     with open(tmp, "w") as fh:
@@ -112,6 +121,7 @@ def test_rccl_collectives_execute_on_device_tensors(tmp_path):
     assert d["bytes"] == 4 * (5 + 70000 + 3 + (1 << 18) + 17)
     assert d["comm_bytes"] == d["n_param_bytes"] > 0         # every gradient of the step went through the exchange
     assert d["rs_ag_bytes"] == d["comm_bytes"] and d["rs_ag_same_losses"] and d["rs_ag_same_weights"]
+    assert d["join_same_losses"] and d["join_same_weights"]
     print("1-rank RCCL gradient exchange: %.1f MB in %s buckets, %.3f ms exposed after the backward pass"
           % (d["comm_bytes"] / 2**20, d["buckets"], d["comm_ms_exposed"]))
     assert 0.0 <= d["comm_ms_exposed"] < 1000.0
