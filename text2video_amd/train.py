@@ -1965,9 +1965,9 @@ class Vid2VidTrainer:
         side = self._d_stream
         side.wait_stream(torch.cuda.current_stream())
         # the weight gradients of these nodes stay ON this stream (it is a side stream already): on the shared weight-gradient
-        # stream they would stand between the generator's pass and every bucket it sends off (GradBuckets._launch joins that
-        # stream first) -- the filler would become a dependency of the critical path (bench.py's step with the exchange:
-        # 90.5 ms against 82.1 without).  Two streams carry GEMMs from here on: one block per CU (side_gemm_hint)
+        # stream they would stand in front of every bucket the generator's pass sends off (GradBuckets._launch orders a
+        # collective behind that stream) -- the filler would hold the exchange up (measured with the join of that time:
+        # 90.5 ms with the exchange against 82.1 without).  Two streams carry GEMMs from here on: one block per CU
         if os.environ.get("T2V_TRAIN_SK_HINT", "1") != "0" and wgrad_stream_on(outputs[0]):
             _WG_SIDE["gemm"] = True
         _WG_SIDE["inline"] = True
