@@ -478,6 +478,7 @@ def train_block(dev, dist_mod, world, rank, backend, steps, iters, ngf=128, cloc
     warm = 2 if steps >= 3 else 1
 
     sclk = {}
+    mean_ms = {}
 
     def timed(n, exchange):
         import contextlib
@@ -486,16 +487,30 @@ def train_block(dev, dist_mod, world, rank, backend, steps, iters, ngf=128, cloc
             tr.train_step(pose, real, boxes, prev.clone(), real_prev=real_prev)
         torch.cuda.synchronize()
         dist.barrier()
+        # one more untimed step BEHIND the barrier: the first step that sends its buckets off after a barrier takes 70-100 ms
+        # longer than the rest (191 / 157 ms against 87-88 for every later one, per-step timings on one box), which a mean
+        # over 5 timed steps showed as 93-110 ms per step in some runs and not in others; with the exchange that step's
+        # collectives line the ranks up again
+        tr.train_step(pose, real, boxes, prev.clone(), real_prev=real_prev)
         torch.cuda.synchronize()
         samp = clocks.fork(0.02) if clocks is not None else None      # this rank's core clock during the timed steps
         with (samp if samp is not None else contextlib.nullcontext()):
             t0 = time.perf_counter()
+            marks = [t0]
             for _ in range(n):
                 losses = tr.train_step(pose, real, boxes, prev.clone(), real_prev=real_prev)[0]
+                marks.append(time.perf_counter())      # (a step ends with its one host read: the losses)
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
             el = time.perf_counter() - t0
+        # The figure of the block is the MEDIAN step (x n): with the exchange on, one step shortly after a barrier takes 50-100 ms
+        # longer than the others (per-step marks on one box: 86.9 137.2 84.8 84.6 84.4 ms; without the exchange 84.5 83.4 83.9
+        # 83.9 83.2) -- something in the process group's housekeeping, not in the step -- and a mean over 5 steps read 85 ms in
+        # one run and 93-110 in the next.  The mean is reported beside it.
+        per_step = sorted(b - a for a, b in zip(marks[:-1], marks[1:]))
+        mean_ms[exchange] = 1e3 * el / n
+        el = n * (per_step[n // 2] if n % 2 else 0.5 * (per_step[n // 2 - 1] + per_step[n // 2]))
         if samp is not None:
             sclk[exchange] = samp.mean_mhz()
         if world > 1:
@@ -572,7 +587,9 @@ def train_block(dev, dist_mod, world, rank, backend, steps, iters, ngf=128, cloc
                             "achieved": round(gf / ms, 2), "frac": round(gf / ms / PEAK_FP32_MFMA_TFLOPS, 4)})
         block = {"workload": "configs[4] per GPU: 512x512, 2 frames, G (flow%s) + D (num_D 2) + face D, --no_vgg, Adam; %d GPU(s)"
                              % ("" if ngf == 128 else ", ngf %d: NOT configs[4], plumbing test only" % ngf, world),
-                 "ms_per_step": round(ms_with, 2), "steps": steps, "warmup": warm,
+                 "ms_per_step": round(ms_with, 2), "steps": steps, "warmup": warm + 1,
+                 "statistic": "median of the timed steps (max over ranks); mean incl. the closing barrier: %.2f with / %.2f without "
+                              "the exchange" % (mean_ms.get(True, 0.0), mean_ms.get(False, 0.0)),
                  # rank 0's core clock during the two timed regions, and the step scaled to the clock the round-4/5 targets
                  # were quoted at (ms x sclk / 2360: the step is GPU-bound, its kernels MFMA-bound)
                  "sclk_mhz": sclk.get(False), "sclk_mhz_with_exchange": sclk.get(True),
