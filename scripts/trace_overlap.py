@@ -12,15 +12,16 @@ def short(n):
     return n.split("(")[0][:60]
 
 
-def main(path, steps=4):
+def main(path, steps=4, window=None):
     rows = list(csv.DictReader(open(path)))
     ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r.get("Queue_Id", "0"), short(r["Kernel_Name"])) for r in rows))
     # the last step: a step ends with the optimisers' two adam_multi_kernel launches (the generator's: > 1 ms, then the
     # discriminators'); boundary = the last Adam launch that follows each long one
     big = [i for i, e in enumerate(ev) if "adam_multi" in e[3] and e[1] - e[0] > 1000000]
     ends = []
-    for b in big:
-        later = [i for i, e in enumerate(ev[b:b + 200], b) if "adam_multi" in e[3]]
+    for n, b in enumerate(big):
+        stop = min(b + 200, big[n + 1] if n + 1 < len(big) else len(ev))
+        later = [i for i, e in enumerate(ev[b:stop], b) if "adam_multi" in e[3]]
         ends.append(later[-1])
     if len(ends) < 2:
         print("fewer than two steps in the trace")
@@ -64,8 +65,8 @@ def main(path, steps=4):
     marks = [("loss_terms", first("loss_terms_kernel")), ("first wino_wgrad_sk", first("wino_wgrad_sk")),
              ("last wino_wgrad_sk ends", first("wino_wgrad_sk", True)), ("first adam_multi", first("adam_multi")), ("end", (t1 - t0) / 1e6)]
     print("  marks: " + ", ".join("%s %.2f" % (k, v) for k, v in marks if v is not None))
-    if len(sys.argv) > 3:      # timeline dump: every launch that starts inside [a, b) ms of the step
-        a, b = (float(v) for v in sys.argv[3].split("-"))
+    if window:      # timeline dump: every launch that starts inside [a, b) ms of the step
+        a, b = (float(v) for v in window.split("-"))
         for s_, e_, q, n in step:
             if a * 1e6 <= s_ - t0 < b * 1e6:
                 print("    %s %9.1f -> %9.1f us (%7.1f)  %s" % ("M" if q == queues[0] else "      S", (s_ - t0) / 1e3, (e_ - t0) / 1e3,
@@ -99,4 +100,4 @@ def main(path, steps=4):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 4)
+    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 4, sys.argv[3] if len(sys.argv) > 3 else None)

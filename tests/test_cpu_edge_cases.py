@@ -317,3 +317,40 @@ def test_direct_weight_gradient_splits_a_batch_that_passes_the_kernels_offset_li
     del calls[:]
     monkeypatch.setattr(T, "_WGRAD_MAX_BYTES", 16)                                      # not even one: one image per launch
     assert torch.allclose(T.direct_weight_gradient(x, dy, None), whole, atol=1e-5) and [c[0] for c in calls] == [1] * 6
+
+
+def test_trace_overlap_reads_a_two_queue_kernel_trace(tmp_path, capsys):
+    """scripts/trace_overlap.py (the two-queue picture of a train step) on a synthetic rocprofv3 kernel trace: two
+    steps, each closed by the generator's and the discriminators' Adam launches; in the last one a side-queue weight gradient
+    overlaps two main-queue kernels for 60 of its 100 us and 30 us are idle."""
+    import csv
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "trace_overlap", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "trace_overlap.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rows, t = [], 0
+
+    def k(name, q, start, dur):
+        rows.append({"Kernel_Name": name, "Queue_Id": q, "Start_Timestamp": start, "End_Timestamp": start + dur})
+    for step in range(2):
+        base = step * 10_000_000
+        k("void t2v::wino_gemm_sk_kernel<x>(p)", "1", base, 50_000)
+        k("t2v::loss_terms_kernel(a)", "1", base + 50_000, 10_000)
+        k("void t2v::wino_wgrad_sk_kernel<16, 4>(p)", "3", base + 60_000, 100_000)        # side queue
+        k("void t2v::wino_gemm_sk_kernel<x>(p)", "1", base + 100_000, 40_000)             # overlaps 40 us
+        k("t2v::winograd4_dy_kernel(a)", "1", base + 140_000, 20_000)                     # overlaps 20 us
+        k("t2v::adam_multi_kernel(a)", "1", base + 190_000, 2_000_000)                    # (30 us idle before it)
+        k("t2v::adam_multi_kernel(a)", "1", base + 2_190_000, 100_000)
+    path = tmp_path / "t_kernel_trace.csv"
+    with open(path, "w", newline="") as fh:
+        w = csv.DictWriter(fh, fieldnames=list(rows[0]))
+        w.writeheader()
+        w.writerows(rows)
+    mod.main(str(path), 2)
+    out = capsys.readouterr().out
+    assert "7 launches" in out and "queues ['1', '3']" in out
+    assert "idle 0.03 ms" in out and "two or more 0.06 ms" in out
+    assert "first wino_wgrad_sk 0.06" in out and "first adam_multi 0.19" in out
+    assert "side queue active from 0.06 to 0.16 ms" in out
