@@ -389,6 +389,7 @@ struct WinoWgradSkParams {
     int Tt, Cin, Cout, Cout_p, Kp;
     int ntiles, ctiles, nk, tiles, tiles_per_xcd, blocks_per_xcd;
     int rounds;   // > 0: whole rounds of one tile per block + half a round cut in two (wino_gemm_sk_kernel's second schedule)
+    int half_round;   // ... 0: whole rounds only (tiles a multiple of the grid: 2304 tiles on one block per CU = 9 rounds)
 };
 typedef unsigned int wg_v4u __attribute__((__vector_size__(16)));
 
@@ -413,10 +414,10 @@ __global__ __launch_bounds__(512) void wino_wgrad_sk_kernel(const WinoWgradSkPar
     const int half = p.blocks_per_xcd >> 1;
     int t0 = 0, tf = 0, tl = 0, kf = 0, kl = nk, has_tail = 0, has_head = 0, nf, nmid;
     if (hybrid) {
-        has_head = jb < half;
-        has_tail = !has_head;
+        has_head = p.half_round && jb < half;
+        has_tail = p.half_round && !has_head;
         nmid = p.rounds;
-        nf = p.rounds + 1;
+        nf = p.rounds + (p.half_round ? 1 : 0);
     } else {
         t0 = xcd * p.tiles_per_xcd;
         const int t1 = min(t0 + p.tiles_per_xcd, p.tiles);
@@ -602,6 +603,13 @@ int launch_wino_wgrad_sk(hipStream_t s, const float* V, const float* Md, float* 
     k.blocks_per_xcd = grid / 8;
     k.tiles_per_xcd = (k.tiles + 7) / 8;
     k.rounds = (k.tiles >= grid && 2 * (k.tiles % grid) == grid && k.nk % 2 == 0 && grid % 16 == 0) ? k.tiles / grid : 0;
+    k.half_round = 1;
+    // whole rounds only (the 2304 tiles of a 1024 -> 1024 layer on ONE block per CU: 9 rounds): the same round-by-round walk --
+    // an XCD's blocks on neighbouring tiles of one position at a time.  On contiguous runs of 9 tiles per block the 32 resident
+    // blocks of an XCD sat on 32 tiles of five positions that share no operand: 1.18 GB of fabric reads per launch against
+    // 0.24 GB (PMC, profiles/pmc/r06_wino_wgrad_sk_one_per_cu.txt), 3.8 TB/s taken from the kernels the form exists to
+    // let in beside it
+    if (!k.rounds && k.tiles >= grid && k.tiles % grid == 0) k.rounds = k.tiles / grid, k.half_round = 0;
     auto kern = wino_wgrad_sk_kernel<16, 4>;
     constexpr int lds = 4 * 2 * 16 * 128 * 4;
     static bool attr_done = false;
